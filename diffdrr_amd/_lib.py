@@ -1,0 +1,86 @@
+"""ctypes binding of ``libdiffdrr_hip.so`` (C ABI: ``include/diffdrr_hip.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` (``hipcc
+--offload-arch=gfx950``) and loaded *after* torch so that it binds to the HIP
+runtime torch already has in the process (same ``libamdhip64.so.7`` soname):
+kernels can then be launched on torch's current stream with torch's device
+pointers.  There is deliberately no CPU or pure-PyTorch fallback: if the
+library is missing, rendering raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdiffdrr_hip.so")
+ABI_VERSION = 1
+
+REDUCE_SUM, REDUCE_MAX = 0, 1
+LOOKUP_STEP, LOOKUP_MID_NEAREST, LOOKUP_MID_TRILINEAR = 0, 1, 2
+SIDDON_AUX = 8
+
+_P, _I, _F = c_void_p, c_int, c_float
+
+# name -> argtypes, in the order of include/diffdrr_hip.h
+_SIGNATURES = {
+    "ddrr_siddon_forward": [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _F, _F, _I, _I, _I, _I, _I,
+                            _I, _I, _P, _P, _P, _P],
+    "ddrr_siddon_backward_rays": [_P, _P, _P, _I, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P],
+    "ddrr_siddon_backward_volume": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _I, _I,
+                                    _I, _I, _I, _P, _P],
+    "ddrr_siddon_forward_channels": [_P, _P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _F, _F, _I,
+                                     _I, _I, _I, _P, _P],
+    "ddrr_trilinear_forward": [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _F, _F, _I, _P, _P, _I,
+                               _I, _I, _I, _I, _I, _I, _P, _P],
+    "ddrr_trilinear_backward": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _I, _P, _P,
+                                _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+}
+EXPORTS = ["ddrr_abi_version", "ddrr_last_error", *_SIGNATURES]
+
+
+class DdrrLibrary:
+    """A loaded implementation of the C ABI (the HIP product library; the
+    tests also bind their host emulation build through this class)."""
+
+    def __init__(self, path: str):
+        self.path = path
+        self.cdll = ctypes.CDLL(path)
+        for name in EXPORTS:
+            if not hasattr(self.cdll, name):
+                raise RuntimeError(f"{path} does not export {name}")
+        self.cdll.ddrr_abi_version.restype = c_int
+        self.cdll.ddrr_last_error.restype = ctypes.c_char_p
+        got = self.cdll.ddrr_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"{path}: ABI version {got}, expected {ABI_VERSION}")
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(self.cdll, name)
+            fn.argtypes = argtypes
+            fn.restype = c_int
+
+    def call(self, name: str, *args):
+        rc = getattr(self.cdll, name)(*args)
+        if rc != 0:
+            msg = self.cdll.ddrr_last_error().decode(errors="replace")
+            raise RuntimeError(f"{name} failed (code {rc}): {msg}")
+
+
+_lib: DdrrLibrary | None = None
+
+
+def get_lib() -> DdrrLibrary:
+    """The HIP library, loaded on first use.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  (must own the HIP runtime before we bind to it)
+
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the MI355X renderers have not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); "
+                "diffdrr_amd has no CPU fallback."
+            )
+        _lib = DdrrLibrary(LIB_PATH)
+    return _lib

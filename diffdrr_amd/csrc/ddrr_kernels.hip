@@ -1,0 +1,478 @@
+// ddrr_kernels.hip -- gfx950 kernels + the C ABI declared in include/diffdrr_hip.h.
+//
+// Launch geometry (all kernels): 256-thread workgroups = 4 wavefronts, one
+// detector ray per lane, one tile of 64 rays per wavefront (ddrr_common.h
+// TileMap).  The grid is 1-D over (pose, tile) with the tile index fastest;
+// workgroup ids are optionally re-mapped so that each of the 8 XCDs (private
+// 4 MiB L2 each) works on one contiguous range of tiles.  No LDS, no MFMA:
+// the path is a gather-bound line integral.
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/diffdrr_hip.h"
+#include "ddrr_common.h"
+#include "siddon_core.h"
+#include "trilinear_core.h"
+
+using namespace ddrr;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / 64;
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *what) {
+    snprintf(g_err, sizeof(g_err), "%s", what);
+    return code;
+}
+int fail_hip(hipError_t e, const char *where) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return (int)e;
+}
+
+struct RayArgs {
+    const float *vol;
+    Dims D;
+    const float *source;
+    int src_n;
+    const float *target;
+    const float *img;
+    int B, N;
+    float shift, eps;
+    TileMap tm;
+    int total_waves;
+    int xcd_swizzle;
+};
+
+// Workgroup id -> logical workgroup id.  Workgroup b is dispatched to XCD
+// b % 8 (observed, used for speed only): give every XCD a contiguous chunk.
+__device__ __forceinline__ int logical_block(int xcd_swizzle) {
+    const int bid = blockIdx.x;
+    if (!xcd_swizzle) return bid;
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = bid & 7;
+    return x * q + (x < r ? x : r) + (bid >> 3);
+}
+
+struct RayId {
+    int b, n;     // pose, ray within pose (n < 0: padding lane)
+    long r;       // b * N + n
+};
+
+__device__ __forceinline__ RayId ray_id(const RayArgs &p) {
+    RayId id;
+    const int wave = logical_block(p.xcd_swizzle) * kWavesPerBlock + (threadIdx.x >> 6);
+    id.b = -1;
+    id.n = -1;
+    id.r = -1;
+    if (wave < p.total_waves) {
+        id.b = wave / p.tm.waves_per_pose;
+        const int w = wave - id.b * p.tm.waves_per_pose;
+        id.n = tile_ray(p.tm, w, threadIdx.x & 63, p.N);
+        id.r = (long)id.b * p.N + id.n;
+    }
+    return id;
+}
+
+__device__ __forceinline__ void load_ray(const RayArgs &p, const RayId &id, float s[3],
+                                         float t[3]) {
+    const float *sp = p.source + ((long)id.b * p.src_n + (p.src_n == 1 ? 0 : id.n)) * 3;
+    const float *tp = p.target + id.r * 3;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        s[a] = sp[a];
+        t[a] = tp[a];
+    }
+}
+
+// ------------------------------------------------------------------ Siddon
+
+template <int REDUCE, bool AUX, bool COUNT>
+__global__ __launch_bounds__(kBlock) void siddon_fwd_kernel(RayArgs p, float *__restrict__ out,
+                                                            float *__restrict__ aux,
+                                                            int *__restrict__ n_vox) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    float rec[SIDDON_AUX];
+    int cnt = 0;
+    const float I =
+        siddon_forward_ray<REDUCE, AUX, COUNT>(p.vol, p.D, s, t, p.shift, p.eps, rec, &cnt);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    out[id.r] = L * I;
+    if (AUX) {
+        float4 *a4 = reinterpret_cast<float4 *>(aux + id.r * SIDDON_AUX);
+        a4[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
+        a4[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);
+    }
+    if (COUNT) n_vox[id.r] = cnt;
+}
+
+template <int REDUCE, int LOOKUP>
+__global__ __launch_bounds__(kBlock) void siddon_fwd_mid_kernel(RayArgs p, int align_corners,
+                                                                float *__restrict__ out) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float I = siddon_forward_ray_midpoint<REDUCE, LOOKUP>(p.vol, p.D, s, t, p.shift, p.eps,
+                                                                align_corners != 0);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    out[id.r] = L * I;
+}
+
+template <int REDUCE>
+__global__ __launch_bounds__(kBlock) void siddon_bwd_rays_kernel(
+    const float *__restrict__ aux, const float *__restrict__ grad_out,
+    const float *__restrict__ source, int src_n, const float *__restrict__ target,
+    const float *__restrict__ img, long R, int N, float eps, float *__restrict__ g_source,
+    float *__restrict__ g_target, float *__restrict__ g_img) {
+    const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= R) return;
+    const long b = r / N;
+    const int n = (int)(r - b * N);
+    const float *sp = source + (b * src_n + (src_n == 1 ? 0 : n)) * 3;
+    const float *tp = target + r * 3;
+    const float s[3] = {sp[0], sp[1], sp[2]}, t[3] = {tp[0], tp[1], tp[2]};
+    const float4 *a4 = reinterpret_cast<const float4 *>(aux + r * SIDDON_AUX);
+    const float4 lo = a4[0], hi = a4[1];
+    const float rec[SIDDON_AUX] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    const float g = grad_out[r];
+    const float L = img ? img[r] : 1.f;
+    float gs[3], gt[3];
+    siddon_backward_ray<REDUCE>(rec, s, t, eps, g * L, gs, gt);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (g_source) g_source[r * 3 + a] = gs[a];
+        if (g_target) g_target[r * 3 + a] = gt[a];
+    }
+    if (g_img) g_img[r] = g * rec[0];
+}
+
+struct AtomicAdder {
+    float *base;
+    __device__ __forceinline__ void operator()(unsigned off, float v) const {
+        unsafeAtomicAdd(base + off, v);  // global_atomic_add_f32, no return
+    }
+};
+
+template <int REDUCE>
+__global__ __launch_bounds__(kBlock) void siddon_bwd_volume_kernel(
+    RayArgs p, const float *__restrict__ grad_out, float *__restrict__ g_volume) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    const float gl = grad_out[id.r] * L;
+    if (gl == 0.f) return;
+    siddon_scatter_ray<REDUCE>(p.vol, p.D, s, t, p.shift, p.eps, gl, AtomicAdder{g_volume});
+}
+
+// mask_to_channels (renderers.py:77-89): the ray owns column out[b, :, n]; runs
+// of one label are flushed with a plain read-modify-write (siddon_channels_ray).
+struct ColumnFlush {
+    float *col;
+    long stride;
+    int C;
+    float L;
+    __device__ __forceinline__ void operator()(int label, float run) const {
+        if (label < C) col[label * stride] += L * run;
+    }
+};
+
+__global__ __launch_bounds__(kBlock) void siddon_fwd_channels_kernel(
+    RayArgs p, const unsigned char *__restrict__ labels, int C, float *__restrict__ out) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    float *col = out + (long)id.b * C * p.N + id.n;  // stride N between channels
+    siddon_channels_ray(p.vol, labels, p.D, s, t, p.shift, p.eps, ColumnFlush{col, p.N, C, L});
+}
+
+// --------------------------------------------------------------- Trilinear
+
+template <int REDUCE, bool NEAREST>
+__global__ __launch_bounds__(kBlock) void trilinear_fwd_kernel(RayArgs p, int n_points,
+                                                               const float *__restrict__ amin,
+                                                               const float *__restrict__ amax,
+                                                               int align_corners,
+                                                               float *__restrict__ out) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float I = trilinear_forward_ray<REDUCE, NEAREST>(p.vol, p.D, s, t, p.shift, p.eps,
+                                                           n_points, amin[0], amax[0],
+                                                           align_corners != 0);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    out[id.r] = L * I;
+}
+
+struct NoAdd {
+    __device__ __forceinline__ void operator()(unsigned, float) const {}
+};
+
+template <bool NEAREST, bool WANT_VOL>
+__global__ __launch_bounds__(kBlock) void trilinear_bwd_kernel(
+    RayArgs p, const float *__restrict__ grad_out, int n_points, const float *__restrict__ amin,
+    const float *__restrict__ amax, int align_corners, float *__restrict__ g_source,
+    float *__restrict__ g_target, float *__restrict__ g_img, float *__restrict__ g_alpha,
+    float *__restrict__ g_volume) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    const float g = grad_out[id.r];
+    const float a0 = amin[0], a1 = amax[0];
+    MarchGrad r;
+    if (WANT_VOL)
+        r = trilinear_backward_ray<NEAREST, true>(p.vol, p.D, s, t, p.shift, p.eps, n_points, a0,
+                                                  a1, align_corners != 0, g * L,
+                                                  AtomicAdder{g_volume});
+    else
+        r = trilinear_backward_ray<NEAREST, false>(p.vol, p.D, s, t, p.shift, p.eps, n_points,
+                                                   a0, a1, align_corners != 0, g * L, NoAdd{});
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (g_source) g_source[id.r * 3 + a] = r.gs[a];
+        if (g_target) g_target[id.r * 3 + a] = r.gt[a];
+    }
+    if (g_img) g_img[id.r] = g * r.sumT * ((a1 - a0) / (float)(n_points - 1));
+    if (g_alpha) {
+        g_alpha[id.r * 2 + 0] = r.g_amin;
+        g_alpha[id.r * 2 + 1] = r.g_amax;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+
+int g_xcd_swizzle = 1;
+
+int check_common(const float *volume, int dx, int dy, int dz, const float *source, int src_n,
+                 const float *target, int B, int N) {
+    if (!volume || !source || !target) return fail(-1, "null volume/source/target pointer");
+    if (dx < 1 || dy < 1 || dz < 1) return fail(-1, "volume dims must be >= 1");
+    if ((long)dx * dy * dz > (1L << 30)) return fail(-1, "volume larger than 2^30 voxels");
+    if (B < 0 || N < 0) return fail(-1, "negative batch or ray count");
+    if (src_n != 1 && src_n != N) return fail(-1, "src_n must be 1 or N");
+    return 0;
+}
+
+RayArgs make_args(const float *volume, int dx, int dy, int dz, const float *source, int src_n,
+                  const float *target, const float *img, int B, int N, float shift, float eps,
+                  int det_h, int det_w, int tile_h, int tile_w) {
+    RayArgs p;
+    p.vol = volume;
+    p.D = Dims{dx, dy, dz};
+    p.source = source;
+    p.src_n = src_n;
+    p.target = target;
+    p.img = img;
+    p.B = B;
+    p.N = N;
+    p.shift = shift;
+    p.eps = eps;
+    p.tm = make_tilemap(N, det_h, det_w, tile_h, tile_w);
+    p.total_waves = B * p.tm.waves_per_pose;
+    p.xcd_swizzle = g_xcd_swizzle;
+    return p;
+}
+
+inline int grid_for(const RayArgs &p) {
+    return (p.total_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+}
+
+int finish(const char *where) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, where);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ddrr_abi_version(void) { return DDRR_ABI_VERSION; }
+const char *ddrr_last_error(void) { return g_err; }
+
+// Experiment knob (not part of the renderer contract): 0/1 XCD-contiguous
+// workgroup mapping.
+int ddrr_set_xcd_swizzle(int on) {
+    int old = g_xcd_swizzle;
+    g_xcd_swizzle = on ? 1 : 0;
+    return old;
+}
+
+int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float *source,
+                        int src_n, const float *target, const float *img, int B, int N,
+                        float voxel_shift, float eps, int reduce_mode, int lookup_mode,
+                        int align_corners, int det_h, int det_w, int tile_h, int tile_w,
+                        float *out, float *aux, int *n_vox, void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!out) return fail(-1, "null out pointer");
+    if (reduce_mode != DDRR_REDUCE_SUM && reduce_mode != DDRR_REDUCE_MAX)
+        return fail(-1, "reduce_mode must be DDRR_REDUCE_SUM or DDRR_REDUCE_MAX");
+    if (B == 0 || N == 0) return 0;
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, det_h, det_w, tile_h, tile_w);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(grid_for(p)), block(kBlock);
+    if (lookup_mode == DDRR_LOOKUP_STEP) {
+        if (align_corners) return fail(-1, "DDRR_LOOKUP_STEP requires align_corners=0");
+        const bool sum = reduce_mode == DDRR_REDUCE_SUM;
+#define LAUNCH(R, A, C) \
+    hipLaunchKernelGGL((siddon_fwd_kernel<R, A, C>), grid, block, 0, st, p, out, aux, n_vox)
+        if (n_vox) {
+            if (aux) return fail(-1, "aux and n_vox cannot be requested together");
+            if (sum) LAUNCH(REDUCE_SUM, false, true);
+            else LAUNCH(REDUCE_MAX, false, true);
+        } else if (aux) {
+            if (sum) LAUNCH(REDUCE_SUM, true, false);
+            else LAUNCH(REDUCE_MAX, true, false);
+        } else {
+            if (sum) LAUNCH(REDUCE_SUM, false, false);
+            else LAUNCH(REDUCE_MAX, false, false);
+        }
+#undef LAUNCH
+    } else if (lookup_mode == DDRR_LOOKUP_MID_NEAREST || lookup_mode == DDRR_LOOKUP_MID_TRILINEAR) {
+        if (aux || n_vox) return fail(-1, "aux / n_vox are only produced by DDRR_LOOKUP_STEP");
+        const bool sum = reduce_mode == DDRR_REDUCE_SUM;
+        const bool tri = lookup_mode == DDRR_LOOKUP_MID_TRILINEAR;
+#define LAUNCH(R, K) \
+    hipLaunchKernelGGL((siddon_fwd_mid_kernel<R, K>), grid, block, 0, st, p, align_corners, out)
+        if (sum && tri) LAUNCH(REDUCE_SUM, LOOKUP_MID_TRILINEAR);
+        else if (sum) LAUNCH(REDUCE_SUM, LOOKUP_MID_NEAREST);
+        else if (tri) LAUNCH(REDUCE_MAX, LOOKUP_MID_TRILINEAR);
+        else LAUNCH(REDUCE_MAX, LOOKUP_MID_NEAREST);
+#undef LAUNCH
+    } else {
+        return fail(-1, "unknown lookup_mode");
+    }
+    return finish("ddrr_siddon_forward");
+}
+
+int ddrr_siddon_backward_rays(const float *aux, const float *grad_out, const float *source,
+                              int src_n, const float *target, const float *img, int B, int N,
+                              float eps, int reduce_mode, float *g_source, float *g_target,
+                              float *g_img, void *stream) {
+    if (!aux || !grad_out || !source || !target) return fail(-1, "null pointer");
+    if (src_n != 1 && src_n != N) return fail(-1, "src_n must be 1 or N");
+    const long R = (long)B * N;
+    if (R == 0) return 0;
+    const dim3 grid((unsigned)((R + kBlock - 1) / kBlock)), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    if (reduce_mode == DDRR_REDUCE_SUM)
+        hipLaunchKernelGGL((siddon_bwd_rays_kernel<REDUCE_SUM>), grid, block, 0, st, aux, grad_out,
+                           source, src_n, target, img, R, N, eps, g_source, g_target, g_img);
+    else if (reduce_mode == DDRR_REDUCE_MAX)
+        hipLaunchKernelGGL((siddon_bwd_rays_kernel<REDUCE_MAX>), grid, block, 0, st, aux, grad_out,
+                           source, src_n, target, img, R, N, eps, g_source, g_target, g_img);
+    else
+        return fail(-1, "bad reduce_mode");
+    return finish("ddrr_siddon_backward_rays");
+}
+
+int ddrr_siddon_backward_volume(const float *volume, int dx, int dy, int dz, const float *source,
+                                int src_n, const float *target, const float *img,
+                                const float *grad_out, int B, int N, float voxel_shift, float eps,
+                                int reduce_mode, int det_h, int det_w, int tile_h, int tile_w,
+                                float *g_volume, void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!grad_out || !g_volume) return fail(-1, "null grad_out / g_volume");
+    if (B == 0 || N == 0) return 0;
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, det_h, det_w, tile_h, tile_w);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(grid_for(p)), block(kBlock);
+    if (reduce_mode == DDRR_REDUCE_SUM)
+        hipLaunchKernelGGL((siddon_bwd_volume_kernel<REDUCE_SUM>), grid, block, 0, st, p, grad_out,
+                           g_volume);
+    else if (reduce_mode == DDRR_REDUCE_MAX)
+        hipLaunchKernelGGL((siddon_bwd_volume_kernel<REDUCE_MAX>), grid, block, 0, st, p, grad_out,
+                           g_volume);
+    else
+        return fail(-1, "bad reduce_mode");
+    return finish("ddrr_siddon_backward_volume");
+}
+
+int ddrr_siddon_forward_channels(const float *volume, const unsigned char *labels, int dx, int dy,
+                                 int dz, const float *source, int src_n, const float *target,
+                                 const float *img, int B, int N, int C, float voxel_shift,
+                                 float eps, int det_h, int det_w, int tile_h, int tile_w,
+                                 float *out, void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!labels || !out || C < 1) return fail(-1, "null labels/out or C < 1");
+    if (B == 0 || N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C * N, st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, det_h, det_w, tile_h, tile_w);
+    hipLaunchKernelGGL(siddon_fwd_channels_kernel, dim3(grid_for(p)), dim3(kBlock), 0, st, p,
+                       labels, C, out);
+    return finish("ddrr_siddon_forward_channels");
+}
+
+int ddrr_trilinear_forward(const float *volume, int dx, int dy, int dz, const float *source,
+                           int src_n, const float *target, const float *img, int B, int N,
+                           float voxel_shift, float eps, int n_points, const float *alphamin,
+                           const float *alphamax, int mode_nearest, int reduce_mode,
+                           int align_corners, int det_h, int det_w, int tile_h, int tile_w,
+                           float *out, void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!out || !alphamin || !alphamax) return fail(-1, "null out / alphamin / alphamax");
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (B == 0 || N == 0) return 0;
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, det_h, det_w, tile_h, tile_w);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(grid_for(p)), block(kBlock);
+    const bool sum = reduce_mode == DDRR_REDUCE_SUM;
+    if (!sum && reduce_mode != DDRR_REDUCE_MAX) return fail(-1, "bad reduce_mode");
+#define LAUNCH(R, NN)                                                                          \
+    hipLaunchKernelGGL((trilinear_fwd_kernel<R, NN>), grid, block, 0, st, p, n_points, alphamin, \
+                       alphamax, align_corners, out)
+    if (sum && !mode_nearest) LAUNCH(REDUCE_SUM, false);
+    else if (sum) LAUNCH(REDUCE_SUM, true);
+    else if (!mode_nearest) LAUNCH(REDUCE_MAX, false);
+    else LAUNCH(REDUCE_MAX, true);
+#undef LAUNCH
+    return finish("ddrr_trilinear_forward");
+}
+
+int ddrr_trilinear_backward(const float *volume, int dx, int dy, int dz, const float *source,
+                            int src_n, const float *target, const float *img,
+                            const float *grad_out, int B, int N, float voxel_shift, float eps,
+                            int n_points, const float *alphamin, const float *alphamax,
+                            int mode_nearest, int align_corners, int det_h, int det_w, int tile_h,
+                            int tile_w, float *g_source, float *g_target, float *g_img,
+                            float *g_alpha, float *g_volume, void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!grad_out || !alphamin || !alphamax) return fail(-1, "null grad_out / alphamin / alphamax");
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (B == 0 || N == 0) return 0;
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, det_h, det_w, tile_h, tile_w);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(grid_for(p)), block(kBlock);
+#define LAUNCH(NN, WV)                                                                          \
+    hipLaunchKernelGGL((trilinear_bwd_kernel<NN, WV>), grid, block, 0, st, p, grad_out, n_points, \
+                       alphamin, alphamax, align_corners, g_source, g_target, g_img, g_alpha,     \
+                       g_volume)
+    if (mode_nearest && g_volume) LAUNCH(true, true);
+    else if (mode_nearest) LAUNCH(true, false);
+    else if (g_volume) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+    return finish("ddrr_trilinear_backward");
+}
+
+}  // extern "C"

@@ -1,0 +1,171 @@
+// trilinear_core.h -- per-ray trilinear ray-marcher for one lane.
+//
+// What it replaces: the reference's Trilinear renderer,
+//   diffdrr/renderers.py:205-241  Trilinear.forward (mask=None branch)
+//   diffdrr/renderers.py:143-169  _get_xyzs / _get_voxel (grid_sample "bilinear", zeros padding)
+// n_points samples at alpha_m = alphamin + u_m (alphamax - alphamin), u = linspace(0, 1, P),
+// rectangular rule with step (alphamax - alphamin)/(P - 1).  alphamin/alphamax
+// are inputs: the host side evaluates the reference's batch-global range
+// (renderers.py:220-223) or forwards the caller's values.
+//
+// A lane owns a ray; samples whose 8-cell cannot touch the volume are skipped
+// (they are exact zeros in the reference), the rest cost four 8-byte fetches
+// (the two z-neighbours of a corner pair are adjacent in memory).
+#pragma once
+
+#include "ddrr_common.h"
+#include "siddon_core.h"  // GridMap, fetch_nearest, fetch_trilinear
+
+namespace ddrr {
+
+// torch.linspace(0, 1, P)[m] as aten's scalar (and GPU) kernel evaluates it.
+DDRR_HD float lin01(int m, int P, float lstep) {
+    return m < P / 2 ? (float)m * lstep : 1.0f - (float)(P - 1 - m) * lstep;
+}
+
+struct MarchSetup {
+    float d[3];
+    float span, step, lstep;
+    int m_lo, m_hi;  // inclusive range of samples that may touch the volume
+};
+
+DDRR_HD MarchSetup march_setup(const Dims D, const GridMap &g, const float s[3], const float t[3],
+                               float eps, int P, float amin, float amax) {
+    MarchSetup q;
+    const int Dn[3] = {D.x, D.y, D.z};
+    float lo = -INFINITY, hi = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        q.d[a] = (t[a] - s[a]) + eps;
+        // index coordinate along the ray: gi(alpha) = g0 + alpha * gd; a sample can
+        // contribute only while -1 < gi < D on every axis
+        const float g0 = fmaf(s[a], g.k[a], g.o[a]);
+        const float gd = q.d[a] * g.k[a];
+        const float a1 = (-1.f - g0) / gd, a2 = ((float)Dn[a] - g0) / gd;
+        lo = fmaxf(lo, fminf(a1, a2));
+        hi = fminf(hi, fmaxf(a1, a2));
+    }
+    q.span = amax - amin;
+    q.step = q.span / (float)(P - 1);  // renderers.py:235
+    q.lstep = 1.0f / (float)(P - 1);
+    q.m_lo = 0;
+    q.m_hi = P - 1;
+    if (q.span > 0.f) {
+        const float sc = (float)(P - 1) / q.span;
+        // two samples of slack on both sides; the per-corner bounds tests stay exact
+        const float flo = fminf(fmaxf(floorf((lo - amin) * sc) - 2.f, 0.f), (float)P);
+        const float fhi = fminf(fmaxf(ceilf((hi - amin) * sc) + 2.f, -1.f), (float)(P - 1));
+        if (flo == flo) q.m_lo = (int)flo;  // NaN guard
+        if (fhi == fhi) q.m_hi = (int)fhi;
+    }
+    return q;
+}
+
+template <int REDUCE, bool NEAREST>
+DDRR_HD float trilinear_forward_ray(const float *__restrict__ vol, const Dims D, const float s[3],
+                                    const float t[3], float shift, float eps, int P, float amin,
+                                    float amax, bool align_corners) {
+    const GridMap g = make_gridmap(D, shift, align_corners);
+    const MarchSetup q = march_setup(D, g, s, t, eps, P, amin, amax);
+    const bool skipped = q.m_lo > 0 || q.m_hi < P - 1;
+    float acc = (REDUCE == REDUCE_SUM || skipped) ? 0.f : -INFINITY;
+    for (int m = q.m_lo; m <= q.m_hi; ++m) {
+        const float al = fmaf(lin01(m, P, q.lstep), q.span, amin);  // renderers.py:224-225
+        const float gx = fmaf(fmaf(al, q.d[0], s[0]), g.k[0], g.o[0]);
+        const float gy = fmaf(fmaf(al, q.d[1], s[1]), g.k[1], g.o[1]);
+        const float gz = fmaf(fmaf(al, q.d[2], s[2]), g.k[2], g.o[2]);
+        const float v = NEAREST ? fetch_nearest(vol, D, gx, gy, gz)
+                                : fetch_trilinear(vol, D, gx, gy, gz, nullptr, false);
+        if (REDUCE == REDUCE_SUM)
+            acc += v;
+        else
+            acc = fmaxf(acc, v);
+    }
+    return acc * q.step;  // caller multiplies by the ray length
+}
+
+// Scatter k * w_c into the 8 corners of a sample (volume gradient).
+template <class Add>
+DDRR_HD void scatter_trilinear(const Dims D, float gx, float gy, float gz, float k, Add add) {
+    const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+    const float ax = gx - fx, ay = gy - fy, az = gz - fz;
+    const int ix = (int)fminf(fmaxf(fx, -2.f), (float)D.x + 1.f);
+    const int iy = (int)fminf(fmaxf(fy, -2.f), (float)D.y + 1.f);
+    const int iz = (int)fminf(fmaxf(fz, -2.f), (float)D.z + 1.f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ox = c & 1, oy = (c >> 1) & 1, oz = c >> 2;
+        const int x = ix + ox, y = iy + oy, z = iz + oz;
+        if (x < 0 || x >= D.x || y < 0 || y >= D.y || z < 0 || z >= D.z) continue;
+        const float w = (ox ? ax : 1.f - ax) * (oy ? ay : 1.f - ay) * (oz ? az : 1.f - az);
+        add((unsigned)((x * D.y + y) * D.z + z), k * w);
+    }
+}
+
+template <class Add>
+DDRR_HD void scatter_nearest(const Dims D, float gx, float gy, float gz, float k, Add add) {
+    const float rx = rintf(gx), ry = rintf(gy), rz = rintf(gz);
+    const bool in = rx >= 0.f && rx < (float)D.x && ry >= 0.f && ry < (float)D.y && rz >= 0.f &&
+                    rz < (float)D.z;
+    if (in) add((unsigned)(((int)rx * D.y + (int)ry) * D.z + (int)rz), k);
+}
+
+struct MarchGrad {
+    float gs[3], gt[3];  // through the sample positions x = s + alpha (t - s + eps)
+    float g_amin, g_amax;
+    float sumT;  // sum of samples (d out / d img = g * step * sumT)
+};
+
+// Backward of the sum-reduced march for one ray.
+// gl = grad_out * ray length.
+template <bool NEAREST, bool WANT_VOL, class Add>
+DDRR_HD MarchGrad trilinear_backward_ray(const float *__restrict__ vol, const Dims D,
+                                         const float s[3], const float t[3], float shift,
+                                         float eps, int P, float amin, float amax,
+                                         bool align_corners, float gl, Add add) {
+    const GridMap g = make_gridmap(D, shift, align_corners);
+    const MarchSetup q = march_setup(D, g, s, t, eps, P, amin, amax);
+    MarchGrad r;
+    float A[3] = {0.f, 0.f, 0.f};   // sum dT
+    float Bv[3] = {0.f, 0.f, 0.f};  // sum alpha dT
+    float Cu = 0.f, Cd = 0.f;       // sum u (dT . d), sum (dT . d)
+    float sumT = 0.f;
+    const float k = gl * q.step;
+    for (int m = q.m_lo; m <= q.m_hi; ++m) {
+        const float u = lin01(m, P, q.lstep);
+        const float al = fmaf(u, q.span, amin);
+        const float gx = fmaf(fmaf(al, q.d[0], s[0]), g.k[0], g.o[0]);
+        const float gy = fmaf(fmaf(al, q.d[1], s[1]), g.k[1], g.o[1]);
+        const float gz = fmaf(fmaf(al, q.d[2], s[2]), g.k[2], g.o[2]);
+        if (NEAREST) {
+            sumT += fetch_nearest(vol, D, gx, gy, gz);
+            if (WANT_VOL) scatter_nearest(D, gx, gy, gz, k, add);
+        } else {
+            float dT[3];
+            sumT += fetch_trilinear(vol, D, gx, gy, gz, dT, true);
+            float ddot = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                dT[a] *= g.k[a];  // d(index coord)/dx
+                A[a] += dT[a];
+                Bv[a] = fmaf(al, dT[a], Bv[a]);
+                ddot = fmaf(dT[a], q.d[a], ddot);
+            }
+            Cd += ddot;
+            Cu = fmaf(u, ddot, Cu);
+            if (WANT_VOL) scatter_trilinear(D, gx, gy, gz, k, add);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        r.gs[a] = k * (A[a] - Bv[a]);  // sum (1 - alpha) dT
+        r.gt[a] = k * Bv[a];           // sum alpha dT
+    }
+    const float w = gl * sumT / (float)(P - 1);  // through step = (amax - amin)/(P-1)
+    r.g_amin = k * (Cd - Cu) - w;
+    r.g_amax = k * Cu + w;
+    r.sumT = sumT;
+    return r;
+}
+
+}  // namespace ddrr

@@ -1,0 +1,199 @@
+"""``DRR``: the reference's user-facing module, rendering on the MI355X.
+
+API-compatible restatement of reference ``diffdrr/drr.py:23-266`` (constructor,
+``forward``, ``render``, ``reshape_transform``, ``set_intrinsics_``,
+``rescale_detector_``, the ``affine`` / ``n_patches`` / ``device`` / ``dtype``
+properties, ``perspective_projection`` / ``inverse_projection``).  The only
+behavioural difference is the renderer behind ``self.renderer``: the fused HIP
+kernels of :mod:`diffdrr_amd.renderers` instead of the vectorised tensor
+program, which makes ``patch_size`` and ``checkpoint_gradients`` unnecessary
+(they are still honoured so that existing code runs unchanged).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from torch.utils.checkpoint import checkpoint
+
+from .detector import Detector
+from .pose import RigidTransform, convert
+from .renderers import Siddon, Trilinear
+
+
+class DRR(nn.Module):
+    """Differentiable digitally reconstructed radiographs from a CT subject."""
+
+    def __init__(
+        self,
+        subject,  # object with .volume.affine, .density.data, .mask, .reorient
+        sdd: float,  # source-to-detector distance
+        height: int,
+        delx: float,  # pixel size along x
+        width: int | None = None,
+        dely: float | None = None,
+        x0: float = 0.0,  # principal point offsets
+        y0: float = 0.0,
+        p_subsample: float | None = None,  # proportion of pixels to render
+        reshape: bool = True,  # return (B, C, H, W)
+        reverse_x_axis: bool = True,  # radiologic convention
+        patch_size: int | None = None,  # render the detector in sequential patches
+        renderer: str = "siddon",
+        voxel_shift: float = 0.5,
+        persistent: bool = True,
+        compile_renderer: bool = False,
+        checkpoint_gradients: bool = False,
+        **renderer_kwargs,
+    ):
+        super().__init__()
+        width = height if width is None else width
+        dely = delx if dely is None else dely
+        n_subsample = int(height * width * p_subsample) if p_subsample is not None else None
+        self.detector = Detector(sdd, height, width, delx, dely, x0, y0, subject.reorient,
+                                 reverse_x_axis=reverse_x_axis, n_subsample=n_subsample)
+
+        self.subject = subject
+        affine = torch.as_tensor(subject.volume.affine, dtype=torch.float32).unsqueeze(0)
+        self.register_buffer("_affine", affine, persistent=persistent)
+        self.register_buffer("_affine_inverse", torch.linalg.inv(affine), persistent=persistent)
+        density = subject.density.data.squeeze().to(torch.float32).contiguous()
+        self.register_buffer("density", density, persistent=persistent)
+        if subject.mask is not None:
+            self.register_buffer("mask", subject.mask.data.to(torch.float32).squeeze(),
+                                 persistent=persistent)
+
+        if renderer == "siddon":
+            self.renderer = Siddon(voxel_shift, **renderer_kwargs)
+        elif renderer == "trilinear":
+            self.renderer = Trilinear(voxel_shift, **renderer_kwargs)
+        else:
+            raise ValueError(f"renderer must be 'siddon' or 'trilinear', not {renderer}")
+        # compile_renderer asked torch.compile to fuse the reference's tensor program;
+        # the renderer here already is one hand-written kernel, so the flag is a no-op.
+        self.compile_renderer = compile_renderer
+        self.reshape = reshape
+        self.patch_size = patch_size
+        self.checkpoint_gradients = checkpoint_gradients
+
+    # ------------------------------------------------------------ properties
+    @property
+    def affine(self):
+        return RigidTransform(self._affine)
+
+    @property
+    def affine_inverse(self):
+        return RigidTransform(self._affine_inverse)
+
+    @property
+    def n_patches(self):
+        return (self.detector.height * self.detector.width) // (self.patch_size**2)
+
+    @property
+    def device(self):
+        return self.density.device
+
+    @property
+    def dtype(self):
+        return self.density.dtype
+
+    def reshape_transform(self, img, batch_size):
+        if self.reshape:
+            if self.detector.n_subsample is None:
+                img = img.view(batch_size, -1, self.detector.height, self.detector.width)
+            else:
+                img = reshape_subsampled_drr(img, self.detector, batch_size)
+        return img
+
+    # --------------------------------------------------------------- forward
+    def forward(self, *args, parameterization: str = None, convention: str = None,
+                calibration: RigidTransform = None, mask_to_channels: bool = False,
+                degrees: bool = False, **kwargs):
+        """Render DRRs for a batch of poses (``RigidTransform`` or raw parameters)."""
+        if parameterization is None:
+            pose = args[0]
+        else:
+            pose = convert(*args, parameterization=parameterization, convention=convention,
+                           degrees=degrees)
+        source, target = self.detector(pose, calibration)
+        if self.checkpoint_gradients:
+            img = checkpoint(self.render, self.density, source, target, mask_to_channels,
+                             **kwargs, use_reentrant=False)
+        else:
+            img = self.render(self.density, source, target, mask_to_channels, **kwargs)
+        return self.reshape_transform(img, batch_size=len(pose))
+
+    def render(self, density: torch.Tensor, source: torch.Tensor, target: torch.Tensor,
+               mask_to_channels: bool = False, **kwargs):
+        """World-space rays -> ``(B, C, N)`` line integrals (reference drr.py:191-227)."""
+        # ray length in world units, before the rays go to voxel space
+        img = (target - source).norm(dim=-1).unsqueeze(1)
+        source = self.affine_inverse(source)
+        target = self.affine_inverse(target)
+
+        kwargs["mask"] = self.mask if mask_to_channels else None
+        full_grid = (self.detector.n_subsample is None and self.patch_size is None and
+                     target.shape[1] == self.detector.height * self.detector.width)
+        self.renderer.detector_shape = \
+            (self.detector.height, self.detector.width) if full_grid else None
+        if self.patch_size is None:
+            return self.renderer(density, source, target, img, **kwargs)
+        partials = [
+            self.renderer(density, source, t, i, **kwargs)
+            for t, i in zip(target.chunk(self.n_patches, dim=1),
+                            img.chunk(self.n_patches, dim=-1))
+        ]
+        return torch.cat(partials, dim=-1)
+
+    # ------------------------------------------------------------ intrinsics
+    def set_intrinsics_(self, sdd: float = None, height: int = None, width: int = None,
+                        delx: float = None, dely: float = None, x0: float = None,
+                        y0: float = None, n_subsample: int = None, reverse_x_axis: bool = None):
+        """Replace the detector in place (reference drr.py:230-255)."""
+        d = self.detector
+        self.detector = Detector(
+            sdd if sdd is not None else d.sdd,
+            height if height is not None else d.height,
+            width if width is not None else d.width,
+            delx if delx is not None else d.delx,
+            dely if dely is not None else d.dely,
+            x0 if x0 is not None else -d.x0,
+            y0 if y0 is not None else -d.y0,
+            self.subject.reorient,
+            n_subsample if n_subsample is not None else d.n_subsample,
+            reverse_x_axis if reverse_x_axis is not None else d.reverse_x_axis,
+        ).to(self.density)
+
+    def rescale_detector_(self, scale: float):
+        """Rescale the detector plane in place (reference drr.py:258-266)."""
+        self.set_intrinsics_(
+            height=int(self.detector.height * scale),
+            width=int(self.detector.width * scale),
+            delx=float(self.detector.delx / scale),
+            dely=float(self.detector.dely / scale),
+        )
+
+    # ------------------------------------------------------------ projections
+    def perspective_projection(self, pose: RigidTransform, pts: torch.Tensor):
+        """World points (3D) -> pixel coordinates (2D) (reference drr.py:269-291)."""
+        extrinsic = (self.detector.reorient.compose(pose)).inverse()
+        x = extrinsic(pts)
+        x = torch.einsum("ij,bnj->bni", self.detector.intrinsic, x)
+        x = x / x[..., -1:].clone()
+        u = self.detector.width - x[..., 0] if self.detector.reverse_x_axis else x[..., 0]
+        v = self.detector.height - x[..., 1]
+        return torch.stack([u, v], dim=-1)
+
+    def inverse_projection(self, pose: RigidTransform, pts: torch.Tensor):
+        """Pixel coordinates (2D) -> points on the detector plane in world space."""
+        v = self.detector.height - pts[..., 1]
+        u = self.detector.width - pts[..., 0] if self.detector.reverse_x_axis else pts[..., 0]
+        uv1 = torch.stack([u, v, torch.ones_like(u)], dim=-1)
+        x = self.detector.sdd * torch.einsum(
+            "ij,bnj->bni", torch.linalg.inv(self.detector.intrinsic), uv1)
+        return self.detector.reorient.compose(pose)(x)
+
+
+def reshape_subsampled_drr(img: torch.Tensor, detector: Detector, batch_size: int):
+    n_points = detector.height * detector.width
+    drr = torch.zeros(batch_size, n_points).to(img)
+    drr[:, detector.subsamples[-1]] = img
+    return drr.view(batch_size, 1, detector.height, detector.width)

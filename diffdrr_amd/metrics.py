@@ -1,0 +1,52 @@
+"""Image similarity used by the registration / sweep paths.
+
+Only normalised cross-correlation is on the path BASELINE.json's configs 4-5
+exercise (reference ``diffdrr/metrics.py:16-63``); gradient-NCC, mutual
+information and the geodesic pose metrics are out of scope.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def to_patches(x, patch_size):
+    """All ``patch_size`` x ``patch_size`` windows (stride 1) as channels."""
+    x = x.unfold(2, patch_size, 1).unfold(3, patch_size, 1)  # b c h' w' p1 p2
+    b, c, h, w, p1, p2 = x.shape
+    return x.permute(0, 1, 4, 5, 2, 3).reshape(b, c * p1 * p2, h, w)
+
+
+class NormalizedCrossCorrelation2d(torch.nn.Module):
+    """Mean of the product of the two z-scored images (global or patch-wise)."""
+
+    def __init__(self, patch_size=None, eps=1e-5):
+        super().__init__()
+        self.patch_size = patch_size
+        self.eps = eps
+
+    def forward(self, x1, x2):
+        if self.patch_size is not None:
+            x1 = to_patches(x1, self.patch_size)
+            x2 = to_patches(x2, self.patch_size)
+        assert x1.shape == x2.shape, "Input images must be the same size"
+        _, c, h, w = x1.shape
+        score = (self.norm(x1) * self.norm(x2)).flatten(1).sum(1)
+        return score / (c * h * w)
+
+    def norm(self, x):
+        mu = x.mean(dim=[-1, -2], keepdim=True)
+        var = x.var(dim=[-1, -2], keepdim=True, correction=0) + self.eps
+        return (x - mu) / var.sqrt()
+
+
+class MultiscaleNormalizedCrossCorrelation2d(torch.nn.Module):
+    """Weighted sum of NCCs at several patch sizes (``None`` = whole image)."""
+
+    def __init__(self, patch_sizes=[None], patch_weights=[1.0], eps=1e-5):
+        super().__init__()
+        assert len(patch_sizes) == len(patch_weights), "Each scale must have a weight"
+        self.nccs = [NormalizedCrossCorrelation2d(p, eps) for p in patch_sizes]
+        self.patch_weights = patch_weights
+
+    def forward(self, x1, x2):
+        return sum(w * ncc(x1, x2) for w, ncc in zip(self.patch_weights, self.nccs))

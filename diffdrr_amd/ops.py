@@ -1,0 +1,193 @@
+"""Tensor-level entry points over the C ABI: validate, allocate, launch.
+
+Every function takes CUDA(HIP) fp32 tensors, launches on torch's current
+stream and returns without synchronising.  CPU tensors are rejected loudly --
+this package renders on the MI355X only.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import _lib
+from ._lib import REDUCE_MAX, REDUCE_SUM, SIDDON_AUX
+
+_REDUCE = {"sum": REDUCE_SUM, "max": REDUCE_MAX}
+_LOOKUP = {"step": _lib.LOOKUP_STEP, "mid_nearest": _lib.LOOKUP_MID_NEAREST,
+           "mid_trilinear": _lib.LOOKUP_MID_TRILINEAR}
+
+
+def reduce_code(reducefn) -> int:
+    if isinstance(reducefn, str) and reducefn in _REDUCE:
+        return _REDUCE[reducefn]
+    if callable(reducefn):
+        raise NotImplementedError(
+            "callable reducefn is not supported by the fused MI355X renderer: the per-segment "
+            "tensor it would receive is never materialised. Use 'sum' or 'max'."
+        )
+    raise ValueError(f"Only supports reducefn 'sum' or 'max', not {reducefn}")
+
+
+def default_tile() -> tuple[int, int]:
+    """(tile_h, tile_w) of the 64 detector pixels one wavefront renders; override
+    with DDRR_TILE=HxW.  Rows map to the volume's fastest axis in the usual AP /
+    lateral geometry, so the default tile is tall."""
+    env = os.environ.get("DDRR_TILE")
+    if env:
+        h, w = (int(v) for v in env.lower().split("x"))
+        if h * w != 64:
+            raise ValueError("DDRR_TILE must multiply to 64")
+        return h, w
+    return 16, 4
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _require_gpu(volume):
+    if not volume.is_cuda:
+        raise RuntimeError(
+            "diffdrr_amd renders on the MI355X only: got a CPU volume tensor (there is no CPU "
+            "fallback; move the module with .to('cuda'))."
+        )
+
+
+def _launch(name, device, *args):
+    """One asynchronous C-ABI call on torch's current stream of `device`."""
+    with torch.cuda.device(device):
+        _lib.get_lib().call(name, *args, torch.cuda.current_stream().cuda_stream)
+
+
+def _check_rays(volume, source, target, img):
+    _require_gpu(volume)
+    for name, t in (("volume", volume), ("source", source), ("target", target), ("img", img)):
+        if t is None:
+            continue
+        if t.dtype != torch.float32:
+            raise NotImplementedError(f"{name} must be float32 (got {t.dtype}): the HIP kernels "
+                                      "are fp32 like the reference's default")
+        if t.device != volume.device:
+            raise RuntimeError(f"{name} is on {t.device}, volume on {volume.device}")
+    if volume.dim() != 3:
+        raise ValueError(f"volume must be (Dx, Dy, Dz), got {tuple(volume.shape)}")
+    if target.dim() != 3 or target.shape[-1] != 3:
+        raise ValueError(f"target must be (B, N, 3), got {tuple(target.shape)}")
+    B, N, _ = target.shape
+    if source.dim() != 3 or source.shape[0] != B or source.shape[2] != 3 or \
+            source.shape[1] not in (1, N):
+        raise ValueError(f"source must be (B, 1, 3) or (B, N, 3), got {tuple(source.shape)}")
+    if img is not None and img.numel() != B * N:
+        raise ValueError(f"img must have B*N = {B * N} elements, got {tuple(img.shape)}")
+    return B, N
+
+
+def _hints(det, tile, N):
+    if det is None or det[0] * det[1] != N:
+        return 0, 0, 1, 64
+    th, tw = default_tile() if tile is None else tile
+    return int(det[0]), int(det[1]), int(th), int(tw)
+
+
+def siddon_forward(volume, source, target, img, *, voxel_shift=0.5, eps=1e-8, reducefn="sum",
+                   lookup="step", align_corners=False, want_aux=False, count_voxels=False,
+                   det=None, tile=None):
+    """-> (out (B,N), aux (B,N,8) | None, n_vox (B,N) int32 | None)"""
+    B, N = _check_rays(volume, source, target, img)
+    volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    out = torch.empty(B, N, dtype=torch.float32, device=volume.device)
+    aux = torch.empty(B, N, SIDDON_AUX, dtype=torch.float32, device=volume.device) \
+        if want_aux else None
+    nvox = torch.empty(B, N, dtype=torch.int32, device=volume.device) if count_voxels else None
+    dh, dw, th, tw = _hints(det, tile, N)
+    _launch(
+        "ddrr_siddon_forward", volume.device, volume.data_ptr(), *volume.shape, source.data_ptr(),
+        source.shape[1], target.data_ptr(), _ptr(img), B, N, float(voxel_shift), float(eps),
+        reduce_code(reducefn), _LOOKUP[lookup], int(bool(align_corners)), dh, dw, th, tw,
+        out.data_ptr(), _ptr(aux), _ptr(nvox))
+    return out, aux, nvox
+
+
+def siddon_backward_rays(aux, grad_out, source, target, img, *, eps=1e-8, reducefn="sum",
+                         want_img_grad=True):
+    """-> (g_source (B,N,3) per ray, g_target (B,N,3), g_img (B,N) | None)"""
+    B, N, _ = target.shape
+    grad_out = grad_out.contiguous()
+    g_source = torch.empty(B, N, 3, dtype=torch.float32, device=target.device)
+    g_target = torch.empty(B, N, 3, dtype=torch.float32, device=target.device)
+    g_img = torch.empty(B, N, dtype=torch.float32, device=target.device) if want_img_grad else None
+    _launch(
+        "ddrr_siddon_backward_rays", target.device, aux.data_ptr(), grad_out.data_ptr(), source.data_ptr(),
+        source.shape[1], target.data_ptr(), _ptr(img), B, N, float(eps),
+        reduce_code(reducefn), g_source.data_ptr(), g_target.data_ptr(), _ptr(g_img))
+    return g_source, g_target, g_img
+
+
+def siddon_backward_volume(volume, source, target, img, grad_out, *, voxel_shift=0.5, eps=1e-8,
+                           reducefn="sum", det=None, tile=None):
+    B, N = _check_rays(volume, source, target, img)
+    g_volume = torch.zeros_like(volume, memory_format=torch.contiguous_format)
+    dh, dw, th, tw = _hints(det, tile, N)
+    _launch(
+        "ddrr_siddon_backward_volume", volume.device, volume.data_ptr(), *volume.shape, source.data_ptr(),
+        source.shape[1], target.data_ptr(), _ptr(img), grad_out.contiguous().data_ptr(), B, N,
+        float(voxel_shift), float(eps), reduce_code(reducefn), dh, dw, th, tw,
+        g_volume.data_ptr())
+    return g_volume
+
+
+def siddon_forward_channels(volume, labels_u8, n_channels, source, target, img, *,
+                            voxel_shift=0.5, eps=1e-8, det=None, tile=None):
+    """-> (B, C, N)"""
+    B, N = _check_rays(volume, source, target, img)
+    if labels_u8.dtype != torch.uint8 or labels_u8.shape != volume.shape:
+        raise ValueError("labels must be a uint8 tensor of the volume's shape")
+    out = torch.empty(B, n_channels, N, dtype=torch.float32, device=volume.device)
+    dh, dw, th, tw = _hints(det, tile, N)
+    _launch(
+        "ddrr_siddon_forward_channels", volume.device, volume.data_ptr(), labels_u8.contiguous().data_ptr(),
+        *volume.shape, source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img), B, N,
+        int(n_channels), float(voxel_shift), float(eps), dh, dw, th, tw, out.data_ptr())
+    return out
+
+
+def trilinear_forward(volume, source, target, img, alphamin, alphamax, *, n_points=500,
+                      voxel_shift=0.5, eps=1e-8, reducefn="sum", mode="bilinear",
+                      align_corners=False, det=None, tile=None):
+    """alphamin / alphamax: 0-dim (or 1-element) device tensors.  -> out (B,N)"""
+    B, N = _check_rays(volume, source, target, img)
+    out = torch.empty(B, N, dtype=torch.float32, device=volume.device)
+    dh, dw, th, tw = _hints(det, tile, N)
+    _launch(
+        "ddrr_trilinear_forward", volume.device, volume.data_ptr(), *volume.shape, source.data_ptr(),
+        source.shape[1], target.data_ptr(), _ptr(img), B, N, float(voxel_shift), float(eps),
+        int(n_points), alphamin.data_ptr(), alphamax.data_ptr(), int(mode == "nearest"),
+        reduce_code(reducefn), int(bool(align_corners)), dh, dw, th, tw, out.data_ptr())
+    return out
+
+
+def trilinear_backward(volume, source, target, img, grad_out, alphamin, alphamax, *, n_points=500,
+                       voxel_shift=0.5, eps=1e-8, mode="bilinear", align_corners=False,
+                       want_rays=True, want_img=True, want_alpha=True, want_volume=False,
+                       det=None, tile=None):
+    """-> dict(g_source per ray, g_target, g_img, g_alpha (B,N,2), g_volume)"""
+    B, N = _check_rays(volume, source, target, img)
+    dev = volume.device
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    g_source = new(B, N, 3) if want_rays else None
+    g_target = new(B, N, 3) if want_rays else None
+    g_img = new(B, N) if want_img else None
+    g_alpha = new(B, N, 2) if want_alpha else None
+    g_volume = torch.zeros_like(volume, memory_format=torch.contiguous_format) \
+        if want_volume else None
+    dh, dw, th, tw = _hints(det, tile, N)
+    _launch(
+        "ddrr_trilinear_backward", dev, volume.data_ptr(), *volume.shape, source.data_ptr(),
+        source.shape[1], target.data_ptr(), _ptr(img), grad_out.contiguous().data_ptr(), B, N,
+        float(voxel_shift), float(eps), int(n_points), alphamin.data_ptr(),
+        alphamax.data_ptr(), int(mode == "nearest"), int(bool(align_corners)), dh, dw, th, tw,
+        _ptr(g_source), _ptr(g_target), _ptr(g_img), _ptr(g_alpha), _ptr(g_volume))
+    return {"g_source": g_source, "g_target": g_target, "g_img": g_img, "g_alpha": g_alpha,
+            "g_volume": g_volume}

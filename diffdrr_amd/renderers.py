@@ -1,0 +1,253 @@
+"""``Siddon`` and ``Trilinear``: the reference's renderer modules, on MI355X.
+
+Same constructor arguments and ``forward`` signatures as reference
+``diffdrr/renderers.py:11-91`` (Siddon) and ``:186-254`` (Trilinear), same
+``(B, 1 or C, N)`` result; the tensor programs behind them are replaced by the
+HIP kernels of ``libdiffdrr_hip.so`` through ``torch.autograd.Function``s, so a
+``DRR`` module (ours or the reference's) differentiates
+w.r.t. pose, ray endpoints and the volume exactly as before.
+
+Unsupported corners raise instead of silently diverging: callable ``reducefn``
+(the per-segment tensor is never materialised), fp64, CPU tensors, and
+gradients through the rarely used Siddon ``mode="bilinear"`` /
+``align_corners=True`` / ``reducefn="max"``-with-Trilinear variants (their
+forward passes are supported).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+def _labels_u8(mask: torch.Tensor):
+    """Label map as uint8 + channel count (reference: ``C = int(mask.max()) + 1``,
+    renderers.py:81 -- a host sync per call there; cached per mask tensor here)."""
+    key = (mask.data_ptr(), mask._version, tuple(mask.shape))
+    cached = getattr(_labels_u8, "_cache", None)
+    if cached is not None and cached[0] == key:
+        return cached[1], cached[2]
+    C = int(mask.max().item()) + 1
+    if C > 256:
+        raise NotImplementedError("mask_to_channels supports at most 256 labels")
+    lab = mask.to(torch.uint8).contiguous()
+    _labels_u8._cache = (key, lab, C)
+    return lab, C
+
+
+class _SiddonFn(torch.autograd.Function):
+    """out (B,N) = img * sum_k V_k dalpha_k (or max_k).  Inputs: volume, source,
+    target, img.  Backward: ddrr_siddon_backward_rays from the 8-float forward
+    record (pose / ray gradients, elementwise) and ddrr_siddon_backward_volume
+    (atomic scatter), replacing SortBackward + grid_sampler_3d_backward."""
+
+    @staticmethod
+    def forward(ctx, volume, source, target, img, cfg):
+        need_rays = any(ctx.needs_input_grad[1:4])
+        want_aux = bool(need_rays and cfg["lookup"] == "step")
+        out, aux, _ = ops.siddon_forward(
+            volume, source, target, img, voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
+            reducefn=cfg["reducefn"], lookup=cfg["lookup"], align_corners=cfg["align_corners"],
+            want_aux=want_aux, det=cfg["det"], tile=cfg["tile"])
+        ctx.cfg = cfg
+        ctx.has_aux = want_aux
+        ctx.save_for_backward(volume, source, target, img, aux if want_aux else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        volume, source, target, img, aux = ctx.saved_tensors
+        cfg = ctx.cfg
+        need_vol, need_s, need_t, need_i = ctx.needs_input_grad[:4]
+        if cfg["lookup"] != "step":
+            raise NotImplementedError(
+                "gradients are only implemented for Siddon(mode='nearest', align_corners=False)")
+        stop = cfg["stop_gradients"]
+        g_vol = g_s = g_t = g_i = None
+        grad_out = grad_out.contiguous()
+        if need_s or need_t or need_i:
+            gs, gt, gi = ops.siddon_backward_rays(
+                aux, grad_out, source, target, img, eps=cfg["eps"], reducefn=cfg["reducefn"],
+                want_img_grad=bool(need_i and not stop))
+            if need_s:
+                g_s = gs.sum(dim=1, keepdim=True) if source.shape[1] == 1 else gs
+            if need_t:
+                g_t = gt
+            if need_i and not stop:
+                g_i = gi.view_as(img)
+        if need_vol and not stop:
+            g_vol = ops.siddon_backward_volume(
+                volume, source, target, img, grad_out, voxel_shift=cfg["voxel_shift"],
+                eps=cfg["eps"], reducefn=cfg["reducefn"], det=cfg["det"], tile=cfg["tile"])
+        return g_vol, g_s, g_t, g_i, None
+
+
+class Siddon(torch.nn.Module):
+    """Differentiable X-ray renderer: Siddon's exact ray tracing (reference
+    renderers.py:11-91) as one fused gfx950 kernel per call."""
+
+    def __init__(
+        self,
+        voxel_shift: float = 0.5,
+        mode: str = "nearest",
+        stop_gradients_through_grid_sample: bool = False,
+        filter_intersections_outside_volume: bool = False,
+        reducefn: str = "sum",
+        eps: float = 1e-8,
+    ):
+        super().__init__()
+        if mode not in ("nearest", "bilinear"):
+            raise ValueError(f"mode must be 'nearest' or 'bilinear', not {mode}")
+        self.mode = mode
+        self.stop_gradients_through_grid_sample = stop_gradients_through_grid_sample
+        # Accepted for signature compatibility.  In the reference the flag only
+        # drops crossings outside the volume (zero-valued segments), and its
+        # implementation raises a TypeError (renderers.py:118 vs :124); the fused
+        # walk never visits those crossings, so the result is the same either way.
+        self.filter_intersections_outside_volume = filter_intersections_outside_volume
+        self.reducefn = reducefn
+        self.voxel_shift = voxel_shift
+        self.eps = eps
+        # performance hints set by DRR (detector grid of the rays; wave tile shape)
+        self.detector_shape = None
+        self.tile = None
+
+    def dims(self, volume):
+        return torch.tensor(volume.shape).to(volume)
+
+    def _cfg(self, align_corners):
+        if self.mode == "bilinear":
+            lookup = "mid_trilinear"
+        elif align_corners:
+            lookup = "mid_nearest"
+        else:
+            lookup = "step"
+        ops.reduce_code(self.reducefn)  # validates / raises like reference `reduce`
+        return {"voxel_shift": self.voxel_shift, "eps": self.eps, "reducefn": self.reducefn,
+                "lookup": lookup, "align_corners": bool(align_corners),
+                "stop_gradients": self.stop_gradients_through_grid_sample,
+                "det": self.detector_shape, "tile": self.tile}
+
+    def forward(self, volume, source, target, img, align_corners=False, mask=None):
+        B, N, _ = target.shape
+        cfg = self._cfg(align_corners)
+        if mask is None:
+            out = _SiddonFn.apply(volume, source, target, img.reshape(B, N), cfg)
+            return out.unsqueeze(1)
+        # mask_to_channels (renderers.py:77-89); forward only, like the reference
+        # in practice (the label gather is not differentiable)
+        if cfg["lookup"] != "step" or self.reducefn != "sum":
+            raise NotImplementedError(
+                "mask_to_channels needs mode='nearest', align_corners=False, reducefn='sum'")
+        if any(t.requires_grad for t in (volume, source, target, img)) and \
+                torch.is_grad_enabled():
+            raise NotImplementedError("mask_to_channels rendering is forward-only here; wrap the "
+                                      "call in torch.no_grad()")
+        labels, C = _labels_u8(mask)
+        return ops.siddon_forward_channels(
+            volume, labels, C, source.contiguous(), target.contiguous(),
+            img.reshape(B, N).contiguous(), voxel_shift=self.voxel_shift, eps=self.eps,
+            det=self.detector_shape, tile=self.tile)
+
+
+def get_alpha_minmax(source, target, dims, voxel_shift, eps):
+    """First / last intersection of each ray with the (one voxel enlarged) volume,
+    clipped to [0, 1]: the reference's ``_get_alpha_minmax`` (renderers.py:124-140),
+    including its far plane at ``dims + 1 - voxel_shift``.  Plain torch so that
+    autograd routes d/d alphamin, d/d alphamax to the arg-min / arg-max ray."""
+    sdd = target - source + eps
+    lo_plane = -voxel_shift
+    hi_plane = dims.to(source) + 1 - voxel_shift
+    a0 = (lo_plane - source) / sdd
+    a1 = (hi_plane - source) / sdd
+    alphamin = torch.minimum(a0, a1).amax(dim=-1, keepdim=True).clamp_min(0.0)
+    alphamax = torch.maximum(a0, a1).amin(dim=-1, keepdim=True).clamp_max(1.0)
+    return alphamin, alphamax
+
+
+class _TrilinearFn(torch.autograd.Function):
+    """out (B,N) = img * step * sum_m T(V, x(alpha_m)).  Inputs: volume, source,
+    target, img, alphamin, alphamax (0-dim device tensors).  Backward: one
+    ddrr_trilinear_backward launch (ray gradients, d/d alphamin, d/d alphamax and
+    the 8-corner atomic scatter), replacing grid_sampler_3d_backward + chain."""
+
+    @staticmethod
+    def forward(ctx, volume, source, target, img, alphamin, alphamax, cfg):
+        out = ops.trilinear_forward(
+            volume, source.contiguous(), target.contiguous(), img.contiguous(), alphamin,
+            alphamax, n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
+            reducefn=cfg["reducefn"], mode=cfg["mode"], align_corners=cfg["align_corners"],
+            det=cfg["det"], tile=cfg["tile"])
+        ctx.cfg = cfg
+        ctx.save_for_backward(volume, source, target, img, alphamin, alphamax)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        volume, source, target, img, alphamin, alphamax = ctx.saved_tensors
+        cfg = ctx.cfg
+        if cfg["reducefn"] != "sum":
+            raise NotImplementedError("Trilinear gradients are implemented for reducefn='sum'")
+        need_vol, need_s, need_t, need_i, need_a0, need_a1 = ctx.needs_input_grad[:6]
+        r = ops.trilinear_backward(
+            volume, source.contiguous(), target.contiguous(), img.contiguous(), grad_out,
+            alphamin, alphamax, n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"],
+            eps=cfg["eps"], mode=cfg["mode"], align_corners=cfg["align_corners"],
+            want_rays=bool(need_s or need_t), want_img=bool(need_i),
+            want_alpha=bool(need_a0 or need_a1), want_volume=bool(need_vol), det=cfg["det"],
+            tile=cfg["tile"])
+        g_s = g_t = g_a0 = g_a1 = g_i = None
+        if need_s:
+            g_s = r["g_source"].sum(dim=1, keepdim=True) if source.shape[1] == 1 \
+                else r["g_source"]
+        if need_t:
+            g_t = r["g_target"]
+        if need_i:
+            g_i = r["g_img"].view_as(img)
+        if need_a0 or need_a1:
+            ga = r["g_alpha"].sum(dim=(0, 1))
+            g_a0 = ga[0].reshape(alphamin.shape) if need_a0 else None
+            g_a1 = ga[1].reshape(alphamax.shape) if need_a1 else None
+        return r["g_volume"], g_s, g_t, g_i, g_a0, g_a1, None
+
+
+class Trilinear(torch.nn.Module):
+    """Differentiable X-ray renderer: trilinear ray marching (reference
+    renderers.py:186-254) as one fused gfx950 kernel per call."""
+
+    def __init__(self, voxel_shift: float = 0.5, mode: str = "bilinear", reducefn: str = "sum",
+                 eps: float = 1e-8):
+        super().__init__()
+        if mode not in ("nearest", "bilinear"):
+            raise ValueError(f"mode must be 'nearest' or 'bilinear', not {mode}")
+        self.mode = mode
+        self.reducefn = reducefn
+        self.voxel_shift = voxel_shift
+        self.eps = eps
+        self.detector_shape = None
+        self.tile = None
+
+    def dims(self, volume):
+        return torch.tensor(volume.shape).to(volume)
+
+    def forward(self, volume, source, target, img, n_points=500, align_corners=False, mask=None,
+                alphamin=None, alphamax=None):
+        B, N, _ = target.shape
+        ops.reduce_code(self.reducefn)
+        if mask is not None:
+            raise NotImplementedError(
+                "mask_to_channels is implemented for the Siddon renderer only (round 1)")
+        if alphamin is None or alphamax is None:
+            # the reference's batch-global marching range (renderers.py:220-223)
+            lo, hi = get_alpha_minmax(source, target, self.dims(volume), self.voxel_shift,
+                                      self.eps)
+            alphamin, alphamax = lo.min(), hi.max()
+        alphamin = torch.as_tensor(alphamin, dtype=volume.dtype, device=volume.device)
+        alphamax = torch.as_tensor(alphamax, dtype=volume.dtype, device=volume.device)
+        cfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift, "eps": self.eps,
+               "reducefn": self.reducefn, "mode": self.mode,
+               "align_corners": bool(align_corners), "det": self.detector_shape,
+               "tile": self.tile}
+        out = _TrilinearFn.apply(volume, source, target, img.reshape(B, N), alphamin, alphamax,
+                                 cfg)
+        return out.unsqueeze(1)

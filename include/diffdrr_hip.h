@@ -1,0 +1,122 @@
+/*
+ * diffdrr_hip.h -- C ABI of libdiffdrr_hip.so: the MI355X (gfx950) renderers
+ * behind DiffDRR's renderer seam.
+ *
+ * The reference has no FFI: its seam is the Python attribute `DRR.renderer`
+ * (an nn.Module chosen at /root/reference/diffdrr/drr.py:94-101 and called at
+ * drr.py:209-224 as `renderer(density, source, target, img, **kwargs)`).  The
+ * entry points below are what a ctypes binding inside
+ * diffdrr/renderers.py would call in place of the tensor programs at
+ *   renderers.py:34-91   Siddon.forward      -> ddrr_siddon_forward (+ _channels)
+ *   renderers.py:205-254 Trilinear.forward   -> ddrr_trilinear_forward
+ * and in place of torch-autograd's backward of those programs
+ *   (grid_sampler_3d_backward, SortBackward, ~30 elementwise backward ops)
+ *                                            -> ddrr_siddon_backward_rays,
+ *                                               ddrr_siddon_backward_volume,
+ *                                               ddrr_trilinear_backward.
+ * INTEGRATION.md shows that binding.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 (HIP, gfx950), dense and
+ *    C-contiguous; nothing is copied, pointers are borrowed for the call only;
+ *  - volume V[dx][dy][dz]  (z fastest: reference drr.py:81-85 `density`;
+ *    the reference only *views* it permuted, renderers.py:160);
+ *  - source (B, src_n, 3) with src_n == 1 (one source per pose, the DRR case:
+ *    detector.py:152) or src_n == N; target (B, N, 3); both in voxel-index
+ *    coordinates (after drr.py:204-205);
+ *  - img (B, N): ray length in world units (drr.py:201), NULL == all ones;
+ *  - out (B, N) (the reference's (B, 1, N) without the singleton);
+ *  - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous
+ *    and never synchronise the device; the library keeps no global state
+ *    besides a thread-local error string;
+ *  - return value: 0 on success, otherwise a hipError_t (or -1 for an
+ *    argument error); ddrr_last_error() describes the last failure.
+ *
+ * det_h/det_w/tile_h/tile_w are a pure performance hint: when the N rays of a
+ * pose are a row-major det_h x det_w detector grid (detector.py:126) each
+ * 64-lane wavefront renders a tile_h x tile_w tile of pixels (tile_h * tile_w
+ * == 64); pass zeros for an arbitrary ray list.  Results do not depend on it.
+ */
+#ifndef DIFFDRR_HIP_H
+#define DIFFDRR_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDRR_ABI_VERSION 1
+
+#define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
+#define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
+
+#define DDRR_LOOKUP_STEP 0          /* mode="nearest", align_corners=False: exact voxel stepping */
+#define DDRR_LOOKUP_MID_NEAREST 1   /* nearest lookup at each segment midpoint (any align_corners) */
+#define DDRR_LOOKUP_MID_TRILINEAR 2 /* Siddon(mode="bilinear"): trilinear lookup at midpoints */
+
+#define DDRR_SIDDON_AUX 8 /* floats per ray in the forward record used by the backward */
+
+int ddrr_abi_version(void);
+const char *ddrr_last_error(void);
+
+/* Siddon.forward, mask=None (renderers.py:34-76).  aux: NULL, or (B, N, 8)
+ * record for ddrr_siddon_backward_rays (only with DDRR_LOOKUP_STEP).
+ * n_vox: NULL, or (B, N) int32 receiving the number of positive-length
+ * in-volume segments of each ray (the algorithmic voxel count). */
+int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float *source,
+                        int src_n, const float *target, const float *img, int B, int N,
+                        float voxel_shift, float eps, int reduce_mode, int lookup_mode,
+                        int align_corners, int det_h, int det_w, int tile_h, int tile_w,
+                        float *out, float *aux, int *n_vox, void *stream);
+
+/* Pose/ray gradients of ddrr_siddon_forward from its aux record: what autograd
+ * of renderers.py:94-113 + :70-71 returns.  g_source is per ray (B, N, 3) (sum
+ * over rays for a broadcast source); g_target (B, N, 3); g_img (B, N), the
+ * gradient w.r.t. `img` (NULL to skip, e.g. stop_gradients_through_grid_sample). */
+int ddrr_siddon_backward_rays(const float *aux, const float *grad_out, const float *source,
+                              int src_n, const float *target, const float *img, int B, int N,
+                              float eps, int reduce_mode, float *g_source, float *g_target,
+                              float *g_img, void *stream);
+
+/* Volume gradient of ddrr_siddon_forward (replaces grid_sampler_3d_backward,
+ * nearest): ACCUMULATES grad_out * img * dalpha into g_volume[dx][dy][dz] with
+ * hardware fp32 atomics; the caller zero-fills g_volume. */
+int ddrr_siddon_backward_volume(const float *volume, int dx, int dy, int dz, const float *source,
+                                int src_n, const float *target, const float *img,
+                                const float *grad_out, int B, int N, float voxel_shift, float eps,
+                                int reduce_mode, int det_h, int det_w, int tile_h, int tile_w,
+                                float *g_volume, void *stream);
+
+/* Siddon.forward with a mask (mask_to_channels, renderers.py:77-89): labels is
+ * the (dx, dy, dz) uint8 label map, out is (B, C, N) and is fully written. */
+int ddrr_siddon_forward_channels(const float *volume, const unsigned char *labels, int dx, int dy,
+                                 int dz, const float *source, int src_n, const float *target,
+                                 const float *img, int B, int N, int C, float voxel_shift,
+                                 float eps, int det_h, int det_w, int tile_h, int tile_w,
+                                 float *out, void *stream);
+
+/* Trilinear.forward, mask=None (renderers.py:205-241).  alphamin/alphamax are
+ * DEVICE scalars (renderers.py:220-223 evaluated by the caller, or the
+ * caller's own values); mode_nearest selects Trilinear(mode="nearest"). */
+int ddrr_trilinear_forward(const float *volume, int dx, int dy, int dz, const float *source,
+                           int src_n, const float *target, const float *img, int B, int N,
+                           float voxel_shift, float eps, int n_points, const float *alphamin,
+                           const float *alphamax, int mode_nearest, int reduce_mode,
+                           int align_corners, int det_h, int det_w, int tile_h, int tile_w,
+                           float *out, void *stream);
+
+/* Backward of ddrr_trilinear_forward (reduce sum).  Any output may be NULL.
+ * g_source/g_target: per ray (B, N, 3), through the sample positions;
+ * g_img (B, N); g_alpha (B, N, 2): per-ray contributions to d/d alphamin and
+ * d/d alphamax (sum them); g_volume: ACCUMULATED with fp32 atomics. */
+int ddrr_trilinear_backward(const float *volume, int dx, int dy, int dz, const float *source,
+                            int src_n, const float *target, const float *img,
+                            const float *grad_out, int B, int N, float voxel_shift, float eps,
+                            int n_points, const float *alphamin, const float *alphamax,
+                            int mode_nearest, int align_corners, int det_h, int det_w, int tile_h,
+                            int tile_w, float *g_source, float *g_target, float *g_img,
+                            float *g_alpha, float *g_volume, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFDRR_HIP_H */

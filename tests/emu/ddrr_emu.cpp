@@ -1,0 +1,255 @@
+// ddrr_emu.cpp -- TEST-ONLY host build of the per-ray kernel cores.
+//
+// Compiles diffdrr_amd/csrc/{siddon,trilinear}_core.h for the CPU (the headers
+// are written as __host__ __device__ code) behind the same C ABI as
+// include/diffdrr_hip.h, with every pointer a HOST pointer.  It lets the
+// traversal logic of the HIP kernels be checked against the oracle in the
+// GPU-less build container (tests/test_emu_vs_oracle.py).  It is NOT a CPU
+// fallback: nothing in diffdrr_amd/ can load it, and it is built into
+// tests/emu/_build only by the tests.
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../diffdrr_amd/csrc/ddrr_common.h"
+#include "../../diffdrr_amd/csrc/siddon_core.h"
+#include "../../diffdrr_amd/csrc/trilinear_core.h"
+#include "../../include/diffdrr_hip.h"
+
+using namespace ddrr;
+
+namespace {
+
+struct Ray {
+    float s[3], t[3], L;
+};
+
+// Visit rays in the same (wave, lane) order as the kernels so that the tile
+// map is exercised too.
+template <class F>
+void for_each_ray(const float *source, int src_n, const float *target, const float *img, int B,
+                  int N, int det_h, int det_w, int tile_h, int tile_w, F f) {
+    const TileMap tm = make_tilemap(N, det_h, det_w, tile_h, tile_w);
+    std::vector<char> seen((size_t)B * N, 0);
+    for (int b = 0; b < B; ++b)
+        for (int w = 0; w < tm.waves_per_pose; ++w)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int n = tile_ray(tm, w, lane, N);
+                if (n < 0) continue;
+                const long r = (long)b * N + n;
+                seen[r]++;
+                Ray ray;
+                const float *sp = source + ((long)b * src_n + (src_n == 1 ? 0 : n)) * 3;
+                for (int a = 0; a < 3; ++a) {
+                    ray.s[a] = sp[a];
+                    ray.t[a] = target[r * 3 + a];
+                }
+                ray.L = img ? img[r] : 1.f;
+                f(b, n, r, ray);
+            }
+    for (size_t i = 0; i < seen.size(); ++i)
+        if (seen[i] != 1) abort();  // the tile map must be a bijection
+}
+
+struct HostAdd {
+    float *base;
+    void operator()(unsigned off, float v) const { base[off] += v; }
+};
+struct NoAdd {
+    void operator()(unsigned, float) const {}
+};
+
+}  // namespace
+
+extern "C" {
+
+int ddrr_abi_version(void) { return DDRR_ABI_VERSION; }
+const char *ddrr_last_error(void) { return ""; }
+
+int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float *source,
+                        int src_n, const float *target, const float *img, int B, int N,
+                        float voxel_shift, float eps, int reduce_mode, int lookup_mode,
+                        int align_corners, int det_h, int det_w, int tile_h, int tile_w,
+                        float *out, float *aux, int *n_vox, void *) {
+    const Dims D{dx, dy, dz};
+    for_each_ray(source, src_n, target, img, B, N, det_h, det_w, tile_h, tile_w,
+                 [&](int, int, long r, const Ray &ray) {
+                     float rec[SIDDON_AUX] = {0};
+                     int cnt = 0;
+                     float I;
+                     const bool sum = reduce_mode == DDRR_REDUCE_SUM;
+                     if (lookup_mode == DDRR_LOOKUP_STEP) {
+                         if (n_vox)
+                             I = sum ? siddon_forward_ray<REDUCE_SUM, false, true>(
+                                           volume, D, ray.s, ray.t, voxel_shift, eps, rec, &cnt)
+                                     : siddon_forward_ray<REDUCE_MAX, false, true>(
+                                           volume, D, ray.s, ray.t, voxel_shift, eps, rec, &cnt);
+                         else if (aux)
+                             I = sum ? siddon_forward_ray<REDUCE_SUM, true, false>(
+                                           volume, D, ray.s, ray.t, voxel_shift, eps, rec, &cnt)
+                                     : siddon_forward_ray<REDUCE_MAX, true, false>(
+                                           volume, D, ray.s, ray.t, voxel_shift, eps, rec, &cnt);
+                         else
+                             I = sum ? siddon_forward_ray<REDUCE_SUM, false, false>(
+                                           volume, D, ray.s, ray.t, voxel_shift, eps, rec, &cnt)
+                                     : siddon_forward_ray<REDUCE_MAX, false, false>(
+                                           volume, D, ray.s, ray.t, voxel_shift, eps, rec, &cnt);
+                     } else if (lookup_mode == DDRR_LOOKUP_MID_TRILINEAR) {
+                         I = sum ? siddon_forward_ray_midpoint<REDUCE_SUM, LOOKUP_MID_TRILINEAR>(
+                                       volume, D, ray.s, ray.t, voxel_shift, eps, align_corners)
+                                 : siddon_forward_ray_midpoint<REDUCE_MAX, LOOKUP_MID_TRILINEAR>(
+                                       volume, D, ray.s, ray.t, voxel_shift, eps, align_corners);
+                     } else {
+                         I = sum ? siddon_forward_ray_midpoint<REDUCE_SUM, LOOKUP_MID_NEAREST>(
+                                       volume, D, ray.s, ray.t, voxel_shift, eps, align_corners)
+                                 : siddon_forward_ray_midpoint<REDUCE_MAX, LOOKUP_MID_NEAREST>(
+                                       volume, D, ray.s, ray.t, voxel_shift, eps, align_corners);
+                     }
+                     out[r] = ray.L * I;
+                     if (aux) memcpy(aux + r * SIDDON_AUX, rec, sizeof(rec));
+                     if (n_vox) n_vox[r] = cnt;
+                 });
+    return 0;
+}
+
+int ddrr_siddon_backward_rays(const float *aux, const float *grad_out, const float *source,
+                              int src_n, const float *target, const float *img, int B, int N,
+                              float eps, int reduce_mode, float *g_source, float *g_target,
+                              float *g_img, void *) {
+    for_each_ray(source, src_n, target, img, B, N, 0, 0, 0, 0,
+                 [&](int, int, long r, const Ray &ray) {
+                     float gs[3], gt[3];
+                     const float *rec = aux + r * SIDDON_AUX;
+                     if (reduce_mode == DDRR_REDUCE_SUM)
+                         siddon_backward_ray<REDUCE_SUM>(rec, ray.s, ray.t, eps,
+                                                         grad_out[r] * ray.L, gs, gt);
+                     else
+                         siddon_backward_ray<REDUCE_MAX>(rec, ray.s, ray.t, eps,
+                                                         grad_out[r] * ray.L, gs, gt);
+                     for (int a = 0; a < 3; ++a) {
+                         if (g_source) g_source[r * 3 + a] = gs[a];
+                         if (g_target) g_target[r * 3 + a] = gt[a];
+                     }
+                     if (g_img) g_img[r] = grad_out[r] * rec[0];
+                 });
+    return 0;
+}
+
+int ddrr_siddon_backward_volume(const float *volume, int dx, int dy, int dz, const float *source,
+                                int src_n, const float *target, const float *img,
+                                const float *grad_out, int B, int N, float voxel_shift, float eps,
+                                int reduce_mode, int det_h, int det_w, int tile_h, int tile_w,
+                                float *g_volume, void *) {
+    const Dims D{dx, dy, dz};
+    for_each_ray(source, src_n, target, img, B, N, det_h, det_w, tile_h, tile_w,
+                 [&](int, int, long r, const Ray &ray) {
+                     const float gl = grad_out[r] * ray.L;
+                     if (reduce_mode == DDRR_REDUCE_SUM)
+                         siddon_scatter_ray<REDUCE_SUM>(volume, D, ray.s, ray.t, voxel_shift, eps,
+                                                        gl, HostAdd{g_volume});
+                     else
+                         siddon_scatter_ray<REDUCE_MAX>(volume, D, ray.s, ray.t, voxel_shift, eps,
+                                                        gl, HostAdd{g_volume});
+                 });
+    return 0;
+}
+
+int ddrr_siddon_forward_channels(const float *volume, const unsigned char *labels, int dx, int dy,
+                                 int dz, const float *source, int src_n, const float *target,
+                                 const float *img, int B, int N, int C, float voxel_shift,
+                                 float eps, int det_h, int det_w, int tile_h, int tile_w,
+                                 float *out, void *) {
+    const Dims D{dx, dy, dz};
+    memset(out, 0, sizeof(float) * (size_t)B * C * N);
+    for_each_ray(source, src_n, target, img, B, N, det_h, det_w, tile_h, tile_w,
+                 [&](int b, int n, long, const Ray &ray) {
+                     float *col = out + (long)b * C * N + n;
+                     siddon_channels_ray(volume, labels, D, ray.s, ray.t, voxel_shift, eps,
+                                         [&](int label, float run) {
+                                             if (label < C) col[(long)label * N] += ray.L * run;
+                                         });
+                 });
+    return 0;
+}
+
+int ddrr_trilinear_forward(const float *volume, int dx, int dy, int dz, const float *source,
+                           int src_n, const float *target, const float *img, int B, int N,
+                           float voxel_shift, float eps, int n_points, const float *alphamin,
+                           const float *alphamax, int mode_nearest, int reduce_mode,
+                           int align_corners, int det_h, int det_w, int tile_h, int tile_w,
+                           float *out, void *) {
+    const Dims D{dx, dy, dz};
+    for_each_ray(
+        source, src_n, target, img, B, N, det_h, det_w, tile_h, tile_w,
+        [&](int, int, long r, const Ray &ray) {
+            float I;
+            const bool sum = reduce_mode == DDRR_REDUCE_SUM;
+            const bool ac = align_corners != 0;
+            if (mode_nearest)
+                I = sum ? trilinear_forward_ray<REDUCE_SUM, true>(volume, D, ray.s, ray.t,
+                                                                  voxel_shift, eps, n_points,
+                                                                  *alphamin, *alphamax, ac)
+                        : trilinear_forward_ray<REDUCE_MAX, true>(volume, D, ray.s, ray.t,
+                                                                  voxel_shift, eps, n_points,
+                                                                  *alphamin, *alphamax, ac);
+            else
+                I = sum ? trilinear_forward_ray<REDUCE_SUM, false>(volume, D, ray.s, ray.t,
+                                                                   voxel_shift, eps, n_points,
+                                                                   *alphamin, *alphamax, ac)
+                        : trilinear_forward_ray<REDUCE_MAX, false>(volume, D, ray.s, ray.t,
+                                                                   voxel_shift, eps, n_points,
+                                                                   *alphamin, *alphamax, ac);
+            out[r] = ray.L * I;
+        });
+    return 0;
+}
+
+int ddrr_trilinear_backward(const float *volume, int dx, int dy, int dz, const float *source,
+                            int src_n, const float *target, const float *img,
+                            const float *grad_out, int B, int N, float voxel_shift, float eps,
+                            int n_points, const float *alphamin, const float *alphamax,
+                            int mode_nearest, int align_corners, int det_h, int det_w, int tile_h,
+                            int tile_w, float *g_source, float *g_target, float *g_img,
+                            float *g_alpha, float *g_volume, void *) {
+    const Dims D{dx, dy, dz};
+    for_each_ray(
+        source, src_n, target, img, B, N, det_h, det_w, tile_h, tile_w,
+        [&](int, int, long r, const Ray &ray) {
+            const float g = grad_out[r];
+            const bool ac = align_corners != 0;
+            MarchGrad m;
+            if (mode_nearest) {
+                if (g_volume)
+                    m = trilinear_backward_ray<true, true>(volume, D, ray.s, ray.t, voxel_shift,
+                                                           eps, n_points, *alphamin, *alphamax, ac,
+                                                           g * ray.L, HostAdd{g_volume});
+                else
+                    m = trilinear_backward_ray<true, false>(volume, D, ray.s, ray.t, voxel_shift,
+                                                            eps, n_points, *alphamin, *alphamax,
+                                                            ac, g * ray.L, NoAdd{});
+            } else {
+                if (g_volume)
+                    m = trilinear_backward_ray<false, true>(volume, D, ray.s, ray.t, voxel_shift,
+                                                            eps, n_points, *alphamin, *alphamax,
+                                                            ac, g * ray.L, HostAdd{g_volume});
+                else
+                    m = trilinear_backward_ray<false, false>(volume, D, ray.s, ray.t, voxel_shift,
+                                                             eps, n_points, *alphamin, *alphamax,
+                                                             ac, g * ray.L, NoAdd{});
+            }
+            for (int a = 0; a < 3; ++a) {
+                if (g_source) g_source[r * 3 + a] = m.gs[a];
+                if (g_target) g_target[r * 3 + a] = m.gt[a];
+            }
+            if (g_img)
+                g_img[r] = g * m.sumT * ((*alphamax - *alphamin) / (float)(n_points - 1));
+            if (g_alpha) {
+                g_alpha[r * 2 + 0] = m.g_amin;
+                g_alpha[r * 2 + 1] = m.g_amax;
+            }
+        });
+    return 0;
+}
+
+}  // extern "C"

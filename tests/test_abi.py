@@ -1,0 +1,95 @@
+"""The C ABI: include/diffdrr_hip.h <-> ctypes signatures <-> built library.
+No compute is issued here (no GPU needed)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+from diffdrr_amd import _lib
+
+HEADER = os.path.join(ROOT, "include", "diffdrr_hip.h")
+
+
+def _declared():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(?:int|const char \*)\s*(ddrr_\w+)\s*\(([^;]*?)\)\s*;", text, re.S):
+        args = m.group(2).strip()
+        decls[m.group(1)] = 0 if args == "void" else len(args.split(","))
+    return decls
+
+
+def test_header_matches_ctypes_signatures():
+    decls = _declared()
+    assert set(decls) == set(_lib.EXPORTS)
+    for name, argtypes in _lib._SIGNATURES.items():
+        assert decls[name] == len(argtypes), name
+
+
+def test_header_constants_match():
+    text = open(HEADER).read()
+    const = dict(re.findall(r"#define (DDRR_\w+) (\d+)", text))
+    assert int(const["DDRR_ABI_VERSION"]) == _lib.ABI_VERSION
+    assert int(const["DDRR_REDUCE_SUM"]) == _lib.REDUCE_SUM
+    assert int(const["DDRR_REDUCE_MAX"]) == _lib.REDUCE_MAX
+    assert int(const["DDRR_LOOKUP_STEP"]) == _lib.LOOKUP_STEP
+    assert int(const["DDRR_LOOKUP_MID_NEAREST"]) == _lib.LOOKUP_MID_NEAREST
+    assert int(const["DDRR_LOOKUP_MID_TRILINEAR"]) == _lib.LOOKUP_MID_TRILINEAR
+    assert int(const["DDRR_SIDDON_AUX"]) == _lib.SIDDON_AUX
+
+
+def test_library_builds_loads_and_exports_every_symbol():
+    """hipcc cross-compiles gfx950 without a GPU; loading the .so and reading its
+    ABI version needs no device."""
+    import __graft_entry__ as entry
+
+    entry.build_hip()
+    assert os.path.exists(_lib.LIB_PATH)
+    lib = _lib.DdrrLibrary(_lib.LIB_PATH)  # checks every export + the ABI version
+    assert lib.cdll.ddrr_abi_version() == _lib.ABI_VERSION
+    syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True,
+                          text=True, check=True).stdout
+    for name in _declared():
+        assert re.search(rf"\bT {name}\b", syms), name
+
+
+def test_library_contains_gfx950_code_object():
+    import __graft_entry__ as entry
+
+    entry.build_hip()
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"siddon_fwd_kernel" in blob
+
+
+def test_product_refuses_cpu_tensors():
+    import torch
+
+    from diffdrr_amd import Siddon
+
+    vol = torch.rand(4, 4, 4)
+    src = torch.zeros(1, 1, 3)
+    tgt = torch.ones(1, 5, 3)
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        Siddon()(vol, src, tgt, torch.ones(1, 1, 5))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.get_lib()
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "diffdrr_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "ref_loader" not in text and "/root/reference" not in text, f
