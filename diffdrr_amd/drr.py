@@ -195,5 +195,6 @@ class DRR(nn.Module):
 def reshape_subsampled_drr(img: torch.Tensor, detector: Detector, batch_size: int):
     n_points = detector.height * detector.width
     drr = torch.zeros(batch_size, n_points).to(img)
-    drr[:, detector.subsamples[-1]] = img
+    # (the reference's `drr[:, idx] = img` only broadcasts for batch_size == 1)
+    drr[:, detector.subsamples[-1]] = img.reshape(batch_size, -1)
     return drr.view(batch_size, 1, detector.height, detector.width)

@@ -10,10 +10,12 @@ import torch
 
 
 def to_patches(x, patch_size):
-    """All ``patch_size`` x ``patch_size`` windows (stride 1) as channels."""
+    """Every ``patch_size`` x ``patch_size`` window (stride 1) becomes one channel
+    whose spatial extent is the window, so that :meth:`norm` z-scores each window
+    on its own (local NCC), as in reference metrics.py:16-18."""
     x = x.unfold(2, patch_size, 1).unfold(3, patch_size, 1)  # b c h' w' p1 p2
     b, c, h, w, p1, p2 = x.shape
-    return x.permute(0, 1, 4, 5, 2, 3).reshape(b, c * p1 * p2, h, w)
+    return x.reshape(b, c * h * w, p1, p2)
 
 
 class NormalizedCrossCorrelation2d(torch.nn.Module):

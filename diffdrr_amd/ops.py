@@ -83,6 +83,11 @@ def _check_rays(volume, source, target, img):
     return B, N
 
 
+def _empty(B, N):
+    """Nothing to render (an empty batch has no valid device pointers to hand over)."""
+    return B == 0 or N == 0
+
+
 def _hints(det, tile, N):
     if det is None or det[0] * det[1] != N:
         return 0, 0, 1, 64
@@ -102,6 +107,8 @@ def siddon_forward(volume, source, target, img, *, voxel_shift=0.5, eps=1e-8, re
         if want_aux else None
     nvox = torch.empty(B, N, dtype=torch.int32, device=volume.device) if count_voxels else None
     dh, dw, th, tw = _hints(det, tile, N)
+    if _empty(B, N):
+        return out, aux, nvox
     _launch(
         "ddrr_siddon_forward", volume.device, volume.data_ptr(), *volume.shape, source.data_ptr(),
         source.shape[1], target.data_ptr(), _ptr(img), B, N, float(voxel_shift), float(eps),
@@ -118,6 +125,8 @@ def siddon_backward_rays(aux, grad_out, source, target, img, *, eps=1e-8, reduce
     g_source = torch.empty(B, N, 3, dtype=torch.float32, device=target.device)
     g_target = torch.empty(B, N, 3, dtype=torch.float32, device=target.device)
     g_img = torch.empty(B, N, dtype=torch.float32, device=target.device) if want_img_grad else None
+    if _empty(B, N):
+        return g_source, g_target, g_img
     _launch(
         "ddrr_siddon_backward_rays", target.device, aux.data_ptr(), grad_out.data_ptr(), source.data_ptr(),
         source.shape[1], target.data_ptr(), _ptr(img), B, N, float(eps),
@@ -130,6 +139,8 @@ def siddon_backward_volume(volume, source, target, img, grad_out, *, voxel_shift
     B, N = _check_rays(volume, source, target, img)
     g_volume = torch.zeros_like(volume, memory_format=torch.contiguous_format)
     dh, dw, th, tw = _hints(det, tile, N)
+    if _empty(B, N):
+        return g_volume
     _launch(
         "ddrr_siddon_backward_volume", volume.device, volume.data_ptr(), *volume.shape, source.data_ptr(),
         source.shape[1], target.data_ptr(), _ptr(img), grad_out.contiguous().data_ptr(), B, N,
@@ -146,6 +157,8 @@ def siddon_forward_channels(volume, labels_u8, n_channels, source, target, img, 
         raise ValueError("labels must be a uint8 tensor of the volume's shape")
     out = torch.empty(B, n_channels, N, dtype=torch.float32, device=volume.device)
     dh, dw, th, tw = _hints(det, tile, N)
+    if _empty(B, N):
+        return out
     _launch(
         "ddrr_siddon_forward_channels", volume.device, volume.data_ptr(), labels_u8.contiguous().data_ptr(),
         *volume.shape, source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img), B, N,
@@ -160,6 +173,8 @@ def trilinear_forward(volume, source, target, img, alphamin, alphamax, *, n_poin
     B, N = _check_rays(volume, source, target, img)
     out = torch.empty(B, N, dtype=torch.float32, device=volume.device)
     dh, dw, th, tw = _hints(det, tile, N)
+    if _empty(B, N):
+        return out
     _launch(
         "ddrr_trilinear_forward", volume.device, volume.data_ptr(), *volume.shape, source.data_ptr(),
         source.shape[1], target.data_ptr(), _ptr(img), B, N, float(voxel_shift), float(eps),
@@ -183,11 +198,14 @@ def trilinear_backward(volume, source, target, img, grad_out, alphamin, alphamax
     g_volume = torch.zeros_like(volume, memory_format=torch.contiguous_format) \
         if want_volume else None
     dh, dw, th, tw = _hints(det, tile, N)
+    res = {"g_source": g_source, "g_target": g_target, "g_img": g_img, "g_alpha": g_alpha,
+           "g_volume": g_volume}
+    if _empty(B, N):
+        return res
     _launch(
         "ddrr_trilinear_backward", dev, volume.data_ptr(), *volume.shape, source.data_ptr(),
         source.shape[1], target.data_ptr(), _ptr(img), grad_out.contiguous().data_ptr(), B, N,
         float(voxel_shift), float(eps), int(n_points), alphamin.data_ptr(),
         alphamax.data_ptr(), int(mode == "nearest"), int(bool(align_corners)), dh, dw, th, tw,
         _ptr(g_source), _ptr(g_target), _ptr(g_img), _ptr(g_alpha), _ptr(g_volume))
-    return {"g_source": g_source, "g_target": g_target, "g_img": g_img, "g_alpha": g_alpha,
-            "g_volume": g_volume}
+    return res

@@ -1,0 +1,184 @@
+"""The per-ray kernel cores (diffdrr_amd/csrc/*_core.h), compiled for the host by
+tests/emu, against the oracle and the reference goldens.  This checks the
+traversal *logic* the HIP kernels execute (3-way merge, software-pipelined
+fetch slots, aux record, scatter, tile map) in the GPU-less container; the same
+comparisons run on the real kernels in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import golden, rel_err
+from diffdrr_amd._lib import SIDDON_AUX
+
+FWD_TOL = 1e-4    # north-star tolerance: image-normalised error vs the reference fp32
+GRAD_TOL = 1e-3
+
+
+def P(a):
+    return None if a is None else a.ctypes.data
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def load(name):
+    g = golden(name)
+    vol, src, tgt = f32(g["volume"]), f32(g["source"]), f32(g["target"])
+    B, N, _ = tgt.shape
+    return g, vol, src, tgt, f32(g["img_f32"].reshape(B, N)), B, N
+
+
+def emu_siddon(emu, vol, src, tgt, img, shift=0.5, red=0, lookup=0, align=0, aux=False,
+               cnt=False, det=(0, 0), tile=(1, 64)):
+    B, N, _ = tgt.shape
+    out = np.zeros((B, N), np.float32)
+    a = np.zeros((B, N, SIDDON_AUX), np.float32) if aux else None
+    c = np.zeros((B, N), np.int32) if cnt else None
+    emu.call("ddrr_siddon_forward", P(vol), *vol.shape, P(src), src.shape[1], P(tgt), P(img), B,
+             N, shift, 1e-8, red, lookup, align, det[0], det[1], tile[0], tile[1], P(out), P(a),
+             P(c), None)
+    return out, a, c
+
+
+@pytest.mark.parametrize("name,red,shift", [
+    ("siddon_sum", 0, 0.5), ("siddon_sum_oblique", 0, 0.5), ("siddon_max", 1, 0.5),
+    ("siddon_per_ray_source", 0, 0.5), ("siddon_shift0", 0, 0.0), ("siddon_stopgrad", 0, 0.5),
+])
+def test_siddon_forward_and_gradients(emu_lib, name, red, shift):
+    g, vol, src, tgt, img, B, N = load(name)
+    out, aux, _ = emu_siddon(emu_lib, vol, src, tgt, img, shift=shift, red=red, aux=True)
+    assert rel_err(out, g["out_f32"].reshape(B, N)) < FWD_TOL
+    # no worse than twice the reference's own fp32 error w.r.t. its fp64 run (+ slack)
+    ref_err = rel_err(g["out_f32"], g["out_f64"])
+    assert rel_err(out, g["out_f64"].reshape(B, N)) < 2 * ref_err + 5e-6
+    # without the aux record the result is bit-identical
+    out2, _, _ = emu_siddon(emu_lib, vol, src, tgt, img, shift=shift, red=red)
+    assert np.array_equal(out, out2)
+
+    go = f32(g["grad_out_f32"].reshape(B, N))
+    gs, gt = np.zeros((B, N, 3), np.float32), np.zeros((B, N, 3), np.float32)
+    gi = np.zeros((B, N), np.float32)
+    emu_lib.call("ddrr_siddon_backward_rays", P(aux), P(go), P(src), src.shape[1], P(tgt), P(img),
+                 B, N, 1e-8, red, P(gs), P(gt), P(gi), None)
+    gs = gs.sum(1, keepdims=True) if src.shape[1] == 1 else gs
+    assert rel_err(gs, g["g_source_f64"]) < GRAD_TOL
+    assert rel_err(gt, g["g_target_f64"]) < GRAD_TOL
+    if "g_img_f64" in g.files:
+        assert rel_err(gi, g["g_img_f64"].reshape(B, N)) < GRAD_TOL
+        gv = np.zeros_like(vol)
+        emu_lib.call("ddrr_siddon_backward_volume", P(vol), *vol.shape, P(src), src.shape[1],
+                     P(tgt), P(img), P(go), B, N, shift, 1e-8, red, 0, 0, 1, 64, P(gv), None)
+        assert rel_err(gv, g["g_volume_f64"]) < GRAD_TOL
+
+
+def test_siddon_special_rays(emu_lib):
+    g, vol, src, tgt, img, B, N = load("siddon_special_rays")
+    out, _, cnt = emu_siddon(emu_lib, vol, src, tgt, img, cnt=True)
+    assert rel_err(out, g["out_f64"].reshape(B, N)) < 1e-5
+    assert out[5, 0] == 0 and out[6, 0] == 0 and cnt[5, 0] == 0 and cnt[6, 0] == 0
+    # generic midpoint path agrees as well
+    out_mid, _, _ = emu_siddon(emu_lib, vol, src, tgt, img, lookup=1)
+    # ray 11 runs exactly inside an x-plane (x = 2.5): which of the two voxels a
+    # midpoint rounds to is decided by the 1e-8 eps, which fp32 cannot resolve; the
+    # midpoint path then makes the reference's fp32 choice, the stepping path its
+    # fp64 choice.  Every other ray is unambiguous.
+    keep = np.arange(B) != 11
+    assert rel_err(out_mid[keep], g["out_f64"].reshape(B, N)[keep]) < 1e-5
+    assert abs(out_mid[11, 0] - g["out_f32"].reshape(B, N)[11, 0]) < 1e-4
+
+
+@pytest.mark.parametrize("name,lookup,align", [
+    ("siddon_bilinear", 2, 0), ("siddon_align_corners", 1, 1), ("siddon_sum", 1, 0),
+    ("siddon_sum_oblique", 1, 0),
+])
+def test_siddon_generic_lookup(emu_lib, name, lookup, align):
+    g, vol, src, tgt, img, B, N = load(name)
+    out, _, _ = emu_siddon(emu_lib, vol, src, tgt, img, lookup=lookup, align=align)
+    assert rel_err(out, g["out_f32"].reshape(B, N)) < FWD_TOL
+
+
+def test_voxel_count_equals_oracle(emu_lib):
+    for name in ("siddon_sum", "siddon_sum_oblique"):
+        g, vol, src, tgt, img, B, N = load(name)
+        _, _, cnt = emu_siddon(emu_lib, vol, src, tgt, img, cnt=True)
+        ref = oracle.siddon(vol, src, tgt, img, count_voxels=True)["n_inside"]
+        # identical up to zero-length segments at exact ties
+        assert np.abs(cnt - ref).max() <= 1
+        assert abs(int(cnt.sum()) - int(ref.sum())) <= 0.002 * ref.sum() + 2
+
+
+def test_tile_map_is_result_invariant(emu_lib):
+    """Any detector tiling must give bit-identical images (it only permutes lanes)."""
+    rng = np.random.default_rng(0)
+    vol = f32(rng.random((10, 12, 9)))
+    H, W = 12, 20  # not multiples of every tile shape -> padding lanes
+    jj, ii = np.meshgrid(np.arange(W), np.arange(H))
+    tgt = np.stack([ii.ravel() * 0.9 - 0.5, np.full(H * W, 30.0), jj.ravel() * 0.45], -1)
+    tgt = f32(tgt[None])
+    src = f32(np.array([[[5.0, -40.0, 4.0]]]))
+    img = f32(np.linalg.norm(tgt - src, axis=-1))
+    base, _, _ = emu_siddon(emu_lib, vol, src, tgt, img)
+    for th, tw in [(64, 1), (32, 2), (16, 4), (8, 8), (4, 16), (2, 32), (1, 64)]:
+        out, _, _ = emu_siddon(emu_lib, vol, src, tgt, img, det=(H, W), tile=(th, tw))
+        assert np.array_equal(out, base), (th, tw)
+
+
+def test_siddon_channels(emu_lib):
+    g, vol, src, tgt, img, B, N = load("siddon_mask")
+    labels = np.ascontiguousarray(g["mask"].astype(np.uint8))
+    C = int(labels.max()) + 1
+    out = np.full((B, C, N), np.nan, np.float32)
+    emu_lib.call("ddrr_siddon_forward_channels", P(vol), P(labels), *vol.shape, P(src),
+                 src.shape[1], P(tgt), P(img), B, N, C, 0.5, 1e-8, 0, 0, 1, 64, P(out), None)
+    assert rel_err(out, g["out_f32"]) < FWD_TOL
+    plain, _, _ = emu_siddon(emu_lib, vol, src, tgt, img)
+    assert rel_err(out.sum(1), plain) < 1e-5  # channels add up to the DRR
+
+
+TRI = [
+    ("trilinear_global_range", 41, None, 0.5), ("trilinear_explicit_range", 64, (0.31, 0.77), 0.5),
+    ("trilinear_oblique", 50, None, 0.5), ("trilinear_shift0", 40, None, 0.0),
+]
+
+
+@pytest.mark.parametrize("name,npts,rng,shift", TRI)
+def test_trilinear_forward_and_gradients(emu_lib, name, npts, rng, shift):
+    g, vol, src, tgt, img, B, N = load(name)
+    if rng is None:
+        lo, hi = oracle.alpha_minmax(src, tgt, vol.shape, voxel_shift=shift)
+        rng = (lo.min(), hi.max())
+    am, aM = np.array([rng[0]], np.float32), np.array([rng[1]], np.float32)
+    out = np.zeros((B, N), np.float32)
+    emu_lib.call("ddrr_trilinear_forward", P(vol), *vol.shape, P(src), src.shape[1], P(tgt),
+                 P(img), B, N, shift, 1e-8, npts, P(am), P(aM), 0, 0, 0, 0, 0, 1, 64, P(out), None)
+    assert rel_err(out, g["out_f32"].reshape(B, N)) < FWD_TOL
+
+    go = f32(g["grad_out_f32"].reshape(B, N))
+    ref = oracle.trilinear(vol.astype(np.float64), src.astype(np.float64), tgt.astype(np.float64),
+                           img.astype(np.float64), n_points=npts, alphamin=float(am[0]),
+                           alphamax=float(aM[0]), voxel_shift=shift,
+                           grad_out=go.astype(np.float64), want_volume_grad=True)
+    gs, gt = np.zeros((B, N, 3), np.float32), np.zeros((B, N, 3), np.float32)
+    gi, ga = np.zeros((B, N), np.float32), np.zeros((B, N, 2), np.float32)
+    gv = np.zeros_like(vol)
+    emu_lib.call("ddrr_trilinear_backward", P(vol), *vol.shape, P(src), src.shape[1], P(tgt),
+                 P(img), P(go), B, N, shift, 1e-8, npts, P(am), P(aM), 0, 0, 0, 0, 1, 64, P(gs),
+                 P(gt), P(gi), P(ga), P(gv), None)
+    assert rel_err(gs.sum(1, keepdims=True), ref["g_source"]) < GRAD_TOL
+    assert rel_err(gt, ref["g_target"]) < GRAD_TOL
+    assert rel_err(gi, ref["g_img"].reshape(B, N)) < GRAD_TOL
+    assert rel_err(gv, ref["g_volume"]) < GRAD_TOL
+    assert abs(ga[..., 0].sum() / ref["g_alphamin"] - 1) < GRAD_TOL
+    assert abs(ga[..., 1].sum() / ref["g_alphamax"] - 1) < GRAD_TOL
+    assert rel_err(gv, g["g_volume_f64"]) < GRAD_TOL  # and the reference's own autograd
+
+
+def test_trilinear_nearest_max(emu_lib):
+    g, vol, src, tgt, img, B, N = load("trilinear_nearest_max")
+    lo, hi = oracle.alpha_minmax(src, tgt, vol.shape)
+    am, aM = np.array([lo.min()], np.float32), np.array([hi.max()], np.float32)
+    out = np.zeros((B, N), np.float32)
+    emu_lib.call("ddrr_trilinear_forward", P(vol), *vol.shape, P(src), src.shape[1], P(tgt),
+                 P(img), B, N, 0.5, 1e-8, 33, P(am), P(aM), 1, 1, 0, 0, 0, 1, 64, P(out), None)
+    assert rel_err(out, g["out_f32"].reshape(B, N)) < FWD_TOL

@@ -1,0 +1,233 @@
+"""The PyTorch-side mirror of the reference's API (pose, Detector, DRR,
+Registration, NCC) against goldens produced by the unmodified reference.  DRR
+rendering runs through the host emulation of the kernel cores (conftest
+``emulated_ops``): this checks the Python / autograd wiring on CPU; the same
+module is checked on the real kernels in test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_err
+from diffdrr_amd import DRR, Detector, Registration, RigidTransform, convert
+from diffdrr_amd import pose as P
+from diffdrr_amd.data import Image, Subject, make_subject
+from diffdrr_amd.metrics import NormalizedCrossCorrelation2d
+
+T = torch.from_numpy
+
+
+# ------------------------------------------------------------------- pose
+
+POSE_CASES = ["axis_angle", "euler_angles", "euler_angles_deg", "quaternion", "rotation_6d",
+              "rotation_9d", "rotation_10d", "quaternion_adjugate", "se3_log_map"]
+POSE_KW = {"euler_angles": {"convention": "ZXY"},
+           "euler_angles_deg": {"convention": "XYZ", "degrees": True}}
+
+
+@pytest.mark.parametrize("name", POSE_CASES)
+def test_convert_matches_reference(name):
+    g = golden("pose")
+    param = "euler_angles" if name.startswith("euler") else name
+    kw = POSE_KW.get(name, {})
+    Tm = convert(T(g[name + "_in"]), T(g["translation"]), parameterization=param, **kw)
+    ref = g[name + "_matrix"]
+    if name == "rotation_10d":
+        # eigenvector sign is arbitrary, but q and -q are the same rotation
+        assert rel_err(Tm.matrix.numpy(), ref) < 1e-4
+    else:
+        assert rel_err(Tm.matrix.numpy(), ref) < 1e-5
+    # round trip: parameters recovered from the matrix rebuild the same matrix
+    back_kw = {"convention": kw["convention"]} if param == "euler_angles" else {}
+    rot, xyz = Tm.convert(param, **back_kw)
+    T2 = convert(rot, xyz, parameterization=param, **back_kw)
+    assert rel_err(T2.matrix.numpy(), ref) < 1e-4
+    assert rel_err(xyz.numpy(), g[name + "_back_xyz"]) < 1e-4
+    if param in ("euler_angles", "axis_angle", "rotation_6d", "se3_log_map"):
+        assert rel_err(rot.numpy(), g[name + "_back_rot"]) < 1e-4
+
+
+def test_rigid_transform_algebra():
+    g = golden("pose")
+    t = T(g["translation"])
+    A = convert(T(g["euler_angles_in"]), t, parameterization="euler_angles", convention="ZXY")
+    B = convert(T(g["axis_angle_in"]), -t, parameterization="axis_angle")
+    assert rel_err(A(T(g["apply_pts"])).numpy(), g["apply_out"]) < 1e-5
+    assert rel_err(A.compose(B).matrix.numpy(), g["compose_matrix"]) < 1e-5
+    assert rel_err(A.inverse().matrix.numpy(), g["inverse_matrix"]) < 1e-5
+    assert len(A) == 4 and A[1:3].matrix.shape == (2, 4, 4)
+    assert RigidTransform(A) is A
+    with pytest.raises(ValueError):
+        convert(t, t, parameterization="euler_angles")
+    with pytest.raises(ValueError):
+        convert(t, t, parameterization="nope")
+
+
+@pytest.mark.parametrize("convention", ["XYZ", "XZY", "YXZ", "YZX", "ZXY", "ZYX",
+                                        "XYX", "XZX", "YXY", "YZY", "ZXZ", "ZYZ"])
+def test_euler_round_trip_all_conventions(convention):
+    g = torch.Generator().manual_seed(3)
+    a = (torch.rand(16, 3, generator=g) - 0.5) * 2.0
+    if convention[0] == convention[2]:
+        a[:, 1] = a[:, 1].abs() + 0.1  # proper Euler: middle angle in (0, pi)
+    R = P.euler_angles_to_matrix(a, convention)
+    assert torch.allclose(P.matrix_to_euler_angles(R, convention), a, atol=1e-5)
+    assert torch.allclose(R @ R.mT, torch.eye(3).expand(16, 3, 3), atol=1e-5)
+
+
+# --------------------------------------------------------------- detector
+
+def _subject_a(g, with_mask=True):
+    vol = T(g["volume"])
+    mask = Image(T(g["mask"]).unsqueeze(0), g["affine"]) if with_mask else None
+    return Subject(Image(vol.unsqueeze(0), g["affine"]), Image(vol.unsqueeze(0), g["affine"]),
+                   T(g["reorient"]), mask)
+
+
+def _geo(g, prefix="geo_"):
+    keys = [k for k in g.files if k.startswith(prefix)]
+    geo = {k[len(prefix):]: g[k].item() for k in keys}
+    for k in ("height", "width"):
+        if k in geo:
+            geo[k] = int(geo[k])
+    return geo
+
+
+def test_detector_rays_match_reference():
+    g = golden("drr_module")
+    geo = _geo(g)
+    det = Detector(geo["sdd"], geo["height"], geo["width"], geo["delx"], geo["dely"], geo["x0"],
+                   geo["y0"], T(g["reorient"]), reverse_x_axis=True)
+    pose = convert(T(g["rot"]), T(g["xyz"]), parameterization="euler_angles", convention="ZXY")
+    assert rel_err(pose.matrix.numpy(), g["pose_matrix_f32"]) < 1e-6
+    source, target = det(pose, None)
+    assert source.shape == (3, 1, 3) and target.shape == (3, geo["height"] * geo["width"], 3)
+    assert rel_err(source.numpy(), g["det_source_f32"]) < 1e-6
+    assert rel_err(target.numpy(), g["det_target_f32"]) < 1e-6
+    assert abs(det.x0 + geo["x0"]) < 1e-6 and abs(det.sdd - geo["sdd"]) < 1e-4
+
+    # odd-sized detector, reverse_x_axis=False, PA orientation
+    geo2 = _geo(g, "b_geo_")
+    det2 = Detector(geo2["sdd"], geo2["height"], geo2["width"], geo2["delx"], geo2["delx"], 0.0,
+                    0.0, T(g["b_reorient"]), reverse_x_axis=False)
+    pose2 = convert(T(g["b_rot"]), T(g["b_xyz"]), parameterization="euler_angles",
+                    convention="ZXY")
+    s2, t2 = det2(pose2, None)
+    assert rel_err(s2.numpy(), g["b_det_source"]) < 1e-6
+    assert rel_err(t2.numpy(), g["b_det_target"]) < 1e-6
+
+
+# -------------------------------------------------------------------- DRR
+
+@pytest.mark.parametrize("renderer,kw", [("siddon", {}), ("trilinear", {"n_points": 60})])
+def test_drr_module_matches_reference(emulated_ops, renderer, kw):
+    g = golden("drr_module")
+    drr = DRR(_subject_a(g), renderer=renderer, **_geo(g))
+    rot = T(g["rot"]).clone().requires_grad_()
+    xyz = T(g["xyz"]).clone().requires_grad_()
+    img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY", **kw)
+    assert img.shape == g[f"{renderer}_img_f32"].shape  # (B, 1, H, W)
+    assert rel_err(img.detach().numpy(), g[f"{renderer}_img_f32"]) < 1e-4
+    assert rel_err(img.detach().numpy(), g[f"{renderer}_img_f64"]) < 1e-4
+    img.backward(T(g[f"{renderer}_grad_out_f32"]))
+    assert rel_err(rot.grad.numpy(), g[f"{renderer}_g_rot_f64"]) < 1e-3
+    assert rel_err(xyz.grad.numpy(), g[f"{renderer}_g_xyz_f64"]) < 1e-3
+
+
+def test_drr_mask_to_channels_and_patches(emulated_ops):
+    g = golden("drr_module")
+    geo = _geo(g)
+    drr = DRR(_subject_a(g), **geo)
+    rot, xyz = T(g["rot"]), T(g["xyz"])
+    with torch.no_grad():
+        ch = drr(rot, xyz, parameterization="euler_angles", convention="ZXY",
+                 mask_to_channels=True)
+        plain = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    assert ch.shape == g["siddon_channels_f32"].shape
+    assert rel_err(ch.numpy(), g["siddon_channels_f32"]) < 1e-4
+    assert rel_err(ch.sum(1, keepdim=True).numpy(), plain.numpy()) < 1e-5
+    drr_p = DRR(_subject_a(g), patch_size=2, **geo)
+    with torch.no_grad():
+        patched = drr_p(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    assert rel_err(patched.numpy(), g["siddon_patched_f32"]) < 1e-4
+    assert torch.equal(patched, plain)  # Siddon is per-ray independent: exact
+
+
+def test_drr_odd_detector_pa(emulated_ops):
+    g = golden("drr_module")
+    vol = T(g["b_volume"])
+    subject = Subject(Image(vol.unsqueeze(0), g["b_affine"]), Image(vol.unsqueeze(0), g["b_affine"]),
+                      T(g["b_reorient"]))
+    drr = DRR(subject, reverse_x_axis=False, **_geo(g, "b_geo_"))
+    pose = convert(T(g["b_rot"]), T(g["b_xyz"]), parameterization="euler_angles",
+                   convention="ZXY")
+    with torch.no_grad():
+        img = drr(pose)
+    assert rel_err(img.numpy(), g["b_img"]) < 1e-4
+
+
+def test_drr_api_surface(emulated_ops):
+    subject = make_subject(torch.rand(8, 9, 10), spacing=(1.0, 2.0, 1.5))
+    drr = DRR(subject, sdd=100.0, height=6, width=4, delx=2.0, p_subsample=0.5)
+    assert drr.detector.n_subsample == 12 and drr.device.type == "cpu"
+    assert drr.dtype == torch.float32 and drr.affine.matrix.shape == (1, 4, 4)
+    rot, xyz = torch.zeros(2, 3), torch.tensor([[0.0, 60.0, 0.0]] * 2)
+    with torch.no_grad():
+        img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    assert img.shape == (2, 1, 6, 4) and (img != 0).sum() <= 24
+    drr.set_intrinsics_(height=5, width=7, n_subsample=None)
+    assert (drr.detector.height, drr.detector.width) == (5, 7)
+    drr.rescale_detector_(2.0)
+    assert drr.detector.height == 10 and abs(drr.detector.delx - 1.0) < 1e-6
+    with pytest.raises(ValueError):
+        DRR(subject, sdd=1.0, height=2, delx=1.0, renderer="nope")
+    with pytest.raises(ValueError):
+        DRR(subject, sdd=1.0, height=2, delx=1.0, reducefn="median")(
+            rot, xyz, parameterization="euler_angles", convention="ZXY")
+    # projection helpers are inverse of each other on the detector plane
+    drr2 = DRR(subject, sdd=100.0, height=6, delx=2.0)
+    pose = convert(rot[:1], xyz[:1], parameterization="euler_angles", convention="ZXY")
+    px = torch.tensor([[[1.0, 2.0], [4.0, 3.0]]])
+    world = drr2.inverse_projection(pose, px.clone())
+    assert torch.allclose(drr2.perspective_projection(pose, world), px, atol=1e-3)
+
+
+# ----------------------------------------------------------- registration
+
+def test_ncc_matches_reference():
+    g = golden("registration")
+    a, b = T(g["ncc_a"]), T(g["ncc_b"])
+    assert rel_err(NormalizedCrossCorrelation2d()(a, b).numpy(), g["ncc_ab"]) < 1e-5
+    assert rel_err(NormalizedCrossCorrelation2d(patch_size=5)(a, b).numpy(),
+                   g["ncc_ab_patch5"]) < 1e-5
+
+
+@pytest.mark.parametrize("stop", [False, True])
+def test_registration_trajectory_matches_reference(emulated_ops, stop):
+    """First SGD steps of the tutorial's registration loop: same losses and the
+    same parameter trajectory as the reference (registration.ipynb:240-316)."""
+    g = golden("registration")
+    vol = T(g["volume"])
+    subject = Subject(Image(vol.unsqueeze(0), g["affine"]), Image(vol.unsqueeze(0), g["affine"]),
+                      T(g["reorient"]))
+    geo = _geo(g)
+    drr = DRR(subject, stop_gradients_through_grid_sample=stop, **geo)
+    gt = T(g["gt"])
+    with torch.no_grad():
+        mine = drr(T(g["true_rot"]), T(g["true_xyz"]), parameterization="euler_angles",
+                   convention="ZXY")
+    assert rel_err(mine.numpy(), g["gt"]) < 1e-4
+    reg = Registration(drr, T(g["rot0"]).clone(), T(g["xyz0"]).clone(),
+                       parameterization="euler_angles", convention="ZXY")
+    crit = NormalizedCrossCorrelation2d()
+    opt = torch.optim.SGD([{"params": [reg._rotation], "lr": 5e-2},
+                           {"params": [reg._translation], "lr": 1e2}], maximize=True)
+    tag = "stop" if stop else "full"
+    for k in range(len(g[f"losses_{tag}"])):
+        opt.zero_grad()
+        loss = crit(gt, reg()).mean()
+        loss.backward()
+        assert abs(loss.item() - g[f"losses_{tag}"][k]) < 2e-3, (k, loss.item())
+        assert rel_err(reg._rotation.detach().numpy(), g[f"rots_{tag}"][k]) < 2e-2
+        assert rel_err(reg._translation.detach().numpy(), g[f"xyzs_{tag}"][k]) < 2e-3
+        opt.step()
+    assert g[f"losses_{tag}"][-1] > g[f"losses_{tag}"][0]  # the reference itself improves
