@@ -26,7 +26,7 @@
 namespace ddrr {
 
 struct SiddonSetup {
-    float d[3], inv[3], c[3], lo[3];
+    float d[3], inv[3], c[3], lo[3], hi[3];
     float entry, exit;
     bool hit;
 };
@@ -41,12 +41,13 @@ DDRR_HD SiddonSetup siddon_setup(const Dims D, const float s[3], const float t[3
     for (int a = 0; a < 3; ++a) {
         q.d[a] = (t[a] - s[a]) + eps;  // renderers.py:104-106, :148
         q.inv[a] = 1.0f / q.d[a];
-        q.c[a] = (-shift - s[a]) * q.inv[a];
+        q.c[a] = (-shift - s[a]) / q.d[a];  // a true division: half an ulp, once per ray
         const float a0 = q.c[a];
         const float aD = fmaf((float)Dn[a], q.inv[a], q.c[a]);
         q.lo[a] = fminf(a0, aD);
+        q.hi[a] = fmaxf(a0, aD);
         q.entry = fmaxf(q.entry, q.lo[a]);
-        q.exit = fminf(q.exit, fmaxf(a0, aD));
+        q.exit = fminf(q.exit, q.hi[a]);
     }
     q.hit = q.entry < q.exit;  // false for NaN
     return q;

@@ -117,6 +117,29 @@ def siddon_forward(volume, source, target, img, *, voxel_shift=0.5, eps=1e-8, re
     return out, aux, nvox
 
 
+def siddon_forward_slab(volume, source, target, img, det, plan, shear, *, voxel_shift=0.5,
+                        eps=1e-8, want_aux=False):
+    """Detector-grid Siddon (sum) through the lockstep slab-march kernel.
+    plan (B,2) int32 / shear (B,S) fp32 from diffdrr_amd.plan.slab_plan.
+    -> (out (B,N), aux (B,N,8) | None)"""
+    B, N = _check_rays(volume, source, target, img)
+    H, W = int(det[0]), int(det[1])
+    if H * W != N or source.shape[1] != 1:
+        raise ValueError("the slab path needs one source per pose and an H*W ray grid")
+    volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    out = torch.empty(B, N, dtype=torch.float32, device=volume.device)
+    aux = torch.empty(B, N, SIDDON_AUX, dtype=torch.float32, device=volume.device) \
+        if want_aux else None
+    if _empty(B, N):
+        return out, aux
+    _launch(
+        "ddrr_siddon_forward_slab", volume.device, volume.data_ptr(), *volume.shape,
+        source.data_ptr(), target.data_ptr(), _ptr(img), B, H, W, float(voxel_shift), float(eps),
+        plan.data_ptr(), shear.data_ptr(), int(shear.shape[1]), out.data_ptr(), _ptr(aux))
+    return out, aux
+
+
 def siddon_backward_rays(aux, grad_out, source, target, img, *, eps=1e-8, reducefn="sum",
                          want_img_grad=True):
     """-> (g_source (B,N,3) per ray, g_target (B,N,3), g_img (B,N) | None)"""

@@ -18,6 +18,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
+from .plan import slab_plan
 
 
 def _labels_u8(mask: torch.Tensor):
@@ -45,10 +46,22 @@ class _SiddonFn(torch.autograd.Function):
     def forward(ctx, volume, source, target, img, cfg):
         need_rays = any(ctx.needs_input_grad[1:4])
         want_aux = bool(need_rays and cfg["lookup"] == "step")
-        out, aux, _ = ops.siddon_forward(
-            volume, source, target, img, voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
-            reducefn=cfg["reducefn"], lookup=cfg["lookup"], align_corners=cfg["align_corners"],
-            want_aux=want_aux, det=cfg["det"], tile=cfg["tile"])
+        N = target.shape[1]
+        slab = (cfg["lookup"] == "step" and cfg["reducefn"] == "sum" and cfg["det"] is not None
+                and cfg["det"][0] * cfg["det"][1] == N and source.shape[1] == 1
+                and min(cfg["det"]) >= 2 and cfg["slab"])
+        if slab:
+            # detector-grid fast path: lockstep slab march, z-epipolar wave composition
+            plan, shear = slab_plan(source, target, *cfg["det"])
+            out, aux = ops.siddon_forward_slab(
+                volume, source, target, img, cfg["det"], plan, shear,
+                voxel_shift=cfg["voxel_shift"], eps=cfg["eps"], want_aux=want_aux)
+        else:
+            out, aux, _ = ops.siddon_forward(
+                volume, source, target, img, voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
+                reducefn=cfg["reducefn"], lookup=cfg["lookup"],
+                align_corners=cfg["align_corners"], want_aux=want_aux, det=cfg["det"],
+                tile=cfg["tile"])
         ctx.cfg = cfg
         ctx.has_aux = want_aux
         ctx.save_for_backward(volume, source, target, img, aux if want_aux else None)
@@ -111,6 +124,7 @@ class Siddon(torch.nn.Module):
         # performance hints set by DRR (detector grid of the rays; wave tile shape)
         self.detector_shape = None
         self.tile = None
+        self.use_slab_march = True  # detector-grid fast path (same results; see slab_core.h)
 
     def dims(self, volume):
         return torch.tensor(volume.shape).to(volume)
@@ -126,7 +140,7 @@ class Siddon(torch.nn.Module):
         return {"voxel_shift": self.voxel_shift, "eps": self.eps, "reducefn": self.reducefn,
                 "lookup": lookup, "align_corners": bool(align_corners),
                 "stop_gradients": self.stop_gradients_through_grid_sample,
-                "det": self.detector_shape, "tile": self.tile}
+                "det": self.detector_shape, "tile": self.tile, "slab": self.use_slab_march}
 
     def forward(self, volume, source, target, img, align_corners=False, mask=None):
         B, N, _ = target.shape

@@ -68,6 +68,19 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
                         int align_corners, int det_h, int det_w, int tile_h, int tile_w,
                         float *out, float *aux, int *n_vox, void *stream);
 
+/* The fast form of ddrr_siddon_forward for the DRR case (sum, nearest,
+ * align_corners=False, one source per pose, the N = det_h * det_w rays of a pose
+ * being a row-major detector grid, detector.py:126): lockstep slab march with
+ * z-epipolar wave composition.  plan (B, 2) int32: {march axis 0|1, or 2 = use the
+ * generic walk; major 0|1}; shear (B, max_strips) fp32: slope of the epipolar lines
+ * per 64-pixel strip (diffdrr_amd/plan.py computes both on the device).  plan and
+ * shear only steer scheduling: the result equals ddrr_siddon_forward's up to fp32
+ * summation order.  aux as in ddrr_siddon_forward. */
+int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const float *source,
+                             const float *target, const float *img, int B, int det_h, int det_w,
+                             float voxel_shift, float eps, const int *plan, const float *shear,
+                             int max_strips, float *out, float *aux, void *stream);
+
 /* Pose/ray gradients of ddrr_siddon_forward from its aux record: what autograd
  * of renderers.py:94-113 + :70-71 returns.  g_source is per ray (B, N, 3) (sum
  * over rays for a broadcast source); g_target (B, N, 3); g_img (B, N), the

@@ -14,6 +14,7 @@
 
 #include "../../diffdrr_amd/csrc/ddrr_common.h"
 #include "../../diffdrr_amd/csrc/siddon_core.h"
+#include "../../diffdrr_amd/csrc/slab_core.h"
 #include "../../diffdrr_amd/csrc/trilinear_core.h"
 #include "../../include/diffdrr_hip.h"
 
@@ -52,6 +53,10 @@ void for_each_ray(const float *source, int src_n, const float *target, const flo
         if (seen[i] != 1) abort();  // the tile map must be a bijection
 }
 
+// Scheduling statistics of the emulated slab kernel (development aid): distinct
+// 128-byte lines a wave touches per iteration vs. voxels it actually needs.
+double g_stat_lines = 0, g_stat_voxels = 0, g_stat_iters = 0, g_stat_slow = 0;
+
 struct HostAdd {
     float *base;
     void operator()(unsigned off, float v) const { base[off] += v; }
@@ -65,6 +70,13 @@ struct NoAdd {
 extern "C" {
 
 int ddrr_abi_version(void) { return DDRR_ABI_VERSION; }
+void emu_stats(double *o, int reset) {
+    o[0] = g_stat_lines;
+    o[1] = g_stat_voxels;
+    o[2] = g_stat_iters;
+    o[3] = g_stat_slow;
+    if (reset) g_stat_lines = g_stat_voxels = g_stat_iters = g_stat_slow = 0;
+}
 const char *ddrr_last_error(void) { return ""; }
 
 int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float *source,
@@ -110,6 +122,131 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
                      if (aux) memcpy(aux + r * SIDDON_AUX, rec, sizeof(rec));
                      if (n_vox) n_vox[r] = cnt;
                  });
+    return 0;
+}
+
+// Wave-level emulation of siddon_fwd_slab_kernel: 64 lane states advanced in
+// lockstep, ballots / reductions done with plain loops.
+int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const float *source,
+                             const float *target, const float *img, int B, int det_h, int det_w,
+                             float voxel_shift, float eps, const int *plan, const float *shear,
+                             int max_strips, float *out, float *aux, void *) {
+    const Dims D{dx, dy, dz};
+    const int N = det_h * det_w;
+    const ShearMap sm = make_shearmap(det_h, det_w);
+    std::vector<char> seen((size_t)B * N, 0);
+    for (int b = 0; b < B; ++b)
+        for (int w = 0; w < sm.waves_per_pose; ++w) {
+            const int march = plan[2 * b], major = plan[2 * b + 1];
+            const int strip = shear_strip_of(sm, major, w);
+            if (strip >= shear_strips(sm, major)) continue;
+            const float sigma = shear[b * max_strips + strip];
+            int n[64];
+            float s[64][3], t[64][3];
+            for (int l = 0; l < 64; ++l) {
+                n[l] = shear_ray(sm, major, w, l, sigma);
+                const long r = (long)b * N + (n[l] < 0 ? 0 : n[l]);
+                if (n[l] >= 0) seen[r]++;
+                for (int a = 0; a < 3; ++a) {
+                    s[l][a] = source[b * 3 + a];
+                    t[l][a] = target[r * 3 + a];
+                }
+            }
+            float I[64], rec[64][SIDDON_AUX];
+            memset(rec, 0, sizeof(rec));
+            if (march > 1) {
+                for (int l = 0; l < 64; ++l)
+                    I[l] = n[l] < 0 ? 0.f
+                           : aux  ? siddon_forward_ray<REDUCE_SUM, true, false>(
+                                        volume, D, s[l], t[l], voxel_shift, eps, rec[l], nullptr)
+                                  : siddon_forward_ray<REDUCE_SUM, false, false>(
+                                        volume, D, s[l], t[l], voxel_shift, eps, rec[l], nullptr);
+            } else {
+                const SlabAxes ax = make_slab_axes(D, march);
+                SlabLane L[64];
+                int nfast = 0, npos = 0;
+                for (int l = 0; l < 64; ++l) {
+                    L[l] = slab_lane_init(D, ax, s[l], t[l], voxel_shift, eps);
+                    if (n[l] < 0) {
+                        L[l].hit = false;
+                        L[l].fast = false;
+                        L[l].done = true;
+                    }
+                    nfast += L[l].fast;
+                    npos += L[l].fast && L[l].dirf_m > 0.f;
+                }
+                const int dirw = 2 * npos >= nfast ? 1 : -1;
+                int kmin = 0x7fffffff, key[64];
+                for (int l = 0; l < 64; ++l) {
+                    L[l].fast = L[l].fast && ((L[l].dirf_m > 0.f) == (dirw > 0));
+                    key[l] = L[l].fast ? L[l].im_in * dirw : 0x7fffffff;
+                    kmin = key[l] < kmin ? key[l] : kmin;
+                }
+                const int cap = ax.Dm + 2;
+                for (int it = 0; it < cap; ++it) {
+                    SlabGeo g[64];
+                    bool anycx = false, anylive = false;
+                    for (int l = 0; l < 64; ++l) {
+                        const bool active = L[l].fast && !L[l].done && it >= key[l] - kmin;
+                        g[l] = slab_geometry(L[l], ax, active);
+                        anycx = anycx || g[l].cx;
+                    }
+                    {   // statistics: distinct 128 B lines among the lanes that need data
+                        unsigned lines[256];
+                        int nl = 0;
+                        bool any = false;
+                        for (int l = 0; l < 64; ++l) {
+                            const bool need = g[l].l0 != 0.f || g[l].l1 != 0.f || g[l].l2 != 0.f;
+                            if (!need) continue;
+                            any = true;
+                            g_stat_voxels += (g[l].l0 > 0.f) + (g[l].l1 > 0.f) + (g[l].l2 > 0.f);
+                            unsigned cand[4] = {g[l].offA >> 7, (g[l].offA + 7) >> 7,
+                                                g[l].offB >> 7, (g[l].offB + 7) >> 7};
+                            for (int c = 0; c < (g[l].cx ? 4 : 2); ++c) {
+                                bool dup = false;
+                                for (int k = 0; k < nl; ++k) dup = dup || lines[k] == cand[c];
+                                if (!dup) lines[nl++] = cand[c];
+                            }
+                        }
+                        g_stat_lines += nl;
+                        g_stat_iters += any;
+                    }
+                    for (int l = 0; l < 64; ++l) {
+                        const float *pa = (const float *)((const char *)volume + g[l].offA);
+                        const float *pb = (const float *)((const char *)volume + g[l].offB);
+                        const float b0 = anycx ? pb[0] : 0.f, b1 = anycx ? pb[1] : 0.f;
+                        if (aux)
+                            slab_consume<true>(L[l], g[l], pa[0], pa[1], b0, b1);
+                        else
+                            slab_consume<false>(L[l], g[l], pa[0], pa[1], b0, b1);
+                        anylive = anylive || (L[l].fast && !L[l].done);
+                    }
+                    if (!anylive) break;
+                }
+                for (int l = 0; l < 64; ++l) {
+                    if (L[l].fast) {
+                        I[l] = L[l].acc;
+                        if (aux) slab_aux_record(L[l], ax, rec[l]);
+                    } else if (L[l].hit) {
+                        g_stat_slow += 1;
+                        I[l] = aux ? siddon_forward_ray<REDUCE_SUM, true, false>(
+                                         volume, D, s[l], t[l], voxel_shift, eps, rec[l], nullptr)
+                                   : siddon_forward_ray<REDUCE_SUM, false, false>(
+                                         volume, D, s[l], t[l], voxel_shift, eps, rec[l], nullptr);
+                    } else {
+                        I[l] = 0.f;
+                    }
+                }
+            }
+            for (int l = 0; l < 64; ++l) {
+                if (n[l] < 0) continue;
+                const long r = (long)b * N + n[l];
+                out[r] = (img ? img[r] : 1.f) * I[l];
+                if (aux) memcpy(aux + r * SIDDON_AUX, rec[l], sizeof(rec[l]));
+            }
+        }
+    for (size_t i = 0; i < seen.size(); ++i)
+        if (seen[i] != 1) abort();  // the shear map must be a bijection
     return 0;
 }
 

@@ -201,10 +201,13 @@ def test_siddon_vs_oracle_medium(gpu, D, det, delx, B, kind):
     # The exact base pose is a measure-zero case for GRADIENTS: the source sits on the
     # volume's symmetry axis, so diagonal pixels cross x- and z-planes at identical alphas
     # and the reference's gradient depends on torch.sort's tie order.
-    # Nudge it; the forward image at the exact base pose is checked in
+    # Poses within a few hundredths of a radian of it still have many crossings closer
+    # than fp32 resolves, where the kernel (alpha = fma(k, 1/d, c)) flips somewhat more
+    # often than the reference (alpha = (plane - s)/d); see DESIGN.md "gradient noise".
+    # Use a clearly generic pose; the forward image at the exact base pose is checked in
     # test_siddon_base_pose_forward.
-    rot[0] += torch.tensor([0.013, -0.021, 0.017], device=gpu)
-    xyz[0] += torch.tensor([0.37, 0.0, -0.23], device=gpu)
+    rot[0] += torch.tensor([0.13, -0.21, 0.17], device=gpu)
+    xyz[0] += torch.tensor([3.7, 0.0, -2.3], device=gpu)
     rot.requires_grad_()
     xyz.requires_grad_()
     img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
@@ -292,14 +295,16 @@ def test_full_size_constant_volume_gives_chord_length(gpu, big):
     assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5
     hit = ref > 0
     assert (nvox[hit] >= 1).all() and int(nvox.max()) <= 3 * 512
+    # (the detector plane of this scene lies INSIDE the 512^3 volume: the marcher's
+    # default [0, 1] range would stop at the target, Siddon integrates the whole line)
     tri = ops.trilinear_forward(ones, s, t, L, torch.tensor(0.0, device=gpu),
-                                torch.tensor(1.0, device=gpu), n_points=2048, det=(256, 256))
+                                torch.tensor(1.5, device=gpu), n_points=3072, det=(256, 256))
     # Trilinear of a box ramps 0 -> 1 over one voxel at each face (zeros padding), which is
     # chord-preserving only for rays that cross faces transversally: check the central
     # 64x64 pixels of the base pose (pose 0), rectangular rule => a couple of steps.
     c = torch.arange(96, 160, device=gpu)
     centre = (c[:, None] * 256 + c[None, :]).reshape(-1)
-    step_len = L[0, centre] / 2047
+    step_len = 1.5 * L[0, centre] / 3071
     assert ((tri[0, centre] - ref[0, centre].float()).abs() <= 2.5 * step_len + 1e-3).all()
 
 
@@ -361,21 +366,76 @@ def test_pose_gradient_matches_fp64_chain(gpu):
     (drr(r, x, parameterization="euler_angles", convention="ZXY") * W).sum().backward()
 
     drr64 = copy.deepcopy(drr).cpu().double()
-    r64 = rot.cpu().double().requires_grad_()
-    x64 = xyz.cpu().double().requires_grad_()
-    pose = convert(r64, x64, parameterization="euler_angles", convention="ZXY")
-    source, target = drr64.detector(pose, None)
-    L = (target - source).norm(dim=-1)
-    s, t = drr64.affine_inverse(source), drr64.affine_inverse(target)
     g = W.cpu().double().reshape(1, -1).expand(2, -1).numpy()
-    o = oracle.siddon(drr64.density.numpy(), s.detach().numpy(), t.detach().numpy(),
-                      L.detach().numpy(), grad_out=g)
-    surrogate = ((torch.from_numpy(o["g_source"]) * s).sum()
-                 + (torch.from_numpy(o["g_target"]) * t).sum()
-                 + (torch.from_numpy(o["g_img"]).reshape(L.shape) * L).sum())
-    surrogate.backward()
-    assert rel_err(r.grad.cpu().numpy(), r64.grad.numpy()) < 5e-3
-    assert rel_err(x.grad.cpu().numpy(), x64.grad.numpy()) < 5e-3
+
+    def chain(ray_grads):
+        r64 = rot.cpu().double().requires_grad_()
+        x64 = xyz.cpu().double().requires_grad_()
+        pose = convert(r64, x64, parameterization="euler_angles", convention="ZXY")
+        source, target = drr64.detector(pose, None)
+        L = (target - source).norm(dim=-1)
+        s, t = drr64.affine_inverse(source), drr64.affine_inverse(target)
+        o = ray_grads(s.detach().numpy(), t.detach().numpy(), L.detach().numpy())
+        as64 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64))  # noqa: E731
+        surrogate = ((as64(o["g_source"]) * s).sum() + (as64(o["g_target"]) * t).sum()
+                     + (as64(o["g_img"]).reshape(L.shape) * L).sum())
+        surrogate.backward()
+        return r64.grad.numpy(), x64.grad.numpy()
+
+    vol64 = drr64.density.numpy()
+    truth_r, truth_x = chain(lambda s, t, L: oracle.siddon(vol64, s, t, L, grad_out=g))
+    # the reference's fp32 arithmetic on the same rays (fp32 oracle), chained exactly:
+    # the rotation gradient is a small difference of large source/target terms and loses
+    # ~2 digits to the fp32 rounding of the ray endpoints alone
+    f32 = lambda a: a.astype(np.float32)  # noqa: E731
+    ref_r, ref_x = chain(lambda s, t, L: oracle.siddon(f32(vol64), f32(s), f32(t), f32(L),
+                                                       grad_out=f32(g)))
+    assert rel_err(r.grad.cpu().numpy(), truth_r) < 2 * rel_err(ref_r, truth_r) + 2e-3
+    assert rel_err(x.grad.cpu().numpy(), truth_x) < 2 * rel_err(ref_x, truth_x) + 2e-3
+
+
+def test_slab_march_equals_generic_walk(gpu, big):
+    """The detector-grid fast path (lockstep slab march, csrc/slab_core.h) against the
+    per-crossing walk on the same rays: same image, same backward record."""
+    from diffdrr_amd.plan import slab_plan
+
+    drr, s, t, L = big
+    V = drr.density
+    ref, aux_ref, _ = ops.siddon_forward(V, s, t, L, want_aux=True, det=(256, 256))
+    plan, shear = slab_plan(s, t, 256, 256)
+    assert plan.shape == (4, 2) and shear.shape == (4, 4)
+    out, aux = ops.siddon_forward_slab(V, s, t, L, (256, 256), plan, shear, want_aux=True)
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+    # identical up to which axis an exact tie is attributed to: measure zero for the
+    # perturbed poses 1..3 (pose 0 is the symmetric base pose, full of exact ties)
+    close = ((aux - aux_ref).abs().amax(-1) <= 1e-4 * aux_ref.abs().max())
+    assert close[1:].float().mean().item() > 0.999
+    assert torch.allclose(aux[..., 0], aux_ref[..., 0], rtol=1e-5, atol=1e-6)
+    # any plan gives the same image: force the other march axis / the generic fallback
+    for march in (0, 1, 2):
+        p2 = plan.clone()
+        p2[:, 0] = march
+        p2[:, 1] = 1 - p2[:, 1]
+        o2 = ops.siddon_forward_slab(V, s, t, L, (256, 256), p2, -shear)[0]
+        assert rel_err(o2.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("H,W", [(70, 45), (64, 64), (33, 130)])
+def test_slab_march_odd_detectors_vs_oracle(gpu, H, W):
+    subject = synthetic_subject(48, kind="noise", seed=0)
+    drr = DRR(subject, sdd=400.0, height=H, width=W, delx=1.1).to(gpu)
+    rot = torch.tensor([[0.0, 0.0, 0.0], [0.5, -0.3, 0.8], [1.5, 0.1, 0.2], [0.1, 1.4, 0.0]],
+                       device=gpu)
+    xyz = torch.tensor([[0.0, 300.0, 0.0], [5.0, 280.0, -7.0], [0.0, 310.0, 3.0],
+                        [2.0, 300.0, 1.0]], device=gpu)
+    img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    s, t, L = voxel_rays(drr, rot, xyz)
+    ref = oracle.siddon(drr.density.cpu().numpy(), s.cpu().numpy(), t.cpu().numpy(),
+                        L.cpu().numpy())["out"]
+    assert rel_err(img.cpu().numpy().reshape(ref.shape), ref) < FWD_TOL
+    drr.renderer.use_slab_march = False
+    img2 = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    assert rel_err(img2.cpu().numpy(), img.cpu().numpy()) < 1e-6
 
 
 def test_deterministic_forward(gpu, big):

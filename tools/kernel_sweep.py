@@ -15,6 +15,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffdrr_amd import DRR, _lib, ops  # noqa: E402
 from diffdrr_amd.data import make_subject, noise_volume  # noqa: E402
+from diffdrr_amd.plan import slab_plan  # noqa: E402
 from diffdrr_amd.pose import convert  # noqa: E402
 
 
@@ -77,6 +78,26 @@ def main():
               f"({alg / med / 1e6 / 8000 * 100:5.1f}% of 8 TB/s)", flush=True)
         return med
 
+    def slab_case(label, s, t, L, xcd, aux=False):
+        lib.cdll.ddrr_set_xcd_swizzle(int(xcd))
+        B = t.shape[0]
+        _, _, nv = ops.siddon_forward(V, s, t, L, count_voxels=True, det=(H, H))
+        nvox = int(nv.sum())
+        alg = 4 * nvox + B * H * H * 20 + 12 * B
+        plan, shear = slab_plan(s, t, H, H)
+        tp, _ = timeit(lambda: slab_plan(s, t, H, H), reps=5)
+        med, best = timeit(lambda: ops.siddon_forward_slab(V, s, t, L, (H, H), plan, shear,
+                                                           want_aux=aux))
+        ref = ops.siddon_forward(V, s, t, L, det=(H, H))[0]
+        out = ops.siddon_forward_slab(V, s, t, L, (H, H), plan, shear)[0]
+        err = ((out - ref).abs().max() / ref.abs().max()).item()
+        print(f"{label:34s} SLAB march  xcd {int(xcd)} aux {int(aux)} B {B:4d} "
+              f"vox/ray {nvox / (B * H * H):6.1f}  {med:8.3f} ms (best {best:7.3f})  "
+              f"{B / med * 1e3:9.0f} DRR/s  {alg / med / 1e6:8.1f} GB/s alg "
+              f"({alg / med / 1e6 / 8000 * 100:5.1f}% of 8 TB/s)  plan {tp:.3f} ms  "
+              f"err vs generic {err:.1e}", flush=True)
+        return med
+
     base = rays(drr, torch.zeros(1, 3, device=dev), torch.tensor([[0.0, 850.0, 0.0]], device=dev))
     pert32 = rays(drr, *poses(32, 2, dev))
     tiles = [(64, 1), (32, 2), (16, 4), (8, 8), (4, 16), (1, 64)]
@@ -90,7 +111,13 @@ def main():
     for tile in tiles:
         fwd_case("base pose x32", *rep, tile, True)
     fwd_case("base pose x32", *rep, (16, 4), False)
+    for xcd in (1, 0):
+        slab_case("base pose x32", *rep, xcd)
     print("## Siddon forward: 32 perturbed poses (bench workload)")
+    for xcd in (1, 0):
+        slab_case("perturbed x32", *pert32, xcd)
+    slab_case("perturbed x32 + aux", *pert32, 1, aux=True)
+    slab_case("base pose B=1", *base, 1)
     for tile in tiles:
         fwd_case("perturbed x32", *pert32, tile, True)
     fwd_case("perturbed x32", *pert32, (16, 4), False)
@@ -102,9 +129,11 @@ def main():
             one = tuple(x[b:b + 1].contiguous() for x in pert32)
             rep1 = tuple(x.expand(16, *x.shape[1:]).contiguous() for x in one)
             fwd_case(f"pose {b} x16", *rep1, (16, 4), True)
-            fwd_case(f"pose {b} x16", *rep1, (8, 8), True)
+            slab_case(f"pose {b} x16", *rep1, True)
         big = rays(drr, *poses(128, 3, dev))
         fwd_case("perturbed x128", *big, (16, 4), True)
+        slab_case("perturbed x128", *big, True)
+        slab_case("perturbed x128", *big, False)
 
     lib.cdll.ddrr_set_xcd_swizzle(1)
     s, t, L = pert32
