@@ -1,0 +1,140 @@
+// brick_core.h -- volume-stationary ("brick") form of the Siddon forward pass.
+//
+// The per-ray kernels stream the volume once per pose; at 512^3 a batch of 32
+// poses re-reads every voxel ~10 times through the L2/Infinity-Cache fabric,
+// which is what bounds them (profiles/r01).  Here the roles are swapped: a
+// workgroup stages one 32^3-voxel brick (128 KiB, fits the 160 KiB LDS of a CU)
+// and traces, from LDS, the part of EVERY ray of EVERY pose of the batch that
+// crosses that brick; the partial line integrals are added to the image with
+// fp32 atomics.  The volume is then read from HBM exactly once per batch, and
+// the ~10 reads per voxel are LDS reads (random-access bandwidth ~8x the
+// texture path's).
+//
+// Which rays cross a brick: the detector grid of a pose is an affine image of
+// the pixel lattice, target(i, j) = o + i e_i + j e_j (reference
+// detector.py:126, 147-153), so the brick's 8 corners project through the
+// source onto a convex pixel region whose bounding box is enumerated.  The box
+// only selects candidates -- each candidate ray is then clipped against the
+// brick with the same plane-crossing arithmetic as the full walk
+// (siddon_setup on the brick's Box), so brick boundaries are exact: adjacent
+// bricks evaluate the shared plane's alpha with the same expression.
+#pragma once
+
+#include "ddrr_common.h"
+#include "siddon_core.h"
+
+namespace ddrr {
+
+constexpr int BRICK = 32;  // brick edge in voxels
+
+struct BrickGrid {
+    int nx, ny, nz;
+};
+
+DDRR_HD BrickGrid brick_grid(const Dims D) {
+    BrickGrid g;
+    g.nx = (D.x + BRICK - 1) / BRICK;
+    g.ny = (D.y + BRICK - 1) / BRICK;
+    g.nz = (D.z + BRICK - 1) / BRICK;
+    return g;
+}
+
+DDRR_HD Box brick_box(const Dims D, const BrickGrid &g, int id) {
+    const int bz = id % g.nz, by = (id / g.nz) % g.ny, bx = id / (g.nz * g.ny);
+    Box b;
+    b.lo[0] = bx * BRICK;
+    b.lo[1] = by * BRICK;
+    b.lo[2] = bz * BRICK;
+    b.hi[0] = b.lo[0] + BRICK < D.x ? b.lo[0] + BRICK : D.x;
+    b.hi[1] = b.lo[1] + BRICK < D.y ? b.lo[1] + BRICK : D.y;
+    b.hi[2] = b.lo[2] + BRICK < D.z ? b.lo[2] + BRICK : D.z;
+    return b;
+}
+
+DDRR_HD Store brick_store(const Box &b) {
+    Store st;
+    st.dims = Dims{BRICK, BRICK, BRICK};
+    st.org[0] = b.lo[0];
+    st.org[1] = b.lo[1];
+    st.org[2] = b.lo[2];
+    return st;
+}
+
+struct PixBox {
+    int i0, i1, j0, j1;  // inclusive; empty when i1 < i0 or j1 < j0
+};
+
+DDRR_HD int pixbox_count(const PixBox &b) {
+    return (b.i1 < b.i0 || b.j1 < b.j0) ? 0 : (b.i1 - b.i0 + 1) * (b.j1 - b.j0 + 1);
+}
+
+// Pixel bounding box of the lines through `src` that meet the box `b`
+// (plane indices; a plane k sits at x = k - shift).  tgt points at the pose's
+// (det_h * det_w, 3) target grid.
+DDRR_HD PixBox project_brick(const float *src, const float *tgt, int det_h, int det_w,
+                             const Box &b, float shift) {
+    const float *t00 = tgt, *t01 = tgt + 3, *t10 = tgt + 3 * det_w;
+    float ei[3], ej[3], r[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        ei[a] = t10[a] - t00[a];
+        ej[a] = t01[a] - t00[a];
+        r[a] = t00[a] - src[a];
+    }
+    // solve lambda * w - i * ei - j * ej = r for every corner w = p - src (Cramer)
+    const float n[3] = {ei[1] * ej[2] - ei[2] * ej[1], ei[2] * ej[0] - ei[0] * ej[2],
+                        ei[0] * ej[1] - ei[1] * ej[0]};  // ei x ej
+    const float rxej[3] = {r[1] * ej[2] - r[2] * ej[1], r[2] * ej[0] - r[0] * ej[2],
+                           r[0] * ej[1] - r[1] * ej[0]};
+    const float rxei[3] = {r[1] * ei[2] - r[2] * ei[1], r[2] * ei[0] - r[0] * ei[2],
+                           r[0] * ei[1] - r[1] * ei[0]};
+    float imin = INFINITY, imax = -INFINITY, jmin = INFINITY, jmax = -INFINITY;
+    int npos = 0, nneg = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float w[3] = {(float)((c & 1) ? b.hi[0] : b.lo[0]) - shift - src[0],
+                            (float)((c & 2) ? b.hi[1] : b.lo[1]) - shift - src[1],
+                            (float)((c & 4) ? b.hi[2] : b.lo[2]) - shift - src[2]};
+        const float det = w[0] * n[0] + w[1] * n[1] + w[2] * n[2];
+        npos += det > 0.f;
+        nneg += det < 0.f;
+        const float inv = 1.0f / det;
+        const float i = -(w[0] * rxej[0] + w[1] * rxej[1] + w[2] * rxej[2]) * inv;
+        const float j = (w[0] * rxei[0] + w[1] * rxei[1] + w[2] * rxei[2]) * inv;
+        imin = fminf(imin, i);
+        imax = fmaxf(imax, i);
+        jmin = fminf(jmin, j);
+        jmax = fmaxf(jmax, j);
+    }
+    PixBox pb;
+    if (npos != 8 && nneg != 8) {
+        // the plane through the source parallel to the detector cuts the box: its
+        // projection is unbounded -> every pixel is a candidate
+        pb.i0 = 0;
+        pb.i1 = det_h - 1;
+        pb.j0 = 0;
+        pb.j1 = det_w - 1;
+        return pb;
+    }
+    // pixel centres are the integer (i, j); keep a small guard band for rounding
+    const float g = 0.02f;
+    const float fi0 = fmaxf(floorf(imin - g), 0.f), fi1 = fminf(ceilf(imax + g), (float)(det_h - 1));
+    const float fj0 = fmaxf(floorf(jmin - g), 0.f), fj1 = fminf(ceilf(jmax + g), (float)(det_w - 1));
+    if (!(fi0 <= fi1) || !(fj0 <= fj1)) {  // also catches NaN
+        pb.i0 = pb.j0 = 0;
+        pb.i1 = pb.j1 = -1;
+        return pb;
+    }
+    pb.i0 = (int)fi0;
+    pb.i1 = (int)fi1;
+    pb.j0 = (int)fj0;
+    pb.j1 = (int)fj1;
+    return pb;
+}
+
+struct LdsFetch {
+    const float *brick;  // BRICK^3 floats, [x][y][z]
+    DDRR_HD float operator()(unsigned boff) const { return brick[boff >> 2]; }
+};
+
+}  // namespace ddrr

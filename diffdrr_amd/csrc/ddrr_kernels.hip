@@ -14,6 +14,7 @@
 #include "../../include/diffdrr_hip.h"
 #include "ddrr_common.h"
 #include "siddon_core.h"
+#include "brick_core.h"
 #include "slab_core.h"
 #include "trilinear_core.h"
 
@@ -101,8 +102,8 @@ __global__ __launch_bounds__(kBlock) void siddon_fwd_kernel(RayArgs p, float *__
     load_ray(p, id, s, t);
     float rec[SIDDON_AUX];
     int cnt = 0;
-    const float I =
-        siddon_forward_ray<REDUCE, AUX, COUNT>(p.vol, p.D, s, t, p.shift, p.eps, rec, &cnt);
+    const float I = siddon_forward_ray<REDUCE, AUX, COUNT>(p.vol, p.D, full_box(p.D), s, t, p.shift,
+                                                           p.eps, rec, &cnt);
     const float L = p.img ? p.img[id.r] : 1.f;
     out[id.r] = L * I;
     if (AUX) {
@@ -210,6 +211,8 @@ struct SlabArgs {
     int max_strips;
     int total_waves;
     int xcd_swizzle;
+    Box box;         // sub-box of the volume this pass covers
+    int accumulate;  // add to out / aux (later passes) instead of overwriting
 };
 
 template <bool AUX>
@@ -237,11 +240,11 @@ __global__ __launch_bounds__(kBlock) void siddon_fwd_slab_kernel(SlabArgs p,
     float rec[SIDDON_AUX];
     float I = 0.f;
     if (march > 1) {  // z-dominant pose: generic per-crossing walk
-        if (n >= 0) I = siddon_forward_ray<REDUCE_SUM, AUX, false>(p.vol, p.D, s, t, p.shift,
+        if (n >= 0) I = siddon_forward_ray<REDUCE_SUM, AUX, false>(p.vol, p.D, p.box, s, t, p.shift,
                                                                    p.eps, rec, nullptr);
     } else {
         const SlabAxes ax = make_slab_axes(p.D, march);
-        SlabLane L = slab_lane_init(p.D, ax, s, t, p.shift, p.eps);
+        SlabLane L = slab_lane_init(p.D, p.box, ax, s, t, p.shift, p.eps);
         if (n < 0) {
             L.hit = false;
             L.fast = false;
@@ -269,8 +272,8 @@ __global__ __launch_bounds__(kBlock) void siddon_fwd_slab_kernel(SlabArgs p,
             I = L.acc;
             if (AUX) slab_aux_record(L, ax, rec);
         } else if (L.hit) {
-            I = siddon_forward_ray<REDUCE_SUM, AUX, false>(p.vol, p.D, s, t, p.shift, p.eps, rec,
-                                                           nullptr);
+            I = siddon_forward_ray<REDUCE_SUM, AUX, false>(p.vol, p.D, p.box, s, t, p.shift, p.eps,
+                                                           rec, nullptr);
         } else if (AUX) {
 #pragma unroll
             for (int k = 0; k < SIDDON_AUX; ++k) rec[k] = 0.f;
@@ -278,11 +281,113 @@ __global__ __launch_bounds__(kBlock) void siddon_fwd_slab_kernel(SlabArgs p,
     }
     if (n < 0) return;
     const float Lm = p.img ? p.img[r] : 1.f;
-    out[r] = Lm * I;
+    // passes over disjoint sub-boxes run one after the other on the stream; the
+    // lane owns its ray's outputs, so a plain read-modify-write accumulates them
+    out[r] = (p.accumulate ? out[r] : 0.f) + Lm * I;
     if (AUX) {
         float4 *a4 = reinterpret_cast<float4 *>(aux + r * SIDDON_AUX);
-        a4[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
-        a4[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);
+        float4 lo = make_float4(rec[0], rec[1], rec[2], rec[3]);
+        float4 hi = make_float4(rec[4], rec[5], rec[6], rec[7]);
+        if (p.accumulate) {
+            const float4 plo = a4[0], phi = a4[1];
+            lo = make_float4(lo.x + plo.x, lo.y + plo.y, lo.z + plo.z, lo.w + plo.w);
+            hi = make_float4(hi.x + phi.x, hi.y + phi.y, hi.z + phi.z, hi.w + phi.w);
+        }
+        a4[0] = lo;
+        a4[1] = hi;
+    }
+}
+
+// ------------------------------------------------- Siddon, brick-stationary
+// One workgroup per 32^3 brick: stage the brick in LDS, then trace from LDS the part
+// of every ray of every pose that crosses it (brick_core.h).  1024 threads, 128 KiB
+// of LDS -> one workgroup per CU, 4 waves per SIMD.
+
+constexpr int kBrickThreads = 1024;
+constexpr int kPoseChunk = 128;
+
+struct BrickArgs {
+    const float *vol;
+    Dims D;
+    const float *source;  // (B, 1, 3)
+    const float *target;  // (B, N, 3), row-major det_h x det_w grid
+    const float *img;
+    int B, det_h, det_w;
+    float shift, eps;
+};
+
+__global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
+    BrickArgs p, float *__restrict__ out) {
+    __shared__ float brick[BRICK * BRICK * BRICK];
+    __shared__ int pbox[kPoseChunk][4];
+    __shared__ int pref[kPoseChunk + 1];
+    const int tid = threadIdx.x;
+    const BrickGrid bg = brick_grid(p.D);
+    const Box box = brick_box(p.D, bg, blockIdx.x);
+    const Store st = brick_store(box);
+    const int N = p.det_h * p.det_w;
+
+    // stage the brick: 32 x 32 rows of 32 floats (one 128-byte line each)
+    for (int row = tid >> 3; row < BRICK * BRICK; row += kBrickThreads >> 3) {
+        const int lx = row / BRICK, ly = row - lx * BRICK, q4 = (tid & 7) * 4;
+        const int x = box.lo[0] + lx, y = box.lo[1] + ly, z = box.lo[2] + q4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (x < box.hi[0] && y < box.hi[1]) {
+            const float *g = p.vol + ((long)x * p.D.y + y) * p.D.z + z;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (z + k < box.hi[2]) v[k] = g[k];
+        }
+        float *d = brick + (lx * BRICK + ly) * BRICK + q4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = v[k];
+    }
+
+    for (int b0 = 0; b0 < p.B; b0 += kPoseChunk) {
+        const int nb = p.B - b0 < kPoseChunk ? p.B - b0 : kPoseChunk;
+        __syncthreads();  // brick staged / previous chunk's tables consumed
+        if (tid < nb) {
+            const PixBox pb = project_brick(p.source + (long)(b0 + tid) * 3,
+                                            p.target + (long)(b0 + tid) * N * 3, p.det_h,
+                                            p.det_w, box, p.shift);
+            pbox[tid][0] = pb.i0;
+            pbox[tid][1] = pb.j0;
+            pbox[tid][2] = pb.j1 - pb.j0 + 1;
+            pbox[tid][3] = pixbox_count(pb);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int k = 0; k < nb; ++k) {
+                pref[k] = acc;
+                acc += pbox[k][3];
+            }
+            pref[nb] = acc;
+        }
+        __syncthreads();
+        const int total = pref[nb];
+        for (int c = tid; c < total; c += kBrickThreads) {
+            // pose of candidate c: last k with pref[k] <= c
+            int lo = 0, hi = nb;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (pref[mid] <= c) lo = mid;
+                else hi = mid;
+            }
+            const int local = c - pref[lo], w = pbox[lo][2];
+            const int di = local / w;
+            const int i = pbox[lo][0] + di, j = pbox[lo][1] + (local - di * w);
+            const long r = (long)(b0 + lo) * N + (long)i * p.det_w + j;
+            float s[3], t[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                s[a] = p.source[(long)(b0 + lo) * 3 + a];
+                t[a] = p.target[r * 3 + a];
+            }
+            const float I = siddon_forward_ray_t<REDUCE_SUM, false, false>(
+                LdsFetch{brick}, st, box, s, t, p.shift, p.eps, nullptr, nullptr);
+            if (I != 0.f) unsafeAtomicAdd(out + r, (p.img ? p.img[r] : 1.f) * I);
+        }
     }
 }
 
@@ -368,6 +473,10 @@ __global__ __launch_bounds__(kBlock) void trilinear_bwd_kernel(
 // ------------------------------------------------------------------ host side
 
 int g_xcd_swizzle = 1;
+// The slab kernel is fastest with the natural round-robin placement: all XCDs then
+// sweep the same poses at the same time, which the shared Infinity Cache likes
+// (profiles/r01/sweep_v2_slab_512.txt: 4.8 ms vs 6.8 ms on the bench workload).
+int g_xcd_swizzle_slab = 0;
 
 int check_common(const float *volume, int dx, int dy, int dz, const float *source, int src_n,
                  const float *target, int B, int N) {
@@ -423,6 +532,11 @@ int ddrr_set_xcd_swizzle(int on) {
     g_xcd_swizzle = on ? 1 : 0;
     return old;
 }
+int ddrr_set_xcd_swizzle_slab(int on) {
+    int old = g_xcd_swizzle_slab;
+    g_xcd_swizzle_slab = on ? 1 : 0;
+    return old;
+}
 
 int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float *source,
                         int src_n, const float *target, const float *img, int B, int N,
@@ -475,7 +589,8 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
 int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const float *source,
                              const float *target, const float *img, int B, int det_h, int det_w,
                              float voxel_shift, float eps, const int *plan, const float *shear,
-                             int max_strips, float *out, float *aux, void *stream) {
+                             int max_strips, const int *box, int accumulate, float *out,
+                             float *aux, void *stream) {
     const int N = det_h * det_w;
     if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
     if (!out || !plan || !shear) return fail(-1, "null out / plan / shear pointer");
@@ -498,7 +613,18 @@ int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const 
     const int need = (det_h > det_w ? det_h : det_w);
     if (max_strips < (need + 63) / 64) return fail(-1, "shear table has too few strips");
     p.total_waves = B * p.sm.waves_per_pose;
-    p.xcd_swizzle = g_xcd_swizzle;
+    p.xcd_swizzle = g_xcd_swizzle_slab;
+    p.box = full_box(p.D);
+    if (box) {
+        const int Dn[3] = {dx, dy, dz};
+        for (int a = 0; a < 3; ++a) {
+            p.box.lo[a] = box[a];
+            p.box.hi[a] = box[3 + a];
+            if (box[a] < 0 || box[3 + a] > Dn[a] || box[a] >= box[3 + a])
+                return fail(-1, "box must satisfy 0 <= lo < hi <= dims");
+        }
+    }
+    p.accumulate = accumulate;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((p.total_waves + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
     if (aux)
@@ -506,6 +632,35 @@ int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const 
     else
         hipLaunchKernelGGL((siddon_fwd_slab_kernel<false>), grid, block, 0, st, p, out, aux);
     return finish("ddrr_siddon_forward_slab");
+}
+
+int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
+                               const float *target, const float *img, int B, int det_h,
+                               int det_w, float voxel_shift, float eps, float *out,
+                               void *stream) {
+    const int N = det_h * det_w;
+    if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
+    if (!out) return fail(-1, "null out pointer");
+    if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * N, st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    BrickArgs p;
+    p.vol = volume;
+    p.D = Dims{dx, dy, dz};
+    p.source = source;
+    p.target = target;
+    p.img = img;
+    p.B = B;
+    p.det_h = det_h;
+    p.det_w = det_w;
+    p.shift = voxel_shift;
+    p.eps = eps;
+    const BrickGrid bg = brick_grid(p.D);
+    hipLaunchKernelGGL(siddon_fwd_brick_kernel, dim3(bg.nx * bg.ny * bg.nz), dim3(kBrickThreads),
+                       0, st, p, out);
+    return finish("ddrr_siddon_forward_bricks");
 }
 
 int ddrr_siddon_backward_rays(const float *aux, const float *grad_out, const float *source,

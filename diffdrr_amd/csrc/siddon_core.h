@@ -25,16 +25,55 @@
 
 namespace ddrr {
 
+// Sub-box of the volume a pass is restricted to, in plane indices per axis
+// (lo <= planes <= hi; voxels lo .. hi-1).  The full volume is {0,0,0}..{Dx,Dy,Dz}.
+// Restricting a walk to a box and adding the results over a partition of the
+// volume into boxes gives the same integral (and the same backward record):
+// used to render a large volume in Infinity-Cache-sized passes.
+struct Box {
+    int lo[3], hi[3];
+};
+
+DDRR_HD Box full_box(const Dims D) {
+    Box b;
+    b.lo[0] = b.lo[1] = b.lo[2] = 0;
+    b.hi[0] = D.x;
+    b.hi[1] = D.y;
+    b.hi[2] = D.z;
+    return b;
+}
+
+// Where the voxels of the box being walked are stored: the whole volume in global
+// memory (dims = volume dims, org = 0), or a brick staged in LDS (dims = the
+// brick's storage dims, org = the brick's first voxel).  Offsets are in bytes.
+struct Store {
+    Dims dims;
+    int org[3];
+};
+
+DDRR_HD Store global_store(const Dims D) {
+    Store st;
+    st.dims = D;
+    st.org[0] = st.org[1] = st.org[2] = 0;
+    return st;
+}
+
+struct GlobalFetch {
+    const float *vol;
+    DDRR_HD float operator()(unsigned boff) const {
+        return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(vol) + boff);
+    }
+};
+
 struct SiddonSetup {
     float d[3], inv[3], c[3], lo[3], hi[3];
     float entry, exit;
     bool hit;
 };
 
-DDRR_HD SiddonSetup siddon_setup(const Dims D, const float s[3], const float t[3], float shift,
+DDRR_HD SiddonSetup siddon_setup(const Box &box, const float s[3], const float t[3], float shift,
                                  float eps) {
     SiddonSetup q;
-    const int Dn[3] = {D.x, D.y, D.z};
     q.entry = -INFINITY;
     q.exit = INFINITY;
 #pragma unroll
@@ -42,8 +81,8 @@ DDRR_HD SiddonSetup siddon_setup(const Dims D, const float s[3], const float t[3
         q.d[a] = (t[a] - s[a]) + eps;  // renderers.py:104-106, :148
         q.inv[a] = 1.0f / q.d[a];
         q.c[a] = (-shift - s[a]) / q.d[a];  // a true division: half an ulp, once per ray
-        const float a0 = q.c[a];
-        const float aD = fmaf((float)Dn[a], q.inv[a], q.c[a]);
+        const float a0 = fmaf((float)box.lo[a], q.inv[a], q.c[a]);
+        const float aD = fmaf((float)box.hi[a], q.inv[a], q.c[a]);
         q.lo[a] = fminf(a0, aD);
         q.hi[a] = fmaxf(a0, aD);
         q.entry = fmaxf(q.entry, q.lo[a]);
@@ -62,11 +101,10 @@ struct SiddonWalk {
     unsigned off;   // BYTE offset of the current voxel (volume <= 2^30 voxels)
 };
 
-DDRR_HD SiddonWalk siddon_enter(const Dims D, const float s[3], float shift,
+DDRR_HD SiddonWalk siddon_enter(const Store &st, const Box &box, const float s[3], float shift,
                                 const SiddonSetup &q) {
     SiddonWalk w;
-    const int Dn[3] = {D.x, D.y, D.z};
-    const int stride[3] = {D.y * D.z * 4, D.z * 4, 4};
+    const int stride[3] = {st.dims.y * st.dims.z * 4, st.dims.z * 4, 4};
     w.off = 0u;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -74,10 +112,10 @@ DDRR_HD SiddonWalk siddon_enter(const Dims D, const float s[3], float shift,
         // position at entry in plane units; the entering axis is pinned to its
         // face voxel, the others are whatever cell the entry point lies in
         float u = floorf(fmaf(q.entry, q.d[a], s[a] + shift));
-        u = fminf(fmaxf(u, 0.f), (float)(Dn[a] - 1));
+        u = fminf(fmaxf(u, (float)box.lo[a]), (float)(box.hi[a] - 1));
         int i = (int)u;
-        if (q.lo[a] == q.entry) i = pos ? 0 : Dn[a] - 1;
-        w.off += (unsigned)(i * stride[a]);
+        if (q.lo[a] == q.entry) i = pos ? box.lo[a] : box.hi[a] - 1;
+        w.off += (unsigned)((i - st.org[a]) * stride[a]);
         w.kf[a] = (float)(i + (pos ? 1 : 0));
         w.dirf[a] = pos ? 1.f : -1.f;
         w.dstep[a] = pos ? stride[a] : -stride[a];
@@ -175,18 +213,19 @@ DDRR_HD SiddonSeg siddon_step(SiddonGen &g, const SiddonSetup &q) {
 // right after it is consumed), on top of the 8 waves per SIMD the 8-wave
 // occupancy provides: the walk is a pure gather whose only lever against HBM /
 // Infinity-Cache latency is the number of outstanding requests.
-template <int REDUCE, bool AUX, bool COUNT>
-DDRR_HD float siddon_forward_ray(const float *__restrict__ vol, const Dims D, const float s[3],
-                                 const float t[3], float shift, float eps, float *aux,
-                                 int *count) {
-    const SiddonSetup q = siddon_setup(D, s, t, shift, eps);
+template <int REDUCE, bool AUX, bool COUNT, class Fetch>
+DDRR_HD float siddon_forward_ray_t(const Fetch &fetch, const Store &st, const Box &box,
+                                   const float s[3], const float t[3], float shift, float eps,
+                                   float *aux, int *count) {
+    const Dims D = st.dims;
+    const SiddonSetup q = siddon_setup(box, s, t, shift, eps);
     float acc = 0.f;  // sum: integral; max: best term (>= 0: segments outside the volume are 0)
     int nvis = 0;
     float S0x = 0.f, S1x = 0.f, S0z = 0.f, S1z = 0.f;             // aux (sum)
     float bV = 0.f, bIn = 0.f, bOut = 0.f, bAin = 0.f, bAout = 0.f;  // aux (max)
     if (q.hit) {
         SiddonGen g;
-        g.w = siddon_enter(D, s, shift, q);
+        g.w = siddon_enter(st, box, s, shift, q);
         g.a_cur = q.entry;
         g.exit = q.exit;
         g.live = true;
@@ -225,19 +264,19 @@ DDRR_HD float siddon_forward_ray(const float *__restrict__ vol, const Dims D, co
     } while (0)
 
         bool liveA = true;
-        float vA = vox(vol, g.w.off);
+        float vA = fetch(g.w.off);
         SiddonSeg rA = siddon_step<REDUCE, AUX>(g, q);
-        float vB = vox(vol, g.w.off);
+        float vB = fetch(g.w.off);
         SiddonSeg rB = siddon_step<REDUCE, AUX>(g, q);
         // safety net: a ray has at most Dx+Dy+Dz+3 crossings, two are retired per trip
         const int cap = (D.x + D.y + D.z + 3) / 2 + 2;
         for (int it = 0; it < cap && liveA; ++it) {
             DDRR_CONSUME(vA, rA);
             liveA = g.live;
-            vA = vox(vol, g.w.off);
+            vA = fetch(g.w.off);
             rA = siddon_step<REDUCE, AUX>(g, q);
             DDRR_CONSUME(vB, rB);
-            vB = vox(vol, g.w.off);
+            vB = fetch(g.w.off);
             rB = siddon_step<REDUCE, AUX>(g, q);
         }
 #undef DDRR_CONSUME
@@ -265,6 +304,14 @@ DDRR_HD float siddon_forward_ray(const float *__restrict__ vol, const Dims D, co
     }
     if (COUNT) *count = nvis;
     return acc;
+}
+
+template <int REDUCE, bool AUX, bool COUNT>
+DDRR_HD float siddon_forward_ray(const float *__restrict__ vol, const Dims D, const Box &box,
+                                 const float s[3], const float t[3], float shift, float eps,
+                                 float *aux, int *count) {
+    return siddon_forward_ray_t<REDUCE, AUX, COUNT>(GlobalFetch{vol}, global_store(D), box, s, t,
+                                                    shift, eps, aux, count);
 }
 
 // Gradient w.r.t. the voxel-space ray endpoints from the forward record
@@ -310,9 +357,10 @@ DDRR_HD void siddon_backward_ray(const float *aux, const float s[3], const float
 template <int REDUCE, class Add>
 DDRR_HD void siddon_scatter_ray(const float *__restrict__ vol, const Dims D, const float s[3],
                                 const float t[3], float shift, float eps, float gl, Add add) {
-    const SiddonSetup q = siddon_setup(D, s, t, shift, eps);
+    const Box box = full_box(D);
+    const SiddonSetup q = siddon_setup(box, s, t, shift, eps);
     if (!q.hit) return;
-    SiddonWalk w = siddon_enter(D, s, shift, q);
+    SiddonWalk w = siddon_enter(global_store(D), box, s, shift, q);
     float a_cur = q.entry;
     unsigned off = w.off;  // bytes
     const int cap = D.x + D.y + D.z + 3;
@@ -354,9 +402,10 @@ DDRR_HD void siddon_channels_ray(const float *__restrict__ vol,
                                  const unsigned char *__restrict__ labels, const Dims D,
                                  const float s[3], const float t[3], float shift, float eps,
                                  Flush flush) {
-    const SiddonSetup q = siddon_setup(D, s, t, shift, eps);
+    const Box box = full_box(D);
+    const SiddonSetup q = siddon_setup(box, s, t, shift, eps);
     if (!q.hit) return;
-    SiddonWalk w = siddon_enter(D, s, shift, q);
+    SiddonWalk w = siddon_enter(global_store(D), box, s, shift, q);
     float a_cur = q.entry, run = 0.f;
     unsigned off = w.off;  // bytes
     int cur = -1;

@@ -67,10 +67,10 @@ struct SlabLane {
 };
 
 // Set a lane up from its ray.  `fast` = can take the slab march.
-DDRR_HD SlabLane slab_lane_init(const Dims D, const SlabAxes &ax, const float s[3],
-                                const float t[3], float shift, float eps) {
+DDRR_HD SlabLane slab_lane_init(const Dims D, const Box &box, const SlabAxes &ax,
+                                const float s[3], const float t[3], float shift, float eps) {
     SlabLane L;
-    const SiddonSetup q = siddon_setup(D, s, t, shift, eps);
+    const SiddonSetup q = siddon_setup(box, s, t, shift, eps);
     const bool mx = ax.m == 0;  // march along x (rows along y) or along y (rows along x)
     L.hit = q.hit;
     L.acc = 0.f;
@@ -103,7 +103,7 @@ DDRR_HD SlabLane slab_lane_init(const Dims D, const SlabAxes &ax, const float s[
     L.dstep_m = L.dstep_u = 0;
     L.diz = 1;
     if (q.hit) {
-        const SiddonWalk w = siddon_enter(D, s, shift, q);
+        const SiddonWalk w = siddon_enter(global_store(D), box, s, shift, q);
         L.km = mx ? w.kf[0] : w.kf[1];
         L.ku = mx ? w.kf[1] : w.kf[0];
         L.kz = w.kf[2];

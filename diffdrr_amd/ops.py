@@ -6,6 +6,7 @@ this package renders on the MI355X only.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 import torch
@@ -117,8 +118,28 @@ def siddon_forward(volume, source, target, img, *, voxel_shift=0.5, eps=1e-8, re
     return out, aux, nvox
 
 
+MALL_PASS_BYTES = 128 << 20  # half the 256 MiB Infinity Cache per pass
+
+
+def volume_passes(shape, pass_bytes=None):
+    """Boxes (host int[6] lists) that partition a volume into Infinity-Cache-sized
+    slabs along x or y (never z: rows along z stay whole)."""
+    pass_bytes = MALL_PASS_BYTES if pass_bytes is None else pass_bytes
+    Dx, Dy, Dz = (int(v) for v in shape)
+    n = max(1, -(-(Dx * Dy * Dz * 4) // pass_bytes))
+    axis = 1 if Dy >= Dx else 0
+    n = min(n, (Dx, Dy)[axis])
+    edges = [round(k * (Dx, Dy)[axis] / n) for k in range(n + 1)]
+    boxes = []
+    for k in range(n):
+        lo, hi = [0, 0, 0], [Dx, Dy, Dz]
+        lo[axis], hi[axis] = edges[k], edges[k + 1]
+        boxes.append(lo + hi)
+    return boxes
+
+
 def siddon_forward_slab(volume, source, target, img, det, plan, shear, *, voxel_shift=0.5,
-                        eps=1e-8, want_aux=False):
+                        eps=1e-8, want_aux=False, boxes=None):
     """Detector-grid Siddon (sum) through the lockstep slab-march kernel.
     plan (B,2) int32 / shear (B,S) fp32 from diffdrr_amd.plan.slab_plan.
     -> (out (B,N), aux (B,N,8) | None)"""
@@ -133,11 +154,36 @@ def siddon_forward_slab(volume, source, target, img, det, plan, shear, *, voxel_
         if want_aux else None
     if _empty(B, N):
         return out, aux
-    _launch(
-        "ddrr_siddon_forward_slab", volume.device, volume.data_ptr(), *volume.shape,
-        source.data_ptr(), target.data_ptr(), _ptr(img), B, H, W, float(voxel_shift), float(eps),
-        plan.data_ptr(), shear.data_ptr(), int(shear.shape[1]), out.data_ptr(), _ptr(aux))
+    boxes = volume_passes(volume.shape) if boxes is None else boxes
+    for k, box in enumerate(boxes):
+        cbox = (ctypes.c_int * 6)(*box)
+        _launch(
+            "ddrr_siddon_forward_slab", volume.device, volume.data_ptr(), *volume.shape,
+            source.data_ptr(), target.data_ptr(), _ptr(img), B, H, W, float(voxel_shift),
+            float(eps), plan.data_ptr(), shear.data_ptr(), int(shear.shape[1]),
+            ctypes.addressof(cbox), int(k > 0), out.data_ptr(), _ptr(aux))
     return out, aux
+
+
+def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, eps=1e-8):
+    """Detector-grid Siddon (sum, forward only) through the volume-stationary brick
+    kernel: every 32^3 brick is staged in LDS once and all rays of all poses are traced
+    through it.  Requires the targets to be the affine detector grid DRR builds.
+    -> out (B,N)"""
+    B, N = _check_rays(volume, source, target, img)
+    H, W = int(det[0]), int(det[1])
+    if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
+        raise ValueError("the brick path needs one source per pose and an H*W >= 2x2 ray grid")
+    volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    out = torch.empty(B, N, dtype=torch.float32, device=volume.device)
+    if _empty(B, N):
+        return out
+    _launch(
+        "ddrr_siddon_forward_bricks", volume.device, volume.data_ptr(), *volume.shape,
+        source.data_ptr(), target.data_ptr(), _ptr(img), B, H, W, float(voxel_shift), float(eps),
+        out.data_ptr())
+    return out
 
 
 def siddon_backward_rays(aux, grad_out, source, target, img, *, eps=1e-8, reducefn="sum",

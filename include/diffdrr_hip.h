@@ -75,11 +75,28 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
  * generic walk; major 0|1}; shear (B, max_strips) fp32: slope of the epipolar lines
  * per 64-pixel strip (diffdrr_amd/plan.py computes both on the device).  plan and
  * shear only steer scheduling: the result equals ddrr_siddon_forward's up to fp32
- * summation order.  aux as in ddrr_siddon_forward. */
+ * summation order.  aux as in ddrr_siddon_forward.
+ * box: NULL, or HOST int[6] {lo_x, lo_y, lo_z, hi_x, hi_y, hi_z}: render only the part of
+ * every ray inside voxels lo..hi-1; with accumulate != 0 the result is ADDED to out / aux.
+ * Rendering a partition of the volume box by box (first call accumulate = 0) gives the
+ * full render: used to keep each pass's footprint inside the 256 MiB Infinity Cache. */
 int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const float *source,
                              const float *target, const float *img, int B, int det_h, int det_w,
                              float voxel_shift, float eps, const int *plan, const float *shear,
-                             int max_strips, float *out, float *aux, void *stream);
+                             int max_strips, const int *box, int accumulate, float *out,
+                             float *aux, void *stream);
+
+/* Volume-stationary form of ddrr_siddon_forward for large pose batches (same DRR case
+ * as ddrr_siddon_forward_slab: sum, nearest, one source per pose, row-major det_h x det_w
+ * target grid that is an affine image of the pixel lattice, detector.py:126-153): one
+ * workgroup per 32^3 brick staged in LDS traces every ray of every pose through it and
+ * adds the partial integrals to `out` (zero-filled by the call) with fp32 atomics.  The
+ * image equals ddrr_siddon_forward's up to fp32 summation order (which is not
+ * deterministic here).  No backward record. */
+int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
+                               const float *target, const float *img, int B, int det_h,
+                               int det_w, float voxel_shift, float eps, float *out,
+                               void *stream);
 
 /* Pose/ray gradients of ddrr_siddon_forward from its aux record: what autograd
  * of renderers.py:94-113 + :70-71 returns.  g_source is per ray (B, N, 3) (sum

@@ -10,10 +10,12 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../diffdrr_amd/csrc/ddrr_common.h"
 #include "../../diffdrr_amd/csrc/siddon_core.h"
+#include "../../diffdrr_amd/csrc/brick_core.h"
 #include "../../diffdrr_amd/csrc/slab_core.h"
 #include "../../diffdrr_amd/csrc/trilinear_core.h"
 #include "../../include/diffdrr_hip.h"
@@ -94,19 +96,19 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
                      if (lookup_mode == DDRR_LOOKUP_STEP) {
                          if (n_vox)
                              I = sum ? siddon_forward_ray<REDUCE_SUM, false, true>(
-                                           volume, D, ray.s, ray.t, voxel_shift, eps, rec, &cnt)
+                                           volume, D, full_box(D), ray.s, ray.t, voxel_shift, eps, rec, &cnt)
                                      : siddon_forward_ray<REDUCE_MAX, false, true>(
-                                           volume, D, ray.s, ray.t, voxel_shift, eps, rec, &cnt);
+                                           volume, D, full_box(D), ray.s, ray.t, voxel_shift, eps, rec, &cnt);
                          else if (aux)
                              I = sum ? siddon_forward_ray<REDUCE_SUM, true, false>(
-                                           volume, D, ray.s, ray.t, voxel_shift, eps, rec, &cnt)
+                                           volume, D, full_box(D), ray.s, ray.t, voxel_shift, eps, rec, &cnt)
                                      : siddon_forward_ray<REDUCE_MAX, true, false>(
-                                           volume, D, ray.s, ray.t, voxel_shift, eps, rec, &cnt);
+                                           volume, D, full_box(D), ray.s, ray.t, voxel_shift, eps, rec, &cnt);
                          else
                              I = sum ? siddon_forward_ray<REDUCE_SUM, false, false>(
-                                           volume, D, ray.s, ray.t, voxel_shift, eps, rec, &cnt)
+                                           volume, D, full_box(D), ray.s, ray.t, voxel_shift, eps, rec, &cnt)
                                      : siddon_forward_ray<REDUCE_MAX, false, false>(
-                                           volume, D, ray.s, ray.t, voxel_shift, eps, rec, &cnt);
+                                           volume, D, full_box(D), ray.s, ray.t, voxel_shift, eps, rec, &cnt);
                      } else if (lookup_mode == DDRR_LOOKUP_MID_TRILINEAR) {
                          I = sum ? siddon_forward_ray_midpoint<REDUCE_SUM, LOOKUP_MID_TRILINEAR>(
                                        volume, D, ray.s, ray.t, voxel_shift, eps, align_corners)
@@ -130,8 +132,15 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
 int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const float *source,
                              const float *target, const float *img, int B, int det_h, int det_w,
                              float voxel_shift, float eps, const int *plan, const float *shear,
-                             int max_strips, float *out, float *aux, void *) {
+                             int max_strips, const int *boxp, int accumulate, float *out,
+                             float *aux, void *) {
     const Dims D{dx, dy, dz};
+    Box box = full_box(D);
+    if (boxp)
+        for (int a = 0; a < 3; ++a) {
+            box.lo[a] = boxp[a];
+            box.hi[a] = boxp[3 + a];
+        }
     const int N = det_h * det_w;
     const ShearMap sm = make_shearmap(det_h, det_w);
     std::vector<char> seen((size_t)B * N, 0);
@@ -158,15 +167,15 @@ int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const 
                 for (int l = 0; l < 64; ++l)
                     I[l] = n[l] < 0 ? 0.f
                            : aux  ? siddon_forward_ray<REDUCE_SUM, true, false>(
-                                        volume, D, s[l], t[l], voxel_shift, eps, rec[l], nullptr)
+                                        volume, D, box, s[l], t[l], voxel_shift, eps, rec[l], nullptr)
                                   : siddon_forward_ray<REDUCE_SUM, false, false>(
-                                        volume, D, s[l], t[l], voxel_shift, eps, rec[l], nullptr);
+                                        volume, D, box, s[l], t[l], voxel_shift, eps, rec[l], nullptr);
             } else {
                 const SlabAxes ax = make_slab_axes(D, march);
                 SlabLane L[64];
                 int nfast = 0, npos = 0;
                 for (int l = 0; l < 64; ++l) {
-                    L[l] = slab_lane_init(D, ax, s[l], t[l], voxel_shift, eps);
+                    L[l] = slab_lane_init(D, box, ax, s[l], t[l], voxel_shift, eps);
                     if (n[l] < 0) {
                         L[l].hit = false;
                         L[l].fast = false;
@@ -230,9 +239,9 @@ int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const 
                     } else if (L[l].hit) {
                         g_stat_slow += 1;
                         I[l] = aux ? siddon_forward_ray<REDUCE_SUM, true, false>(
-                                         volume, D, s[l], t[l], voxel_shift, eps, rec[l], nullptr)
+                                         volume, D, box, s[l], t[l], voxel_shift, eps, rec[l], nullptr)
                                    : siddon_forward_ray<REDUCE_SUM, false, false>(
-                                         volume, D, s[l], t[l], voxel_shift, eps, rec[l], nullptr);
+                                         volume, D, box, s[l], t[l], voxel_shift, eps, rec[l], nullptr);
                     } else {
                         I[l] = 0.f;
                     }
@@ -241,12 +250,54 @@ int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const 
             for (int l = 0; l < 64; ++l) {
                 if (n[l] < 0) continue;
                 const long r = (long)b * N + n[l];
-                out[r] = (img ? img[r] : 1.f) * I[l];
-                if (aux) memcpy(aux + r * SIDDON_AUX, rec[l], sizeof(rec[l]));
+                out[r] = (accumulate ? out[r] : 0.f) + (img ? img[r] : 1.f) * I[l];
+                if (aux)
+                    for (int k = 0; k < SIDDON_AUX; ++k)
+                        aux[r * SIDDON_AUX + k] =
+                            (accumulate ? aux[r * SIDDON_AUX + k] : 0.f) + rec[l][k];
             }
         }
     for (size_t i = 0; i < seen.size(); ++i)
         if (seen[i] != 1) abort();  // the shear map must be a bijection
+    return 0;
+}
+
+// Host emulation of siddon_fwd_brick_kernel: same enumeration, same clipping, LDS brick
+// replaced by a local copy, atomics by plain adds.
+int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
+                               const float *target, const float *img, int B, int det_h,
+                               int det_w, float voxel_shift, float eps, float *out, void *) {
+    const Dims D{dx, dy, dz};
+    const int N = det_h * det_w;
+    memset(out, 0, sizeof(float) * (size_t)B * N);
+    const BrickGrid bg = brick_grid(D);
+    std::vector<float> brick((size_t)BRICK * BRICK * BRICK);
+    for (int id = 0; id < bg.nx * bg.ny * bg.nz; ++id) {
+        const Box box = brick_box(D, bg, id);
+        const Store st = brick_store(box);
+        std::fill(brick.begin(), brick.end(), 0.f);
+        for (int x = box.lo[0]; x < box.hi[0]; ++x)
+            for (int y = box.lo[1]; y < box.hi[1]; ++y)
+                for (int z = box.lo[2]; z < box.hi[2]; ++z)
+                    brick[((x - box.lo[0]) * BRICK + (y - box.lo[1])) * BRICK + (z - box.lo[2])] =
+                        volume[((long)x * dy + y) * dz + z];
+        for (int b = 0; b < B; ++b) {
+            const PixBox pb = project_brick(source + (long)b * 3, target + (long)b * N * 3, det_h,
+                                            det_w, box, voxel_shift);
+            for (int i = pb.i0; i <= pb.i1; ++i)
+                for (int j = pb.j0; j <= pb.j1; ++j) {
+                    const long r = (long)b * N + (long)i * det_w + j;
+                    float s[3], t[3];
+                    for (int a = 0; a < 3; ++a) {
+                        s[a] = source[(long)b * 3 + a];
+                        t[a] = target[r * 3 + a];
+                    }
+                    const float I = siddon_forward_ray_t<REDUCE_SUM, false, false>(
+                        LdsFetch{brick.data()}, st, box, s, t, voxel_shift, eps, nullptr, nullptr);
+                    if (I != 0.f) out[r] += (img ? img[r] : 1.f) * I;
+                }
+        }
+    }
     return 0;
 }
 

@@ -237,6 +237,22 @@ def test_slab_march_vs_oracle_and_generic(emulated_ops, D, H, W, delx):
         # source on a symmetry plane of the volume have many exact ties)
         assert close.float().mean().item() > (0.9 if name in ("base", "diag45") else 0.98), name
         assert torch.allclose(aux[b, :, 0], aux_gen[b, :, 0], rtol=1e-5, atol=1e-6), name
+    # Infinity-Cache passes: rendering a partition of the volume box by box and adding up
+    # reproduces the single-pass image and backward record (split along y, then along x)
+    Dx, Dy, Dz = V.shape
+    for boxes in (ops.volume_passes(V.shape, pass_bytes=V.numel() * 4 // 3 - 64),
+                  [[0, 0, 0, 11, Dy, Dz], [11, 0, 0, 30, Dy, Dz], [30, 0, 0, Dx, Dy, Dz]],
+                  [[0, 0, 0, Dx, Dy, 7], [0, 0, 7, Dx, Dy, Dz]]):
+        assert len(boxes) >= 2
+        outp, auxp = ops.siddon_forward_slab(V, s, t, L, (H, W), plan, shear, want_aux=True,
+                                             boxes=boxes)
+        assert rel_err(outp.numpy(), out.numpy()) < 1e-5
+        closep = (auxp - aux).abs().amax(-1) <= 1e-4 * aux.abs().max()
+        assert closep.float().mean().item() > 0.97
+    # volume-stationary brick kernel: per-brick pieces of every ray, added up
+    outb = ops.siddon_forward_bricks(V, s, t, L, (H, W))
+    for b, (name, _, _) in enumerate(SLAB_POSES):
+        assert rel_err(outb[b].numpy(), out[b].numpy()) < 1e-5, name
     # the plan never changes results: flip majors, shears and march axes
     p2 = plan.clone()
     p2[:, 0] = (p2[:, 0] + 1) % 3

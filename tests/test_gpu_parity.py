@@ -405,19 +405,49 @@ def test_slab_march_equals_generic_walk(gpu, big):
     plan, shear = slab_plan(s, t, 256, 256)
     assert plan.shape == (4, 2) and shear.shape == (4, 4)
     out, aux = ops.siddon_forward_slab(V, s, t, L, (256, 256), plan, shear, want_aux=True)
-    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5  # 4 Infinity-Cache passes
     # identical up to which axis an exact tie is attributed to: measure zero for the
     # perturbed poses 1..3 (pose 0 is the symmetric base pose, full of exact ties)
     close = ((aux - aux_ref).abs().amax(-1) <= 1e-4 * aux_ref.abs().max())
     assert close[1:].float().mean().item() > 0.999
-    assert torch.allclose(aux[..., 0], aux_ref[..., 0], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(aux[..., 0], aux_ref[..., 0], rtol=1e-4, atol=1e-5)
     # any plan gives the same image: force the other march axis / the generic fallback
     for march in (0, 1, 2):
         p2 = plan.clone()
         p2[:, 0] = march
         p2[:, 1] = 1 - p2[:, 1]
         o2 = ops.siddon_forward_slab(V, s, t, L, (256, 256), p2, -shear)[0]
-        assert rel_err(o2.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+        assert rel_err(o2.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+
+
+def test_brick_kernel_equals_generic_walk(gpu, big):
+    """Volume-stationary brick kernel (csrc/brick_core.h) at full size: same image as the
+    per-crossing walk up to the order in which the per-brick pieces are added."""
+    drr, s, t, L = big
+    V = drr.density
+    ref = ops.siddon_forward(V, s, t, L, det=(256, 256))[0]
+    out = ops.siddon_forward_bricks(V, s, t, L, (256, 256))
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 5e-6
+    again = ops.siddon_forward_bricks(V, s, t, L, (256, 256))
+    assert rel_err(again.cpu().numpy(), out.cpu().numpy()) < 2e-6  # atomics: not bit-stable
+
+
+def test_brick_kernel_small_and_ragged_volumes(gpu):
+    for dims, (H, W) in (((40, 70, 33), (24, 31)), ((32, 32, 32), (16, 16)), ((5, 9, 64), (8, 8))):
+        subject = make_subject(torch.rand(*dims, generator=torch.Generator().manual_seed(1)),
+                               spacing=(1.0, 1.5, 2.0))
+        drr = DRR(subject, sdd=300.0, height=H, width=W, delx=2.0).to(gpu)
+        # (not the exact base pose: with an odd detector its centre column runs exactly
+        # inside a voxel plane, where fp32 cannot tell the two neighbouring voxels apart)
+        rot = torch.tensor([[0.01, 0.02, -0.01], [0.6, -0.4, 0.9], [1.5, 0.2, 0.1],
+                            [0.2, 0.1, 0.0]], device=gpu)
+        xyz = torch.tensor([[0.3, 200.0, 0.2], [4.0, 180.0, -6.0], [1.0, 210.0, 2.0],
+                            [2.0, 5.0, -3.0]], device=gpu)  # last: source inside the volume
+        s, t, L = voxel_rays(drr, rot, xyz)
+        ref = oracle.siddon(drr.density.cpu().numpy(), s.cpu().numpy(), t.cpu().numpy(),
+                            L.cpu().numpy())["out"].reshape(4, -1)
+        out = ops.siddon_forward_bricks(drr.density, s, t, L, (H, W))
+        assert rel_err(out.cpu().numpy(), ref) < FWD_TOL, dims
 
 
 @pytest.mark.parametrize("H,W", [(70, 45), (64, 64), (33, 130)])

@@ -78,8 +78,10 @@ def main():
               f"({alg / med / 1e6 / 8000 * 100:5.1f}% of 8 TB/s)", flush=True)
         return med
 
-    def slab_case(label, s, t, L, xcd, aux=False):
-        lib.cdll.ddrr_set_xcd_swizzle(int(xcd))
+    def slab_case(label, s, t, L, xcd, aux=False, passes=None):
+        lib.cdll.ddrr_set_xcd_swizzle_slab(int(xcd))
+        boxes = None if passes is None else ops.volume_passes(
+            V.shape, pass_bytes=-(-V.numel() * 4 // passes))
         B = t.shape[0]
         _, _, nv = ops.siddon_forward(V, s, t, L, count_voxels=True, det=(H, H))
         nvox = int(nv.sum())
@@ -87,15 +89,32 @@ def main():
         plan, shear = slab_plan(s, t, H, H)
         tp, _ = timeit(lambda: slab_plan(s, t, H, H), reps=5)
         med, best = timeit(lambda: ops.siddon_forward_slab(V, s, t, L, (H, H), plan, shear,
-                                                           want_aux=aux))
+                                                           want_aux=aux, boxes=boxes))
         ref = ops.siddon_forward(V, s, t, L, det=(H, H))[0]
-        out = ops.siddon_forward_slab(V, s, t, L, (H, H), plan, shear)[0]
+        out = ops.siddon_forward_slab(V, s, t, L, (H, H), plan, shear, boxes=boxes)[0]
+        label = f"{label} p{len(boxes) if boxes else 'auto'}"
         err = ((out - ref).abs().max() / ref.abs().max()).item()
         print(f"{label:34s} SLAB march  xcd {int(xcd)} aux {int(aux)} B {B:4d} "
               f"vox/ray {nvox / (B * H * H):6.1f}  {med:8.3f} ms (best {best:7.3f})  "
               f"{B / med * 1e3:9.0f} DRR/s  {alg / med / 1e6:8.1f} GB/s alg "
               f"({alg / med / 1e6 / 8000 * 100:5.1f}% of 8 TB/s)  plan {tp:.3f} ms  "
               f"err vs generic {err:.1e}", flush=True)
+        return med
+
+    def brick_case(label, s, t, L):
+        B = t.shape[0]
+        _, _, nv = ops.siddon_forward(V, s, t, L, count_voxels=True, det=(H, H))
+        nvox = int(nv.sum())
+        alg = 4 * nvox + B * H * H * 20 + 12 * B
+        med, best = timeit(lambda: ops.siddon_forward_bricks(V, s, t, L, (H, H)))
+        ref = ops.siddon_forward(V, s, t, L, det=(H, H))[0]
+        out = ops.siddon_forward_bricks(V, s, t, L, (H, H))
+        err = ((out - ref).abs().max() / ref.abs().max()).item()
+        print(f"{label:34s} BRICK (LDS) B {B:4d} "
+              f"vox/ray {nvox / (B * H * H):6.1f}  {med:8.3f} ms (best {best:7.3f})  "
+              f"{B / med * 1e3:9.0f} DRR/s  {alg / med / 1e6:8.1f} GB/s alg "
+              f"({alg / med / 1e6 / 8000 * 100:5.1f}% of 8 TB/s)  err vs generic {err:.1e}",
+              flush=True)
         return med
 
     base = rays(drr, torch.zeros(1, 3, device=dev), torch.tensor([[0.0, 850.0, 0.0]], device=dev))
@@ -112,12 +131,20 @@ def main():
         fwd_case("base pose x32", *rep, tile, True)
     fwd_case("base pose x32", *rep, (16, 4), False)
     for xcd in (1, 0):
+        slab_case("base pose x32", *rep, xcd, passes=1)
         slab_case("base pose x32", *rep, xcd)
+    brick_case("base pose x32", *rep)
+    brick_case("base pose B=1", *base)
     print("## Siddon forward: 32 perturbed poses (bench workload)")
+    brick_case("perturbed x32", *pert32)
+    brick_case("perturbed x8", *(x[:8].contiguous() for x in pert32))
+    brick_case("perturbed x128", *rays(drr, *poses(128, 3, dev)))
     for xcd in (1, 0):
-        slab_case("perturbed x32", *pert32, xcd)
-    slab_case("perturbed x32 + aux", *pert32, 1, aux=True)
-    slab_case("base pose B=1", *base, 1)
+        for passes in (1, 2, 4, 8, 16):
+            slab_case("perturbed x32", *pert32, xcd, passes=passes)
+    slab_case("perturbed x32 + aux", *pert32, 0, aux=True)
+    slab_case("perturbed x32 + aux", *pert32, 0, aux=True, passes=1)
+    slab_case("base pose B=1", *base, 0)
     for tile in tiles:
         fwd_case("perturbed x32", *pert32, tile, True)
     fwd_case("perturbed x32", *pert32, (16, 4), False)
@@ -129,11 +156,12 @@ def main():
             one = tuple(x[b:b + 1].contiguous() for x in pert32)
             rep1 = tuple(x.expand(16, *x.shape[1:]).contiguous() for x in one)
             fwd_case(f"pose {b} x16", *rep1, (16, 4), True)
-            slab_case(f"pose {b} x16", *rep1, True)
+            slab_case(f"pose {b} x16", *rep1, False)
         big = rays(drr, *poses(128, 3, dev))
         fwd_case("perturbed x128", *big, (16, 4), True)
-        slab_case("perturbed x128", *big, True)
+        slab_case("perturbed x128", *big, False, passes=1)
         slab_case("perturbed x128", *big, False)
+        slab_case("perturbed x128", *big, False, passes=8)
 
     lib.cdll.ddrr_set_xcd_swizzle(1)
     s, t, L = pert32
