@@ -406,11 +406,19 @@ def test_slab_march_equals_generic_walk(gpu, big):
     assert plan.shape == (4, 2) and shear.shape == (4, 4)
     out, aux = ops.siddon_forward_slab(V, s, t, L, (256, 256), plan, shear, want_aux=True)
     assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5  # 4 Infinity-Cache passes
-    # identical up to which axis an exact tie is attributed to: measure zero for the
-    # perturbed poses 1..3 (pose 0 is the symmetric base pose, full of exact ties)
+    # identical up to which axis a crossing pair that ties IN FP32 is attributed to.  At
+    # 512^3 a ray has ~1500 crossings ~7e-4 apart in alpha, so ~1-2 % of the rays hold one
+    # pair closer than an fp32 ulp (measured 1.35 %); on those the two walks split
+    # V_before - V_after differently between the two axes (the reference's own split there
+    # is its sort order).  Pose 0 is the symmetric base pose, full of exact ties.
     close = ((aux - aux_ref).abs().amax(-1) <= 1e-4 * aux_ref.abs().max())
-    assert close[1:].float().mean().item() > 0.999
+    assert close[1:].float().mean().item() > 0.97
     assert torch.allclose(aux[..., 0], aux_ref[..., 0], rtol=1e-4, atol=1e-5)
+    # what does not depend on the attribution: sum_a S0_a = 0 and sum_a S1_a = I per ray
+    scale = aux_ref.abs().max()
+    for a in (aux, aux_ref):
+        assert (a[..., 1:4].sum(-1).abs().max() <= 2e-5 * scale)
+        assert ((a[..., 4:7].sum(-1) - a[..., 0]).abs().max() <= 2e-5 * scale)
     # any plan gives the same image: force the other march axis / the generic fallback
     for march in (0, 1, 2):
         p2 = plan.clone()
