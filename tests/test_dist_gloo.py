@@ -1,0 +1,102 @@
+"""World-size-2 run of the pose-sharded sweep (diffdrr_amd/dist.py) on CPU over gloo:
+the N>1 path of bench.py / SURVEY.md section 8(e) without GPUs.  Each rank renders its
+slice of the pose batch (through the host emulation of the kernels, test-only) and the
+per-pose similarities are all_gathered; the result must equal the single-process sweep."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _scene():
+    from diffdrr_amd import DRR, NormalizedCrossCorrelation2d
+    from diffdrr_amd.data import synthetic_subject
+
+    drr = DRR(synthetic_subject(24, kind="phantom", seed=0), sdd=300.0, height=20, width=16,
+              delx=2.0)
+    g = torch.Generator().manual_seed(5)
+    P = 7  # ragged over 2 ranks: 4 + 3
+    rot = (torch.rand(P, 3, generator=g) - 0.5) * 0.6
+    xyz = torch.tensor([0.0, 150.0, 0.0]) + (torch.rand(P, 3, generator=g) - 0.5) * 10.0
+    return drr, NormalizedCrossCorrelation2d(), rot, xyz
+
+
+def _patch_ops():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import build_emu
+    from diffdrr_amd import ops
+    from diffdrr_amd._lib import DdrrLibrary
+
+    emu = DdrrLibrary(build_emu())
+    ops._require_gpu = lambda volume: None
+    ops._launch = lambda name, device, *a: emu.call(name, *a, None)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    _patch_ops()
+    from diffdrr_amd import dist as ddist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        drr, ncc, rot, xyz = _scene()
+        with torch.no_grad():
+            fixed = drr(torch.zeros(1, 3), torch.tensor([[0.0, 150.0, 0.0]]),
+                        parameterization="euler_angles", convention="ZXY")
+        vals = ddist.sweep(drr, ncc, fixed, rot, xyz, chunk=3)
+        lo, hi = ddist.shard_bounds(rot.shape[0], rank, world)
+        q.put((rank, vals.tolist(), (lo, hi)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_bounds_partition():
+    from diffdrr_amd.dist import shard_bounds
+
+    for n in (0, 1, 7, 8, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            cuts = [shard_bounds(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_pose_sharded_sweep_world2_matches_single_process(emulated_ops):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference of the same sweep (world = 1 path of the same function)
+    from diffdrr_amd import dist as ddist
+
+    drr, ncc, rot, xyz = _scene()
+    with torch.no_grad():
+        fixed = drr(torch.zeros(1, 3), torch.tensor([[0.0, 150.0, 0.0]]),
+                    parameterization="euler_angles", convention="ZXY")
+    ref = ddist.sweep(drr, ncc, fixed, rot, xyz, chunk=3)
+    assert got[0][2] == (0, 4) and got[1][2] == (4, 7)
+    for _, vals, _ in got:  # every rank holds the full, identical result
+        assert torch.allclose(torch.tensor(vals), ref, rtol=0, atol=1e-6)
+    assert ref.shape == (7,) and torch.isfinite(ref).all()

@@ -16,6 +16,7 @@ ap.add_argument("--tile", default="16x4")
 ap.add_argument("--xcd", type=int, default=1)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--size", type=int, default=512)
+ap.add_argument("--kernel", default="generic", choices=["generic", "slab", "brick"])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 D, H = a.size, 256
@@ -32,6 +33,15 @@ elif a.case.startswith("same"):  # one perturbed pose replicated
     one = tuple(x[4:5] for x in rays(drr, *poses(8, 2, dev)))
     s, t, L = (x.expand(B, *x.shape[1:]).contiguous() for x in one)
 th, tw = (int(v) for v in a.tile.split("x"))
+if a.kernel == "slab":
+    from diffdrr_amd.plan import slab_plan
+
+    plan, shear = slab_plan(s, t, H, H)
 for _ in range(a.reps):
-    ops.siddon_forward(drr.density, s, t, L, det=(H, H), tile=(th, tw))
+    if a.kernel == "generic":
+        ops.siddon_forward(drr.density, s, t, L, det=(H, H), tile=(th, tw))
+    elif a.kernel == "slab":
+        ops.siddon_forward_slab(drr.density, s, t, L, (H, H), plan, shear)
+    else:
+        ops.siddon_forward_bricks(drr.density, s, t, L, (H, H))
 torch.cuda.synchronize()
