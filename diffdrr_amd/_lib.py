@@ -15,11 +15,13 @@ from ctypes import c_float, c_int, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffdrr_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 REDUCE_SUM, REDUCE_MAX = 0, 1
 LOOKUP_STEP, LOOKUP_MID_NEAREST, LOOKUP_MID_TRILINEAR = 0, 1, 2
 SIDDON_AUX = 8
+AUX_INTERLEAVED, AUX_PLANAR = 0, 1
+BRICK_AUX_PLANES = 5
 
 _P, _I, _F = c_void_p, c_int, c_float
 
@@ -29,8 +31,8 @@ _SIGNATURES = {
                             _I, _I, _P, _P, _P, _P],
     "ddrr_siddon_forward_slab": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _I, _P,
                                  _I, _P, _P, _P],
-    "ddrr_siddon_forward_bricks": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P],
-    "ddrr_siddon_backward_rays": [_P, _P, _P, _I, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P],
+    "ddrr_siddon_forward_bricks": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P],
+    "ddrr_siddon_backward_rays": [_P, _I, _P, _P, _I, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P],
     "ddrr_siddon_backward_volume": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _I, _I,
                                     _I, _I, _I, _P, _P],
     "ddrr_siddon_forward_channels": [_P, _P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _F, _F, _I,

@@ -51,12 +51,24 @@ DDRR_HD Box brick_box(const Dims D, const BrickGrid &g, int id) {
     return b;
 }
 
-DDRR_HD Store brick_store(const Box &b) {
+// How a brick is laid out in LDS: z contiguous, rows and planes padded so that the
+// voxels a wave reads in one step (neighbouring rays: a small patch perpendicular to the
+// rays) spread over the 32 banks.  Strides in floats.
+struct BrickLayout {
+    int sy, sx;
+};
+
+DDRR_HD int brick_floats(const BrickLayout &lay) { return lay.sx * BRICK; }
+
+DDRR_HD Store brick_store(const Box &b, const BrickLayout &lay) {
     Store st;
     st.dims = Dims{BRICK, BRICK, BRICK};
     st.org[0] = b.lo[0];
     st.org[1] = b.lo[1];
     st.org[2] = b.lo[2];
+    st.stride[0] = lay.sx * 4;
+    st.stride[1] = lay.sy * 4;
+    st.stride[2] = 4;
     return st;
 }
 
@@ -133,8 +145,20 @@ DDRR_HD PixBox project_brick(const float *src, const float *tgt, int det_h, int 
 }
 
 struct LdsFetch {
-    const float *brick;  // BRICK^3 floats, [x][y][z]
-    DDRR_HD float operator()(unsigned boff) const { return brick[boff >> 2]; }
+    const float *brick;  // BrickLayout-strided floats
+    DDRR_HD float operator()(unsigned boff) const {
+        return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(brick) + boff);
+    }
 };
+
+// Candidate pixel `local` (row-major index into the pixel box) -> (i, j).
+DDRR_HD void pixbox_pixel(int i0, int j0, int w, float inv_w, int local, int &i, int &j) {
+    // exact for the box sizes that occur (local < 2^22): no integer division
+    int di = (int)(((float)local + 0.5f) * inv_w);
+    di -= (di * w > local) ? 1 : 0;
+    di += ((di + 1) * w <= local) ? 1 : 0;
+    i = i0 + di;
+    j = j0 + (local - di * w);
+}
 
 }  // namespace ddrr

@@ -131,8 +131,8 @@ template <int REDUCE>
 __global__ __launch_bounds__(kBlock) void siddon_bwd_rays_kernel(
     const float *__restrict__ aux, const float *__restrict__ grad_out,
     const float *__restrict__ source, int src_n, const float *__restrict__ target,
-    const float *__restrict__ img, long R, int N, float eps, float *__restrict__ g_source,
-    float *__restrict__ g_target, float *__restrict__ g_img) {
+    const float *__restrict__ img, long R, int N, float eps, int planar,
+    float *__restrict__ g_source, float *__restrict__ g_target, float *__restrict__ g_img) {
     const long r = (long)blockIdx.x * kBlock + threadIdx.x;
     if (r >= R) return;
     const long b = r / N;
@@ -140,9 +140,26 @@ __global__ __launch_bounds__(kBlock) void siddon_bwd_rays_kernel(
     const float *sp = source + (b * src_n + (src_n == 1 ? 0 : n)) * 3;
     const float *tp = target + r * 3;
     const float s[3] = {sp[0], sp[1], sp[2]}, t[3] = {tp[0], tp[1], tp[2]};
-    const float4 *a4 = reinterpret_cast<const float4 *>(aux + r * SIDDON_AUX);
-    const float4 lo = a4[0], hi = a4[1];
-    const float rec[SIDDON_AUX] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    float rec[SIDDON_AUX];
+    if (planar) {
+        // record of the brick kernel: planes I, S0x, S0z, S1x, S1z of R floats each; the y
+        // components follow from sum_a S0_a = 0, sum_a S1_a = I
+        const float I = aux[r], S0x = aux[R + r], S0z = aux[2 * R + r];
+        const float S1x = aux[3 * R + r], S1z = aux[4 * R + r];
+        rec[0] = I;
+        rec[1] = S0x;
+        rec[2] = -(S0x + S0z);
+        rec[3] = S0z;
+        rec[4] = S1x;
+        rec[5] = I - (S1x + S1z);
+        rec[6] = S1z;
+        rec[7] = 0.f;
+    } else {
+        const float4 *a4 = reinterpret_cast<const float4 *>(aux + r * SIDDON_AUX);
+        const float4 lo = a4[0], hi = a4[1];
+        rec[0] = lo.x, rec[1] = lo.y, rec[2] = lo.z, rec[3] = lo.w;
+        rec[4] = hi.x, rec[5] = hi.y, rec[6] = hi.z, rec[7] = hi.w;
+    }
     const float g = grad_out[r];
     const float L = img ? img[r] : 1.f;
     float gs[3], gt[3];
@@ -299,12 +316,23 @@ __global__ __launch_bounds__(kBlock) void siddon_fwd_slab_kernel(SlabArgs p,
 }
 
 // ------------------------------------------------- Siddon, brick-stationary
-// One workgroup per 32^3 brick: stage the brick in LDS, then trace from LDS the part
-// of every ray of every pose that crosses it (brick_core.h).  1024 threads, 128 KiB
-// of LDS -> one workgroup per CU, 4 waves per SIMD.
+// One workgroup per 32^3 brick: stage the brick in LDS (padded layout), then trace from
+// LDS the part of every ray of every pose that crosses it (brick_core.h).  1024 threads
+// and ~150 KiB of LDS -> one workgroup per CU, 4 waves per SIMD.
+//
+// Work distribution inside the workgroup (no block-wide barriers in the hot loop):
+//  * a unit = 64 consecutive candidate pixels of one pose's projected pixel box; waves
+//    pull units from one LDS counter;
+//  * phase A (all 64 lanes): clip the candidate ray against the brick; the hits are
+//    compacted (ballot + mbcnt) into the wave's private LDS queue;
+//  * phase B: as soon as the queue holds 64 hits they are walked with every lane busy;
+//    the remainder is drained at the end.  A queue entry is (pose, pixel).
 
 constexpr int kBrickThreads = 1024;
-constexpr int kPoseChunk = 128;
+constexpr int kBrickWaves = kBrickThreads / 64;
+constexpr int kPoseChunk = 64;
+constexpr int kQueueCap = 128;
+constexpr int kBrickAuxPlanes = 5;  // I, S0x, S0z, S1x, S1z (y follows from the sums)
 
 struct BrickArgs {
     const float *vol;
@@ -314,20 +342,58 @@ struct BrickArgs {
     const float *img;
     int B, det_h, det_w;
     float shift, eps;
+    BrickLayout lay;
+    long aux_plane;  // elements per plane of the planar backward record (B * N)
 };
 
+inline size_t brick_lds_bytes(const BrickLayout &lay) {
+    return (size_t)brick_floats(lay) * 4 + (size_t)kBrickWaves * kQueueCap * 8 +
+           (size_t)(kPoseChunk * 4 + kPoseChunk + 1 + 1) * 4;
+}
+
+template <bool AUX>
+__device__ __forceinline__ void brick_item(const BrickArgs &p, const float *brick, const Store &st,
+                                           const Box &box, int b, int pix, float *__restrict__ out,
+                                           float *__restrict__ aux) {
+    const long r = (long)b * ((long)p.det_h * p.det_w) + pix;
+    float s[3], t[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        s[a] = p.source[(long)b * 3 + a];
+        t[a] = p.target[r * 3 + a];
+    }
+    const SiddonSetup q = siddon_setup_fast(box, s, t, p.shift, p.eps);
+    float rec[SIDDON_AUX];
+    const float I = siddon_walk_t<REDUCE_SUM, AUX, false>(LdsFetch{brick}, st, box, s, p.shift, q,
+                                                          rec, nullptr);
+    const float L = p.img ? p.img[r] : 1.f;
+    unsafeAtomicAdd(out + r, L * I);
+    if (AUX) {
+        unsafeAtomicAdd(aux + r, I);
+        unsafeAtomicAdd(aux + p.aux_plane + r, rec[1]);
+        unsafeAtomicAdd(aux + 2 * p.aux_plane + r, rec[3]);
+        unsafeAtomicAdd(aux + 3 * p.aux_plane + r, rec[4]);
+        unsafeAtomicAdd(aux + 4 * p.aux_plane + r, rec[6]);
+    }
+}
+
+template <bool AUX>
 __global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
-    BrickArgs p, float *__restrict__ out) {
-    __shared__ float brick[BRICK * BRICK * BRICK];
-    __shared__ int pbox[kPoseChunk][4];
-    __shared__ int pref[kPoseChunk + 1];
-    const int tid = threadIdx.x;
+    BrickArgs p, float *__restrict__ out, float *__restrict__ aux) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float *brick = reinterpret_cast<float *>(smem_raw);
+    unsigned *queue = reinterpret_cast<unsigned *>(brick + brick_floats(p.lay));
+    int *pbox = reinterpret_cast<int *>(queue + kBrickWaves * kQueueCap * 2);  // [chunk][4]
+    int *pref = pbox + kPoseChunk * 4;                                          // [chunk + 1]
+    int *counter = pref + kPoseChunk + 1;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const BrickGrid bg = brick_grid(p.D);
     const Box box = brick_box(p.D, bg, blockIdx.x);
-    const Store st = brick_store(box);
+    const Store st = brick_store(box, p.lay);
     const int N = p.det_h * p.det_w;
 
-    // stage the brick: 32 x 32 rows of 32 floats (one 128-byte line each)
+    // stage the brick: 32 x 32 rows of 32 floats (one 128-byte line each), zero padded
     for (int row = tid >> 3; row < BRICK * BRICK; row += kBrickThreads >> 3) {
         const int lx = row / BRICK, ly = row - lx * BRICK, q4 = (tid & 7) * 4;
         const int x = box.lo[0] + lx, y = box.lo[1] + ly, z = box.lo[2] + q4;
@@ -338,56 +404,89 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
             for (int k = 0; k < 4; ++k)
                 if (z + k < box.hi[2]) v[k] = g[k];
         }
-        float *d = brick + (lx * BRICK + ly) * BRICK + q4;
+        float *d = brick + lx * p.lay.sx + ly * p.lay.sy + q4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) d[k] = v[k];
     }
 
+    volatile unsigned *myq = queue + wave * kQueueCap * 2;
+    int qn = 0;  // hits waiting in this wave's queue (wave-uniform)
+
     for (int b0 = 0; b0 < p.B; b0 += kPoseChunk) {
         const int nb = p.B - b0 < kPoseChunk ? p.B - b0 : kPoseChunk;
-        __syncthreads();  // brick staged / previous chunk's tables consumed
+        __syncthreads();  // brick staged / previous chunk's tables no longer in use
         if (tid < nb) {
             const PixBox pb = project_brick(p.source + (long)(b0 + tid) * 3,
                                             p.target + (long)(b0 + tid) * N * 3, p.det_h,
                                             p.det_w, box, p.shift);
-            pbox[tid][0] = pb.i0;
-            pbox[tid][1] = pb.j0;
-            pbox[tid][2] = pb.j1 - pb.j0 + 1;
-            pbox[tid][3] = pixbox_count(pb);
+            pbox[tid * 4 + 0] = pb.i0;
+            pbox[tid * 4 + 1] = pb.j0;
+            pbox[tid * 4 + 2] = pb.j1 - pb.j0 + 1;
+            pbox[tid * 4 + 3] = pixbox_count(pb);
         }
+        if (tid == 0) *counter = 0;
         __syncthreads();
         if (tid == 0) {
             int acc = 0;
             for (int k = 0; k < nb; ++k) {
                 pref[k] = acc;
-                acc += pbox[k][3];
+                acc += (pbox[k * 4 + 3] + 63) >> 6;
             }
             pref[nb] = acc;
         }
         __syncthreads();
-        const int total = pref[nb];
-        for (int c = tid; c < total; c += kBrickThreads) {
-            // pose of candidate c: last k with pref[k] <= c
-            int lo = 0, hi = nb;
+        const int units = pref[nb];
+        for (;;) {
+            int u = 0;
+            if (lane == 0) u = atomicAdd(counter, 1);
+            u = __builtin_amdgcn_readfirstlane(u);
+            if (u >= units) break;
+            int lo = 0, hi = nb;  // pose of unit u: last k with pref[k] <= u
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
-                if (pref[mid] <= c) lo = mid;
+                if (pref[mid] <= u) lo = mid;
                 else hi = mid;
             }
-            const int local = c - pref[lo], w = pbox[lo][2];
-            const int di = local / w;
-            const int i = pbox[lo][0] + di, j = pbox[lo][1] + (local - di * w);
-            const long r = (long)(b0 + lo) * N + (long)i * p.det_w + j;
-            float s[3], t[3];
+            const int b = b0 + lo;
+            const int i0 = pbox[lo * 4], j0 = pbox[lo * 4 + 1], w = pbox[lo * 4 + 2];
+            const int count = pbox[lo * 4 + 3];
+            const int local = (u - pref[lo]) * 64 + lane;
+            bool hit = false;
+            int pix = 0;
+            if (local < count) {
+                int i, j;
+                pixbox_pixel(i0, j0, w, 1.0f / (float)w, local, i, j);
+                pix = i * p.det_w + j;
+                const long r = (long)b * N + pix;
+                float s[3], t[3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                s[a] = p.source[(long)(b0 + lo) * 3 + a];
-                t[a] = p.target[r * 3 + a];
+                for (int a = 0; a < 3; ++a) {
+                    s[a] = p.source[(long)b * 3 + a];
+                    t[a] = p.target[r * 3 + a];
+                }
+                hit = siddon_setup_fast(box, s, t, p.shift, p.eps).hit;
             }
-            const float I = siddon_forward_ray_t<REDUCE_SUM, false, false>(
-                LdsFetch{brick}, st, box, s, t, p.shift, p.eps, nullptr, nullptr);
-            if (I != 0.f) unsafeAtomicAdd(out + r, (p.img ? p.img[r] : 1.f) * I);
+            const unsigned long long mask = __ballot(hit);
+            if (hit) {
+                const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi(
+                                         (unsigned)(mask >> 32),
+                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                myq[2 * pos] = (unsigned)b;
+                myq[2 * pos + 1] = (unsigned)pix;
+            }
+            qn += __popcll(mask);
+            __builtin_amdgcn_wave_barrier();
+            if (qn >= 64) {
+                qn -= 64;
+                const int b_it = (int)myq[2 * (qn + lane)], pix_it = (int)myq[2 * (qn + lane) + 1];
+                brick_item<AUX>(p, brick, st, box, b_it, pix_it, out, aux);
+                __builtin_amdgcn_wave_barrier();
+            }
         }
+    }
+    if (lane < qn) {
+        const int b_it = (int)myq[2 * lane], pix_it = (int)myq[2 * lane + 1];
+        brick_item<AUX>(p, brick, st, box, b_it, pix_it, out, aux);
     }
 }
 
@@ -477,6 +576,9 @@ int g_xcd_swizzle = 1;
 // sweep the same poses at the same time, which the shared Infinity Cache likes
 // (profiles/r01/sweep_v2_slab_512.txt: 4.8 ms vs 6.8 ms on the bench workload).
 int g_xcd_swizzle_slab = 0;
+// LDS layout of a brick (floats): rows padded 32 -> 33, planes 32*33 -> 1057, so that
+// x-, y- and z-neighbours all fall in different banks.
+BrickLayout g_brick_layout = {33, 32 * 33 + 1};
 
 int check_common(const float *volume, int dx, int dy, int dz, const float *source, int src_n,
                  const float *target, int B, int N) {
@@ -531,6 +633,14 @@ int ddrr_set_xcd_swizzle(int on) {
     int old = g_xcd_swizzle;
     g_xcd_swizzle = on ? 1 : 0;
     return old;
+}
+// Experiment knob: LDS strides (floats) of a staged brick; sy >= 32, sx >= 32 * sy.
+int ddrr_set_brick_layout(int sy, int sx) {
+    if (sy < BRICK || sx < BRICK * sy) return -1;
+    BrickLayout lay = {sy, sx};
+    if (brick_lds_bytes(lay) > 160 * 1024) return -1;
+    g_brick_layout = lay;
+    return 0;
 }
 int ddrr_set_xcd_swizzle_slab(int on) {
     int old = g_xcd_swizzle_slab;
@@ -636,7 +746,7 @@ int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const 
 
 int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
                                const float *target, const float *img, int B, int det_h,
-                               int det_w, float voxel_shift, float eps, float *out,
+                               int det_w, float voxel_shift, float eps, float *out, float *aux,
                                void *stream) {
     const int N = det_h * det_w;
     if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
@@ -645,6 +755,8 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * N, st);
+    if (e == hipSuccess && aux)
+        e = hipMemsetAsync(aux, 0, sizeof(float) * (size_t)kBrickAuxPlanes * B * N, st);
     if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
     BrickArgs p;
     p.vol = volume;
@@ -657,28 +769,49 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     p.det_w = det_w;
     p.shift = voxel_shift;
     p.eps = eps;
+    p.lay = g_brick_layout;
+    p.aux_plane = (long)B * N;
+    const size_t lds = brick_lds_bytes(p.lay);
+    static bool attr_set = false;  // raise the dynamic-LDS limit once per process
+    if (!attr_set) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&siddon_fwd_brick_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&siddon_fwd_brick_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute");
+        attr_set = true;
+    }
     const BrickGrid bg = brick_grid(p.D);
-    hipLaunchKernelGGL(siddon_fwd_brick_kernel, dim3(bg.nx * bg.ny * bg.nz), dim3(kBrickThreads),
-                       0, st, p, out);
+    const dim3 grid(bg.nx * bg.ny * bg.nz), block(kBrickThreads);
+    if (aux)
+        hipLaunchKernelGGL(siddon_fwd_brick_kernel<true>, grid, block, lds, st, p, out, aux);
+    else
+        hipLaunchKernelGGL(siddon_fwd_brick_kernel<false>, grid, block, lds, st, p, out, aux);
     return finish("ddrr_siddon_forward_bricks");
 }
 
-int ddrr_siddon_backward_rays(const float *aux, const float *grad_out, const float *source,
-                              int src_n, const float *target, const float *img, int B, int N,
-                              float eps, int reduce_mode, float *g_source, float *g_target,
-                              float *g_img, void *stream) {
+int ddrr_siddon_backward_rays(const float *aux, int aux_layout, const float *grad_out,
+                              const float *source, int src_n, const float *target,
+                              const float *img, int B, int N, float eps, int reduce_mode,
+                              float *g_source, float *g_target, float *g_img, void *stream) {
     if (!aux || !grad_out || !source || !target) return fail(-1, "null pointer");
     if (src_n != 1 && src_n != N) return fail(-1, "src_n must be 1 or N");
+    if (aux_layout != DDRR_AUX_INTERLEAVED && aux_layout != DDRR_AUX_PLANAR)
+        return fail(-1, "bad aux_layout");
+    if (aux_layout == DDRR_AUX_PLANAR && reduce_mode != DDRR_REDUCE_SUM)
+        return fail(-1, "the planar record exists for reduce sum only");
     const long R = (long)B * N;
     if (R == 0) return 0;
     const dim3 grid((unsigned)((R + kBlock - 1) / kBlock)), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
     if (reduce_mode == DDRR_REDUCE_SUM)
         hipLaunchKernelGGL((siddon_bwd_rays_kernel<REDUCE_SUM>), grid, block, 0, st, aux, grad_out,
-                           source, src_n, target, img, R, N, eps, g_source, g_target, g_img);
+                           source, src_n, target, img, R, N, eps, aux_layout, g_source, g_target,
+                           g_img);
     else if (reduce_mode == DDRR_REDUCE_MAX)
         hipLaunchKernelGGL((siddon_bwd_rays_kernel<REDUCE_MAX>), grid, block, 0, st, aux, grad_out,
-                           source, src_n, target, img, R, N, eps, g_source, g_target, g_img);
+                           source, src_n, target, img, R, N, eps, 0, g_source, g_target, g_img);
     else
         return fail(-1, "bad reduce_mode");
     return finish("ddrr_siddon_backward_rays");

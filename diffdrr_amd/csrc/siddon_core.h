@@ -47,14 +47,18 @@ DDRR_HD Box full_box(const Dims D) {
 // memory (dims = volume dims, org = 0), or a brick staged in LDS (dims = the
 // brick's storage dims, org = the brick's first voxel).  Offsets are in bytes.
 struct Store {
-    Dims dims;
-    int org[3];
+    Dims dims;      // extent of the stored box in voxels (bounds the walk's trip count)
+    int org[3];     // first voxel of the stored box
+    int stride[3];  // BYTE strides of one voxel step along x, y, z
 };
 
 DDRR_HD Store global_store(const Dims D) {
     Store st;
     st.dims = D;
     st.org[0] = st.org[1] = st.org[2] = 0;
+    st.stride[0] = D.y * D.z * 4;
+    st.stride[1] = D.z * 4;
+    st.stride[2] = 4;
     return st;
 }
 
@@ -92,6 +96,47 @@ DDRR_HD SiddonSetup siddon_setup(const Box &box, const float s[3], const float t
     return q;
 }
 
+// Reciprocal for the per-(ray, brick) setup of the volume-stationary kernel, where the
+// setup runs ~25x per ray: v_rcp_f32 + one Newton step (<= 1 ulp) instead of the
+// IEEE division sequence.  Deterministic in its input, so two bricks that share a plane
+// still evaluate that plane's alpha identically.
+DDRR_HD float fast_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float r1 = fmaf(fmaf(-x, r0, 1.0f), r0, r0);
+    return (r1 == r1) ? r1 : r0;  // x = 0 or inf: keep the hardware's inf / 0
+#else
+    return 1.0f / x;
+#endif
+}
+
+DDRR_HD SiddonSetup siddon_setup_fast(const Box &box, const float s[3], const float t[3],
+                                      float shift, float eps) {
+    SiddonSetup q;
+    q.entry = -INFINITY;
+    q.exit = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        q.d[a] = (t[a] - s[a]) + eps;
+        q.inv[a] = fast_rcp(q.d[a]);
+        // (-shift - s) / d by one residual correction of the product: the offset of a
+        // whole axis' planes against the other two axes' is what the integral is most
+        // sensitive to (dI = S0_a * dalpha), so c is kept at division accuracy
+        const float num = -shift - s[a];
+        const float c0 = num * q.inv[a];
+        const float c1 = fmaf(fmaf(-c0, q.d[a], num), q.inv[a], c0);
+        q.c[a] = (c1 == c1) ? c1 : c0;
+        const float a0 = fmaf((float)box.lo[a], q.inv[a], q.c[a]);
+        const float aD = fmaf((float)box.hi[a], q.inv[a], q.c[a]);
+        q.lo[a] = fminf(a0, aD);
+        q.hi[a] = fmaxf(a0, aD);
+        q.entry = fmaxf(q.entry, q.lo[a]);
+        q.exit = fminf(q.exit, q.hi[a]);
+    }
+    q.hit = q.entry < q.exit;  // false for NaN
+    return q;
+}
+
 // State of the 3-way merge once the ray is inside the volume.
 struct SiddonWalk {
     float kf[3];    // index of the next plane to be crossed, per axis (as float)
@@ -104,7 +149,7 @@ struct SiddonWalk {
 DDRR_HD SiddonWalk siddon_enter(const Store &st, const Box &box, const float s[3], float shift,
                                 const SiddonSetup &q) {
     SiddonWalk w;
-    const int stride[3] = {st.dims.y * st.dims.z * 4, st.dims.z * 4, 4};
+    const int stride[3] = {st.stride[0], st.stride[1], st.stride[2]};
     w.off = 0u;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -114,7 +159,22 @@ DDRR_HD SiddonWalk siddon_enter(const Store &st, const Box &box, const float s[3
         float u = floorf(fmaf(q.entry, q.d[a], s[a] + shift));
         u = fminf(fmaxf(u, (float)box.lo[a]), (float)(box.hi[a] - 1));
         int i = (int)u;
-        if (q.lo[a] == q.entry) i = pos ? box.lo[a] : box.hi[a] - 1;
+        if (q.lo[a] == q.entry) {
+            i = pos ? box.lo[a] : box.hi[a] - 1;
+        } else {
+            // The cell must agree with the ORDER OF THE ALPHAS the walk steps by, not only
+            // with the position: for a ray gliding along a plane of this axis (|d_a| tiny)
+            // a position error of 1e-5 voxel is an alpha error of any size, and a cell on
+            // the wrong side of an already-passed plane would open with a segment of
+            // negative length (or skip one).  Move one cell if the plane ahead is already
+            // behind `entry`, or the plane behind is still ahead of it.
+            const float a_ahead = fmaf((float)(i + (pos ? 1 : 0)), q.inv[a], q.c[a]);
+            const float a_behind = fmaf((float)(i + (pos ? 0 : 1)), q.inv[a], q.c[a]);
+            const int di = pos ? 1 : -1;
+            if (a_ahead < q.entry) i += di;
+            else if (a_behind > q.entry) i -= di;
+            i = i < box.lo[a] ? box.lo[a] : (i > box.hi[a] - 1 ? box.hi[a] - 1 : i);
+        }
         w.off += (unsigned)((i - st.org[a]) * stride[a]);
         w.kf[a] = (float)(i + (pos ? 1 : 0));
         w.dirf[a] = pos ? 1.f : -1.f;
@@ -214,11 +274,10 @@ DDRR_HD SiddonSeg siddon_step(SiddonGen &g, const SiddonSetup &q) {
 // occupancy provides: the walk is a pure gather whose only lever against HBM /
 // Infinity-Cache latency is the number of outstanding requests.
 template <int REDUCE, bool AUX, bool COUNT, class Fetch>
-DDRR_HD float siddon_forward_ray_t(const Fetch &fetch, const Store &st, const Box &box,
-                                   const float s[3], const float t[3], float shift, float eps,
-                                   float *aux, int *count) {
+DDRR_HD float siddon_walk_t(const Fetch &fetch, const Store &st, const Box &box,
+                            const float s[3], float shift, const SiddonSetup &q, float *aux,
+                            int *count) {
     const Dims D = st.dims;
-    const SiddonSetup q = siddon_setup(box, s, t, shift, eps);
     float acc = 0.f;  // sum: integral; max: best term (>= 0: segments outside the volume are 0)
     int nvis = 0;
     float S0x = 0.f, S1x = 0.f, S0z = 0.f, S1z = 0.f;             // aux (sum)
@@ -304,6 +363,14 @@ DDRR_HD float siddon_forward_ray_t(const Fetch &fetch, const Store &st, const Bo
     }
     if (COUNT) *count = nvis;
     return acc;
+}
+
+template <int REDUCE, bool AUX, bool COUNT, class Fetch>
+DDRR_HD float siddon_forward_ray_t(const Fetch &fetch, const Store &st, const Box &box,
+                                   const float s[3], const float t[3], float shift, float eps,
+                                   float *aux, int *count) {
+    const SiddonSetup q = siddon_setup(box, s, t, shift, eps);
+    return siddon_walk_t<REDUCE, AUX, COUNT>(fetch, st, box, s, shift, q, aux, count);
 }
 
 template <int REDUCE, bool AUX, bool COUNT>

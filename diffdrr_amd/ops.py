@@ -165,11 +165,12 @@ def siddon_forward_slab(volume, source, target, img, det, plan, shear, *, voxel_
     return out, aux
 
 
-def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, eps=1e-8):
-    """Detector-grid Siddon (sum, forward only) through the volume-stationary brick
-    kernel: every 32^3 brick is staged in LDS once and all rays of all poses are traced
-    through it.  Requires the targets to be the affine detector grid DRR builds.
-    -> out (B,N)"""
+def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, eps=1e-8,
+                          want_aux=False):
+    """Detector-grid Siddon (sum) through the volume-stationary brick kernel: every 32^3
+    brick is staged in LDS once and all rays of all poses are traced through it.
+    Requires the targets to be the affine detector grid DRR builds.
+    -> (out (B,N), aux (5,B,N) planar backward record | None)"""
     B, N = _check_rays(volume, source, target, img)
     H, W = int(det[0]), int(det[1])
     if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
@@ -177,19 +178,28 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
     volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
     img = None if img is None else img.contiguous()
     out = torch.empty(B, N, dtype=torch.float32, device=volume.device)
+    aux = torch.empty(_lib.BRICK_AUX_PLANES, B, N, dtype=torch.float32, device=volume.device) \
+        if want_aux else None
     if _empty(B, N):
-        return out
+        return out, aux
     _launch(
         "ddrr_siddon_forward_bricks", volume.device, volume.data_ptr(), *volume.shape,
         source.data_ptr(), target.data_ptr(), _ptr(img), B, H, W, float(voxel_shift), float(eps),
-        out.data_ptr())
-    return out
+        out.data_ptr(), _ptr(aux))
+    return out, aux
 
 
 def siddon_backward_rays(aux, grad_out, source, target, img, *, eps=1e-8, reducefn="sum",
                          want_img_grad=True):
-    """-> (g_source (B,N,3) per ray, g_target (B,N,3), g_img (B,N) | None)"""
+    """aux: (B,N,8) interleaved record (generic / slab forward) or (5,B,N) planar record
+    (brick forward).  -> (g_source (B,N,3) per ray, g_target (B,N,3), g_img (B,N) | None)"""
     B, N, _ = target.shape
+    if aux.shape == (B, N, SIDDON_AUX):
+        layout = _lib.AUX_INTERLEAVED
+    elif aux.shape == (_lib.BRICK_AUX_PLANES, B, N):
+        layout = _lib.AUX_PLANAR
+    else:
+        raise ValueError(f"aux has shape {tuple(aux.shape)}: neither (B,N,8) nor (5,B,N)")
     grad_out = grad_out.contiguous()
     g_source = torch.empty(B, N, 3, dtype=torch.float32, device=target.device)
     g_target = torch.empty(B, N, 3, dtype=torch.float32, device=target.device)
@@ -197,7 +207,7 @@ def siddon_backward_rays(aux, grad_out, source, target, img, *, eps=1e-8, reduce
     if _empty(B, N):
         return g_source, g_target, g_img
     _launch(
-        "ddrr_siddon_backward_rays", target.device, aux.data_ptr(), grad_out.data_ptr(), source.data_ptr(),
+        "ddrr_siddon_backward_rays", target.device, aux.data_ptr(), layout, grad_out.data_ptr(), source.data_ptr(),
         source.shape[1], target.data_ptr(), _ptr(img), B, N, float(eps),
         reduce_code(reducefn), g_source.data_ptr(), g_target.data_ptr(), _ptr(g_img))
     return g_source, g_target, g_img

@@ -47,10 +47,15 @@ class _SiddonFn(torch.autograd.Function):
         need_rays = any(ctx.needs_input_grad[1:4])
         want_aux = bool(need_rays and cfg["lookup"] == "step")
         N = target.shape[1]
-        slab = (cfg["lookup"] == "step" and cfg["reducefn"] == "sum" and cfg["det"] is not None
+        grid = (cfg["lookup"] == "step" and cfg["reducefn"] == "sum" and cfg["det"] is not None
                 and cfg["det"][0] * cfg["det"][1] == N and source.shape[1] == 1
-                and min(cfg["det"]) >= 2 and cfg["slab"])
-        if slab:
+                and min(cfg["det"]) >= 2)
+        if grid and cfg["path"] == "bricks":
+            # detector-grid fast path: volume-stationary LDS bricks (volume read once)
+            out, aux = ops.siddon_forward_bricks(
+                volume, source, target, img, cfg["det"], voxel_shift=cfg["voxel_shift"],
+                eps=cfg["eps"], want_aux=want_aux)
+        elif grid and cfg["path"] == "slab":
             # detector-grid fast path: lockstep slab march, z-epipolar wave composition
             plan, shear = slab_plan(source, target, *cfg["det"])
             out, aux = ops.siddon_forward_slab(
@@ -124,7 +129,9 @@ class Siddon(torch.nn.Module):
         # performance hints set by DRR (detector grid of the rays; wave tile shape)
         self.detector_shape = None
         self.tile = None
-        self.use_slab_march = True  # detector-grid fast path (same results; see slab_core.h)
+        # which kernel renders a detector-grid call (same results up to summation order):
+        # "bricks" (volume-stationary, brick_core.h), "slab" (slab_core.h) or "generic"
+        self.grid_path = "bricks"
 
     def dims(self, volume):
         return torch.tensor(volume.shape).to(volume)
@@ -140,7 +147,7 @@ class Siddon(torch.nn.Module):
         return {"voxel_shift": self.voxel_shift, "eps": self.eps, "reducefn": self.reducefn,
                 "lookup": lookup, "align_corners": bool(align_corners),
                 "stop_gradients": self.stop_gradients_through_grid_sample,
-                "det": self.detector_shape, "tile": self.tile, "slab": self.use_slab_march}
+                "det": self.detector_shape, "tile": self.tile, "path": self.grid_path}
 
     def forward(self, volume, source, target, img, align_corners=False, mask=None):
         B, N, _ = target.shape

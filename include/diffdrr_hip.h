@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 1
+#define DDRR_ABI_VERSION 2
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -54,6 +54,11 @@ extern "C" {
 #define DDRR_LOOKUP_MID_TRILINEAR 2 /* Siddon(mode="bilinear"): trilinear lookup at midpoints */
 
 #define DDRR_SIDDON_AUX 8 /* floats per ray in the forward record used by the backward */
+
+/* layouts of the forward record handed to ddrr_siddon_backward_rays */
+#define DDRR_AUX_INTERLEAVED 0 /* (B, N, 8): ddrr_siddon_forward, ddrr_siddon_forward_slab */
+#define DDRR_AUX_PLANAR 1      /* (5, B, N) planes I, S0x, S0z, S1x, S1z: ddrr_siddon_forward_bricks */
+#define DDRR_BRICK_AUX_PLANES 5
 
 int ddrr_abi_version(void);
 const char *ddrr_last_error(void);
@@ -86,26 +91,28 @@ int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const 
                              int max_strips, const int *box, int accumulate, float *out,
                              float *aux, void *stream);
 
-/* Volume-stationary form of ddrr_siddon_forward for large pose batches (same DRR case
- * as ddrr_siddon_forward_slab: sum, nearest, one source per pose, row-major det_h x det_w
+/* Volume-stationary form of ddrr_siddon_forward (same DRR case as
+ * ddrr_siddon_forward_slab: sum, nearest, one source per pose, row-major det_h x det_w
  * target grid that is an affine image of the pixel lattice, detector.py:126-153): one
  * workgroup per 32^3 brick staged in LDS traces every ray of every pose through it and
  * adds the partial integrals to `out` (zero-filled by the call) with fp32 atomics.  The
- * image equals ddrr_siddon_forward's up to fp32 summation order (which is not
- * deterministic here).  No backward record. */
+ * volume is read from HBM once per call, whatever B.  The image equals
+ * ddrr_siddon_forward's up to fp32 summation order (which is not deterministic here).
+ * aux: NULL, or a (DDRR_BRICK_AUX_PLANES, B, N) planar backward record (zero-filled and
+ * accumulated by the call) for ddrr_siddon_backward_rays(aux_layout = DDRR_AUX_PLANAR). */
 int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
                                const float *target, const float *img, int B, int det_h,
-                               int det_w, float voxel_shift, float eps, float *out,
+                               int det_w, float voxel_shift, float eps, float *out, float *aux,
                                void *stream);
 
-/* Pose/ray gradients of ddrr_siddon_forward from its aux record: what autograd
- * of renderers.py:94-113 + :70-71 returns.  g_source is per ray (B, N, 3) (sum
+/* Pose/ray gradients of ddrr_siddon_forward from its aux record (aux_layout says which
+ * forward wrote it): what autograd of renderers.py:94-113 + :70-71 returns.  g_source is per ray (B, N, 3) (sum
  * over rays for a broadcast source); g_target (B, N, 3); g_img (B, N), the
  * gradient w.r.t. `img` (NULL to skip, e.g. stop_gradients_through_grid_sample). */
-int ddrr_siddon_backward_rays(const float *aux, const float *grad_out, const float *source,
-                              int src_n, const float *target, const float *img, int B, int N,
-                              float eps, int reduce_mode, float *g_source, float *g_target,
-                              float *g_img, void *stream);
+int ddrr_siddon_backward_rays(const float *aux, int aux_layout, const float *grad_out,
+                              const float *source, int src_n, const float *target,
+                              const float *img, int B, int N, float eps, int reduce_mode,
+                              float *g_source, float *g_target, float *g_img, void *stream);
 
 /* Volume gradient of ddrr_siddon_forward (replaces grid_sampler_3d_backward,
  * nearest): ACCUMULATES grad_out * img * dalpha into g_volume[dx][dy][dz] with

@@ -41,10 +41,9 @@ def rel_err(a, b):
 
 
 def build_emu():
-    deps = [EMU_SRC] + [
-        os.path.join(ROOT, "diffdrr_amd", "csrc", f)
-        for f in ("ddrr_common.h", "siddon_core.h", "trilinear_core.h")
-    ] + [os.path.join(ROOT, "include", "diffdrr_hip.h")]
+    csrc = os.path.join(ROOT, "diffdrr_amd", "csrc")
+    deps = [EMU_SRC] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] \
+        + [os.path.join(ROOT, "include", "diffdrr_hip.h")]
     if os.path.exists(EMU_SO) and all(os.path.getmtime(d) <= os.path.getmtime(EMU_SO)
                                       for d in deps):
         return EMU_SO

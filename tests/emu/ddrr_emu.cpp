@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "../../diffdrr_amd/csrc/ddrr_common.h"
@@ -262,53 +263,105 @@ int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const 
     return 0;
 }
 
-// Host emulation of siddon_fwd_brick_kernel: same enumeration, same clipping, LDS brick
-// replaced by a local copy, atomics by plain adds.
+// Host emulation of siddon_fwd_brick_kernel: same unit enumeration (64-candidate strips of
+// the projected pixel box), same clipping, hits compacted into a queue and walked in
+// batches of 64 like a wave does; LDS brick replaced by a local padded copy (same
+// BrickLayout strides), atomics by plain adds.
 int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
                                const float *target, const float *img, int B, int det_h,
-                               int det_w, float voxel_shift, float eps, float *out, void *) {
+                               int det_w, float voxel_shift, float eps, float *out, float *aux,
+                               void *) {
     const Dims D{dx, dy, dz};
     const int N = det_h * det_w;
+    const long plane = (long)B * N;
     memset(out, 0, sizeof(float) * (size_t)B * N);
+    if (aux) memset(aux, 0, sizeof(float) * (size_t)DDRR_BRICK_AUX_PLANES * B * N);
     const BrickGrid bg = brick_grid(D);
-    std::vector<float> brick((size_t)BRICK * BRICK * BRICK);
+    const BrickLayout lay{33, 32 * 33 + 1};
+    std::vector<float> brick((size_t)brick_floats(lay));
+    std::vector<std::pair<int, int>> queue;
     for (int id = 0; id < bg.nx * bg.ny * bg.nz; ++id) {
         const Box box = brick_box(D, bg, id);
-        const Store st = brick_store(box);
+        const Store st = brick_store(box, lay);
         std::fill(brick.begin(), brick.end(), 0.f);
         for (int x = box.lo[0]; x < box.hi[0]; ++x)
             for (int y = box.lo[1]; y < box.hi[1]; ++y)
                 for (int z = box.lo[2]; z < box.hi[2]; ++z)
-                    brick[((x - box.lo[0]) * BRICK + (y - box.lo[1])) * BRICK + (z - box.lo[2])] =
+                    brick[(x - box.lo[0]) * lay.sx + (y - box.lo[1]) * lay.sy + (z - box.lo[2])] =
                         volume[((long)x * dy + y) * dz + z];
+        auto item = [&](int b, int pix) {
+            const long r = (long)b * N + pix;
+            float s[3], t[3];
+            for (int a = 0; a < 3; ++a) {
+                s[a] = source[(long)b * 3 + a];
+                t[a] = target[r * 3 + a];
+            }
+            const SiddonSetup q = siddon_setup_fast(box, s, t, voxel_shift, eps);
+            if (!q.hit) abort();  // phase A and phase B evaluate the same expression
+            float rec[SIDDON_AUX];
+            float I;
+            if (aux)
+                I = siddon_walk_t<REDUCE_SUM, true, false>(LdsFetch{brick.data()}, st, box, s,
+                                                           voxel_shift, q, rec, nullptr);
+            else
+                I = siddon_walk_t<REDUCE_SUM, false, false>(LdsFetch{brick.data()}, st, box, s,
+                                                            voxel_shift, q, rec, nullptr);
+            out[r] += (img ? img[r] : 1.f) * I;
+            if (aux) {
+                aux[r] += I;
+                aux[plane + r] += rec[1];
+                aux[2 * plane + r] += rec[3];
+                aux[3 * plane + r] += rec[4];
+                aux[4 * plane + r] += rec[6];
+            }
+        };
+        queue.clear();
         for (int b = 0; b < B; ++b) {
             const PixBox pb = project_brick(source + (long)b * 3, target + (long)b * N * 3, det_h,
                                             det_w, box, voxel_shift);
-            for (int i = pb.i0; i <= pb.i1; ++i)
-                for (int j = pb.j0; j <= pb.j1; ++j) {
-                    const long r = (long)b * N + (long)i * det_w + j;
-                    float s[3], t[3];
-                    for (int a = 0; a < 3; ++a) {
-                        s[a] = source[(long)b * 3 + a];
-                        t[a] = target[r * 3 + a];
-                    }
-                    const float I = siddon_forward_ray_t<REDUCE_SUM, false, false>(
-                        LdsFetch{brick.data()}, st, box, s, t, voxel_shift, eps, nullptr, nullptr);
-                    if (I != 0.f) out[r] += (img ? img[r] : 1.f) * I;
+            const int count = pixbox_count(pb), w = pb.j1 - pb.j0 + 1;
+            for (int local = 0; local < count; ++local) {
+                int i, j;
+                pixbox_pixel(pb.i0, pb.j0, w, 1.0f / (float)w, local, i, j);
+                if (i != pb.i0 + local / w || j != pb.j0 + local % w) abort();
+                const long r = (long)b * N + (long)i * det_w + j;
+                float s[3], t[3];
+                for (int a = 0; a < 3; ++a) {
+                    s[a] = source[(long)b * 3 + a];
+                    t[a] = target[r * 3 + a];
                 }
+                if (siddon_setup_fast(box, s, t, voxel_shift, eps).hit)
+                    queue.emplace_back(b, i * det_w + j);
+                if (queue.size() >= 64) {  // a full wave of hits: walk them
+                    for (size_t k = queue.size() - 64; k < queue.size(); ++k)
+                        item(queue[k].first, queue[k].second);
+                    queue.resize(queue.size() - 64);
+                }
+            }
         }
+        for (auto &it : queue) item(it.first, it.second);
     }
     return 0;
 }
 
-int ddrr_siddon_backward_rays(const float *aux, const float *grad_out, const float *source,
-                              int src_n, const float *target, const float *img, int B, int N,
-                              float eps, int reduce_mode, float *g_source, float *g_target,
-                              float *g_img, void *) {
+int ddrr_siddon_backward_rays(const float *aux, int aux_layout, const float *grad_out,
+                              const float *source, int src_n, const float *target,
+                              const float *img, int B, int N, float eps, int reduce_mode,
+                              float *g_source, float *g_target, float *g_img, void *) {
+    const long R = (long)B * N;
     for_each_ray(source, src_n, target, img, B, N, 0, 0, 0, 0,
                  [&](int, int, long r, const Ray &ray) {
                      float gs[3], gt[3];
-                     const float *rec = aux + r * SIDDON_AUX;
+                     float planar[SIDDON_AUX];
+                     if (aux_layout == DDRR_AUX_PLANAR) {
+                         const float I = aux[r], S0x = aux[R + r], S0z = aux[2 * R + r];
+                         const float S1x = aux[3 * R + r], S1z = aux[4 * R + r];
+                         const float v[SIDDON_AUX] = {I, S0x, -(S0x + S0z), S0z,
+                                                      S1x, I - (S1x + S1z), S1z, 0.f};
+                         memcpy(planar, v, sizeof(v));
+                     }
+                     const float *rec =
+                         aux_layout == DDRR_AUX_PLANAR ? planar : aux + r * SIDDON_AUX;
                      if (reduce_mode == DDRR_REDUCE_SUM)
                          siddon_backward_ray<REDUCE_SUM>(rec, ray.s, ray.t, eps,
                                                          grad_out[r] * ray.L, gs, gt);

@@ -1,0 +1,54 @@
+"""Kernel-only timing of the volume-stationary brick kernel (development tool).
+Usage: python tools/brick_bench.py [--size 512] [--det 256] [--layouts 33:1057,36:1168]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diffdrr_amd import DRR, _lib, ops  # noqa: E402
+from diffdrr_amd.data import make_subject, noise_volume  # noqa: E402
+from tools.kernel_sweep import poses, rays, timeit  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=512)
+ap.add_argument("--det", type=int, default=256)
+ap.add_argument("--layouts", default="33:1057")
+ap.add_argument("--cases", default="pert32,pert32aux,base32,pert1,pert8,pert128")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+D, H = a.size, a.det
+drr = DRR(make_subject(noise_volume(D, 0)), sdd=1020.0, height=H, delx=2.4 * (256 / H) * (D / 512)).to(dev)
+V = drr.density
+lib = _lib.get_lib()
+print(f"# {torch.cuda.get_device_name(0)}  volume {D}^3  detector {H}^2")
+base = rays(drr, torch.zeros(1, 3, device=dev), torch.tensor([[0.0, 850.0, 0.0]], device=dev))
+sets = {}
+for case in a.cases.split(","):
+    aux = case.endswith("aux")
+    name = case[:-3] if aux else case
+    if name.startswith("base"):
+        B = int(name[4:])
+        s, t, L = (x.expand(B, *x.shape[1:]).contiguous() for x in base)
+    else:
+        s, t, L = rays(drr, *poses(int(name[4:]), 2, dev))
+    sets[case] = (s, t, L, aux)
+for lay in a.layouts.split(","):
+    sy, sx = (int(v) for v in lay.split(":"))
+    rc = lib.cdll.ddrr_set_brick_layout(sy, sx)
+    if rc != 0:
+        print(f"layout {lay}: rejected")
+        continue
+    for case, (s, t, L, aux) in sets.items():
+        B = t.shape[0]
+        _, _, nv = ops.siddon_forward(V, s, t, L, count_voxels=True, det=(H, H))
+        nvox = int(nv.sum())
+        alg = 4 * nvox + B * H * H * 20 + 12 * B
+        med, best = timeit(lambda: ops.siddon_forward_bricks(V, s, t, L, (H, H), want_aux=aux))
+        ref = ops.siddon_forward(V, s, t, L, det=(H, H))[0]
+        out = ops.siddon_forward_bricks(V, s, t, L, (H, H), want_aux=aux)[0]
+        err = ((out - ref).abs().max() / ref.abs().max()).item()
+        print(f"layout {lay:9s} {case:12s} B {B:4d} vox/ray {nvox / (B * H * H):6.1f}  {med:8.3f} ms "
+              f"(best {best:7.3f})  {B / med * 1e3:9.0f} DRR/s  {alg / med / 1e6:8.1f} GB/s alg "
+              f"({alg / med / 1e6 / 8000 * 100:5.1f}% of 8 TB/s)  err vs generic {err:.1e}", flush=True)

@@ -108,7 +108,7 @@ def main():
         alg = 4 * nvox + B * H * H * 20 + 12 * B
         med, best = timeit(lambda: ops.siddon_forward_bricks(V, s, t, L, (H, H)))
         ref = ops.siddon_forward(V, s, t, L, det=(H, H))[0]
-        out = ops.siddon_forward_bricks(V, s, t, L, (H, H))
+        out = ops.siddon_forward_bricks(V, s, t, L, (H, H))[0]
         err = ((out - ref).abs().max() / ref.abs().max()).item()
         print(f"{label:34s} BRICK (LDS) B {B:4d} "
               f"vox/ray {nvox / (B * H * H):6.1f}  {med:8.3f} ms (best {best:7.3f})  "

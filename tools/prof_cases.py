@@ -17,6 +17,7 @@ ap.add_argument("--xcd", type=int, default=1)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--kernel", default="generic", choices=["generic", "slab", "brick"])
+ap.add_argument("--aux", type=int, default=0)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 D, H = a.size, 256
@@ -43,5 +44,5 @@ for _ in range(a.reps):
     elif a.kernel == "slab":
         ops.siddon_forward_slab(drr.density, s, t, L, (H, H), plan, shear)
     else:
-        ops.siddon_forward_bricks(drr.density, s, t, L, (H, H))
+        ops.siddon_forward_bricks(drr.density, s, t, L, (H, H), want_aux=bool(a.aux))
 torch.cuda.synchronize()
