@@ -151,6 +151,33 @@ struct LdsFetch {
     }
 };
 
+// Phase-A test of a candidate ray against a brick: a cheap slab clip (hardware reciprocal,
+// no refinement) with a little slack, so that it never rejects a ray whose exact clip
+// (siddon_setup_fast, evaluated later on the survivors) is a chord longer than rounding
+// noise; false positives cost one idle lane in the walk.  `n_est` ~ number of plane
+// crossings inside the brick: used only to group hits of similar length into one wave.
+DDRR_HD bool brick_maybe_hit(const Box &box, const float s[3], const float t[3], float shift,
+                             float eps, float &n_est) {
+    float entry = -INFINITY, exit = INFINITY, l1 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float d = (t[a] - s[a]) + eps;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float inv = __builtin_amdgcn_rcpf(d);
+#else
+        const float inv = 1.0f / d;
+#endif
+        const float a0 = ((float)box.lo[a] - shift - s[a]) * inv;
+        const float a1 = ((float)box.hi[a] - shift - s[a]) * inv;
+        entry = fmaxf(entry, fminf(a0, a1));
+        exit = fminf(exit, fmaxf(a0, a1));
+        l1 += fabsf(d);
+    }
+    const float slack = 1e-6f * fmaxf(fabsf(entry), fabsf(exit));
+    n_est = (exit - entry) * l1;
+    return entry < exit + slack;  // false for NaN
+}
+
 // Candidate pixel `local` (row-major index into the pixel box) -> (i, j).
 DDRR_HD void pixbox_pixel(int i0, int j0, int w, float inv_w, int local, int &i, int &j) {
     // exact for the box sizes that occur (local < 2^22): no integer division

@@ -15,6 +15,7 @@
 #include "ddrr_common.h"
 #include "siddon_core.h"
 #include "brick_core.h"
+#include "brick_walk.h"
 #include "slab_core.h"
 #include "trilinear_core.h"
 
@@ -317,21 +318,26 @@ __global__ __launch_bounds__(kBlock) void siddon_fwd_slab_kernel(SlabArgs p,
 
 // ------------------------------------------------- Siddon, brick-stationary
 // One workgroup per 32^3 brick: stage the brick in LDS (padded layout), then trace from
-// LDS the part of every ray of every pose that crosses it (brick_core.h).  1024 threads
-// and ~150 KiB of LDS -> one workgroup per CU, 4 waves per SIMD.
+// LDS the part of every ray of every pose that crosses it (brick_core.h, brick_walk.h).
+// 1024 threads and ~159 KiB of LDS -> one workgroup per CU, 4 waves per SIMD.
 //
 // Work distribution inside the workgroup (no block-wide barriers in the hot loop):
-//  * a unit = 64 consecutive candidate pixels of one pose's projected pixel box; waves
-//    pull units from one LDS counter;
-//  * phase A (all 64 lanes): clip the candidate ray against the brick; the hits are
-//    compacted (ballot + mbcnt) into the wave's private LDS queue;
-//  * phase B: as soon as the queue holds 64 hits they are walked with every lane busy;
-//    the remainder is drained at the end.  A queue entry is (pose, pixel).
+//  * per pose the brick's 8 corners are projected onto the detector: a pixel box of
+//    candidates; a unit = 64 consecutive candidates of one pose; waves pull units from one
+//    LDS counter in increasing order, so the unit -> pose lookup is a forward cursor;
+//  * phase A (all 64 lanes, arithmetic only): conservative slab test of the candidate
+//    against the brick from the pose's affine detector model; the hits are compacted
+//    (ballot + mbcnt) into the wave's private LDS queues, one queue per length class
+//    (estimated number of crossings), so that a wave walks rays of similar length;
+//  * phase B: as soon as a queue holds 64 hits their real rays are clipped exactly and
+//    walked with every lane busy; the remainders are walked together at the end.
+//    A queue entry is (pose << pix_bits) | pixel.
 
 constexpr int kBrickThreads = 1024;
 constexpr int kBrickWaves = kBrickThreads / 64;
-constexpr int kPoseChunk = 64;
+constexpr int kPoseChunk = 32;
 constexpr int kQueueCap = 128;
+constexpr int kBuckets = 3;
 constexpr int kBrickAuxPlanes = 5;  // I, S0x, S0z, S1x, S1z (y follows from the sums)
 
 struct BrickArgs {
@@ -343,39 +349,44 @@ struct BrickArgs {
     int B, det_h, det_w;
     float shift, eps;
     BrickLayout lay;
-    long aux_plane;  // elements per plane of the planar backward record (B * N)
+    unsigned aux_plane;  // elements per plane of the planar backward record (B * N)
+    int pix_bits;        // queue entry = (pose << pix_bits) | pixel
+    float t1, t2;        // length-class thresholds on the estimated crossing count
 };
 
 inline size_t brick_lds_bytes(const BrickLayout &lay) {
-    return (size_t)brick_floats(lay) * 4 + (size_t)kBrickWaves * kQueueCap * 8 +
-           (size_t)(kPoseChunk * 4 + kPoseChunk + 1 + 1) * 4;
+    return (size_t)brick_floats(lay) * 4 + (size_t)kBrickWaves * kBuckets * kQueueCap * 4 +
+           (size_t)(kPoseChunk * kRowWords + kPoseChunk + 1 + 1) * 4;
 }
 
+// Phase B for one queue entry: load the real ray, clip, walk, add to the image.
+// Offsets are 32-bit: the host checks 12 * B * N < 2^32.
 template <bool AUX>
-__device__ __forceinline__ void brick_item(const BrickArgs &p, const float *brick, const Store &st,
-                                           const Box &box, int b, int pix, float *__restrict__ out,
-                                           float *__restrict__ aux) {
-    const long r = (long)b * ((long)p.det_h * p.det_w) + pix;
-    float s[3], t[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        s[a] = p.source[(long)b * 3 + a];
-        t[a] = p.target[r * 3 + a];
-    }
-    const SiddonSetup q = siddon_setup_fast(box, s, t, p.shift, p.eps);
-    float rec[SIDDON_AUX];
-    const float I = siddon_walk_t<REDUCE_SUM, AUX, false>(LdsFetch{brick}, st, box, s, p.shift, q,
-                                                          rec, nullptr);
+__device__ __forceinline__ void brick_item(const BrickArgs &p, const float *brick,
+                                           const BrickGeom &G, unsigned b, unsigned pix,
+                                           float *__restrict__ out, float *__restrict__ aux) {
+    const unsigned r = b * (unsigned)(p.det_h * p.det_w) + pix;
+    const float *sp = p.source + b * 3u, *tp = p.target + r * 3u;
+    const float s[3] = {sp[0], sp[1], sp[2]}, t[3] = {tp[0], tp[1], tp[2]};
     const float L = p.img ? p.img[r] : 1.f;
+    float I, rec[4];
+    if (!brick_trace<AUX>(LdsFetch{brick}, G, s, t, p.shift, p.eps, I, rec)) return;
     unsafeAtomicAdd(out + r, L * I);
     if (AUX) {
         unsafeAtomicAdd(aux + r, I);
-        unsafeAtomicAdd(aux + p.aux_plane + r, rec[1]);
-        unsafeAtomicAdd(aux + 2 * p.aux_plane + r, rec[3]);
-        unsafeAtomicAdd(aux + 3 * p.aux_plane + r, rec[4]);
-        unsafeAtomicAdd(aux + 4 * p.aux_plane + r, rec[6]);
+        unsafeAtomicAdd(aux + p.aux_plane + r, rec[0]);
+        unsafeAtomicAdd(aux + 2u * p.aux_plane + r, rec[1]);
+        unsafeAtomicAdd(aux + 3u * p.aux_plane + r, rec[2]);
+        unsafeAtomicAdd(aux + 4u * p.aux_plane + r, rec[3]);
     }
 }
+
+__device__ __forceinline__ int lane_rank(unsigned long long mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 template <bool AUX>
 __global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
@@ -383,14 +394,14 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *brick = reinterpret_cast<float *>(smem_raw);
     unsigned *queue = reinterpret_cast<unsigned *>(brick + brick_floats(p.lay));
-    int *pbox = reinterpret_cast<int *>(queue + kBrickWaves * kQueueCap * 2);  // [chunk][4]
-    int *pref = pbox + kPoseChunk * 4;                                          // [chunk + 1]
+    float *rows = reinterpret_cast<float *>(queue + kBrickWaves * kBuckets * kQueueCap);
+    int *pref = reinterpret_cast<int *>(rows + kPoseChunk * kRowWords);  // [chunk + 1]
     int *counter = pref + kPoseChunk + 1;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const BrickGrid bg = brick_grid(p.D);
     const Box box = brick_box(p.D, bg, blockIdx.x);
-    const Store st = brick_store(box, p.lay);
+    const BrickGeom G = brick_geom(box, p.lay);
     const int N = p.det_h * p.det_w;
 
     // stage the brick: 32 x 32 rows of 32 floats (one 128-byte line each), zero padded
@@ -409,20 +420,22 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
         for (int k = 0; k < 4; ++k) d[k] = v[k];
     }
 
-    volatile unsigned *myq = queue + wave * kQueueCap * 2;
-    int qn = 0;  // hits waiting in this wave's queue (wave-uniform)
+    volatile unsigned *myq = queue + wave * kBuckets * kQueueCap;
+    int qn0 = 0, qn1 = 0, qn2 = 0;  // hits waiting per length class (wave-uniform)
+    const unsigned pix_mask = (1u << p.pix_bits) - 1u;
 
-    for (int b0 = 0; b0 < p.B; b0 += kPoseChunk) {
+    const int n_chunks = (p.B + kPoseChunk - 1) / kPoseChunk;
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const int b0 = ch * kPoseChunk;
         const int nb = p.B - b0 < kPoseChunk ? p.B - b0 : kPoseChunk;
+        const bool last_chunk = ch == n_chunks - 1;
         __syncthreads();  // brick staged / previous chunk's tables no longer in use
         if (tid < nb) {
-            const PixBox pb = project_brick(p.source + (long)(b0 + tid) * 3,
-                                            p.target + (long)(b0 + tid) * N * 3, p.det_h,
-                                            p.det_w, box, p.shift);
-            pbox[tid * 4 + 0] = pb.i0;
-            pbox[tid * 4 + 1] = pb.j0;
-            pbox[tid * 4 + 2] = pb.j1 - pb.j0 + 1;
-            pbox[tid * 4 + 3] = pixbox_count(pb);
+            const PoseGrid pg = pose_grid(p.source + (long)(b0 + tid) * 3,
+                                          p.target + (long)(b0 + tid) * N * 3, p.det_h, p.det_w);
+            const PixBox pb = project_brick_grid(pg, p.det_h, p.det_w, box, p.shift);
+            const BrickRow r = brick_row(pg, pb, box, p.shift, p.eps);
+            *reinterpret_cast<BrickRow *>(rows + tid * kRowWords) = r;
         }
         if (tid == 0) *counter = 0;
         __syncthreads();
@@ -430,63 +443,84 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
             int acc = 0;
             for (int k = 0; k < nb; ++k) {
                 pref[k] = acc;
-                acc += (pbox[k * 4 + 3] + 63) >> 6;
+                acc += (reinterpret_cast<const BrickRow *>(rows + k * kRowWords)->count + 63) >> 6;
             }
             pref[nb] = acc;
         }
         __syncthreads();
         const int units = pref[nb];
+        int cur = 0, cur_lo = 0, cur_hi = uni(pref[1]);
         for (;;) {
             int u = 0;
             if (lane == 0) u = atomicAdd(counter, 1);
-            u = __builtin_amdgcn_readfirstlane(u);
-            if (u >= units) break;
-            int lo = 0, hi = nb;  // pose of unit u: last k with pref[k] <= u
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (pref[mid] <= u) lo = mid;
-                else hi = mid;
-            }
-            const int b = b0 + lo;
-            const int i0 = pbox[lo * 4], j0 = pbox[lo * 4 + 1], w = pbox[lo * 4 + 2];
-            const int count = pbox[lo * 4 + 3];
-            const int local = (u - pref[lo]) * 64 + lane;
-            bool hit = false;
-            int pix = 0;
-            if (local < count) {
-                int i, j;
-                pixbox_pixel(i0, j0, w, 1.0f / (float)w, local, i, j);
-                pix = i * p.det_w + j;
-                const long r = (long)b * N + pix;
-                float s[3], t[3];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    s[a] = p.source[(long)b * 3 + a];
-                    t[a] = p.target[r * 3 + a];
+            u = uni(u);
+            const bool drain = u >= units;  // no unit left in this chunk
+            if (drain && !last_chunk) break;
+            if (!drain) {
+                while (u >= cur_hi) {  // units arrive in increasing order: forward cursor
+                    ++cur;
+                    cur_lo = cur_hi;
+                    cur_hi = uni(pref[cur + 1]);
                 }
-                hit = siddon_setup_fast(box, s, t, p.shift, p.eps).hit;
-            }
-            const unsigned long long mask = __ballot(hit);
-            if (hit) {
-                const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi(
-                                         (unsigned)(mask >> 32),
-                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                myq[2 * pos] = (unsigned)b;
-                myq[2 * pos + 1] = (unsigned)pix;
-            }
-            qn += __popcll(mask);
-            __builtin_amdgcn_wave_barrier();
-            if (qn >= 64) {
-                qn -= 64;
-                const int b_it = (int)myq[2 * (qn + lane)], pix_it = (int)myq[2 * (qn + lane) + 1];
-                brick_item<AUX>(p, brick, st, box, b_it, pix_it, out, aux);
+                const BrickRow r = *reinterpret_cast<const BrickRow *>(rows + cur * kRowWords);
+                const int local = (u - cur_lo) * 64 + lane;
+                int pix = 0;
+                float n_est = 0.f;
+                const bool hit = local < uni(r.count) &&
+                                 brick_candidate(r, local, p.det_w, pix, n_est);
+                const int cls = n_est < p.t1 ? 0 : (n_est < p.t2 ? 1 : 2);
+                const unsigned long long m0 = __ballot(hit && cls == 0);
+                const unsigned long long m1 = __ballot(hit && cls == 1);
+                const unsigned long long m2 = __ballot(hit && cls == 2);
+                if (hit) {
+                    const unsigned long long mine = cls == 0 ? m0 : (cls == 1 ? m1 : m2);
+                    const int qb = cls == 0 ? qn0 : (cls == 1 ? qn1 : qn2);
+                    myq[cls * kQueueCap + qb + lane_rank(mine)] =
+                        ((unsigned)(b0 + cur) << p.pix_bits) | (unsigned)pix;
+                }
+                qn0 += __popcll(m0);
+                qn1 += __popcll(m1);
+                qn2 += __popcll(m2);
                 __builtin_amdgcn_wave_barrier();
             }
+            // walk every full batch of 64 hits of one class; when draining, what is left
+            // of all classes together (longest first), 64 at a time
+            for (;;) {
+                int k = -1, n = 0;
+                if (qn0 >= 64) k = 0, n = 64;
+                else if (qn1 >= 64) k = 1, n = 64;
+                else if (qn2 >= 64) k = 2, n = 64;
+                unsigned e = 0;
+                if (k >= 0) {
+                    const int base = (k == 0 ? qn0 : (k == 1 ? qn1 : qn2)) - 64;
+                    qn0 -= k == 0 ? 64 : 0;
+                    qn1 -= k == 1 ? 64 : 0;
+                    qn2 -= k == 2 ? 64 : 0;
+                    e = myq[k * kQueueCap + base + lane];
+                } else if (drain && qn0 + qn1 + qn2 > 0) {
+                    // virtual queue [class 2 | class 1 | class 0], taken from the front
+                    const int tot = qn0 + qn1 + qn2;
+                    n = tot < 64 ? tot : 64;
+                    const int i2 = lane, i1 = lane - qn2, i0 = lane - qn2 - qn1;
+                    if (lane < n)
+                        e = i2 < qn2 ? myq[2 * kQueueCap + qn2 - 1 - i2]
+                                     : (i1 < qn1 ? myq[kQueueCap + qn1 - 1 - i1]
+                                                 : myq[qn0 - 1 - i0]);
+                    // consumed from the tops of the stacks
+                    const int t2 = qn2 < n ? qn2 : n;
+                    const int t1 = qn1 < n - t2 ? qn1 : n - t2;
+                    qn2 -= t2;
+                    qn1 -= t1;
+                    qn0 -= n - t2 - t1;
+                } else {
+                    break;
+                }
+                if (lane < n)
+                    brick_item<AUX>(p, brick, G, e >> p.pix_bits, e & pix_mask, out, aux);
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (drain) break;
         }
-    }
-    if (lane < qn) {
-        const int b_it = (int)myq[2 * lane], pix_it = (int)myq[2 * lane + 1];
-        brick_item<AUX>(p, brick, st, box, b_it, pix_it, out, aux);
     }
 }
 
@@ -579,6 +613,8 @@ int g_xcd_swizzle_slab = 0;
 // LDS layout of a brick (floats): rows padded 32 -> 33, planes 32*33 -> 1057, so that
 // x-, y- and z-neighbours all fall in different banks.
 BrickLayout g_brick_layout = {33, 32 * 33 + 1};
+// length classes of brick hits (estimated plane crossings inside the brick)
+float g_brick_t1 = 14.f, g_brick_t2 = 34.f;
 
 int check_common(const float *volume, int dx, int dy, int dz, const float *source, int src_n,
                  const float *target, int B, int N) {
@@ -640,6 +676,11 @@ int ddrr_set_brick_layout(int sy, int sx) {
     BrickLayout lay = {sy, sx};
     if (brick_lds_bytes(lay) > 160 * 1024) return -1;
     g_brick_layout = lay;
+    return 0;
+}
+int ddrr_set_brick_classes(float t1, float t2) {
+    g_brick_t1 = t1;
+    g_brick_t2 = t2;
     return 0;
 }
 int ddrr_set_xcd_swizzle_slab(int on) {
@@ -770,7 +811,16 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     p.shift = voxel_shift;
     p.eps = eps;
     p.lay = g_brick_layout;
-    p.aux_plane = (long)B * N;
+    if ((long)B * N * 12 >= (1L << 32))
+        return fail(-1, "B * N too large for one brick launch (12 B N must stay below 2^32): "
+                        "split the pose batch");
+    p.aux_plane = (unsigned)((long)B * N);
+    p.pix_bits = 1;
+    while ((1L << p.pix_bits) < N) ++p.pix_bits;
+    if (((long)B << p.pix_bits) > (1L << 32))
+        return fail(-1, "B * 2^ceil(log2 N) exceeds 2^32: split the pose batch");
+    p.t1 = g_brick_t1;
+    p.t2 = g_brick_t2;
     const size_t lds = brick_lds_bytes(p.lay);
     static bool attr_set = false;  // raise the dynamic-LDS limit once per process
     if (!attr_set) {

@@ -17,6 +17,7 @@
 #include "../../diffdrr_amd/csrc/ddrr_common.h"
 #include "../../diffdrr_amd/csrc/siddon_core.h"
 #include "../../diffdrr_amd/csrc/brick_core.h"
+#include "../../diffdrr_amd/csrc/brick_walk.h"
 #include "../../diffdrr_amd/csrc/slab_core.h"
 #include "../../diffdrr_amd/csrc/trilinear_core.h"
 #include "../../include/diffdrr_hip.h"
@@ -263,10 +264,11 @@ int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const 
     return 0;
 }
 
-// Host emulation of siddon_fwd_brick_kernel: same unit enumeration (64-candidate strips of
-// the projected pixel box), same clipping, hits compacted into a queue and walked in
-// batches of 64 like a wave does; LDS brick replaced by a local padded copy (same
-// BrickLayout strides), atomics by plain adds.
+// Host emulation of siddon_fwd_brick_kernel: same per-pose table (affine detector model,
+// projected pixel box), same arithmetic phase-A test, hits compacted into three
+// length-class queues and walked in batches of 64 like a wave does, same exact clip and
+// walk (brick_walk.h); LDS brick replaced by a local padded copy (same BrickLayout
+// strides), atomics by plain adds.
 int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
                                const float *target, const float *img, int B, int det_h,
                                int det_w, float voxel_shift, float eps, float *out, float *aux,
@@ -279,10 +281,10 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     const BrickGrid bg = brick_grid(D);
     const BrickLayout lay{33, 32 * 33 + 1};
     std::vector<float> brick((size_t)brick_floats(lay));
-    std::vector<std::pair<int, int>> queue;
+    std::vector<std::pair<int, int>> queues[3];
     for (int id = 0; id < bg.nx * bg.ny * bg.nz; ++id) {
         const Box box = brick_box(D, bg, id);
-        const Store st = brick_store(box, lay);
+        const BrickGeom G = brick_geom(box, lay);
         std::fill(brick.begin(), brick.end(), 0.f);
         for (int x = box.lo[0]; x < box.hi[0]; ++x)
             for (int y = box.lo[1]; y < box.hi[1]; ++y)
@@ -296,50 +298,58 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                 s[a] = source[(long)b * 3 + a];
                 t[a] = target[r * 3 + a];
             }
-            const SiddonSetup q = siddon_setup_fast(box, s, t, voxel_shift, eps);
-            if (!q.hit) abort();  // phase A and phase B evaluate the same expression
-            float rec[SIDDON_AUX];
-            float I;
-            if (aux)
-                I = siddon_walk_t<REDUCE_SUM, true, false>(LdsFetch{brick.data()}, st, box, s,
-                                                           voxel_shift, q, rec, nullptr);
-            else
-                I = siddon_walk_t<REDUCE_SUM, false, false>(LdsFetch{brick.data()}, st, box, s,
-                                                            voxel_shift, q, rec, nullptr);
+            float I, rec[4];
+            const bool hit = aux ? brick_trace<true>(LdsFetch{brick.data()}, G, s, t, voxel_shift,
+                                                     eps, I, rec)
+                                 : brick_trace<false>(LdsFetch{brick.data()}, G, s, t,
+                                                      voxel_shift, eps, I, rec);
+            if (!hit) return;  // phase A's margin let a non-crossing ray through
             out[r] += (img ? img[r] : 1.f) * I;
             if (aux) {
                 aux[r] += I;
-                aux[plane + r] += rec[1];
-                aux[2 * plane + r] += rec[3];
-                aux[3 * plane + r] += rec[4];
-                aux[4 * plane + r] += rec[6];
+                for (int k = 0; k < 4; ++k) aux[(k + 1) * plane + r] += rec[k];
             }
         };
-        queue.clear();
+        for (auto &qk : queues) qk.clear();
         for (int b = 0; b < B; ++b) {
-            const PixBox pb = project_brick(source + (long)b * 3, target + (long)b * N * 3, det_h,
-                                            det_w, box, voxel_shift);
-            const int count = pixbox_count(pb), w = pb.j1 - pb.j0 + 1;
-            for (int local = 0; local < count; ++local) {
-                int i, j;
-                pixbox_pixel(pb.i0, pb.j0, w, 1.0f / (float)w, local, i, j);
-                if (i != pb.i0 + local / w || j != pb.j0 + local % w) abort();
-                const long r = (long)b * N + (long)i * det_w + j;
+            const PoseGrid pg = pose_grid(source + (long)b * 3, target + (long)b * N * 3, det_h,
+                                          det_w);
+            const PixBox pb = project_brick_grid(pg, det_h, det_w, box, voxel_shift);
+            const BrickRow row = brick_row(pg, pb, box, voxel_shift, eps);
+            // phase A must never lose a ray the exact clip accepts: check EVERY pixel of the
+            // pose against the exact clip, inside and outside the projected pixel box
+            std::vector<char> cand((size_t)N, 0);
+            for (int local = 0; local < row.count; ++local) {
+                int pix;
+                float n_est;
+                const bool maybe = brick_candidate(row, local, det_w, pix, n_est);
+                if (pix != (row.i0 + local / row.w) * det_w + row.j0 + local % row.w) abort();
+                if (!maybe) continue;
+                cand[pix] = 1;
+                auto &qk = queues[n_est < 14.f ? 0 : (n_est < 34.f ? 1 : 2)];
+                qk.emplace_back(b, pix);
+                if (qk.size() >= 64) {  // a full wave of hits of one length class: walk them
+                    for (size_t k = qk.size() - 64; k < qk.size(); ++k)
+                        item(qk[k].first, qk[k].second);
+                    qk.resize(qk.size() - 64);
+                }
+            }
+            for (int pix = 0; pix < N; ++pix) {
+                if (cand[pix]) continue;
+                const long r = (long)b * N + pix;
                 float s[3], t[3];
                 for (int a = 0; a < 3; ++a) {
                     s[a] = source[(long)b * 3 + a];
                     t[a] = target[r * 3 + a];
                 }
-                if (siddon_setup_fast(box, s, t, voxel_shift, eps).hit)
-                    queue.emplace_back(b, i * det_w + j);
-                if (queue.size() >= 64) {  // a full wave of hits: walk them
-                    for (size_t k = queue.size() - 64; k < queue.size(); ++k)
-                        item(queue[k].first, queue[k].second);
-                    queue.resize(queue.size() - 64);
-                }
+                float I, rec[4];
+                if (brick_trace<false>(LdsFetch{brick.data()}, G, s, t, voxel_shift, eps, I, rec) &&
+                    I != 0.f)
+                    abort();
             }
         }
-        for (auto &it : queue) item(it.first, it.second);
+        for (int k = 2; k >= 0; --k)
+            for (auto &it : queues[k]) item(it.first, it.second);
     }
     return 0;
 }

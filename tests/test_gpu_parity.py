@@ -478,9 +478,11 @@ def test_brick_kernel_small_and_ragged_volumes(gpu):
 def test_slab_march_odd_detectors_vs_oracle(gpu, H, W):
     subject = synthetic_subject(48, kind="noise", seed=0)
     drr = DRR(subject, sdd=400.0, height=H, width=W, delx=1.1).to(gpu)
-    rot = torch.tensor([[0.0, 0.0, 0.0], [0.5, -0.3, 0.8], [1.5, 0.1, 0.2], [0.1, 1.4, 0.0]],
+    # (not the exact base pose: with an odd detector its centre row glides inside a voxel
+    # plane, where the reference's fp32 position rounding -- not geometry -- picks the voxel)
+    rot = torch.tensor([[0.01, 0.02, -0.01], [0.5, -0.3, 0.8], [1.5, 0.1, 0.2], [0.1, 1.4, 0.0]],
                        device=gpu)
-    xyz = torch.tensor([[0.0, 300.0, 0.0], [5.0, 280.0, -7.0], [0.0, 310.0, 3.0],
+    xyz = torch.tensor([[0.3, 300.0, 0.2], [5.0, 280.0, -7.0], [0.0, 310.0, 3.0],
                         [2.0, 300.0, 1.0]], device=gpu)
     img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
     s, t, L = voxel_rays(drr, rot, xyz)

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 run() {  # name, rocprof args...
   local name=$1; shift
-  (cd /tmp && timeout 300 rocprofv3 "$@" -d "$ROOT/$OUT/$name" -o "$name" --output-format csv -- python "$ROOT/tools/prof_cases.py" "${PCARGS[@]}") > "$OUT/$name.log" 2>&1
+  (cd /tmp && timeout 60 rocprofv3 "$@" -d "$ROOT/$OUT/$name" -o "$name" --output-format csv -- python "$ROOT/tools/prof_cases.py" "${PCARGS[@]}") > "$OUT/$name.log" 2>&1
 }
 PCARGS=("$@")
 run trace --kernel-trace --stats
