@@ -5,9 +5,9 @@
 Workload (BASELINE.json `metric`; SURVEY.md section 8d common scene): 512^3 fp32 volume
 resident in HBM, 256x256 detector (delx 2.4, sdd 1020, AP), Siddon renderer, a
 batch of 32 perturbed poses per GPU per step.  One step = pose parameters ->
-`convert` -> `Detector` -> HIP Siddon forward (+ backward record) -> per-pose NCC
-against a fixed target image -> backward to the 6-DoF pose parameters (HIP
-ray-gradient kernel + autograd through the pose chain).  With N > 1 every rank
+`convert` -> fused ray generation (HIP) -> HIP Siddon forward (+ backward record) ->
+per-pose NCC against a fixed target image -> backward to the 6-DoF pose parameters
+(HIP pose-gradient kernel + autograd through the 4x4 pose chain).  With N > 1 every rank
 renders its own 32 poses (weak scaling, volume replicated) and the per-pose
 losses are all-gathered over RCCL each step.
 
@@ -209,11 +209,12 @@ def main():
                        key=lambda n: timer.total_ms(n)[0])
         fwd_total, n_fwd = timer.total_ms(fwd_name)
         fwd_ms = fwd_total / args.steps
-        bwd_ms = timer.total_ms("ddrr_siddon_backward_rays")[0] / args.steps
+        bwd_ms = sum(timer.total_ms(n)[0] for n in timer.events if "backward" in n) / args.steps
         achieved = alg_bytes / (fwd_ms * 1e-3) / 1e9
         ms_per_step = dt / args.steps * 1e3
         log(f"[bench] step {ms_per_step:.3f} ms | {fwd_name} {fwd_ms:.3f} ms/step in "
-            f"{n_fwd // args.steps} launch(es) | bwd_rays kernel {bwd_ms:.3f} ms | host+torch remainder "
+            f"{n_fwd // args.steps} launch(es) | backward kernels {bwd_ms:.3f} ms | raygen "
+            f"{timer.total_ms('ddrr_raygen_forward')[0] / args.steps:.3f} ms | host+torch remainder "
             f"{ms_per_step - fwd_ms - bwd_ms:.3f} ms | voxels/ray {n_vox / (B * H * H):.1f} "
             f"| {alg_bytes / B / 1e6:.1f} MB algorithmic per DRR")
         result = {

@@ -184,7 +184,13 @@ DDRR_HD BrickGeom brick_geom(const Box &box, const BrickLayout &lay) {
     return G;
 }
 
-DDRR_HD float med3f(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+DDRR_HD float med3f(float v, float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(v, lo, hi);  // one v_med3_f32, lo <= hi
+#else
+    return fminf(fmaxf(v, lo), hi);
+#endif
+}
 
 // Exact clip + walk of one ray through one brick.  `fetch(byte offset)` reads the LDS
 // copy.  Returns false if the ray does not cross the brick (phase A's margin let it

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
 
+from . import ops
 from .detector import Detector
 from .pose import RigidTransform, convert
 from .renderers import Siddon, Trilinear
@@ -113,6 +114,9 @@ class DRR(nn.Module):
         else:
             pose = convert(*args, parameterization=parameterization, convention=convention,
                            degrees=degrees)
+        if self._fused_ok(mask_to_channels, kwargs):
+            return self.reshape_transform(self._render_fused(pose, calibration),
+                                          batch_size=len(pose))
         source, target = self.detector(pose, calibration)
         if self.checkpoint_gradients:
             img = checkpoint(self.render, self.density, source, target, mask_to_channels,
@@ -120,6 +124,30 @@ class DRR(nn.Module):
         else:
             img = self.render(self.density, source, target, mask_to_channels, **kwargs)
         return self.reshape_transform(img, batch_size=len(pose))
+
+    # The DRR case end to end on the GPU: pose -> rays -> line integrals without the
+    # (B, N, 3) ray tensors (and their gradients) passing through PyTorch ops.  Same maths
+    # in the same order as `detector(...)` + `render(...)` (reference detector.py:144-154,
+    # drr.py:191-227); used whenever nothing asks for a feature only the general path has.
+    fuse_ray_generation = True
+
+    def _fused_ok(self, mask_to_channels, kwargs):
+        r = self.renderer
+        return (self.fuse_ray_generation and isinstance(r, Siddon) and r.supports_pose_entry()
+                and ops.on_device(self.density) and self.density.dtype == torch.float32
+                and not mask_to_channels and not kwargs and not self.checkpoint_gradients
+                and self.patch_size is None and self.detector.n_subsample is None
+                and min(self.detector.height, self.detector.width) >= 2)
+
+    def _render_fused(self, pose, calibration):
+        det = self.detector
+        cal = det.calibration if calibration is None else calibration
+        P = cal(det.target)[0].detach()                      # (N,3) detector.py:147-150
+        Mw = (pose.matrix @ det._reorient)[:, :3, :]         # reorient.compose(extrinsic)
+        Ainv = self._affine_inverse[0, :3, :] if self._affine_inverse.dim() == 3 \
+            else self._affine_inverse[:3, :]
+        self.renderer.detector_shape = (det.height, det.width)
+        return self.renderer.render_poses(self.density, Mw, P, Ainv)
 
     def render(self, density: torch.Tensor, source: torch.Tensor, target: torch.Tensor,
                mask_to_channels: bool = False, **kwargs):

@@ -47,6 +47,11 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def on_device(t) -> bool:
+    """Whether `t` lives where the kernels run (the tests' host emulation patches this)."""
+    return t.is_cuda
+
+
 def _require_gpu(volume):
     if not volume.is_cuda:
         raise RuntimeError(
@@ -213,6 +218,54 @@ def siddon_backward_rays(aux, grad_out, source, target, img, *, eps=1e-8, reduce
     return g_source, g_target, g_img
 
 
+def raygen_forward(Mw, Ainv, P):
+    """Fused ray generation (detector.py:151-153 + drr.py:201-205).  Mw (B,3,4) world pose
+    per DRR, Ainv (3,4) world -> voxel, P (N,3) calibrated detector points.
+    -> (source_v (B,1,3), target_v (B,N,3), img (B,N))"""
+    _require_gpu(Mw)
+    B, N = Mw.shape[0], P.shape[0]
+    if Mw.shape[1:] != (3, 4) or Ainv.shape != (3, 4) or P.shape != (N, 3):
+        raise ValueError("raygen_forward: Mw (B,3,4), Ainv (3,4), P (N,3) expected")
+    for t in (Mw, Ainv, P):
+        if t.dtype != torch.float32 or t.device != Mw.device:
+            raise NotImplementedError("raygen_forward needs float32 tensors on one device")
+    Mw, Ainv, P = Mw.contiguous(), Ainv.contiguous(), P.contiguous()
+    dev = Mw.device
+    source = torch.empty(B, 1, 3, dtype=torch.float32, device=dev)
+    target = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+    img = torch.empty(B, N, dtype=torch.float32, device=dev)
+    if not _empty(B, N):
+        _launch("ddrr_raygen_forward", dev, Mw.data_ptr(), Ainv.data_ptr(), P.data_ptr(), B, N,
+                source.data_ptr(), target.data_ptr(), img.data_ptr())
+    elif B > 0:
+        source.zero_()
+    return source, target, img
+
+
+def siddon_backward_pose(aux, grad_out, source, target, img, Mw, Ainv, P, *, eps=1e-8,
+                         with_img_path=True):
+    """dLoss/dMw (B,3,4): the renderer's ray gradients chained through the ray generation
+    and reduced per pose in one kernel (reduce sum)."""
+    B, N, _ = target.shape
+    if aux.shape == (B, N, SIDDON_AUX):
+        layout = _lib.AUX_INTERLEAVED
+    elif aux.shape == (_lib.BRICK_AUX_PLANES, B, N):
+        layout = _lib.AUX_PLANAR
+    else:
+        raise ValueError(f"aux has shape {tuple(aux.shape)}: neither (B,N,8) nor (5,B,N)")
+    gMw = torch.zeros(B, 3, 4, dtype=torch.float32, device=target.device)
+    if B == 0:
+        return gMw
+    # (named, so that a contiguous copy outlives the launch)
+    grad_out, source, target, img = (t.contiguous() for t in (grad_out, source, target, img))
+    Mw, Ainv, P = Mw.contiguous(), Ainv.contiguous(), P.contiguous()
+    _launch("ddrr_siddon_backward_pose", target.device, aux.data_ptr(), layout,
+            grad_out.data_ptr(), source.data_ptr(), target.data_ptr(), img.data_ptr(),
+            Mw.data_ptr(), Ainv.data_ptr(), P.data_ptr(), B, N, float(eps),
+            int(bool(with_img_path)), gMw.data_ptr())
+    return gMw
+
+
 def siddon_backward_volume(volume, source, target, img, grad_out, *, voxel_shift=0.5, eps=1e-8,
                            reducefn="sum", det=None, tile=None):
     B, N = _check_rays(volume, source, target, img)
@@ -220,9 +273,11 @@ def siddon_backward_volume(volume, source, target, img, grad_out, *, voxel_shift
     dh, dw, th, tw = _hints(det, tile, N)
     if _empty(B, N):
         return g_volume
+    volume, source, target, grad_out = (t.contiguous() for t in (volume, source, target, grad_out))
+    img = None if img is None else img.contiguous()
     _launch(
         "ddrr_siddon_backward_volume", volume.device, volume.data_ptr(), *volume.shape, source.data_ptr(),
-        source.shape[1], target.data_ptr(), _ptr(img), grad_out.contiguous().data_ptr(), B, N,
+        source.shape[1], target.data_ptr(), _ptr(img), grad_out.data_ptr(), B, N,
         float(voxel_shift), float(eps), reduce_code(reducefn), dh, dw, th, tw,
         g_volume.data_ptr())
     return g_volume
@@ -238,8 +293,9 @@ def siddon_forward_channels(volume, labels_u8, n_channels, source, target, img, 
     dh, dw, th, tw = _hints(det, tile, N)
     if _empty(B, N):
         return out
+    labels_u8, volume = labels_u8.contiguous(), volume.contiguous()
     _launch(
-        "ddrr_siddon_forward_channels", volume.device, volume.data_ptr(), labels_u8.contiguous().data_ptr(),
+        "ddrr_siddon_forward_channels", volume.device, volume.data_ptr(), labels_u8.data_ptr(),
         *volume.shape, source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img), B, N,
         int(n_channels), float(voxel_shift), float(eps), dh, dw, th, tw, out.data_ptr())
     return out
@@ -281,9 +337,10 @@ def trilinear_backward(volume, source, target, img, grad_out, alphamin, alphamax
            "g_volume": g_volume}
     if _empty(B, N):
         return res
+    grad_out = grad_out.contiguous()
     _launch(
         "ddrr_trilinear_backward", dev, volume.data_ptr(), *volume.shape, source.data_ptr(),
-        source.shape[1], target.data_ptr(), _ptr(img), grad_out.contiguous().data_ptr(), B, N,
+        source.shape[1], target.data_ptr(), _ptr(img), grad_out.data_ptr(), B, N,
         float(voxel_shift), float(eps), int(n_points), alphamin.data_ptr(),
         alphamax.data_ptr(), int(mode == "nearest"), int(bool(align_corners)), dh, dw, th, tw,
         _ptr(g_source), _ptr(g_target), _ptr(g_img), _ptr(g_alpha), _ptr(g_volume))

@@ -100,6 +100,53 @@ class _SiddonFn(torch.autograd.Function):
         return g_vol, g_s, g_t, g_i, None
 
 
+class _SiddonPoseFn(torch.autograd.Function):
+    """The DRR case end to end: world pose per DRR -> image.  Inputs: volume, Mw (B,3,4)
+    (extrinsic o reorient), P (N,3) calibrated detector points, Ainv (3,4) world -> voxel.
+    Forward = fused ray generation (ddrr_raygen_forward: detector.py:151-153 +
+    drr.py:201-205) + the Siddon kernel; backward = ddrr_siddon_backward_pose (ray
+    gradients chained through the ray generation and reduced to dLoss/dMw in one kernel)
+    and, if asked for, the volume-gradient scatter."""
+
+    @staticmethod
+    def forward(ctx, volume, Mw, P, Ainv, cfg):
+        source, target, img = ops.raygen_forward(Mw, Ainv, P)
+        want_aux = bool(ctx.needs_input_grad[1])
+        if cfg["path"] == "bricks":
+            out, aux = ops.siddon_forward_bricks(
+                volume, source, target, img, cfg["det"], voxel_shift=cfg["voxel_shift"],
+                eps=cfg["eps"], want_aux=want_aux)
+        elif cfg["path"] == "slab":
+            plan, shear = slab_plan(source, target, *cfg["det"])
+            out, aux = ops.siddon_forward_slab(
+                volume, source, target, img, cfg["det"], plan, shear,
+                voxel_shift=cfg["voxel_shift"], eps=cfg["eps"], want_aux=want_aux)
+        else:
+            out, aux, _ = ops.siddon_forward(
+                volume, source, target, img, voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
+                want_aux=want_aux, det=cfg["det"], tile=cfg["tile"])
+        ctx.cfg = cfg
+        ctx.save_for_backward(volume, Mw, P, Ainv, source, target, img, aux)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        volume, Mw, P, Ainv, source, target, img, aux = ctx.saved_tensors
+        cfg = ctx.cfg
+        need_vol, need_M = ctx.needs_input_grad[:2]
+        stop = cfg["stop_gradients"]
+        g_vol = g_M = None
+        grad_out = grad_out.contiguous()
+        if need_M:
+            g_M = ops.siddon_backward_pose(aux, grad_out, source, target, img, Mw, Ainv, P,
+                                           eps=cfg["eps"], with_img_path=not stop)
+        if need_vol and not stop:
+            g_vol = ops.siddon_backward_volume(
+                volume, source, target, img, grad_out, voxel_shift=cfg["voxel_shift"],
+                eps=cfg["eps"], reducefn="sum", det=cfg["det"], tile=cfg["tile"])
+        return g_vol, g_M, None, None, None
+
+
 class Siddon(torch.nn.Module):
     """Differentiable X-ray renderer: Siddon's exact ray tracing (reference
     renderers.py:11-91) as one fused gfx950 kernel per call."""
@@ -148,6 +195,18 @@ class Siddon(torch.nn.Module):
                 "lookup": lookup, "align_corners": bool(align_corners),
                 "stop_gradients": self.stop_gradients_through_grid_sample,
                 "det": self.detector_shape, "tile": self.tile, "path": self.grid_path}
+
+    def supports_pose_entry(self):
+        """Whether ``render_poses`` (the fused DRR entry) computes what ``forward`` would."""
+        return self.mode == "nearest" and self.reducefn == "sum"
+
+    def render_poses(self, volume, Mw, P, Ainv):
+        """The DRR case without materialising the ray tensors in PyTorch: ``Mw`` (B,3,4)
+        world pose per DRR (extrinsic o reorient), ``P`` (N,3) calibrated detector points,
+        ``Ainv`` (3,4) world -> voxel.  Equals ``forward(volume, *rays(Mw, P, Ainv))``;
+        -> (B, 1, N)."""
+        cfg = self._cfg(False)
+        return _SiddonPoseFn.apply(volume, Mw, P, Ainv, cfg).unsqueeze(1)
 
     def forward(self, volume, source, target, img, align_corners=False, mask=None):
         B, N, _ = target.shape

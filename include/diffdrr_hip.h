@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 2
+#define DDRR_ABI_VERSION 3
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -152,6 +152,26 @@ int ddrr_trilinear_backward(const float *volume, int dx, int dy, int dz, const f
                             int mode_nearest, int align_corners, int det_h, int det_w, int tile_h,
                             int tile_w, float *g_source, float *g_target, float *g_img,
                             float *g_alpha, float *g_volume, void *stream);
+
+/* Fused ray generation for the DRR case: replaces the tensor programs between a pose and
+ * the renderer call -- detector.py:151-153 (pose = reorient o extrinsic applied to the
+ * calibrated detector points), drr.py:201 (img = ||target - source||, world units) and
+ * drr.py:204-205 (affine_inverse to voxel coordinates).  Mw (B, 3, 4): world pose of the
+ * C-arm per DRR; Ainv (3, 4): world -> voxel; P (N, 3): calibrated detector points
+ * (detector.py:147-150).  Writes source_v (B, 3), target_v (B, N, 3), img (B, N). */
+int ddrr_raygen_forward(const float *Mw, const float *Ainv, const float *P, int B, int N,
+                        float *source_v, float *target_v, float *img, void *stream);
+
+/* Adjoint of ddrr_raygen_forward chained behind ddrr_siddon_backward_rays, reduced per
+ * pose in the kernel: gMw (B, 3, 4) = dLoss/dMw from the forward record `aux`, grad_out
+ * (B, N) and the rays the forward used.  Replaces torch autograd of renderers.py:94-113,
+ * drr.py:201-205 and detector.py:151-153 (no (B, N, 3) gradient tensor is materialised).
+ * with_img_path = 0 drops the gradient through `img`
+ * (stop_gradients_through_grid_sample, renderers.py:63-65).  Reduce sum only. */
+int ddrr_siddon_backward_pose(const float *aux, int aux_layout, const float *grad_out,
+                              const float *source_v, const float *target_v, const float *img,
+                              const float *Mw, const float *Ainv, const float *P, int B, int N,
+                              float eps, int with_img_path, float *gMw, void *stream);
 
 #ifdef __cplusplus
 }

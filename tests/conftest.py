@@ -69,6 +69,7 @@ def emulated_ops(emu_lib, monkeypatch):
     from diffdrr_amd import ops
 
     monkeypatch.setattr(ops, "_require_gpu", lambda volume: None)
+    monkeypatch.setattr(ops, "on_device", lambda t: True)
     monkeypatch.setattr(ops, "_launch", lambda name, device, *a: emu_lib.call(name, *a, None))
     return ops
 

@@ -18,6 +18,7 @@
 #include "../../diffdrr_amd/csrc/siddon_core.h"
 #include "../../diffdrr_amd/csrc/brick_core.h"
 #include "../../diffdrr_amd/csrc/brick_walk.h"
+#include "../../diffdrr_amd/csrc/raygen_core.h"
 #include "../../diffdrr_amd/csrc/slab_core.h"
 #include "../../diffdrr_amd/csrc/trilinear_core.h"
 #include "../../include/diffdrr_hip.h"
@@ -500,6 +501,53 @@ int ddrr_trilinear_backward(const float *volume, int dx, int dy, int dz, const f
                 g_alpha[r * 2 + 1] = m.g_amax;
             }
         });
+    return 0;
+}
+
+int ddrr_raygen_forward(const float *Mw, const float *Ainv, const float *P, int B, int N,
+                        float *source_v, float *target_v, float *img, void *) {
+    for (int b = 0; b < B; ++b) {
+        const float *M = Mw + (long)b * 12;
+        const float sw[3] = {M[3], M[7], M[11]};
+        apply34(Ainv, sw, source_v + b * 3);
+        for (int n = 0; n < N; ++n) {
+            const RayGenOut o = raygen_ray(M, Ainv, P + (long)n * 3);
+            const long r = (long)b * N + n;
+            for (int a = 0; a < 3; ++a) target_v[r * 3 + a] = o.tv[a];
+            img[r] = o.L;
+        }
+    }
+    return 0;
+}
+
+int ddrr_siddon_backward_pose(const float *aux, int aux_layout, const float *grad_out,
+                              const float *source_v, const float *target_v, const float *img,
+                              const float *Mw, const float *Ainv, const float *P, int B, int N,
+                              float eps, int with_img_path, float *gMw, void *) {
+    const long R = (long)B * N;
+    for (int b = 0; b < B; ++b) {
+        float acc[12] = {0};
+        const float *s = source_v + b * 3;
+        for (int n = 0; n < N; ++n) {
+            const long r = (long)b * N + n;
+            float rec[SIDDON_AUX];
+            if (aux_layout == DDRR_AUX_PLANAR) {
+                const float I = aux[r], S0x = aux[R + r], S0z = aux[2 * R + r];
+                const float S1x = aux[3 * R + r], S1z = aux[4 * R + r];
+                const float v[SIDDON_AUX] = {I, S0x, -(S0x + S0z), S0z,
+                                             S1x, I - (S1x + S1z), S1z, 0.f};
+                memcpy(rec, v, sizeof(v));
+            } else {
+                memcpy(rec, aux + r * SIDDON_AUX, sizeof(rec));
+            }
+            float gs[3], gt[3];
+            siddon_backward_ray<REDUCE_SUM>(rec, s, target_v + r * 3, eps, grad_out[r] * img[r],
+                                            gs, gt);
+            raygen_ray_adjoint(Mw + (long)b * 12, Ainv, P + (long)n * 3, gt, gs,
+                               with_img_path ? grad_out[r] * rec[0] : 0.f, img[r], acc);
+        }
+        memcpy(gMw + (long)b * 12, acc, sizeof(acc));
+    }
     return 0;
 }
 

@@ -42,6 +42,7 @@ def _patch_ops():
 
     emu = DdrrLibrary(build_emu())
     ops._require_gpu = lambda volume: None
+    ops.on_device = lambda t: True
     ops._launch = lambda name, device, *a: emu.call(name, *a, None)
 
 

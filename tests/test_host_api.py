@@ -231,3 +231,54 @@ def test_registration_trajectory_matches_reference(emulated_ops, stop):
         assert rel_err(reg._translation.detach().numpy(), g[f"xyzs_{tag}"][k]) < 2e-3
         opt.step()
     assert g[f"losses_{tag}"][-1] > g[f"losses_{tag}"][0]  # the reference itself improves
+
+
+@pytest.mark.parametrize("stop", [False, True])
+@pytest.mark.parametrize("path", ["bricks", "generic"])
+def test_fused_ray_generation_equals_general_path(emulated_ops, path, stop):
+    """DRR.forward's fused entry (raygen kernel + renderer + pose-gradient kernel,
+    csrc/raygen_core.h) against the general path (Detector + render in PyTorch, renderer
+    on ray tensors): same image, same gradients w.r.t. the pose parameters and the volume."""
+    from diffdrr_amd import DRR
+    from diffdrr_amd.data import synthetic_subject
+
+    drr = DRR(synthetic_subject(40, kind="noise", seed=0), sdd=400.0, height=22, width=30,
+              delx=1.8, stop_gradients_through_grid_sample=stop)
+    drr.renderer.grid_path = path
+    drr.density.requires_grad_(not stop)
+    rot0 = torch.tensor([[0.1, -0.2, 0.3], [0.6, 0.4, -0.5], [0.0, 0.01, 0.02]])
+    xyz0 = torch.tensor([[3.0, 250.0, -2.0], [10.0, 230.0, 6.0], [0.5, 260.0, 0.3]])
+    go = torch.rand(3, 1, 22, 30, generator=torch.Generator().manual_seed(4))
+    res = {}
+    for fused in (True, False):
+        drr.fuse_ray_generation = fused
+        rot, xyz = rot0.clone().requires_grad_(), xyz0.clone().requires_grad_()
+        drr.density.grad = None
+        img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+        (img * go).sum().backward()
+        res[fused] = (img.detach(), rot.grad, xyz.grad,
+                      None if stop else drr.density.grad.clone())
+    a, b = res[True], res[False]
+    assert rel_err(a[0].numpy(), b[0].numpy()) < 1e-5
+    assert rel_err(a[1].numpy(), b[1].numpy()) < 2e-3
+    assert rel_err(a[2].numpy(), b[2].numpy()) < 2e-3
+    if not stop:
+        assert rel_err(a[3].numpy(), b[3].numpy()) < 1e-5
+
+
+def test_fused_entry_is_skipped_when_a_general_feature_is_asked_for(emulated_ops):
+    from diffdrr_amd import DRR
+    from diffdrr_amd.data import synthetic_subject
+
+    drr = DRR(synthetic_subject(24, kind="phantom", seed=0), sdd=300.0, height=12, delx=2.0)
+    assert drr._fused_ok(False, {})
+    assert not drr._fused_ok(True, {})                       # mask_to_channels
+    assert not drr._fused_ok(False, {"align_corners": True})  # renderer kwargs
+    drr.renderer.reducefn = "max"
+    assert not drr._fused_ok(False, {})
+    drr2 = DRR(synthetic_subject(24, kind="phantom", seed=0), sdd=300.0, height=12, delx=2.0,
+               renderer="trilinear")
+    assert not drr2._fused_ok(False, {})
+    drr3 = DRR(synthetic_subject(24, kind="phantom", seed=0), sdd=300.0, height=12, delx=2.0,
+               patch_size=6)
+    assert not drr3._fused_ok(False, {})

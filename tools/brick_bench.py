@@ -16,6 +16,8 @@ ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--det", type=int, default=256)
 ap.add_argument("--layouts", default="33:1057")
 ap.add_argument("--cases", default="pert32,pert32aux,base32,pert1,pert8,pert128")
+ap.add_argument("--dbg", default="0")
+ap.add_argument("--classes", default="14:34")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 D, H = a.size, a.det
@@ -34,8 +36,14 @@ for case in a.cases.split(","):
     else:
         s, t, L = rays(drr, *poses(int(name[4:]), 2, dev))
     sets[case] = (s, t, L, aux)
-for lay in a.layouts.split(","):
+import itertools
+for lay, dbg, cl in itertools.product(a.layouts.split(","), a.dbg.split(","), a.classes.split(",")):
     sy, sx = (int(v) for v in lay.split(":"))
+    lib.cdll.ddrr_set_brick_debug(int(dbg))
+    t1, t2 = (float(v) for v in cl.split(":"))
+    import ctypes
+    lib.cdll.ddrr_set_brick_classes(ctypes.c_float(t1), ctypes.c_float(t2))
+    lay = f"{lay} dbg{dbg} cls{cl}"
     rc = lib.cdll.ddrr_set_brick_layout(sy, sx)
     if rc != 0:
         print(f"layout {lay}: rejected")
@@ -49,6 +57,6 @@ for lay in a.layouts.split(","):
         ref = ops.siddon_forward(V, s, t, L, det=(H, H))[0]
         out = ops.siddon_forward_bricks(V, s, t, L, (H, H), want_aux=aux)[0]
         err = ((out - ref).abs().max() / ref.abs().max()).item()
-        print(f"layout {lay:9s} {case:12s} B {B:4d} vox/ray {nvox / (B * H * H):6.1f}  {med:8.3f} ms "
+        print(f"layout {lay:26s} {case:12s} B {B:4d} vox/ray {nvox / (B * H * H):6.1f}  {med:8.3f} ms "
               f"(best {best:7.3f})  {B / med * 1e3:9.0f} DRR/s  {alg / med / 1e6:8.1f} GB/s alg "
               f"({alg / med / 1e6 / 8000 * 100:5.1f}% of 8 TB/s)  err vs generic {err:.1e}", flush=True)
