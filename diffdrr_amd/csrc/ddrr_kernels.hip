@@ -354,11 +354,12 @@ struct BrickArgs {
     int pix_bits;        // queue entry = (pose << pix_bits) | pixel
     float t1, t2;        // length-class thresholds on the estimated crossing count
     int dbg;             // experiment switches (0 in production)
+    int *work;           // global brick counter of this launch (zero at launch)
 };
 
 inline size_t brick_lds_bytes(const BrickLayout &lay) {
     return (size_t)brick_floats(lay) * 4 + (size_t)kBrickWaves * kBuckets * kQueueCap * 4 +
-           (size_t)(kPoseChunk * kRowWords + kPoseChunk + 1 + 1) * 4;
+           (size_t)(kPoseChunk * kRowWords + 2) * 4;
 }
 
 // Phase B for one queue entry: load the real ray, clip, walk, add to the image.
@@ -397,41 +398,34 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
     float *brick = reinterpret_cast<float *>(smem_raw);
     unsigned *queue = reinterpret_cast<unsigned *>(brick + brick_floats(p.lay));
     float *rows = reinterpret_cast<float *>(queue + kBrickWaves * kBuckets * kQueueCap);
-    int *pref = reinterpret_cast<int *>(rows + kPoseChunk * kRowWords);  // [chunk + 1]
-    int *counter = pref + kPoseChunk + 1;
+    int *counter = reinterpret_cast<int *>(rows + kPoseChunk * kRowWords);  // [0] unit, [1] brick
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const BrickGrid bg = brick_grid(p.D);
-    const Box box = brick_box(p.D, bg, blockIdx.x);
-    const BrickGeom G = brick_geom(box, p.lay);
+    const int n_bricks = bg.nx * bg.ny * bg.nz;
     const int N = p.det_h * p.det_w;
-
-    // stage the brick: 32 x 32 rows of 32 floats (one 128-byte line each), zero padded
-    for (int row = tid >> 3; row < BRICK * BRICK; row += kBrickThreads >> 3) {
-        const int lx = row / BRICK, ly = row - lx * BRICK, q4 = (tid & 7) * 4;
-        const int x = box.lo[0] + lx, y = box.lo[1] + ly, z = box.lo[2] + q4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (x < box.hi[0] && y < box.hi[1]) {
-            const float *g = p.vol + ((long)x * p.D.y + y) * p.D.z + z;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (z + k < box.hi[2]) v[k] = g[k];
-        }
-        float *d = brick + lx * p.lay.sx + ly * p.lay.sy + q4;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) d[k] = v[k];
-    }
-
     volatile unsigned *myq = queue + wave * kBuckets * kQueueCap;
-    int qn0 = 0, qn1 = 0, qn2 = 0;  // hits waiting per length class (wave-uniform)
     const unsigned pix_mask = (1u << p.pix_bits) - 1u;
-
     const int n_chunks = (p.B + kPoseChunk - 1) / kPoseChunk;
+    const bool vec_ok = (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.vol) & 15) == 0;
+
+  // Persistent workgroups: bricks are handed out by a global counter, so a CU that drew
+  // light bricks (far from the sources: fewer rays cross them) simply takes more of them.
+  for (;;) {
+    __syncthreads();  // every wave is done with the previous brick's LDS
+    if (tid == 0) counter[1] = atomicAdd(p.work, 1);
+    __syncthreads();
+    const int brick_id = counter[1];
+    if (brick_id >= n_bricks) break;
+    const Box box = brick_box(p.D, bg, brick_id);
+    const BrickGeom G = brick_geom(box, p.lay);
+    int qn0 = 0, qn1 = 0, qn2 = 0;  // hits waiting per length class (wave-uniform)
+
     for (int ch = 0; ch < n_chunks; ++ch) {
         const int b0 = ch * kPoseChunk;
         const int nb = p.B - b0 < kPoseChunk ? p.B - b0 : kPoseChunk;
         const bool last_chunk = ch == n_chunks - 1;
-        __syncthreads();  // brick staged / previous chunk's tables no longer in use
+        if (ch > 0) __syncthreads();  // previous chunk's table no longer in use
         if (tid < nb) {
             const PoseGrid pg = pose_grid(p.source + (long)(b0 + tid) * 3,
                                           p.target + (long)(b0 + tid) * N * 3, p.det_h, p.det_w);
@@ -439,22 +433,44 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
             const BrickRow r = brick_row(pg, pb, box, p.shift, p.eps);
             *reinterpret_cast<BrickRow *>(rows + tid * kRowWords) = r;
         }
-        if (tid == 0) *counter = 0;
-        __syncthreads();
-        if (tid == 0) {
-            int acc = 0;
-            for (int k = 0; k < nb; ++k) {
-                pref[k] = acc;
-                acc += (reinterpret_cast<const BrickRow *>(rows + k * kRowWords)->count + 63) >> 6;
+        if (tid == 0) counter[0] = 0;
+        if (ch == 0) {
+            // stage the brick: 32 x 32 rows of 32 floats (one 128-byte line each), zero padded
+            for (int row = tid >> 3; row < BRICK * BRICK; row += kBrickThreads >> 3) {
+                const int lx = row / BRICK, ly = row - lx * BRICK, q4 = (tid & 7) * 4;
+                const int x = box.lo[0] + lx, y = box.lo[1] + ly, z = box.lo[2] + q4;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (x < box.hi[0] && y < box.hi[1]) {
+                    const float *g = p.vol + ((long)x * p.D.y + y) * p.D.z + z;
+                    if (vec_ok && z + 4 <= box.hi[2]) {
+                        const float4 q = *reinterpret_cast<const float4 *>(g);
+                        v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (z + k < box.hi[2]) v[k] = g[k];
+                    }
+                }
+                float *d = brick + lx * p.lay.sx + ly * p.lay.sy + q4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = v[k];
             }
-            pref[nb] = acc;
         }
         __syncthreads();
-        const int units = pref[nb];
-        int cur = 0, cur_lo = 0, cur_hi = uni(pref[1]);
+        // units per pose -> inclusive prefix, held by every wave in registers (lane k: pose k)
+        int incl = lane < nb ? (reinterpret_cast<const BrickRow *>(rows + lane * kRowWords)->count +
+                                63) >> 6
+                             : 0;
+#pragma unroll
+        for (int o = 1; o < kPoseChunk; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            incl += lane >= o ? up : 0;
+        }
+        const int units = __builtin_amdgcn_readlane(incl, kPoseChunk - 1);
+        int cur = 0, cur_lo = 0, cur_hi = __builtin_amdgcn_readlane(incl, 0);
         for (;;) {
             int u = 0;
-            if (lane == 0) u = atomicAdd(counter, 1);
+            if (lane == 0) u = atomicAdd(&counter[0], 1);
             u = uni(u);
             const bool drain = u >= units;  // no unit left in this chunk
             if (drain && !last_chunk) break;
@@ -462,7 +478,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
                 while (u >= cur_hi) {  // units arrive in increasing order: forward cursor
                     ++cur;
                     cur_lo = cur_hi;
-                    cur_hi = uni(pref[cur + 1]);
+                    cur_hi = __builtin_amdgcn_readlane(incl, uni(cur));
                 }
                 const BrickRow r = *reinterpret_cast<const BrickRow *>(rows + cur * kRowWords);
                 const int local = (u - cur_lo) * 64 + lane;
@@ -539,6 +555,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
             if (drain) break;
         }
     }
+  }
 }
 
 // mask_to_channels (renderers.py:77-89): the ray owns column out[b, :, n]; runs
@@ -943,8 +960,28 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute");
         attr_set = true;
     }
+    // one brick counter per launch, from a small per-device ring (launches in flight on
+    // different streams must not share one); zeroed on the launch's stream
+    constexpr int kRing = 64, kMaxDev = 64;
+    static int *ring[kMaxDev] = {nullptr};
+    static int n_cu[kMaxDev] = {0};
+    static unsigned slot[kMaxDev] = {0};
+    int dev = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return fail_hip(e, "hipGetDevice");
+    if (dev < 0 || dev >= kMaxDev) return fail(-1, "device index out of range");
+    if (!ring[dev]) {
+        if ((e = hipMalloc(reinterpret_cast<void **>(&ring[dev]), kRing * sizeof(int))) != hipSuccess)
+            return fail_hip(e, "hipMalloc(brick counters)");
+        if ((e = hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev)) !=
+            hipSuccess)
+            return fail_hip(e, "hipDeviceGetAttribute");
+    }
+    p.work = ring[dev] + (slot[dev]++ % kRing);
+    if ((e = hipMemsetAsync(p.work, 0, sizeof(int), st)) != hipSuccess)
+        return fail_hip(e, "hipMemsetAsync");
     const BrickGrid bg = brick_grid(p.D);
-    const dim3 grid(bg.nx * bg.ny * bg.nz), block(kBrickThreads);
+    const int n_bricks = bg.nx * bg.ny * bg.nz;
+    const dim3 grid(n_bricks < n_cu[dev] ? n_bricks : n_cu[dev]), block(kBrickThreads);
     if (aux)
         hipLaunchKernelGGL(siddon_fwd_brick_kernel<true>, grid, block, lds, st, p, out, aux);
     else
