@@ -391,6 +391,11 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask) {
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <bool AUX>
 __global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
     BrickArgs p, float *__restrict__ out, float *__restrict__ aux) {
@@ -404,7 +409,9 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
     const BrickGrid bg = brick_grid(p.D);
     const int n_bricks = bg.nx * bg.ny * bg.nz;
     const int N = p.det_h * p.det_w;
-    volatile unsigned *myq = queue + wave * kBuckets * kQueueCap;
+    // wave-private: written and read by lanes of the same wave only.  LDS operations of a
+    // wave execute in order; wave_fence() keeps the compiler from reordering them.
+    unsigned *myq = queue + wave * kBuckets * kQueueCap;
     const unsigned pix_mask = (1u << p.pix_bits) - 1u;
     const int n_chunks = (p.B + kPoseChunk - 1) / kPoseChunk;
     const bool vec_ok = (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.vol) & 15) == 0;
@@ -501,20 +508,20 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
                     n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
                         0, __builtin_bit_cast(int, n_grp), 0x141, 0xf, 0xf, true)));  // 7 - lane
                 }
-                const int cls = n_grp < p.t1 ? 0 : (n_grp < p.t2 ? 1 : 2);
-                const unsigned long long m0 = __ballot(hit && cls == 0);
-                const unsigned long long m1 = __ballot(hit && cls == 1);
-                const unsigned long long m2 = __ballot(hit && cls == 2);
+                const bool c0 = n_grp < p.t1, c1 = !c0 && n_grp < p.t2;
+                const unsigned long long m0 = __ballot(hit && c0);
+                const unsigned long long m1 = __ballot(hit && c1);
+                const unsigned long long m2 = __ballot(hit && !c0 && !c1);
                 if (hit) {
-                    const unsigned long long mine = cls == 0 ? m0 : (cls == 1 ? m1 : m2);
-                    const int qb = cls == 0 ? qn0 : (cls == 1 ? qn1 : qn2);
-                    myq[cls * kQueueCap + qb + lane_rank(mine)] =
-                        ((unsigned)(b0 + cur) << p.pix_bits) | (unsigned)pix;
+                    const int r0 = lane_rank(m0), r1 = lane_rank(m1), r2 = lane_rank(m2);
+                    const int slot = c0 ? qn0 + r0 : (c1 ? kQueueCap + qn1 + r1
+                                                         : 2 * kQueueCap + qn2 + r2);
+                    myq[slot] = ((unsigned)(b0 + cur) << p.pix_bits) | (unsigned)pix;
                 }
                 qn0 = uni(qn0 + (int)__popcll(m0));
                 qn1 = uni(qn1 + (int)__popcll(m1));
                 qn2 = uni(qn2 + (int)__popcll(m2));
-                __builtin_amdgcn_wave_barrier();
+                wave_fence();
             }
             // walk every full batch of 64 hits of one class; when draining, what is left
             // of all classes together (longest first), 64 at a time
@@ -550,7 +557,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
                 }
                 if (lane < n)
                     brick_item<AUX>(p, brick, G, e >> p.pix_bits, e & pix_mask, out, aux);
-                __builtin_amdgcn_wave_barrier();
+                wave_fence();
             }
             if (drain) break;
         }
