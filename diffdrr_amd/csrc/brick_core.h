@@ -178,6 +178,29 @@ DDRR_HD bool brick_maybe_hit(const Box &box, const float s[3], const float t[3],
     return entry < exit + slack;  // false for NaN
 }
 
+#if defined(__HIPCC__)
+// Fetch by ABSOLUTE LDS byte address (the brick's base is folded into the offset the walk
+// carries, so a step issues `ds_read_b32 v, addr` with no address arithmetic).
+struct LdsAbsFetch {
+    static __device__ __forceinline__ unsigned base_of(const float *brick) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) float *)brick;
+#else
+        (void)brick;
+        return 0u;  // (host pass of the single-source compile: never executed)
+#endif
+    }
+    __device__ __forceinline__ float operator()(unsigned addr) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return *(const __attribute__((address_space(3))) float *)(unsigned long long)addr;
+#else
+        (void)addr;
+        return 0.f;
+#endif
+    }
+};
+#endif
+
 // Candidate pixel `local` (row-major index into the pixel box) -> (i, j).
 DDRR_HD void pixbox_pixel(int i0, int j0, int w, float inv_w, int local, int &i, int &j) {
     // exact for the box sizes that occur (local < 2^22): no integer division

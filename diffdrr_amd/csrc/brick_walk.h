@@ -168,7 +168,7 @@ DDRR_HD bool brick_candidate(const BrickRow &r, int local, int det_w, int &pix, 
 
 struct BrickGeom {
     float lof[3], hif[3];  // the brick's first / last plane index per axis, as floats
-    int stride[3];         // BYTE strides of the LDS copy
+    float stridef[3];      // BYTE strides of the LDS copy (as floats: offsets stay < 2^24)
 };
 
 DDRR_HD BrickGeom brick_geom(const Box &box, const BrickLayout &lay) {
@@ -178,9 +178,9 @@ DDRR_HD BrickGeom brick_geom(const Box &box, const BrickLayout &lay) {
         G.lof[a] = (float)box.lo[a];
         G.hif[a] = (float)box.hi[a];
     }
-    G.stride[0] = lay.sx * 4;
-    G.stride[1] = lay.sy * 4;
-    G.stride[2] = 4;
+    G.stridef[0] = (float)(lay.sx * 4);
+    G.stridef[1] = (float)(lay.sy * 4);
+    G.stridef[2] = 4.f;
     return G;
 }
 
@@ -192,14 +192,16 @@ DDRR_HD float med3f(float v, float lo, float hi) {
 #endif
 }
 
-// Exact clip + walk of one ray through one brick.  `fetch(byte offset)` reads the LDS
-// copy.  Returns false if the ray does not cross the brick (phase A's margin let it
+// Exact clip + walk of one ray through one brick.  `fetch(fetch_base + byte offset)` reads
+// the LDS copy (fetch_base: 0 for a pointer-relative fetch, the brick's LDS address for
+// LdsAbsFetch; the sum stays an exact fp32 integer).  Returns false if the ray does not cross the brick (phase A's margin let it
 // through).  I = sum V dalpha over the brick.  With AUX, rec = {S0x, S0z, S1x, S1z} of the
 // brick-local backward record (voxels outside the brick count as 0, so that the records
 // of the bricks along a ray add up to the whole ray's: siddon_core.h SIDDON_AUX).
 template <bool AUX, class Fetch>
-DDRR_HD bool brick_trace(const Fetch &fetch, const BrickGeom &G, const float s[3],
-                         const float t[3], float shift, float eps, float &I, float rec[4]) {
+DDRR_HD bool brick_trace(const Fetch &fetch, float fetch_base, const BrickGeom &G,
+                         const float s[3], const float t[3], float shift, float eps, float &I,
+                         float rec[4]) {
     float d[3], inv[3], c[3], mn[3];
     float entry = -INFINITY, exit = INFINITY;
 #pragma unroll
@@ -228,8 +230,11 @@ DDRR_HD bool brick_trace(const Fetch &fetch, const BrickGeom &G, const float s[3
 
     // entry cell per axis (siddon_enter, incl. its alpha-order consistency rule)
     float k[3], an[3], dirf[3];
-    int dstep[3];
-    float offf = 0.f;
+    // The voxel's byte offset is an affine function of the three plane counters,
+    //   off = sum_a (k_a - p01_a - lo_a) stride_a,
+    // exact in fp32 (< 2^24): three FMAs and a convert per step instead of three selects
+    // and two integer adds, and no per-axis step registers.
+    float offc = fetch_base;  // what `fetch` wants added to the brick-relative offset
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const bool pos = d[a] > 0.f;
@@ -244,57 +249,113 @@ DDRR_HD bool brick_trace(const Fetch &fetch, const BrickGeom &G, const float s[3
         u = (mn[a] == entry) ? (pos ? G.lof[a] : cmax) : u;  // entering axis: its face cell
         k[a] = u + p01;
         an[a] = fmaf(k[a], inv[a], c[a]);
-        offf = fmaf(u - G.lof[a], (float)G.stride[a], offf);  // exact: < 2^24
-        dstep[a] = pos ? G.stride[a] : -G.stride[a];
+        offc = fmaf(-(p01 + G.lof[a]), G.stridef[a], offc);
     }
-    unsigned off = (unsigned)(int)offf;
+#define DDRR_BRICK_OFF() \
+    ((unsigned)(int)fmaf(k[0], G.stridef[0], fmaf(k[1], G.stridef[1], fmaf(k[2], G.stridef[2], offc))))
+    unsigned off = DDRR_BRICK_OFF();
 
-    // which crossing opened the first segment, exclusive x > y > z (for the record)
-    bool ox = mn[0] == entry;
-    bool oz = !ox && !(mn[1] == entry);
+    // The walk, software-pipelined by hand.  Step i closes segment i (the ray inside voxel
+    // i): it needs that voxel's VALUE only for the products, never for the geometry, so a
+    // voxel is requested one step ahead (its address is known once the plane counters
+    // have moved) and consumed one step late: the LDS latency (~100+ cycles with bank
+    // conflicts) is covered by a full step of arithmetic instead of stalling every step.
+    // Three value registers rotate (r[i % 3] holds voxel i); with the backward record the
+    // crossing that OPENED segment i-1 is settled together with it: V_before - V_after =
+    // voxel i-2 - voxel i-1, weighted by 1 and by the crossing's alpha for its axis
+    // (exclusive attribution x > y > z, as in siddon_core.h).
+    float r0 = fetch(off), r1 = 0.f, r2 = 0.f;  // voxel 0 requested; voxels -1, -2 := 0
+    float len_p = 0.f;       // length of segment i-1
+    float aop_p = entry;     // alpha of the crossing that opened segment i-1
+    bool ox_p = false, oz_p = false;  // ... and its axis (x / z; y follows from the sums)
+    // the crossing that opens segment 0 is the entry into the brick
+    bool ox_c = mn[0] == entry;
+    bool oz_c = !ox_c && !(mn[1] == entry);
     float a_cur = entry, acc = 0.f;
-    float v = fetch(off), v_prev = 0.f;
     float S0x = 0.f, S1x = 0.f, S0z = 0.f, S1z = 0.f;
-    for (int it = 0; it < 3 * BRICK + 3; ++it) {  // a brick holds < 3 * BRICK crossings
-        const float a_next = fminf(fminf(an[0], an[1]), an[2]);
-        const bool m0 = an[0] <= a_next, m1 = an[1] <= a_next, m2 = an[2] <= a_next;
-        const bool cont = a_next < exit;
-        const unsigned noff = off + (unsigned)((m0 ? dstep[0] : 0) + (m1 ? dstep[1] : 0) +
-                                               (m2 ? dstep[2] : 0));
-        // request the next voxel before the arithmetic of this step (stay put on the last)
-        const float vn = fetch(cont ? noff : off);
-        k[0] += m0 ? dirf[0] : 0.f;
-        k[1] += m1 ? dirf[1] : 0.f;
-        k[2] += m2 ? dirf[2] : 0.f;
-        an[0] = fmaf(k[0], inv[0], c[0]);
-        an[1] = fmaf(k[1], inv[1], c[1]);
-        an[2] = fmaf(k[2], inv[2], c[2]);
-        acc = fmaf(v, a_next - a_cur, acc);
-        if (AUX) {
-            // the crossing at a_cur that opened this segment: V_before - V_after
-            const float dv = v_prev - v;
-            const float dx = ox ? dv : 0.f, dz = oz ? dv : 0.f;
-            S0x += dx;
-            S1x = fmaf(dx, a_cur, S1x);
-            S0z += dz;
-            S1z = fmaf(dz, a_cur, S1z);
-            ox = m0;
-            oz = m2 && !m0 && !m1;
-            v_prev = v;
-        }
-        a_cur = a_next;
-        if (!cont) break;
-        off = noff;
-        v = vn;
+
+// RC: voxel i (requested during step i-1)   RN: voxel i+1 (requested now; still holds
+// voxel i-2 at the top of the step)         RP: voxel i-1
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DDRR_PIN(x) asm volatile("" : "+v"(x))
+#else
+#define DDRR_PIN(x) (void)(x)
+#endif
+#define DDRR_BRICK_STEP(IDX, RC, RN, RP)                                                          \
+    {                                                                                          \
+        /* settle segment i-1 and the crossing that opened it */                               \
+        acc = fmaf(RP, len_p, acc);                                                            \
+        if (AUX) {                                                                             \
+            const float dv = RN - RP;                                                          \
+            const float dx = ox_p ? dv : 0.f, dz = oz_p ? dv : 0.f;                            \
+            S0x += dx;                                                                         \
+            S1x = fmaf(dx, aop_p, S1x);                                                        \
+            S0z += dz;                                                                         \
+            S1z = fmaf(dz, aop_p, S1z);                                                        \
+        }                                                                                      \
+        /* geometry of step i */                                                               \
+        const float a_next = fminf(fminf(an[0], an[1]), an[2]);                                \
+        const bool m0 = an[0] <= a_next, m1 = an[1] <= a_next, m2 = an[2] <= a_next;           \
+        const bool cont = a_next < exit;                                                       \
+        k[0] += m0 ? dirf[0] : 0.f;                                                            \
+        k[1] += m1 ? dirf[1] : 0.f;                                                            \
+        k[2] += m2 ? dirf[2] : 0.f;                                                            \
+        const unsigned noff = DDRR_BRICK_NEXT_OFF();                                           \
+        RN = fetch(noff); /* voxel i+1 */                                                      \
+        an[0] = fmaf(k[0], inv[0], c[0]);                                                      \
+        an[1] = fmaf(k[1], inv[1], c[1]);                                                      \
+        an[2] = fmaf(k[2], inv[2], c[2]);                                                      \
+        len_p = a_next - a_cur;                                                                \
+        aop_p = a_cur;                                                                         \
+        ox_p = ox_c;                                                                           \
+        oz_p = oz_c;                                                                           \
+        ox_c = m0;                                                                             \
+        oz_c = m2 && !m0 && !m1;                                                               \
+        a_cur = a_next;                                                                        \
+        if (!cont) {                                                                           \
+            /* the ray leaves the brick: settle segment i, the crossing that opened it and  */ \
+            /* the exit crossing (V_after = 0).  DDRR_PIN keeps these uses of the voxel     */ \
+            /* values inside this branch: hoisted above it (they mirror the top of the next */ \
+            /* step) they would make every step wait for the load it has just issued.       */ \
+            float rc = RC, rp = RP;                                                            \
+            DDRR_PIN(rc);                                                                      \
+            DDRR_PIN(rp);                                                                      \
+            acc = fmaf(rc, len_p, acc);                                                        \
+            if (AUX) {                                                                         \
+                const float dv = rp - rc;                                                      \
+                const float dx = ox_p ? dv : 0.f, dz = oz_p ? dv : 0.f;                        \
+                const float ex = ox_c ? rc : 0.f, ez = oz_c ? rc : 0.f;                        \
+                S0x += dx + ex;                                                                \
+                S1x = fmaf(ex, a_cur, fmaf(dx, aop_p, S1x));                                   \
+                S0z += dz + ez;                                                                \
+                S1z = fmaf(ez, a_cur, fmaf(dz, aop_p, S1z));                                   \
+            }                                                                                  \
+            break;                                                                             \
+        }                                                                                      \
+        off = noff;                                                                            \
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+// (a ray that is leaving requests one cell beyond the brick: inside the workgroup's LDS
+// allocation, or out of its range, which the hardware answers with 0; never used)
+#define DDRR_BRICK_NEXT_OFF() DDRR_BRICK_OFF()
+#else
+#define DDRR_BRICK_NEXT_OFF() (cont ? DDRR_BRICK_OFF() : off)
+#endif
+    for (int it = 0; it < BRICK + 2; ++it) {  // a brick holds < 3 * BRICK crossings
+        DDRR_BRICK_STEP(0, r0, r1, r2)
+        DDRR_BRICK_STEP(1, r1, r2, r0)
+        DDRR_BRICK_STEP(2, r2, r0, r1)
+    }
+#undef DDRR_BRICK_STEP
+#undef DDRR_PIN
+#undef DDRR_BRICK_NEXT_OFF
+#undef DDRR_BRICK_OFF
     I = acc;
     if (AUX) {
-        // the crossing through which the ray leaves the brick (V_after = 0)
-        const float dx = ox ? v_prev : 0.f, dz = oz ? v_prev : 0.f;
-        rec[0] = S0x + dx;
-        rec[1] = S0z + dz;
-        rec[2] = fmaf(dx, a_cur, S1x);
-        rec[3] = fmaf(dz, a_cur, S1z);
+        rec[0] = S0x;
+        rec[1] = S0z;
+        rec[2] = S1x;
+        rec[3] = S1z;
     }
     return true;
 }

@@ -373,7 +373,9 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
     const float s[3] = {sp[0], sp[1], sp[2]}, t[3] = {tp[0], tp[1], tp[2]};
     const float L = p.img ? p.img[r] : 1.f;
     float I, rec[4];
-    if (!brick_trace<AUX>(LdsFetch{brick}, G, s, t, p.shift, p.eps, I, rec)) return;
+    if (!brick_trace<AUX>(LdsAbsFetch{}, (float)LdsAbsFetch::base_of(brick), G, s, t, p.shift,
+                          p.eps, I, rec))
+        return;
     if (!(p.dbg & 2)) unsafeAtomicAdd(out + r, L * I);
     if (AUX && !(p.dbg & 1)) {
         unsafeAtomicAdd(aux + r, I);

@@ -300,9 +300,9 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                 t[a] = target[r * 3 + a];
             }
             float I, rec[4];
-            const bool hit = aux ? brick_trace<true>(LdsFetch{brick.data()}, G, s, t, voxel_shift,
+            const bool hit = aux ? brick_trace<true>(LdsFetch{brick.data()}, 0.f, G, s, t, voxel_shift,
                                                      eps, I, rec)
-                                 : brick_trace<false>(LdsFetch{brick.data()}, G, s, t,
+                                 : brick_trace<false>(LdsFetch{brick.data()}, 0.f, G, s, t,
                                                       voxel_shift, eps, I, rec);
             if (!hit) return;  // phase A's margin let a non-crossing ray through
             out[r] += (img ? img[r] : 1.f) * I;
@@ -344,7 +344,7 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                     t[a] = target[r * 3 + a];
                 }
                 float I, rec[4];
-                if (brick_trace<false>(LdsFetch{brick.data()}, G, s, t, voxel_shift, eps, I, rec) &&
+                if (brick_trace<false>(LdsFetch{brick.data()}, 0.f, G, s, t, voxel_shift, eps, I, rec) &&
                     I != 0.f)
                     abort();
             }
