@@ -211,6 +211,16 @@ def main():
         fwd_ms = fwd_total / args.steps
         bwd_ms = sum(timer.total_ms(n)[0] for n in timer.events if "backward" in n) / args.steps
         achieved = alg_bytes / (fwd_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this very command
+        # (they cannot be collected from inside the process); only for the workload they
+        # were measured on
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+        if (D, H, B) == (512, 256, 32) and fwd_name == "ddrr_siddon_forward_bricks" \
+                and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f)["siddon_fwd_brick_kernel<true>"]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         ms_per_step = dt / args.steps * 1e3
         log(f"[bench] step {ms_per_step:.3f} ms | {fwd_name} {fwd_ms:.3f} ms/step in "
             f"{n_fwd // args.steps} launch(es) | backward kernels {bwd_ms:.3f} ms | raygen "
@@ -248,7 +258,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": fwd_ms,
                 "launches_per_step": n_fwd // args.steps,
