@@ -192,9 +192,98 @@ DDRR_HD float med3f(float v, float lo, float hi) {
 #endif
 }
 
+// State of a ray at its entry into a brick: the exact clip (same expressions as
+// siddon_setup_fast: a plane shared by two bricks gets the same alpha in both) and the
+// entry cell (siddon_enter, incl. its alpha-order consistency rule).
+struct BrickEntry {
+    float inv[3], c[3], mn[3];
+    float k[3], an[3], dirf[3];
+    float entry, exit;
+    float offc;  // voxel byte offset = offc + sum_a k_a stride_a
+    bool hit;
+};
+
+// The voxel's byte offset is an affine function of the three plane counters,
+//   off = sum_a (k_a - p01_a - lo_a) stride_a  (+ base: what the accessor wants added),
+// exact in fp32 (< 2^24): three FMAs and a convert per step instead of three selects and
+// two integer adds, and no per-axis step registers.
+DDRR_HD BrickEntry brick_enter(const BrickGeom &G, const float s[3], const float t[3],
+                               float shift, float eps, float base) {
+    BrickEntry E;
+    float d[3];
+    E.entry = -INFINITY;
+    E.exit = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        d[a] = (t[a] - s[a]) + eps;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float r0 = __builtin_amdgcn_rcpf(d[a]);
+        E.inv[a] = fmaf(fmaf(-d[a], r0, 1.0f), r0, r0);
+#else
+        E.inv[a] = 1.0f / d[a];
+#endif
+        const float num = -shift - s[a];
+        const float c0 = num * E.inv[a];
+        E.c[a] = fmaf(fmaf(-c0, d[a], num), E.inv[a], c0);
+        const float a_lo = fmaf(G.lof[a], E.inv[a], E.c[a]);
+        const float a_hi = fmaf(G.hif[a], E.inv[a], E.c[a]);
+        E.mn[a] = fminf(a_lo, a_hi);
+        E.entry = fmaxf(E.entry, E.mn[a]);
+        E.exit = fminf(E.exit, fmaxf(a_lo, a_hi));
+    }
+    E.hit = E.entry < E.exit;  // false for NaN
+    E.offc = base;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const bool pos = d[a] > 0.f;
+        const float p01 = pos ? 1.f : 0.f;
+        E.dirf[a] = pos ? 1.f : -1.f;
+        const float cmax = G.hif[a] - 1.f;
+        float u = med3f(floorf(fmaf(E.entry, d[a], s[a] + shift)), G.lof[a], cmax);
+        const float a_ahead = fmaf(u + p01, E.inv[a], E.c[a]);
+        const float a_behind = fmaf(u + (1.f - p01), E.inv[a], E.c[a]);
+        const float adj = (a_ahead < E.entry ? E.dirf[a] : 0.f) -
+                          (a_behind > E.entry ? E.dirf[a] : 0.f);
+        u = med3f(u + adj, G.lof[a], cmax);
+        u = (E.mn[a] == E.entry) ? (pos ? G.lof[a] : cmax) : u;  // entering axis: face cell
+        E.k[a] = u + p01;
+        E.an[a] = fmaf(E.k[a], E.inv[a], E.c[a]);
+        E.offc = fmaf(-(p01 + G.lof[a]), G.stridef[a], E.offc);
+    }
+    return E;
+}
+
+// Volume gradient of one ray through one brick: adds w * dalpha_k to the LDS cell of every
+// voxel the ray crosses (d out / d V[k] = L dalpha_k, reference: grid_sampler_3d_backward
+// behind renderers.py:159-164).  `add(base + byte offset, value)` is the scatter.
+template <class Add>
+DDRR_HD bool brick_scatter(const Add &add, float add_base, const BrickGeom &G, const float s[3],
+                           const float t[3], float shift, float eps, float w) {
+    const BrickEntry E = brick_enter(G, s, t, shift, eps, add_base);
+    if (!E.hit) return false;
+    float k[3] = {E.k[0], E.k[1], E.k[2]}, an[3] = {E.an[0], E.an[1], E.an[2]};
+    float a_cur = E.entry;
+    for (int it = 0; it < 3 * BRICK + 3; ++it) {
+        const unsigned off = (unsigned)(int)fmaf(
+            k[0], G.stridef[0], fmaf(k[1], G.stridef[1], fmaf(k[2], G.stridef[2], E.offc)));
+        const float a_next = fminf(fminf(an[0], an[1]), an[2]);
+        add(off, w * (a_next - a_cur));
+        if (!(a_next < E.exit)) break;
+        k[0] += an[0] <= a_next ? E.dirf[0] : 0.f;
+        k[1] += an[1] <= a_next ? E.dirf[1] : 0.f;
+        k[2] += an[2] <= a_next ? E.dirf[2] : 0.f;
+        an[0] = fmaf(k[0], E.inv[0], E.c[0]);
+        an[1] = fmaf(k[1], E.inv[1], E.c[1]);
+        an[2] = fmaf(k[2], E.inv[2], E.c[2]);
+        a_cur = a_next;
+    }
+    return true;
+}
+
 // Exact clip + walk of one ray through one brick.  `fetch(fetch_base + byte offset)` reads
 // the LDS copy (fetch_base: 0 for a pointer-relative fetch, the brick's LDS address for
-// LdsAbsFetch; the sum stays an exact fp32 integer).  Returns false if the ray does not cross the brick (phase A's margin let it
+// LdsAbsFetch; the sum stays an exact fp32 integer).
+// Returns false if the ray does not cross the brick (phase A's margin let it
 // through).  I = sum V dalpha over the brick.  With AUX, rec = {S0x, S0z, S1x, S1z} of the
 // brick-local backward record (voxels outside the brick count as 0, so that the records
 // of the bricks along a ray add up to the whole ray's: siddon_core.h SIDDON_AUX).
@@ -202,55 +291,14 @@ template <bool AUX, class Fetch>
 DDRR_HD bool brick_trace(const Fetch &fetch, float fetch_base, const BrickGeom &G,
                          const float s[3], const float t[3], float shift, float eps, float &I,
                          float rec[4]) {
-    float d[3], inv[3], c[3], mn[3];
-    float entry = -INFINITY, exit = INFINITY;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        // the same expressions as siddon_setup_fast: a plane shared by two bricks gets the
-        // same alpha in both
-        d[a] = (t[a] - s[a]) + eps;
-#if defined(__HIP_DEVICE_COMPILE__)
-        const float r0 = __builtin_amdgcn_rcpf(d[a]);
-        inv[a] = fmaf(fmaf(-d[a], r0, 1.0f), r0, r0);
-#else
-        inv[a] = 1.0f / d[a];
-#endif
-        const float num = -shift - s[a];
-        const float c0 = num * inv[a];
-        c[a] = fmaf(fmaf(-c0, d[a], num), inv[a], c0);
-        const float a_lo = fmaf(G.lof[a], inv[a], c[a]);
-        const float a_hi = fmaf(G.hif[a], inv[a], c[a]);
-        mn[a] = fminf(a_lo, a_hi);
-        entry = fmaxf(entry, mn[a]);
-        exit = fminf(exit, fmaxf(a_lo, a_hi));
-    }
+    const BrickEntry E = brick_enter(G, s, t, shift, eps, fetch_base);
     I = 0.f;
     if (AUX) rec[0] = rec[1] = rec[2] = rec[3] = 0.f;
-    if (!(entry < exit)) return false;  // also NaN
-
-    // entry cell per axis (siddon_enter, incl. its alpha-order consistency rule)
-    float k[3], an[3], dirf[3];
-    // The voxel's byte offset is an affine function of the three plane counters,
-    //   off = sum_a (k_a - p01_a - lo_a) stride_a,
-    // exact in fp32 (< 2^24): three FMAs and a convert per step instead of three selects
-    // and two integer adds, and no per-axis step registers.
-    float offc = fetch_base;  // what `fetch` wants added to the brick-relative offset
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const bool pos = d[a] > 0.f;
-        const float p01 = pos ? 1.f : 0.f;
-        dirf[a] = pos ? 1.f : -1.f;
-        const float cmax = G.hif[a] - 1.f;
-        float u = med3f(floorf(fmaf(entry, d[a], s[a] + shift)), G.lof[a], cmax);
-        const float a_ahead = fmaf(u + p01, inv[a], c[a]);
-        const float a_behind = fmaf(u + (1.f - p01), inv[a], c[a]);
-        const float adj = (a_ahead < entry ? dirf[a] : 0.f) - (a_behind > entry ? dirf[a] : 0.f);
-        u = med3f(u + adj, G.lof[a], cmax);
-        u = (mn[a] == entry) ? (pos ? G.lof[a] : cmax) : u;  // entering axis: its face cell
-        k[a] = u + p01;
-        an[a] = fmaf(k[a], inv[a], c[a]);
-        offc = fmaf(-(p01 + G.lof[a]), G.stridef[a], offc);
-    }
+    if (!E.hit) return false;
+    float k[3] = {E.k[0], E.k[1], E.k[2]}, an[3] = {E.an[0], E.an[1], E.an[2]};
+    const float inv[3] = {E.inv[0], E.inv[1], E.inv[2]}, c[3] = {E.c[0], E.c[1], E.c[2]};
+    const float dirf[3] = {E.dirf[0], E.dirf[1], E.dirf[2]}, mn[3] = {E.mn[0], E.mn[1], E.mn[2]};
+    const float entry = E.entry, exit = E.exit, offc = E.offc;
 #define DDRR_BRICK_OFF() \
     ((unsigned)(int)fmaf(k[0], G.stridef[0], fmaf(k[1], G.stridef[1], fmaf(k[2], G.stridef[2], offc))))
     unsigned off = DDRR_BRICK_OFF();

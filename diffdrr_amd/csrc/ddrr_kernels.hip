@@ -355,27 +355,55 @@ struct BrickArgs {
     float t1, t2;        // length-class thresholds on the estimated crossing count
     int dbg;             // experiment switches (0 in production)
     int *work;           // global brick counter of this launch (zero at launch)
+    const float *grad_out;  // BRICK_VOLGRAD: dLoss/dout (B, N)
+    float *g_volume;        // BRICK_VOLGRAD: dLoss/dvolume, fully written
 };
+
+// what a brick launch computes
+constexpr int BRICK_FWD = 0;      // out
+constexpr int BRICK_FWD_AUX = 1;  // out + planar backward record
+constexpr int BRICK_VOLGRAD = 2;  // g_volume (the brick in LDS is the accumulator)
 
 inline size_t brick_lds_bytes(const BrickLayout &lay) {
     return (size_t)brick_floats(lay) * 4 + (size_t)kBrickWaves * kBuckets * kQueueCap * 4 +
            (size_t)(kPoseChunk * kRowWords + 2) * 4;
 }
 
-// Phase B for one queue entry: load the real ray, clip, walk, add to the image.
+#if defined(__HIPCC__)
+// ds_add_f32 by absolute LDS byte address (the volume-gradient accumulator)
+struct LdsAbsAdd {
+    __device__ __forceinline__ void operator()(unsigned addr, float v) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __hip_atomic_fetch_add((float *)(__attribute__((address_space(3))) float *)(unsigned long long)addr,
+                               v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        (void)addr;
+        (void)v;
+#endif
+    }
+};
+#endif
+
+// Phase B for one queue entry: load the real ray, clip, walk; add to the image (forward)
+// or scatter into the LDS accumulator (volume gradient).
 // Offsets are 32-bit: the host checks 12 * B * N < 2^32.
-template <bool AUX>
+template <int MODE>
 __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *brick,
                                            const BrickGeom &G, unsigned b, unsigned pix,
                                            float *__restrict__ out, float *__restrict__ aux) {
+    constexpr bool AUX = MODE == BRICK_FWD_AUX;
     const unsigned r = b * (unsigned)(p.det_h * p.det_w) + pix;
     const float *sp = p.source + b * 3u, *tp = p.target + r * 3u;
     const float s[3] = {sp[0], sp[1], sp[2]}, t[3] = {tp[0], tp[1], tp[2]};
     const float L = p.img ? p.img[r] : 1.f;
-    float I, rec[4];
-    if (!brick_trace<AUX>(LdsAbsFetch{}, (float)LdsAbsFetch::base_of(brick), G, s, t, p.shift,
-                          p.eps, I, rec))
+    const float base = (float)LdsAbsFetch::base_of(brick);
+    if (MODE == BRICK_VOLGRAD) {
+        const float w = p.grad_out[r] * L;
+        if (w != 0.f) brick_scatter(LdsAbsAdd{}, base, G, s, t, p.shift, p.eps, w);
         return;
+    }
+    float I, rec[4];
+    if (!brick_trace<AUX>(LdsAbsFetch{}, base, G, s, t, p.shift, p.eps, I, rec)) return;
     if (!(p.dbg & 2)) unsafeAtomicAdd(out + r, L * I);
     if (AUX && !(p.dbg & 1)) {
         unsafeAtomicAdd(aux + r, I);
@@ -398,9 +426,10 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <bool AUX>
-__global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
+template <int MODE>
+__global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     BrickArgs p, float *__restrict__ out, float *__restrict__ aux) {
+    constexpr bool AUX = MODE == BRICK_FWD_AUX;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *brick = reinterpret_cast<float *>(smem_raw);
     unsigned *queue = reinterpret_cast<unsigned *>(brick + brick_floats(p.lay));
@@ -449,7 +478,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
                 const int lx = row / BRICK, ly = row - lx * BRICK, q4 = (tid & 7) * 4;
                 const int x = box.lo[0] + lx, y = box.lo[1] + ly, z = box.lo[2] + q4;
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (x < box.hi[0] && y < box.hi[1]) {
+                if (MODE != BRICK_VOLGRAD && x < box.hi[0] && y < box.hi[1]) {
                     const float *g = p.vol + ((long)x * p.D.y + y) * p.D.z + z;
                     if (vec_ok && z + 4 <= box.hi[2]) {
                         const float4 q = *reinterpret_cast<const float4 *>(g);
@@ -558,10 +587,26 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_fwd_brick_kernel(
                     break;
                 }
                 if (lane < n)
-                    brick_item<AUX>(p, brick, G, e >> p.pix_bits, e & pix_mask, out, aux);
+                    brick_item<MODE>(p, brick, G, e >> p.pix_bits, e & pix_mask, out, aux);
                 wave_fence();
             }
             if (drain) break;
+        }
+    }
+    if (MODE == BRICK_VOLGRAD) {
+        // every ray of every pose has been scattered into the LDS accumulator: the brick
+        // owns its voxels, so the gradient is stored, not added
+        __syncthreads();
+        for (int row = tid >> 3; row < BRICK * BRICK; row += kBrickThreads >> 3) {
+            const int lx = row / BRICK, ly = row - lx * BRICK, q4 = (tid & 7) * 4;
+            const int x = box.lo[0] + lx, y = box.lo[1] + ly, z = box.lo[2] + q4;
+            if (x < box.hi[0] && y < box.hi[1]) {
+                const float *src = brick + lx * p.lay.sx + ly * p.lay.sy + q4;
+                float *g = p.g_volume + ((long)x * p.D.y + y) * p.D.z + z;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (z + k < box.hi[2]) g[k] = src[k];
+            }
         }
     }
   }
@@ -921,20 +966,12 @@ int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const 
     return finish("ddrr_siddon_forward_slab");
 }
 
-int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
-                               const float *target, const float *img, int B, int det_h,
-                               int det_w, float voxel_shift, float eps, float *out, float *aux,
-                               void *stream) {
+namespace {
+int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const float *source,
+                  const float *target, const float *img, const float *grad_out, int B, int det_h,
+                  int det_w, float voxel_shift, float eps, float *out, float *aux,
+                  float *g_volume, hipStream_t st, const char *who) {
     const int N = det_h * det_w;
-    if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
-    if (!out) return fail(-1, "null out pointer");
-    if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
-    if (B == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * N, st);
-    if (e == hipSuccess && aux)
-        e = hipMemsetAsync(aux, 0, sizeof(float) * (size_t)kBrickAuxPlanes * B * N, st);
-    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
     BrickArgs p;
     p.vol = volume;
     p.D = Dims{dx, dy, dz};
@@ -958,15 +995,19 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     p.t1 = g_brick_t1;
     p.t2 = g_brick_t2;
     p.dbg = g_brick_dbg;
+    p.grad_out = grad_out;
+    p.g_volume = g_volume;
     const size_t lds = brick_lds_bytes(p.lay);
+    hipError_t e;
     static bool attr_set = false;  // raise the dynamic-LDS limit once per process
     if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&siddon_fwd_brick_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&siddon_fwd_brick_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute");
+        const void *fns[3] = {reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_FWD>),
+                              reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_FWD_AUX>),
+                              reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_VOLGRAD>)};
+        for (const void *fn : fns)
+            if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024)) != hipSuccess)
+                return fail_hip(e, "hipFuncSetAttribute");
         attr_set = true;
     }
     // one brick counter per launch, from a small per-device ring (launches in flight on
@@ -991,11 +1032,52 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     const BrickGrid bg = brick_grid(p.D);
     const int n_bricks = bg.nx * bg.ny * bg.nz;
     const dim3 grid(n_bricks < n_cu[dev] ? n_bricks : n_cu[dev]), block(kBrickThreads);
-    if (aux)
-        hipLaunchKernelGGL(siddon_fwd_brick_kernel<true>, grid, block, lds, st, p, out, aux);
+    if (mode == BRICK_FWD)
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_FWD>, grid, block, lds, st, p, out, aux);
+    else if (mode == BRICK_FWD_AUX)
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_FWD_AUX>, grid, block, lds, st, p, out, aux);
     else
-        hipLaunchKernelGGL(siddon_fwd_brick_kernel<false>, grid, block, lds, st, p, out, aux);
-    return finish("ddrr_siddon_forward_bricks");
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_VOLGRAD>, grid, block, lds, st, p, out, aux);
+    return finish(who);
+}
+}  // namespace
+
+int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
+                               const float *target, const float *img, int B, int det_h,
+                               int det_w, float voxel_shift, float eps, float *out, float *aux,
+                               void *stream) {
+    const int N = det_h * det_w;
+    if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
+    if (!out) return fail(-1, "null out pointer");
+    if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * N, st);
+    if (e == hipSuccess && aux)
+        e = hipMemsetAsync(aux, 0, sizeof(float) * (size_t)kBrickAuxPlanes * B * N, st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    return launch_bricks(aux ? BRICK_FWD_AUX : BRICK_FWD, volume, dx, dy, dz, source, target, img,
+                         nullptr, B, det_h, det_w, voxel_shift, eps, out, aux, nullptr, st,
+                         "ddrr_siddon_forward_bricks");
+}
+
+int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *source,
+                                       const float *target, const float *img,
+                                       const float *grad_out, int B, int det_h, int det_w,
+                                       float voxel_shift, float eps, float *g_volume,
+                                       void *stream) {
+    const int N = det_h * det_w;
+    if (!g_volume || !grad_out) return fail(-1, "null grad_out / g_volume");
+    if (int rc = check_common(g_volume, dx, dy, dz, source, 1, target, B, N)) return rc;
+    if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {  // nothing contributes: the gradient is zero
+        hipError_t e = hipMemsetAsync(g_volume, 0, sizeof(float) * (size_t)dx * dy * dz, st);
+        return e == hipSuccess ? 0 : fail_hip(e, "hipMemsetAsync");
+    }
+    return launch_bricks(BRICK_VOLGRAD, nullptr, dx, dy, dz, source, target, img, grad_out, B,
+                         det_h, det_w, voxel_shift, eps, nullptr, nullptr, g_volume, st,
+                         "ddrr_siddon_backward_volume_bricks");
 }
 
 int ddrr_siddon_backward_rays(const float *aux, int aux_layout, const float *grad_out,

@@ -283,6 +283,26 @@ def siddon_backward_volume(volume, source, target, img, grad_out, *, voxel_shift
     return g_volume
 
 
+def siddon_backward_volume_bricks(volume_shape, source, target, img, grad_out, det, *,
+                                  voxel_shift=0.5, eps=1e-8):
+    """Detector-grid Siddon (sum) volume gradient through the volume-stationary brick
+    kernel: every 32^3 brick of the gradient is accumulated in LDS and stored once.
+    -> g_volume (Dx,Dy,Dz), fully written"""
+    B, N, _ = target.shape
+    H, W = int(det[0]), int(det[1])
+    if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
+        raise ValueError("the brick path needs one source per pose and an H*W >= 2x2 ray grid")
+    _require_gpu(target)
+    source, target, grad_out = source.contiguous(), target.contiguous(), grad_out.contiguous()
+    img = None if img is None else img.contiguous()
+    Dx, Dy, Dz = (int(v) for v in volume_shape)
+    g_volume = torch.empty(Dx, Dy, Dz, dtype=torch.float32, device=target.device)
+    _launch("ddrr_siddon_backward_volume_bricks", target.device, Dx, Dy, Dz, source.data_ptr(),
+            target.data_ptr(), _ptr(img), grad_out.data_ptr(), B, H, W, float(voxel_shift),
+            float(eps), g_volume.data_ptr())
+    return g_volume
+
+
 def siddon_forward_channels(volume, labels_u8, n_channels, source, target, img, *,
                             voxel_shift=0.5, eps=1e-8, det=None, tile=None):
     """-> (B, C, N)"""

@@ -36,6 +36,22 @@ def _labels_u8(mask: torch.Tensor):
     return lab, C
 
 
+def _volume_gradient(volume, source, target, img, grad_out, cfg):
+    """dLoss/dvolume: the volume-stationary brick kernel for a detector-grid render
+    (LDS accumulation, no global atomics), the re-walk with global atomics otherwise."""
+    N = target.shape[1]
+    grid = (cfg["lookup"] == "step" and cfg["reducefn"] == "sum" and cfg["det"] is not None
+            and cfg["det"][0] * cfg["det"][1] == N and source.shape[1] == 1
+            and min(cfg["det"]) >= 2)
+    if grid and cfg["path"] == "bricks":
+        return ops.siddon_backward_volume_bricks(
+            volume.shape, source, target, img, grad_out, cfg["det"],
+            voxel_shift=cfg["voxel_shift"], eps=cfg["eps"])
+    return ops.siddon_backward_volume(
+        volume, source, target, img, grad_out, voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
+        reducefn=cfg["reducefn"], det=cfg["det"], tile=cfg["tile"])
+
+
 class _SiddonFn(torch.autograd.Function):
     """out (B,N) = img * sum_k V_k dalpha_k (or max_k).  Inputs: volume, source,
     target, img.  Backward: ddrr_siddon_backward_rays from the 8-float forward
@@ -94,9 +110,7 @@ class _SiddonFn(torch.autograd.Function):
             if need_i and not stop:
                 g_i = gi.view_as(img)
         if need_vol and not stop:
-            g_vol = ops.siddon_backward_volume(
-                volume, source, target, img, grad_out, voxel_shift=cfg["voxel_shift"],
-                eps=cfg["eps"], reducefn=cfg["reducefn"], det=cfg["det"], tile=cfg["tile"])
+            g_vol = _volume_gradient(volume, source, target, img, grad_out, cfg)
         return g_vol, g_s, g_t, g_i, None
 
 
@@ -141,9 +155,7 @@ class _SiddonPoseFn(torch.autograd.Function):
             g_M = ops.siddon_backward_pose(aux, grad_out, source, target, img, Mw, Ainv, P,
                                            eps=cfg["eps"], with_img_path=not stop)
         if need_vol and not stop:
-            g_vol = ops.siddon_backward_volume(
-                volume, source, target, img, grad_out, voxel_shift=cfg["voxel_shift"],
-                eps=cfg["eps"], reducefn="sum", det=cfg["det"], tile=cfg["tile"])
+            g_vol = _volume_gradient(volume, source, target, img, grad_out, cfg)
         return g_vol, g_M, None, None, None
 
 

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 3
+#define DDRR_ABI_VERSION 4
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -104,6 +104,18 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                                const float *target, const float *img, int B, int det_h,
                                int det_w, float voxel_shift, float eps, float *out, float *aux,
                                void *stream);
+
+/* Volume gradient for the DRR case of ddrr_siddon_forward_bricks (reduce sum), also
+ * volume-stationary: each 32^3 brick of g_volume is accumulated in LDS (ds_add_f32) from
+ * every ray of every pose that crosses it and STORED once -- no global atomics, no
+ * zero-fill by the caller; g_volume (dx, dy, dz) is fully written.  Replaces
+ * grid_sampler_3d_backward (nearest) behind renderers.py:159-164 like
+ * ddrr_siddon_backward_volume, which remains the entry for arbitrary ray lists. */
+int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *source,
+                                       const float *target, const float *img,
+                                       const float *grad_out, int B, int det_h, int det_w,
+                                       float voxel_shift, float eps, float *g_volume,
+                                       void *stream);
 
 /* Pose/ray gradients of ddrr_siddon_forward from its aux record (aux_layout says which
  * forward wrote it): what autograd of renderers.py:94-113 + :70-71 returns.  g_source is per ray (B, N, 3) (sum

@@ -355,6 +355,54 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     return 0;
 }
 
+// Host emulation of the volume-gradient brick kernel: per brick, every candidate of every
+// pose scatters w * dalpha into a local padded accumulator, which is then stored.
+int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *source,
+                                       const float *target, const float *img,
+                                       const float *grad_out, int B, int det_h, int det_w,
+                                       float voxel_shift, float eps, float *g_volume, void *) {
+    const Dims D{dx, dy, dz};
+    const int N = det_h * det_w;
+    const BrickGrid bg = brick_grid(D);
+    const BrickLayout lay{33, 32 * 33 + 1};
+    std::vector<float> brick((size_t)brick_floats(lay));
+    struct HostAddBytes {
+        float *base;
+        void operator()(unsigned off, float v) const { base[off >> 2] += v; }
+    };
+    for (int id = 0; id < bg.nx * bg.ny * bg.nz; ++id) {
+        const Box box = brick_box(D, bg, id);
+        const BrickGeom G = brick_geom(box, lay);
+        std::fill(brick.begin(), brick.end(), 0.f);
+        for (int b = 0; b < B; ++b) {
+            const PoseGrid pg = pose_grid(source + (long)b * 3, target + (long)b * N * 3, det_h,
+                                          det_w);
+            const PixBox pb = project_brick_grid(pg, det_h, det_w, box, voxel_shift);
+            const BrickRow row = brick_row(pg, pb, box, voxel_shift, eps);
+            for (int local = 0; local < row.count; ++local) {
+                int pix;
+                float n_est;
+                if (!brick_candidate(row, local, det_w, pix, n_est)) continue;
+                const long r = (long)b * N + pix;
+                float s[3], t[3];
+                for (int a = 0; a < 3; ++a) {
+                    s[a] = source[(long)b * 3 + a];
+                    t[a] = target[r * 3 + a];
+                }
+                const float w = grad_out[r] * (img ? img[r] : 1.f);
+                if (w != 0.f)
+                    brick_scatter(HostAddBytes{brick.data()}, 0.f, G, s, t, voxel_shift, eps, w);
+            }
+        }
+        for (int x = box.lo[0]; x < box.hi[0]; ++x)
+            for (int y = box.lo[1]; y < box.hi[1]; ++y)
+                for (int z = box.lo[2]; z < box.hi[2]; ++z)
+                    g_volume[((long)x * dy + y) * dz + z] =
+                        brick[(x - box.lo[0]) * lay.sx + (y - box.lo[1]) * lay.sy + (z - box.lo[2])];
+    }
+    return 0;
+}
+
 int ddrr_siddon_backward_rays(const float *aux, int aux_layout, const float *grad_out,
                               const float *source, int src_n, const float *target,
                               const float *img, int B, int N, float eps, int reduce_mode,

@@ -555,3 +555,20 @@ def test_fused_ray_generation_equals_general_path(gpu, stop):
     assert (drr.affine_inverse(t) - t2).abs().max().item() < 2e-4
     assert (drr.affine_inverse(s) - s2).abs().max().item() < 2e-4
     assert (L - L2).abs().max().item() < 2e-4
+
+
+def test_volume_gradient_bricks_full_size(gpu, big):
+    """Brick volume gradient (LDS accumulation, no global atomics) at 512^3: equals the
+    re-walk with global atomics, is the adjoint of the forward, and is deterministic up to
+    the LDS summation order."""
+    drr, s, t, L = big
+    V = drr.density
+    go = torch.rand(s.shape[0], 256 * 256, device=gpu, generator=torch.Generator(gpu).manual_seed(1))
+    ref = ops.siddon_backward_volume(V, s, t, L, go, det=(256, 256))
+    out = ops.siddon_backward_volume_bricks(V.shape, s, t, L, go, (256, 256))
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    img = ops.siddon_forward_bricks(V, s, t, L, (256, 256))[0]
+    lhs, rhs = (out.double() * V.double()).sum().item(), (go.double() * img.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-5 * abs(rhs)
+    again = ops.siddon_backward_volume_bricks(V.shape, s, t, L, go, (256, 256))
+    assert rel_err(again.cpu().numpy(), out.cpu().numpy()) < 2e-6
