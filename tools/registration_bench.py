@@ -1,0 +1,61 @@
+"""BASELINE.json config 4: 2D/3D registration loop at 512^3 / 256^2 on one MI355X.
+A ground-truth DRR is rendered at a known pose; a `Registration` module starts from a
+perturbed pose and is optimised against it with NCC (reference
+notebooks/tutorials/registration.ipynb:144-316): SGD(maximize) with lr_rot 5e-2 /
+lr_xyz 1e2 (registration.ipynb:240-247), stop at NCC > 0.999 or 500 iterations.
+Prints iterations to converge, it/s and the final pose error."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diffdrr_amd import DRR, NormalizedCrossCorrelation2d, Registration  # noqa: E402
+from diffdrr_amd.data import synthetic_subject  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=512)
+ap.add_argument("--det", type=int, default=256)
+ap.add_argument("--stop-gradients", type=int, default=1)
+ap.add_argument("--optim", default="sgd")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+D, H = a.size, a.det
+drr = DRR(synthetic_subject(D, kind="phantom", seed=0), sdd=1020.0, height=H, delx=2.4 * (256 / H) * (D / 512),
+          stop_gradients_through_grid_sample=bool(a.stop_gradients)).to(dev)
+true_rot = torch.tensor([[0.0, 0.0, 0.0]], device=dev)
+true_xyz = torch.tensor([[0.0, 850.0, 0.0]], device=dev)
+with torch.no_grad():
+    gt = drr(true_rot, true_xyz, parameterization="euler_angles", convention="ZXY")
+g = torch.Generator().manual_seed(1)
+rot = true_rot + ((torch.rand(1, 3, generator=g) - 0.5) * 0.4).to(dev)       # +-0.2 rad
+xyz = true_xyz + ((torch.rand(1, 3, generator=g) - 0.5) * 60.0).to(dev)      # +-30 mm
+reg = Registration(drr, rot.clone(), xyz.clone(), parameterization="euler_angles", convention="ZXY")
+ncc = NormalizedCrossCorrelation2d()
+if a.optim == "sgd":
+    opt = torch.optim.SGD([{"params": [reg._rotation], "lr": 5e-2},
+                           {"params": [reg._translation], "lr": 1e2}], maximize=True)
+else:
+    opt = torch.optim.Adam([{"params": [reg._rotation], "lr": 1e-1},
+                            {"params": [reg._translation], "lr": 5e0}], maximize=True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+its, val = 0, 0.0
+for its in range(1, 501):
+    opt.zero_grad()
+    loss = ncc(gt, reg()).sum()
+    loss.backward()
+    opt.step()
+    if its % 10 == 0 or its < 3:
+        val = loss.item()  # (host sync only every 10 iterations)
+        if val > 0.999:
+            break
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+er = (reg.rotation.detach() - true_rot).abs().max().item()
+et = (reg.translation.detach() - true_xyz).abs().max().item()
+print(f"{D}^3 -> {H}^2 registration ({a.optim}, stop_gradients={a.stop_gradients}): {its} iterations, "
+      f"NCC {val:.5f}, {its / dt:.1f} it/s ({dt / its * 1e3:.2f} ms/it), "
+      f"final error: rot {er:.4f} rad, xyz {et:.3f} mm (start: 0.2 rad / 30 mm box)")
