@@ -39,9 +39,26 @@ DDRR_HD PoseGrid pose_grid(const float *src, const float *tgt, int det_h, int de
     return g;
 }
 
+// A box between planes given in (fractional) plane-index units: plane k sits at x = k - shift.
+// Siddon bricks: integer planes lo .. hi; trilinear bricks: the base-cell box in index
+// coordinates, lo + 1/2 .. lo + 31 + 1/2.
+struct BoxF {
+    float lo[3], hi[3];
+};
+
+DDRR_HD BoxF boxf(const Box &b) {
+    BoxF f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        f.lo[a] = (float)b.lo[a];
+        f.hi[a] = (float)b.hi[a];
+    }
+    return f;
+}
+
 // Pixel bounding box of the lines through the source that meet the box `b` (plane indices;
 // plane k sits at x = k - shift): the 8 corners are projected onto the pixel lattice.
-DDRR_HD PixBox project_brick_grid(const PoseGrid &g, int det_h, int det_w, const Box &b,
+DDRR_HD PixBox project_brick_grid(const PoseGrid &g, int det_h, int det_w, const BoxF &b,
                                   float shift) {
     float r[3];
 #pragma unroll
@@ -58,9 +75,9 @@ DDRR_HD PixBox project_brick_grid(const PoseGrid &g, int det_h, int det_w, const
     int npos = 0, nneg = 0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const float w[3] = {(float)((c & 1) ? b.hi[0] : b.lo[0]) - shift - g.s[0],
-                            (float)((c & 2) ? b.hi[1] : b.lo[1]) - shift - g.s[1],
-                            (float)((c & 4) ? b.hi[2] : b.lo[2]) - shift - g.s[2]};
+        const float w[3] = {((c & 1) ? b.hi[0] : b.lo[0]) - shift - g.s[0],
+                            ((c & 2) ? b.hi[1] : b.lo[1]) - shift - g.s[1],
+                            ((c & 4) ? b.hi[2] : b.lo[2]) - shift - g.s[2]};
         const float det = w[0] * n[0] + w[1] * n[1] + w[2] * n[2];
         npos += det > 0.f;
         nneg += det < 0.f;
@@ -98,14 +115,15 @@ DDRR_HD PixBox project_brick_grid(const PoseGrid &g, int det_h, int det_w, const
     return pb;
 }
 
-// One row of the per-(pose, brick) table phase A reads (20 words).
-constexpr int kRowWords = 20;
+// One row of the per-(pose, brick) table phase A reads (21 words).
+constexpr int kRowWords = 21;
 struct BrickRow {
     float D0[3];   // (t00 - s) + eps : direction of pixel (0, 0)
     float ei[3], ej[3];
     float P0[3];   // (lo - margin) - shift - s : numerators of the slab planes
     float P1[3];   // (hi + margin) - shift - s
     float inv_w;   // 1 / width of the pixel box
+    float nscale;  // > 0: work estimate = (exit - entry) * nscale (samples); else crossings
     int i0, j0, w, count;
 };
 
@@ -113,16 +131,17 @@ struct BrickRow {
 // from the stored targets, so a ray with a real chord in the brick is never rejected
 constexpr float kBrickMargin = 0.01f;
 
-DDRR_HD BrickRow brick_row(const PoseGrid &g, const PixBox &pb, const Box &box, float shift,
-                           float eps) {
+DDRR_HD BrickRow brick_row(const PoseGrid &g, const PixBox &pb, const BoxF &box, float shift,
+                           float eps, float nscale) {
     BrickRow r;
+    r.nscale = nscale;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         r.D0[a] = (g.t00[a] - g.s[a]) + eps;
         r.ei[a] = g.ei[a];
         r.ej[a] = g.ej[a];
-        r.P0[a] = ((float)box.lo[a] - kBrickMargin) - shift - g.s[a];
-        r.P1[a] = ((float)box.hi[a] + kBrickMargin) - shift - g.s[a];
+        r.P0[a] = (box.lo[a] - kBrickMargin) - shift - g.s[a];
+        r.P1[a] = (box.hi[a] + kBrickMargin) - shift - g.s[a];
     }
     r.i0 = pb.i0;
     r.j0 = pb.j0;
@@ -160,7 +179,7 @@ DDRR_HD bool brick_candidate(const BrickRow &r, int local, int det_w, int &pix, 
         exit = fminf(exit, fmaxf(a0, a1));
         l1 += fabsf(d);
     }
-    n_est = (exit - entry) * l1;
+    n_est = (exit - entry) * (r.nscale > 0.f ? r.nscale : l1);
     return entry < exit;  // false for NaN
 }
 

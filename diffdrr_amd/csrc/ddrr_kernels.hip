@@ -17,6 +17,7 @@
 #include "brick_core.h"
 #include "brick_walk.h"
 #include "raygen_core.h"
+#include "tri_brick.h"
 #include "slab_core.h"
 #include "trilinear_core.h"
 
@@ -355,14 +356,18 @@ struct BrickArgs {
     float t1, t2;        // length-class thresholds on the estimated crossing count
     int dbg;             // experiment switches (0 in production)
     int *work;           // global brick counter of this launch (zero at launch)
-    const float *grad_out;  // BRICK_VOLGRAD: dLoss/dout (B, N)
-    float *g_volume;        // BRICK_VOLGRAD: dLoss/dvolume, fully written
+    const float *grad_out;  // *_VOLGRAD: dLoss/dout (B, N)
+    float *g_volume;        // *_VOLGRAD: dLoss/dvolume
+    int n_points;           // BRICK_TRI_*: samples per ray
+    const float *amin, *amax;  // BRICK_TRI_*: device scalars (renderers.py:220-223)
 };
 
 // what a brick launch computes
 constexpr int BRICK_FWD = 0;      // out
 constexpr int BRICK_FWD_AUX = 1;  // out + planar backward record
 constexpr int BRICK_VOLGRAD = 2;  // g_volume (the brick in LDS is the accumulator)
+constexpr int BRICK_TRI_FWD = 3;      // trilinear marcher: out
+constexpr int BRICK_TRI_VOLGRAD = 4;  // trilinear marcher: g_volume
 
 inline size_t brick_lds_bytes(const BrickLayout &lay) {
     return (size_t)brick_floats(lay) * 4 + (size_t)kBrickWaves * kBuckets * kQueueCap * 4 +
@@ -402,6 +407,28 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
         if (w != 0.f) brick_scatter(LdsAbsAdd{}, base, G, s, t, p.shift, p.eps, w);
         return;
     }
+    if (MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_VOLGRAD) {
+        TriGeom T;  // G.lof holds the first base cell here (set by the kernel)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            T.lo[a] = G.lof[a];
+            T.stridef[a] = G.stridef[a];
+        }
+        const float a0 = p.amin[0], a1 = p.amax[0];
+        const float step = (a1 - a0) / (float)(p.n_points - 1);  // renderers.py:235
+        float sumT;
+        if (MODE == BRICK_TRI_FWD) {
+            if (tri_brick_march<false>(LdsAbsFetch{}, base, T, s, t, p.shift, p.eps, p.n_points, a0,
+                                       a1, 0.f, sumT))
+                unsafeAtomicAdd(out + r, L * step * sumT);
+        } else {
+            const float w = p.grad_out[r] * L * step;
+            if (w != 0.f)
+                tri_brick_march<true>(LdsAbsAdd{}, base, T, s, t, p.shift, p.eps, p.n_points, a0,
+                                      a1, w, sumT);
+        }
+        return;
+    }
     float I, rec[4];
     if (!brick_trace<AUX>(LdsAbsFetch{}, base, G, s, t, p.shift, p.eps, I, rec)) return;
     if (!(p.dbg & 2)) unsafeAtomicAdd(out + r, L * I);
@@ -430,6 +457,8 @@ template <int MODE>
 __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     BrickArgs p, float *__restrict__ out, float *__restrict__ aux) {
     constexpr bool AUX = MODE == BRICK_FWD_AUX;
+    constexpr bool TRI = MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_VOLGRAD;
+    constexpr bool GRAD = MODE == BRICK_VOLGRAD || MODE == BRICK_TRI_VOLGRAD;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *brick = reinterpret_cast<float *>(smem_raw);
     unsigned *queue = reinterpret_cast<unsigned *>(brick + brick_floats(p.lay));
@@ -437,7 +466,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     int *counter = reinterpret_cast<int *>(rows + kPoseChunk * kRowWords);  // [0] unit, [1] brick
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const BrickGrid bg = brick_grid(p.D);
+    const BrickGrid bg = TRI ? tri_brick_grid(p.D) : brick_grid(p.D);
     const int n_bricks = bg.nx * bg.ny * bg.nz;
     const int N = p.det_h * p.det_w;
     // wave-private: written and read by lanes of the same wave only.  LDS operations of a
@@ -455,8 +484,30 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     __syncthreads();
     const int brick_id = counter[1];
     if (brick_id >= n_bricks) break;
-    const Box box = brick_box(p.D, bg, brick_id);
-    const BrickGeom G = brick_geom(box, p.lay);
+    // `box`: the voxels staged in LDS; `cells`: the planes the candidates are clipped against
+    Box box;
+    BoxF cells;
+    if (TRI) {
+        int lo[3];
+        tri_brick_lo(bg, brick_id, lo);
+        const int Dn[3] = {p.D.x, p.D.y, p.D.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            box.lo[a] = lo[a];  // may be -1: staged as zeros (the zero padding)
+            box.hi[a] = lo[a] + BRICK < Dn[a] ? lo[a] + BRICK : Dn[a];
+            cells.lo[a] = (float)lo[a] + 0.5f;  // g = lo  <=>  plane index lo + 1/2
+            cells.hi[a] = (float)(lo[a] + TRI_CELLS) + 0.5f;
+        }
+    } else {
+        box = brick_box(p.D, bg, brick_id);
+        cells = boxf(box);
+    }
+    BrickGeom G = brick_geom(box, p.lay);
+    if (TRI) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) G.lof[a] = (float)box.lo[a];
+    }
+    const float nscale = TRI ? (float)(p.n_points - 1) / (p.amax[0] - p.amin[0]) : 0.f;
     int qn0 = 0, qn1 = 0, qn2 = 0;  // hits waiting per length class (wave-uniform)
 
     for (int ch = 0; ch < n_chunks; ++ch) {
@@ -467,8 +518,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         if (tid < nb) {
             const PoseGrid pg = pose_grid(p.source + (long)(b0 + tid) * 3,
                                           p.target + (long)(b0 + tid) * N * 3, p.det_h, p.det_w);
-            const PixBox pb = project_brick_grid(pg, p.det_h, p.det_w, box, p.shift);
-            const BrickRow r = brick_row(pg, pb, box, p.shift, p.eps);
+            const PixBox pb = project_brick_grid(pg, p.det_h, p.det_w, cells, p.shift);
+            const BrickRow r = brick_row(pg, pb, cells, p.shift, p.eps, nscale);
             *reinterpret_cast<BrickRow *>(rows + tid * kRowWords) = r;
         }
         if (tid == 0) counter[0] = 0;
@@ -478,15 +529,15 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                 const int lx = row / BRICK, ly = row - lx * BRICK, q4 = (tid & 7) * 4;
                 const int x = box.lo[0] + lx, y = box.lo[1] + ly, z = box.lo[2] + q4;
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (MODE != BRICK_VOLGRAD && x < box.hi[0] && y < box.hi[1]) {
+                if (!GRAD && x >= 0 && y >= 0 && x < box.hi[0] && y < box.hi[1]) {
                     const float *g = p.vol + ((long)x * p.D.y + y) * p.D.z + z;
-                    if (vec_ok && z + 4 <= box.hi[2]) {
+                    if (!TRI && vec_ok && z + 4 <= box.hi[2]) {
                         const float4 q = *reinterpret_cast<const float4 *>(g);
                         v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
                     } else {
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            if (z + k < box.hi[2]) v[k] = g[k];
+                            if (z + k >= 0 && z + k < box.hi[2]) v[k] = g[k];
                     }
                 }
                 float *d = brick + lx * p.lay.sx + ly * p.lay.sy + q4;
@@ -593,19 +644,27 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
             if (drain) break;
         }
     }
-    if (MODE == BRICK_VOLGRAD) {
-        // every ray of every pose has been scattered into the LDS accumulator: the brick
-        // owns its voxels, so the gradient is stored, not added
+    if (GRAD) {
+        // every ray of every pose has been scattered into the LDS accumulator.  Siddon
+        // bricks own their voxels: the gradient is stored.  Trilinear bricks overlap by one
+        // voxel layer (the halo): cells 0 and 31 of an axis are shared with the neighbour
+        // and are added with atomics into the zero-filled gradient, the rest is stored.
         __syncthreads();
         for (int row = tid >> 3; row < BRICK * BRICK; row += kBrickThreads >> 3) {
             const int lx = row / BRICK, ly = row - lx * BRICK, q4 = (tid & 7) * 4;
             const int x = box.lo[0] + lx, y = box.lo[1] + ly, z = box.lo[2] + q4;
-            if (x < box.hi[0] && y < box.hi[1]) {
+            if (x >= 0 && y >= 0 && x < box.hi[0] && y < box.hi[1]) {
                 const float *src = brick + lx * p.lay.sx + ly * p.lay.sy + q4;
                 float *g = p.g_volume + ((long)x * p.D.y + y) * p.D.z + z;
+                const bool shell_xy = lx == 0 || lx == BRICK - 1 || ly == 0 || ly == BRICK - 1;
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (z + k < box.hi[2]) g[k] = src[k];
+                for (int k = 0; k < 4; ++k) {
+                    if (z + k < 0 || z + k >= box.hi[2]) continue;
+                    if (TRI && (shell_xy || q4 + k == 0 || q4 + k == BRICK - 1))
+                        unsafeAtomicAdd(g + k, src[k]);
+                    else
+                        g[k] = src[k];
+                }
             }
         }
     }
@@ -791,6 +850,7 @@ int g_xcd_swizzle_slab = 0;
 BrickLayout g_brick_layout = {33, 32 * 33 + 1};
 // length classes of brick hits (estimated plane crossings inside the brick)
 float g_brick_t1 = 18.f, g_brick_t2 = 40.f;
+float g_tri_t1 = 10.f, g_tri_t2 = 22.f;  // same for the marcher, in samples per brick
 int g_brick_dbg = 0;
 
 int check_common(const float *volume, int dx, int dy, int dz, const float *source, int src_n,
@@ -970,7 +1030,8 @@ namespace {
 int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const float *source,
                   const float *target, const float *img, const float *grad_out, int B, int det_h,
                   int det_w, float voxel_shift, float eps, float *out, float *aux,
-                  float *g_volume, hipStream_t st, const char *who) {
+                  float *g_volume, hipStream_t st, const char *who, int n_points = 0,
+                  const float *amin = nullptr, const float *amax = nullptr) {
     const int N = det_h * det_w;
     BrickArgs p;
     p.vol = volume;
@@ -997,13 +1058,22 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     p.dbg = g_brick_dbg;
     p.grad_out = grad_out;
     p.g_volume = g_volume;
+    p.n_points = n_points;
+    p.amin = amin;
+    p.amax = amax;
+    if (mode == BRICK_TRI_FWD || mode == BRICK_TRI_VOLGRAD) {
+        p.t1 = g_tri_t1;
+        p.t2 = g_tri_t2;
+    }
     const size_t lds = brick_lds_bytes(p.lay);
     hipError_t e;
     static bool attr_set = false;  // raise the dynamic-LDS limit once per process
     if (!attr_set) {
-        const void *fns[3] = {reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_FWD>),
+        const void *fns[5] = {reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_FWD>),
                               reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_FWD_AUX>),
-                              reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_VOLGRAD>)};
+                              reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_VOLGRAD>),
+                              reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_FWD>),
+                              reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_VOLGRAD>)};
         for (const void *fn : fns)
             if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024)) != hipSuccess)
@@ -1029,10 +1099,16 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     p.work = ring[dev] + (slot[dev]++ % kRing);
     if ((e = hipMemsetAsync(p.work, 0, sizeof(int), st)) != hipSuccess)
         return fail_hip(e, "hipMemsetAsync");
-    const BrickGrid bg = brick_grid(p.D);
+    const bool tri = mode == BRICK_TRI_FWD || mode == BRICK_TRI_VOLGRAD;
+    const BrickGrid bg = tri ? tri_brick_grid(p.D) : brick_grid(p.D);
     const int n_bricks = bg.nx * bg.ny * bg.nz;
     const dim3 grid(n_bricks < n_cu[dev] ? n_bricks : n_cu[dev]), block(kBrickThreads);
-    if (mode == BRICK_FWD)
+    if (mode == BRICK_TRI_FWD)
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_FWD>, grid, block, lds, st, p, out, aux);
+    else if (mode == BRICK_TRI_VOLGRAD)
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_VOLGRAD>, grid, block, lds, st, p, out,
+                           aux);
+    else if (mode == BRICK_FWD)
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_FWD>, grid, block, lds, st, p, out, aux);
     else if (mode == BRICK_FWD_AUX)
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_FWD_AUX>, grid, block, lds, st, p, out, aux);
@@ -1078,6 +1154,46 @@ int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *sour
     return launch_bricks(BRICK_VOLGRAD, nullptr, dx, dy, dz, source, target, img, grad_out, B,
                          det_h, det_w, voxel_shift, eps, nullptr, nullptr, g_volume, st,
                          "ddrr_siddon_backward_volume_bricks");
+}
+
+int ddrr_trilinear_forward_bricks(const float *volume, int dx, int dy, int dz,
+                                  const float *source, const float *target, const float *img,
+                                  int B, int det_h, int det_w, float voxel_shift, float eps,
+                                  int n_points, const float *alphamin, const float *alphamax,
+                                  float *out, void *stream) {
+    const int N = det_h * det_w;
+    if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
+    if (!out || !alphamin || !alphamax) return fail(-1, "null out / alphamin / alphamax");
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * N, st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    return launch_bricks(BRICK_TRI_FWD, volume, dx, dy, dz, source, target, img, nullptr, B, det_h,
+                         det_w, voxel_shift, eps, out, nullptr, nullptr, st,
+                         "ddrr_trilinear_forward_bricks", n_points, alphamin, alphamax);
+}
+
+int ddrr_trilinear_backward_volume_bricks(int dx, int dy, int dz, const float *source,
+                                          const float *target, const float *img,
+                                          const float *grad_out, int B, int det_h, int det_w,
+                                          float voxel_shift, float eps, int n_points,
+                                          const float *alphamin, const float *alphamax,
+                                          float *g_volume, void *stream) {
+    const int N = det_h * det_w;
+    if (!g_volume || !grad_out || !alphamin || !alphamax)
+        return fail(-1, "null grad_out / g_volume / alphamin / alphamax");
+    if (int rc = check_common(g_volume, dx, dy, dz, source, 1, target, B, N)) return rc;
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(g_volume, 0, sizeof(float) * (size_t)dx * dy * dz, st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    if (B == 0) return 0;
+    return launch_bricks(BRICK_TRI_VOLGRAD, nullptr, dx, dy, dz, source, target, img, grad_out, B,
+                         det_h, det_w, voxel_shift, eps, nullptr, nullptr, g_volume, st,
+                         "ddrr_trilinear_backward_volume_bricks", n_points, alphamin, alphamax);
 }
 
 int ddrr_siddon_backward_rays(const float *aux, int aux_layout, const float *grad_out,

@@ -338,6 +338,45 @@ def trilinear_forward(volume, source, target, img, alphamin, alphamax, *, n_poin
     return out
 
 
+def trilinear_forward_bricks(volume, source, target, img, alphamin, alphamax, det, *,
+                             n_points=500, voxel_shift=0.5, eps=1e-8):
+    """Detector-grid trilinear march (bilinear, sum, align_corners=False) through the
+    volume-stationary brick kernel.  -> out (B,N)"""
+    B, N = _check_rays(volume, source, target, img)
+    H, W = int(det[0]), int(det[1])
+    if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
+        raise ValueError("the brick path needs one source per pose and an H*W >= 2x2 ray grid")
+    volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    out = torch.empty(B, N, dtype=torch.float32, device=volume.device)
+    if _empty(B, N):
+        return out
+    _launch("ddrr_trilinear_forward_bricks", volume.device, volume.data_ptr(), *volume.shape,
+            source.data_ptr(), target.data_ptr(), _ptr(img), B, H, W, float(voxel_shift),
+            float(eps), int(n_points), alphamin.data_ptr(), alphamax.data_ptr(), out.data_ptr())
+    return out
+
+
+def trilinear_backward_volume_bricks(volume_shape, source, target, img, grad_out, alphamin,
+                                     alphamax, det, *, n_points=500, voxel_shift=0.5, eps=1e-8):
+    """Volume gradient of the detector-grid trilinear march through the brick kernel (LDS
+    accumulation).  -> g_volume (Dx,Dy,Dz)"""
+    B, N, _ = target.shape
+    H, W = int(det[0]), int(det[1])
+    if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
+        raise ValueError("the brick path needs one source per pose and an H*W >= 2x2 ray grid")
+    _require_gpu(target)
+    source, target, grad_out = source.contiguous(), target.contiguous(), grad_out.contiguous()
+    img = None if img is None else img.contiguous()
+    Dx, Dy, Dz = (int(v) for v in volume_shape)
+    g_volume = torch.empty(Dx, Dy, Dz, dtype=torch.float32, device=target.device)
+    _launch("ddrr_trilinear_backward_volume_bricks", target.device, Dx, Dy, Dz,
+            source.data_ptr(), target.data_ptr(), _ptr(img), grad_out.data_ptr(), B, H, W,
+            float(voxel_shift), float(eps), int(n_points), alphamin.data_ptr(),
+            alphamax.data_ptr(), g_volume.data_ptr())
+    return g_volume
+
+
 def trilinear_backward(volume, source, target, img, grad_out, alphamin, alphamax, *, n_points=500,
                        voxel_shift=0.5, eps=1e-8, mode="bilinear", align_corners=False,
                        want_rays=True, want_img=True, want_alpha=True, want_volume=False,

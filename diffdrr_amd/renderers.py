@@ -264,12 +264,26 @@ class _TrilinearFn(torch.autograd.Function):
     the 8-corner atomic scatter), replacing grid_sampler_3d_backward + chain."""
 
     @staticmethod
+    def _grid(cfg, source, target):
+        """The volume-stationary brick kernels apply: detector grid, bilinear, sum."""
+        N = target.shape[1]
+        return (cfg["bricks"] and cfg["mode"] == "bilinear" and cfg["reducefn"] == "sum"
+                and not cfg["align_corners"] and cfg["det"] is not None
+                and cfg["det"][0] * cfg["det"][1] == N and source.shape[1] == 1
+                and min(cfg["det"]) >= 2)
+
+    @staticmethod
     def forward(ctx, volume, source, target, img, alphamin, alphamax, cfg):
-        out = ops.trilinear_forward(
-            volume, source.contiguous(), target.contiguous(), img.contiguous(), alphamin,
-            alphamax, n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
-            reducefn=cfg["reducefn"], mode=cfg["mode"], align_corners=cfg["align_corners"],
-            det=cfg["det"], tile=cfg["tile"])
+        if _TrilinearFn._grid(cfg, source, target):
+            out = ops.trilinear_forward_bricks(
+                volume, source, target, img, alphamin, alphamax, cfg["det"],
+                n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"])
+        else:
+            out = ops.trilinear_forward(
+                volume, source.contiguous(), target.contiguous(), img.contiguous(), alphamin,
+                alphamax, n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"],
+                eps=cfg["eps"], reducefn=cfg["reducefn"], mode=cfg["mode"],
+                align_corners=cfg["align_corners"], det=cfg["det"], tile=cfg["tile"])
         ctx.cfg = cfg
         ctx.save_for_backward(volume, source, target, img, alphamin, alphamax)
         return out
@@ -281,6 +295,16 @@ class _TrilinearFn(torch.autograd.Function):
         if cfg["reducefn"] != "sum":
             raise NotImplementedError("Trilinear gradients are implemented for reducefn='sum'")
         need_vol, need_s, need_t, need_i, need_a0, need_a1 = ctx.needs_input_grad[:6]
+        g_vol_bricks = None
+        if need_vol and _TrilinearFn._grid(cfg, source, target):
+            # volume gradient: LDS accumulation per brick instead of 8 global atomics per
+            # sample; the per-ray kernel below then only produces the ray gradients
+            g_vol_bricks = ops.trilinear_backward_volume_bricks(
+                volume.shape, source, target, img, grad_out, alphamin, alphamax, cfg["det"],
+                n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"])
+            need_vol = False
+            if not (need_s or need_t or need_i or need_a0 or need_a1):
+                return g_vol_bricks, None, None, None, None, None, None
         r = ops.trilinear_backward(
             volume, source.contiguous(), target.contiguous(), img.contiguous(), grad_out,
             alphamin, alphamax, n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"],
@@ -300,7 +324,8 @@ class _TrilinearFn(torch.autograd.Function):
             ga = r["g_alpha"].sum(dim=(0, 1))
             g_a0 = ga[0].reshape(alphamin.shape) if need_a0 else None
             g_a1 = ga[1].reshape(alphamax.shape) if need_a1 else None
-        return r["g_volume"], g_s, g_t, g_i, g_a0, g_a1, None
+        return (g_vol_bricks if g_vol_bricks is not None else r["g_volume"]), g_s, g_t, g_i, \
+            g_a0, g_a1, None
 
 
 class Trilinear(torch.nn.Module):
@@ -318,6 +343,7 @@ class Trilinear(torch.nn.Module):
         self.eps = eps
         self.detector_shape = None
         self.tile = None
+        self.use_bricks = True  # detector-grid calls: volume-stationary kernels (tri_brick.h)
 
     def dims(self, volume):
         return torch.tensor(volume.shape).to(volume)
@@ -339,7 +365,7 @@ class Trilinear(torch.nn.Module):
         cfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift, "eps": self.eps,
                "reducefn": self.reducefn, "mode": self.mode,
                "align_corners": bool(align_corners), "det": self.detector_shape,
-               "tile": self.tile}
+               "tile": self.tile, "bricks": self.use_bricks}
         out = _TrilinearFn.apply(volume, source, target, img.reshape(B, N), alphamin, alphamax,
                                  cfg)
         return out.unsqueeze(1)

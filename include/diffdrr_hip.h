@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 4
+#define DDRR_ABI_VERSION 5
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -152,6 +152,27 @@ int ddrr_trilinear_forward(const float *volume, int dx, int dy, int dz, const fl
                            const float *alphamax, int mode_nearest, int reduce_mode,
                            int align_corners, int det_h, int det_w, int tile_h, int tile_w,
                            float *out, void *stream);
+
+/* Volume-stationary forms of the marcher for the DRR case (one source per pose, det_h x
+ * det_w target grid, mode "bilinear", reducefn "sum", align_corners = 0): bricks of 31^3 base
+ * cells (+1 voxel halo, staged as 32^3 in LDS; voxels outside the volume staged as zeros =
+ * the zero padding); a sample belongs to the brick holding floor(index coordinate).
+ * _forward_bricks: out (B, N) zero-filled by the call and accumulated with atomics.
+ * _backward_volume_bricks: g_volume (dx, dy, dz) zero-filled by the call; each brick
+ * accumulates in LDS (ds_add_f32) and is written once (halo layers with atomics).
+ * Replace renderers.py:205-241 and grid_sampler_3d_backward (bilinear) like the two
+ * entries above, which remain the path for arbitrary ray lists and other modes. */
+int ddrr_trilinear_forward_bricks(const float *volume, int dx, int dy, int dz,
+                                  const float *source, const float *target, const float *img,
+                                  int B, int det_h, int det_w, float voxel_shift, float eps,
+                                  int n_points, const float *alphamin, const float *alphamax,
+                                  float *out, void *stream);
+int ddrr_trilinear_backward_volume_bricks(int dx, int dy, int dz, const float *source,
+                                          const float *target, const float *img,
+                                          const float *grad_out, int B, int det_h, int det_w,
+                                          float voxel_shift, float eps, int n_points,
+                                          const float *alphamin, const float *alphamax,
+                                          float *g_volume, void *stream);
 
 /* Backward of ddrr_trilinear_forward (reduce sum).  Any output may be NULL.
  * g_source/g_target: per ray (B, N, 3), through the sample positions;

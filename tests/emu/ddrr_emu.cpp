@@ -19,6 +19,7 @@
 #include "../../diffdrr_amd/csrc/brick_core.h"
 #include "../../diffdrr_amd/csrc/brick_walk.h"
 #include "../../diffdrr_amd/csrc/raygen_core.h"
+#include "../../diffdrr_amd/csrc/tri_brick.h"
 #include "../../diffdrr_amd/csrc/slab_core.h"
 #include "../../diffdrr_amd/csrc/trilinear_core.h"
 #include "../../include/diffdrr_hip.h"
@@ -70,6 +71,105 @@ struct NoAdd {
     void operator()(unsigned, float) const {}
 };
 
+}  // namespace
+
+// Host emulation of the trilinear brick kernels: per brick of 31^3 base cells (32^3 staged
+// voxels, zeros outside the volume), every candidate pixel of every pose marches its
+// samples; forward accumulates out, backward scatters into the staged accumulator which
+// is then added to g_volume.
+namespace {
+template <bool SCATTER>
+int tri_bricks_host(const float *volume, int dx, int dy, int dz, const float *source,
+                    const float *target, const float *img, const float *grad_out, int B, int det_h,
+                    int det_w, float voxel_shift, float eps, int n_points, float amin, float amax,
+                    float *out, float *g_volume) {
+    const Dims D{dx, dy, dz};
+    const int N = det_h * det_w, Dn[3] = {dx, dy, dz};
+    const BrickGrid bg = tri_brick_grid(D);
+    const BrickLayout lay{33, 32 * 33 + 1};
+    std::vector<float> brick((size_t)brick_floats(lay));
+    struct HostFetch {
+        const float *base;
+        float operator()(unsigned off) const { return base[off >> 2]; }
+    };
+    struct HostAddB {
+        float *base;
+        void operator()(unsigned off, float v) const { base[off >> 2] += v; }
+    };
+    const float step = (amax - amin) / (float)(n_points - 1);
+    const float nscale = (float)(n_points - 1) / (amax - amin);
+    for (int id = 0; id < bg.nx * bg.ny * bg.nz; ++id) {
+        int lo[3];
+        tri_brick_lo(bg, id, lo);
+        BoxF cells;
+        for (int a = 0; a < 3; ++a) {
+            cells.lo[a] = (float)lo[a] + 0.5f;
+            cells.hi[a] = (float)(lo[a] + TRI_CELLS) + 0.5f;
+        }
+        const TriGeom G = tri_geom(lo, lay);
+        std::fill(brick.begin(), brick.end(), 0.f);
+        if (!SCATTER)
+            for (int lx = 0; lx < BRICK; ++lx)
+                for (int ly = 0; ly < BRICK; ++ly)
+                    for (int lz = 0; lz < BRICK; ++lz) {
+                        const int x = lo[0] + lx, y = lo[1] + ly, z = lo[2] + lz;
+                        if (x < 0 || y < 0 || z < 0 || x >= dx || y >= dy || z >= dz) continue;
+                        brick[lx * lay.sx + ly * lay.sy + lz] = volume[((long)x * dy + y) * dz + z];
+                    }
+        for (int b = 0; b < B; ++b) {
+            const PoseGrid pg = pose_grid(source + (long)b * 3, target + (long)b * N * 3, det_h,
+                                          det_w);
+            const PixBox pb = project_brick_grid(pg, det_h, det_w, cells, voxel_shift);
+            const BrickRow row = brick_row(pg, pb, cells, voxel_shift, eps, nscale);
+            std::vector<char> cand((size_t)N, 0);
+            auto ray = [&](int pix, float s[3], float t[3]) {
+                const long r = (long)b * N + pix;
+                for (int a = 0; a < 3; ++a) {
+                    s[a] = source[(long)b * 3 + a];
+                    t[a] = target[r * 3 + a];
+                }
+                return r;
+            };
+            for (int local = 0; local < row.count; ++local) {
+                int pix;
+                float n_est;
+                if (!brick_candidate(row, local, det_w, pix, n_est)) continue;
+                cand[pix] = 1;
+                float s[3], t[3], sumT;
+                const long r = ray(pix, s, t);
+                const float L = img ? img[r] : 1.f;
+                if (SCATTER) {
+                    tri_brick_march<true>(HostAddB{brick.data()}, 0.f, G, s, t, voxel_shift, eps,
+                                          n_points, amin, amax, grad_out[r] * L * step, sumT);
+                } else if (tri_brick_march<false>(HostFetch{brick.data()}, 0.f, G, s, t,
+                                                  voxel_shift, eps, n_points, amin, amax, 0.f,
+                                                  sumT)) {
+                    out[r] += L * step * sumT;
+                }
+            }
+            if (!SCATTER)  // phase A must not lose a pixel with samples in this brick
+                for (int pix = 0; pix < N; ++pix) {
+                    if (cand[pix]) continue;
+                    float s[3], t[3], sumT;
+                    ray(pix, s, t);
+                    if (tri_brick_march<false>(HostFetch{brick.data()}, 0.f, G, s, t, voxel_shift,
+                                               eps, n_points, amin, amax, 0.f, sumT) &&
+                        sumT != 0.f)
+                        abort();
+                }
+        }
+        if (SCATTER)
+            for (int lx = 0; lx < BRICK; ++lx)
+                for (int ly = 0; ly < BRICK; ++ly)
+                    for (int lz = 0; lz < BRICK; ++lz) {
+                        const int x = lo[0] + lx, y = lo[1] + ly, z = lo[2] + lz;
+                        if (x < 0 || y < 0 || z < 0 || x >= dx || y >= dy || z >= dz) continue;
+                        g_volume[((long)x * dy + y) * dz + z] += brick[lx * lay.sx + ly * lay.sy + lz];
+                    }
+        (void)Dn;
+    }
+    return 0;
+}
 }  // namespace
 
 extern "C" {
@@ -315,8 +415,8 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
         for (int b = 0; b < B; ++b) {
             const PoseGrid pg = pose_grid(source + (long)b * 3, target + (long)b * N * 3, det_h,
                                           det_w);
-            const PixBox pb = project_brick_grid(pg, det_h, det_w, box, voxel_shift);
-            const BrickRow row = brick_row(pg, pb, box, voxel_shift, eps);
+            const PixBox pb = project_brick_grid(pg, det_h, det_w, boxf(box), voxel_shift);
+            const BrickRow row = brick_row(pg, pb, boxf(box), voxel_shift, eps, 0.f);
             // phase A must never lose a ray the exact clip accepts: check EVERY pixel of the
             // pose against the exact clip, inside and outside the projected pixel box
             std::vector<char> cand((size_t)N, 0);
@@ -377,8 +477,8 @@ int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *sour
         for (int b = 0; b < B; ++b) {
             const PoseGrid pg = pose_grid(source + (long)b * 3, target + (long)b * N * 3, det_h,
                                           det_w);
-            const PixBox pb = project_brick_grid(pg, det_h, det_w, box, voxel_shift);
-            const BrickRow row = brick_row(pg, pb, box, voxel_shift, eps);
+            const PixBox pb = project_brick_grid(pg, det_h, det_w, boxf(box), voxel_shift);
+            const BrickRow row = brick_row(pg, pb, boxf(box), voxel_shift, eps, 0.f);
             for (int local = 0; local < row.count; ++local) {
                 int pix;
                 float n_est;
@@ -401,6 +501,28 @@ int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *sour
                         brick[(x - box.lo[0]) * lay.sx + (y - box.lo[1]) * lay.sy + (z - box.lo[2])];
     }
     return 0;
+}
+
+int ddrr_trilinear_forward_bricks(const float *volume, int dx, int dy, int dz,
+                                  const float *source, const float *target, const float *img,
+                                  int B, int det_h, int det_w, float voxel_shift, float eps,
+                                  int n_points, const float *alphamin, const float *alphamax,
+                                  float *out, void *) {
+    memset(out, 0, sizeof(float) * (size_t)B * det_h * det_w);
+    return tri_bricks_host<false>(volume, dx, dy, dz, source, target, img, nullptr, B, det_h, det_w,
+                                  voxel_shift, eps, n_points, *alphamin, *alphamax, out, nullptr);
+}
+
+int ddrr_trilinear_backward_volume_bricks(int dx, int dy, int dz, const float *source,
+                                          const float *target, const float *img,
+                                          const float *grad_out, int B, int det_h, int det_w,
+                                          float voxel_shift, float eps, int n_points,
+                                          const float *alphamin, const float *alphamax,
+                                          float *g_volume, void *) {
+    memset(g_volume, 0, sizeof(float) * (size_t)dx * dy * dz);
+    return tri_bricks_host<true>(nullptr, dx, dy, dz, source, target, img, grad_out, B, det_h,
+                                 det_w, voxel_shift, eps, n_points, *alphamin, *alphamax, nullptr,
+                                 g_volume);
 }
 
 int ddrr_siddon_backward_rays(const float *aux, int aux_layout, const float *grad_out,
