@@ -115,8 +115,8 @@ DDRR_HD PixBox project_brick_grid(const PoseGrid &g, int det_h, int det_w, const
     return pb;
 }
 
-// One row of the per-(pose, brick) table phase A reads (21 words).
-constexpr int kRowWords = 21;
+// One row of the per-(pose, brick) table phase A reads (22 words).
+constexpr int kRowWords = 22;
 struct BrickRow {
     float D0[3];   // (t00 - s) + eps : direction of pixel (0, 0)
     float ei[3], ej[3];
@@ -125,7 +125,43 @@ struct BrickRow {
     float inv_w;   // 1 / width of the pixel box
     float nscale;  // > 0: work estimate = (exit - entry) * nscale (samples); else crossings
     int i0, j0, w, count;
+    int perm_k;    // candidate order: local -> (local * perm_k) mod count (1 = row-major)
 };
+
+// Scatter kernels want the 64 rays of a wave FAR APART: neighbouring rays cross the same
+// voxels, and 64 LDS atomics on a handful of addresses serialise.  A multiplicative shuffle
+// of the candidate order (a bijection of 0..count-1 when gcd(k, count) = 1) puts consecutive
+// candidates ~3 detector rows and ~3 columns apart.
+DDRR_HD int scatter_perm_k(int w, int count) {
+    if (count < 64) return 1;
+    int k = 3 * w + 3;
+    if (k >= count) k = count / 2 + 1;
+    for (int tries = 0; tries < 64; ++tries, ++k) {
+        int a = k, b = count;
+        while (b) {
+            const int r = a % b;
+            a = b;
+            b = r;
+        }
+        if (a == 1) return k;
+    }
+    return 1;
+}
+
+DDRR_HD int scatter_perm(int local, int k, int count, float inv_count) {
+    if (k == 1) return local;
+    // (local * k) mod count; the product stays below 2^24 for every pixel box that fits a
+    // detector of up to 4096^2 / bricks... guard: fall back to exact integer arithmetic
+    const int prod = local * k;
+    if (prod < (1 << 23)) {
+        int q = (int)((float)prod * inv_count);
+        int r = prod - q * count;
+        r += r < 0 ? count : 0;
+        r -= r >= count ? count : 0;
+        return r;
+    }
+    return (int)(((long)local * k) % count);
+}
 
 // margin (voxels) by which phase A inflates the brick: covers the affine model's distance
 // from the stored targets, so a ray with a real chord in the brick is never rejected
@@ -148,6 +184,7 @@ DDRR_HD BrickRow brick_row(const PoseGrid &g, const PixBox &pb, const BoxF &box,
     r.w = pb.j1 - pb.j0 + 1;
     r.count = pixbox_count(pb);
     r.inv_w = 1.0f / (float)(r.w > 0 ? r.w : 1);
+    r.perm_k = 1;
     return r;
 }
 

@@ -375,10 +375,23 @@ inline size_t brick_lds_bytes(const BrickLayout &lay) {
 }
 
 #if defined(__HIPCC__)
-// ds_add_f32 by absolute LDS byte address (the volume-gradient accumulator)
+// Scatter into the LDS accumulator by absolute LDS byte address.  LDS float atomics run at
+// ~0.7 lane per clock on gfx950 (measured: ds_add_f32 occupies the LDS pipe ~90 cycles per
+// wave instruction, conflicts or not), integer ones 4x faster: the accumulator is int32
+// fixed point, value = count / q, with q chosen per launch from a bound on the largest sum
+// a voxel can receive (volgrad_prepare_kernel); q == 0 selects the float path (the bound
+// does not exist, e.g. the source lies inside the volume).  Integer sums are associative:
+// the fixed-point gradient is bit-reproducible.
 struct LdsAbsAdd {
+    float q;
     __device__ __forceinline__ void operator()(unsigned addr, float v) const {
 #if defined(__HIP_DEVICE_COMPILE__)
+        if (q != 0.f) {
+            __hip_atomic_fetch_add((int *)(__attribute__((address_space(3))) int *)(unsigned long long)addr,
+                                   __float2int_rn(v * q), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
+        }
         __hip_atomic_fetch_add((float *)(__attribute__((address_space(3))) float *)(unsigned long long)addr,
                                v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
@@ -395,7 +408,8 @@ struct LdsAbsAdd {
 template <int MODE>
 __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *brick,
                                            const BrickGeom &G, unsigned b, unsigned pix,
-                                           float *__restrict__ out, float *__restrict__ aux) {
+                                           float fixq, float *__restrict__ out,
+                                           float *__restrict__ aux) {
     constexpr bool AUX = MODE == BRICK_FWD_AUX;
     const unsigned r = b * (unsigned)(p.det_h * p.det_w) + pix;
     const float *sp = p.source + b * 3u, *tp = p.target + r * 3u;
@@ -404,7 +418,7 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
     const float base = (float)LdsAbsFetch::base_of(brick);
     if (MODE == BRICK_VOLGRAD) {
         const float w = p.grad_out[r] * L;
-        if (w != 0.f) brick_scatter(LdsAbsAdd{}, base, G, s, t, p.shift, p.eps, w);
+        if (w != 0.f) brick_scatter(LdsAbsAdd{fixq}, base, G, s, t, p.shift, p.eps, w);
         return;
     }
     if (MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_VOLGRAD) {
@@ -424,8 +438,8 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
         } else {
             const float w = p.grad_out[r] * L * step;
             if (w != 0.f)
-                tri_brick_march<true>(LdsAbsAdd{}, base, T, s, t, p.shift, p.eps, p.n_points, a0,
-                                      a1, w, sumT);
+                tri_brick_march<true>(LdsAbsAdd{fixq}, base, T, s, t, p.shift, p.eps, p.n_points,
+                                      a0, a1, w, sumT);
         }
         return;
     }
@@ -475,6 +489,15 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     const unsigned pix_mask = (1u << p.pix_bits) - 1u;
     const int n_chunks = (p.B + kPoseChunk - 1) / kPoseChunk;
     const bool vec_ok = (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.vol) & 15) == 0;
+    // fixed-point scale of the LDS accumulator (volume-gradient modes): the largest sum a
+    // voxel can receive is n_sum (contributions) * wmax (each) -- volgrad_prepare_kernel
+    float fixq = 0.f;
+    if (GRAD && !(p.dbg & 32)) {
+        const float wmax = __uint_as_float((unsigned)p.work[1]);
+        const float n_sum = reinterpret_cast<const float *>(p.work)[2];
+        if (wmax > 0.f && wmax < 1e30f && n_sum > 0.f && n_sum <= 16384.f)
+            fixq = 2.0e9f / (n_sum * wmax);
+    }
 
   // Persistent workgroups: bricks are handed out by a global counter, so a CU that drew
   // light bricks (far from the sources: fewer rays cross them) simply takes more of them.
@@ -519,7 +542,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
             const PoseGrid pg = pose_grid(p.source + (long)(b0 + tid) * 3,
                                           p.target + (long)(b0 + tid) * N * 3, p.det_h, p.det_w);
             const PixBox pb = project_brick_grid(pg, p.det_h, p.det_w, cells, p.shift);
-            const BrickRow r = brick_row(pg, pb, cells, p.shift, p.eps, nscale);
+            BrickRow r = brick_row(pg, pb, cells, p.shift, p.eps, nscale);
+            if (GRAD && !(p.dbg & 16)) r.perm_k = scatter_perm_k(r.w, r.count);
             *reinterpret_cast<BrickRow *>(rows + tid * kRowWords) = r;
         }
         if (tid == 0) counter[0] = 0;
@@ -570,11 +594,14 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                     cur_hi = __builtin_amdgcn_readlane(incl, uni(cur));
                 }
                 const BrickRow r = *reinterpret_cast<const BrickRow *>(rows + cur * kRowWords);
-                const int local = (u - cur_lo) * 64 + lane;
+                int local = (u - cur_lo) * 64 + lane;
+                const bool valid = local < uni(r.count);
+                if (GRAD && valid)
+                    local = scatter_perm(local, uni(r.perm_k), uni(r.count),
+                                         1.0f / (float)uni(r.count));
                 int pix = 0;
                 float n_est = 0.f;
-                const bool hit = local < uni(r.count) &&
-                                 brick_candidate(r, local, p.det_w, pix, n_est);
+                const bool hit = valid && brick_candidate(r, local, p.det_w, pix, n_est);
                 // With the backward record (5 atomics per hit instead of 1) the length class
                 // of a hit is that of the longest hit among its 8 neighbours in candidate
                 // order (consecutive pixels of a detector row): a batch is then made of runs
@@ -638,7 +665,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                     break;
                 }
                 if (lane < n)
-                    brick_item<MODE>(p, brick, G, e >> p.pix_bits, e & pix_mask, out, aux);
+                    brick_item<MODE>(p, brick, G, e >> p.pix_bits, e & pix_mask, fixq, out, aux);
                 wave_fence();
             }
             if (drain) break;
@@ -660,10 +687,11 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (z + k < 0 || z + k >= box.hi[2]) continue;
+                    const float val = fixq != 0.f ? (float)__float_as_int(src[k]) / fixq : src[k];
                     if (TRI && (shell_xy || q4 + k == 0 || q4 + k == BRICK - 1))
-                        unsafeAtomicAdd(g + k, src[k]);
+                        unsafeAtomicAdd(g + k, val);
                     else
-                        g[k] = src[k];
+                        g[k] = val;
                 }
             }
         }
@@ -692,6 +720,72 @@ __global__ __launch_bounds__(kBlock) void siddon_fwd_channels_kernel(
     const float L = p.img ? p.img[id.r] : 1.f;
     float *col = out + (long)id.b * C * p.N + id.n;  // stride N between channels
     siddon_channels_ray(p.vol, labels, p.D, s, t, p.shift, p.eps, ColumnFlush{col, p.N, C, L});
+}
+
+// ------------------------------------------- volume-gradient fixed-point bound
+// work[1] = bits of max over rays of the largest single contribution a ray can make to a
+// voxel; work[2] = float: bound on the number of such contributions a voxel can receive in
+// this launch (sum over poses of the rays that can cross one voxel); see LdsAbsAdd.
+//   Siddon:    |g| L dalpha,  dalpha |d| <= sqrt(3)           ->  sqrt(3) |g| L / |d|
+//   trilinear: |g| L step per sample, at most 2 sqrt(3) / (step |d|) + 1 samples of a ray
+//              touch one voxel                                 ->  |g| L (2 sqrt(3) / |d| + step)
+// Rays of a pose through one voxel: those whose pixel lies in the voxel's (8-cell's)
+// shadow, at most (extent * |t - s| / rho_min / e_min + 2)^2 with rho_min the distance from
+// the source to the volume (0: no bound, the float path is taken).
+__global__ __launch_bounds__(kBlock) void volgrad_prepare_kernel(
+    int tri, const float *__restrict__ source, const float *__restrict__ target,
+    const float *__restrict__ img, const float *__restrict__ grad_out, int N, int det_w, Dims D,
+    float shift, float eps, int n_points, const float *__restrict__ amin,
+    const float *__restrict__ amax, int *__restrict__ work) {
+    const int b = blockIdx.y;
+    const float s[3] = {source[b * 3], source[b * 3 + 1], source[b * 3 + 2]};
+    const float step = tri ? (amax[0] - amin[0]) / (float)(n_points - 1) : 0.f;
+    float wmax = 0.f;
+    for (int n = blockIdx.x * kBlock + threadIdx.x; n < N; n += gridDim.x * kBlock) {
+        const long r = (long)b * N + n;
+        const float dx = target[r * 3] - s[0] + eps, dy = target[r * 3 + 1] - s[1] + eps;
+        const float dz = target[r * 3 + 2] - s[2] + eps;
+        const float dn = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float L = img ? img[r] : 1.f;
+        const float c = tri ? (3.4642f / dn + step) : 1.7321f / dn;
+        wmax = fmaxf(wmax, fabsf(grad_out[r]) * L * c);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(work) + 1, __float_as_uint(wmax));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // distance from the source to the volume box (voxel coordinates, planes at k - shift)
+        const float lo = -shift, hi[3] = {(float)D.x - shift, (float)D.y - shift, (float)D.z - shift};
+        float rho2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float gap = fmaxf(fmaxf(lo - s[a], s[a] - hi[a]), 0.f);
+            rho2 += gap * gap;
+        }
+        const float *t0 = target + (long)b * N * 3;
+        float e_i = 0.f, e_j = 0.f, dst = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float di = t0[(long)det_w * 3 + a] - t0[a], dj = t0[3 + a] - t0[a];
+            const float dt = t0[a] - s[a];
+            e_i += di * di;
+            e_j += dj * dj;
+            dst += dt * dt;
+        }
+        // the detector point farthest from the source bounds |t - s| (corner pixels)
+        const float *tc = t0 + (long)(N - 1) * 3;
+        float dst2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dst2 += (tc[a] - s[a]) * (tc[a] - s[a]);
+        const float reach = sqrtf(fmaxf(dst, dst2)), e_min = sqrtf(fminf(e_i, e_j));
+        const float extent = tri ? 3.4642f : 1.7321f;
+        float R = INFINITY;
+        if (rho2 > 1.f && e_min > 0.f) {
+            const float side = extent * reach / (sqrtf(rho2) * e_min) + 2.f;
+            R = side * side;
+        }
+        atomicAdd(reinterpret_cast<float *>(work) + 2, R);
+    }
 }
 
 // ------------------------------------------------ fused ray generation (DRR case)
@@ -1090,15 +1184,23 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     if ((e = hipGetDevice(&dev)) != hipSuccess) return fail_hip(e, "hipGetDevice");
     if (dev < 0 || dev >= kMaxDev) return fail(-1, "device index out of range");
     if (!ring[dev]) {
-        if ((e = hipMalloc(reinterpret_cast<void **>(&ring[dev]), kRing * sizeof(int))) != hipSuccess)
+        if ((e = hipMalloc(reinterpret_cast<void **>(&ring[dev]), kRing * 4 * sizeof(int))) != hipSuccess)
             return fail_hip(e, "hipMalloc(brick counters)");
         if ((e = hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev)) !=
             hipSuccess)
             return fail_hip(e, "hipDeviceGetAttribute");
     }
-    p.work = ring[dev] + (slot[dev]++ % kRing);
-    if ((e = hipMemsetAsync(p.work, 0, sizeof(int), st)) != hipSuccess)
+    p.work = ring[dev] + 4 * (slot[dev]++ % kRing);  // {brick counter, wmax bits, n_sum, -}
+    if ((e = hipMemsetAsync(p.work, 0, 4 * sizeof(int), st)) != hipSuccess)
         return fail_hip(e, "hipMemsetAsync");
+    if (mode == BRICK_VOLGRAD || mode == BRICK_TRI_VOLGRAD) {
+        const int tri = mode == BRICK_TRI_VOLGRAD;
+        int bx = (N + kBlock - 1) / kBlock;
+        bx = bx > 64 ? 64 : bx;
+        hipLaunchKernelGGL(volgrad_prepare_kernel, dim3(bx, B), dim3(kBlock), 0, st, tri, source,
+                           target, img, grad_out, N, det_w, p.D, voxel_shift, eps, n_points, amin,
+                           amax, p.work);
+    }
     const bool tri = mode == BRICK_TRI_FWD || mode == BRICK_TRI_VOLGRAD;
     const BrickGrid bg = tri ? tri_brick_grid(p.D) : brick_grid(p.D);
     const int n_bricks = bg.nx * bg.ny * bg.nz;

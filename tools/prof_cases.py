@@ -16,7 +16,7 @@ ap.add_argument("--tile", default="16x4")
 ap.add_argument("--xcd", type=int, default=1)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--size", type=int, default=512)
-ap.add_argument("--kernel", default="generic", choices=["generic", "slab", "brick"])
+ap.add_argument("--kernel", default="generic", choices=["generic", "slab", "brick", "volgrad"])
 ap.add_argument("--aux", type=int, default=0)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -43,6 +43,8 @@ for _ in range(a.reps):
         ops.siddon_forward(drr.density, s, t, L, det=(H, H), tile=(th, tw))
     elif a.kernel == "slab":
         ops.siddon_forward_slab(drr.density, s, t, L, (H, H), plan, shear)
+    elif a.kernel == "volgrad":
+        ops.siddon_backward_volume_bricks(drr.density.shape, s, t, L, torch.ones_like(L), (H, H))
     else:
         ops.siddon_forward_bricks(drr.density, s, t, L, (H, H), want_aux=bool(a.aux))
 torch.cuda.synchronize()

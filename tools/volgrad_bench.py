@@ -5,6 +5,9 @@ from diffdrr_amd import DRR, ops
 from diffdrr_amd.data import make_subject, noise_volume
 from tools.kernel_sweep import poses, rays, timeit
 dev = torch.device("cuda:0")
+from diffdrr_amd import _lib
+if len(sys.argv) > 1:
+    _lib.get_lib().cdll.ddrr_set_brick_debug(int(sys.argv[1]))
 for D, H, Bs in ((512, 256, (1, 8, 32)), (256, 256, (32,))):
     drr = DRR(make_subject(noise_volume(D, 0)), sdd=1020.0, height=H, delx=2.4 * D / 512).to(dev)
     V = drr.density
