@@ -639,3 +639,24 @@ def test_volume_gradient_bricks_fixed_point_and_float_paths(gpu):
     a = ops.siddon_backward_volume_bricks(V.shape, s, t, L, go, (H, W))
     b = ops.siddon_backward_volume_bricks(V.shape, s, t, L, go, (H, W))
     assert torch.equal(a, b)
+
+
+def test_brick_kernels_many_poses_multi_chunk(gpu):
+    """More poses than one pose-table chunk (32): the brick kernels walk the batch in chunks
+    with leftovers carried across them; B = 75 -> 3 chunks, against the per-ray kernels."""
+    H, W, B = 20, 28, 75
+    drr = DRR(synthetic_subject(50, kind="noise", seed=0), sdd=400.0, height=H, width=W,
+              delx=1.5).to(gpu)
+    g = torch.Generator().manual_seed(12)
+    rot = ((torch.rand(B, 3, generator=g) - 0.5) * 2.0).to(gpu)
+    xyz = (torch.tensor([0.0, 280.0, 0.0]) + (torch.rand(B, 3, generator=g) - 0.5) * 40).to(gpu)
+    s, t, L = voxel_rays(drr, rot, xyz)
+    V = drr.density
+    ref, aux_ref, _ = ops.siddon_forward(V, s, t, L, want_aux=True)
+    out, aux = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True)
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    assert torch.allclose(aux[0], aux_ref[..., 0], rtol=1e-4, atol=1e-5)
+    go = torch.rand(B, H * W, device=gpu, generator=torch.Generator(gpu).manual_seed(1))
+    gref = ops.siddon_backward_volume(V, s, t, L, go)
+    gout = ops.siddon_backward_volume_bricks(V.shape, s, t, L, go, (H, W))
+    assert rel_err(gout.cpu().numpy(), gref.cpu().numpy()) < 2e-5
