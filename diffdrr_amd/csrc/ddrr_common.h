@@ -30,6 +30,29 @@ struct Dims {
     int x, y, z;
 };
 
+// Separately rounded product / sum (never contracted into an FMA): for the few places that
+// restate a reference expression bit for bit.
+// (hipcc contracts a * b + c by default and __fmul_rn / __fadd_rn do not stop it: the
+// operations are emitted without the `contract` flag through the pragma.)
+DDRR_HD float mul_rn(float a, float b) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+    return a * b;
+#else
+    volatile float r = a * b;
+    return r;
+#endif
+}
+DDRR_HD float add_rn(float a, float b) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+    return a + b;
+#else
+    volatile float r = a + b;
+    return r;
+#endif
+}
+
 DDRR_HD float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 DDRR_HD float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 DDRR_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

@@ -895,6 +895,20 @@ __global__ __launch_bounds__(kBlock) void trilinear_fwd_kernel(RayArgs p, int n_
     out[id.r] = L * I;
 }
 
+__global__ __launch_bounds__(kBlock) void trilinear_fwd_channels_kernel(
+    RayArgs p, const unsigned char *__restrict__ labels, int C, int n_points,
+    const float *__restrict__ amin, const float *__restrict__ amax, int align_corners,
+    float *__restrict__ out) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    float *col = out + (long)id.b * C * p.N + id.n;  // stride N between channels
+    trilinear_channels_ray(p.vol, labels, p.D, s, t, p.shift, p.eps, n_points, amin[0], amax[0],
+                           align_corners != 0, ColumnFlush{col, p.N, C, L});
+}
+
 struct NoAdd {
     __device__ __forceinline__ void operator()(unsigned, float) const {}
 };
@@ -1390,6 +1404,28 @@ int ddrr_trilinear_forward(const float *volume, int dx, int dy, int dz, const fl
     else LAUNCH(REDUCE_MAX, true);
 #undef LAUNCH
     return finish("ddrr_trilinear_forward");
+}
+
+int ddrr_trilinear_forward_channels(const float *volume, const unsigned char *labels, int dx,
+                                    int dy, int dz, const float *source, int src_n,
+                                    const float *target, const float *img, int B, int N, int C,
+                                    float voxel_shift, float eps, int n_points,
+                                    const float *alphamin, const float *alphamax,
+                                    int align_corners, int det_h, int det_w, int tile_h,
+                                    int tile_w, float *out, void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!labels || !out || C < 1) return fail(-1, "null labels/out or C < 1");
+    if (!alphamin || !alphamax) return fail(-1, "null alphamin / alphamax");
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (B == 0 || N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C * N, st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, det_h, det_w, tile_h, tile_w);
+    hipLaunchKernelGGL(trilinear_fwd_channels_kernel, dim3(grid_for(p)), dim3(kBlock), 0, st, p,
+                       labels, C, n_points, alphamin, alphamax, align_corners, out);
+    return finish("ddrr_trilinear_forward_channels");
 }
 
 int ddrr_trilinear_backward(const float *volume, int dx, int dy, int dz, const float *source,

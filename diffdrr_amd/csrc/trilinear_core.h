@@ -84,6 +84,59 @@ DDRR_HD float trilinear_forward_ray(const float *__restrict__ vol, const Dims D,
     return acc * q.step;  // caller multiplies by the ray length
 }
 
+// mask_to_channels for the marcher (renderers.py:242-252): every sample's value goes to
+// the channel of the label found by a NEAREST lookup of the mask at the sample point
+// (0 outside the volume).  The ray owns its output column: a run of samples with one
+// label is summed in a register and handed to `flush(label, sum)` when the label changes.
+template <class Flush>
+DDRR_HD void trilinear_channels_ray(const float *__restrict__ vol,
+                                    const unsigned char *__restrict__ labels, const Dims D,
+                                    const float s[3], const float t[3], float shift, float eps,
+                                    int P, float amin, float amax, bool align_corners,
+                                    Flush flush) {
+    const GridMap g = make_gridmap(D, shift, align_corners);
+    const MarchSetup q = march_setup(D, g, s, t, eps, P, amin, amax);
+    int cur = -1;
+    float run = 0.f;
+    for (int m = q.m_lo; m <= q.m_hi; ++m) {
+        const float al = fmaf(lin01(m, P, q.lstep), q.span, amin);
+        const float gx = fmaf(fmaf(al, q.d[0], s[0]), g.k[0], g.o[0]);
+        const float gy = fmaf(fmaf(al, q.d[1], s[1]), g.k[1], g.o[1]);
+        const float gz = fmaf(fmaf(al, q.d[2], s[2]), g.k[2], g.o[2]);
+        const float v = fetch_trilinear(vol, D, gx, gy, gz, nullptr, false);
+        // The label lookup is discontinuous, and the first sample of the ray that sets the
+        // batch-global alphamin sits exactly ON the volume's face (g = -1/2): which side it
+        // falls on is decided by the reference's fp32 round trip through normalised
+        // coordinates (renderers.py:152, then aten's un-normalisation), so that is restated
+        // here for the label (the interpolated value is continuous and does not need it).
+        // alphas = linspace * (alphamax - alphamin) + alphamin; x = s + alpha * d; each
+        // operation rounded on its own, as the reference's tensor ops are
+        const float al_ref = add_rn(mul_rn(lin01(m, P, q.lstep), q.span), amin);
+        const float Dn[3] = {(float)D.x, (float)D.y, (float)D.z};
+        float rr[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float x = add_rn(s[a], mul_rn(al_ref, q.d[a]));
+            const float nrm = add_rn(mul_rn(2.f, add_rn(x, shift)) / Dn[a], -1.f);
+            const float un = align_corners
+                                 ? mul_rn(add_rn(nrm, 1.f) / 2.f, Dn[a] - 1.f)
+                                 : add_rn(mul_rn(add_rn(nrm, 1.f), Dn[a]), -1.f) / 2.f;
+            rr[a] = rintf(un);  // half-to-even == nearbyint
+        }
+        const float rx = rr[0], ry = rr[1], rz = rr[2];
+        const bool in = rx >= 0.f && rx < (float)D.x && ry >= 0.f && ry < (float)D.y &&
+                        rz >= 0.f && rz < (float)D.z;
+        const int lab = in ? (int)labels[((int)rx * D.y + (int)ry) * D.z + (int)rz] : 0;
+        if (lab != cur) {
+            if (cur >= 0) flush(cur, run * q.step);
+            cur = lab;
+            run = 0.f;
+        }
+        run += v;
+    }
+    if (cur >= 0) flush(cur, run * q.step);
+}
+
 // Scatter k * w_c into the 8 corners of a sample (volume gradient).
 template <class Add>
 DDRR_HD void scatter_trilinear(const Dims D, float gx, float gy, float gz, float k, Add add) {

@@ -338,6 +338,28 @@ def trilinear_forward(volume, source, target, img, alphamin, alphamax, *, n_poin
     return out
 
 
+def trilinear_forward_channels(volume, labels_u8, n_channels, source, target, img, alphamin,
+                               alphamax, *, n_points=500, voxel_shift=0.5, eps=1e-8,
+                               align_corners=False, det=None, tile=None):
+    """Trilinear.forward with a mask (renderers.py:242-252).  -> (B, C, N)"""
+    B, N = _check_rays(volume, source, target, img)
+    if labels_u8.dtype != torch.uint8 or labels_u8.shape != volume.shape:
+        raise ValueError("labels must be a uint8 tensor of the volume's shape")
+    out = torch.empty(B, n_channels, N, dtype=torch.float32, device=volume.device)
+    dh, dw, th, tw = _hints(det, tile, N)
+    if _empty(B, N):
+        return out
+    labels_u8, volume = labels_u8.contiguous(), volume.contiguous()
+    source, target = source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    _launch(
+        "ddrr_trilinear_forward_channels", volume.device, volume.data_ptr(), labels_u8.data_ptr(),
+        *volume.shape, source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img), B, N,
+        int(n_channels), float(voxel_shift), float(eps), int(n_points), alphamin.data_ptr(),
+        alphamax.data_ptr(), int(bool(align_corners)), dh, dw, th, tw, out.data_ptr())
+    return out
+
+
 def trilinear_forward_bricks(volume, source, target, img, alphamin, alphamax, det, *,
                              n_points=500, voxel_shift=0.5, eps=1e-8):
     """Detector-grid trilinear march (bilinear, sum, align_corners=False) through the

@@ -352,9 +352,6 @@ class Trilinear(torch.nn.Module):
                 alphamin=None, alphamax=None):
         B, N, _ = target.shape
         ops.reduce_code(self.reducefn)
-        if mask is not None:
-            raise NotImplementedError(
-                "mask_to_channels is implemented for the Siddon renderer only (round 1)")
         if alphamin is None or alphamax is None:
             # the reference's batch-global marching range (renderers.py:220-223)
             lo, hi = get_alpha_minmax(source, target, self.dims(volume), self.voxel_shift,
@@ -362,6 +359,21 @@ class Trilinear(torch.nn.Module):
             alphamin, alphamax = lo.min(), hi.max()
         alphamin = torch.as_tensor(alphamin, dtype=volume.dtype, device=volume.device)
         alphamax = torch.as_tensor(alphamax, dtype=volume.dtype, device=volume.device)
+        if mask is not None:
+            # mask_to_channels (renderers.py:242-252); forward only, like the Siddon branch
+            if self.mode != "bilinear" or self.reducefn != "sum":
+                raise NotImplementedError(
+                    "mask_to_channels needs mode='bilinear' and reducefn='sum'")
+            if any(t.requires_grad for t in (volume, source, target, img)) and \
+                    torch.is_grad_enabled():
+                raise NotImplementedError("mask_to_channels rendering is forward-only here; wrap "
+                                          "the call in torch.no_grad()")
+            labels, C = _labels_u8(mask)
+            return ops.trilinear_forward_channels(
+                volume, labels, C, source, target, img.reshape(B, N), alphamin.reshape(1),
+                alphamax.reshape(1), n_points=int(n_points), voxel_shift=self.voxel_shift,
+                eps=self.eps, align_corners=bool(align_corners), det=self.detector_shape,
+                tile=self.tile)
         cfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift, "eps": self.eps,
                "reducefn": self.reducefn, "mode": self.mode,
                "align_corners": bool(align_corners), "det": self.detector_shape,

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 5
+#define DDRR_ABI_VERSION 6
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -152,6 +152,17 @@ int ddrr_trilinear_forward(const float *volume, int dx, int dy, int dz, const fl
                            const float *alphamax, int mode_nearest, int reduce_mode,
                            int align_corners, int det_h, int det_w, int tile_h, int tile_w,
                            float *out, void *stream);
+
+/* Trilinear.forward with a mask (mask_to_channels, renderers.py:242-252): every sample goes
+ * to the channel of the mask label found by a nearest lookup at the sample point; labels is
+ * the (dx, dy, dz) uint8 label map, out is (B, C, N) and is fully written. */
+int ddrr_trilinear_forward_channels(const float *volume, const unsigned char *labels, int dx,
+                                    int dy, int dz, const float *source, int src_n,
+                                    const float *target, const float *img, int B, int N, int C,
+                                    float voxel_shift, float eps, int n_points,
+                                    const float *alphamin, const float *alphamax,
+                                    int align_corners, int det_h, int det_w, int tile_h,
+                                    int tile_w, float *out, void *stream);
 
 /* Volume-stationary forms of the marcher for the DRR case (one source per pose, det_h x
  * det_w target grid, mode "bilinear", reducefn "sum", align_corners = 0): bricks of 31^3 base

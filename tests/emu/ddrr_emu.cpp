@@ -595,6 +595,27 @@ int ddrr_siddon_forward_channels(const float *volume, const unsigned char *label
     return 0;
 }
 
+int ddrr_trilinear_forward_channels(const float *volume, const unsigned char *labels, int dx,
+                                    int dy, int dz, const float *source, int src_n,
+                                    const float *target, const float *img, int B, int N, int C,
+                                    float voxel_shift, float eps, int n_points,
+                                    const float *alphamin, const float *alphamax,
+                                    int align_corners, int det_h, int det_w, int tile_h,
+                                    int tile_w, float *out, void *) {
+    const Dims D{dx, dy, dz};
+    memset(out, 0, sizeof(float) * (size_t)B * C * N);
+    for_each_ray(source, src_n, target, img, B, N, det_h, det_w, tile_h, tile_w,
+                 [&](int b, int n, long, const Ray &ray) {
+                     float *col = out + (long)b * C * N + n;
+                     trilinear_channels_ray(volume, labels, D, ray.s, ray.t, voxel_shift, eps,
+                                            n_points, *alphamin, *alphamax, align_corners != 0,
+                                            [&](int label, float run) {
+                                                if (label < C) col[(long)label * N] += ray.L * run;
+                                            });
+                 });
+    return 0;
+}
+
 int ddrr_trilinear_forward(const float *volume, int dx, int dy, int dz, const float *source,
                            int src_n, const float *target, const float *img, int B, int N,
                            float voxel_shift, float eps, int n_points, const float *alphamin,

@@ -406,3 +406,22 @@ def test_trilinear_bricks_equal_per_ray_march(emulated_ops):
         res[bricks] = (o.detach(), Vg.grad, sg.grad, tg.grad)
     for x, y in zip(res[True], res[False]):
         assert rel_err(x.numpy(), y.numpy()) < 1e-5
+
+
+def test_trilinear_channels(emu_lib):
+    """Trilinear mask_to_channels (renderers.py:242-252) against the reference fixture."""
+    g, vol, src, tgt, img, B, N = load("trilinear_mask")
+    labels = np.ascontiguousarray(g["mask"].astype(np.uint8))
+    C = int(labels.max()) + 1
+    lo, hi = oracle.alpha_minmax(src, tgt, vol.shape)
+    am, aM = np.array([lo.min()], np.float32), np.array([hi.max()], np.float32)
+    out = np.full((B, C, N), np.nan, np.float32)
+    emu_lib.call("ddrr_trilinear_forward_channels", P(vol), P(labels), *vol.shape, P(src),
+                 src.shape[1], P(tgt), P(img), B, N, C, 0.5, 1e-8, 40, P(am), P(aM), 0, 0, 0, 1, 64,
+                 P(out), None)
+    assert out.shape == g["out_f32"].shape
+    assert rel_err(out, g["out_f32"]) < FWD_TOL
+    plain = np.zeros((B, N), np.float32)
+    emu_lib.call("ddrr_trilinear_forward", P(vol), *vol.shape, P(src), src.shape[1], P(tgt),
+                 P(img), B, N, 0.5, 1e-8, 40, P(am), P(aM), 0, 0, 0, 0, 0, 1, 64, P(plain), None)
+    assert rel_err(out.sum(1), plain) < 1e-5  # channels add up to the DRR

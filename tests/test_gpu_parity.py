@@ -660,3 +660,24 @@ def test_brick_kernels_many_poses_multi_chunk(gpu):
     gref = ops.siddon_backward_volume(V, s, t, L, go)
     gout = ops.siddon_backward_volume_bricks(V.shape, s, t, L, go, (H, W))
     assert rel_err(gout.cpu().numpy(), gref.cpu().numpy()) < 2e-5
+
+
+def test_trilinear_mask_golden(gpu):
+    """Trilinear mask_to_channels (renderers.py:242-252) against the reference fixture."""
+    g = golden("trilinear_mask")
+    vol, src, tgt, img = dev_inputs(g, gpu)
+    mask = torch.from_numpy(g["mask"]).to(gpu)
+    # The first sample of the ray that sets the batch-global alphamin lies exactly on the
+    # volume's face, where the label lookup is discontinuous: the fixture pins the
+    # reference's CPU evaluation of the range, so the range is evaluated on the CPU here
+    # (on the GPU torch's division may differ in the last bit, as it would for the
+    # reference itself).
+    from diffdrr_amd.renderers import get_alpha_minmax
+
+    lo, hi = get_alpha_minmax(src.cpu(), tgt.cpu(), torch.tensor(vol.shape), 0.5, 1e-8)
+    rng = {"alphamin": lo.min().to(gpu), "alphamax": hi.max().to(gpu)}
+    out = Trilinear()(vol, src, tgt, img, n_points=40, mask=mask, **rng)
+    assert out.shape == g["out_f32"].shape
+    assert rel_err(out.cpu().numpy(), g["out_f32"]) < FWD_TOL
+    plain = Trilinear()(vol, src, tgt, img, n_points=40, **rng)
+    assert rel_err(out.sum(1, keepdim=True).cpu().numpy(), plain.cpu().numpy()) < 1e-5
