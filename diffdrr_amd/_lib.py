@@ -11,11 +11,11 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_float, c_int, c_void_p
+from ctypes import c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffdrr_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 REDUCE_SUM, REDUCE_MAX = 0, 1
 LOOKUP_STEP, LOOKUP_MID_NEAREST, LOOKUP_MID_TRILINEAR = 0, 1, 2
@@ -23,7 +23,7 @@ SIDDON_AUX = 8
 AUX_INTERLEAVED, AUX_PLANAR = 0, 1
 BRICK_AUX_PLANES = 5
 
-_P, _I, _F = c_void_p, c_int, c_float
+_P, _I, _F, _L = c_void_p, c_int, c_float, c_long
 
 # name -> argtypes, in the order of include/diffdrr_hip.h
 _SIGNATURES = {
@@ -48,6 +48,8 @@ _SIGNATURES = {
                                       _P, _P],
     "ddrr_trilinear_backward_volume_bricks": [_I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I,
                                               _P, _P, _P, _P],
+    "ddrr_ncc_forward": [_P, _L, _P, _I, _I, _F, _P, _P, _P],
+    "ddrr_ncc_backward": [_P, _L, _P, _P, _P, _I, _I, _P, _P, _P],
     "ddrr_raygen_forward": [_P, _P, _P, _I, _I, _P, _P, _P, _P],
     "ddrr_siddon_backward_pose": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P, _P],
 }

@@ -876,6 +876,76 @@ __global__ __launch_bounds__(kBlock) void siddon_bwd_pose_kernel(
     }
 }
 
+// ------------------------------------------------- fused NCC (sweep / registration)
+// NormalizedCrossCorrelation2d with patch_size = None (reference metrics.py:21-44):
+// ncc_b = mean(z1 * z2), z = (x - mean) / sqrt(var + eps), one value per image pair.
+// One workgroup per pair, two passes over the pair (means, then centred moments: no
+// cancellation); stats[b] = {mu1, s1, mu2, s2, ncc}.  x1 may be one image shared by the
+// whole batch (x1_stride = 0).
+constexpr int kNccThreads = 1024;
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();  // red may still be read by the previous call
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < kNccThreads / 64; ++w) t += red[w];
+    return t;
+}
+
+__global__ __launch_bounds__(kNccThreads) void ncc_fwd_kernel(
+    const float *__restrict__ x1, long x1_stride, const float *__restrict__ x2, int N, float eps,
+    float *__restrict__ out, float *__restrict__ stats) {
+    __shared__ float red[kNccThreads / 64];
+    const int b = blockIdx.x;
+    const float *p1 = x1 + b * x1_stride, *p2 = x2 + (long)b * N;
+    float a1 = 0.f, a2 = 0.f;
+    for (int n = threadIdx.x; n < N; n += kNccThreads) {
+        a1 += p1[n];
+        a2 += p2[n];
+    }
+    const float inv_n = 1.0f / (float)N;
+    const float mu1 = block_sum(a1, red) * inv_n, mu2 = block_sum(a2, red) * inv_n;
+    float v1 = 0.f, v2 = 0.f, c12 = 0.f;
+    for (int n = threadIdx.x; n < N; n += kNccThreads) {
+        const float d1 = p1[n] - mu1, d2 = p2[n] - mu2;
+        v1 = fmaf(d1, d1, v1);
+        v2 = fmaf(d2, d2, v2);
+        c12 = fmaf(d1, d2, c12);
+    }
+    const float s1 = sqrtf(block_sum(v1, red) * inv_n + eps);
+    const float s2 = sqrtf(block_sum(v2, red) * inv_n + eps);
+    const float ncc = block_sum(c12, red) * inv_n / (s1 * s2);
+    if (threadIdx.x == 0) {
+        out[b] = ncc;
+        stats[b * 5 + 0] = mu1;
+        stats[b * 5 + 1] = s1;
+        stats[b * 5 + 2] = mu2;
+        stats[b * 5 + 3] = s2;
+        stats[b * 5 + 4] = ncc;
+    }
+}
+
+// d ncc / d x2[n] = (z1[n] - z2[n] ncc) / (N s2), and symmetrically for x1 (per pair; a
+// shared x1 gets no gradient from this kernel).
+__global__ __launch_bounds__(kBlock) void ncc_bwd_kernel(
+    const float *__restrict__ x1, long x1_stride, const float *__restrict__ x2,
+    const float *__restrict__ stats, const float *__restrict__ g_out, int N,
+    float *__restrict__ g_x1, float *__restrict__ g_x2) {
+    const int b = blockIdx.y, n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const float mu1 = stats[b * 5], s1 = stats[b * 5 + 1], mu2 = stats[b * 5 + 2];
+    const float s2 = stats[b * 5 + 3], ncc = stats[b * 5 + 4];
+    const float z1 = (x1[b * x1_stride + n] - mu1) / s1, z2 = (x2[(long)b * N + n] - mu2) / s2;
+    const float g = g_out[b] / (float)N;
+    if (g_x2) g_x2[(long)b * N + n] = g * (z1 - z2 * ncc) / s2;
+    if (g_x1) g_x1[(long)b * N + n] = g * (z2 - z1 * ncc) / s1;
+}
+
 // --------------------------------------------------------------- Trilinear
 
 template <int REDUCE, bool NEAREST>
@@ -1486,6 +1556,27 @@ int ddrr_siddon_backward_pose(const float *aux, int aux_layout, const float *gra
     hipLaunchKernelGGL(siddon_bwd_pose_kernel, grid, block, 0, st, aux, aux_layout, grad_out,
                        source_v, target_v, img, Mw, Ainv, P, B, N, eps, with_img_path, gMw);
     return finish("ddrr_siddon_backward_pose");
+}
+
+int ddrr_ncc_forward(const float *x1, long x1_stride, const float *x2, int B, int N, float eps,
+                     float *out, float *stats, void *stream) {
+    if (!x1 || !x2 || !out || !stats) return fail(-1, "null pointer");
+    if (B < 0 || N < 1) return fail(-1, "bad batch / image size");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(ncc_fwd_kernel, dim3(B), dim3(kNccThreads), 0, (hipStream_t)stream, x1,
+                       x1_stride, x2, N, eps, out, stats);
+    return finish("ddrr_ncc_forward");
+}
+
+int ddrr_ncc_backward(const float *x1, long x1_stride, const float *x2, const float *stats,
+                      const float *g_out, int B, int N, float *g_x1, float *g_x2, void *stream) {
+    if (!x1 || !x2 || !stats || !g_out) return fail(-1, "null pointer");
+    if (g_x1 && x1_stride == 0) return fail(-1, "a shared x1 gets no gradient here");
+    if (B < 0 || N < 1) return fail(-1, "bad batch / image size");
+    if (B == 0 || B > 65535) return B == 0 ? 0 : fail(-1, "at most 65535 pairs per call");
+    hipLaunchKernelGGL(ncc_bwd_kernel, dim3((N + kBlock - 1) / kBlock, B), dim3(kBlock), 0,
+                       (hipStream_t)stream, x1, x1_stride, x2, stats, g_out, N, g_x1, g_x2);
+    return finish("ddrr_ncc_backward");
 }
 
 }  // extern "C"

@@ -8,6 +8,32 @@ from __future__ import annotations
 
 import torch
 
+from . import ops
+
+
+class _NCCFn(torch.autograd.Function):
+    """Whole-image NCC of single-channel image pairs as one kernel each way
+    (ddrr_ncc_forward / ddrr_ncc_backward).  x1 (B or 1, N), x2 (B, N) -> (B,)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, eps):
+        out, stats = ops.ncc_forward(x1, x2, eps)
+        ctx.save_for_backward(x1, x2, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, x2, stats = ctx.saved_tensors
+        need1, need2 = ctx.needs_input_grad[:2]
+        shared = x1.shape[0] == 1 and x2.shape[0] != 1
+        if need1 and shared:
+            # a fixed image shared by the batch: its gradient is a sum over the batch;
+            # rare (the fixed image is data), so take the general route
+            g1, g2 = ops.ncc_backward(x1.expand_as(x2).contiguous(), x2, stats, g, True, need2)
+            return g1.sum(0, keepdim=True), g2, None
+        g1, g2 = ops.ncc_backward(x1, x2, stats, g, need1, need2)
+        return g1, g2, None
+
 
 def to_patches(x, patch_size):
     """Every ``patch_size`` x ``patch_size`` window (stride 1) becomes one channel
@@ -32,6 +58,14 @@ class NormalizedCrossCorrelation2d(torch.nn.Module):
             x2 = to_patches(x2, self.patch_size)
         assert x1.shape == x2.shape, "Input images must be the same size"
         _, c, h, w = x1.shape
+        if (self.patch_size is None and c == 1 and ops.on_device(x2) and x1.device == x2.device
+                and x1.dtype == x2.dtype == torch.float32):
+            # one fused kernel per direction; an `expand`ed fixed image is read once per pose
+            # from the same memory instead of being materialised
+            b = x2.shape[0]
+            shared = b > 1 and x1.stride(0) == 0
+            a = (x1[:1] if shared else x1).reshape(1 if shared else b, h * w)
+            return _NCCFn.apply(a, x2.reshape(b, h * w), self.eps)
         score = (self.norm(x1) * self.norm(x2)).flatten(1).sum(1)
         return score / (c * h * w)
 

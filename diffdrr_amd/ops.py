@@ -218,6 +218,32 @@ def siddon_backward_rays(aux, grad_out, source, target, img, *, eps=1e-8, reduce
     return g_source, g_target, g_img
 
 
+def ncc_forward(x1, x2, eps):
+    """x2 (B,N); x1 (B,N) or (1,N) shared by the batch.  -> (ncc (B), stats (B,5))"""
+    _require_gpu(x2)
+    B, N = x2.shape
+    shared = x1.shape[0] == 1 and B != 1
+    x1, x2 = x1.contiguous(), x2.contiguous()
+    out = torch.empty(B, dtype=torch.float32, device=x2.device)
+    stats = torch.empty(B, 5, dtype=torch.float32, device=x2.device)
+    if B:
+        _launch("ddrr_ncc_forward", x2.device, x1.data_ptr(), 0 if shared else N, x2.data_ptr(), B,
+                N, float(eps), out.data_ptr(), stats.data_ptr())
+    return out, stats
+
+
+def ncc_backward(x1, x2, stats, g_out, want_x1, want_x2):
+    B, N = x2.shape
+    shared = x1.shape[0] == 1 and B != 1
+    x1, x2, g_out = x1.contiguous(), x2.contiguous(), g_out.contiguous()
+    g_x2 = torch.empty_like(x2) if want_x2 else None
+    g_x1 = torch.empty_like(x2) if (want_x1 and not shared) else None
+    if B:
+        _launch("ddrr_ncc_backward", x2.device, x1.data_ptr(), 0 if shared else N, x2.data_ptr(),
+                stats.data_ptr(), g_out.data_ptr(), B, N, _ptr(g_x1), _ptr(g_x2))
+    return g_x1, g_x2
+
+
 def raygen_forward(Mw, Ainv, P):
     """Fused ray generation (detector.py:151-153 + drr.py:201-205).  Mw (B,3,4) world pose
     per DRR, Ainv (3,4) world -> voxel, P (N,3) calibrated detector points.

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 6
+#define DDRR_ABI_VERSION 7
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -216,6 +216,18 @@ int ddrr_siddon_backward_pose(const float *aux, int aux_layout, const float *gra
                               const float *source_v, const float *target_v, const float *img,
                               const float *Mw, const float *Ainv, const float *P, int B, int N,
                               float eps, int with_img_path, float *gMw, void *stream);
+
+/* NormalizedCrossCorrelation2d, patch_size = None (reference metrics.py:21-44) for image
+ * pairs of N pixels: out (B) = mean(z1 z2), z = (x - mean) / sqrt(var + eps).  x2 (B, N);
+ * x1 (B, N) with x1_stride = N, or ONE image shared by the batch with x1_stride = 0 (the
+ * fixed image of a registration / sweep).  stats (B, 5) = {mu1, s1, mu2, s2, ncc} for the
+ * backward.  One kernel instead of ~10 reductions / elementwise passes. */
+int ddrr_ncc_forward(const float *x1, long x1_stride, const float *x2, int B, int N, float eps,
+                     float *out, float *stats, void *stream);
+
+/* Gradient of ddrr_ncc_forward w.r.t. x2 (and x1 unless shared); either may be NULL. */
+int ddrr_ncc_backward(const float *x1, long x1_stride, const float *x2, const float *stats,
+                      const float *g_out, int B, int N, float *g_x1, float *g_x2, void *stream);
 
 #ifdef __cplusplus
 }

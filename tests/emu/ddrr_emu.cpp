@@ -742,4 +742,40 @@ int ddrr_siddon_backward_pose(const float *aux, int aux_layout, const float *gra
     return 0;
 }
 
+int ddrr_ncc_forward(const float *x1, long x1_stride, const float *x2, int B, int N, float eps,
+                     float *out, float *stats, void *) {
+    for (int b = 0; b < B; ++b) {
+        const float *p1 = x1 + b * x1_stride, *p2 = x2 + (long)b * N;
+        double a1 = 0, a2 = 0;
+        for (int n = 0; n < N; ++n) a1 += p1[n], a2 += p2[n];
+        const float mu1 = (float)(a1 / N), mu2 = (float)(a2 / N);
+        double v1 = 0, v2 = 0, c12 = 0;
+        for (int n = 0; n < N; ++n) {
+            const double d1 = p1[n] - mu1, d2 = p2[n] - mu2;
+            v1 += d1 * d1, v2 += d2 * d2, c12 += d1 * d2;
+        }
+        const float s1 = sqrtf((float)(v1 / N) + eps), s2 = sqrtf((float)(v2 / N) + eps);
+        const float ncc = (float)(c12 / N) / (s1 * s2);
+        out[b] = ncc;
+        const float st[5] = {mu1, s1, mu2, s2, ncc};
+        memcpy(stats + b * 5, st, sizeof(st));
+    }
+    return 0;
+}
+
+int ddrr_ncc_backward(const float *x1, long x1_stride, const float *x2, const float *stats,
+                      const float *g_out, int B, int N, float *g_x1, float *g_x2, void *) {
+    for (int b = 0; b < B; ++b) {
+        const float *st = stats + b * 5;
+        const float g = g_out[b] / (float)N;
+        for (int n = 0; n < N; ++n) {
+            const float z1 = (x1[b * x1_stride + n] - st[0]) / st[1];
+            const float z2 = (x2[(long)b * N + n] - st[2]) / st[3];
+            if (g_x2) g_x2[(long)b * N + n] = g * (z1 - z2 * st[4]) / st[3];
+            if (g_x1) g_x1[(long)b * N + n] = g * (z2 - z1 * st[4]) / st[1];
+        }
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -681,3 +681,26 @@ def test_trilinear_mask_golden(gpu):
     assert rel_err(out.cpu().numpy(), g["out_f32"]) < FWD_TOL
     plain = Trilinear()(vol, src, tgt, img, n_points=40, **rng)
     assert rel_err(out.sum(1, keepdim=True).cpu().numpy(), plain.cpu().numpy()) < 1e-5
+
+
+def test_fused_ncc_kernels(gpu):
+    """ddrr_ncc_forward / _backward (reference metrics.py:21-44) on the GPU against the
+    PyTorch formula, on DRR-like images (large mean): values and gradients."""
+    from diffdrr_amd import NormalizedCrossCorrelation2d
+
+    g = torch.Generator().manual_seed(0)
+    ncc = NormalizedCrossCorrelation2d()
+    fixed = (350 + 60 * torch.rand(1, 1, 256, 256, generator=g)).to(gpu)
+    x2 = (330 + 80 * torch.rand(6, 1, 256, 256, generator=g)).to(gpu)
+    w = torch.rand(6, generator=g).to(gpu)
+
+    def formula(a, b):
+        return ((ncc.norm(a) * ncc.norm(b)).flatten(1).sum(1)) / (256 * 256)
+
+    b1, b2 = x2.clone().requires_grad_(), x2.clone().requires_grad_()
+    fused = ncc(fixed.expand(6, -1, -1, -1), b1)
+    ref = formula(fixed.expand(6, -1, -1, -1).double(), b2.double())
+    assert torch.allclose(fused.double(), ref, atol=5e-6)
+    (fused * w).sum().backward()
+    (ref * w.double()).sum().backward()
+    assert rel_err(b1.grad.cpu().numpy(), b2.grad.cpu().numpy()) < 1e-4

@@ -282,3 +282,36 @@ def test_fused_entry_is_skipped_when_a_general_feature_is_asked_for(emulated_ops
     drr3 = DRR(synthetic_subject(24, kind="phantom", seed=0), sdd=300.0, height=12, delx=2.0,
                patch_size=6)
     assert not drr3._fused_ok(False, {})
+
+
+def test_fused_ncc_equals_pytorch_formula(emulated_ops):
+    """The fused NCC kernels (ddrr_ncc_forward / _backward, reference metrics.py:21-44)
+    against the module's PyTorch formula: values and gradients, paired and with a fixed
+    image shared by the batch (expand)."""
+    from diffdrr_amd import NormalizedCrossCorrelation2d
+
+    g = torch.Generator().manual_seed(0)
+    ncc = NormalizedCrossCorrelation2d()
+    x1 = 300 + 40 * torch.rand(5, 1, 18, 22, generator=g)
+    x2 = 280 + 55 * torch.rand(5, 1, 18, 22, generator=g)
+    w = torch.rand(5, generator=g)
+
+    def formula(a, b):
+        return ((ncc.norm(a) * ncc.norm(b)).flatten(1).sum(1)) / (18 * 22)
+
+    for shared in (False, True):
+        a_in = (x1[:1].expand(5, -1, -1, -1) if shared else x1)
+        a1, b1 = a_in.clone().requires_grad_(), x2.clone().requires_grad_()
+        a2, b2 = a_in.clone().requires_grad_(), x2.clone().requires_grad_()
+        fused = ncc(a1.expand_as(b1) if False else a1, b1)
+        ref = formula(a2, b2)
+        assert torch.allclose(fused, ref, atol=2e-6)
+        (fused * w).sum().backward()
+        (ref * w).sum().backward()
+        assert rel_err(b1.grad.numpy(), b2.grad.numpy()) < 1e-4
+        assert rel_err(a1.grad.numpy(), a2.grad.numpy()) < 1e-4
+    # the stride-0 fixed image (what Registration / sweeps pass) takes the shared route
+    fixed = x1[:1]
+    b3 = x2.clone().requires_grad_()
+    v = ncc(fixed.expand(5, -1, -1, -1), b3)
+    assert torch.allclose(v, formula(fixed.expand(5, -1, -1, -1), x2), atol=2e-6)
