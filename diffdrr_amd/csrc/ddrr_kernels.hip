@@ -876,6 +876,41 @@ __global__ __launch_bounds__(kBlock) void siddon_bwd_pose_kernel(
     }
 }
 
+// -------------------------------------------------- Euler pose -> world matrix
+__global__ __launch_bounds__(kBlock) void pose_euler_fwd_kernel(
+    const float *__restrict__ rot, const float *__restrict__ xyz, int a0, int a1, int a2,
+    const float *__restrict__ Ro, int B, float *__restrict__ Mw) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= B) return;
+    const float th[3] = {rot[b * 3], rot[b * 3 + 1], rot[b * 3 + 2]};
+    const float t[3] = {xyz[b * 3], xyz[b * 3 + 1], xyz[b * 3 + 2]};
+    const int axes[3] = {a0, a1, a2};
+    float M[12];
+    pose_euler_forward(th, t, axes, Ro, M);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Mw[b * 12 + k] = M[k];
+}
+
+__global__ __launch_bounds__(kBlock) void pose_euler_bwd_kernel(
+    const float *__restrict__ rot, const float *__restrict__ xyz, int a0, int a1, int a2,
+    const float *__restrict__ Ro, const float *__restrict__ gMw, int B, float *__restrict__ g_rot,
+    float *__restrict__ g_xyz) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= B) return;
+    const float th[3] = {rot[b * 3], rot[b * 3 + 1], rot[b * 3 + 2]};
+    const float t[3] = {xyz[b * 3], xyz[b * 3 + 1], xyz[b * 3 + 2]};
+    const int axes[3] = {a0, a1, a2};
+    float g[12], gt[3], gx[3];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) g[k] = gMw[b * 12 + k];
+    pose_euler_backward(th, t, axes, Ro, g, gt, gx);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        g_rot[b * 3 + k] = gt[k];
+        g_xyz[b * 3 + k] = gx[k];
+    }
+}
+
 // ------------------------------------------------- fused NCC (sweep / registration)
 // NormalizedCrossCorrelation2d with patch_size = None (reference metrics.py:21-44):
 // ncc_b = mean(z1 * z2), z = (x - mean) / sqrt(var + eps), one value per image pair.
@@ -1577,6 +1612,29 @@ int ddrr_ncc_backward(const float *x1, long x1_stride, const float *x2, const fl
     hipLaunchKernelGGL(ncc_bwd_kernel, dim3((N + kBlock - 1) / kBlock, B), dim3(kBlock), 0,
                        (hipStream_t)stream, x1, x1_stride, x2, stats, g_out, N, g_x1, g_x2);
     return finish("ddrr_ncc_backward");
+}
+
+int ddrr_pose_euler_forward(const float *rot, const float *xyz, int a0, int a1, int a2,
+                            const float *reorient34, int B, float *Mw, void *stream) {
+    if (!rot || !xyz || !reorient34 || !Mw) return fail(-1, "null pointer");
+    if (a0 < 0 || a0 > 2 || a1 < 0 || a1 > 2 || a2 < 0 || a2 > 2 || a1 == a0 || a1 == a2)
+        return fail(-1, "invalid Euler convention");
+    if (B <= 0) return B == 0 ? 0 : fail(-1, "negative batch");
+    hipLaunchKernelGGL(pose_euler_fwd_kernel, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                       (hipStream_t)stream, rot, xyz, a0, a1, a2, reorient34, B, Mw);
+    return finish("ddrr_pose_euler_forward");
+}
+
+int ddrr_pose_euler_backward(const float *rot, const float *xyz, int a0, int a1, int a2,
+                             const float *reorient34, const float *gMw, int B, float *g_rot,
+                             float *g_xyz, void *stream) {
+    if (!rot || !xyz || !reorient34 || !gMw || !g_rot || !g_xyz) return fail(-1, "null pointer");
+    if (a0 < 0 || a0 > 2 || a1 < 0 || a1 > 2 || a2 < 0 || a2 > 2 || a1 == a0 || a1 == a2)
+        return fail(-1, "invalid Euler convention");
+    if (B <= 0) return B == 0 ? 0 : fail(-1, "negative batch");
+    hipLaunchKernelGGL(pose_euler_bwd_kernel, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                       (hipStream_t)stream, rot, xyz, a0, a1, a2, reorient34, gMw, B, g_rot, g_xyz);
+    return finish("ddrr_pose_euler_backward");
 }
 
 }  // extern "C"

@@ -67,4 +67,101 @@ DDRR_HD void raygen_ray_adjoint(const float *Mw, const float *Ainv, const float 
     }
 }
 
+// ------------------------------------------------------------ Euler pose -> Mw
+// World pose of the C-arm from Euler angles + translation, in one step:
+//   R  = E(a0, th0) E(a1, th1) E(a2, th2)         pose.py:444-470 (euler_angles_to_matrix)
+//   M  = [R | R xyz]                               pose.py:155-157, 108-114 (convert)
+//   Mw = M @ reorient                              detector.py:151 (reorient.compose(pose))
+// and its adjoint.  axes[k] in {0: X, 1: Y, 2: Z}; Ro (3,4): top rows of the 4x4 reorient.
+
+// elementary rotation about `axis` by th, or its derivative w.r.t. th (row-major 3x3)
+DDRR_HD void elem_rot(int axis, float th, bool deriv, float E[9]) {
+    // Rotation about `axis` (0 X, 1 Y, 2 Z) or its derivative w.r.t. the angle.  With
+    // p = axis+1, q = axis+2 (mod 3): E[axis][axis] = 1, E[p][p] = E[q][q] = c, E[p][q] = -s,
+    // E[q][p] = s.  Written as selects on compile-time (i, j) so that E stays in registers.
+    const float c = cosf(th), s = sinf(th);
+    const float cc = deriv ? -s : c, ss = deriv ? c : s, one = deriv ? 0.f : 1.f;
+    const int p = axis == 2 ? 0 : axis + 1, q = axis == 0 ? 2 : axis - 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float v = 0.f;
+            if (i == j) v = (i == axis) ? one : cc;
+            else if (i == p && j == q) v = -ss;
+            else if (i == q && j == p) v = ss;
+            E[3 * i + j] = v;
+        }
+    }
+}
+
+DDRR_HD void mat3_mul(const float A[9], const float B[9], float C[9]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            C[3 * i + j] = fmaf(A[3 * i + 2], B[6 + j], fmaf(A[3 * i + 1], B[3 + j], A[3 * i] * B[j]));
+}
+
+DDRR_HD void pose_euler_forward(const float th[3], const float xyz[3], const int axes[3],
+                                const float *Ro, float Mw[12]) {
+    float E0[9], E1[9], E2[9], T[9], R[9];
+    elem_rot(axes[0], th[0], false, E0);
+    elem_rot(axes[1], th[1], false, E1);
+    elem_rot(axes[2], th[2], false, E2);
+    mat3_mul(E0, E1, T);
+    mat3_mul(T, E2, R);
+    const float v[3] = {Ro[3] + xyz[0], Ro[7] + xyz[1], Ro[11] + xyz[2]};  // to + xyz
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            Mw[4 * i + j] = fmaf(R[3 * i + 2], Ro[8 + j], fmaf(R[3 * i + 1], Ro[4 + j], R[3 * i] * Ro[j]));
+        Mw[4 * i + 3] = fmaf(R[3 * i + 2], v[2], fmaf(R[3 * i + 1], v[1], R[3 * i] * v[0]));
+    }
+}
+
+DDRR_HD void pose_euler_backward(const float th[3], const float xyz[3], const int axes[3],
+                                 const float *Ro, const float gMw[12], float g_th[3],
+                                 float g_xyz[3]) {
+    float E0[9], E1[9], E2[9], D0[9], D1[9], D2[9], T[9], R[9];
+    elem_rot(axes[0], th[0], false, E0);
+    elem_rot(axes[1], th[1], false, E1);
+    elem_rot(axes[2], th[2], false, E2);
+    elem_rot(axes[0], th[0], true, D0);
+    elem_rot(axes[1], th[1], true, D1);
+    elem_rot(axes[2], th[2], true, D2);
+    mat3_mul(E0, E1, T);
+    mat3_mul(T, E2, R);
+    const float v[3] = {Ro[3] + xyz[0], Ro[7] + xyz[1], Ro[11] + xyz[2]};
+    // dL/dR = gMw[:, :3] Ro3^T + gMw[:, 3] (x) (to + xyz);  dL/dxyz = R^T gMw[:, 3]
+    float GR[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            GR[3 * i + j] = fmaf(gMw[4 * i + 3], v[j],
+                                 fmaf(gMw[4 * i + 2], Ro[4 * j + 2],
+                                      fmaf(gMw[4 * i + 1], Ro[4 * j + 1], gMw[4 * i] * Ro[4 * j])));
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        g_xyz[j] = fmaf(R[6 + j], gMw[11], fmaf(R[3 + j], gMw[7], R[j] * gMw[3]));
+    // dL/dth_k = <dL/dR, dR/dth_k>
+    float A[9], Bm[9];
+    auto dot9 = [&](const float X[9]) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc = fmaf(GR[k], X[k], acc);
+        return acc;
+    };
+    mat3_mul(D0, E1, A);
+    mat3_mul(A, E2, Bm);
+    g_th[0] = dot9(Bm);
+    mat3_mul(E0, D1, A);
+    mat3_mul(A, E2, Bm);
+    g_th[1] = dot9(Bm);
+    mat3_mul(T, D2, Bm);
+    g_th[2] = dot9(Bm);
+}
+
 }  // namespace ddrr

@@ -17,7 +17,7 @@ from torch.utils.checkpoint import checkpoint
 
 from . import ops
 from .detector import Detector
-from .pose import RigidTransform, convert
+from .pose import RigidTransform, convert, euler_world_pose
 from .renderers import Siddon, Trilinear
 
 
@@ -109,12 +109,21 @@ class DRR(nn.Module):
                 calibration: RigidTransform = None, mask_to_channels: bool = False,
                 degrees: bool = False, **kwargs):
         """Render DRRs for a batch of poses (``RigidTransform`` or raw parameters)."""
+        fused = self._fused_ok(mask_to_channels, kwargs)
+        if (fused and parameterization == "euler_angles" and len(args) == 2
+                and all(torch.is_tensor(a) and a.dim() == 2 and a.shape[-1] == 3
+                        and a.dtype == torch.float32 and ops.on_device(a) for a in args)):
+            # pose parameters -> world matrix in one kernel (pose.py euler_world_pose)
+            Mw = euler_world_pose(args[0], args[1], convention, self.detector._reorient,
+                                  degrees=degrees)
+            return self.reshape_transform(self._render_fused_Mw(Mw, calibration),
+                                          batch_size=len(Mw))
         if parameterization is None:
             pose = args[0]
         else:
             pose = convert(*args, parameterization=parameterization, convention=convention,
                            degrees=degrees)
-        if self._fused_ok(mask_to_channels, kwargs):
+        if fused:
             return self.reshape_transform(self._render_fused(pose, calibration),
                                           batch_size=len(pose))
         source, target = self.detector(pose, calibration)
@@ -140,10 +149,13 @@ class DRR(nn.Module):
                 and min(self.detector.height, self.detector.width) >= 2)
 
     def _render_fused(self, pose, calibration):
+        Mw = (pose.matrix @ self.detector._reorient)[:, :3, :]   # reorient.compose(extrinsic)
+        return self._render_fused_Mw(Mw, calibration)
+
+    def _render_fused_Mw(self, Mw, calibration):
         det = self.detector
         cal = det.calibration if calibration is None else calibration
         P = cal(det.target)[0].detach()                      # (N,3) detector.py:147-150
-        Mw = (pose.matrix @ det._reorient)[:, :3, :]         # reorient.compose(extrinsic)
         Ainv = self._affine_inverse[0, :3, :] if self._affine_inverse.dim() == 3 \
             else self._affine_inverse[:3, :]
         self.renderer.detector_shape = (det.height, det.width)

@@ -218,6 +218,29 @@ def siddon_backward_rays(aux, grad_out, source, target, img, *, eps=1e-8, reduce
     return g_source, g_target, g_img
 
 
+def pose_euler_forward(rot, xyz, axes, reorient34):
+    """rot, xyz (B,3) radians / world units; axes: 3 ints in {0,1,2}; reorient34 (3,4).
+    -> Mw (B,3,4) = [R | R xyz] @ reorient"""
+    _require_gpu(rot)
+    B = rot.shape[0]
+    rot, xyz, reorient34 = rot.contiguous(), xyz.contiguous(), reorient34.contiguous()
+    Mw = torch.empty(B, 3, 4, dtype=torch.float32, device=rot.device)
+    if B:
+        _launch("ddrr_pose_euler_forward", rot.device, rot.data_ptr(), xyz.data_ptr(), *axes,
+                reorient34.data_ptr(), B, Mw.data_ptr())
+    return Mw
+
+
+def pose_euler_backward(rot, xyz, axes, reorient34, gMw):
+    B = rot.shape[0]
+    rot, xyz, reorient34, gMw = (t.contiguous() for t in (rot, xyz, reorient34, gMw))
+    g_rot, g_xyz = torch.empty_like(rot), torch.empty_like(xyz)
+    if B:
+        _launch("ddrr_pose_euler_backward", rot.device, rot.data_ptr(), xyz.data_ptr(), *axes,
+                reorient34.data_ptr(), gMw.data_ptr(), B, g_rot.data_ptr(), g_xyz.data_ptr())
+    return g_rot, g_xyz
+
+
 def ncc_forward(x1, x2, eps):
     """x2 (B,N); x1 (B,N) or (1,N) shared by the batch.  -> (ncc (B), stats (B,5))"""
     _require_gpu(x2)

@@ -128,6 +128,39 @@ class RigidTransform(torch.nn.Module):
         return se3_log_map(self.matrix)
 
 
+class _PoseEulerFn(torch.autograd.Function):
+    """Euler angles (radians) + translation -> world pose of the C-arm, (B,3,4) =
+    ([R | R xyz] @ reorient)[:, :3] as ONE kernel each way (ddrr_pose_euler_forward /
+    _backward) instead of the ~35 + ~70 small launches of `convert` + `compose` below:
+    with the renderer at ~0.3 ms per DRR those launches were most of a registration step."""
+
+    @staticmethod
+    def forward(ctx, rot, xyz, reorient34, axes):
+        from . import ops
+
+        ctx.axes = axes
+        ctx.save_for_backward(rot, xyz, reorient34)
+        return ops.pose_euler_forward(rot, xyz, axes, reorient34)
+
+    @staticmethod
+    def backward(ctx, gMw):
+        from . import ops
+
+        rot, xyz, reorient34 = ctx.saved_tensors
+        g_rot, g_xyz = ops.pose_euler_backward(rot, xyz, ctx.axes, reorient34, gMw)
+        return g_rot, g_xyz, None, None
+
+
+def euler_world_pose(rot, xyz, convention, reorient, degrees=False):
+    """``(reorient.compose(convert(rot, xyz, "euler_angles", convention))).matrix[:, :3]``
+    through the fused kernels (float32 tensors on the GPU)."""
+    _check_convention(convention)
+    if degrees:
+        rot = rot / 180 * math.pi
+    axes = tuple(_AXIS[c] for c in convention)
+    return _PoseEulerFn.apply(rot, xyz, reorient[:3, :].contiguous(), axes)
+
+
 def make_matrix(R: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
     assert len(R) == len(t)
     bottom = torch.zeros(len(R), 1, 4, dtype=R.dtype, device=R.device)

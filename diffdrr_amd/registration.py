@@ -20,7 +20,11 @@ class Registration(nn.Module):
         self.convention = convention
 
     def forward(self, **kwargs):
-        return self.drr(self.pose, **kwargs)
+        # (same result as the reference's `self.drr(self.pose, **kwargs)`; handing the raw
+        # parameters over lets DRR take its fused pose -> rays path for Euler angles)
+        return self.drr(self._rotation, self._translation,
+                        parameterization=self.parameterization, convention=self.convention,
+                        **kwargs)
 
     @property
     def pose(self):

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 7
+#define DDRR_ABI_VERSION 8
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -216,6 +216,18 @@ int ddrr_siddon_backward_pose(const float *aux, int aux_layout, const float *gra
                               const float *source_v, const float *target_v, const float *img,
                               const float *Mw, const float *Ainv, const float *P, int B, int N,
                               float eps, int with_img_path, float *gMw, void *stream);
+
+/* World pose of the C-arm per DRR from Euler angles (radians) + translation in one launch:
+ * Mw (B, 3, 4) = [R | R xyz] @ reorient, R = E(a0, rot0) E(a1, rot1) E(a2, rot2), axes a_k in
+ * {0: X, 1: Y, 2: Z} -- reference pose.py:444-470 (euler_angles_to_matrix), pose.py:155-157
+ * + 108-114 (convert / make_matrix) and detector.py:151 (reorient.compose(pose)), ~35 ATen
+ * launches there and ~70 in their backward.  reorient34: top 3 rows of the 4x4 reorient.
+ * _backward: g_rot (B, 3), g_xyz (B, 3) from gMw (B, 3, 4). */
+int ddrr_pose_euler_forward(const float *rot, const float *xyz, int a0, int a1, int a2,
+                            const float *reorient34, int B, float *Mw, void *stream);
+int ddrr_pose_euler_backward(const float *rot, const float *xyz, int a0, int a1, int a2,
+                             const float *reorient34, const float *gMw, int B, float *g_rot,
+                             float *g_xyz, void *stream);
 
 /* NormalizedCrossCorrelation2d, patch_size = None (reference metrics.py:21-44) for image
  * pairs of N pixels: out (B) = mean(z1 z2), z = (x - mean) / sqrt(var + eps).  x2 (B, N);

@@ -778,4 +778,22 @@ int ddrr_ncc_backward(const float *x1, long x1_stride, const float *x2, const fl
     return 0;
 }
 
+int ddrr_pose_euler_forward(const float *rot, const float *xyz, int a0, int a1, int a2,
+                            const float *reorient34, int B, float *Mw, void *) {
+    const int axes[3] = {a0, a1, a2};
+    for (int b = 0; b < B; ++b)
+        pose_euler_forward(rot + b * 3, xyz + b * 3, axes, reorient34, Mw + b * 12);
+    return 0;
+}
+
+int ddrr_pose_euler_backward(const float *rot, const float *xyz, int a0, int a1, int a2,
+                             const float *reorient34, const float *gMw, int B, float *g_rot,
+                             float *g_xyz, void *) {
+    const int axes[3] = {a0, a1, a2};
+    for (int b = 0; b < B; ++b)
+        pose_euler_backward(rot + b * 3, xyz + b * 3, axes, reorient34, gMw + b * 12, g_rot + b * 3,
+                            g_xyz + b * 3);
+    return 0;
+}
+
 }  // extern "C"

@@ -536,7 +536,10 @@ def test_fused_ray_generation_equals_general_path(gpu, stop):
         drr.fuse_ray_generation = fused
         rot, xyz = rot0.clone().requires_grad_(), xyz0.clone().requires_grad_()
         drr.density.grad = None
-        img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+        # (a RigidTransform goes in, so that both paths see bit-identical rays: with the
+        # fused Euler pose kernel the rotation differs from torch's matmul chain in the last
+        # bit, enough to flip fp32 ties in single rays' gradient records)
+        img = drr(convert(rot, xyz, parameterization="euler_angles", convention="ZXY"))
         (img * go).sum().backward()
         res[fused] = (img.detach().cpu().numpy(), rot.grad.cpu().numpy(), xyz.grad.cpu().numpy(),
                       None if stop else drr.density.grad.cpu().numpy())
@@ -704,3 +707,29 @@ def test_fused_ncc_kernels(gpu):
     (fused * w).sum().backward()
     (ref * w.double()).sum().backward()
     assert rel_err(b1.grad.cpu().numpy(), b2.grad.cpu().numpy()) < 1e-4
+
+
+def test_fused_euler_pose_on_gpu(gpu):
+    """Raw Euler parameters -> DRR through the fused pose kernel (ddrr_pose_euler_forward)
+    against the same call with a RigidTransform built by `convert` in PyTorch."""
+    from diffdrr_amd.pose import RigidTransform, euler_world_pose
+
+    drr = DRR(synthetic_subject(64, kind="phantom", seed=0), sdd=500.0, height=48, delx=2.0).to(gpu)
+    g = torch.Generator().manual_seed(21)
+    rot0 = ((torch.rand(9, 3, generator=g) - 0.5) * 3.0).to(gpu)
+    xyz0 = (torch.tensor([0.0, 350.0, 0.0]) + (torch.rand(9, 3, generator=g) - 0.5) * 50).to(gpu)
+    for conv in ("ZXY", "XYZ", "YXY"):
+        r1, x1 = rot0.clone().requires_grad_(), xyz0.clone().requires_grad_()
+        r2, x2 = rot0.clone().requires_grad_(), xyz0.clone().requires_grad_()
+        Mw = euler_world_pose(r1, x1, conv, drr.detector._reorient)
+        ref = RigidTransform(drr.detector._reorient).compose(
+            convert(r2, x2, parameterization="euler_angles", convention=conv)).matrix[:, :3, :]
+        assert torch.allclose(Mw, ref, rtol=1e-5, atol=2e-4), conv
+        w = torch.rand(9, 3, 4, device=gpu, generator=torch.Generator(gpu).manual_seed(2))
+        (Mw * w).sum().backward()
+        (ref * w).sum().backward()
+        assert rel_err(r1.grad.cpu().numpy(), r2.grad.cpu().numpy()) < 1e-4, conv
+        assert rel_err(x1.grad.cpu().numpy(), x2.grad.cpu().numpy()) < 1e-5, conv
+    a = drr(rot0, xyz0, parameterization="euler_angles", convention="ZXY")
+    b = drr(convert(rot0, xyz0, parameterization="euler_angles", convention="ZXY"))
+    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5

@@ -149,7 +149,13 @@ def test_drr_mask_to_channels_and_patches(emulated_ops):
     with torch.no_grad():
         patched = drr_p(rot, xyz, parameterization="euler_angles", convention="ZXY")
     assert rel_err(patched.numpy(), g["siddon_patched_f32"]) < 1e-4
-    assert torch.equal(patched, plain)  # Siddon is per-ray independent: exact
+    # (patched renders take the general path, `plain` the fused pose -> rays kernels, whose
+    # rotation matrix differs from torch's matmul chain in the last bit)
+    assert rel_err(patched.numpy(), plain.numpy()) < 1e-5
+    drr.fuse_ray_generation = False
+    with torch.no_grad():
+        general = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    assert torch.equal(patched, general)  # Siddon is per-ray independent: exact
 
 
 def test_drr_odd_detector_pa(emulated_ops):
@@ -254,7 +260,10 @@ def test_fused_ray_generation_equals_general_path(emulated_ops, path, stop):
         drr.fuse_ray_generation = fused
         rot, xyz = rot0.clone().requires_grad_(), xyz0.clone().requires_grad_()
         drr.density.grad = None
-        img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+        # (a RigidTransform goes in, so that both paths see bit-identical rays: with the
+        # fused Euler pose kernel the rotation differs from torch's matmul chain in the last
+        # bit, enough to flip fp32 ties in single rays' gradient records)
+        img = drr(convert(rot, xyz, parameterization="euler_angles", convention="ZXY"))
         (img * go).sum().backward()
         res[fused] = (img.detach(), rot.grad, xyz.grad,
                       None if stop else drr.density.grad.clone())
@@ -315,3 +324,30 @@ def test_fused_ncc_equals_pytorch_formula(emulated_ops):
     b3 = x2.clone().requires_grad_()
     v = ncc(fixed.expand(5, -1, -1, -1), b3)
     assert torch.allclose(v, formula(fixed.expand(5, -1, -1, -1), x2), atol=2e-6)
+
+
+@pytest.mark.parametrize("convention", ["ZXY", "XYZ", "YZX", "ZYX", "XZX", "YXY"])
+def test_fused_euler_pose_equals_convert_chain(emulated_ops, convention):
+    """ddrr_pose_euler_forward / _backward (one kernel each way) against
+    reorient.compose(convert(rot, xyz, 'euler_angles', convention)) in PyTorch: the 3x4
+    world matrix and its gradients w.r.t. angles and translation, incl. degrees."""
+    from diffdrr_amd.data import reorient_matrix
+    from diffdrr_amd.pose import RigidTransform, convert, euler_world_pose
+
+    g = torch.Generator().manual_seed(3)
+    reorient = reorient_matrix("AP")
+    w = torch.rand(5, 3, 4, generator=g)
+    for degrees in (False, True):
+        rot0 = (torch.rand(5, 3, generator=g) - 0.5) * (300.0 if degrees else 5.0)
+        xyz0 = (torch.rand(5, 3, generator=g) - 0.5) * 800
+        r1, x1 = rot0.clone().requires_grad_(), xyz0.clone().requires_grad_()
+        r2, x2 = rot0.clone().requires_grad_(), xyz0.clone().requires_grad_()
+        fused = euler_world_pose(r1, x1, convention, reorient, degrees=degrees)
+        pose = convert(r2, x2, parameterization="euler_angles", convention=convention,
+                       degrees=degrees)
+        ref = RigidTransform(reorient).compose(pose).matrix[:, :3, :]
+        assert torch.allclose(fused, ref, rtol=1e-5, atol=2e-4)
+        (fused * w).sum().backward()
+        (ref * w).sum().backward()
+        assert rel_err(r1.grad.numpy(), r2.grad.numpy()) < 1e-4
+        assert rel_err(x1.grad.numpy(), x2.grad.numpy()) < 1e-5
