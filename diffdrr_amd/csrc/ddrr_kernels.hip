@@ -538,6 +538,16 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         const int nb = p.B - b0 < kPoseChunk ? p.B - b0 : kPoseChunk;
         const bool last_chunk = ch == n_chunks - 1;
         if (ch > 0) __syncthreads();  // previous chunk's table no longer in use
+        // The chunk's row table (one thread per pose) and, for the first chunk, the brick: a
+        // thread owns 8 quads of 4 floats; all of its loads are issued before the first LDS
+        // store, so a brick costs one memory round trip instead of eight.
+        constexpr int kQuads = BRICK * BRICK * 8 / kBrickThreads;
+        static_assert(kQuads * kBrickThreads == BRICK * BRICK * 8, "brick staging");
+        const int q4 = (tid & 7) * 4, z = box.lo[2] + q4;
+        float *const d0 = brick + q4;
+        const bool stage_vec = ch == 0 && !GRAD && !TRI && vec_ok;
+        // z and D.z are multiples of 4: a quad is wholly inside or wholly outside
+        const bool in_z = z + 4 <= box.hi[2];
         if (tid < nb) {
             const PoseGrid pg = pose_grid(p.source + (long)(b0 + tid) * 3,
                                           p.target + (long)(b0 + tid) * N * 3, p.det_h, p.det_w);
@@ -547,26 +557,59 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
             *reinterpret_cast<BrickRow *>(rows + tid * kRowWords) = r;
         }
         if (tid == 0) counter[0] = 0;
-        if (ch == 0) {
-            // stage the brick: 32 x 32 rows of 32 floats (one 128-byte line each), zero padded
-            for (int row = tid >> 3; row < BRICK * BRICK; row += kBrickThreads >> 3) {
-                const int lx = row / BRICK, ly = row - lx * BRICK, q4 = (tid & 7) * 4;
-                const int x = box.lo[0] + lx, y = box.lo[1] + ly, z = box.lo[2] + q4;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (!GRAD && x >= 0 && y >= 0 && x < box.hi[0] && y < box.hi[1]) {
-                    const float *g = p.vol + ((long)x * p.D.y + y) * p.D.z + z;
-                    if (!TRI && vec_ok && z + 4 <= box.hi[2]) {
-                        const float4 q = *reinterpret_cast<const float4 *>(g);
-                        v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
-                    } else {
+        float4 q[kQuads];
+        if (stage_vec) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (z + k >= 0 && z + k < box.hi[2]) v[k] = g[k];
+            for (int it = 0; it < kQuads; ++it) {
+                const int row = (tid >> 3) + it * (kBrickThreads >> 3);
+                const int lx = row / BRICK, ly = row - lx * BRICK;
+                const int x = box.lo[0] + lx, y = box.lo[1] + ly;
+                // clamped (always readable) address; what lies outside is zeroed below
+                const int xc = x < p.D.x ? x : p.D.x - 1, yc = y < p.D.y ? y : p.D.y - 1;
+                q[it] = *reinterpret_cast<const float4 *>(
+                    p.vol + ((long)xc * p.D.y + yc) * p.D.z + (in_z ? z : 0));
+            }
+        }
+        if (stage_vec) {
+#pragma unroll
+            for (int it = 0; it < kQuads; ++it) {
+                const int row = (tid >> 3) + it * (kBrickThreads >> 3);
+                const int lx = row / BRICK, ly = row - lx * BRICK;
+                const bool in = in_z && box.lo[0] + lx < box.hi[0] && box.lo[1] + ly < box.hi[1];
+                float *d = d0 + lx * p.lay.sx + ly * p.lay.sy;
+                d[0] = in ? q[it].x : 0.f;
+                d[1] = in ? q[it].y : 0.f;
+                d[2] = in ? q[it].z : 0.f;
+                d[3] = in ? q[it].w : 0.f;
+            }
+        } else if (ch == 0) {
+            // general path (halo bricks of the trilinear marcher, unaligned volumes, and the
+            // zero fill of the gradient accumulator), two quads in flight
+#pragma unroll 1
+            for (int h = 0; h < kQuads; h += 2) {
+                float v[2][4];
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int row = (tid >> 3) + (h + it) * (kBrickThreads >> 3);
+                    const int lx = row / BRICK, ly = row - lx * BRICK;
+                    const int x = box.lo[0] + lx, y = box.lo[1] + ly;
+                    const bool in_xy = !GRAD && x >= 0 && y >= 0 && x < box.hi[0] && y < box.hi[1];
+                    const int xc = clampi(x, 0, p.D.x - 1), yc = clampi(y, 0, p.D.y - 1);
+                    const float *g = p.vol + ((long)xc * p.D.y + yc) * p.D.z;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool in = in_xy && z + k >= 0 && z + k < box.hi[2];
+                        v[it][k] = in ? g[z + k] : 0.f;
                     }
                 }
-                float *d = brick + lx * p.lay.sx + ly * p.lay.sy + q4;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) d[k] = v[k];
+                for (int it = 0; it < 2; ++it) {
+                    const int row = (tid >> 3) + (h + it) * (kBrickThreads >> 3);
+                    const int lx = row / BRICK, ly = row - lx * BRICK;
+                    float *d = d0 + lx * p.lay.sx + ly * p.lay.sy;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d[k] = v[it][k];
+                }
             }
         }
         __syncthreads();
