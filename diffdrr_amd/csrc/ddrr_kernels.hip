@@ -765,6 +765,64 @@ __global__ __launch_bounds__(kBlock) void siddon_fwd_channels_kernel(
     siddon_channels_ray(p.vol, labels, p.D, s, t, p.shift, p.eps, ColumnFlush{col, p.N, C, L});
 }
 
+// Backward of mask_to_channels (what autograd of renderers.py:77-89 returns): the loss
+// gradient of a segment is that of the channel its label selects, so the ray is walked
+// once more over the WEIGHTED volume v * grad_out[b, label, n]; the record of that walk
+// gives the endpoint gradients exactly as in the single-channel case (gl = ray length).
+struct ChannelFetch {
+    const float *vol;
+    const unsigned char *labels;
+    const float *gcol;  // grad_out + [b, 0, n]
+    long stride;        // N: distance between channels
+    int C;
+    __device__ __forceinline__ float operator()(unsigned boff) const {
+        const unsigned idx = boff >> 2;
+        const int lab = labels[idx];
+        return lab < C ? vol[idx] * gcol[lab * stride] : 0.f;
+    }
+};
+
+struct ChannelAdder {
+    float *g_volume;
+    const unsigned char *labels;
+    const float *gcol;
+    long stride;
+    int C;
+    __device__ __forceinline__ void operator()(unsigned idx, float v) const {
+        const int lab = labels[idx];
+        if (lab < C) unsafeAtomicAdd(g_volume + idx, v * gcol[lab * stride]);
+    }
+};
+
+__global__ __launch_bounds__(kBlock) void siddon_bwd_channels_kernel(
+    RayArgs p, const unsigned char *__restrict__ labels, int C,
+    const float *__restrict__ grad_out, float *__restrict__ g_source,
+    float *__restrict__ g_target, float *__restrict__ g_img, float *__restrict__ g_volume) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    const float *gcol = grad_out + (long)id.b * C * p.N + id.n;
+    if (g_source || g_target || g_img) {
+        float rec[SIDDON_AUX];
+        siddon_forward_ray_t<REDUCE_SUM, true, false>(ChannelFetch{p.vol, labels, gcol, p.N, C},
+                                                      global_store(p.D), full_box(p.D), s, t,
+                                                      p.shift, p.eps, rec, nullptr);
+        float gs[3], gt[3];
+        siddon_backward_ray<REDUCE_SUM>(rec, s, t, p.eps, L, gs, gt);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (g_source) g_source[id.r * 3 + a] = gs[a];
+            if (g_target) g_target[id.r * 3 + a] = gt[a];
+        }
+        if (g_img) g_img[id.r] = rec[0];
+    }
+    if (g_volume)
+        siddon_scatter_ray<REDUCE_SUM>(p.vol, p.D, s, t, p.shift, p.eps, L,
+                                       ChannelAdder{g_volume, labels, gcol, p.N, C});
+}
+
 // ------------------------------------------- volume-gradient fixed-point bound
 // work[1] = bits of max over rays of the largest single contribution a ray can make to a
 // voxel; work[2] = float: bound on the number of such contributions a voxel can receive in
@@ -1088,6 +1146,42 @@ __global__ __launch_bounds__(kBlock) void trilinear_bwd_kernel(
         if (g_target) g_target[id.r * 3 + a] = r.gt[a];
     }
     if (g_img) g_img[id.r] = g * r.sumT * ((a1 - a0) / (float)(n_points - 1));
+    if (g_alpha) {
+        g_alpha[id.r * 2 + 0] = r.g_amin;
+        g_alpha[id.r * 2 + 1] = r.g_amax;
+    }
+}
+
+// Backward of the marcher's mask_to_channels (renderers.py:242-252): every sample carries
+// the incoming gradient of the channel its nearest label selects.
+template <bool WANT_VOL>
+__global__ __launch_bounds__(kBlock) void trilinear_bwd_channels_kernel(
+    RayArgs p, const unsigned char *__restrict__ labels, int C,
+    const float *__restrict__ grad_out, int n_points, const float *__restrict__ amin,
+    const float *__restrict__ amax, int align_corners, float *__restrict__ g_source,
+    float *__restrict__ g_target, float *__restrict__ g_img, float *__restrict__ g_alpha,
+    float *__restrict__ g_volume) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    const float a0 = amin[0], a1 = amax[0];
+    const LabelWeight wt{labels, p.D, grad_out + (long)id.b * C * p.N + id.n, p.N, C, a0,
+                         p.shift, {s[0], s[1], s[2]}, align_corners != 0};
+    MarchGrad r;
+    if (WANT_VOL)
+        r = trilinear_backward_ray<false, true>(p.vol, p.D, s, t, p.shift, p.eps, n_points, a0, a1,
+                                                align_corners != 0, L, AtomicAdder{g_volume}, wt);
+    else
+        r = trilinear_backward_ray<false, false>(p.vol, p.D, s, t, p.shift, p.eps, n_points, a0,
+                                                 a1, align_corners != 0, L, NoAdd{}, wt);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (g_source) g_source[id.r * 3 + a] = r.gs[a];
+        if (g_target) g_target[id.r * 3 + a] = r.gt[a];
+    }
+    if (g_img) g_img[id.r] = r.sumT * ((a1 - a0) / (float)(n_points - 1));
     if (g_alpha) {
         g_alpha[id.r * 2 + 0] = r.g_amin;
         g_alpha[id.r * 2 + 1] = r.g_amax;
@@ -1527,6 +1621,23 @@ int ddrr_siddon_forward_channels(const float *volume, const unsigned char *label
     return finish("ddrr_siddon_forward_channels");
 }
 
+int ddrr_siddon_backward_channels(const float *volume, const unsigned char *labels, int dx,
+                                  int dy, int dz, const float *source, int src_n,
+                                  const float *target, const float *img, const float *grad_out,
+                                  int B, int N, int C, float voxel_shift, float eps, int det_h,
+                                  int det_w, int tile_h, int tile_w, float *g_source,
+                                  float *g_target, float *g_img, float *g_volume, void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!labels || !grad_out || C < 1) return fail(-1, "null labels/grad_out or C < 1");
+    if (B == 0 || N == 0) return 0;
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, det_h, det_w, tile_h, tile_w);
+    hipLaunchKernelGGL(siddon_bwd_channels_kernel, dim3(grid_for(p)), dim3(kBlock), 0,
+                       (hipStream_t)stream, p, labels, C, grad_out, g_source, g_target, g_img,
+                       g_volume);
+    return finish("ddrr_siddon_backward_channels");
+}
+
 int ddrr_trilinear_forward(const float *volume, int dx, int dy, int dz, const float *source,
                            int src_n, const float *target, const float *img, int B, int N,
                            float voxel_shift, float eps, int n_points, const float *alphamin,
@@ -1601,6 +1712,35 @@ int ddrr_trilinear_backward(const float *volume, int dx, int dy, int dz, const f
     else LAUNCH(false, false);
 #undef LAUNCH
     return finish("ddrr_trilinear_backward");
+}
+
+int ddrr_trilinear_backward_channels(const float *volume, const unsigned char *labels, int dx,
+                                     int dy, int dz, const float *source, int src_n,
+                                     const float *target, const float *img,
+                                     const float *grad_out, int B, int N, int C,
+                                     float voxel_shift, float eps, int n_points,
+                                     const float *alphamin, const float *alphamax,
+                                     int align_corners, int det_h, int det_w, int tile_h,
+                                     int tile_w, float *g_source, float *g_target, float *g_img,
+                                     float *g_alpha, float *g_volume, void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!labels || !grad_out || !alphamin || !alphamax || C < 1)
+        return fail(-1, "null labels / grad_out / alphamin / alphamax or C < 1");
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (B == 0 || N == 0) return 0;
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, det_h, det_w, tile_h, tile_w);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(grid_for(p)), block(kBlock);
+    if (g_volume)
+        hipLaunchKernelGGL((trilinear_bwd_channels_kernel<true>), grid, block, 0, st, p, labels, C,
+                           grad_out, n_points, alphamin, alphamax, align_corners, g_source,
+                           g_target, g_img, g_alpha, g_volume);
+    else
+        hipLaunchKernelGGL((trilinear_bwd_channels_kernel<false>), grid, block, 0, st, p, labels, C,
+                           grad_out, n_points, alphamin, alphamax, align_corners, g_source,
+                           g_target, g_img, g_alpha, g_volume);
+    return finish("ddrr_trilinear_backward_channels");
 }
 
 int ddrr_raygen_forward(const float *Mw, const float *Ainv, const float *P, int B, int N,

@@ -84,6 +84,34 @@ DDRR_HD float trilinear_forward_ray(const float *__restrict__ vol, const Dims D,
     return acc * q.step;  // caller multiplies by the ray length
 }
 
+// Label of the sample with linspace value `lin` (mask_to_channels, renderers.py:242-252).
+// The label lookup is discontinuous, and the first sample of the ray that sets the
+// batch-global alphamin sits exactly ON the volume's face (g = -1/2): which side it falls on
+// is decided by the reference's fp32 round trip through normalised coordinates
+// (renderers.py:152, then aten's un-normalisation), so that is restated here for the label
+// (the interpolated value is continuous and does not need it).  alphas = linspace *
+// (alphamax - alphamin) + alphamin; x = s + alpha * d; each operation rounded on its own, as
+// the reference's tensor ops are.  0 outside the volume.
+DDRR_HD int march_label(const unsigned char *__restrict__ labels, const Dims D, float lin,
+                        const MarchSetup &q, float amin, const float s[3], float shift,
+                        bool align_corners) {
+    const float al_ref = add_rn(mul_rn(lin, q.span), amin);
+    const float Dn[3] = {(float)D.x, (float)D.y, (float)D.z};
+    float rr[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = add_rn(s[a], mul_rn(al_ref, q.d[a]));
+        const float nrm = add_rn(mul_rn(2.f, add_rn(x, shift)) / Dn[a], -1.f);
+        const float un = align_corners ? mul_rn(add_rn(nrm, 1.f) / 2.f, Dn[a] - 1.f)
+                                       : add_rn(mul_rn(add_rn(nrm, 1.f), Dn[a]), -1.f) / 2.f;
+        rr[a] = rintf(un);  // half-to-even == nearbyint
+    }
+    const float rx = rr[0], ry = rr[1], rz = rr[2];
+    const bool in = rx >= 0.f && rx < (float)D.x && ry >= 0.f && ry < (float)D.y && rz >= 0.f &&
+                    rz < (float)D.z;
+    return in ? (int)labels[((int)rx * D.y + (int)ry) * D.z + (int)rz] : 0;
+}
+
 // mask_to_channels for the marcher (renderers.py:242-252): every sample's value goes to
 // the channel of the label found by a NEAREST lookup of the mask at the sample point
 // (0 outside the volume).  The ray owns its output column: a run of samples with one
@@ -104,29 +132,7 @@ DDRR_HD void trilinear_channels_ray(const float *__restrict__ vol,
         const float gy = fmaf(fmaf(al, q.d[1], s[1]), g.k[1], g.o[1]);
         const float gz = fmaf(fmaf(al, q.d[2], s[2]), g.k[2], g.o[2]);
         const float v = fetch_trilinear(vol, D, gx, gy, gz, nullptr, false);
-        // The label lookup is discontinuous, and the first sample of the ray that sets the
-        // batch-global alphamin sits exactly ON the volume's face (g = -1/2): which side it
-        // falls on is decided by the reference's fp32 round trip through normalised
-        // coordinates (renderers.py:152, then aten's un-normalisation), so that is restated
-        // here for the label (the interpolated value is continuous and does not need it).
-        // alphas = linspace * (alphamax - alphamin) + alphamin; x = s + alpha * d; each
-        // operation rounded on its own, as the reference's tensor ops are
-        const float al_ref = add_rn(mul_rn(lin01(m, P, q.lstep), q.span), amin);
-        const float Dn[3] = {(float)D.x, (float)D.y, (float)D.z};
-        float rr[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float x = add_rn(s[a], mul_rn(al_ref, q.d[a]));
-            const float nrm = add_rn(mul_rn(2.f, add_rn(x, shift)) / Dn[a], -1.f);
-            const float un = align_corners
-                                 ? mul_rn(add_rn(nrm, 1.f) / 2.f, Dn[a] - 1.f)
-                                 : add_rn(mul_rn(add_rn(nrm, 1.f), Dn[a]), -1.f) / 2.f;
-            rr[a] = rintf(un);  // half-to-even == nearbyint
-        }
-        const float rx = rr[0], ry = rr[1], rz = rr[2];
-        const bool in = rx >= 0.f && rx < (float)D.x && ry >= 0.f && ry < (float)D.y &&
-                        rz >= 0.f && rz < (float)D.z;
-        const int lab = in ? (int)labels[((int)rx * D.y + (int)ry) * D.z + (int)rz] : 0;
+        const int lab = march_label(labels, D, lin01(m, P, q.lstep), q, amin, s, shift, align_corners);
         if (lab != cur) {
             if (cur >= 0) flush(cur, run * q.step);
             cur = lab;
@@ -169,13 +175,35 @@ struct MarchGrad {
     float sumT;  // sum of samples (d out / d img = g * step * sumT)
 };
 
+// Per-sample weight of the backward pass: 1 for the plain march; with mask_to_channels the
+// incoming gradient of the channel the sample's label selects (grad_out is (B, C, N): `gcol`
+// points at [b, 0, n], channels are `stride` apart).  The label has no gradient of its own.
+struct UnitWeight {
+    DDRR_HD float operator()(float, const MarchSetup &) const { return 1.f; }
+};
+struct LabelWeight {
+    const unsigned char *labels;
+    Dims D;
+    const float *gcol;
+    long stride;
+    int C;
+    float amin, shift;
+    float s[3];
+    bool align_corners;
+    DDRR_HD float operator()(float lin, const MarchSetup &q) const {
+        const int lab = march_label(labels, D, lin, q, amin, s, shift, align_corners);
+        return lab < C ? gcol[lab * stride] : 0.f;
+    }
+};
+
 // Backward of the sum-reduced march for one ray.
-// gl = grad_out * ray length.
-template <bool NEAREST, bool WANT_VOL, class Add>
+// gl = grad_out * ray length (the ray length alone when `wt` carries the gradient).
+template <bool NEAREST, bool WANT_VOL, class Add, class Weight = UnitWeight>
 DDRR_HD MarchGrad trilinear_backward_ray(const float *__restrict__ vol, const Dims D,
                                          const float s[3], const float t[3], float shift,
                                          float eps, int P, float amin, float amax,
-                                         bool align_corners, float gl, Add add) {
+                                         bool align_corners, float gl, Add add,
+                                         Weight wt = Weight()) {
     const GridMap g = make_gridmap(D, shift, align_corners);
     const MarchSetup q = march_setup(D, g, s, t, eps, P, amin, amax);
     MarchGrad r;
@@ -190,23 +218,24 @@ DDRR_HD MarchGrad trilinear_backward_ray(const float *__restrict__ vol, const Di
         const float gx = fmaf(fmaf(al, q.d[0], s[0]), g.k[0], g.o[0]);
         const float gy = fmaf(fmaf(al, q.d[1], s[1]), g.k[1], g.o[1]);
         const float gz = fmaf(fmaf(al, q.d[2], s[2]), g.k[2], g.o[2]);
+        const float w = wt(u, q);
         if (NEAREST) {
-            sumT += fetch_nearest(vol, D, gx, gy, gz);
-            if (WANT_VOL) scatter_nearest(D, gx, gy, gz, k, add);
+            sumT = fmaf(w, fetch_nearest(vol, D, gx, gy, gz), sumT);
+            if (WANT_VOL) scatter_nearest(D, gx, gy, gz, k * w, add);
         } else {
             float dT[3];
-            sumT += fetch_trilinear(vol, D, gx, gy, gz, dT, true);
+            sumT = fmaf(w, fetch_trilinear(vol, D, gx, gy, gz, dT, true), sumT);
             float ddot = 0.f;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                dT[a] *= g.k[a];  // d(index coord)/dx
+                dT[a] *= g.k[a] * w;  // d(index coord)/dx
                 A[a] += dT[a];
                 Bv[a] = fmaf(al, dT[a], Bv[a]);
                 ddot = fmaf(dT[a], q.d[a], ddot);
             }
             Cd += ddot;
             Cu = fmaf(u, ddot, Cu);
-            if (WANT_VOL) scatter_trilinear(D, gx, gy, gz, k, add);
+            if (WANT_VOL) scatter_trilinear(D, gx, gy, gz, k * w, add);
         }
     }
 #pragma unroll
@@ -214,9 +243,9 @@ DDRR_HD MarchGrad trilinear_backward_ray(const float *__restrict__ vol, const Di
         r.gs[a] = k * (A[a] - Bv[a]);  // sum (1 - alpha) dT
         r.gt[a] = k * Bv[a];           // sum alpha dT
     }
-    const float w = gl * sumT / (float)(P - 1);  // through step = (amax - amin)/(P-1)
-    r.g_amin = k * (Cd - Cu) - w;
-    r.g_amax = k * Cu + w;
+    const float ws = gl * sumT / (float)(P - 1);  // through step = (amax - amin)/(P-1)
+    r.g_amin = k * (Cd - Cu) - ws;
+    r.g_amax = k * Cu + ws;
     r.sumT = sumT;
     return r;
 }

@@ -370,6 +370,36 @@ def siddon_forward_channels(volume, labels_u8, n_channels, source, target, img, 
     return out
 
 
+def siddon_backward_channels(volume, labels_u8, source, target, img, grad_out, *, voxel_shift=0.5,
+                             eps=1e-8, want_rays=True, want_img=True, want_volume=False,
+                             det=None, tile=None):
+    """Backward of :func:`siddon_forward_channels` for grad_out (B, C, N).
+    -> (g_source per ray (B,N,3), g_target (B,N,3), g_img (B,N), g_volume), None where not asked."""
+    B, N = _check_rays(volume, source, target, img)
+    dev = volume.device
+    C = grad_out.shape[1]
+    if grad_out.shape != (B, C, N):
+        raise ValueError(f"grad_out must be (B, C, N) = ({B}, C, {N}), got {tuple(grad_out.shape)}")
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    g_source = new(B, N, 3) if want_rays else None
+    g_target = new(B, N, 3) if want_rays else None
+    g_img = new(B, N) if want_img else None
+    g_volume = torch.zeros_like(volume, memory_format=torch.contiguous_format) \
+        if want_volume else None
+    dh, dw, th, tw = _hints(det, tile, N)
+    if _empty(B, N):
+        return g_source, g_target, g_img, g_volume
+    labels_u8, volume, grad_out = labels_u8.contiguous(), volume.contiguous(), grad_out.contiguous()
+    source, target = source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    _launch(
+        "ddrr_siddon_backward_channels", dev, volume.data_ptr(), labels_u8.data_ptr(),
+        *volume.shape, source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img),
+        grad_out.data_ptr(), B, N, int(C), float(voxel_shift), float(eps), dh, dw, th, tw,
+        _ptr(g_source), _ptr(g_target), _ptr(g_img), _ptr(g_volume))
+    return g_source, g_target, g_img, g_volume
+
+
 def trilinear_forward(volume, source, target, img, alphamin, alphamax, *, n_points=500,
                       voxel_shift=0.5, eps=1e-8, reducefn="sum", mode="bilinear",
                       align_corners=False, det=None, tile=None):
@@ -446,6 +476,41 @@ def trilinear_backward_volume_bricks(volume_shape, source, target, img, grad_out
             float(voxel_shift), float(eps), int(n_points), alphamin.data_ptr(),
             alphamax.data_ptr(), g_volume.data_ptr())
     return g_volume
+
+
+def trilinear_backward_channels(volume, labels_u8, source, target, img, grad_out, alphamin,
+                                alphamax, *, n_points=500, voxel_shift=0.5, eps=1e-8,
+                                align_corners=False, want_rays=True, want_img=True,
+                                want_alpha=True, want_volume=False, det=None, tile=None):
+    """Backward of :func:`trilinear_forward_channels` for grad_out (B, C, N); results as
+    :func:`trilinear_backward`."""
+    B, N = _check_rays(volume, source, target, img)
+    dev = volume.device
+    C = grad_out.shape[1]
+    if grad_out.shape != (B, C, N):
+        raise ValueError(f"grad_out must be (B, C, N) = ({B}, C, {N}), got {tuple(grad_out.shape)}")
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    g_source = new(B, N, 3) if want_rays else None
+    g_target = new(B, N, 3) if want_rays else None
+    g_img = new(B, N) if want_img else None
+    g_alpha = new(B, N, 2) if want_alpha else None
+    g_volume = torch.zeros_like(volume, memory_format=torch.contiguous_format) \
+        if want_volume else None
+    dh, dw, th, tw = _hints(det, tile, N)
+    res = {"g_source": g_source, "g_target": g_target, "g_img": g_img, "g_alpha": g_alpha,
+           "g_volume": g_volume}
+    if _empty(B, N):
+        return res
+    labels_u8, volume, grad_out = labels_u8.contiguous(), volume.contiguous(), grad_out.contiguous()
+    source, target = source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    _launch(
+        "ddrr_trilinear_backward_channels", dev, volume.data_ptr(), labels_u8.data_ptr(),
+        *volume.shape, source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img),
+        grad_out.data_ptr(), B, N, int(C), float(voxel_shift), float(eps), int(n_points),
+        alphamin.data_ptr(), alphamax.data_ptr(), int(bool(align_corners)), dh, dw, th, tw,
+        _ptr(g_source), _ptr(g_target), _ptr(g_img), _ptr(g_alpha), _ptr(g_volume))
+    return res
 
 
 def trilinear_backward(volume, source, target, img, grad_out, alphamin, alphamax, *, n_points=500,

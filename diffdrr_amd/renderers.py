@@ -114,6 +114,40 @@ class _SiddonFn(torch.autograd.Function):
         return g_vol, g_s, g_t, g_i, None
 
 
+class _SiddonChannelsFn(torch.autograd.Function):
+    """mask_to_channels (renderers.py:77-89): out (B,C,N), channel c = the line integral over
+    the voxels labelled c.  Backward: one ddrr_siddon_backward_channels launch (the ray is
+    re-walked over the volume weighted by the incoming gradient of each voxel's channel),
+    replacing ScatterAddBackward + SortBackward + grid_sampler_3d_backward."""
+
+    @staticmethod
+    def forward(ctx, volume, source, target, img, labels, C, cfg):
+        out = ops.siddon_forward_channels(
+            volume, labels, C, source.contiguous(), target.contiguous(), img.contiguous(),
+            voxel_shift=cfg["voxel_shift"], eps=cfg["eps"], det=cfg["det"], tile=cfg["tile"])
+        ctx.cfg = cfg
+        ctx.save_for_backward(volume, source, target, img, labels)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        volume, source, target, img, labels = ctx.saved_tensors
+        cfg = ctx.cfg
+        need_vol, need_s, need_t, need_i = ctx.needs_input_grad[:4]
+        stop = cfg["stop_gradients"]
+        gs, gt, gi, gv = ops.siddon_backward_channels(
+            volume, labels, source, target, img, grad_out, voxel_shift=cfg["voxel_shift"],
+            eps=cfg["eps"], want_rays=bool(need_s or need_t), want_img=bool(need_i and not stop),
+            want_volume=bool(need_vol and not stop), det=cfg["det"], tile=cfg["tile"])
+        g_s = g_t = None
+        if need_s:
+            g_s = gs.sum(dim=1, keepdim=True) if source.shape[1] == 1 else gs
+        if need_t:
+            g_t = gt
+        g_i = gi.view_as(img) if gi is not None else None
+        return gv, g_s, g_t, g_i, None, None, None
+
+
 class _SiddonPoseFn(torch.autograd.Function):
     """The DRR case end to end: world pose per DRR -> image.  Inputs: volume, Mw (B,3,4)
     (extrinsic o reorient), P (N,3) calibrated detector points, Ainv (3,4) world -> voxel.
@@ -226,20 +260,12 @@ class Siddon(torch.nn.Module):
         if mask is None:
             out = _SiddonFn.apply(volume, source, target, img.reshape(B, N), cfg)
             return out.unsqueeze(1)
-        # mask_to_channels (renderers.py:77-89); forward only, like the reference
-        # in practice (the label gather is not differentiable)
+        # mask_to_channels (renderers.py:77-89)
         if cfg["lookup"] != "step" or self.reducefn != "sum":
             raise NotImplementedError(
                 "mask_to_channels needs mode='nearest', align_corners=False, reducefn='sum'")
-        if any(t.requires_grad for t in (volume, source, target, img)) and \
-                torch.is_grad_enabled():
-            raise NotImplementedError("mask_to_channels rendering is forward-only here; wrap the "
-                                      "call in torch.no_grad()")
         labels, C = _labels_u8(mask)
-        return ops.siddon_forward_channels(
-            volume, labels, C, source.contiguous(), target.contiguous(),
-            img.reshape(B, N).contiguous(), voxel_shift=self.voxel_shift, eps=self.eps,
-            det=self.detector_shape, tile=self.tile)
+        return _SiddonChannelsFn.apply(volume, source, target, img.reshape(B, N), labels, C, cfg)
 
 
 def get_alpha_minmax(source, target, dims, voxel_shift, eps):
@@ -328,6 +354,49 @@ class _TrilinearFn(torch.autograd.Function):
             g_a0, g_a1, None
 
 
+class _TrilinearChannelsFn(torch.autograd.Function):
+    """The marcher's mask_to_channels (renderers.py:242-252): out (B,C,N); backward = one
+    ddrr_trilinear_backward_channels launch (every sample weighted by the incoming gradient
+    of the channel its nearest label selects)."""
+
+    @staticmethod
+    def forward(ctx, volume, source, target, img, alphamin, alphamax, labels, C, cfg):
+        source, target, img = source.contiguous(), target.contiguous(), img.contiguous()
+        out = ops.trilinear_forward_channels(
+            volume, labels, C, source, target, img, alphamin.reshape(1), alphamax.reshape(1),
+            n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
+            align_corners=cfg["align_corners"], det=cfg["det"], tile=cfg["tile"])
+        ctx.cfg = cfg
+        ctx.save_for_backward(volume, source, target, img, alphamin, alphamax, labels)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        volume, source, target, img, alphamin, alphamax, labels = ctx.saved_tensors
+        cfg = ctx.cfg
+        need_vol, need_s, need_t, need_i, need_a0, need_a1 = ctx.needs_input_grad[:6]
+        r = ops.trilinear_backward_channels(
+            volume, labels, source, target, img, grad_out, alphamin.reshape(1),
+            alphamax.reshape(1), n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"],
+            eps=cfg["eps"], align_corners=cfg["align_corners"],
+            want_rays=bool(need_s or need_t), want_img=bool(need_i),
+            want_alpha=bool(need_a0 or need_a1), want_volume=bool(need_vol), det=cfg["det"],
+            tile=cfg["tile"])
+        g_s = g_t = g_a0 = g_a1 = g_i = None
+        if need_s:
+            g_s = r["g_source"].sum(dim=1, keepdim=True) if source.shape[1] == 1 \
+                else r["g_source"]
+        if need_t:
+            g_t = r["g_target"]
+        if need_i:
+            g_i = r["g_img"].view_as(img)
+        if need_a0 or need_a1:
+            ga = r["g_alpha"].sum(dim=(0, 1))
+            g_a0 = ga[0].reshape(alphamin.shape) if need_a0 else None
+            g_a1 = ga[1].reshape(alphamax.shape) if need_a1 else None
+        return r["g_volume"], g_s, g_t, g_i, g_a0, g_a1, None, None, None
+
+
 class Trilinear(torch.nn.Module):
     """Differentiable X-ray renderer: trilinear ray marching (reference
     renderers.py:186-254) as one fused gfx950 kernel per call."""
@@ -360,20 +429,16 @@ class Trilinear(torch.nn.Module):
         alphamin = torch.as_tensor(alphamin, dtype=volume.dtype, device=volume.device)
         alphamax = torch.as_tensor(alphamax, dtype=volume.dtype, device=volume.device)
         if mask is not None:
-            # mask_to_channels (renderers.py:242-252); forward only, like the Siddon branch
+            # mask_to_channels (renderers.py:242-252)
             if self.mode != "bilinear" or self.reducefn != "sum":
                 raise NotImplementedError(
                     "mask_to_channels needs mode='bilinear' and reducefn='sum'")
-            if any(t.requires_grad for t in (volume, source, target, img)) and \
-                    torch.is_grad_enabled():
-                raise NotImplementedError("mask_to_channels rendering is forward-only here; wrap "
-                                          "the call in torch.no_grad()")
             labels, C = _labels_u8(mask)
-            return ops.trilinear_forward_channels(
-                volume, labels, C, source, target, img.reshape(B, N), alphamin.reshape(1),
-                alphamax.reshape(1), n_points=int(n_points), voxel_shift=self.voxel_shift,
-                eps=self.eps, align_corners=bool(align_corners), det=self.detector_shape,
-                tile=self.tile)
+            ccfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift, "eps": self.eps,
+                    "align_corners": bool(align_corners), "det": self.detector_shape,
+                    "tile": self.tile}
+            return _TrilinearChannelsFn.apply(volume, source, target, img.reshape(B, N), alphamin,
+                                              alphamax, labels, C, ccfg)
         cfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift, "eps": self.eps,
                "reducefn": self.reducefn, "mode": self.mode,
                "align_corners": bool(align_corners), "det": self.detector_shape,

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 8
+#define DDRR_ABI_VERSION 9
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -143,6 +143,17 @@ int ddrr_siddon_forward_channels(const float *volume, const unsigned char *label
                                  float eps, int det_h, int det_w, int tile_h, int tile_w,
                                  float *out, void *stream);
 
+/* Backward of ddrr_siddon_forward_channels: what autograd of renderers.py:77-89 (scatter_add
+ * of the weighted segments into channels) returns for grad_out (B, C, N).  Outputs as in
+ * ddrr_siddon_backward_rays (per ray; any may be NULL); g_volume: NULL, or ACCUMULATED with
+ * fp32 atomics (the caller zero-fills). */
+int ddrr_siddon_backward_channels(const float *volume, const unsigned char *labels, int dx,
+                                  int dy, int dz, const float *source, int src_n,
+                                  const float *target, const float *img, const float *grad_out,
+                                  int B, int N, int C, float voxel_shift, float eps, int det_h,
+                                  int det_w, int tile_h, int tile_w, float *g_source,
+                                  float *g_target, float *g_img, float *g_volume, void *stream);
+
 /* Trilinear.forward, mask=None (renderers.py:205-241).  alphamin/alphamax are
  * DEVICE scalars (renderers.py:220-223 evaluated by the caller, or the
  * caller's own values); mode_nearest selects Trilinear(mode="nearest"). */
@@ -196,6 +207,18 @@ int ddrr_trilinear_backward(const float *volume, int dx, int dy, int dz, const f
                             int mode_nearest, int align_corners, int det_h, int det_w, int tile_h,
                             int tile_w, float *g_source, float *g_target, float *g_img,
                             float *g_alpha, float *g_volume, void *stream);
+
+/* Backward of ddrr_trilinear_forward_channels (autograd of renderers.py:242-252) for grad_out
+ * (B, C, N); outputs as in ddrr_trilinear_backward. */
+int ddrr_trilinear_backward_channels(const float *volume, const unsigned char *labels, int dx,
+                                     int dy, int dz, const float *source, int src_n,
+                                     const float *target, const float *img,
+                                     const float *grad_out, int B, int N, int C,
+                                     float voxel_shift, float eps, int n_points,
+                                     const float *alphamin, const float *alphamax,
+                                     int align_corners, int det_h, int det_w, int tile_h,
+                                     int tile_w, float *g_source, float *g_target, float *g_img,
+                                     float *g_alpha, float *g_volume, void *stream);
 
 /* Fused ray generation for the DRR case: replaces the tensor programs between a pose and
  * the renderer call -- detector.py:151-153 (pose = reorient o extrinsic applied to the

@@ -133,6 +133,27 @@ def siddon_channels(volume, mask, source, target, img=None, *, n_channels=None, 
     return out.astype(terms.dtype)
 
 
+def siddon_channels_grad(volume, mask, source, target, img, grad_out, **kw):
+    """Autograd of the mask_to_channels branch (renderers.py:77-89) for grad_out (B, C, N).
+    With a nearest lookup, channel c is exactly the Siddon render of the volume with every
+    voxel not labelled c set to zero, so the gradients are the sum over channels of the
+    single-channel analytic gradients (g_volume of channel c masked to its voxels)."""
+    mask = np.asarray(mask)
+    C = grad_out.shape[1]
+    tot = None
+    for c in range(C):
+        sel = mask == c
+        r = siddon(np.where(sel, volume, 0), source, target, img, grad_out=grad_out[:, c, :],
+                   want_volume_grad=True, **kw)
+        r["g_volume"] = np.where(sel, r["g_volume"], 0)
+        if tot is None:
+            tot = {k: np.array(r[k], dtype=np.float64) for k in ("g_source", "g_target", "g_img", "g_volume")}
+        else:
+            for k in tot:
+                tot[k] += r[k]
+    return tot
+
+
 def alpha_minmax(source, target, dims, *, voxel_shift=0.5, eps=1e-8):
     """_get_alpha_minmax (renderers.py:124-140), per ray -> (B,N,1) each."""
     dtype = target.dtype

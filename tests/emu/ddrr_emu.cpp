@@ -595,6 +595,84 @@ int ddrr_siddon_forward_channels(const float *volume, const unsigned char *label
     return 0;
 }
 
+int ddrr_siddon_backward_channels(const float *volume, const unsigned char *labels, int dx,
+                                  int dy, int dz, const float *source, int src_n,
+                                  const float *target, const float *img, const float *grad_out,
+                                  int B, int N, int C, float voxel_shift, float eps, int det_h,
+                                  int det_w, int tile_h, int tile_w, float *g_source,
+                                  float *g_target, float *g_img, float *g_volume, void *) {
+    const Dims D{dx, dy, dz};
+    for_each_ray(
+        source, src_n, target, img, B, N, det_h, det_w, tile_h, tile_w,
+        [&](int b, int n, long r, const Ray &ray) {
+            const float *gcol = grad_out + (long)b * C * N + n;
+            if (g_source || g_target || g_img) {
+                float rec[SIDDON_AUX];
+                auto fetch = [&](unsigned boff) {
+                    const unsigned idx = boff >> 2;
+                    const int lab = labels[idx];
+                    return lab < C ? volume[idx] * gcol[(long)lab * N] : 0.f;
+                };
+                siddon_forward_ray_t<REDUCE_SUM, true, false>(fetch, global_store(D), full_box(D),
+                                                              ray.s, ray.t, voxel_shift, eps, rec,
+                                                              nullptr);
+                float gs[3], gt[3];
+                siddon_backward_ray<REDUCE_SUM>(rec, ray.s, ray.t, eps, ray.L, gs, gt);
+                for (int a = 0; a < 3; ++a) {
+                    if (g_source) g_source[r * 3 + a] = gs[a];
+                    if (g_target) g_target[r * 3 + a] = gt[a];
+                }
+                if (g_img) g_img[r] = rec[0];
+            }
+            if (g_volume)
+                siddon_scatter_ray<REDUCE_SUM>(volume, D, ray.s, ray.t, voxel_shift, eps, ray.L,
+                                               [&](unsigned idx, float v) {
+                                                   const int lab = labels[idx];
+                                                   if (lab < C)
+                                                       g_volume[idx] += v * gcol[(long)lab * N];
+                                               });
+        });
+    return 0;
+}
+
+int ddrr_trilinear_backward_channels(const float *volume, const unsigned char *labels, int dx,
+                                     int dy, int dz, const float *source, int src_n,
+                                     const float *target, const float *img,
+                                     const float *grad_out, int B, int N, int C,
+                                     float voxel_shift, float eps, int n_points,
+                                     const float *alphamin, const float *alphamax,
+                                     int align_corners, int det_h, int det_w, int tile_h,
+                                     int tile_w, float *g_source, float *g_target, float *g_img,
+                                     float *g_alpha, float *g_volume, void *) {
+    const Dims D{dx, dy, dz};
+    for_each_ray(
+        source, src_n, target, img, B, N, det_h, det_w, tile_h, tile_w,
+        [&](int b, int n, long r, const Ray &ray) {
+            const bool ac = align_corners != 0;
+            const LabelWeight wt{labels, D, grad_out + (long)b * C * N + n, N, C, *alphamin,
+                                 voxel_shift, {ray.s[0], ray.s[1], ray.s[2]}, ac};
+            MarchGrad m;
+            if (g_volume)
+                m = trilinear_backward_ray<false, true>(volume, D, ray.s, ray.t, voxel_shift, eps,
+                                                        n_points, *alphamin, *alphamax, ac, ray.L,
+                                                        HostAdd{g_volume}, wt);
+            else
+                m = trilinear_backward_ray<false, false>(volume, D, ray.s, ray.t, voxel_shift, eps,
+                                                         n_points, *alphamin, *alphamax, ac, ray.L,
+                                                         NoAdd{}, wt);
+            for (int a = 0; a < 3; ++a) {
+                if (g_source) g_source[r * 3 + a] = m.gs[a];
+                if (g_target) g_target[r * 3 + a] = m.gt[a];
+            }
+            if (g_img) g_img[r] = m.sumT * ((*alphamax - *alphamin) / (float)(n_points - 1));
+            if (g_alpha) {
+                g_alpha[r * 2 + 0] = m.g_amin;
+                g_alpha[r * 2 + 1] = m.g_amax;
+            }
+        });
+    return 0;
+}
+
 int ddrr_trilinear_forward_channels(const float *volume, const unsigned char *labels, int dx,
                                     int dy, int dz, const float *source, int src_n,
                                     const float *target, const float *img, int B, int N, int C,

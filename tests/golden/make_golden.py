@@ -160,7 +160,7 @@ def make_renderer_fixtures():
     g = torch.Generator().manual_seed(19)
     mask = torch.randint(0, 5, dims, generator=g).to(F32)
     renderer_fixture("siddon_mask", lambda: R.Siddon(), {}, dims,
-                     lambda g: random_rays(g, dims, 2, 32), 19, mask=mask, want_grads=False)
+                     lambda g: random_rays(g, dims, 2, 32), 19, mask=mask)
 
     renderer_fixture("trilinear_global_range", lambda: R.Trilinear(), {"n_points": 41}, dims,
                      lambda g: random_rays(g, dims, 2, 32), 20)
@@ -173,7 +173,7 @@ def make_renderer_fixtures():
                      lambda: R.Trilinear(mode="nearest", reducefn="max"), {"n_points": 33}, dims,
                      lambda g: random_rays(g, dims, 2, 32), 23, want_grads=False)
     renderer_fixture("trilinear_mask", lambda: R.Trilinear(), {"n_points": 40}, dims,
-                     lambda g: random_rays(g, dims, 2, 32), 24, mask=mask, want_grads=False)
+                     lambda g: random_rays(g, dims, 2, 32), 24, mask=mask)
     renderer_fixture("trilinear_shift0", lambda: R.Trilinear(voxel_shift=0.0), {"n_points": 40},
                      dims, lambda g: random_rays(g, dims, 2, 32), 25, meta={"voxel_shift": 0.0})
 

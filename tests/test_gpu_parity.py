@@ -85,6 +85,19 @@ def test_siddon_mask_golden(gpu):
     assert rel_err(out.sum(1, keepdim=True).cpu().numpy(), plain.cpu().numpy()) < 1e-5
 
 
+def test_siddon_mask_gradients_golden(gpu):
+    """mask_to_channels backward (ddrr_siddon_backward_channels) against the reference's
+    autograd through its scatter_add (renderers.py:77-89): grad_out is (B, C, N)."""
+    g = golden("siddon_mask")
+    vol, src, tgt, img = (t.requires_grad_() for t in dev_inputs(g, gpu))
+    mask = torch.from_numpy(g["mask"]).to(gpu)
+    out = Siddon()(vol, src, tgt, img, mask=mask)
+    go = torch.from_numpy(g["grad_out_f32"]).to(gpu)
+    grads = torch.autograd.grad(out, [src, tgt, img, vol], go)
+    for name, gr in zip(("g_source", "g_target", "g_img", "g_volume"), grads):
+        assert rel_err(gr.cpu().numpy(), g[name + "_f64"]) < GRAD_TOL, name
+
+
 @pytest.mark.parametrize("name,npts,rng,shift", [
     ("trilinear_global_range", 41, None, 0.5), ("trilinear_explicit_range", 64, (0.31, 0.77), 0.5),
     ("trilinear_oblique", 50, None, 0.5), ("trilinear_shift0", 40, None, 0.0),
@@ -684,6 +697,18 @@ def test_trilinear_mask_golden(gpu):
     assert rel_err(out.cpu().numpy(), g["out_f32"]) < FWD_TOL
     plain = Trilinear()(vol, src, tgt, img, n_points=40, **rng)
     assert rel_err(out.sum(1, keepdim=True).cpu().numpy(), plain.cpu().numpy()) < 1e-5
+    # backward (ddrr_trilinear_backward_channels) against the reference's autograd; the
+    # range stays a differentiable function of the rays (its arg-min / arg-max ray)
+    src_c, tgt_c = src.cpu().requires_grad_(), tgt.cpu().requires_grad_()
+    lo, hi = get_alpha_minmax(src_c, tgt_c, torch.tensor(vol.shape), 0.5, 1e-8)
+    src_g, tgt_g = src_c.to(gpu), tgt_c.to(gpu)
+    vol_g, img_g = vol.clone().requires_grad_(), img.clone().requires_grad_()
+    out = Trilinear()(vol_g, src_g, tgt_g, img_g, n_points=40, mask=mask,
+                      alphamin=lo.min().to(gpu), alphamax=hi.max().to(gpu))
+    go = torch.from_numpy(g["grad_out_f32"]).to(gpu)
+    grads = torch.autograd.grad(out, [src_c, tgt_c, img_g, vol_g], go)
+    for name, gr in zip(("g_source", "g_target", "g_img", "g_volume"), grads):
+        assert rel_err(gr.cpu().numpy(), g[name + "_f32"]) < GRAD_TOL, name
 
 
 def test_fused_ncc_kernels(gpu):

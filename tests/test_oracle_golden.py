@@ -77,6 +77,16 @@ def test_siddon_mask_channels():
     assert rel_err(ch.sum(1, keepdims=True), oracle.siddon(vol, src, tgt, img)["out"]) < 1e-12
 
 
+def test_siddon_mask_channel_gradients():
+    """The oracle's channel-wise gradients against the reference's autograd through its
+    scatter_add (fixture generated from the unmodified reference)."""
+    g = golden("siddon_mask")
+    vol, src, tgt, img = _inputs(g, "f64")
+    r = oracle.siddon_channels_grad(vol, g["mask"], src, tgt, img, g["grad_out_f64"])
+    for k in ("g_source", "g_target", "g_img", "g_volume"):
+        assert rel_err(r[k], g[k + "_f64"]) < 1e-10, k
+
+
 TRI_CASES = [
     ("trilinear_global_range", dict(n_points=41), None),
     ("trilinear_explicit_range", dict(n_points=64), (0.31, 0.77)),
