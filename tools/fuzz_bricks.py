@@ -1,0 +1,85 @@
+"""Randomised consistency sweep (development tool, GPU): the volume-stationary brick kernels
+against the per-ray generic kernels over random volume shapes, detector sizes and poses
+(including sources inside / next to the volume and large rotations).
+Usage: python tools/fuzz_bricks.py [--cases 40] [--seed 0]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diffdrr_amd import DRR, convert, ops  # noqa: E402
+from diffdrr_amd.data import make_subject  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=40)
+ap.add_argument("--seed", type=int, default=0)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(a.seed)
+
+
+def ri(lo, hi):
+    return int(torch.randint(lo, hi + 1, (1,), generator=g))
+
+
+def ru(lo, hi, *shape):
+    return lo + (hi - lo) * torch.rand(*shape, generator=g)
+
+
+worst = {"fwd": 0.0, "aux": 0.0, "volgrad": 0.0, "tri": 0.0, "trivol": 0.0}
+for case in range(a.cases):
+    dims = (ri(20, 150), ri(20, 150), ri(20, 150))
+    H, W = ri(2, 90), ri(2, 90)
+    B = ri(1, 5)
+    spacing = tuple(float(x) for x in ru(0.5, 2.0, 3))
+    vol = torch.rand(*dims, generator=g)
+    drr = DRR(make_subject(vol, spacing=spacing), sdd=float(ru(300, 1500, 1)), height=H, width=W,
+              delx=float(ru(0.5, 4.0, 1))).to(dev)
+    kind = case % 4
+    rot = ru(-3.1, 3.1, B, 3) if kind != 0 else ru(-0.3, 0.3, B, 3)
+    if kind == 3:   # source inside or right next to the volume
+        xyz = ru(-0.6, 0.6, B, 3) * torch.tensor(dims) * torch.tensor(spacing)
+    else:
+        xyz = torch.stack([ru(-50, 50, B), ru(200, 1200, B), ru(-50, 50, B)], -1)
+    with torch.no_grad():
+        pose = convert(rot.to(dev), xyz.to(dev), parameterization="euler_angles", convention="ZXY")
+        source, target = drr.detector(pose, None)
+        L = (target - source).norm(dim=-1).contiguous()
+        s = drr.affine_inverse(source).contiguous()
+        t = drr.affine_inverse(target).contiguous()
+    V = drr.density
+    ref, aux_ref, _ = ops.siddon_forward(V, s, t, L, want_aux=True)
+    out, aux = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True)
+    scale = ref.abs().max().item() + 1e-30
+    e_f = (out - ref).abs().max().item() / scale
+    go = torch.rand(ref.shape, generator=g).to(dev)
+    gsb, gtb, gib = ops.siddon_backward_rays(aux, go, s, t, L)
+    gsg, gtg, gig = ops.siddon_backward_rays(aux_ref, go, s, t, L)
+    e_a = ((gtb.sum(1) - gtg.sum(1)).abs().max() / (gtg.sum(1).abs().max() + 1e-30)).item()
+    e_a = max(e_a, ((gib - gig).abs().max() / (gig.abs().max() + 1e-30)).item())
+    gv_ref = ops.siddon_backward_volume(V, s, t, L, go)
+    gv = ops.siddon_backward_volume_bricks(V.shape, s, t, L, go, (H, W))
+    e_v = ((gv - gv_ref).abs().max() / (gv_ref.abs().max() + 1e-30)).item()
+    # trilinear
+    from diffdrr_amd.renderers import get_alpha_minmax
+    lo, hi = get_alpha_minmax(s, t, torch.tensor(V.shape, device=dev), 0.5, 1e-8)
+    amin, amax = lo.min().reshape(1), hi.max().reshape(1)
+    P = ri(20, 300)
+    if min(H, W) >= 2 and amax.item() > amin.item():
+        tr = ops.trilinear_forward(V, s, t, L, amin, amax, n_points=P)
+        tb = ops.trilinear_forward_bricks(V, s, t, L, amin, amax, (H, W), n_points=P)
+        e_t = ((tb - tr).abs().max() / (tr.abs().max() + 1e-30)).item()
+        rv = ops.trilinear_backward(V, s, t, L, go, amin, amax, n_points=P, want_rays=False,
+                                    want_img=False, want_alpha=False, want_volume=True)["g_volume"]
+        bv = ops.trilinear_backward_volume_bricks(V.shape, s, t, L, go, amin, amax, (H, W), n_points=P)
+        e_tv = ((bv - rv).abs().max() / (rv.abs().max() + 1e-30)).item()
+    else:
+        e_t = e_tv = 0.0
+    for k, e in zip(worst, (e_f, e_a, e_v, e_t, e_tv)):
+        worst[k] = max(worst[k], e if e == e else float("inf"))
+    flag = " <<<" if max(e_f, e_v, e_t, e_tv) > 2e-4 or e_a > 5e-3 or e_f != e_f else ""
+    print(f"case {case:3d} kind {kind} dims {dims} det {H}x{W} B {B} P {P}: fwd {e_f:.1e} "
+          f"pose-grad {e_a:.1e} volgrad {e_v:.1e} tri {e_t:.1e} trivol {e_tv:.1e}{flag}", flush=True)
+print("worst", {k: f"{v:.1e}" for k, v in worst.items()})
