@@ -421,7 +421,15 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
         if (w != 0.f) brick_scatter(LdsAbsAdd{fixq}, base, G, s, t, p.shift, p.eps, w);
         return;
     }
-    if (MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_VOLGRAD) {
+    if (MODE == BRICK_TRI_VOLGRAD) {
+        const float a0 = p.amin[0], a1 = p.amax[0];
+        const float w = p.grad_out[r] * L * ((a1 - a0) / (float)(p.n_points - 1));
+        if (w != 0.f)
+            tri_owner_scatter(LdsAbsAdd{fixq}, base, G.lof, G.hif, G.stridef, s, t, p.shift, p.eps,
+                              p.n_points, a0, a1, w);
+        return;
+    }
+    if (MODE == BRICK_TRI_FWD) {
         TriGeom T;  // G.lof holds the first base cell here (set by the kernel)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -431,16 +439,9 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
         const float a0 = p.amin[0], a1 = p.amax[0];
         const float step = (a1 - a0) / (float)(p.n_points - 1);  // renderers.py:235
         float sumT;
-        if (MODE == BRICK_TRI_FWD) {
-            if (tri_brick_march<false>(LdsAbsFetch{}, base, T, s, t, p.shift, p.eps, p.n_points, a0,
-                                       a1, 0.f, sumT))
-                unsafeAtomicAdd(out + r, L * step * sumT);
-        } else {
-            const float w = p.grad_out[r] * L * step;
-            if (w != 0.f)
-                tri_brick_march<true>(LdsAbsAdd{fixq}, base, T, s, t, p.shift, p.eps, p.n_points,
-                                      a0, a1, w, sumT);
-        }
+        if (tri_brick_march<false>(LdsAbsFetch{}, base, T, s, t, p.shift, p.eps, p.n_points, a0, a1,
+                                   0.f, sumT))
+            unsafeAtomicAdd(out + r, L * step * sumT);
         return;
     }
     float I, rec[4];
@@ -471,7 +472,10 @@ template <int MODE>
 __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     BrickArgs p, float *__restrict__ out, float *__restrict__ aux) {
     constexpr bool AUX = MODE == BRICK_FWD_AUX;
-    constexpr bool TRI = MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_VOLGRAD;
+    // TRI: bricks of 31^3 base cells + halo (the marcher's forward); the marcher's volume
+    // gradient (TRI_OWNER) runs on the plain 32^3 voxel bricks, see tri_brick.h
+    constexpr bool TRI = MODE == BRICK_TRI_FWD;
+    constexpr bool TRI_OWNER = MODE == BRICK_TRI_VOLGRAD;
     constexpr bool GRAD = MODE == BRICK_VOLGRAD || MODE == BRICK_TRI_VOLGRAD;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *brick = reinterpret_cast<float *>(smem_raw);
@@ -489,6 +493,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     const unsigned pix_mask = (1u << p.pix_bits) - 1u;
     const int n_chunks = (p.B + kPoseChunk - 1) / kPoseChunk;
     const bool vec_ok = (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.vol) & 15) == 0;
+    const bool vec_out = GRAD && (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.g_volume) & 15) == 0;
     // fixed-point scale of the LDS accumulator (volume-gradient modes): the largest sum a
     // voxel can receive is n_sum (contributions) * wmax (each) -- volgrad_prepare_kernel
     float fixq = 0.f;
@@ -524,13 +529,21 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     } else {
         box = brick_box(p.D, bg, brick_id);
         cells = boxf(box);
+        if (TRI_OWNER) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                // samples whose base cell is lo - 1 .. hi - 1 (g = c <=> plane index c + 1/2)
+                cells.lo[a] = (float)(box.lo[a] - 1) + 0.5f;
+                cells.hi[a] = (float)box.hi[a] + 0.5f;
+            }
+        }
     }
     BrickGeom G = brick_geom(box, p.lay);
     if (TRI) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) G.lof[a] = (float)box.lo[a];
     }
-    const float nscale = TRI ? (float)(p.n_points - 1) / (p.amax[0] - p.amin[0]) : 0.f;
+    const float nscale = (TRI || TRI_OWNER) ? (float)(p.n_points - 1) / (p.amax[0] - p.amin[0]) : 0.f;
     int qn0 = 0, qn1 = 0, qn2 = 0;  // hits waiting per length class (wave-uniform)
 
     for (int ch = 0; ch < n_chunks; ++ch) {
@@ -715,26 +728,26 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         }
     }
     if (GRAD) {
-        // every ray of every pose has been scattered into the LDS accumulator.  Siddon
-        // bricks own their voxels: the gradient is stored.  Trilinear bricks overlap by one
-        // voxel layer (the halo): cells 0 and 31 of an axis are shared with the neighbour
-        // and are added with atomics into the zero-filled gradient, the rest is stored.
+        // every ray of every pose has been scattered into the LDS accumulator, and the brick
+        // owns its voxels (Siddon bricks, and the marcher's owner bricks): the gradient is
+        // complete and is stored, 16 bytes per thread
         __syncthreads();
         for (int row = tid >> 3; row < BRICK * BRICK; row += kBrickThreads >> 3) {
             const int lx = row / BRICK, ly = row - lx * BRICK, q4 = (tid & 7) * 4;
             const int x = box.lo[0] + lx, y = box.lo[1] + ly, z = box.lo[2] + q4;
-            if (x >= 0 && y >= 0 && x < box.hi[0] && y < box.hi[1]) {
+            if (x < box.hi[0] && y < box.hi[1]) {
                 const float *src = brick + lx * p.lay.sx + ly * p.lay.sy + q4;
                 float *g = p.g_volume + ((long)x * p.D.y + y) * p.D.z + z;
-                const bool shell_xy = lx == 0 || lx == BRICK - 1 || ly == 0 || ly == BRICK - 1;
+                float val[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (z + k < 0 || z + k >= box.hi[2]) continue;
-                    const float val = fixq != 0.f ? (float)__float_as_int(src[k]) / fixq : src[k];
-                    if (TRI && (shell_xy || q4 + k == 0 || q4 + k == BRICK - 1))
-                        unsafeAtomicAdd(g + k, val);
-                    else
-                        g[k] = val;
+                for (int k = 0; k < 4; ++k)
+                    val[k] = fixq != 0.f ? (float)__float_as_int(src[k]) / fixq : src[k];
+                if (vec_out && z + 4 <= box.hi[2]) {
+                    *reinterpret_cast<float4 *>(g) = make_float4(val[0], val[1], val[2], val[3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (z + k < box.hi[2]) g[k] = val[k];
                 }
             }
         }
@@ -1457,8 +1470,7 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
                            target, img, grad_out, N, det_w, p.D, voxel_shift, eps, n_points, amin,
                            amax, p.work);
     }
-    const bool tri = mode == BRICK_TRI_FWD || mode == BRICK_TRI_VOLGRAD;
-    const BrickGrid bg = tri ? tri_brick_grid(p.D) : brick_grid(p.D);
+    const BrickGrid bg = mode == BRICK_TRI_FWD ? tri_brick_grid(p.D) : brick_grid(p.D);
     const int n_bricks = bg.nx * bg.ny * bg.nz;
     const dim3 grid(n_bricks < n_cu[dev] ? n_bricks : n_cu[dev]), block(kBrickThreads);
     if (mode == BRICK_TRI_FWD)
@@ -1546,9 +1558,10 @@ int ddrr_trilinear_backward_volume_bricks(int dx, int dy, int dz, const float *s
     if (n_points < 2) return fail(-1, "n_points must be >= 2");
     if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(g_volume, 0, sizeof(float) * (size_t)dx * dy * dz, st);
-    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
-    if (B == 0) return 0;
+    if (B == 0) {
+        hipError_t e = hipMemsetAsync(g_volume, 0, sizeof(float) * (size_t)dx * dy * dz, st);
+        return e == hipSuccess ? 0 : fail_hip(e, "hipMemsetAsync");
+    }
     return launch_bricks(BRICK_TRI_VOLGRAD, nullptr, dx, dy, dz, source, target, img, grad_out, B,
                          det_h, det_w, voxel_shift, eps, nullptr, nullptr, g_volume, st,
                          "ddrr_trilinear_backward_volume_bricks", n_points, alphamin, alphamax);

@@ -11,6 +11,14 @@
 // is what the far corners need; voxels outside the volume are staged as zeros, which IS the
 // zero padding.  Every brick evaluates a sample's g with the same expression and keeps it
 // only if its base corner is inside, so the bricks partition the samples exactly.
+//
+// The volume gradient uses OWNER bricks instead (tri_owner_scatter): a brick owns the 32^3
+// voxels [lo, lo + 32) -- the plain Siddon brick grid -- and visits every sample whose 8-cell
+// touches one of them (base cell in [lo - 1, lo + 31]), adding only the corners it owns.
+// Samples next to a brick face are visited by 2 (4, 8) bricks, ~20 % more visits in all, but a
+// voxel's gradient is complete in one brick's LDS accumulator and is STORED: no halo, no global
+// atomics (the halo layers of base-cell bricks cost 5768 scattered atomics per brick: 1.7 of
+// 2.6 ms at 512^3, one pose).
 #pragma once
 
 #include "brick_core.h"
@@ -136,6 +144,71 @@ DDRR_HD bool tri_brick_march(const Acc &acc, float base, const TriGeom &G, const
     }
     sumT = sum;
     return true;
+}
+
+// Volume gradient of one ray inside one OWNER brick: voxels [lo, hi) per axis (hi - lo <= 32),
+// staged at LDS offset (v - lo) . stride.  `acc(addr, value)` adds into the LDS accumulator;
+// corners outside [lo, hi) belong to a neighbour (or lie outside the volume) and are skipped.
+template <class Acc>
+DDRR_HD void tri_owner_scatter(const Acc &acc, float base, const float lo[3], const float hi[3],
+                               const float stridef[3], const float s[3], const float t[3],
+                               float shift, float eps, int P, float amin, float amax, float w) {
+    const float go = shift - 0.5f;  // align_corners = False: g = x + shift - 1/2
+    float d[3], entry = -INFINITY, exit = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        d[a] = (t[a] - s[a]) + eps;
+        const float g0 = s[a] + go;
+        // base cells lo - 1 .. hi - 1  <=>  g in [lo - 1, hi)
+        const float a1 = (lo[a] - 1.f - g0) / d[a], a2 = (hi[a] - g0) / d[a];
+        entry = fmaxf(entry, fminf(a1, a2));
+        exit = fminf(exit, fmaxf(a1, a2));
+    }
+    const float span = amax - amin;
+    if (!(entry < exit) || !(span > 0.f)) return;
+    const float lstep = 1.0f / (float)(P - 1), sc = (float)(P - 1) / span;
+    const float f0 = fminf(fmaxf(floorf((entry - amin) * sc) - 1.f, 0.f), (float)P);
+    const float f1 = fminf(fmaxf(ceilf((exit - amin) * sc) + 1.f, -1.f), (float)(P - 1));
+    if (!(f0 <= f1)) return;
+    const int m0 = (int)f0, m1 = (int)f1;
+    const float offc = fmaf(-lo[0], stridef[0], fmaf(-lo[1], stridef[1], fmaf(-lo[2], stridef[2], base)));
+    const float sx = stridef[0], sy = stridef[1];
+    for (int m = m0; m <= m1; ++m) {
+        const float al = fmaf(lin01(m, P, lstep), span, amin);  // renderers.py:224-225
+        const float gx = fmaf(al, d[0], s[0]) + go;
+        const float gy = fmaf(al, d[1], s[1]) + go;
+        const float gz = fmaf(al, d[2], s[2]) + go;
+        const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+        // which of the two corners per axis this brick owns
+        const bool x0 = fx >= lo[0] && fx < hi[0], x1 = fx + 1.f >= lo[0] && fx + 1.f < hi[0];
+        const bool y0 = fy >= lo[1] && fy < hi[1], y1 = fy + 1.f >= lo[1] && fy + 1.f < hi[1];
+        const bool z0 = fz >= lo[2] && fz < hi[2], z1 = fz + 1.f >= lo[2] && fz + 1.f < hi[2];
+        if (!((x0 || x1) && (y0 || y1) && (z0 || z1))) continue;
+        const float ax = gx - fx, ay = gy - fy, az = gz - fz;
+        const float o00 = fmaf(fx, sx, fmaf(fy, sy, fmaf(fz, 4.f, offc)));
+        // (offsets of corners that are not owned may be negative: never converted or used)
+        const float wx0 = 1.f - ax, wy0 = 1.f - ay, wz0 = 1.f - az;
+        if (x0 && y0) {
+            const unsigned a00 = (unsigned)(int)(o00 + (z0 ? 0.f : 4.f));
+            if (z0) acc(a00, w * (wx0 * wy0 * wz0));
+            if (z1) acc(z0 ? a00 + 4u : a00, w * (wx0 * wy0 * az));
+        }
+        if (x1 && y0) {
+            const unsigned a10 = (unsigned)(int)(o00 + sx + (z0 ? 0.f : 4.f));
+            if (z0) acc(a10, w * (ax * wy0 * wz0));
+            if (z1) acc(z0 ? a10 + 4u : a10, w * (ax * wy0 * az));
+        }
+        if (x0 && y1) {
+            const unsigned a01 = (unsigned)(int)(o00 + sy + (z0 ? 0.f : 4.f));
+            if (z0) acc(a01, w * (wx0 * ay * wz0));
+            if (z1) acc(z0 ? a01 + 4u : a01, w * (wx0 * ay * az));
+        }
+        if (x1 && y1) {
+            const unsigned a11 = (unsigned)(int)(o00 + sx + sy + (z0 ? 0.f : 4.f));
+            if (z0) acc(a11, w * (ax * ay * wz0));
+            if (z1) acc(z0 ? a11 + 4u : a11, w * (ax * ay * az));
+        }
+    }
 }
 
 }  // namespace ddrr

@@ -180,8 +180,9 @@ int ddrr_trilinear_forward_channels(const float *volume, const unsigned char *la
  * cells (+1 voxel halo, staged as 32^3 in LDS; voxels outside the volume staged as zeros =
  * the zero padding); a sample belongs to the brick holding floor(index coordinate).
  * _forward_bricks: out (B, N) zero-filled by the call and accumulated with atomics.
- * _backward_volume_bricks: g_volume (dx, dy, dz) zero-filled by the call; each brick
- * accumulates in LDS (ds_add_f32) and is written once (halo layers with atomics).
+ * _backward_volume_bricks: g_volume (dx, dy, dz) is fully written, no zero fill needed: on
+ * 32^3 voxel bricks that OWN their voxels (a sample is visited by every brick owning one of
+ * its 8 corners), accumulated in LDS and stored once -- no global atomics.
  * Replace renderers.py:205-241 and grid_sampler_3d_backward (bilinear) like the two
  * entries above, which remain the path for arbitrary ray lists and other modes. */
 int ddrr_trilinear_forward_bricks(const float *volume, int dx, int dy, int dz,

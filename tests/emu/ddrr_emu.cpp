@@ -170,6 +170,78 @@ int tri_bricks_host(const float *volume, int dx, int dy, int dz, const float *so
     }
     return 0;
 }
+
+// The marcher's volume gradient on OWNER bricks (tri_owner_scatter): per 32^3 voxel brick,
+// every candidate pixel of every pose scatters the corners the brick owns into the staged
+// accumulator, which is then stored (each voxel exactly once: g_volume needs no zero fill).
+int tri_owner_host(int dx, int dy, int dz, const float *source, const float *target,
+                   const float *img, const float *grad_out, int B, int det_h, int det_w,
+                   float voxel_shift, float eps, int n_points, float amin, float amax,
+                   float *g_volume) {
+    const Dims D{dx, dy, dz};
+    const int N = det_h * det_w;
+    const BrickGrid bg = brick_grid(D);
+    const BrickLayout lay{33, 32 * 33 + 1};
+    std::vector<float> brick((size_t)brick_floats(lay));
+    struct HostAddB {
+        float *base;
+        void operator()(unsigned off, float v) const { base[off >> 2] += v; }
+    };
+    const float step = (amax - amin) / (float)(n_points - 1);
+    const float nscale = (float)(n_points - 1) / (amax - amin);
+    for (int id = 0; id < bg.nx * bg.ny * bg.nz; ++id) {
+        const Box box = brick_box(D, bg, id);
+        const BrickGeom G = brick_geom(box, lay);
+        BoxF cells;
+        for (int a = 0; a < 3; ++a) {
+            cells.lo[a] = (float)(box.lo[a] - 1) + 0.5f;
+            cells.hi[a] = (float)box.hi[a] + 0.5f;
+        }
+        std::fill(brick.begin(), brick.end(), 0.f);
+        for (int b = 0; b < B; ++b) {
+            const PoseGrid pg = pose_grid(source + (long)b * 3, target + (long)b * N * 3, det_h,
+                                          det_w);
+            const PixBox pb = project_brick_grid(pg, det_h, det_w, cells, voxel_shift);
+            const BrickRow row = brick_row(pg, pb, cells, voxel_shift, eps, nscale);
+            std::vector<char> cand((size_t)N, 0);
+            auto scatter = [&](int pix, float *acc) {
+                const long r = (long)b * N + pix;
+                float s[3], t[3];
+                for (int a = 0; a < 3; ++a) {
+                    s[a] = source[(long)b * 3 + a];
+                    t[a] = target[r * 3 + a];
+                }
+                const float L = img ? img[r] : 1.f;
+                tri_owner_scatter(HostAddB{acc}, 0.f, G.lof, G.hif, G.stridef, s, t, voxel_shift,
+                                  eps, n_points, amin, amax, grad_out[r] * L * step);
+            };
+            for (int local = 0; local < row.count; ++local) {
+                int pix;
+                float n_est;
+                if (!brick_candidate(row, local, det_w, pix, n_est)) continue;
+                cand[pix] = 1;
+                scatter(pix, brick.data());
+            }
+            // phase A must not lose a pixel with samples that touch this brick
+            std::vector<float> probe(brick.size());
+            for (int pix = 0; pix < N; ++pix) {
+                if (cand[pix] || grad_out[(long)b * N + pix] == 0.f) continue;
+                std::fill(probe.begin(), probe.end(), 0.f);
+                scatter(pix, probe.data());
+                for (float v : probe)
+                    if (v != 0.f) abort();
+            }
+        }
+        for (int lx = 0; lx < BRICK; ++lx)
+            for (int ly = 0; ly < BRICK; ++ly)
+                for (int lz = 0; lz < BRICK; ++lz) {
+                    const int x = box.lo[0] + lx, y = box.lo[1] + ly, z = box.lo[2] + lz;
+                    if (x >= box.hi[0] || y >= box.hi[1] || z >= box.hi[2]) continue;
+                    g_volume[((long)x * dy + y) * dz + z] = brick[lx * lay.sx + ly * lay.sy + lz];
+                }
+    }
+    return 0;
+}
 }  // namespace
 
 extern "C" {
@@ -519,10 +591,10 @@ int ddrr_trilinear_backward_volume_bricks(int dx, int dy, int dz, const float *s
                                           float voxel_shift, float eps, int n_points,
                                           const float *alphamin, const float *alphamax,
                                           float *g_volume, void *) {
-    memset(g_volume, 0, sizeof(float) * (size_t)dx * dy * dz);
-    return tri_bricks_host<true>(nullptr, dx, dy, dz, source, target, img, grad_out, B, det_h,
-                                 det_w, voxel_shift, eps, n_points, *alphamin, *alphamax, nullptr,
-                                 g_volume);
+    // poison: every voxel must be stored by exactly one owner brick
+    for (size_t i = 0; i < (size_t)dx * dy * dz; ++i) g_volume[i] = NAN;
+    return tri_owner_host(dx, dy, dz, source, target, img, grad_out, B, det_h, det_w, voxel_shift,
+                          eps, n_points, *alphamin, *alphamax, g_volume);
 }
 
 int ddrr_siddon_backward_rays(const float *aux, int aux_layout, const float *grad_out,
