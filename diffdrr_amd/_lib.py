@@ -15,7 +15,7 @@ from ctypes import c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffdrr_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 REDUCE_SUM, REDUCE_MAX = 0, 1
 LOOKUP_STEP, LOOKUP_MID_NEAREST, LOOKUP_MID_TRILINEAR = 0, 1, 2
@@ -50,7 +50,9 @@ _SIGNATURES = {
     "ddrr_trilinear_forward_channels": [_P, _P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _F, _F, _I,
                                         _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "ddrr_trilinear_forward_bricks": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _P,
-                                      _P, _P],
+                                      _P, _P, _P],
+    "ddrr_trilinear_backward_rays": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P,
+                                     _P],
     "ddrr_trilinear_backward_volume_bricks": [_I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I,
                                               _P, _P, _P, _P],
     "ddrr_pose_euler_forward": [_P, _P, _I, _I, _I, _P, _I, _P, _P],

@@ -368,6 +368,7 @@ constexpr int BRICK_FWD_AUX = 1;  // out + planar backward record
 constexpr int BRICK_VOLGRAD = 2;  // g_volume (the brick in LDS is the accumulator)
 constexpr int BRICK_TRI_FWD = 3;      // trilinear marcher: out
 constexpr int BRICK_TRI_VOLGRAD = 4;  // trilinear marcher: g_volume
+constexpr int BRICK_TRI_FWD_AUX = 5;  // trilinear marcher: planar backward record (out follows from it)
 
 inline size_t brick_lds_bytes(const BrickLayout &lay) {
     return (size_t)brick_floats(lay) * 4 + (size_t)kBrickWaves * kBuckets * kQueueCap * 4 +
@@ -429,7 +430,7 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
                               p.n_points, a0, a1, w);
         return;
     }
-    if (MODE == BRICK_TRI_FWD) {
+    if (MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_FWD_AUX) {
         TriGeom T;  // G.lof holds the first base cell here (set by the kernel)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -437,11 +438,19 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
             T.stridef[a] = G.stridef[a];
         }
         const float a0 = p.amin[0], a1 = p.amax[0];
-        const float step = (a1 - a0) / (float)(p.n_points - 1);  // renderers.py:235
-        float sumT;
-        if (tri_brick_march<false>(LdsAbsFetch{}, base, T, s, t, p.shift, p.eps, p.n_points, a0, a1,
-                                   0.f, sumT))
+        float sumT, rec[6];
+        if (!tri_brick_march<MODE == BRICK_TRI_FWD_AUX>(LdsAbsFetch{}, base, T, s, t, p.shift, p.eps,
+                                                        p.n_points, a0, a1, sumT, rec))
+            return;
+        if (MODE == BRICK_TRI_FWD) {
+            const float step = (a1 - a0) / (float)(p.n_points - 1);  // renderers.py:235
             unsafeAtomicAdd(out + r, L * step * sumT);
+        } else {
+            // the record alone: out = L step sumT is formed from plane 0 afterwards
+            unsafeAtomicAdd(aux + r, sumT);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) unsafeAtomicAdd(aux + (unsigned)(k + 1) * p.aux_plane + r, rec[k]);
+        }
         return;
     }
     float I, rec[4];
@@ -474,7 +483,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     constexpr bool AUX = MODE == BRICK_FWD_AUX;
     // TRI: bricks of 31^3 base cells + halo (the marcher's forward); the marcher's volume
     // gradient (TRI_OWNER) runs on the plain 32^3 voxel bricks, see tri_brick.h
-    constexpr bool TRI = MODE == BRICK_TRI_FWD;
+    constexpr bool TRI = MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_FWD_AUX;
     constexpr bool TRI_OWNER = MODE == BRICK_TRI_VOLGRAD;
     constexpr bool GRAD = MODE == BRICK_VOLGRAD || MODE == BRICK_TRI_VOLGRAD;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -665,7 +674,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                 // is per line, not per lane (measured: 3.55 -> 2.74 ms; without the record
                 // the per-lane classes win, 1.87 vs 2.01 ms).
                 float n_grp = hit ? n_est : 0.f;
-                if (AUX) {
+                if (AUX || MODE == BRICK_TRI_FWD_AUX) {
                     n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
                         0, __builtin_bit_cast(int, n_grp), 0xB1, 0xf, 0xf, true)));   // lane ^ 1
                     n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
@@ -1201,6 +1210,48 @@ __global__ __launch_bounds__(kBlock) void trilinear_bwd_channels_kernel(
     }
 }
 
+// out = L * step * sumT from plane 0 of the marcher's planar record (the record launch
+// does not touch `out`).
+__global__ __launch_bounds__(kBlock) void tri_out_from_record_kernel(
+    const float *__restrict__ aux, const float *__restrict__ img, long R, int n_points,
+    const float *__restrict__ amin, const float *__restrict__ amax, float *__restrict__ out) {
+    const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= R) return;
+    const float step = (amax[0] - amin[0]) / (float)(n_points - 1);  // renderers.py:235
+    out[r] = (img ? img[r] : 1.f) * step * aux[r];
+}
+
+// Ray / range gradients of the march from the planar record of ddrr_trilinear_forward_bricks
+// (planes sumT, sum dT_xyz, sum alpha dT_xyz of R floats each): elementwise.
+__global__ __launch_bounds__(kBlock) void trilinear_bwd_record_kernel(
+    const float *__restrict__ aux, const float *__restrict__ grad_out,
+    const float *__restrict__ source, const float *__restrict__ target,
+    const float *__restrict__ img, long R, int N, float eps, int n_points,
+    const float *__restrict__ amin, const float *__restrict__ amax, float *__restrict__ g_source,
+    float *__restrict__ g_target, float *__restrict__ g_img, float *__restrict__ g_alpha) {
+    const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= R) return;
+    const long b = r / N;
+    const float *sp = source + b * 3, *tp = target + r * 3;
+    const float s[3] = {sp[0], sp[1], sp[2]}, t[3] = {tp[0], tp[1], tp[2]};
+    const float A[3] = {aux[R + r], aux[2 * R + r], aux[3 * R + r]};
+    const float Bv[3] = {aux[4 * R + r], aux[5 * R + r], aux[6 * R + r]};
+    const float g = grad_out[r], L = img ? img[r] : 1.f;
+    const float a0 = amin[0], a1 = amax[0];
+    const MarchGrad m = trilinear_backward_from_record(aux[r], A, Bv, s, t, eps, n_points, a0, a1,
+                                                       g * L);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (g_source) g_source[r * 3 + a] = m.gs[a];
+        if (g_target) g_target[r * 3 + a] = m.gt[a];
+    }
+    if (g_img) g_img[r] = g * m.sumT * ((a1 - a0) / (float)(n_points - 1));
+    if (g_alpha) {
+        g_alpha[r * 2 + 0] = m.g_amin;
+        g_alpha[r * 2 + 1] = m.g_amax;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 
 int g_xcd_swizzle = 1;
@@ -1424,7 +1475,7 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     p.n_points = n_points;
     p.amin = amin;
     p.amax = amax;
-    if (mode == BRICK_TRI_FWD || mode == BRICK_TRI_VOLGRAD) {
+    if (mode == BRICK_TRI_FWD || mode == BRICK_TRI_VOLGRAD || mode == BRICK_TRI_FWD_AUX) {
         p.t1 = g_tri_t1;
         p.t2 = g_tri_t2;
     }
@@ -1432,7 +1483,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     hipError_t e;
     static bool attr_set = false;  // raise the dynamic-LDS limit once per process
     if (!attr_set) {
-        const void *fns[5] = {reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_FWD>),
+        const void *fns[6] = {reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_FWD_AUX>),
+                              reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_FWD>),
                               reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_FWD_AUX>),
                               reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_VOLGRAD>),
                               reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_FWD>),
@@ -1470,11 +1522,15 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
                            target, img, grad_out, N, det_w, p.D, voxel_shift, eps, n_points, amin,
                            amax, p.work);
     }
-    const BrickGrid bg = mode == BRICK_TRI_FWD ? tri_brick_grid(p.D) : brick_grid(p.D);
+    const BrickGrid bg = (mode == BRICK_TRI_FWD || mode == BRICK_TRI_FWD_AUX) ? tri_brick_grid(p.D)
+                                                                              : brick_grid(p.D);
     const int n_bricks = bg.nx * bg.ny * bg.nz;
     const dim3 grid(n_bricks < n_cu[dev] ? n_bricks : n_cu[dev]), block(kBrickThreads);
     if (mode == BRICK_TRI_FWD)
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_FWD>, grid, block, lds, st, p, out, aux);
+    else if (mode == BRICK_TRI_FWD_AUX)
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_FWD_AUX>, grid, block, lds, st, p, out,
+                           aux);
     else if (mode == BRICK_TRI_VOLGRAD)
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_VOLGRAD>, grid, block, lds, st, p, out,
                            aux);
@@ -1530,7 +1586,7 @@ int ddrr_trilinear_forward_bricks(const float *volume, int dx, int dy, int dz,
                                   const float *source, const float *target, const float *img,
                                   int B, int det_h, int det_w, float voxel_shift, float eps,
                                   int n_points, const float *alphamin, const float *alphamax,
-                                  float *out, void *stream) {
+                                  float *out, float *aux, void *stream) {
     const int N = det_h * det_w;
     if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
     if (!out || !alphamin || !alphamax) return fail(-1, "null out / alphamin / alphamax");
@@ -1538,11 +1594,38 @@ int ddrr_trilinear_forward_bricks(const float *volume, int dx, int dy, int dz,
     if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * N, st);
+    const long R = (long)B * N;
+    hipError_t e = hipMemsetAsync(aux ? aux : out, 0,
+                                  sizeof(float) * (size_t)R * (aux ? DDRR_TRI_AUX_PLANES : 1), st);
     if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
-    return launch_bricks(BRICK_TRI_FWD, volume, dx, dy, dz, source, target, img, nullptr, B, det_h,
-                         det_w, voxel_shift, eps, out, nullptr, nullptr, st,
-                         "ddrr_trilinear_forward_bricks", n_points, alphamin, alphamax);
+    if (!aux)
+        return launch_bricks(BRICK_TRI_FWD, volume, dx, dy, dz, source, target, img, nullptr, B,
+                             det_h, det_w, voxel_shift, eps, out, nullptr, nullptr, st,
+                             "ddrr_trilinear_forward_bricks", n_points, alphamin, alphamax);
+    if (int rc = launch_bricks(BRICK_TRI_FWD_AUX, volume, dx, dy, dz, source, target, img, nullptr,
+                               B, det_h, det_w, voxel_shift, eps, out, aux, nullptr, st,
+                               "ddrr_trilinear_forward_bricks", n_points, alphamin, alphamax))
+        return rc;
+    hipLaunchKernelGGL(tri_out_from_record_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, st, aux, img, R, n_points, alphamin, alphamax, out);
+    return finish("ddrr_trilinear_forward_bricks");
+}
+
+int ddrr_trilinear_backward_rays(const float *aux, const float *grad_out, const float *source,
+                                 const float *target, const float *img, int B, int N, float eps,
+                                 int n_points, const float *alphamin, const float *alphamax,
+                                 float *g_source, float *g_target, float *g_img, float *g_alpha,
+                                 void *stream) {
+    if (!aux || !grad_out || !source || !target || !alphamin || !alphamax)
+        return fail(-1, "null pointer");
+    if (B < 0 || N < 0) return fail(-1, "negative batch or ray count");
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    const long R = (long)B * N;
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(trilinear_bwd_record_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, (hipStream_t)stream, aux, grad_out, source, target, img, R,
+                       N, eps, n_points, alphamin, alphamax, g_source, g_target, g_img, g_alpha);
+    return finish("ddrr_trilinear_backward_rays");
 }
 
 int ddrr_trilinear_backward_volume_bricks(int dx, int dy, int dz, const float *source,

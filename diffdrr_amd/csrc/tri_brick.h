@@ -60,18 +60,22 @@ DDRR_HD TriGeom tri_geom(const int lo[3], const BrickLayout &lay) {
     return G;
 }
 
-// March one ray through one brick.
-//   SCATTER = false: sumT += T of every sample whose base corner is in the brick
-//                    (`acc(addr)` fetches a voxel of the LDS copy);
-//   SCATTER = true : the sample's 8 corner weights times `w` are added to the LDS
-//                    accumulator (`acc(addr, value)`): the volume gradient, d out / d V[c] =
-//                    L step w_c (grid_sampler_3d_backward, bilinear).
+constexpr int TRI_AUX_PLANES = 7;  // sum T, sum dT (3), sum alpha dT (3)
+
+// March one ray through one brick: sumT += T of every sample whose base corner is in the brick
+// (`acc(addr)` fetches a voxel of the LDS copy).  AUX: also the backward record of those
+// samples, rec = {sum dT_x, dT_y, dT_z, sum alpha dT_x, dT_y, dT_z} with dT the gradient of the
+// zero-padded trilinear interpolant w.r.t. the index coordinates (fetch_trilinear's `grad`);
+// everything trilinear_backward_ray needs follows from it: d = t - s + eps is constant along
+// the ray, so sum (dT . d) = (sum dT) . d and sum u (dT . d) = ((sum alpha dT) . d - alphamin
+// (sum dT) . d) / (alphamax - alphamin).
 // `base` is what the accessor wants added to the brick-relative byte offset.
-template <bool SCATTER, class Acc>
+template <bool AUX, class Acc>
 DDRR_HD bool tri_brick_march(const Acc &acc, float base, const TriGeom &G, const float s[3],
                              const float t[3], float shift, float eps, int P, float amin,
-                             float amax, float w, float &sumT) {
+                             float amax, float &sumT, float rec[6]) {
     sumT = 0.f;
+    if (AUX) rec[0] = rec[1] = rec[2] = rec[3] = rec[4] = rec[5] = 0.f;
     const float go = shift - 0.5f;  // align_corners = False: g = x + shift - 1/2
     float d[3], entry = -INFINITY, exit = INFINITY;
 #pragma unroll
@@ -94,7 +98,7 @@ DDRR_HD bool tri_brick_march(const Acc &acc, float base, const TriGeom &G, const
     const float offc = fmaf(-G.lo[0], G.stridef[0],
                             fmaf(-G.lo[1], G.stridef[1], fmaf(-G.lo[2], G.stridef[2], base)));
     const float sx = G.stridef[0], sy = G.stridef[1];
-    float sum = 0.f;
+    float sum = 0.f, Ax = 0.f, Ay = 0.f, Az = 0.f, Bx = 0.f, By = 0.f, Bz = 0.f;
     for (int m = m0; m <= m1; ++m) {
         const float al = fmaf(lin01(m, P, lstep), span, amin);  // renderers.py:224-225
         const float gx = fmaf(al, d[0], s[0]) + go;
@@ -110,40 +114,73 @@ DDRR_HD bool tri_brick_march(const Acc &acc, float base, const TriGeom &G, const
         const unsigned a00 = (unsigned)(int)o00;
         const unsigned a10 = (unsigned)(int)(o00 + sx), a01 = (unsigned)(int)(o00 + sy);
         const unsigned a11 = (unsigned)(int)(o00 + sx + sy);
-        if constexpr (!SCATTER) {
-            // aten grid_sampler_3d, corner order of trilinear_core.h fetch_trilinear
-            float T = 0.f;
-            {
-                const float v0 = acc(a00), v1 = acc(a00 + 4u);
-                T = fmaf((1.f - ax) * (1.f - ay), fmaf(az, v1 - v0, v0), T);
-            }
-            {
-                const float v0 = acc(a10), v1 = acc(a10 + 4u);
-                T = fmaf(ax * (1.f - ay), fmaf(az, v1 - v0, v0), T);
-            }
-            {
-                const float v0 = acc(a01), v1 = acc(a01 + 4u);
-                T = fmaf((1.f - ax) * ay, fmaf(az, v1 - v0, v0), T);
-            }
-            {
-                const float v0 = acc(a11), v1 = acc(a11 + 4u);
-                T = fmaf(ax * ay, fmaf(az, v1 - v0, v0), T);
-            }
-            sum += T;
-        } else {
-            const float wx0 = 1.f - ax, wy0 = 1.f - ay, wz0 = 1.f - az;
-            acc(a00, w * (wx0 * wy0 * wz0));
-            acc(a00 + 4u, w * (wx0 * wy0 * az));
-            acc(a10, w * (ax * wy0 * wz0));
-            acc(a10 + 4u, w * (ax * wy0 * az));
-            acc(a01, w * (wx0 * ay * wz0));
-            acc(a01 + 4u, w * (wx0 * ay * az));
-            acc(a11, w * (ax * ay * wz0));
-            acc(a11 + 4u, w * (ax * ay * az));
+        // aten grid_sampler_3d, corner order of trilinear_core.h fetch_trilinear: the four
+        // (x, y) corner columns, each interpolated along z first
+        const float v000 = acc(a00), v001 = acc(a00 + 4u), v100 = acc(a10), v101 = acc(a10 + 4u);
+        const float v010 = acc(a01), v011 = acc(a01 + 4u), v110 = acc(a11), v111 = acc(a11 + 4u);
+        const float wx0 = 1.f - ax, wy0 = 1.f - ay;
+        const float dz00 = v001 - v000, dz10 = v101 - v100, dz01 = v011 - v010, dz11 = v111 - v110;
+        const float l00 = fmaf(az, dz00, v000), l10 = fmaf(az, dz10, v100);
+        const float l01 = fmaf(az, dz01, v010), l11 = fmaf(az, dz11, v110);
+        float T = (wx0 * wy0) * l00;
+        T = fmaf(ax * wy0, l10, T);
+        T = fmaf(wx0 * ay, l01, T);
+        T = fmaf(ax * ay, l11, T);
+        sum += T;
+        if (AUX) {
+            // fetch_trilinear's gX, gY, gZ in the same summation order
+            float gX = -wy0 * l00;
+            gX = fmaf(wy0, l10, gX);
+            gX = fmaf(-ay, l01, gX);
+            gX = fmaf(ay, l11, gX);
+            float gY = -wx0 * l00;
+            gY = fmaf(-ax, l10, gY);
+            gY = fmaf(wx0, l01, gY);
+            gY = fmaf(ax, l11, gY);
+            float gZ = (wx0 * wy0) * dz00;
+            gZ = fmaf(ax * wy0, dz10, gZ);
+            gZ = fmaf(wx0 * ay, dz01, gZ);
+            gZ = fmaf(ax * ay, dz11, gZ);
+            Ax += gX;
+            Ay += gY;
+            Az += gZ;
+            Bx = fmaf(al, gX, Bx);
+            By = fmaf(al, gY, By);
+            Bz = fmaf(al, gZ, Bz);
         }
     }
     sumT = sum;
+    if (AUX) {
+        rec[0] = Ax, rec[1] = Ay, rec[2] = Az;
+        rec[3] = Bx, rec[4] = By, rec[5] = Bz;
+    }
     return true;
+}
+
+// Backward of the sum-reduced march from the record of tri_brick_march<AUX> (the sums over
+// ALL bricks): what trilinear_backward_ray computes by marching (align_corners = False, so
+// d(index coordinate)/dx = 1).  gl = grad_out * ray length.
+DDRR_HD MarchGrad trilinear_backward_from_record(float sumT, const float A[3], const float Bv[3],
+                                                 const float s[3], const float t[3], float eps,
+                                                 int P, float amin, float amax, float gl) {
+    MarchGrad r;
+    const float span = amax - amin, step = span / (float)(P - 1);
+    const float k = gl * step;
+    float Cd = 0.f, Bd = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float d = (t[a] - s[a]) + eps;
+        r.gs[a] = k * (A[a] - Bv[a]);  // sum (1 - alpha) dT
+        r.gt[a] = k * Bv[a];           // sum alpha dT
+        Cd = fmaf(A[a], d, Cd);
+        Bd = fmaf(Bv[a], d, Bd);
+    }
+    const float Cu = span > 0.f ? (Bd - amin * Cd) / span : 0.f;  // sum u (dT . d)
+    const float ws = gl * sumT / (float)(P - 1);  // through step = (amax - amin)/(P-1)
+    r.g_amin = k * (Cd - Cu) - ws;
+    r.g_amax = k * Cu + ws;
+    r.sumT = sumT;
+    return r;
 }
 
 // Volume gradient of one ray inside one OWNER brick: voxels [lo, hi) per axis (hi - lo <= 32),

@@ -439,10 +439,14 @@ def trilinear_forward_channels(volume, labels_u8, n_channels, source, target, im
     return out
 
 
+TRI_AUX_PLANES = 7  # sum T, sum dT_xyz, sum alpha dT_xyz (include/diffdrr_hip.h)
+
+
 def trilinear_forward_bricks(volume, source, target, img, alphamin, alphamax, det, *,
-                             n_points=500, voxel_shift=0.5, eps=1e-8):
+                             n_points=500, voxel_shift=0.5, eps=1e-8, want_aux=False):
     """Detector-grid trilinear march (bilinear, sum, align_corners=False) through the
-    volume-stationary brick kernel.  -> out (B,N)"""
+    volume-stationary brick kernel.  -> out (B,N), or (out, aux (7,B,N)) with ``want_aux``:
+    the planar backward record for :func:`trilinear_backward_rays`."""
     B, N = _check_rays(volume, source, target, img)
     H, W = int(det[0]), int(det[1])
     if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
@@ -450,12 +454,40 @@ def trilinear_forward_bricks(volume, source, target, img, alphamin, alphamax, de
     volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
     img = None if img is None else img.contiguous()
     out = torch.empty(B, N, dtype=torch.float32, device=volume.device)
+    aux = torch.empty(TRI_AUX_PLANES, B, N, dtype=torch.float32, device=volume.device) \
+        if want_aux else None
+    if not _empty(B, N):
+        _launch("ddrr_trilinear_forward_bricks", volume.device, volume.data_ptr(), *volume.shape,
+                source.data_ptr(), target.data_ptr(), _ptr(img), B, H, W, float(voxel_shift),
+                float(eps), int(n_points), alphamin.data_ptr(), alphamax.data_ptr(),
+                out.data_ptr(), _ptr(aux))
+    return (out, aux) if want_aux else out
+
+
+def trilinear_backward_rays(aux, grad_out, source, target, img, alphamin, alphamax, *,
+                            n_points=500, eps=1e-8, want_rays=True, want_img=True,
+                            want_alpha=True):
+    """Ray / range gradients of the march from the record of :func:`trilinear_forward_bricks`;
+    results as :func:`trilinear_backward` (without g_volume)."""
+    B, N, _ = target.shape
+    dev = target.device
+    _require_gpu(target)
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    g_source = new(B, N, 3) if want_rays else None
+    g_target = new(B, N, 3) if want_rays else None
+    g_img = new(B, N) if want_img else None
+    g_alpha = new(B, N, 2) if want_alpha else None
+    res = {"g_source": g_source, "g_target": g_target, "g_img": g_img, "g_alpha": g_alpha,
+           "g_volume": None}
     if _empty(B, N):
-        return out
-    _launch("ddrr_trilinear_forward_bricks", volume.device, volume.data_ptr(), *volume.shape,
-            source.data_ptr(), target.data_ptr(), _ptr(img), B, H, W, float(voxel_shift),
-            float(eps), int(n_points), alphamin.data_ptr(), alphamax.data_ptr(), out.data_ptr())
-    return out
+        return res
+    source, target, grad_out = source.contiguous(), target.contiguous(), grad_out.contiguous()
+    img = None if img is None else img.contiguous()
+    _launch("ddrr_trilinear_backward_rays", dev, aux.data_ptr(), grad_out.data_ptr(),
+            source.data_ptr(), target.data_ptr(), _ptr(img), B, N, float(eps), int(n_points),
+            alphamin.data_ptr(), alphamax.data_ptr(), _ptr(g_source), _ptr(g_target), _ptr(g_img),
+            _ptr(g_alpha))
+    return res
 
 
 def trilinear_backward_volume_bricks(volume_shape, source, target, img, grad_out, alphamin,

@@ -300,10 +300,16 @@ class _TrilinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, volume, source, target, img, alphamin, alphamax, cfg):
+        aux = None
         if _TrilinearFn._grid(cfg, source, target):
-            out = ops.trilinear_forward_bricks(
+            # with ray / range gradients to come, the brick kernel also leaves the backward
+            # record (sum dT, sum alpha dT per ray): backward is then elementwise
+            want_aux = any(ctx.needs_input_grad[1:6])
+            res = ops.trilinear_forward_bricks(
                 volume, source, target, img, alphamin, alphamax, cfg["det"],
-                n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"])
+                n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
+                want_aux=want_aux)
+            out, aux = res if want_aux else (res, None)
         else:
             out = ops.trilinear_forward(
                 volume, source.contiguous(), target.contiguous(), img.contiguous(), alphamin,
@@ -311,16 +317,17 @@ class _TrilinearFn(torch.autograd.Function):
                 eps=cfg["eps"], reducefn=cfg["reducefn"], mode=cfg["mode"],
                 align_corners=cfg["align_corners"], det=cfg["det"], tile=cfg["tile"])
         ctx.cfg = cfg
-        ctx.save_for_backward(volume, source, target, img, alphamin, alphamax)
+        ctx.save_for_backward(volume, source, target, img, alphamin, alphamax, aux)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        volume, source, target, img, alphamin, alphamax = ctx.saved_tensors
+        volume, source, target, img, alphamin, alphamax, aux = ctx.saved_tensors
         cfg = ctx.cfg
         if cfg["reducefn"] != "sum":
             raise NotImplementedError("Trilinear gradients are implemented for reducefn='sum'")
         need_vol, need_s, need_t, need_i, need_a0, need_a1 = ctx.needs_input_grad[:6]
+        need_rays = need_s or need_t or need_i or need_a0 or need_a1
         g_vol_bricks = None
         if need_vol and _TrilinearFn._grid(cfg, source, target):
             # volume gradient: LDS accumulation per brick instead of 8 global atomics per
@@ -329,15 +336,21 @@ class _TrilinearFn(torch.autograd.Function):
                 volume.shape, source, target, img, grad_out, alphamin, alphamax, cfg["det"],
                 n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"])
             need_vol = False
-            if not (need_s or need_t or need_i or need_a0 or need_a1):
+            if not need_rays:
                 return g_vol_bricks, None, None, None, None, None, None
-        r = ops.trilinear_backward(
-            volume, source.contiguous(), target.contiguous(), img.contiguous(), grad_out,
-            alphamin, alphamax, n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"],
-            eps=cfg["eps"], mode=cfg["mode"], align_corners=cfg["align_corners"],
-            want_rays=bool(need_s or need_t), want_img=bool(need_i),
-            want_alpha=bool(need_a0 or need_a1), want_volume=bool(need_vol), det=cfg["det"],
-            tile=cfg["tile"])
+        if aux is not None and not need_vol:
+            r = ops.trilinear_backward_rays(
+                aux, grad_out, source, target, img, alphamin, alphamax, n_points=cfg["n_points"],
+                eps=cfg["eps"], want_rays=bool(need_s or need_t), want_img=bool(need_i),
+                want_alpha=bool(need_a0 or need_a1))
+        else:
+            r = ops.trilinear_backward(
+                volume, source.contiguous(), target.contiguous(), img.contiguous(), grad_out,
+                alphamin, alphamax, n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"],
+                eps=cfg["eps"], mode=cfg["mode"], align_corners=cfg["align_corners"],
+                want_rays=bool(need_s or need_t), want_img=bool(need_i),
+                want_alpha=bool(need_a0 or need_a1), want_volume=bool(need_vol), det=cfg["det"],
+                tile=cfg["tile"])
         g_s = g_t = g_a0 = g_a1 = g_i = None
         if need_s:
             g_s = r["g_source"].sum(dim=1, keepdim=True) if source.shape[1] == 1 \

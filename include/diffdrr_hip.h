@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 9
+#define DDRR_ABI_VERSION 10
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -59,6 +59,7 @@ extern "C" {
 #define DDRR_AUX_INTERLEAVED 0 /* (B, N, 8): ddrr_siddon_forward, ddrr_siddon_forward_slab */
 #define DDRR_AUX_PLANAR 1      /* (5, B, N) planes I, S0x, S0z, S1x, S1z: ddrr_siddon_forward_bricks */
 #define DDRR_BRICK_AUX_PLANES 5
+#define DDRR_TRI_AUX_PLANES 7   /* sum T, sum dT_xyz, sum alpha dT_xyz: ddrr_trilinear_forward_bricks */
 
 int ddrr_abi_version(void);
 const char *ddrr_last_error(void);
@@ -179,7 +180,9 @@ int ddrr_trilinear_forward_channels(const float *volume, const unsigned char *la
  * det_w target grid, mode "bilinear", reducefn "sum", align_corners = 0): bricks of 31^3 base
  * cells (+1 voxel halo, staged as 32^3 in LDS; voxels outside the volume staged as zeros =
  * the zero padding); a sample belongs to the brick holding floor(index coordinate).
- * _forward_bricks: out (B, N) zero-filled by the call and accumulated with atomics.
+ * _forward_bricks: out (B, N) zero-filled by the call and accumulated with atomics; aux: NULL,
+ * or a (DDRR_TRI_AUX_PLANES, B, N) planar backward record for ddrr_trilinear_backward_rays
+ * (then only the record is accumulated and out = img * step * plane 0 is formed from it).
  * _backward_volume_bricks: g_volume (dx, dy, dz) is fully written, no zero fill needed: on
  * 32^3 voxel bricks that OWN their voxels (a sample is visited by every brick owning one of
  * its 8 corners), accumulated in LDS and stored once -- no global atomics.
@@ -189,7 +192,15 @@ int ddrr_trilinear_forward_bricks(const float *volume, int dx, int dy, int dz,
                                   const float *source, const float *target, const float *img,
                                   int B, int det_h, int det_w, float voxel_shift, float eps,
                                   int n_points, const float *alphamin, const float *alphamax,
-                                  float *out, void *stream);
+                                  float *out, float *aux, void *stream);
+/* Ray / range gradients of the march from the record of ddrr_trilinear_forward_bricks
+ * (what ddrr_trilinear_backward computes by marching again); one source per pose.
+ * Any output may be NULL; shapes as in ddrr_trilinear_backward. */
+int ddrr_trilinear_backward_rays(const float *aux, const float *grad_out, const float *source,
+                                 const float *target, const float *img, int B, int N, float eps,
+                                 int n_points, const float *alphamin, const float *alphamax,
+                                 float *g_source, float *g_target, float *g_img, float *g_alpha,
+                                 void *stream);
 int ddrr_trilinear_backward_volume_bricks(int dx, int dy, int dz, const float *source,
                                           const float *target, const float *img,
                                           const float *grad_out, int B, int det_h, int det_w,

@@ -73,28 +73,23 @@ struct NoAdd {
 
 }  // namespace
 
-// Host emulation of the trilinear brick kernels: per brick of 31^3 base cells (32^3 staged
-// voxels, zeros outside the volume), every candidate pixel of every pose marches its
-// samples; forward accumulates out, backward scatters into the staged accumulator which
-// is then added to g_volume.
 namespace {
-template <bool SCATTER>
+// Host emulation of the marcher's forward brick kernel: per brick of 31^3 base cells (32^3
+// staged voxels, zeros outside the volume), every candidate pixel of every pose marches its
+// samples; accumulates out, or (aux != NULL) the 7-plane backward record.
 int tri_bricks_host(const float *volume, int dx, int dy, int dz, const float *source,
-                    const float *target, const float *img, const float *grad_out, int B, int det_h,
-                    int det_w, float voxel_shift, float eps, int n_points, float amin, float amax,
-                    float *out, float *g_volume) {
+                    const float *target, const float *img, int B, int det_h, int det_w,
+                    float voxel_shift, float eps, int n_points, float amin, float amax,
+                    float *out, float *aux) {
     const Dims D{dx, dy, dz};
-    const int N = det_h * det_w, Dn[3] = {dx, dy, dz};
+    const int N = det_h * det_w;
+    const long R = (long)B * N;
     const BrickGrid bg = tri_brick_grid(D);
     const BrickLayout lay{33, 32 * 33 + 1};
     std::vector<float> brick((size_t)brick_floats(lay));
     struct HostFetch {
         const float *base;
         float operator()(unsigned off) const { return base[off >> 2]; }
-    };
-    struct HostAddB {
-        float *base;
-        void operator()(unsigned off, float v) const { base[off >> 2] += v; }
     };
     const float step = (amax - amin) / (float)(n_points - 1);
     const float nscale = (float)(n_points - 1) / (amax - amin);
@@ -108,14 +103,13 @@ int tri_bricks_host(const float *volume, int dx, int dy, int dz, const float *so
         }
         const TriGeom G = tri_geom(lo, lay);
         std::fill(brick.begin(), brick.end(), 0.f);
-        if (!SCATTER)
-            for (int lx = 0; lx < BRICK; ++lx)
-                for (int ly = 0; ly < BRICK; ++ly)
-                    for (int lz = 0; lz < BRICK; ++lz) {
-                        const int x = lo[0] + lx, y = lo[1] + ly, z = lo[2] + lz;
-                        if (x < 0 || y < 0 || z < 0 || x >= dx || y >= dy || z >= dz) continue;
-                        brick[lx * lay.sx + ly * lay.sy + lz] = volume[((long)x * dy + y) * dz + z];
-                    }
+        for (int lx = 0; lx < BRICK; ++lx)
+            for (int ly = 0; ly < BRICK; ++ly)
+                for (int lz = 0; lz < BRICK; ++lz) {
+                    const int x = lo[0] + lx, y = lo[1] + ly, z = lo[2] + lz;
+                    if (x < 0 || y < 0 || z < 0 || x >= dx || y >= dy || z >= dz) continue;
+                    brick[lx * lay.sx + ly * lay.sy + lz] = volume[((long)x * dy + y) * dz + z];
+                }
         for (int b = 0; b < B; ++b) {
             const PoseGrid pg = pose_grid(source + (long)b * 3, target + (long)b * N * 3, det_h,
                                           det_w);
@@ -135,39 +129,35 @@ int tri_bricks_host(const float *volume, int dx, int dy, int dz, const float *so
                 float n_est;
                 if (!brick_candidate(row, local, det_w, pix, n_est)) continue;
                 cand[pix] = 1;
-                float s[3], t[3], sumT;
+                float s[3], t[3], sumT, rec[6];
                 const long r = ray(pix, s, t);
                 const float L = img ? img[r] : 1.f;
-                if (SCATTER) {
-                    tri_brick_march<true>(HostAddB{brick.data()}, 0.f, G, s, t, voxel_shift, eps,
-                                          n_points, amin, amax, grad_out[r] * L * step, sumT);
+                if (aux) {
+                    if (tri_brick_march<true>(HostFetch{brick.data()}, 0.f, G, s, t, voxel_shift,
+                                              eps, n_points, amin, amax, sumT, rec)) {
+                        aux[r] += sumT;
+                        for (int k = 0; k < 6; ++k) aux[(k + 1) * R + r] += rec[k];
+                    }
                 } else if (tri_brick_march<false>(HostFetch{brick.data()}, 0.f, G, s, t,
-                                                  voxel_shift, eps, n_points, amin, amax, 0.f,
-                                                  sumT)) {
+                                                  voxel_shift, eps, n_points, amin, amax, sumT,
+                                                  rec)) {
                     out[r] += L * step * sumT;
                 }
             }
-            if (!SCATTER)  // phase A must not lose a pixel with samples in this brick
-                for (int pix = 0; pix < N; ++pix) {
-                    if (cand[pix]) continue;
-                    float s[3], t[3], sumT;
-                    ray(pix, s, t);
-                    if (tri_brick_march<false>(HostFetch{brick.data()}, 0.f, G, s, t, voxel_shift,
-                                               eps, n_points, amin, amax, 0.f, sumT) &&
-                        sumT != 0.f)
-                        abort();
-                }
+            // phase A must not lose a pixel with samples in this brick
+            for (int pix = 0; pix < N; ++pix) {
+                if (cand[pix]) continue;
+                float s[3], t[3], sumT, rec[6];
+                ray(pix, s, t);
+                if (tri_brick_march<false>(HostFetch{brick.data()}, 0.f, G, s, t, voxel_shift, eps,
+                                           n_points, amin, amax, sumT, rec) &&
+                    sumT != 0.f)
+                    abort();
+            }
         }
-        if (SCATTER)
-            for (int lx = 0; lx < BRICK; ++lx)
-                for (int ly = 0; ly < BRICK; ++ly)
-                    for (int lz = 0; lz < BRICK; ++lz) {
-                        const int x = lo[0] + lx, y = lo[1] + ly, z = lo[2] + lz;
-                        if (x < 0 || y < 0 || z < 0 || x >= dx || y >= dy || z >= dz) continue;
-                        g_volume[((long)x * dy + y) * dz + z] += brick[lx * lay.sx + ly * lay.sy + lz];
-                    }
-        (void)Dn;
     }
+    if (aux)
+        for (long r = 0; r < R; ++r) out[r] = (img ? img[r] : 1.f) * step * aux[r];
     return 0;
 }
 
@@ -579,10 +569,39 @@ int ddrr_trilinear_forward_bricks(const float *volume, int dx, int dy, int dz,
                                   const float *source, const float *target, const float *img,
                                   int B, int det_h, int det_w, float voxel_shift, float eps,
                                   int n_points, const float *alphamin, const float *alphamax,
-                                  float *out, void *) {
-    memset(out, 0, sizeof(float) * (size_t)B * det_h * det_w);
-    return tri_bricks_host<false>(volume, dx, dy, dz, source, target, img, nullptr, B, det_h, det_w,
-                                  voxel_shift, eps, n_points, *alphamin, *alphamax, out, nullptr);
+                                  float *out, float *aux, void *) {
+    const size_t R = (size_t)B * det_h * det_w;
+    memset(out, 0, sizeof(float) * R);
+    if (aux) memset(aux, 0, sizeof(float) * R * DDRR_TRI_AUX_PLANES);
+    return tri_bricks_host(volume, dx, dy, dz, source, target, img, B, det_h, det_w, voxel_shift,
+                           eps, n_points, *alphamin, *alphamax, out, aux);
+}
+
+int ddrr_trilinear_backward_rays(const float *aux, const float *grad_out, const float *source,
+                                 const float *target, const float *img, int B, int N, float eps,
+                                 int n_points, const float *alphamin, const float *alphamax,
+                                 float *g_source, float *g_target, float *g_img, float *g_alpha,
+                                 void *) {
+    const long R = (long)B * N;
+    for (long r = 0; r < R; ++r) {
+        const long b = r / N;
+        const float *s = source + b * 3, *t = target + r * 3;
+        const float A[3] = {aux[R + r], aux[2 * R + r], aux[3 * R + r]};
+        const float Bv[3] = {aux[4 * R + r], aux[5 * R + r], aux[6 * R + r]};
+        const float g = grad_out[r], L = img ? img[r] : 1.f;
+        const MarchGrad m = trilinear_backward_from_record(aux[r], A, Bv, s, t, eps, n_points,
+                                                           *alphamin, *alphamax, g * L);
+        for (int a = 0; a < 3; ++a) {
+            if (g_source) g_source[r * 3 + a] = m.gs[a];
+            if (g_target) g_target[r * 3 + a] = m.gt[a];
+        }
+        if (g_img) g_img[r] = g * m.sumT * ((*alphamax - *alphamin) / (float)(n_points - 1));
+        if (g_alpha) {
+            g_alpha[r * 2 + 0] = m.g_amin;
+            g_alpha[r * 2 + 1] = m.g_amax;
+        }
+    }
+    return 0;
 }
 
 int ddrr_trilinear_backward_volume_bricks(int dx, int dy, int dz, const float *source,

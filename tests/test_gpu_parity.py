@@ -613,6 +613,16 @@ def test_trilinear_bricks_full_size(gpu, big):
     lhs = (gout.double() * V.double()).sum().item()
     rhs = (go.double() * out.double()).sum().item()
     assert abs(lhs - rhs) < 1e-5 * abs(rhs)
+    # forward + record: same image; ray / range gradients from the record equal the re-march
+    out2, aux = ops.trilinear_forward_bricks(V, s, t, L, amin, amax, (256, 256), n_points=P,
+                                             want_aux=True)
+    assert rel_err(out2.cpu().numpy(), ref.cpu().numpy()) < 5e-6
+    rec = ops.trilinear_backward_rays(aux, go, s, t, L, amin, amax, n_points=P)
+    rem = ops.trilinear_backward(V, s, t, L, go, amin, amax, n_points=P, det=(256, 256))
+    for k in ("g_target", "g_source", "g_img"):
+        assert rel_err(rec[k].cpu().numpy(), rem[k].cpu().numpy()) < 2e-5, k
+    ga, gb = rec["g_alpha"].double().sum((0, 1)), rem["g_alpha"].double().sum((0, 1))
+    assert ((ga - gb).abs() / gb.abs()).max().item() < 1e-4
 
 
 def test_volume_gradient_bricks_fixed_point_and_float_paths(gpu):

@@ -75,6 +75,11 @@ for case in range(a.cases):
                                     want_img=False, want_alpha=False, want_volume=True)["g_volume"]
         bv = ops.trilinear_backward_volume_bricks(V.shape, s, t, L, go, amin, amax, (H, W), n_points=P)
         e_tv = ((bv - rv).abs().max() / (rv.abs().max() + 1e-30)).item()
+        _, taux = ops.trilinear_forward_bricks(V, s, t, L, amin, amax, (H, W), n_points=P, want_aux=True)
+        rec = ops.trilinear_backward_rays(taux, go, s, t, L, amin, amax, n_points=P)
+        rem = ops.trilinear_backward(V, s, t, L, go, amin, amax, n_points=P)
+        for k in ("g_source", "g_target", "g_img"):
+            e_t = max(e_t, ((rec[k] - rem[k]).abs().max() / (rem[k].abs().max() + 1e-30)).item())
     else:
         e_t = e_tv = 0.0
     for k, e in zip(worst, (e_f, e_a, e_v, e_t, e_tv)):

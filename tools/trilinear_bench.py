@@ -20,6 +20,11 @@ for H, Bs in ((512, (1, 4)), (256, (8,))):
         fr, _ = timeit(lambda: ops.trilinear_forward(V, s, t, L, amin, amax, n_points=P, det=(H, H)), reps=3, warm=1)
         gb, _ = timeit(lambda: ops.trilinear_backward_volume_bricks(V.shape, s, t, L, go, amin, amax, (H, H), n_points=P))
         gr, _ = timeit(lambda: ops.trilinear_backward(V, s, t, L, go, amin, amax, n_points=P, want_rays=False, want_img=False, want_alpha=False, want_volume=True, det=(H, H)), reps=3, warm=1)
+        fa, _ = timeit(lambda: ops.trilinear_forward_bricks(V, s, t, L, amin, amax, (H, H), n_points=P, want_aux=True))
+        _, aux = ops.trilinear_forward_bricks(V, s, t, L, amin, amax, (H, H), n_points=P, want_aux=True)
+        ba, _ = timeit(lambda: ops.trilinear_backward_rays(aux, go, s, t, L, amin, amax, n_points=P))
+        br, _ = timeit(lambda: ops.trilinear_backward(V, s, t, L, go, amin, amax, n_points=P, det=(H, H)), reps=3, warm=1)
+        print(f"   ray/range gradients: forward+record bricks {fa:7.3f} ms + from record {ba:7.3f} ms | per-ray re-march {br:7.3f} ms", flush=True)
         # samples whose 8-cell touches the volume: count via a forward of a ones volume? use alpha range estimate
         nsamp = B * H * H * P
         print(f"{D}^3 det {H}^2 P={P} B={B}: forward bricks {fb:7.3f} ms | per-ray {fr:7.3f} ms   "
