@@ -674,7 +674,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                 // is per line, not per lane (measured: 3.55 -> 2.74 ms; without the record
                 // the per-lane classes win, 1.87 vs 2.01 ms).
                 float n_grp = hit ? n_est : 0.f;
-                if (AUX || MODE == BRICK_TRI_FWD_AUX) {
+                if ((AUX || MODE == BRICK_TRI_FWD_AUX) && !(p.dbg & 8)) {
                     n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
                         0, __builtin_bit_cast(int, n_grp), 0xB1, 0xf, 0xf, true)));   // lane ^ 1
                     n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
@@ -1329,6 +1329,10 @@ int ddrr_set_brick_layout(int sy, int sx) {
     g_brick_layout = lay;
     return 0;
 }
+// Experiment switches of the brick kernels (0 in production; results are wrong with 1, 2):
+//   1 skip the record's atomics, 2 skip the image atomic, 8 per-lane length classes also with
+//   the record (no groups of 8 pixels), 16 no scatter permutation, 32 float LDS accumulation.
+// profiles/r01/exp_record_cost.txt holds the decomposition these gave for the record.
 int ddrr_set_brick_debug(int flags) {
     g_brick_dbg = flags;
     return 0;
