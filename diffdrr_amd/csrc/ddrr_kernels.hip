@@ -455,7 +455,8 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
     }
     float I, rec[4];
     if (!brick_trace<AUX>(LdsAbsFetch{}, base, G, s, t, p.shift, p.eps, I, rec)) return;
-    if (!(p.dbg & 2)) unsafeAtomicAdd(out + r, L * I);
+    // with the record, out = L * (plane I) is formed afterwards (siddon_out_from_record_kernel)
+    if (!AUX && !(p.dbg & 2)) unsafeAtomicAdd(out + r, L * I);
     if (AUX && !(p.dbg & 1)) {
         unsafeAtomicAdd(aux + r, I);
         unsafeAtomicAdd(aux + p.aux_plane + r, rec[0]);
@@ -1210,6 +1211,14 @@ __global__ __launch_bounds__(kBlock) void trilinear_bwd_channels_kernel(
     }
 }
 
+// out = L * I from plane 0 of the Siddon planar record (the record launch leaves `out` alone:
+// one atomic less per ray and brick).
+__global__ __launch_bounds__(kBlock) void siddon_out_from_record_kernel(
+    const float *__restrict__ aux, const float *__restrict__ img, long R, float *__restrict__ out) {
+    const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (r < R) out[r] = (img ? img[r] : 1.f) * aux[r];
+}
+
 // out = L * step * sumT from plane 0 of the marcher's planar record (the record launch
 // does not touch `out`).
 __global__ __launch_bounds__(kBlock) void tri_out_from_record_kernel(
@@ -1558,13 +1567,18 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * N, st);
-    if (e == hipSuccess && aux)
-        e = hipMemsetAsync(aux, 0, sizeof(float) * (size_t)kBrickAuxPlanes * B * N, st);
+    const long R = (long)B * N;
+    hipError_t e = hipMemsetAsync(aux ? aux : out, 0,
+                                  sizeof(float) * (size_t)R * (aux ? kBrickAuxPlanes : 1), st);
     if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
-    return launch_bricks(aux ? BRICK_FWD_AUX : BRICK_FWD, volume, dx, dy, dz, source, target, img,
-                         nullptr, B, det_h, det_w, voxel_shift, eps, out, aux, nullptr, st,
-                         "ddrr_siddon_forward_bricks");
+    if (int rc = launch_bricks(aux ? BRICK_FWD_AUX : BRICK_FWD, volume, dx, dy, dz, source, target,
+                               img, nullptr, B, det_h, det_w, voxel_shift, eps, out, aux, nullptr,
+                               st, "ddrr_siddon_forward_bricks"))
+        return rc;
+    if (!aux) return 0;
+    hipLaunchKernelGGL(siddon_out_from_record_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, st, aux, img, R, out);
+    return finish("ddrr_siddon_forward_bricks");
 }
 
 int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *source,
