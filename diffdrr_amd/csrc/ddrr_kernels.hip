@@ -17,6 +17,7 @@
 #include "brick_core.h"
 #include "brick_walk.h"
 #include "raygen_core.h"
+#include "segments_core.h"
 #include "tri_brick.h"
 #include "slab_core.h"
 #include "trilinear_core.h"
@@ -844,6 +845,42 @@ __global__ __launch_bounds__(kBlock) void siddon_bwd_channels_kernel(
     if (g_volume)
         siddon_scatter_ray<REDUCE_SUM>(p.vol, p.D, s, t, p.shift, p.eps, L,
                                        ChannelAdder{g_volume, labels, gcol, p.N, C});
+}
+
+// The materialised per-segment terms for a callable reducefn (segments_core.h).  terms is
+// (B, M - 1, N): the ray owns column [b, :, n], consecutive lanes write consecutive floats.
+__global__ __launch_bounds__(kBlock) void siddon_segments_kernel(RayArgs p,
+                                                                 float *__restrict__ terms) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    const long M1 = (long)p.D.x + p.D.y + p.D.z + 2;
+    siddon_segments_ray(p.vol, p.D, s, t, p.shift, p.eps, L, terms + (long)id.b * M1 * p.N + id.n,
+                        p.N);
+}
+
+template <bool WANT_VOL>
+__global__ __launch_bounds__(kBlock) void siddon_segments_bwd_kernel(
+    RayArgs p, const float *__restrict__ g_terms, float *__restrict__ g_source,
+    float *__restrict__ g_target, float *__restrict__ g_img, float *__restrict__ g_volume) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    const long M1 = (long)p.D.x + p.D.y + p.D.z + 2;
+    float gs[3], gt[3], gi;
+    siddon_segments_backward_ray<WANT_VOL>(p.vol, p.D, s, t, p.shift, p.eps, L,
+                                           g_terms + (long)id.b * M1 * p.N + id.n, p.N, gs, gt, gi,
+                                           AtomicAdder{g_volume});
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (g_source) g_source[id.r * 3 + a] = gs[a];
+        if (g_target) g_target[id.r * 3 + a] = gt[a];
+    }
+    if (g_img) g_img[id.r] = gi;
 }
 
 // ------------------------------------------- volume-gradient fixed-point bound
@@ -1750,6 +1787,40 @@ int ddrr_siddon_backward_channels(const float *volume, const unsigned char *labe
                        (hipStream_t)stream, p, labels, C, grad_out, g_source, g_target, g_img,
                        g_volume);
     return finish("ddrr_siddon_backward_channels");
+}
+
+int ddrr_siddon_segments(const float *volume, int dx, int dy, int dz, const float *source,
+                         int src_n, const float *target, const float *img, int B, int N,
+                         float voxel_shift, float eps, float *terms, void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!terms) return fail(-1, "null terms pointer");
+    if (B == 0 || N == 0) return 0;
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, 0, 0, 1, 64);
+    hipLaunchKernelGGL(siddon_segments_kernel, dim3(grid_for(p)), dim3(kBlock), 0,
+                       (hipStream_t)stream, p, terms);
+    return finish("ddrr_siddon_segments");
+}
+
+int ddrr_siddon_segments_backward(const float *volume, int dx, int dy, int dz, const float *source,
+                                  int src_n, const float *target, const float *img,
+                                  const float *grad_terms, int B, int N, float voxel_shift,
+                                  float eps, float *g_source, float *g_target, float *g_img,
+                                  float *g_volume, void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!grad_terms) return fail(-1, "null grad_terms pointer");
+    if (B == 0 || N == 0) return 0;
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, 0, 0, 1, 64);
+    const dim3 grid(grid_for(p)), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    if (g_volume)
+        hipLaunchKernelGGL((siddon_segments_bwd_kernel<true>), grid, block, 0, st, p, grad_terms,
+                           g_source, g_target, g_img, g_volume);
+    else
+        hipLaunchKernelGGL((siddon_segments_bwd_kernel<false>), grid, block, 0, st, p, grad_terms,
+                           g_source, g_target, g_img, g_volume);
+    return finish("ddrr_siddon_segments_backward");
 }
 
 int ddrr_trilinear_forward(const float *volume, int dx, int dy, int dz, const float *source,

@@ -24,9 +24,8 @@ def reduce_code(reducefn) -> int:
         return _REDUCE[reducefn]
     if callable(reducefn):
         raise NotImplementedError(
-            "callable reducefn is not supported by the fused MI355X renderer: the per-segment "
-            "tensor it would receive is never materialised. Use 'sum' or 'max'."
-        )
+            "a callable reducefn needs the materialised per-segment tensor: only Siddon(mode="
+            "'nearest') without a mask provides it (ops.siddon_segments)")
     raise ValueError(f"Only supports reducefn 'sum' or 'max', not {reducefn}")
 
 
@@ -368,6 +367,46 @@ def siddon_forward_channels(volume, labels_u8, n_channels, source, target, img, 
         *volume.shape, source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img), B, N,
         int(n_channels), float(voxel_shift), float(eps), dh, dw, th, tw, out.data_ptr())
     return out
+
+
+def siddon_segments(volume, source, target, img, *, voxel_shift=0.5, eps=1e-8):
+    """The per-segment terms a callable ``reducefn`` receives (renderers.py:70-71).
+    -> (B, M-1, N) with M = Dx+Dy+Dz+3; transpose(1, 2) is the reference's layout."""
+    B, N = _check_rays(volume, source, target, img)
+    M1 = sum(int(v) for v in volume.shape) + 2
+    terms = torch.empty(B, M1, N, dtype=torch.float32, device=volume.device)
+    if _empty(B, N):
+        return terms
+    volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    _launch("ddrr_siddon_segments", volume.device, volume.data_ptr(), *volume.shape,
+            source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img), B, N,
+            float(voxel_shift), float(eps), terms.data_ptr())
+    return terms
+
+
+def siddon_segments_backward(volume, source, target, img, grad_terms, *, voxel_shift=0.5, eps=1e-8,
+                             want_rays=True, want_img=True, want_volume=False):
+    """Backward of :func:`siddon_segments` for grad_terms (B, M-1, N).
+    -> (g_source per ray, g_target, g_img, g_volume), None where not asked."""
+    B, N = _check_rays(volume, source, target, img)
+    dev = volume.device
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    g_source = new(B, N, 3) if want_rays else None
+    g_target = new(B, N, 3) if want_rays else None
+    g_img = new(B, N) if want_img else None
+    g_volume = torch.zeros_like(volume, memory_format=torch.contiguous_format) \
+        if want_volume else None
+    if _empty(B, N):
+        return g_source, g_target, g_img, g_volume
+    volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    grad_terms = grad_terms.contiguous()
+    _launch("ddrr_siddon_segments_backward", dev, volume.data_ptr(), *volume.shape,
+            source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img),
+            grad_terms.data_ptr(), B, N, float(voxel_shift), float(eps), _ptr(g_source),
+            _ptr(g_target), _ptr(g_img), _ptr(g_volume))
+    return g_source, g_target, g_img, g_volume
 
 
 def siddon_backward_channels(volume, labels_u8, source, target, img, grad_out, *, voxel_shift=0.5,

@@ -148,6 +148,38 @@ class _SiddonChannelsFn(torch.autograd.Function):
         return gv, g_s, g_t, g_i, None, None, None
 
 
+class _SiddonSegmentsFn(torch.autograd.Function):
+    """The (B, N, M-1) per-segment tensor the reference hands to a callable ``reducefn``
+    (renderers.py:70-71, 175-183), materialised by ddrr_siddon_segments; backward =
+    ddrr_siddon_segments_backward (one more walk weighted by the incoming gradient)."""
+
+    @staticmethod
+    def forward(ctx, volume, source, target, img, cfg):
+        terms = ops.siddon_segments(volume, source, target, img, voxel_shift=cfg["voxel_shift"],
+                                    eps=cfg["eps"])
+        ctx.cfg = cfg
+        ctx.save_for_backward(volume, source, target, img)
+        return terms.transpose(1, 2)  # (B, N, M-1), the reference's layout (a view)
+
+    @staticmethod
+    def backward(ctx, grad):
+        volume, source, target, img = ctx.saved_tensors
+        cfg = ctx.cfg
+        need_vol, need_s, need_t, need_i = ctx.needs_input_grad[:4]
+        stop = cfg["stop_gradients"]
+        gs, gt, gi, gv = ops.siddon_segments_backward(
+            volume, source, target, img, grad.transpose(1, 2), voxel_shift=cfg["voxel_shift"],
+            eps=cfg["eps"], want_rays=bool(need_s or need_t), want_img=bool(need_i and not stop),
+            want_volume=bool(need_vol and not stop))
+        g_s = g_t = None
+        if need_s:
+            g_s = gs.sum(dim=1, keepdim=True) if source.shape[1] == 1 else gs
+        if need_t:
+            g_t = gt
+        g_i = gi.view_as(img) if gi is not None else None
+        return gv, g_s, g_t, g_i, None
+
+
 class _SiddonPoseFn(torch.autograd.Function):
     """The DRR case end to end: world pose per DRR -> image.  Inputs: volume, Mw (B,3,4)
     (extrinsic o reorient), P (N,3) calibrated detector points, Ainv (3,4) world -> voxel.
@@ -256,6 +288,16 @@ class Siddon(torch.nn.Module):
 
     def forward(self, volume, source, target, img, align_corners=False, mask=None):
         B, N, _ = target.shape
+        if callable(self.reducefn) and not isinstance(self.reducefn, str):
+            # a user reduction over the per-segment tensor (renderers.py:175-183,
+            # introduction.ipynb:506-529): the tensor is materialised for it
+            if self.mode != "nearest" or align_corners or mask is not None:
+                raise NotImplementedError("a callable reducefn needs mode='nearest', "
+                                          "align_corners=False and no mask")
+            cfg = {"voxel_shift": self.voxel_shift, "eps": self.eps,
+                   "stop_gradients": self.stop_gradients_through_grid_sample}
+            terms = _SiddonSegmentsFn.apply(volume, source, target, img.reshape(B, N), cfg)
+            return self.reducefn(terms).unsqueeze(1)
         cfg = self._cfg(align_corners)
         if mask is None:
             out = _SiddonFn.apply(volume, source, target, img.reshape(B, N), cfg)

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 10
+#define DDRR_ABI_VERSION 11
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -154,6 +154,22 @@ int ddrr_siddon_backward_channels(const float *volume, const unsigned char *labe
                                   int B, int N, int C, float voxel_shift, float eps, int det_h,
                                   int det_w, int tile_h, int tile_w, float *g_source,
                                   float *g_target, float *g_img, float *g_volume, void *stream);
+
+/* The materialised per-segment tensor the reference hands to a CALLABLE reducefn
+ * (renderers.py:70-71, 175-183; notebooks/tutorials/introduction.ipynb:506-529): terms is
+ * (B, M - 1, N) with M = dx + dy + dz + 3 sorted plane crossings -- i.e. the reference's
+ * (B, N, M - 1) tensor transposed, so that rays write coalesced; term k = img * V * dalpha of the
+ * k-th interval between consecutive crossings, 0 outside the volume (mode "nearest",
+ * align_corners = 0).  _backward: autograd of it for grad_terms (B, M - 1, N); outputs as in
+ * ddrr_siddon_backward_channels. */
+int ddrr_siddon_segments(const float *volume, int dx, int dy, int dz, const float *source,
+                         int src_n, const float *target, const float *img, int B, int N,
+                         float voxel_shift, float eps, float *terms, void *stream);
+int ddrr_siddon_segments_backward(const float *volume, int dx, int dy, int dz, const float *source,
+                                  int src_n, const float *target, const float *img,
+                                  const float *grad_terms, int B, int N, float voxel_shift,
+                                  float eps, float *g_source, float *g_target, float *g_img,
+                                  float *g_volume, void *stream);
 
 /* Trilinear.forward, mask=None (renderers.py:205-241).  alphamin/alphamax are
  * DEVICE scalars (renderers.py:220-223 evaluated by the caller, or the

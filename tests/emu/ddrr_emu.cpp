@@ -19,6 +19,7 @@
 #include "../../diffdrr_amd/csrc/brick_core.h"
 #include "../../diffdrr_amd/csrc/brick_walk.h"
 #include "../../diffdrr_amd/csrc/raygen_core.h"
+#include "../../diffdrr_amd/csrc/segments_core.h"
 #include "../../diffdrr_amd/csrc/tri_brick.h"
 #include "../../diffdrr_amd/csrc/slab_core.h"
 #include "../../diffdrr_amd/csrc/trilinear_core.h"
@@ -761,6 +762,46 @@ int ddrr_trilinear_backward_channels(const float *volume, const unsigned char *l
                 g_alpha[r * 2 + 1] = m.g_amax;
             }
         });
+    return 0;
+}
+
+int ddrr_siddon_segments(const float *volume, int dx, int dy, int dz, const float *source,
+                         int src_n, const float *target, const float *img, int B, int N,
+                         float voxel_shift, float eps, float *terms, void *) {
+    const Dims D{dx, dy, dz};
+    const long M1 = (long)dx + dy + dz + 2;
+    for_each_ray(source, src_n, target, img, B, N, 0, 0, 1, 64,
+                 [&](int b, int n, long, const Ray &ray) {
+                     siddon_segments_ray(volume, D, ray.s, ray.t, voxel_shift, eps, ray.L,
+                                         terms + (long)b * M1 * N + n, N);
+                 });
+    return 0;
+}
+
+int ddrr_siddon_segments_backward(const float *volume, int dx, int dy, int dz, const float *source,
+                                  int src_n, const float *target, const float *img,
+                                  const float *grad_terms, int B, int N, float voxel_shift,
+                                  float eps, float *g_source, float *g_target, float *g_img,
+                                  float *g_volume, void *) {
+    const Dims D{dx, dy, dz};
+    const long M1 = (long)dx + dy + dz + 2;
+    for_each_ray(source, src_n, target, img, B, N, 0, 0, 1, 64,
+                 [&](int b, int n, long r, const Ray &ray) {
+                     float gs[3], gt[3], gi;
+                     const float *g = grad_terms + (long)b * M1 * N + n;
+                     if (g_volume)
+                         siddon_segments_backward_ray<true>(volume, D, ray.s, ray.t, voxel_shift,
+                                                            eps, ray.L, g, N, gs, gt, gi,
+                                                            HostAdd{g_volume});
+                     else
+                         siddon_segments_backward_ray<false>(volume, D, ray.s, ray.t, voxel_shift,
+                                                             eps, ray.L, g, N, gs, gt, gi, NoAdd{});
+                     for (int a = 0; a < 3; ++a) {
+                         if (g_source) g_source[r * 3 + a] = gs[a];
+                         if (g_target) g_target[r * 3 + a] = gt[a];
+                     }
+                     if (g_img) g_img[r] = gi;
+                 });
     return 0;
 }
 

@@ -134,6 +134,11 @@ def renderer_fixture(name, make, call_kw, dims, rays, seed, mask=None, want_grad
     save(name, **arrays)
 
 
+def topk_sum(img):
+    """The reference tutorial's custom reduction: sum of the k largest per-segment terms."""
+    return img.sort(descending=True).values[..., :6].sum(dim=-1)
+
+
 def make_renderer_fixtures():
     dims = (12, 10, 14)  # deliberately non-cubic: catches axis transposes
     R = ref
@@ -157,6 +162,9 @@ def make_renderer_fixtures():
                      lambda g: random_rays(g, dims, 2, 32), 17, want_grads=False)
     renderer_fixture("siddon_align_corners", lambda: R.Siddon(), {"align_corners": True}, dims,
                      lambda g: random_rays(g, dims, 2, 32), 18, want_grads=False)
+    # a callable reducefn over the per-segment tensor (introduction.ipynb:506-529: top-k sum)
+    renderer_fixture("siddon_callable", lambda: R.Siddon(reducefn=topk_sum), {}, dims,
+                     lambda g: random_rays(g, dims, 2, 32), 26)
     g = torch.Generator().manual_seed(19)
     mask = torch.randint(0, 5, dims, generator=g).to(F32)
     renderer_fixture("siddon_mask", lambda: R.Siddon(), {}, dims,

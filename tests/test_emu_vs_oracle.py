@@ -425,3 +425,16 @@ def test_trilinear_channels(emu_lib):
     emu_lib.call("ddrr_trilinear_forward", P(vol), *vol.shape, P(src), src.shape[1], P(tgt),
                  P(img), B, N, 0.5, 1e-8, 40, P(am), P(aM), 0, 0, 0, 0, 0, 1, 64, P(plain), None)
     assert rel_err(out.sum(1), plain) < 1e-5  # channels add up to the DRR
+
+
+def test_siddon_segments_equal_oracle_terms(emu_lib):
+    """ddrr_siddon_segments against the oracle's restatement of the (B, N, M-1) tensor the
+    reference holds before `reduce` (renderers.py:71): position by position."""
+    g, vol, src, tgt, img, B, N = load("siddon_sum_oblique")
+    M1 = sum(vol.shape) + 2
+    terms = np.full((B, M1, N), np.nan, np.float32)
+    emu_lib.call("ddrr_siddon_segments", P(vol), *vol.shape, P(src), src.shape[1], P(tgt), P(img),
+                 B, N, 0.5, 1e-8, P(terms), None)
+    ref, _ = oracle.siddon_segments(vol, src, tgt, img)
+    assert ref.shape == (B, N, M1)
+    assert rel_err(terms.transpose(0, 2, 1), ref) < 1e-5
