@@ -542,8 +542,12 @@ def test_empty_and_ragged_inputs(gpu):
     t = torch.tensor([[[0.0, 30.0, 0.0]]], device=gpu)
     out = Siddon()(thin, s, t, torch.full((1, 1, 1), 50.0, device=gpu))
     assert abs(out.item() - thin.sum().item()) < 1e-4  # 9 unit-length voxels * 50/50
+    # a callable reducefn gets the materialised per-segment tensor (ddrr_siddon_segments)
+    one = torch.ones(1, 1, 1, device=gpu)
+    a = Siddon(reducefn=lambda x: x.sum(-1))(vol, s, t, one)
+    assert torch.allclose(a, Siddon()(vol, s, t, one), rtol=1e-5, atol=1e-6)
     with pytest.raises(NotImplementedError):
-        Siddon(reducefn=lambda x: x.sum(-1))(vol, s, t, torch.ones(1, 1, 1, device=gpu))
+        Siddon(mode="bilinear", reducefn=lambda x: x.sum(-1))(vol, s, t, one)
     with pytest.raises(NotImplementedError):
         Siddon()(vol.double(), s.double(), t.double(), torch.ones(1, 1, 1, device=gpu).double())
 
