@@ -1,0 +1,827 @@
+// bricks.hip -- the volume-stationary kernels (brick_core.h, brick_walk.h, tri_brick.h): one
+// persistent 1024-thread workgroup per CU stages 32^3 bricks in LDS and traces every ray of
+// every pose through them; Siddon forward (+ backward record), Siddon and trilinear volume
+// gradients, trilinear forward (+ record); and the elementwise kernels that consume the records.
+#include "runtime.h"
+#include "siddon_core.h"
+#include "brick_core.h"
+#include "brick_walk.h"
+#include "tri_brick.h"
+#include "trilinear_core.h"
+
+using namespace ddrr;
+using namespace ddrr_rt;
+
+namespace {
+
+// ------------------------------------------------- Siddon, brick-stationary
+// One workgroup per 32^3 brick: stage the brick in LDS (padded layout), then trace from
+// LDS the part of every ray of every pose that crosses it (brick_core.h, brick_walk.h).
+// 1024 threads and ~159 KiB of LDS -> one workgroup per CU, 4 waves per SIMD.
+//
+// Work distribution inside the workgroup (no block-wide barriers in the hot loop):
+//  * per pose the brick's 8 corners are projected onto the detector: a pixel box of
+//    candidates; a unit = 64 consecutive candidates of one pose; waves pull units from one
+//    LDS counter in increasing order, so the unit -> pose lookup is a forward cursor;
+//  * phase A (all 64 lanes, arithmetic only): conservative slab test of the candidate
+//    against the brick from the pose's affine detector model; the hits are compacted
+//    (ballot + mbcnt) into the wave's private LDS queues, one queue per length class
+//    (estimated number of crossings), so that a wave walks rays of similar length;
+//  * phase B: as soon as a queue holds 64 hits their real rays are clipped exactly and
+//    walked with every lane busy; the remainders are walked together at the end.
+//    A queue entry is (pose << pix_bits) | pixel.
+
+constexpr int kBrickThreads = 1024;
+constexpr int kBrickWaves = kBrickThreads / 64;
+constexpr int kPoseChunk = 32;
+constexpr int kQueueCap = 128;
+constexpr int kBuckets = 3;
+constexpr int kBrickAuxPlanes = 5;  // I, S0x, S0z, S1x, S1z (y follows from the sums)
+
+struct BrickArgs {
+    const float *vol;
+    Dims D;
+    const float *source;  // (B, 1, 3)
+    const float *target;  // (B, N, 3), row-major det_h x det_w grid
+    const float *img;
+    int B, det_h, det_w;
+    float shift, eps;
+    BrickLayout lay;
+    unsigned aux_plane;  // elements per plane of the planar backward record (B * N)
+    int pix_bits;        // queue entry = (pose << pix_bits) | pixel
+    float t1, t2;        // length-class thresholds on the estimated crossing count
+    int dbg;             // experiment switches (0 in production)
+    int *work;           // global brick counter of this launch (zero at launch)
+    const float *grad_out;  // *_VOLGRAD: dLoss/dout (B, N)
+    float *g_volume;        // *_VOLGRAD: dLoss/dvolume
+    int n_points;           // BRICK_TRI_*: samples per ray
+    const float *amin, *amax;  // BRICK_TRI_*: device scalars (renderers.py:220-223)
+};
+
+// what a brick launch computes
+constexpr int BRICK_FWD = 0;      // out
+constexpr int BRICK_FWD_AUX = 1;  // out + planar backward record
+constexpr int BRICK_VOLGRAD = 2;  // g_volume (the brick in LDS is the accumulator)
+constexpr int BRICK_TRI_FWD = 3;      // trilinear marcher: out
+constexpr int BRICK_TRI_VOLGRAD = 4;  // trilinear marcher: g_volume
+constexpr int BRICK_TRI_FWD_AUX = 5;  // trilinear marcher: planar backward record (out follows from it)
+
+inline size_t brick_lds_bytes(const BrickLayout &lay) {
+    return (size_t)brick_floats(lay) * 4 + (size_t)kBrickWaves * kBuckets * kQueueCap * 4 +
+           (size_t)(kPoseChunk * kRowWords + 2) * 4;
+}
+
+#if defined(__HIPCC__)
+// Scatter into the LDS accumulator by absolute LDS byte address.  LDS float atomics run at
+// ~0.7 lane per clock on gfx950 (measured: ds_add_f32 occupies the LDS pipe ~90 cycles per
+// wave instruction, conflicts or not), integer ones 4x faster: the accumulator is int32
+// fixed point, value = count / q, with q chosen per launch from a bound on the largest sum
+// a voxel can receive (volgrad_prepare_kernel); q == 0 selects the float path (the bound
+// does not exist, e.g. the source lies inside the volume).  Integer sums are associative:
+// the fixed-point gradient is bit-reproducible.
+struct LdsAbsAdd {
+    float q;
+    __device__ __forceinline__ void operator()(unsigned addr, float v) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (q != 0.f) {
+            __hip_atomic_fetch_add((int *)(__attribute__((address_space(3))) int *)(unsigned long long)addr,
+                                   __float2int_rn(v * q), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
+        }
+        __hip_atomic_fetch_add((float *)(__attribute__((address_space(3))) float *)(unsigned long long)addr,
+                               v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        (void)addr;
+        (void)v;
+#endif
+    }
+};
+#endif
+
+// Phase B for one queue entry: load the real ray, clip, walk; add to the image (forward)
+// or scatter into the LDS accumulator (volume gradient).
+// Offsets are 32-bit: the host checks 12 * B * N < 2^32.
+template <int MODE>
+__device__ __forceinline__ void brick_item(const BrickArgs &p, const float *brick,
+                                           const BrickGeom &G, unsigned b, unsigned pix,
+                                           float fixq, float *__restrict__ out,
+                                           float *__restrict__ aux) {
+    constexpr bool AUX = MODE == BRICK_FWD_AUX;
+    const unsigned r = b * (unsigned)(p.det_h * p.det_w) + pix;
+    const float *sp = p.source + b * 3u, *tp = p.target + r * 3u;
+    const float s[3] = {sp[0], sp[1], sp[2]}, t[3] = {tp[0], tp[1], tp[2]};
+    const float L = p.img ? p.img[r] : 1.f;
+    const float base = (float)LdsAbsFetch::base_of(brick);
+    if (MODE == BRICK_VOLGRAD) {
+        const float w = p.grad_out[r] * L;
+        if (w != 0.f) brick_scatter(LdsAbsAdd{fixq}, base, G, s, t, p.shift, p.eps, w);
+        return;
+    }
+    if (MODE == BRICK_TRI_VOLGRAD) {
+        const float a0 = p.amin[0], a1 = p.amax[0];
+        const float w = p.grad_out[r] * L * ((a1 - a0) / (float)(p.n_points - 1));
+        if (w != 0.f)
+            tri_owner_scatter(LdsAbsAdd{fixq}, base, G.lof, G.hif, G.stridef, s, t, p.shift, p.eps,
+                              p.n_points, a0, a1, w);
+        return;
+    }
+    if (MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_FWD_AUX) {
+        TriGeom T;  // G.lof holds the first base cell here (set by the kernel)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            T.lo[a] = G.lof[a];
+            T.stridef[a] = G.stridef[a];
+        }
+        const float a0 = p.amin[0], a1 = p.amax[0];
+        float sumT, rec[6];
+        if (!tri_brick_march<MODE == BRICK_TRI_FWD_AUX>(LdsAbsFetch{}, base, T, s, t, p.shift, p.eps,
+                                                        p.n_points, a0, a1, sumT, rec))
+            return;
+        if (MODE == BRICK_TRI_FWD) {
+            const float step = (a1 - a0) / (float)(p.n_points - 1);  // renderers.py:235
+            unsafeAtomicAdd(out + r, L * step * sumT);
+        } else {
+            // the record alone: out = L step sumT is formed from plane 0 afterwards
+            unsafeAtomicAdd(aux + r, sumT);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) unsafeAtomicAdd(aux + (unsigned)(k + 1) * p.aux_plane + r, rec[k]);
+        }
+        return;
+    }
+    float I, rec[4];
+    if (!brick_trace<AUX>(LdsAbsFetch{}, base, G, s, t, p.shift, p.eps, I, rec)) return;
+    // with the record, out = L * (plane I) is formed afterwards (siddon_out_from_record_kernel)
+    if (!AUX && !(p.dbg & 2)) unsafeAtomicAdd(out + r, L * I);
+    if (AUX && !(p.dbg & 1)) {
+        unsafeAtomicAdd(aux + r, I);
+        unsafeAtomicAdd(aux + p.aux_plane + r, rec[0]);
+        unsafeAtomicAdd(aux + 2u * p.aux_plane + r, rec[1]);
+        unsafeAtomicAdd(aux + 3u * p.aux_plane + r, rec[2]);
+        unsafeAtomicAdd(aux + 4u * p.aux_plane + r, rec[3]);
+    }
+}
+
+__device__ __forceinline__ int lane_rank(unsigned long long mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
+    BrickArgs p, float *__restrict__ out, float *__restrict__ aux) {
+    constexpr bool AUX = MODE == BRICK_FWD_AUX;
+    // TRI: bricks of 31^3 base cells + halo (the marcher's forward); the marcher's volume
+    // gradient (TRI_OWNER) runs on the plain 32^3 voxel bricks, see tri_brick.h
+    constexpr bool TRI = MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_FWD_AUX;
+    constexpr bool TRI_OWNER = MODE == BRICK_TRI_VOLGRAD;
+    constexpr bool GRAD = MODE == BRICK_VOLGRAD || MODE == BRICK_TRI_VOLGRAD;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float *brick = reinterpret_cast<float *>(smem_raw);
+    unsigned *queue = reinterpret_cast<unsigned *>(brick + brick_floats(p.lay));
+    float *rows = reinterpret_cast<float *>(queue + kBrickWaves * kBuckets * kQueueCap);
+    int *counter = reinterpret_cast<int *>(rows + kPoseChunk * kRowWords);  // [0] unit, [1] brick
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const BrickGrid bg = TRI ? tri_brick_grid(p.D) : brick_grid(p.D);
+    const int n_bricks = bg.nx * bg.ny * bg.nz;
+    const int N = p.det_h * p.det_w;
+    // wave-private: written and read by lanes of the same wave only.  LDS operations of a
+    // wave execute in order; wave_fence() keeps the compiler from reordering them.
+    unsigned *myq = queue + wave * kBuckets * kQueueCap;
+    const unsigned pix_mask = (1u << p.pix_bits) - 1u;
+    const int n_chunks = (p.B + kPoseChunk - 1) / kPoseChunk;
+    const bool vec_ok = (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.vol) & 15) == 0;
+    const bool vec_out = GRAD && (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.g_volume) & 15) == 0;
+    // fixed-point scale of the LDS accumulator (volume-gradient modes): the largest sum a
+    // voxel can receive is n_sum (contributions) * wmax (each) -- volgrad_prepare_kernel
+    float fixq = 0.f;
+    if (GRAD && !(p.dbg & 32)) {
+        const float wmax = __uint_as_float((unsigned)p.work[1]);
+        const float n_sum = reinterpret_cast<const float *>(p.work)[2];
+        if (wmax > 0.f && wmax < 1e30f && n_sum > 0.f && n_sum <= 16384.f)
+            fixq = 2.0e9f / (n_sum * wmax);
+    }
+
+  // Persistent workgroups: bricks are handed out by a global counter, so a CU that drew
+  // light bricks (far from the sources: fewer rays cross them) simply takes more of them.
+  for (;;) {
+    __syncthreads();  // every wave is done with the previous brick's LDS
+    if (tid == 0) counter[1] = atomicAdd(p.work, 1);
+    __syncthreads();
+    const int brick_id = counter[1];
+    if (brick_id >= n_bricks) break;
+    // `box`: the voxels staged in LDS; `cells`: the planes the candidates are clipped against
+    Box box;
+    BoxF cells;
+    if (TRI) {
+        int lo[3];
+        tri_brick_lo(bg, brick_id, lo);
+        const int Dn[3] = {p.D.x, p.D.y, p.D.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            box.lo[a] = lo[a];  // may be -1: staged as zeros (the zero padding)
+            box.hi[a] = lo[a] + BRICK < Dn[a] ? lo[a] + BRICK : Dn[a];
+            cells.lo[a] = (float)lo[a] + 0.5f;  // g = lo  <=>  plane index lo + 1/2
+            cells.hi[a] = (float)(lo[a] + TRI_CELLS) + 0.5f;
+        }
+    } else {
+        box = brick_box(p.D, bg, brick_id);
+        cells = boxf(box);
+        if (TRI_OWNER) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                // samples whose base cell is lo - 1 .. hi - 1 (g = c <=> plane index c + 1/2)
+                cells.lo[a] = (float)(box.lo[a] - 1) + 0.5f;
+                cells.hi[a] = (float)box.hi[a] + 0.5f;
+            }
+        }
+    }
+    BrickGeom G = brick_geom(box, p.lay);
+    if (TRI) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) G.lof[a] = (float)box.lo[a];
+    }
+    const float nscale = (TRI || TRI_OWNER) ? (float)(p.n_points - 1) / (p.amax[0] - p.amin[0]) : 0.f;
+    int qn0 = 0, qn1 = 0, qn2 = 0;  // hits waiting per length class (wave-uniform)
+
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const int b0 = ch * kPoseChunk;
+        const int nb = p.B - b0 < kPoseChunk ? p.B - b0 : kPoseChunk;
+        const bool last_chunk = ch == n_chunks - 1;
+        if (ch > 0) __syncthreads();  // previous chunk's table no longer in use
+        // The chunk's row table (one thread per pose) and, for the first chunk, the brick: a
+        // thread owns 8 quads of 4 floats; all of its loads are issued before the first LDS
+        // store, so a brick costs one memory round trip instead of eight.
+        constexpr int kQuads = BRICK * BRICK * 8 / kBrickThreads;
+        static_assert(kQuads * kBrickThreads == BRICK * BRICK * 8, "brick staging");
+        const int q4 = (tid & 7) * 4, z = box.lo[2] + q4;
+        float *const d0 = brick + q4;
+        const bool stage_vec = ch == 0 && !GRAD && !TRI && vec_ok;
+        // z and D.z are multiples of 4: a quad is wholly inside or wholly outside
+        const bool in_z = z + 4 <= box.hi[2];
+        if (tid < nb) {
+            const PoseGrid pg = pose_grid(p.source + (long)(b0 + tid) * 3,
+                                          p.target + (long)(b0 + tid) * N * 3, p.det_h, p.det_w);
+            const PixBox pb = project_brick_grid(pg, p.det_h, p.det_w, cells, p.shift);
+            BrickRow r = brick_row(pg, pb, cells, p.shift, p.eps, nscale);
+            if (GRAD && !(p.dbg & 16)) r.perm_k = scatter_perm_k(r.w, r.count);
+            *reinterpret_cast<BrickRow *>(rows + tid * kRowWords) = r;
+        }
+        if (tid == 0) counter[0] = 0;
+        float4 q[kQuads];
+        if (stage_vec) {
+#pragma unroll
+            for (int it = 0; it < kQuads; ++it) {
+                const int row = (tid >> 3) + it * (kBrickThreads >> 3);
+                const int lx = row / BRICK, ly = row - lx * BRICK;
+                const int x = box.lo[0] + lx, y = box.lo[1] + ly;
+                // clamped (always readable) address; what lies outside is zeroed below
+                const int xc = x < p.D.x ? x : p.D.x - 1, yc = y < p.D.y ? y : p.D.y - 1;
+                q[it] = *reinterpret_cast<const float4 *>(
+                    p.vol + ((long)xc * p.D.y + yc) * p.D.z + (in_z ? z : 0));
+            }
+        }
+        if (stage_vec) {
+#pragma unroll
+            for (int it = 0; it < kQuads; ++it) {
+                const int row = (tid >> 3) + it * (kBrickThreads >> 3);
+                const int lx = row / BRICK, ly = row - lx * BRICK;
+                const bool in = in_z && box.lo[0] + lx < box.hi[0] && box.lo[1] + ly < box.hi[1];
+                float *d = d0 + lx * p.lay.sx + ly * p.lay.sy;
+                d[0] = in ? q[it].x : 0.f;
+                d[1] = in ? q[it].y : 0.f;
+                d[2] = in ? q[it].z : 0.f;
+                d[3] = in ? q[it].w : 0.f;
+            }
+        } else if (ch == 0) {
+            // general path (halo bricks of the trilinear marcher, unaligned volumes, and the
+            // zero fill of the gradient accumulator), two quads in flight
+#pragma unroll 1
+            for (int h = 0; h < kQuads; h += 2) {
+                float v[2][4];
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int row = (tid >> 3) + (h + it) * (kBrickThreads >> 3);
+                    const int lx = row / BRICK, ly = row - lx * BRICK;
+                    const int x = box.lo[0] + lx, y = box.lo[1] + ly;
+                    const bool in_xy = !GRAD && x >= 0 && y >= 0 && x < box.hi[0] && y < box.hi[1];
+                    const int xc = clampi(x, 0, p.D.x - 1), yc = clampi(y, 0, p.D.y - 1);
+                    const float *g = p.vol + ((long)xc * p.D.y + yc) * p.D.z;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool in = in_xy && z + k >= 0 && z + k < box.hi[2];
+                        v[it][k] = in ? g[z + k] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int row = (tid >> 3) + (h + it) * (kBrickThreads >> 3);
+                    const int lx = row / BRICK, ly = row - lx * BRICK;
+                    float *d = d0 + lx * p.lay.sx + ly * p.lay.sy;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d[k] = v[it][k];
+                }
+            }
+        }
+        __syncthreads();
+        // units per pose -> inclusive prefix, held by every wave in registers (lane k: pose k)
+        int incl = lane < nb ? (reinterpret_cast<const BrickRow *>(rows + lane * kRowWords)->count +
+                                63) >> 6
+                             : 0;
+#pragma unroll
+        for (int o = 1; o < kPoseChunk; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            incl += lane >= o ? up : 0;
+        }
+        const int units = __builtin_amdgcn_readlane(incl, kPoseChunk - 1);
+        int cur = 0, cur_lo = 0, cur_hi = __builtin_amdgcn_readlane(incl, 0);
+        for (;;) {
+            int u = 0;
+            if (lane == 0) u = atomicAdd(&counter[0], 1);
+            u = uni(u);
+            const bool drain = u >= units;  // no unit left in this chunk
+            if (drain && !last_chunk) break;
+            if (!drain) {
+                while (u >= cur_hi) {  // units arrive in increasing order: forward cursor
+                    ++cur;
+                    cur_lo = cur_hi;
+                    cur_hi = __builtin_amdgcn_readlane(incl, uni(cur));
+                }
+                const BrickRow r = *reinterpret_cast<const BrickRow *>(rows + cur * kRowWords);
+                int local = (u - cur_lo) * 64 + lane;
+                const bool valid = local < uni(r.count);
+                if (GRAD && valid)
+                    local = scatter_perm(local, uni(r.perm_k), uni(r.count),
+                                         1.0f / (float)uni(r.count));
+                int pix = 0;
+                float n_est = 0.f;
+                const bool hit = valid && brick_candidate(r, local, p.det_w, pix, n_est);
+                // With the backward record (5 atomics per hit instead of 1) the length class
+                // of a hit is that of the longest hit among its 8 neighbours in candidate
+                // order (consecutive pixels of a detector row): a batch is then made of runs
+                // of >= 8 adjacent pixels and its atomics touch few cache lines -- their cost
+                // is per line, not per lane (measured: 3.55 -> 2.74 ms; without the record
+                // the per-lane classes win, 1.87 vs 2.01 ms).
+                float n_grp = hit ? n_est : 0.f;
+                if ((AUX || MODE == BRICK_TRI_FWD_AUX) && !(p.dbg & 8)) {
+                    n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                        0, __builtin_bit_cast(int, n_grp), 0xB1, 0xf, 0xf, true)));   // lane ^ 1
+                    n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                        0, __builtin_bit_cast(int, n_grp), 0x4E, 0xf, 0xf, true)));   // lane ^ 2
+                    n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                        0, __builtin_bit_cast(int, n_grp), 0x141, 0xf, 0xf, true)));  // 7 - lane
+                }
+                const bool c0 = n_grp < p.t1, c1 = !c0 && n_grp < p.t2;
+                const unsigned long long m0 = __ballot(hit && c0);
+                const unsigned long long m1 = __ballot(hit && c1);
+                const unsigned long long m2 = __ballot(hit && !c0 && !c1);
+                if (hit) {
+                    const int r0 = lane_rank(m0), r1 = lane_rank(m1), r2 = lane_rank(m2);
+                    const int slot = c0 ? qn0 + r0 : (c1 ? kQueueCap + qn1 + r1
+                                                         : 2 * kQueueCap + qn2 + r2);
+                    myq[slot] = ((unsigned)(b0 + cur) << p.pix_bits) | (unsigned)pix;
+                }
+                qn0 = uni(qn0 + (int)__popcll(m0));
+                qn1 = uni(qn1 + (int)__popcll(m1));
+                qn2 = uni(qn2 + (int)__popcll(m2));
+                wave_fence();
+            }
+            // walk every full batch of 64 hits of one class; when draining, what is left
+            // of all classes together (longest first), 64 at a time
+            for (;;) {
+                int k = -1, n = 0;
+                if (qn0 >= 64) k = 0, n = 64;
+                else if (qn1 >= 64) k = 1, n = 64;
+                else if (qn2 >= 64) k = 2, n = 64;
+                unsigned e = 0;
+                if (k >= 0) {
+                    const int base = (k == 0 ? qn0 : (k == 1 ? qn1 : qn2)) - 64;
+                    qn0 -= k == 0 ? 64 : 0;
+                    qn1 -= k == 1 ? 64 : 0;
+                    qn2 -= k == 2 ? 64 : 0;
+                    e = myq[k * kQueueCap + base + lane];
+                } else if (drain && qn0 + qn1 + qn2 > 0) {
+                    // virtual queue [class 2 | class 1 | class 0], taken from the front
+                    const int tot = qn0 + qn1 + qn2;
+                    n = tot < 64 ? tot : 64;
+                    const int i2 = lane, i1 = lane - qn2, i0 = lane - qn2 - qn1;
+                    if (lane < n)
+                        e = i2 < qn2 ? myq[2 * kQueueCap + qn2 - 1 - i2]
+                                     : (i1 < qn1 ? myq[kQueueCap + qn1 - 1 - i1]
+                                                 : myq[qn0 - 1 - i0]);
+                    // consumed from the tops of the stacks
+                    const int t2 = qn2 < n ? qn2 : n;
+                    const int t1 = qn1 < n - t2 ? qn1 : n - t2;
+                    qn2 -= t2;
+                    qn1 -= t1;
+                    qn0 -= n - t2 - t1;
+                } else {
+                    break;
+                }
+                if (lane < n)
+                    brick_item<MODE>(p, brick, G, e >> p.pix_bits, e & pix_mask, fixq, out, aux);
+                wave_fence();
+            }
+            if (drain) break;
+        }
+    }
+    if (GRAD) {
+        // every ray of every pose has been scattered into the LDS accumulator, and the brick
+        // owns its voxels (Siddon bricks, and the marcher's owner bricks): the gradient is
+        // complete and is stored, 16 bytes per thread
+        __syncthreads();
+        for (int row = tid >> 3; row < BRICK * BRICK; row += kBrickThreads >> 3) {
+            const int lx = row / BRICK, ly = row - lx * BRICK, q4 = (tid & 7) * 4;
+            const int x = box.lo[0] + lx, y = box.lo[1] + ly, z = box.lo[2] + q4;
+            if (x < box.hi[0] && y < box.hi[1]) {
+                const float *src = brick + lx * p.lay.sx + ly * p.lay.sy + q4;
+                float *g = p.g_volume + ((long)x * p.D.y + y) * p.D.z + z;
+                float val[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    val[k] = fixq != 0.f ? (float)__float_as_int(src[k]) / fixq : src[k];
+                if (vec_out && z + 4 <= box.hi[2]) {
+                    *reinterpret_cast<float4 *>(g) = make_float4(val[0], val[1], val[2], val[3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (z + k < box.hi[2]) g[k] = val[k];
+                }
+            }
+        }
+    }
+  }
+}
+
+// ------------------------------------------- volume-gradient fixed-point bound
+// work[1] = bits of max over rays of the largest single contribution a ray can make to a
+// voxel; work[2] = float: bound on the number of such contributions a voxel can receive in
+// this launch (sum over poses of the rays that can cross one voxel); see LdsAbsAdd.
+//   Siddon:    |g| L dalpha,  dalpha |d| <= sqrt(3)           ->  sqrt(3) |g| L / |d|
+//   trilinear: |g| L step per sample, at most 2 sqrt(3) / (step |d|) + 1 samples of a ray
+//              touch one voxel                                 ->  |g| L (2 sqrt(3) / |d| + step)
+// Rays of a pose through one voxel: those whose pixel lies in the voxel's (8-cell's)
+// shadow, at most (extent * |t - s| / rho_min / e_min + 2)^2 with rho_min the distance from
+// the source to the volume (0: no bound, the float path is taken).
+__global__ __launch_bounds__(kBlock) void volgrad_prepare_kernel(
+    int tri, const float *__restrict__ source, const float *__restrict__ target,
+    const float *__restrict__ img, const float *__restrict__ grad_out, int N, int det_w, Dims D,
+    float shift, float eps, int n_points, const float *__restrict__ amin,
+    const float *__restrict__ amax, int *__restrict__ work) {
+    const int b = blockIdx.y;
+    const float s[3] = {source[b * 3], source[b * 3 + 1], source[b * 3 + 2]};
+    const float step = tri ? (amax[0] - amin[0]) / (float)(n_points - 1) : 0.f;
+    float wmax = 0.f;
+    for (int n = blockIdx.x * kBlock + threadIdx.x; n < N; n += gridDim.x * kBlock) {
+        const long r = (long)b * N + n;
+        const float dx = target[r * 3] - s[0] + eps, dy = target[r * 3 + 1] - s[1] + eps;
+        const float dz = target[r * 3 + 2] - s[2] + eps;
+        const float dn = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float L = img ? img[r] : 1.f;
+        const float c = tri ? (3.4642f / dn + step) : 1.7321f / dn;
+        wmax = fmaxf(wmax, fabsf(grad_out[r]) * L * c);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(work) + 1, __float_as_uint(wmax));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // distance from the source to the volume box (voxel coordinates, planes at k - shift)
+        const float lo = -shift, hi[3] = {(float)D.x - shift, (float)D.y - shift, (float)D.z - shift};
+        float rho2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float gap = fmaxf(fmaxf(lo - s[a], s[a] - hi[a]), 0.f);
+            rho2 += gap * gap;
+        }
+        const float *t0 = target + (long)b * N * 3;
+        float e_i = 0.f, e_j = 0.f, dst = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float di = t0[(long)det_w * 3 + a] - t0[a], dj = t0[3 + a] - t0[a];
+            const float dt = t0[a] - s[a];
+            e_i += di * di;
+            e_j += dj * dj;
+            dst += dt * dt;
+        }
+        // the detector point farthest from the source bounds |t - s| (corner pixels)
+        const float *tc = t0 + (long)(N - 1) * 3;
+        float dst2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dst2 += (tc[a] - s[a]) * (tc[a] - s[a]);
+        const float reach = sqrtf(fmaxf(dst, dst2)), e_min = sqrtf(fminf(e_i, e_j));
+        const float extent = tri ? 3.4642f : 1.7321f;
+        float R = INFINITY;
+        if (rho2 > 1.f && e_min > 0.f) {
+            const float side = extent * reach / (sqrtf(rho2) * e_min) + 2.f;
+            R = side * side;
+        }
+        atomicAdd(reinterpret_cast<float *>(work) + 2, R);
+    }
+}
+
+// out = L * I from plane 0 of the Siddon planar record (the record launch leaves `out` alone:
+// one atomic less per ray and brick).
+__global__ __launch_bounds__(kBlock) void siddon_out_from_record_kernel(
+    const float *__restrict__ aux, const float *__restrict__ img, long R, float *__restrict__ out) {
+    const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (r < R) out[r] = (img ? img[r] : 1.f) * aux[r];
+}
+
+// out = L * step * sumT from plane 0 of the marcher's planar record (the record launch
+// does not touch `out`).
+__global__ __launch_bounds__(kBlock) void tri_out_from_record_kernel(
+    const float *__restrict__ aux, const float *__restrict__ img, long R, int n_points,
+    const float *__restrict__ amin, const float *__restrict__ amax, float *__restrict__ out) {
+    const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= R) return;
+    const float step = (amax[0] - amin[0]) / (float)(n_points - 1);  // renderers.py:235
+    out[r] = (img ? img[r] : 1.f) * step * aux[r];
+}
+
+// Ray / range gradients of the march from the planar record of ddrr_trilinear_forward_bricks
+// (planes sumT, sum dT_xyz, sum alpha dT_xyz of R floats each): elementwise.
+__global__ __launch_bounds__(kBlock) void trilinear_bwd_record_kernel(
+    const float *__restrict__ aux, const float *__restrict__ grad_out,
+    const float *__restrict__ source, const float *__restrict__ target,
+    const float *__restrict__ img, long R, int N, float eps, int n_points,
+    const float *__restrict__ amin, const float *__restrict__ amax, float *__restrict__ g_source,
+    float *__restrict__ g_target, float *__restrict__ g_img, float *__restrict__ g_alpha) {
+    const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= R) return;
+    const long b = r / N;
+    const float *sp = source + b * 3, *tp = target + r * 3;
+    const float s[3] = {sp[0], sp[1], sp[2]}, t[3] = {tp[0], tp[1], tp[2]};
+    const float A[3] = {aux[R + r], aux[2 * R + r], aux[3 * R + r]};
+    const float Bv[3] = {aux[4 * R + r], aux[5 * R + r], aux[6 * R + r]};
+    const float g = grad_out[r], L = img ? img[r] : 1.f;
+    const float a0 = amin[0], a1 = amax[0];
+    const MarchGrad m = trilinear_backward_from_record(aux[r], A, Bv, s, t, eps, n_points, a0, a1,
+                                                       g * L);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (g_source) g_source[r * 3 + a] = m.gs[a];
+        if (g_target) g_target[r * 3 + a] = m.gt[a];
+    }
+    if (g_img) g_img[r] = g * m.sumT * ((a1 - a0) / (float)(n_points - 1));
+    if (g_alpha) {
+        g_alpha[r * 2 + 0] = m.g_amin;
+        g_alpha[r * 2 + 1] = m.g_amax;
+    }
+}
+
+// LDS layout of a brick (floats): rows padded 32 -> 33, planes 32*33 -> 1057, so that
+// x-, y- and z-neighbours all fall in different banks.
+BrickLayout g_brick_layout = {33, 32 * 33 + 1};
+// length classes of brick hits (estimated plane crossings inside the brick)
+float g_brick_t1 = 18.f, g_brick_t2 = 40.f;
+float g_tri_t1 = 10.f, g_tri_t2 = 22.f;  // same for the marcher, in samples per brick
+int g_brick_dbg = 0;
+
+int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const float *source,
+                  const float *target, const float *img, const float *grad_out, int B, int det_h,
+                  int det_w, float voxel_shift, float eps, float *out, float *aux,
+                  float *g_volume, hipStream_t st, const char *who, int n_points = 0,
+                  const float *amin = nullptr, const float *amax = nullptr) {
+    const int N = det_h * det_w;
+    BrickArgs p;
+    p.vol = volume;
+    p.D = Dims{dx, dy, dz};
+    p.source = source;
+    p.target = target;
+    p.img = img;
+    p.B = B;
+    p.det_h = det_h;
+    p.det_w = det_w;
+    p.shift = voxel_shift;
+    p.eps = eps;
+    p.lay = g_brick_layout;
+    if ((long)B * N * 12 >= (1L << 32))
+        return fail(-1, "B * N too large for one brick launch (12 B N must stay below 2^32): "
+                        "split the pose batch");
+    p.aux_plane = (unsigned)((long)B * N);
+    p.pix_bits = 1;
+    while ((1L << p.pix_bits) < N) ++p.pix_bits;
+    if (((long)B << p.pix_bits) > (1L << 32))
+        return fail(-1, "B * 2^ceil(log2 N) exceeds 2^32: split the pose batch");
+    p.t1 = g_brick_t1;
+    p.t2 = g_brick_t2;
+    p.dbg = g_brick_dbg;
+    p.grad_out = grad_out;
+    p.g_volume = g_volume;
+    p.n_points = n_points;
+    p.amin = amin;
+    p.amax = amax;
+    if (mode == BRICK_TRI_FWD || mode == BRICK_TRI_VOLGRAD || mode == BRICK_TRI_FWD_AUX) {
+        p.t1 = g_tri_t1;
+        p.t2 = g_tri_t2;
+    }
+    const size_t lds = brick_lds_bytes(p.lay);
+    hipError_t e;
+    static bool attr_set = false;  // raise the dynamic-LDS limit once per process
+    if (!attr_set) {
+        const void *fns[6] = {reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_FWD_AUX>),
+                              reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_FWD>),
+                              reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_FWD_AUX>),
+                              reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_VOLGRAD>),
+                              reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_FWD>),
+                              reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_VOLGRAD>)};
+        for (const void *fn : fns)
+            if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024)) != hipSuccess)
+                return fail_hip(e, "hipFuncSetAttribute");
+        attr_set = true;
+    }
+    // one brick counter per launch, from a small per-device ring (launches in flight on
+    // different streams must not share one); zeroed on the launch's stream
+    constexpr int kRing = 64, kMaxDev = 64;
+    static int *ring[kMaxDev] = {nullptr};
+    static int n_cu[kMaxDev] = {0};
+    static unsigned slot[kMaxDev] = {0};
+    int dev = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return fail_hip(e, "hipGetDevice");
+    if (dev < 0 || dev >= kMaxDev) return fail(-1, "device index out of range");
+    if (!ring[dev]) {
+        if ((e = hipMalloc(reinterpret_cast<void **>(&ring[dev]), kRing * 4 * sizeof(int))) != hipSuccess)
+            return fail_hip(e, "hipMalloc(brick counters)");
+        if ((e = hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev)) !=
+            hipSuccess)
+            return fail_hip(e, "hipDeviceGetAttribute");
+    }
+    p.work = ring[dev] + 4 * (slot[dev]++ % kRing);  // {brick counter, wmax bits, n_sum, -}
+    if ((e = hipMemsetAsync(p.work, 0, 4 * sizeof(int), st)) != hipSuccess)
+        return fail_hip(e, "hipMemsetAsync");
+    if (mode == BRICK_VOLGRAD || mode == BRICK_TRI_VOLGRAD) {
+        const int tri = mode == BRICK_TRI_VOLGRAD;
+        int bx = (N + kBlock - 1) / kBlock;
+        bx = bx > 64 ? 64 : bx;
+        hipLaunchKernelGGL(volgrad_prepare_kernel, dim3(bx, B), dim3(kBlock), 0, st, tri, source,
+                           target, img, grad_out, N, det_w, p.D, voxel_shift, eps, n_points, amin,
+                           amax, p.work);
+    }
+    const BrickGrid bg = (mode == BRICK_TRI_FWD || mode == BRICK_TRI_FWD_AUX) ? tri_brick_grid(p.D)
+                                                                              : brick_grid(p.D);
+    const int n_bricks = bg.nx * bg.ny * bg.nz;
+    const dim3 grid(n_bricks < n_cu[dev] ? n_bricks : n_cu[dev]), block(kBrickThreads);
+    if (mode == BRICK_TRI_FWD)
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_FWD>, grid, block, lds, st, p, out, aux);
+    else if (mode == BRICK_TRI_FWD_AUX)
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_FWD_AUX>, grid, block, lds, st, p, out,
+                           aux);
+    else if (mode == BRICK_TRI_VOLGRAD)
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_VOLGRAD>, grid, block, lds, st, p, out,
+                           aux);
+    else if (mode == BRICK_FWD)
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_FWD>, grid, block, lds, st, p, out, aux);
+    else if (mode == BRICK_FWD_AUX)
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_FWD_AUX>, grid, block, lds, st, p, out, aux);
+    else
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_VOLGRAD>, grid, block, lds, st, p, out, aux);
+    return finish(who);
+}
+
+}  // namespace
+
+extern "C" {
+
+// Experiment knob: LDS strides (floats) of a staged brick; sy >= 32, sx >= 32 * sy.
+int ddrr_set_brick_layout(int sy, int sx) {
+    if (sy < BRICK || sx < BRICK * sy) return -1;
+    BrickLayout lay = {sy, sx};
+    if (brick_lds_bytes(lay) > 160 * 1024) return -1;
+    g_brick_layout = lay;
+    return 0;
+}
+// Experiment switches of the brick kernels (0 in production; results are wrong with 1, 2):
+//   1 skip the record's atomics, 2 skip the image atomic, 8 per-lane length classes also with
+//   the record (no groups of 8 pixels), 16 no scatter permutation, 32 float LDS accumulation.
+// profiles/r01/exp_record_cost.txt holds the decomposition these gave for the record.
+int ddrr_set_brick_debug(int flags) {
+    g_brick_dbg = flags;
+    return 0;
+}
+int ddrr_set_brick_classes(float t1, float t2) {
+    g_brick_t1 = t1;
+    g_brick_t2 = t2;
+    return 0;
+}
+
+int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
+                               const float *target, const float *img, int B, int det_h,
+                               int det_w, float voxel_shift, float eps, float *out, float *aux,
+                               void *stream) {
+    const int N = det_h * det_w;
+    if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
+    if (!out) return fail(-1, "null out pointer");
+    if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const long R = (long)B * N;
+    hipError_t e = hipMemsetAsync(aux ? aux : out, 0,
+                                  sizeof(float) * (size_t)R * (aux ? kBrickAuxPlanes : 1), st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    if (int rc = launch_bricks(aux ? BRICK_FWD_AUX : BRICK_FWD, volume, dx, dy, dz, source, target,
+                               img, nullptr, B, det_h, det_w, voxel_shift, eps, out, aux, nullptr,
+                               st, "ddrr_siddon_forward_bricks"))
+        return rc;
+    if (!aux) return 0;
+    hipLaunchKernelGGL(siddon_out_from_record_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, st, aux, img, R, out);
+    return finish("ddrr_siddon_forward_bricks");
+}
+
+int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *source,
+                                       const float *target, const float *img,
+                                       const float *grad_out, int B, int det_h, int det_w,
+                                       float voxel_shift, float eps, float *g_volume,
+                                       void *stream) {
+    const int N = det_h * det_w;
+    if (!g_volume || !grad_out) return fail(-1, "null grad_out / g_volume");
+    if (int rc = check_common(g_volume, dx, dy, dz, source, 1, target, B, N)) return rc;
+    if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {  // nothing contributes: the gradient is zero
+        hipError_t e = hipMemsetAsync(g_volume, 0, sizeof(float) * (size_t)dx * dy * dz, st);
+        return e == hipSuccess ? 0 : fail_hip(e, "hipMemsetAsync");
+    }
+    return launch_bricks(BRICK_VOLGRAD, nullptr, dx, dy, dz, source, target, img, grad_out, B,
+                         det_h, det_w, voxel_shift, eps, nullptr, nullptr, g_volume, st,
+                         "ddrr_siddon_backward_volume_bricks");
+}
+
+int ddrr_trilinear_forward_bricks(const float *volume, int dx, int dy, int dz,
+                                  const float *source, const float *target, const float *img,
+                                  int B, int det_h, int det_w, float voxel_shift, float eps,
+                                  int n_points, const float *alphamin, const float *alphamax,
+                                  float *out, float *aux, void *stream) {
+    const int N = det_h * det_w;
+    if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
+    if (!out || !alphamin || !alphamax) return fail(-1, "null out / alphamin / alphamax");
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const long R = (long)B * N;
+    hipError_t e = hipMemsetAsync(aux ? aux : out, 0,
+                                  sizeof(float) * (size_t)R * (aux ? DDRR_TRI_AUX_PLANES : 1), st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    if (!aux)
+        return launch_bricks(BRICK_TRI_FWD, volume, dx, dy, dz, source, target, img, nullptr, B,
+                             det_h, det_w, voxel_shift, eps, out, nullptr, nullptr, st,
+                             "ddrr_trilinear_forward_bricks", n_points, alphamin, alphamax);
+    if (int rc = launch_bricks(BRICK_TRI_FWD_AUX, volume, dx, dy, dz, source, target, img, nullptr,
+                               B, det_h, det_w, voxel_shift, eps, out, aux, nullptr, st,
+                               "ddrr_trilinear_forward_bricks", n_points, alphamin, alphamax))
+        return rc;
+    hipLaunchKernelGGL(tri_out_from_record_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, st, aux, img, R, n_points, alphamin, alphamax, out);
+    return finish("ddrr_trilinear_forward_bricks");
+}
+
+int ddrr_trilinear_backward_rays(const float *aux, const float *grad_out, const float *source,
+                                 const float *target, const float *img, int B, int N, float eps,
+                                 int n_points, const float *alphamin, const float *alphamax,
+                                 float *g_source, float *g_target, float *g_img, float *g_alpha,
+                                 void *stream) {
+    if (!aux || !grad_out || !source || !target || !alphamin || !alphamax)
+        return fail(-1, "null pointer");
+    if (B < 0 || N < 0) return fail(-1, "negative batch or ray count");
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    const long R = (long)B * N;
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(trilinear_bwd_record_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, (hipStream_t)stream, aux, grad_out, source, target, img, R,
+                       N, eps, n_points, alphamin, alphamax, g_source, g_target, g_img, g_alpha);
+    return finish("ddrr_trilinear_backward_rays");
+}
+
+int ddrr_trilinear_backward_volume_bricks(int dx, int dy, int dz, const float *source,
+                                          const float *target, const float *img,
+                                          const float *grad_out, int B, int det_h, int det_w,
+                                          float voxel_shift, float eps, int n_points,
+                                          const float *alphamin, const float *alphamax,
+                                          float *g_volume, void *stream) {
+    const int N = det_h * det_w;
+    if (!g_volume || !grad_out || !alphamin || !alphamax)
+        return fail(-1, "null grad_out / g_volume / alphamin / alphamax");
+    if (int rc = check_common(g_volume, dx, dy, dz, source, 1, target, B, N)) return rc;
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        hipError_t e = hipMemsetAsync(g_volume, 0, sizeof(float) * (size_t)dx * dy * dz, st);
+        return e == hipSuccess ? 0 : fail_hip(e, "hipMemsetAsync");
+    }
+    return launch_bricks(BRICK_TRI_VOLGRAD, nullptr, dx, dy, dz, source, target, img, grad_out, B,
+                         det_h, det_w, voxel_shift, eps, nullptr, nullptr, g_volume, st,
+                         "ddrr_trilinear_backward_volume_bricks", n_points, alphamin, alphamax);
+}
+
+}  // extern "C"

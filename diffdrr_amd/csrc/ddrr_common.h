@@ -4,7 +4,7 @@
 // same source can also be compiled for the host by the test-only emulation
 // build (tests/emu), which lets the traversal logic be checked against the
 // oracle in the GPU-less build container.  The product only ever runs the
-// __global__ kernels in ddrr_kernels.hip.
+// __global__ kernels of the *.hip translation units.
 #pragma once
 
 #include <math.h>

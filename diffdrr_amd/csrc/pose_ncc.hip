@@ -1,0 +1,286 @@
+// pose_ncc.hip -- the small kernels either side of the renderers on the DRR path: Euler pose ->
+// world matrix, fused ray generation, the pose-gradient reduction, normalised cross-correlation.
+#include "runtime.h"
+#include "siddon_core.h"
+#include "raygen_core.h"
+
+using namespace ddrr;
+using namespace ddrr_rt;
+
+namespace {
+
+// ------------------------------------------------ fused ray generation (DRR case)
+
+// source_v (B,3), target_v (B,N,3), img (B,N) from one world pose per DRR (raygen_core.h)
+__global__ __launch_bounds__(kBlock) void raygen_fwd_kernel(
+    const float *__restrict__ Mw, const float *__restrict__ Ainv, const float *__restrict__ P,
+    int N, float *__restrict__ source_v, float *__restrict__ target_v, float *__restrict__ img) {
+    const int b = blockIdx.y, n = blockIdx.x * kBlock + threadIdx.x;
+    const float *M = Mw + (long)b * 12;
+    if (n == 0) {
+        const float sw[3] = {M[3], M[7], M[11]};
+        float sv[3];
+        apply34(Ainv, sw, sv);
+        source_v[b * 3 + 0] = sv[0];
+        source_v[b * 3 + 1] = sv[1];
+        source_v[b * 3 + 2] = sv[2];
+    }
+    if (n >= N) return;
+    const float Pn[3] = {P[n * 3], P[n * 3 + 1], P[n * 3 + 2]};
+    const RayGenOut o = raygen_ray(M, Ainv, Pn);
+    const long r = (long)b * N + n;
+    target_v[r * 3 + 0] = o.tv[0];
+    target_v[r * 3 + 1] = o.tv[1];
+    target_v[r * 3 + 2] = o.tv[2];
+    img[r] = o.L;
+}
+
+// dLoss/dMw (B,3,4) from the forward's backward record: the renderer's per-ray endpoint
+// gradients (siddon_backward_ray) are chained through the ray generation and reduced per
+// pose inside the kernel; no per-ray gradient tensor is written.  A block covers
+// kPoseRaysPerBlock rays of one pose and adds its 12 partial sums with atomics.
+constexpr int kPoseRaysPerBlock = 4096;
+
+__global__ __launch_bounds__(kBlock) void siddon_bwd_pose_kernel(
+    const float *__restrict__ aux, int planar, const float *__restrict__ grad_out,
+    const float *__restrict__ source_v, const float *__restrict__ target_v,
+    const float *__restrict__ img, const float *__restrict__ Mw, const float *__restrict__ Ainv,
+    const float *__restrict__ P, int B, int N, float eps, int with_img_path,
+    float *__restrict__ gMw) {
+    __shared__ float red[kWavesPerBlock][12];
+    const int b = blockIdx.y;
+    const long R = (long)B * N;
+    const float *M = Mw + (long)b * 12;
+    const float s[3] = {source_v[b * 3], source_v[b * 3 + 1], source_v[b * 3 + 2]};
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    const int n_end = min(N, (int)(blockIdx.x + 1) * kPoseRaysPerBlock);
+    for (int n = blockIdx.x * kPoseRaysPerBlock + threadIdx.x; n < n_end; n += kBlock) {
+        const long r = (long)b * N + n;
+        float rec[SIDDON_AUX];
+        if (planar) {
+            const float I = aux[r], S0x = aux[R + r], S0z = aux[2 * R + r];
+            const float S1x = aux[3 * R + r], S1z = aux[4 * R + r];
+            rec[0] = I, rec[1] = S0x, rec[2] = -(S0x + S0z), rec[3] = S0z;
+            rec[4] = S1x, rec[5] = I - (S1x + S1z), rec[6] = S1z, rec[7] = 0.f;
+        } else {
+            const float4 *a4 = reinterpret_cast<const float4 *>(aux + r * SIDDON_AUX);
+            const float4 lo = a4[0], hi = a4[1];
+            rec[0] = lo.x, rec[1] = lo.y, rec[2] = lo.z, rec[3] = lo.w;
+            rec[4] = hi.x, rec[5] = hi.y, rec[6] = hi.z, rec[7] = hi.w;
+        }
+        const float t[3] = {target_v[r * 3], target_v[r * 3 + 1], target_v[r * 3 + 2]};
+        const float Pn[3] = {P[n * 3], P[n * 3 + 1], P[n * 3 + 2]};
+        const float g = grad_out[r], L = img[r];
+        float gs[3], gt[3];
+        siddon_backward_ray<REDUCE_SUM>(rec, s, t, eps, g * L, gs, gt);
+        raygen_ray_adjoint(M, Ainv, Pn, gt, gs, with_img_path ? g * rec[0] : 0.f, L, acc);
+    }
+    // 12 sums over the block: wave butterflies, then the 4 waves through LDS
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o, 64);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) red[wave][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) v += red[w][threadIdx.x];
+        unsafeAtomicAdd(gMw + (long)b * 12 + threadIdx.x, v);
+    }
+}
+
+// -------------------------------------------------- Euler pose -> world matrix
+__global__ __launch_bounds__(kBlock) void pose_euler_fwd_kernel(
+    const float *__restrict__ rot, const float *__restrict__ xyz, int a0, int a1, int a2,
+    const float *__restrict__ Ro, int B, float *__restrict__ Mw) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= B) return;
+    const float th[3] = {rot[b * 3], rot[b * 3 + 1], rot[b * 3 + 2]};
+    const float t[3] = {xyz[b * 3], xyz[b * 3 + 1], xyz[b * 3 + 2]};
+    const int axes[3] = {a0, a1, a2};
+    float M[12];
+    pose_euler_forward(th, t, axes, Ro, M);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Mw[b * 12 + k] = M[k];
+}
+
+__global__ __launch_bounds__(kBlock) void pose_euler_bwd_kernel(
+    const float *__restrict__ rot, const float *__restrict__ xyz, int a0, int a1, int a2,
+    const float *__restrict__ Ro, const float *__restrict__ gMw, int B, float *__restrict__ g_rot,
+    float *__restrict__ g_xyz) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= B) return;
+    const float th[3] = {rot[b * 3], rot[b * 3 + 1], rot[b * 3 + 2]};
+    const float t[3] = {xyz[b * 3], xyz[b * 3 + 1], xyz[b * 3 + 2]};
+    const int axes[3] = {a0, a1, a2};
+    float g[12], gt[3], gx[3];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) g[k] = gMw[b * 12 + k];
+    pose_euler_backward(th, t, axes, Ro, g, gt, gx);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        g_rot[b * 3 + k] = gt[k];
+        g_xyz[b * 3 + k] = gx[k];
+    }
+}
+
+// ------------------------------------------------- fused NCC (sweep / registration)
+// NormalizedCrossCorrelation2d with patch_size = None (reference metrics.py:21-44):
+// ncc_b = mean(z1 * z2), z = (x - mean) / sqrt(var + eps), one value per image pair.
+// One workgroup per pair, two passes over the pair (means, then centred moments: no
+// cancellation); stats[b] = {mu1, s1, mu2, s2, ncc}.  x1 may be one image shared by the
+// whole batch (x1_stride = 0).
+constexpr int kNccThreads = 1024;
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();  // red may still be read by the previous call
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < kNccThreads / 64; ++w) t += red[w];
+    return t;
+}
+
+__global__ __launch_bounds__(kNccThreads) void ncc_fwd_kernel(
+    const float *__restrict__ x1, long x1_stride, const float *__restrict__ x2, int N, float eps,
+    float *__restrict__ out, float *__restrict__ stats) {
+    __shared__ float red[kNccThreads / 64];
+    const int b = blockIdx.x;
+    const float *p1 = x1 + b * x1_stride, *p2 = x2 + (long)b * N;
+    float a1 = 0.f, a2 = 0.f;
+    for (int n = threadIdx.x; n < N; n += kNccThreads) {
+        a1 += p1[n];
+        a2 += p2[n];
+    }
+    const float inv_n = 1.0f / (float)N;
+    const float mu1 = block_sum(a1, red) * inv_n, mu2 = block_sum(a2, red) * inv_n;
+    float v1 = 0.f, v2 = 0.f, c12 = 0.f;
+    for (int n = threadIdx.x; n < N; n += kNccThreads) {
+        const float d1 = p1[n] - mu1, d2 = p2[n] - mu2;
+        v1 = fmaf(d1, d1, v1);
+        v2 = fmaf(d2, d2, v2);
+        c12 = fmaf(d1, d2, c12);
+    }
+    const float s1 = sqrtf(block_sum(v1, red) * inv_n + eps);
+    const float s2 = sqrtf(block_sum(v2, red) * inv_n + eps);
+    const float ncc = block_sum(c12, red) * inv_n / (s1 * s2);
+    if (threadIdx.x == 0) {
+        out[b] = ncc;
+        stats[b * 5 + 0] = mu1;
+        stats[b * 5 + 1] = s1;
+        stats[b * 5 + 2] = mu2;
+        stats[b * 5 + 3] = s2;
+        stats[b * 5 + 4] = ncc;
+    }
+}
+
+// d ncc / d x2[n] = (z1[n] - z2[n] ncc) / (N s2), and symmetrically for x1 (per pair; a
+// shared x1 gets no gradient from this kernel).
+__global__ __launch_bounds__(kBlock) void ncc_bwd_kernel(
+    const float *__restrict__ x1, long x1_stride, const float *__restrict__ x2,
+    const float *__restrict__ stats, const float *__restrict__ g_out, int N,
+    float *__restrict__ g_x1, float *__restrict__ g_x2) {
+    const int b = blockIdx.y, n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const float mu1 = stats[b * 5], s1 = stats[b * 5 + 1], mu2 = stats[b * 5 + 2];
+    const float s2 = stats[b * 5 + 3], ncc = stats[b * 5 + 4];
+    const float z1 = (x1[b * x1_stride + n] - mu1) / s1, z2 = (x2[(long)b * N + n] - mu2) / s2;
+    const float g = g_out[b] / (float)N;
+    if (g_x2) g_x2[(long)b * N + n] = g * (z1 - z2 * ncc) / s2;
+    if (g_x1) g_x1[(long)b * N + n] = g * (z2 - z1 * ncc) / s1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ddrr_raygen_forward(const float *Mw, const float *Ainv, const float *P, int B, int N,
+                        float *source_v, float *target_v, float *img, void *stream) {
+    if (!Mw || !Ainv || !P || !source_v || !target_v || !img) return fail(-1, "null pointer");
+    if (B < 0 || N < 0) return fail(-1, "negative batch or ray count");
+    if (B == 0 || N == 0) return 0;
+    if (B > 65535) return fail(-1, "at most 65535 poses per call");
+    const dim3 grid((N + kBlock - 1) / kBlock, B), block(kBlock);
+    hipLaunchKernelGGL(raygen_fwd_kernel, grid, block, 0, (hipStream_t)stream, Mw, Ainv, P, N,
+                       source_v, target_v, img);
+    return finish("ddrr_raygen_forward");
+}
+
+int ddrr_siddon_backward_pose(const float *aux, int aux_layout, const float *grad_out,
+                              const float *source_v, const float *target_v, const float *img,
+                              const float *Mw, const float *Ainv, const float *P, int B, int N,
+                              float eps, int with_img_path, float *gMw, void *stream) {
+    if (!aux || !grad_out || !source_v || !target_v || !img || !Mw || !Ainv || !P || !gMw)
+        return fail(-1, "null pointer");
+    if (aux_layout != DDRR_AUX_INTERLEAVED && aux_layout != DDRR_AUX_PLANAR)
+        return fail(-1, "bad aux_layout");
+    if (B < 0 || N < 0) return fail(-1, "negative batch or ray count");
+    if (B == 0) return 0;
+    if (B > 65535) return fail(-1, "at most 65535 poses per call");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(gMw, 0, sizeof(float) * 12 * (size_t)B, st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    if (N == 0) return 0;
+    const dim3 grid((N + kPoseRaysPerBlock - 1) / kPoseRaysPerBlock, B), block(kBlock);
+    hipLaunchKernelGGL(siddon_bwd_pose_kernel, grid, block, 0, st, aux, aux_layout, grad_out,
+                       source_v, target_v, img, Mw, Ainv, P, B, N, eps, with_img_path, gMw);
+    return finish("ddrr_siddon_backward_pose");
+}
+
+int ddrr_ncc_forward(const float *x1, long x1_stride, const float *x2, int B, int N, float eps,
+                     float *out, float *stats, void *stream) {
+    if (!x1 || !x2 || !out || !stats) return fail(-1, "null pointer");
+    if (B < 0 || N < 1) return fail(-1, "bad batch / image size");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(ncc_fwd_kernel, dim3(B), dim3(kNccThreads), 0, (hipStream_t)stream, x1,
+                       x1_stride, x2, N, eps, out, stats);
+    return finish("ddrr_ncc_forward");
+}
+
+int ddrr_ncc_backward(const float *x1, long x1_stride, const float *x2, const float *stats,
+                      const float *g_out, int B, int N, float *g_x1, float *g_x2, void *stream) {
+    if (!x1 || !x2 || !stats || !g_out) return fail(-1, "null pointer");
+    if (g_x1 && x1_stride == 0) return fail(-1, "a shared x1 gets no gradient here");
+    if (B < 0 || N < 1) return fail(-1, "bad batch / image size");
+    if (B == 0 || B > 65535) return B == 0 ? 0 : fail(-1, "at most 65535 pairs per call");
+    hipLaunchKernelGGL(ncc_bwd_kernel, dim3((N + kBlock - 1) / kBlock, B), dim3(kBlock), 0,
+                       (hipStream_t)stream, x1, x1_stride, x2, stats, g_out, N, g_x1, g_x2);
+    return finish("ddrr_ncc_backward");
+}
+
+int ddrr_pose_euler_forward(const float *rot, const float *xyz, int a0, int a1, int a2,
+                            const float *reorient34, int B, float *Mw, void *stream) {
+    if (!rot || !xyz || !reorient34 || !Mw) return fail(-1, "null pointer");
+    if (a0 < 0 || a0 > 2 || a1 < 0 || a1 > 2 || a2 < 0 || a2 > 2 || a1 == a0 || a1 == a2)
+        return fail(-1, "invalid Euler convention");
+    if (B <= 0) return B == 0 ? 0 : fail(-1, "negative batch");
+    hipLaunchKernelGGL(pose_euler_fwd_kernel, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                       (hipStream_t)stream, rot, xyz, a0, a1, a2, reorient34, B, Mw);
+    return finish("ddrr_pose_euler_forward");
+}
+
+int ddrr_pose_euler_backward(const float *rot, const float *xyz, int a0, int a1, int a2,
+                             const float *reorient34, const float *gMw, int B, float *g_rot,
+                             float *g_xyz, void *stream) {
+    if (!rot || !xyz || !reorient34 || !gMw || !g_rot || !g_xyz) return fail(-1, "null pointer");
+    if (a0 < 0 || a0 > 2 || a1 < 0 || a1 > 2 || a2 < 0 || a2 > 2 || a1 == a0 || a1 == a2)
+        return fail(-1, "invalid Euler convention");
+    if (B <= 0) return B == 0 ? 0 : fail(-1, "negative batch");
+    hipLaunchKernelGGL(pose_euler_bwd_kernel, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                       (hipStream_t)stream, rot, xyz, a0, a1, a2, reorient34, gMw, B, g_rot, g_xyz);
+    return finish("ddrr_pose_euler_backward");
+}
+
+}  // extern "C"

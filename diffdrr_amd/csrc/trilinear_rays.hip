@@ -1,0 +1,223 @@
+// trilinear_rays.hip -- the per-ray trilinear marcher (trilinear_core.h): forward, backward,
+// mask_to_channels, and their C-ABI entries.  The volume-stationary forms live in bricks.hip.
+#include "runtime.h"
+#include "siddon_core.h"
+#include "trilinear_core.h"
+
+using namespace ddrr;
+using namespace ddrr_rt;
+
+namespace {
+
+// --------------------------------------------------------------- Trilinear
+
+template <int REDUCE, bool NEAREST>
+__global__ __launch_bounds__(kBlock) void trilinear_fwd_kernel(RayArgs p, int n_points,
+                                                               const float *__restrict__ amin,
+                                                               const float *__restrict__ amax,
+                                                               int align_corners,
+                                                               float *__restrict__ out) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float I = trilinear_forward_ray<REDUCE, NEAREST>(p.vol, p.D, s, t, p.shift, p.eps,
+                                                           n_points, amin[0], amax[0],
+                                                           align_corners != 0);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    out[id.r] = L * I;
+}
+
+__global__ __launch_bounds__(kBlock) void trilinear_fwd_channels_kernel(
+    RayArgs p, const unsigned char *__restrict__ labels, int C, int n_points,
+    const float *__restrict__ amin, const float *__restrict__ amax, int align_corners,
+    float *__restrict__ out) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    float *col = out + (long)id.b * C * p.N + id.n;  // stride N between channels
+    trilinear_channels_ray(p.vol, labels, p.D, s, t, p.shift, p.eps, n_points, amin[0], amax[0],
+                           align_corners != 0, ColumnFlush{col, p.N, C, L});
+}
+
+template <bool NEAREST, bool WANT_VOL>
+__global__ __launch_bounds__(kBlock) void trilinear_bwd_kernel(
+    RayArgs p, const float *__restrict__ grad_out, int n_points, const float *__restrict__ amin,
+    const float *__restrict__ amax, int align_corners, float *__restrict__ g_source,
+    float *__restrict__ g_target, float *__restrict__ g_img, float *__restrict__ g_alpha,
+    float *__restrict__ g_volume) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    const float g = grad_out[id.r];
+    const float a0 = amin[0], a1 = amax[0];
+    MarchGrad r;
+    if (WANT_VOL)
+        r = trilinear_backward_ray<NEAREST, true>(p.vol, p.D, s, t, p.shift, p.eps, n_points, a0,
+                                                  a1, align_corners != 0, g * L,
+                                                  AtomicAdder{g_volume});
+    else
+        r = trilinear_backward_ray<NEAREST, false>(p.vol, p.D, s, t, p.shift, p.eps, n_points,
+                                                   a0, a1, align_corners != 0, g * L, NoAdd{});
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (g_source) g_source[id.r * 3 + a] = r.gs[a];
+        if (g_target) g_target[id.r * 3 + a] = r.gt[a];
+    }
+    if (g_img) g_img[id.r] = g * r.sumT * ((a1 - a0) / (float)(n_points - 1));
+    if (g_alpha) {
+        g_alpha[id.r * 2 + 0] = r.g_amin;
+        g_alpha[id.r * 2 + 1] = r.g_amax;
+    }
+}
+
+// Backward of the marcher's mask_to_channels (renderers.py:242-252): every sample carries
+// the incoming gradient of the channel its nearest label selects.
+template <bool WANT_VOL>
+__global__ __launch_bounds__(kBlock) void trilinear_bwd_channels_kernel(
+    RayArgs p, const unsigned char *__restrict__ labels, int C,
+    const float *__restrict__ grad_out, int n_points, const float *__restrict__ amin,
+    const float *__restrict__ amax, int align_corners, float *__restrict__ g_source,
+    float *__restrict__ g_target, float *__restrict__ g_img, float *__restrict__ g_alpha,
+    float *__restrict__ g_volume) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    const float a0 = amin[0], a1 = amax[0];
+    const LabelWeight wt{labels, p.D, grad_out + (long)id.b * C * p.N + id.n, p.N, C, a0,
+                         p.shift, {s[0], s[1], s[2]}, align_corners != 0};
+    MarchGrad r;
+    if (WANT_VOL)
+        r = trilinear_backward_ray<false, true>(p.vol, p.D, s, t, p.shift, p.eps, n_points, a0, a1,
+                                                align_corners != 0, L, AtomicAdder{g_volume}, wt);
+    else
+        r = trilinear_backward_ray<false, false>(p.vol, p.D, s, t, p.shift, p.eps, n_points, a0,
+                                                 a1, align_corners != 0, L, NoAdd{}, wt);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (g_source) g_source[id.r * 3 + a] = r.gs[a];
+        if (g_target) g_target[id.r * 3 + a] = r.gt[a];
+    }
+    if (g_img) g_img[id.r] = r.sumT * ((a1 - a0) / (float)(n_points - 1));
+    if (g_alpha) {
+        g_alpha[id.r * 2 + 0] = r.g_amin;
+        g_alpha[id.r * 2 + 1] = r.g_amax;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ddrr_trilinear_forward(const float *volume, int dx, int dy, int dz, const float *source,
+                           int src_n, const float *target, const float *img, int B, int N,
+                           float voxel_shift, float eps, int n_points, const float *alphamin,
+                           const float *alphamax, int mode_nearest, int reduce_mode,
+                           int align_corners, int det_h, int det_w, int tile_h, int tile_w,
+                           float *out, void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!out || !alphamin || !alphamax) return fail(-1, "null out / alphamin / alphamax");
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (B == 0 || N == 0) return 0;
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, det_h, det_w, tile_h, tile_w);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(grid_for(p)), block(kBlock);
+    const bool sum = reduce_mode == DDRR_REDUCE_SUM;
+    if (!sum && reduce_mode != DDRR_REDUCE_MAX) return fail(-1, "bad reduce_mode");
+#define LAUNCH(R, NN)                                                                          \
+    hipLaunchKernelGGL((trilinear_fwd_kernel<R, NN>), grid, block, 0, st, p, n_points, alphamin, \
+                       alphamax, align_corners, out)
+    if (sum && !mode_nearest) LAUNCH(REDUCE_SUM, false);
+    else if (sum) LAUNCH(REDUCE_SUM, true);
+    else if (!mode_nearest) LAUNCH(REDUCE_MAX, false);
+    else LAUNCH(REDUCE_MAX, true);
+#undef LAUNCH
+    return finish("ddrr_trilinear_forward");
+}
+
+int ddrr_trilinear_forward_channels(const float *volume, const unsigned char *labels, int dx,
+                                    int dy, int dz, const float *source, int src_n,
+                                    const float *target, const float *img, int B, int N, int C,
+                                    float voxel_shift, float eps, int n_points,
+                                    const float *alphamin, const float *alphamax,
+                                    int align_corners, int det_h, int det_w, int tile_h,
+                                    int tile_w, float *out, void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!labels || !out || C < 1) return fail(-1, "null labels/out or C < 1");
+    if (!alphamin || !alphamax) return fail(-1, "null alphamin / alphamax");
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (B == 0 || N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C * N, st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, det_h, det_w, tile_h, tile_w);
+    hipLaunchKernelGGL(trilinear_fwd_channels_kernel, dim3(grid_for(p)), dim3(kBlock), 0, st, p,
+                       labels, C, n_points, alphamin, alphamax, align_corners, out);
+    return finish("ddrr_trilinear_forward_channels");
+}
+
+int ddrr_trilinear_backward(const float *volume, int dx, int dy, int dz, const float *source,
+                            int src_n, const float *target, const float *img,
+                            const float *grad_out, int B, int N, float voxel_shift, float eps,
+                            int n_points, const float *alphamin, const float *alphamax,
+                            int mode_nearest, int align_corners, int det_h, int det_w, int tile_h,
+                            int tile_w, float *g_source, float *g_target, float *g_img,
+                            float *g_alpha, float *g_volume, void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!grad_out || !alphamin || !alphamax) return fail(-1, "null grad_out / alphamin / alphamax");
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (B == 0 || N == 0) return 0;
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, det_h, det_w, tile_h, tile_w);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(grid_for(p)), block(kBlock);
+#define LAUNCH(NN, WV)                                                                          \
+    hipLaunchKernelGGL((trilinear_bwd_kernel<NN, WV>), grid, block, 0, st, p, grad_out, n_points, \
+                       alphamin, alphamax, align_corners, g_source, g_target, g_img, g_alpha,     \
+                       g_volume)
+    if (mode_nearest && g_volume) LAUNCH(true, true);
+    else if (mode_nearest) LAUNCH(true, false);
+    else if (g_volume) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+    return finish("ddrr_trilinear_backward");
+}
+
+int ddrr_trilinear_backward_channels(const float *volume, const unsigned char *labels, int dx,
+                                     int dy, int dz, const float *source, int src_n,
+                                     const float *target, const float *img,
+                                     const float *grad_out, int B, int N, int C,
+                                     float voxel_shift, float eps, int n_points,
+                                     const float *alphamin, const float *alphamax,
+                                     int align_corners, int det_h, int det_w, int tile_h,
+                                     int tile_w, float *g_source, float *g_target, float *g_img,
+                                     float *g_alpha, float *g_volume, void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!labels || !grad_out || !alphamin || !alphamax || C < 1)
+        return fail(-1, "null labels / grad_out / alphamin / alphamax or C < 1");
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (B == 0 || N == 0) return 0;
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, det_h, det_w, tile_h, tile_w);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(grid_for(p)), block(kBlock);
+    if (g_volume)
+        hipLaunchKernelGGL((trilinear_bwd_channels_kernel<true>), grid, block, 0, st, p, labels, C,
+                           grad_out, n_points, alphamin, alphamax, align_corners, g_source,
+                           g_target, g_img, g_alpha, g_volume);
+    else
+        hipLaunchKernelGGL((trilinear_bwd_channels_kernel<false>), grid, block, 0, st, p, labels, C,
+                           grad_out, n_points, alphamin, alphamax, align_corners, g_source,
+                           g_target, g_img, g_alpha, g_volume);
+    return finish("ddrr_trilinear_backward_channels");
+}
+
+}  // extern "C"
