@@ -112,6 +112,30 @@ DDRR_HD int march_label(const unsigned char *__restrict__ labels, const Dims D, 
     return in ? (int)labels[((int)rx * D.y + (int)ry) * D.z + (int)rz] : 0;
 }
 
+// The per-sample tensor the reference hands to a callable reducefn (renderers.py:226-238):
+// samples[m] = L * step * T(V, x(alpha_m)), m = 0 .. P - 1 (zero outside the volume).
+template <bool NEAREST>
+DDRR_HD void trilinear_samples_ray(const float *__restrict__ vol, const Dims D, const float s[3],
+                                   const float t[3], float shift, float eps, int P, float amin,
+                                   float amax, bool align_corners, float L,
+                                   float *__restrict__ samples, long stride) {
+    const GridMap g = make_gridmap(D, shift, align_corners);
+    const MarchSetup q = march_setup(D, g, s, t, eps, P, amin, amax);
+    const float k = L * q.step;
+    for (int m = 0; m < P; ++m) {
+        float v = 0.f;
+        if (m >= q.m_lo && m <= q.m_hi) {
+            const float al = fmaf(lin01(m, P, q.lstep), q.span, amin);
+            const float gx = fmaf(fmaf(al, q.d[0], s[0]), g.k[0], g.o[0]);
+            const float gy = fmaf(fmaf(al, q.d[1], s[1]), g.k[1], g.o[1]);
+            const float gz = fmaf(fmaf(al, q.d[2], s[2]), g.k[2], g.o[2]);
+            v = NEAREST ? fetch_nearest(vol, D, gx, gy, gz)
+                        : fetch_trilinear(vol, D, gx, gy, gz, nullptr, false);
+        }
+        samples[m * stride] = k * v;
+    }
+}
+
 // mask_to_channels for the marcher (renderers.py:242-252): every sample's value goes to
 // the channel of the label found by a NEAREST lookup of the mask at the sample point
 // (0 outside the volume).  The ray owns its output column: a run of samples with one
@@ -179,7 +203,14 @@ struct MarchGrad {
 // incoming gradient of the channel the sample's label selects (grad_out is (B, C, N): `gcol`
 // points at [b, 0, n], channels are `stride` apart).  The label has no gradient of its own.
 struct UnitWeight {
-    DDRR_HD float operator()(float, const MarchSetup &) const { return 1.f; }
+    DDRR_HD float operator()(int, float, const MarchSetup &) const { return 1.f; }
+};
+// a callable reducefn: the incoming gradient of sample m itself (grad is (B, P, N): `g` points
+// at [b, 0, n], samples are `stride` apart)
+struct SampleWeight {
+    const float *g;
+    long stride;
+    DDRR_HD float operator()(int m, float, const MarchSetup &) const { return g[m * stride]; }
 };
 struct LabelWeight {
     const unsigned char *labels;
@@ -190,7 +221,7 @@ struct LabelWeight {
     float amin, shift;
     float s[3];
     bool align_corners;
-    DDRR_HD float operator()(float lin, const MarchSetup &q) const {
+    DDRR_HD float operator()(int, float lin, const MarchSetup &q) const {
         const int lab = march_label(labels, D, lin, q, amin, s, shift, align_corners);
         return lab < C ? gcol[lab * stride] : 0.f;
     }
@@ -218,7 +249,7 @@ DDRR_HD MarchGrad trilinear_backward_ray(const float *__restrict__ vol, const Di
         const float gx = fmaf(fmaf(al, q.d[0], s[0]), g.k[0], g.o[0]);
         const float gy = fmaf(fmaf(al, q.d[1], s[1]), g.k[1], g.o[1]);
         const float gz = fmaf(fmaf(al, q.d[2], s[2]), g.k[2], g.o[2]);
-        const float w = wt(u, q);
+        const float w = wt(m, u, q);
         if (NEAREST) {
             sumT = fmaf(w, fetch_nearest(vol, D, gx, gy, gz), sumT);
             if (WANT_VOL) scatter_nearest(D, gx, gy, gz, k * w, add);

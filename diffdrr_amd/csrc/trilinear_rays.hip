@@ -111,6 +111,55 @@ __global__ __launch_bounds__(kBlock) void trilinear_bwd_channels_kernel(
     }
 }
 
+// The materialised per-sample tensor for a callable reducefn; samples is (B, P, N): the ray
+// owns column [b, :, n], consecutive lanes write consecutive floats.
+template <bool NEAREST>
+__global__ __launch_bounds__(kBlock) void trilinear_samples_kernel(
+    RayArgs p, int n_points, const float *__restrict__ amin, const float *__restrict__ amax,
+    int align_corners, float *__restrict__ samples) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    trilinear_samples_ray<NEAREST>(p.vol, p.D, s, t, p.shift, p.eps, n_points, amin[0], amax[0],
+                                   align_corners != 0, L,
+                                   samples + (long)id.b * n_points * p.N + id.n, p.N);
+}
+
+template <bool NEAREST, bool WANT_VOL>
+__global__ __launch_bounds__(kBlock) void trilinear_samples_bwd_kernel(
+    RayArgs p, const float *__restrict__ g_samples, int n_points, const float *__restrict__ amin,
+    const float *__restrict__ amax, int align_corners, float *__restrict__ g_source,
+    float *__restrict__ g_target, float *__restrict__ g_img, float *__restrict__ g_alpha,
+    float *__restrict__ g_volume) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    const float a0 = amin[0], a1 = amax[0];
+    const SampleWeight wt{g_samples + (long)id.b * n_points * p.N + id.n, p.N};
+    MarchGrad r;
+    if (WANT_VOL)
+        r = trilinear_backward_ray<NEAREST, true>(p.vol, p.D, s, t, p.shift, p.eps, n_points, a0,
+                                                  a1, align_corners != 0, L,
+                                                  AtomicAdder{g_volume}, wt);
+    else
+        r = trilinear_backward_ray<NEAREST, false>(p.vol, p.D, s, t, p.shift, p.eps, n_points, a0,
+                                                   a1, align_corners != 0, L, NoAdd{}, wt);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (g_source) g_source[id.r * 3 + a] = r.gs[a];
+        if (g_target) g_target[id.r * 3 + a] = r.gt[a];
+    }
+    if (g_img) g_img[id.r] = r.sumT * ((a1 - a0) / (float)(n_points - 1));
+    if (g_alpha) {
+        g_alpha[id.r * 2 + 0] = r.g_amin;
+        g_alpha[id.r * 2 + 1] = r.g_amax;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -218,6 +267,57 @@ int ddrr_trilinear_backward_channels(const float *volume, const unsigned char *l
                            grad_out, n_points, alphamin, alphamax, align_corners, g_source,
                            g_target, g_img, g_alpha, g_volume);
     return finish("ddrr_trilinear_backward_channels");
+}
+
+int ddrr_trilinear_samples(const float *volume, int dx, int dy, int dz, const float *source,
+                           int src_n, const float *target, const float *img, int B, int N,
+                           float voxel_shift, float eps, int n_points, const float *alphamin,
+                           const float *alphamax, int mode_nearest, int align_corners,
+                           float *samples, void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!samples || !alphamin || !alphamax) return fail(-1, "null samples / alphamin / alphamax");
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (B == 0 || N == 0) return 0;
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, 0, 0, 1, 64);
+    const dim3 grid(grid_for(p)), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode_nearest)
+        hipLaunchKernelGGL((trilinear_samples_kernel<true>), grid, block, 0, st, p, n_points,
+                           alphamin, alphamax, align_corners, samples);
+    else
+        hipLaunchKernelGGL((trilinear_samples_kernel<false>), grid, block, 0, st, p, n_points,
+                           alphamin, alphamax, align_corners, samples);
+    return finish("ddrr_trilinear_samples");
+}
+
+int ddrr_trilinear_samples_backward(const float *volume, int dx, int dy, int dz,
+                                    const float *source, int src_n, const float *target,
+                                    const float *img, const float *grad_samples, int B, int N,
+                                    float voxel_shift, float eps, int n_points,
+                                    const float *alphamin, const float *alphamax,
+                                    int mode_nearest, int align_corners, float *g_source,
+                                    float *g_target, float *g_img, float *g_alpha,
+                                    float *g_volume, void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!grad_samples || !alphamin || !alphamax)
+        return fail(-1, "null grad_samples / alphamin / alphamax");
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (B == 0 || N == 0) return 0;
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, 0, 0, 1, 64);
+    const dim3 grid(grid_for(p)), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(NN, WV)                                                                            \
+    hipLaunchKernelGGL((trilinear_samples_bwd_kernel<NN, WV>), grid, block, 0, st, p, grad_samples, \
+                       n_points, alphamin, alphamax, align_corners, g_source, g_target, g_img,     \
+                       g_alpha, g_volume)
+    if (mode_nearest && g_volume) LAUNCH(true, true);
+    else if (mode_nearest) LAUNCH(true, false);
+    else if (g_volume) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+    return finish("ddrr_trilinear_samples_backward");
 }
 
 }  // extern "C"

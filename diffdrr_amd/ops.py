@@ -549,6 +549,54 @@ def trilinear_backward_volume_bricks(volume_shape, source, target, img, grad_out
     return g_volume
 
 
+def trilinear_samples(volume, source, target, img, alphamin, alphamax, *, n_points=500,
+                      voxel_shift=0.5, eps=1e-8, mode="bilinear", align_corners=False):
+    """The per-sample terms a callable ``reducefn`` of the marcher receives
+    (renderers.py:226-238).  -> (B, P, N); transpose(1, 2) is the reference's layout."""
+    B, N = _check_rays(volume, source, target, img)
+    out = torch.empty(B, int(n_points), N, dtype=torch.float32, device=volume.device)
+    if _empty(B, N):
+        return out
+    volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    _launch("ddrr_trilinear_samples", volume.device, volume.data_ptr(), *volume.shape,
+            source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img), B, N,
+            float(voxel_shift), float(eps), int(n_points), alphamin.data_ptr(),
+            alphamax.data_ptr(), int(mode == "nearest"), int(bool(align_corners)), out.data_ptr())
+    return out
+
+
+def trilinear_samples_backward(volume, source, target, img, grad_samples, alphamin, alphamax, *,
+                               n_points=500, voxel_shift=0.5, eps=1e-8, mode="bilinear",
+                               align_corners=False, want_rays=True, want_img=True,
+                               want_alpha=True, want_volume=False):
+    """Backward of :func:`trilinear_samples` for grad_samples (B, P, N); results as
+    :func:`trilinear_backward`."""
+    B, N = _check_rays(volume, source, target, img)
+    dev = volume.device
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    g_source = new(B, N, 3) if want_rays else None
+    g_target = new(B, N, 3) if want_rays else None
+    g_img = new(B, N) if want_img else None
+    g_alpha = new(B, N, 2) if want_alpha else None
+    g_volume = torch.zeros_like(volume, memory_format=torch.contiguous_format) \
+        if want_volume else None
+    res = {"g_source": g_source, "g_target": g_target, "g_img": g_img, "g_alpha": g_alpha,
+           "g_volume": g_volume}
+    if _empty(B, N):
+        return res
+    volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    grad_samples = grad_samples.contiguous()
+    _launch("ddrr_trilinear_samples_backward", dev, volume.data_ptr(), *volume.shape,
+            source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img),
+            grad_samples.data_ptr(), B, N, float(voxel_shift), float(eps), int(n_points),
+            alphamin.data_ptr(), alphamax.data_ptr(), int(mode == "nearest"),
+            int(bool(align_corners)), _ptr(g_source), _ptr(g_target), _ptr(g_img), _ptr(g_alpha),
+            _ptr(g_volume))
+    return res
+
+
 def trilinear_backward_channels(volume, labels_u8, source, target, img, grad_out, alphamin,
                                 alphamax, *, n_points=500, voxel_shift=0.5, eps=1e-8,
                                 align_corners=False, want_rays=True, want_img=True,

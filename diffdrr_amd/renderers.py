@@ -452,6 +452,46 @@ class _TrilinearChannelsFn(torch.autograd.Function):
         return r["g_volume"], g_s, g_t, g_i, g_a0, g_a1, None, None, None
 
 
+class _TrilinearSamplesFn(torch.autograd.Function):
+    """The (B, N, P) per-sample tensor the reference hands to a callable ``reducefn`` of the
+    marcher (renderers.py:226-238): ddrr_trilinear_samples / _backward."""
+
+    @staticmethod
+    def forward(ctx, volume, source, target, img, alphamin, alphamax, cfg):
+        out = ops.trilinear_samples(
+            volume, source, target, img, alphamin.reshape(1), alphamax.reshape(1),
+            n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
+            mode=cfg["mode"], align_corners=cfg["align_corners"])
+        ctx.cfg = cfg
+        ctx.save_for_backward(volume, source, target, img, alphamin, alphamax)
+        return out.transpose(1, 2)  # (B, N, P), the reference's layout (a view)
+
+    @staticmethod
+    def backward(ctx, grad):
+        volume, source, target, img, alphamin, alphamax = ctx.saved_tensors
+        cfg = ctx.cfg
+        need_vol, need_s, need_t, need_i, need_a0, need_a1 = ctx.needs_input_grad[:6]
+        r = ops.trilinear_samples_backward(
+            volume, source, target, img, grad.transpose(1, 2), alphamin.reshape(1),
+            alphamax.reshape(1), n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"],
+            eps=cfg["eps"], mode=cfg["mode"], align_corners=cfg["align_corners"],
+            want_rays=bool(need_s or need_t), want_img=bool(need_i),
+            want_alpha=bool(need_a0 or need_a1), want_volume=bool(need_vol))
+        g_s = g_t = g_a0 = g_a1 = g_i = None
+        if need_s:
+            g_s = r["g_source"].sum(dim=1, keepdim=True) if source.shape[1] == 1 \
+                else r["g_source"]
+        if need_t:
+            g_t = r["g_target"]
+        if need_i:
+            g_i = r["g_img"].view_as(img)
+        if need_a0 or need_a1:
+            ga = r["g_alpha"].sum(dim=(0, 1))
+            g_a0 = ga[0].reshape(alphamin.shape) if need_a0 else None
+            g_a1 = ga[1].reshape(alphamax.shape) if need_a1 else None
+        return r["g_volume"], g_s, g_t, g_i, g_a0, g_a1, None
+
+
 class Trilinear(torch.nn.Module):
     """Differentiable X-ray renderer: trilinear ray marching (reference
     renderers.py:186-254) as one fused gfx950 kernel per call."""
@@ -475,7 +515,9 @@ class Trilinear(torch.nn.Module):
     def forward(self, volume, source, target, img, n_points=500, align_corners=False, mask=None,
                 alphamin=None, alphamax=None):
         B, N, _ = target.shape
-        ops.reduce_code(self.reducefn)
+        user_reduce = callable(self.reducefn) and not isinstance(self.reducefn, str)
+        if not user_reduce:
+            ops.reduce_code(self.reducefn)
         if alphamin is None or alphamax is None:
             # the reference's batch-global marching range (renderers.py:220-223)
             lo, hi = get_alpha_minmax(source, target, self.dims(volume), self.voxel_shift,
@@ -483,6 +525,15 @@ class Trilinear(torch.nn.Module):
             alphamin, alphamax = lo.min(), hi.max()
         alphamin = torch.as_tensor(alphamin, dtype=volume.dtype, device=volume.device)
         alphamax = torch.as_tensor(alphamax, dtype=volume.dtype, device=volume.device)
+        if user_reduce:
+            # a user reduction over the per-sample tensor (renderers.py:236-240)
+            if mask is not None:
+                raise NotImplementedError("a callable reducefn cannot be combined with a mask")
+            scfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift, "eps": self.eps,
+                    "mode": self.mode, "align_corners": bool(align_corners)}
+            samples = _TrilinearSamplesFn.apply(volume, source, target, img.reshape(B, N),
+                                                alphamin, alphamax, scfg)
+            return self.reducefn(samples).unsqueeze(1)
         if mask is not None:
             # mask_to_channels (renderers.py:242-252)
             if self.mode != "bilinear" or self.reducefn != "sum":

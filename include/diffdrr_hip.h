@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 11
+#define DDRR_ABI_VERSION 12
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -247,6 +247,24 @@ int ddrr_trilinear_backward_channels(const float *volume, const unsigned char *l
                                      int align_corners, int det_h, int det_w, int tile_h,
                                      int tile_w, float *g_source, float *g_target, float *g_img,
                                      float *g_alpha, float *g_volume, void *stream);
+
+/* The materialised per-sample tensor the reference hands to a CALLABLE reducefn of the marcher
+ * (renderers.py:226-238): samples is (B, n_points, N) -- the reference's (B, N, P) transposed --
+ * with samples[m] = img * step * T(V, x(alpha_m)).  _backward: its autograd for grad_samples
+ * (B, n_points, N); outputs as in ddrr_trilinear_backward. */
+int ddrr_trilinear_samples(const float *volume, int dx, int dy, int dz, const float *source,
+                           int src_n, const float *target, const float *img, int B, int N,
+                           float voxel_shift, float eps, int n_points, const float *alphamin,
+                           const float *alphamax, int mode_nearest, int align_corners,
+                           float *samples, void *stream);
+int ddrr_trilinear_samples_backward(const float *volume, int dx, int dy, int dz,
+                                    const float *source, int src_n, const float *target,
+                                    const float *img, const float *grad_samples, int B, int N,
+                                    float voxel_shift, float eps, int n_points,
+                                    const float *alphamin, const float *alphamax,
+                                    int mode_nearest, int align_corners, float *g_source,
+                                    float *g_target, float *g_img, float *g_alpha,
+                                    float *g_volume, void *stream);
 
 /* Fused ray generation for the DRR case: replaces the tensor programs between a pose and
  * the renderer call -- detector.py:151-153 (pose = reorient o extrinsic applied to the

@@ -101,6 +101,22 @@ def test_siddon_callable_reducefn_golden(gpu):
         assert rel_err(gr.cpu().numpy(), g[name + "_f64"]) < GRAD_TOL, name
 
 
+def test_trilinear_callable_reducefn_golden(gpu):
+    """Callable reducefn of the marcher (ddrr_trilinear_samples / _backward) against the
+    reference's autograd (top-6 sum over the per-sample tensor)."""
+    def topk_sum(img):
+        return img.sort(descending=True).values[..., :6].sum(dim=-1)
+
+    g = golden("trilinear_callable")
+    vol, src, tgt, img = (t.requires_grad_() for t in dev_inputs(g, gpu))
+    out = Trilinear(reducefn=topk_sum)(vol, src, tgt, img, n_points=40)
+    assert rel_err(out.detach().cpu().numpy(), g["out_f32"]) < FWD_TOL
+    go = torch.from_numpy(g["grad_out_f32"]).to(gpu)
+    grads = torch.autograd.grad(out, [src, tgt, img, vol], go)
+    for name, gr in zip(("g_source", "g_target", "g_img", "g_volume"), grads):
+        assert rel_err(gr.cpu().numpy(), g[name + "_f64"]) < GRAD_TOL, name
+
+
 def test_siddon_mask_gradients_golden(gpu):
     """mask_to_channels backward (ddrr_siddon_backward_channels) against the reference's
     autograd through its scatter_add (renderers.py:77-89): grad_out is (B, C, N)."""

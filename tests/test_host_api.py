@@ -430,3 +430,26 @@ def test_siddon_callable_reducefn(emulated_ops):
     assert terms.shape == (B, N, sum(vol.shape) + 2)
     plain = Siddon()(vol, src, tgt, img)
     assert rel_err(terms.sum(-1).detach().numpy(), plain.squeeze(1).detach().numpy()) < 1e-5
+
+
+def test_trilinear_callable_reducefn(emulated_ops):
+    """A callable ``reducefn`` of the marcher over the materialised per-sample tensor
+    (reference renderers.py:226-240), values and gradients against the reference's autograd."""
+    from diffdrr_amd import Trilinear
+
+    def topk_sum(img):
+        return img.sort(descending=True).values[..., :6].sum(dim=-1)
+
+    g = golden("trilinear_callable")
+    f32 = lambda k: torch.from_numpy(np.ascontiguousarray(g[k], dtype=np.float32))  # noqa: E731
+    vol, src, tgt, img = (f32(k).requires_grad_() for k in ("volume", "source", "target", "img_f32"))
+    out = Trilinear(reducefn=topk_sum)(vol, src, tgt, img, n_points=40)
+    assert out.shape == g["out_f32"].shape
+    assert rel_err(out.detach().numpy(), g["out_f32"]) < 1e-4
+    grads = torch.autograd.grad(out, [src, tgt, img, vol], f32("grad_out_f32"))
+    for name, gr in zip(("g_source", "g_target", "g_img", "g_volume"), grads):
+        assert rel_err(gr.numpy(), g[name + "_f64"]) < 1e-3, name
+    samples = Trilinear(reducefn=lambda t: t)(vol, src, tgt, img, n_points=40).squeeze(1)
+    assert samples.shape == (tgt.shape[0], tgt.shape[1], 40)
+    plain = Trilinear()(vol, src, tgt, img, n_points=40)
+    assert rel_err(samples.sum(-1).detach().numpy(), plain.squeeze(1).detach().numpy()) < 1e-5
