@@ -219,7 +219,7 @@ def main():
         if (D, H, B) == (512, 256, 32) and fwd_name == "ddrr_siddon_forward_bricks" \
                 and os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f)["siddon_fwd_brick_kernel<true>"]["hbm_bytes_per_launch"]
+                traffic = json.load(f)["forward_record"]["hbm_bytes_per_launch"]
             traffic_src = "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         ms_per_step = dt / args.steps * 1e3
         log(f"[bench] step {ms_per_step:.3f} ms | {fwd_name} {fwd_ms:.3f} ms/step in "
