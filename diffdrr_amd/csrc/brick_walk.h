@@ -377,6 +377,9 @@ DDRR_HD bool brick_trace(const Fetch &fetch, float fetch_base, const BrickGeom &
     bool oz_c = !ox_c && !(mn[1] == entry);
     float a_cur = entry, acc = 0.f;
     float S0x = 0.f, S1x = 0.f, S0z = 0.f, S1z = 0.f;
+    // put aside when the ray leaves: voxels i and i-1, axis flags (1: the crossing that opened
+    // segment i, 2: the exit crossing) of x and z
+    float e_rc = 0.f, e_rp = 0.f, e_fx = 0.f, e_fz = 0.f;
 
 // RC: voxel i (requested during step i-1)   RN: voxel i+1 (requested now; still holds
 // voxel i-2 at the top of the step)         RP: voxel i-1
@@ -417,22 +420,18 @@ DDRR_HD bool brick_trace(const Fetch &fetch, float fetch_base, const BrickGeom &
         oz_c = m2 && !m0 && !m1;                                                               \
         a_cur = a_next;                                                                        \
         if (!cont) {                                                                           \
-            /* the ray leaves the brick: settle segment i, the crossing that opened it and  */ \
-            /* the exit crossing (V_after = 0).  DDRR_PIN keeps these uses of the voxel     */ \
-            /* values inside this branch: hoisted above it (they mirror the top of the next */ \
-            /* step) they would make every step wait for the load it has just issued.       */ \
-            float rc = RC, rp = RP;                                                            \
-            DDRR_PIN(rc);                                                                      \
-            DDRR_PIN(rp);                                                                      \
-            acc = fmaf(rc, len_p, acc);                                                        \
+            /* the ray leaves the brick.  This block runs at every step at which ANY lane of */ \
+            /* the wave leaves, so it only puts aside what the settling after the loop needs */ \
+            /* (the value registers rotate, the axis flags live in scalar masks).  DDRR_PIN   */ \
+            /* keeps the uses of the voxel values inside this branch: hoisted above it they  */ \
+            /* would make every step wait for the load it has just issued.                   */ \
+            e_rc = RC;                                                                         \
+            e_rp = RP;                                                                         \
+            DDRR_PIN(e_rc);                                                                    \
+            DDRR_PIN(e_rp);                                                                    \
             if (AUX) {                                                                         \
-                const float dv = rp - rc;                                                      \
-                const float dx = ox_p ? dv : 0.f, dz = oz_p ? dv : 0.f;                        \
-                const float ex = ox_c ? rc : 0.f, ez = oz_c ? rc : 0.f;                        \
-                S0x += dx + ex;                                                                \
-                S1x = fmaf(ex, a_cur, fmaf(dx, aop_p, S1x));                                   \
-                S0z += dz + ez;                                                                \
-                S1z = fmaf(ez, a_cur, fmaf(dz, aop_p, S1z));                                   \
+                e_fx = (ox_p ? 1.f : 0.f) + (ox_c ? 2.f : 0.f);                                \
+                e_fz = (oz_p ? 1.f : 0.f) + (oz_c ? 2.f : 0.f);                                \
             }                                                                                  \
             break;                                                                             \
         }                                                                                      \
@@ -454,6 +453,19 @@ DDRR_HD bool brick_trace(const Fetch &fetch, float fetch_base, const BrickGeom &
 #undef DDRR_PIN
 #undef DDRR_BRICK_NEXT_OFF
 #undef DDRR_BRICK_OFF
+    // settle segment i, the crossing that opened it, and the exit crossing (V_after = 0)
+    acc = fmaf(e_rc, len_p, acc);
+    if (AUX) {
+        const float dv = e_rp - e_rc;
+        const bool xp = e_fx == 1.f || e_fx == 3.f, xc = e_fx >= 2.f;
+        const bool zp = e_fz == 1.f || e_fz == 3.f, zc = e_fz >= 2.f;
+        const float dx = xp ? dv : 0.f, dz = zp ? dv : 0.f;
+        const float ex = xc ? e_rc : 0.f, ez = zc ? e_rc : 0.f;
+        S0x += dx + ex;
+        S1x = fmaf(ex, a_cur, fmaf(dx, aop_p, S1x));
+        S0z += dz + ez;
+        S1z = fmaf(ez, a_cur, fmaf(dz, aop_p, S1z));
+    }
     I = acc;
     if (AUX) {
         rec[0] = S0x;
