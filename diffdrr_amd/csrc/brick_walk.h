@@ -377,6 +377,25 @@ DDRR_HD bool brick_trace(const Fetch &fetch, float fetch_base, const BrickGeom &
     bool oz_c = !ox_c && !(mn[1] == entry);
     float a_cur = entry, acc = 0.f;
     float S0x = 0.f, S1x = 0.f, S0z = 0.f, S1z = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (x, z) pairs of the record as 2-vectors: one v_pk_add_f32 and one v_pk_fma_f32 per step
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f S0v = {0.f, 0.f}, S1v = {0.f, 0.f};
+#define DDRR_REC_ADD(dx, dz, al)                                   \
+    {                                                              \
+        const v2f dv2 = {dx, dz}, al2 = {al, al};                  \
+        S0v += dv2;                                                \
+        S1v = __builtin_elementwise_fma(dv2, al2, S1v);            \
+    }
+#else
+#define DDRR_REC_ADD(dx, dz, al)  \
+    {                             \
+        S0x += dx;                \
+        S1x = fmaf(dx, al, S1x);  \
+        S0z += dz;                \
+        S1z = fmaf(dz, al, S1z);  \
+    }
+#endif
     // put aside when the ray leaves: voxels i and i-1, axis flags (1: the crossing that opened
     // segment i, 2: the exit crossing) of x and z
     float e_rc = 0.f, e_rp = 0.f, e_fx = 0.f, e_fz = 0.f;
@@ -395,10 +414,7 @@ DDRR_HD bool brick_trace(const Fetch &fetch, float fetch_base, const BrickGeom &
         if (AUX) {                                                                             \
             const float dv = RN - RP;                                                          \
             const float dx = ox_p ? dv : 0.f, dz = oz_p ? dv : 0.f;                            \
-            S0x += dx;                                                                         \
-            S1x = fmaf(dx, aop_p, S1x);                                                        \
-            S0z += dz;                                                                         \
-            S1z = fmaf(dz, aop_p, S1z);                                                        \
+            DDRR_REC_ADD(dx, dz, aop_p);                                                       \
         }                                                                                      \
         /* geometry of step i */                                                               \
         const float a_next = fminf(fminf(an[0], an[1]), an[2]);                                \
@@ -453,6 +469,13 @@ DDRR_HD bool brick_trace(const Fetch &fetch, float fetch_base, const BrickGeom &
 #undef DDRR_PIN
 #undef DDRR_BRICK_NEXT_OFF
 #undef DDRR_BRICK_OFF
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (AUX) {
+        S0x = S0v.x, S0z = S0v.y;
+        S1x = S1v.x, S1z = S1v.y;
+    }
+#endif
+#undef DDRR_REC_ADD
     // settle segment i, the crossing that opened it, and the exit crossing (V_after = 0)
     acc = fmaf(e_rc, len_p, acc);
     if (AUX) {
