@@ -140,47 +140,63 @@ __global__ __launch_bounds__(kBlock) void pose_euler_bwd_kernel(
 // whole batch (x1_stride = 0).
 constexpr int kNccThreads = 1024;
 
-__device__ __forceinline__ float block_sum(float v, float *red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __syncthreads();  // red may still be read by the previous call
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < kNccThreads / 64; ++w) t += red[w];
-    return t;
-}
-
+// One pass over the pair: the five raw moments are accumulated in double (no cancellation
+// worth mentioning: 1e-16 mu^2 / var), 16-byte loads where the rows allow it, one block
+// reduction of all five.
 __global__ __launch_bounds__(kNccThreads) void ncc_fwd_kernel(
     const float *__restrict__ x1, long x1_stride, const float *__restrict__ x2, int N, float eps,
     float *__restrict__ out, float *__restrict__ stats) {
-    __shared__ float red[kNccThreads / 64];
+    __shared__ double red[5][kNccThreads / 64];
     const int b = blockIdx.x;
     const float *p1 = x1 + b * x1_stride, *p2 = x2 + (long)b * N;
-    float a1 = 0.f, a2 = 0.f;
-    for (int n = threadIdx.x; n < N; n += kNccThreads) {
-        a1 += p1[n];
-        a2 += p2[n];
+    double m[5] = {0., 0., 0., 0., 0.};  // sum x1, x2, x1^2, x2^2, x1 x2
+    auto take = [&](float a, float c) {
+        const double da = (double)a, dc = (double)c;
+        m[0] += da;
+        m[1] += dc;
+        m[2] = fma(da, da, m[2]);
+        m[3] = fma(dc, dc, m[3]);
+        m[4] = fma(da, dc, m[4]);
+    };
+    const bool vec = (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
+    if (vec) {
+        const float4 *q1 = reinterpret_cast<const float4 *>(p1), *q2 = reinterpret_cast<const float4 *>(p2);
+        for (int n = threadIdx.x; n < (N >> 2); n += kNccThreads) {
+            const float4 a = q1[n], c = q2[n];
+            take(a.x, c.x);
+            take(a.y, c.y);
+            take(a.z, c.z);
+            take(a.w, c.w);
+        }
+    } else {
+        for (int n = threadIdx.x; n < N; n += kNccThreads) take(p1[n], p2[n]);
     }
-    const float inv_n = 1.0f / (float)N;
-    const float mu1 = block_sum(a1, red) * inv_n, mu2 = block_sum(a2, red) * inv_n;
-    float v1 = 0.f, v2 = 0.f, c12 = 0.f;
-    for (int n = threadIdx.x; n < N; n += kNccThreads) {
-        const float d1 = p1[n] - mu1, d2 = p2[n] - mu2;
-        v1 = fmaf(d1, d1, v1);
-        v2 = fmaf(d2, d2, v2);
-        c12 = fmaf(d1, d2, c12);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        double v = m[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[k][wave] = v;
     }
-    const float s1 = sqrtf(block_sum(v1, red) * inv_n + eps);
-    const float s2 = sqrtf(block_sum(v2, red) * inv_n + eps);
-    const float ncc = block_sum(c12, red) * inv_n / (s1 * s2);
+    __syncthreads();
     if (threadIdx.x == 0) {
+        double t[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            t[k] = 0.;
+            for (int w = 0; w < kNccThreads / 64; ++w) t[k] += red[k][w];
+        }
+        const double inv_n = 1.0 / (double)N;
+        const double mu1 = t[0] * inv_n, mu2 = t[1] * inv_n;
+        const double v1 = t[2] * inv_n - mu1 * mu1, v2 = t[3] * inv_n - mu2 * mu2;
+        const double c12 = t[4] * inv_n - mu1 * mu2;
+        const float s1 = sqrtf((float)v1 + eps), s2 = sqrtf((float)v2 + eps);
+        const float ncc = (float)c12 / (s1 * s2);
         out[b] = ncc;
-        stats[b * 5 + 0] = mu1;
+        stats[b * 5 + 0] = (float)mu1;
         stats[b * 5 + 1] = s1;
-        stats[b * 5 + 2] = mu2;
+        stats[b * 5 + 2] = (float)mu2;
         stats[b * 5 + 3] = s2;
         stats[b * 5 + 4] = ncc;
     }
