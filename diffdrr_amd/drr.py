@@ -154,8 +154,19 @@ class DRR(nn.Module):
 
     def _render_fused_Mw(self, Mw, calibration):
         det = self.detector
-        cal = det.calibration if calibration is None else calibration
-        P = cal(det.target)[0].detach()                      # (N,3) detector.py:147-150
+        if calibration is None:
+            # the calibrated detector points only change with the intrinsics: cached per
+            # (calibration buffer version, target buffer, device)
+            # (the key holds the buffer objects themselves: alive, so not confusable with new ones)
+            key = getattr(self, "_P_key", None)
+            if key is None or key[0] is not det._calibration or key[1] != det._calibration._version \
+                    or key[2] is not det.target or key[3] != det.target._version:
+                self._P_cache = det.calibration(det.target)[0].detach()
+                self._P_key = (det._calibration, det._calibration._version, det.target,
+                               det.target._version)
+            P = self._P_cache
+        else:
+            P = calibration(det.target)[0].detach()          # (N,3) detector.py:147-150
         Ainv = self._affine_inverse[0, :3, :] if self._affine_inverse.dim() == 3 \
             else self._affine_inverse[:3, :]
         self.renderer.detector_shape = (det.height, det.width)
