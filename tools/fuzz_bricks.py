@@ -15,6 +15,7 @@ from diffdrr_amd.data import make_subject  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=40)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--smooth", action="store_true", help="smooth volume instead of noise")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(a.seed)
@@ -35,6 +36,9 @@ for case in range(a.cases):
     B = ri(1, 5)
     spacing = tuple(float(x) for x in ru(0.5, 2.0, 3))
     vol = torch.rand(*dims, generator=g)
+    if a.smooth:  # a smooth field: neighbouring voxels differ by ~1 %
+        ax = [torch.linspace(0, float(ru(2, 6, 1)), d) for d in dims]
+        vol = 0.5 + 0.5 * torch.sin(ax[0])[:, None, None] * torch.cos(ax[1])[None, :, None] * torch.sin(ax[2] + 1.0)[None, None, :]
     drr = DRR(make_subject(vol, spacing=spacing), sdd=float(ru(300, 1500, 1)), height=H, width=W,
               delx=float(ru(0.5, 4.0, 1))).to(dev)
     kind = case % 4
