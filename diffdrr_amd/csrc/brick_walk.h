@@ -396,8 +396,8 @@ DDRR_HD bool brick_trace(const Fetch &fetch, float fetch_base, const BrickGeom &
         S1z = fmaf(dz, al, S1z);  \
     }
 #endif
-    // put aside when the ray leaves: voxels i and i-1, axis flags (1: the crossing that opened
-    // segment i, 2: the exit crossing) of x and z
+    // put aside when the ray leaves: voxels i and i-1, the axis of the crossing that opened
+    // segment i (e_fx) and of the exit crossing (e_fz)
     float e_rc = 0.f, e_rp = 0.f, e_fx = 0.f, e_fz = 0.f;
 
 // RC: voxel i (requested during step i-1)   RN: voxel i+1 (requested now; still holds
@@ -445,9 +445,9 @@ DDRR_HD bool brick_trace(const Fetch &fetch, float fetch_base, const BrickGeom &
             e_rp = RP;                                                                         \
             DDRR_PIN(e_rc);                                                                    \
             DDRR_PIN(e_rp);                                                                    \
-            if (AUX) {                                                                         \
-                e_fx = (ox_p ? 1.f : 0.f) + (ox_c ? 2.f : 0.f);                                \
-                e_fz = (oz_p ? 1.f : 0.f) + (oz_c ? 2.f : 0.f);                                \
+            if (AUX) { /* axis of the two crossings: 1 x, 2 z, 0 y (x and z exclude each other) */ \
+                e_fx = ox_p ? 1.f : (oz_p ? 2.f : 0.f);                                        \
+                e_fz = ox_c ? 1.f : (oz_c ? 2.f : 0.f);                                        \
             }                                                                                  \
             break;                                                                             \
         }                                                                                      \
@@ -480,8 +480,8 @@ DDRR_HD bool brick_trace(const Fetch &fetch, float fetch_base, const BrickGeom &
     acc = fmaf(e_rc, len_p, acc);
     if (AUX) {
         const float dv = e_rp - e_rc;
-        const bool xp = e_fx == 1.f || e_fx == 3.f, xc = e_fx >= 2.f;
-        const bool zp = e_fz == 1.f || e_fz == 3.f, zc = e_fz >= 2.f;
+        const bool xp = e_fx == 1.f, zp = e_fx == 2.f;  // the crossing that opened segment i
+        const bool xc = e_fz == 1.f, zc = e_fz == 2.f;  // the exit crossing
         const float dx = xp ? dv : 0.f, dz = zp ? dv : 0.f;
         const float ex = xc ? e_rc : 0.f, ez = zc ? e_rc : 0.f;
         S0x += dx + ex;
