@@ -506,7 +506,7 @@ DDRR_HD void siddon_channels_ray(const float *__restrict__ vol,
 // Voxel looked up from every segment's midpoint exactly as the reference does
 // (renderers.py:57-60): needed for align_corners=True and for Siddon with
 // mode="bilinear", where a segment does not map onto a single voxel.  Slower
-// (no prefetch, more arithmetic); forward only.
+// (no prefetch, more arithmetic).
 
 struct GridMap {  // index coordinate = fma(x, k, o) per axis
     float k[3], o[3];
@@ -637,6 +637,131 @@ DDRR_HD float siddon_forward_ray_midpoint(const float *__restrict__ vol, const D
         have_prev = true;
     }
     return acc;
+}
+
+// Scatter k * w_c into the 8 corners of a sample (volume gradient).
+template <class Add>
+DDRR_HD void scatter_trilinear(const Dims D, float gx, float gy, float gz, float k, Add add) {
+    const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+    const float ax = gx - fx, ay = gy - fy, az = gz - fz;
+    const int ix = (int)fminf(fmaxf(fx, -2.f), (float)D.x + 1.f);
+    const int iy = (int)fminf(fmaxf(fy, -2.f), (float)D.y + 1.f);
+    const int iz = (int)fminf(fmaxf(fz, -2.f), (float)D.z + 1.f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ox = c & 1, oy = (c >> 1) & 1, oz = c >> 2;
+        const int x = ix + ox, y = iy + oy, z = iz + oz;
+        if (x < 0 || x >= D.x || y < 0 || y >= D.y || z < 0 || z >= D.z) continue;
+        const float w = (ox ? ax : 1.f - ax) * (oy ? ay : 1.f - ay) * (oz ? az : 1.f - az);
+        add((unsigned)((x * D.y + y) * D.z + z), k * w);
+    }
+}
+
+template <class Add>
+DDRR_HD void scatter_nearest(const Dims D, float gx, float gy, float gz, float k, Add add) {
+    const float rx = rintf(gx), ry = rintf(gy), rz = rintf(gz);
+    const bool in = rx >= 0.f && rx < (float)D.x && ry >= 0.f && ry < (float)D.y && rz >= 0.f &&
+                    rz < (float)D.z;
+    if (in) add((unsigned)(((int)rx * D.y + (int)ry) * D.z + (int)rz), k);
+}
+
+// Backward of siddon_forward_ray_midpoint (reduce sum): what autograd returns for the
+// reference's midpoint formulation (renderers.py:57-71).  With segment k between crossings k and
+// k+1, T_k the looked-up value at its midpoint m_k = (alpha_k + alpha_{k+1})/2 and, for the
+// bilinear lookup, G_k = d T / d x there:
+//   I = sum_k T_k (alpha_{k+1} - alpha_k);
+//   d I = sum_c coef_c d alpha_c + sum_k seg_k G_k . ((1 - m_k) ds + m_k dt),
+//   coef_c = (T_{c-1} - T_c) + (w_{c-1} + w_c) / 2,  w_k = seg_k (G_k . d)   (through d m_k),
+// and d alpha_c / d s_a = (alpha_c - 1)/d_a, d alpha_c / d t_a = -alpha_c/d_a on the crossing's
+// own axis (tied crossings: one axis, x before y before z).  gl = grad_out * ray length;
+// I is returned for d out / d img; `add(flat voxel index, value)` scatters the volume gradient
+// (the 8 corner weights for the bilinear lookup).
+template <int LOOKUP, bool WANT_VOL, class Add>
+DDRR_HD float siddon_backward_ray_midpoint(const float *__restrict__ vol, const Dims D,
+                                           const float s[3], const float t[3], float shift,
+                                           float eps, bool align_corners, float gl, float gs[3],
+                                           float gt[3], Add add) {
+    const int Dn[3] = {D.x, D.y, D.z};
+    const GridMap g = make_gridmap(D, shift, align_corners);
+    float d[3], inv[3], c[3], kf[3], dirf[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        d[a] = (t[a] - s[a]) + eps;
+        inv[a] = 1.0f / d[a];
+        c[a] = (-shift - s[a]) * inv[a];
+        const bool pos = d[a] > 0.f;
+        kf[a] = pos ? 0.f : (float)Dn[a];
+        dirf[a] = pos ? 1.f : -1.f;
+    }
+    float S0[3] = {0.f, 0.f, 0.f}, S1[3] = {0.f, 0.f, 0.f};
+    float Es[3] = {0.f, 0.f, 0.f}, Et[3] = {0.f, 0.f, 0.f};
+    float I = 0.f, a_cur = 0.f, T_prev = 0.f, w_prev = 0.f;
+    int ax_open = 0;
+    bool have_prev = false;
+    const int cap = D.x + D.y + D.z + 3;
+    for (int it = 0; it < cap; ++it) {
+        float an[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const bool done = kf[a] < 0.f || kf[a] > (float)Dn[a];
+            an[a] = done ? INFINITY : fmaf(kf[a], inv[a], c[a]);
+        }
+        const float a_next = min3f(an[0], an[1], an[2]);
+        if (!(a_next < INFINITY)) break;
+        if (have_prev) {
+            const float seg = a_next - a_cur, mid = 0.5f * (a_cur + a_next);
+            const float gx = fmaf(fmaf(mid, d[0], s[0]), g.k[0], g.o[0]);
+            const float gy = fmaf(fmaf(mid, d[1], s[1]), g.k[1], g.o[1]);
+            const float gz = fmaf(fmaf(mid, d[2], s[2]), g.k[2], g.o[2]);
+            float T, w = 0.f;
+            if (LOOKUP == LOOKUP_MID_TRILINEAR) {
+                float dT[3];
+                T = fetch_trilinear(vol, D, gx, gy, gz, dT, true);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float G = dT[a] * g.k[a];  // d T / d x_a
+                    w = fmaf(G, d[a], w);
+                    Es[a] = fmaf(seg * (1.f - mid), G, Es[a]);
+                    Et[a] = fmaf(seg * mid, G, Et[a]);
+                }
+                w *= seg;
+                if (WANT_VOL) scatter_trilinear(D, gx, gy, gz, gl * seg, add);
+            } else {
+                T = fetch_nearest(vol, D, gx, gy, gz);
+                if (WANT_VOL) scatter_nearest(D, gx, gy, gz, gl * seg, add);
+            }
+            I = fmaf(T, seg, I);
+            // the crossing that opened this segment
+            const float coef = (T_prev - T) + 0.5f * (w_prev + w);
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                if (a == ax_open) {
+                    S0[a] += coef;
+                    S1[a] = fmaf(coef, a_cur, S1[a]);
+                }
+            T_prev = T;
+            w_prev = w;
+        }
+        ax_open = an[0] <= a_next ? 0 : (an[1] <= a_next ? 1 : 2);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) kf[a] += (an[a] <= a_next) ? dirf[a] : 0.f;
+        a_cur = a_next;
+        have_prev = true;
+    }
+    // the last crossing closes the last segment
+    const float coef = T_prev + 0.5f * w_prev;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        if (a == ax_open && have_prev) {
+            S0[a] += coef;
+            S1[a] = fmaf(coef, a_cur, S1[a]);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        gs[a] = gl * fmaf(S1[a] - S0[a], inv[a], Es[a]);
+        gt[a] = gl * fmaf(-S1[a], inv[a], Et[a]);
+    }
+    return I;
 }
 
 }  // namespace ddrr

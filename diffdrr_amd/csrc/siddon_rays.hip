@@ -337,6 +337,29 @@ __global__ __launch_bounds__(kBlock) void siddon_segments_bwd_kernel(
     if (g_img) g_img[id.r] = gi;
 }
 
+// Backward of the midpoint-lookup forms (align_corners = True, mode "bilinear"): one more walk
+// (siddon_backward_ray_midpoint), no record.
+template <int LOOKUP, bool WANT_VOL>
+__global__ __launch_bounds__(kBlock) void siddon_bwd_mid_kernel(
+    RayArgs p, const float *__restrict__ grad_out, int align_corners, float *__restrict__ g_source,
+    float *__restrict__ g_target, float *__restrict__ g_img, float *__restrict__ g_volume) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    const float g = grad_out[id.r];
+    float gs[3], gt[3];
+    const float I = siddon_backward_ray_midpoint<LOOKUP, WANT_VOL>(
+        p.vol, p.D, s, t, p.shift, p.eps, align_corners != 0, g * L, gs, gt, AtomicAdder{g_volume});
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (g_source) g_source[id.r * 3 + a] = gs[a];
+        if (g_target) g_target[id.r * 3 + a] = gt[a];
+    }
+    if (g_img) g_img[id.r] = g * I;
+}
+
 // The slab kernel is fastest with the natural round-robin placement: all XCDs then
 // sweep the same poses at the same time, which the shared Infinity Cache likes
 // (profiles/r01/sweep_v2_slab_512.txt: 4.8 ms vs 6.8 ms on the bench workload).
@@ -564,6 +587,32 @@ int ddrr_siddon_segments_backward(const float *volume, int dx, int dy, int dz, c
         hipLaunchKernelGGL((siddon_segments_bwd_kernel<false>), grid, block, 0, st, p, grad_terms,
                            g_source, g_target, g_img, g_volume);
     return finish("ddrr_siddon_segments_backward");
+}
+
+int ddrr_siddon_backward_midpoint(const float *volume, int dx, int dy, int dz, const float *source,
+                                  int src_n, const float *target, const float *img,
+                                  const float *grad_out, int B, int N, float voxel_shift,
+                                  float eps, int lookup_mode, int align_corners, float *g_source,
+                                  float *g_target, float *g_img, float *g_volume, void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!grad_out) return fail(-1, "null grad_out pointer");
+    if (lookup_mode != DDRR_LOOKUP_MID_NEAREST && lookup_mode != DDRR_LOOKUP_MID_TRILINEAR)
+        return fail(-1, "lookup_mode must be a midpoint lookup");
+    if (B == 0 || N == 0) return 0;
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, 0, 0, 1, 64);
+    const dim3 grid(grid_for(p)), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(LK, WV)                                                                          \
+    hipLaunchKernelGGL((siddon_bwd_mid_kernel<LK, WV>), grid, block, 0, st, p, grad_out,         \
+                       align_corners, g_source, g_target, g_img, g_volume)
+    const bool tri = lookup_mode == DDRR_LOOKUP_MID_TRILINEAR;
+    if (tri && g_volume) LAUNCH(LOOKUP_MID_TRILINEAR, true);
+    else if (tri) LAUNCH(LOOKUP_MID_TRILINEAR, false);
+    else if (g_volume) LAUNCH(LOOKUP_MID_NEAREST, true);
+    else LAUNCH(LOOKUP_MID_NEAREST, false);
+#undef LAUNCH
+    return finish("ddrr_siddon_backward_midpoint");
 }
 
 }  // extern "C"

@@ -167,32 +167,6 @@ DDRR_HD void trilinear_channels_ray(const float *__restrict__ vol,
     if (cur >= 0) flush(cur, run * q.step);
 }
 
-// Scatter k * w_c into the 8 corners of a sample (volume gradient).
-template <class Add>
-DDRR_HD void scatter_trilinear(const Dims D, float gx, float gy, float gz, float k, Add add) {
-    const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
-    const float ax = gx - fx, ay = gy - fy, az = gz - fz;
-    const int ix = (int)fminf(fmaxf(fx, -2.f), (float)D.x + 1.f);
-    const int iy = (int)fminf(fmaxf(fy, -2.f), (float)D.y + 1.f);
-    const int iz = (int)fminf(fmaxf(fz, -2.f), (float)D.z + 1.f);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int ox = c & 1, oy = (c >> 1) & 1, oz = c >> 2;
-        const int x = ix + ox, y = iy + oy, z = iz + oz;
-        if (x < 0 || x >= D.x || y < 0 || y >= D.y || z < 0 || z >= D.z) continue;
-        const float w = (ox ? ax : 1.f - ax) * (oy ? ay : 1.f - ay) * (oz ? az : 1.f - az);
-        add((unsigned)((x * D.y + y) * D.z + z), k * w);
-    }
-}
-
-template <class Add>
-DDRR_HD void scatter_nearest(const Dims D, float gx, float gy, float gz, float k, Add add) {
-    const float rx = rintf(gx), ry = rintf(gy), rz = rintf(gz);
-    const bool in = rx >= 0.f && rx < (float)D.x && ry >= 0.f && ry < (float)D.y && rz >= 0.f &&
-                    rz < (float)D.z;
-    if (in) add((unsigned)(((int)rx * D.y + (int)ry) * D.z + (int)rz), k);
-}
-
 struct MarchGrad {
     float gs[3], gt[3];  // through the sample positions x = s + alpha (t - s + eps)
     float g_amin, g_amax;

@@ -369,6 +369,31 @@ def siddon_forward_channels(volume, labels_u8, n_channels, source, target, img, 
     return out
 
 
+def siddon_backward_midpoint(volume, source, target, img, grad_out, *, voxel_shift=0.5, eps=1e-8,
+                             lookup="mid_nearest", align_corners=False, want_rays=True,
+                             want_img=True, want_volume=False):
+    """Backward of :func:`siddon_forward` for the midpoint lookups (reduce sum).
+    -> (g_source per ray, g_target, g_img, g_volume), None where not asked."""
+    B, N = _check_rays(volume, source, target, img)
+    dev = volume.device
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    g_source = new(B, N, 3) if want_rays else None
+    g_target = new(B, N, 3) if want_rays else None
+    g_img = new(B, N) if want_img else None
+    g_volume = torch.zeros_like(volume, memory_format=torch.contiguous_format) \
+        if want_volume else None
+    if _empty(B, N):
+        return g_source, g_target, g_img, g_volume
+    volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    grad_out = grad_out.contiguous()
+    _launch("ddrr_siddon_backward_midpoint", dev, volume.data_ptr(), *volume.shape,
+            source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img), grad_out.data_ptr(),
+            B, N, float(voxel_shift), float(eps), _LOOKUP[lookup], int(bool(align_corners)),
+            _ptr(g_source), _ptr(g_target), _ptr(g_img), _ptr(g_volume))
+    return g_source, g_target, g_img, g_volume
+
+
 def siddon_segments(volume, source, target, img, *, voxel_shift=0.5, eps=1e-8):
     """The per-segment terms a callable ``reducefn`` receives (renderers.py:70-71).
     -> (B, M-1, N) with M = Dx+Dy+Dz+3; transpose(1, 2) is the reference's layout."""

@@ -93,10 +93,24 @@ class _SiddonFn(torch.autograd.Function):
         volume, source, target, img, aux = ctx.saved_tensors
         cfg = ctx.cfg
         need_vol, need_s, need_t, need_i = ctx.needs_input_grad[:4]
-        if cfg["lookup"] != "step":
-            raise NotImplementedError(
-                "gradients are only implemented for Siddon(mode='nearest', align_corners=False)")
         stop = cfg["stop_gradients"]
+        if cfg["lookup"] != "step":
+            # midpoint lookups (align_corners=True, mode="bilinear"): one more walk
+            if cfg["reducefn"] != "sum":
+                raise NotImplementedError("gradients of the midpoint lookups need reducefn='sum'")
+            if stop:
+                raise NotImplementedError("stop_gradients_through_grid_sample is implemented for "
+                                          "mode='nearest', align_corners=False")
+            gs, gt, gi, gv = ops.siddon_backward_midpoint(
+                volume, source, target, img, grad_out, voxel_shift=cfg["voxel_shift"],
+                eps=cfg["eps"], lookup=cfg["lookup"], align_corners=cfg["align_corners"],
+                want_rays=bool(need_s or need_t), want_img=bool(need_i),
+                want_volume=bool(need_vol))
+            g_s = None
+            if need_s:
+                g_s = gs.sum(dim=1, keepdim=True) if source.shape[1] == 1 else gs
+            return gv, g_s, (gt if need_t else None), \
+                (gi.view_as(img) if need_i else None), None
         g_vol = g_s = g_t = g_i = None
         grad_out = grad_out.contiguous()
         if need_s or need_t or need_i:

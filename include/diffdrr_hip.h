@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 12
+#define DDRR_ABI_VERSION 13
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -135,6 +135,17 @@ int ddrr_siddon_backward_volume(const float *volume, int dx, int dy, int dz, con
                                 const float *grad_out, int B, int N, float voxel_shift, float eps,
                                 int reduce_mode, int det_h, int det_w, int tile_h, int tile_w,
                                 float *g_volume, void *stream);
+
+/* Backward of ddrr_siddon_forward for the midpoint lookups (DDRR_LOOKUP_MID_NEAREST: mode
+ * "nearest" with align_corners = 1; DDRR_LOOKUP_MID_TRILINEAR: Siddon(mode="bilinear")), reduce
+ * sum: autograd of renderers.py:57-71 incl. the path through the midpoint positions
+ * (grid_sampler_3d_backward).  Outputs per ray, any may be NULL; g_volume ACCUMULATED with fp32
+ * atomics (the caller zero-fills). */
+int ddrr_siddon_backward_midpoint(const float *volume, int dx, int dy, int dz, const float *source,
+                                  int src_n, const float *target, const float *img,
+                                  const float *grad_out, int B, int N, float voxel_shift,
+                                  float eps, int lookup_mode, int align_corners, float *g_source,
+                                  float *g_target, float *g_img, float *g_volume, void *stream);
 
 /* Siddon.forward with a mask (mask_to_channels, renderers.py:77-89): labels is
  * the (dx, dy, dz) uint8 label map, out is (B, C, N) and is fully written. */

@@ -765,6 +765,40 @@ int ddrr_trilinear_backward_channels(const float *volume, const unsigned char *l
     return 0;
 }
 
+int ddrr_siddon_backward_midpoint(const float *volume, int dx, int dy, int dz, const float *source,
+                                  int src_n, const float *target, const float *img,
+                                  const float *grad_out, int B, int N, float voxel_shift,
+                                  float eps, int lookup_mode, int align_corners, float *g_source,
+                                  float *g_target, float *g_img, float *g_volume, void *) {
+    const Dims D{dx, dy, dz};
+    for_each_ray(
+        source, src_n, target, img, B, N, 0, 0, 1, 64, [&](int, int, long r, const Ray &ray) {
+            const float g = grad_out[r];
+            const bool ac = align_corners != 0;
+            float gs[3], gt[3], I;
+            if (lookup_mode == DDRR_LOOKUP_MID_TRILINEAR)
+                I = g_volume ? siddon_backward_ray_midpoint<LOOKUP_MID_TRILINEAR, true>(
+                                   volume, D, ray.s, ray.t, voxel_shift, eps, ac, g * ray.L, gs, gt,
+                                   HostAdd{g_volume})
+                             : siddon_backward_ray_midpoint<LOOKUP_MID_TRILINEAR, false>(
+                                   volume, D, ray.s, ray.t, voxel_shift, eps, ac, g * ray.L, gs, gt,
+                                   NoAdd{});
+            else
+                I = g_volume ? siddon_backward_ray_midpoint<LOOKUP_MID_NEAREST, true>(
+                                   volume, D, ray.s, ray.t, voxel_shift, eps, ac, g * ray.L, gs, gt,
+                                   HostAdd{g_volume})
+                             : siddon_backward_ray_midpoint<LOOKUP_MID_NEAREST, false>(
+                                   volume, D, ray.s, ray.t, voxel_shift, eps, ac, g * ray.L, gs, gt,
+                                   NoAdd{});
+            for (int a = 0; a < 3; ++a) {
+                if (g_source) g_source[r * 3 + a] = gs[a];
+                if (g_target) g_target[r * 3 + a] = gt[a];
+            }
+            if (g_img) g_img[r] = g * I;
+        });
+    return 0;
+}
+
 int ddrr_siddon_segments(const float *volume, int dx, int dy, int dz, const float *source,
                          int src_n, const float *target, const float *img, int B, int N,
                          float voxel_shift, float eps, float *terms, void *) {

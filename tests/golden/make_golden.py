@@ -159,9 +159,9 @@ def make_renderer_fixtures():
                      lambda: R.Siddon(stop_gradients_through_grid_sample=True), {}, dims,
                      lambda g: random_rays(g, dims, 2, 32), 16)
     renderer_fixture("siddon_bilinear", lambda: R.Siddon(mode="bilinear"), {}, dims,
-                     lambda g: random_rays(g, dims, 2, 32), 17, want_grads=False)
+                     lambda g: random_rays(g, dims, 2, 32), 17)
     renderer_fixture("siddon_align_corners", lambda: R.Siddon(), {"align_corners": True}, dims,
-                     lambda g: random_rays(g, dims, 2, 32), 18, want_grads=False)
+                     lambda g: random_rays(g, dims, 2, 32), 18)
     # a callable reducefn over the per-segment tensor (introduction.ipynb:506-529: top-k sum)
     renderer_fixture("siddon_callable", lambda: R.Siddon(reducefn=topk_sum), {}, dims,
                      lambda g: random_rays(g, dims, 2, 32), 26)

@@ -117,6 +117,22 @@ def test_trilinear_callable_reducefn_golden(gpu):
         assert rel_err(gr.cpu().numpy(), g[name + "_f64"]) < GRAD_TOL, name
 
 
+@pytest.mark.parametrize("name,ctor,call", [
+    ("siddon_bilinear", {"mode": "bilinear"}, {}),
+    ("siddon_align_corners", {}, {"align_corners": True}),
+])
+def test_siddon_midpoint_gradients_golden(gpu, name, ctor, call):
+    """ddrr_siddon_backward_midpoint against the reference's autograd for the midpoint lookups."""
+    g = golden(name)
+    vol, src, tgt, img = (t.requires_grad_() for t in dev_inputs(g, gpu))
+    out = Siddon(**ctor)(vol, src, tgt, img, **call)
+    assert rel_err(out.detach().cpu().numpy(), g["out_f32"]) < FWD_TOL
+    go = torch.from_numpy(g["grad_out_f32"]).to(gpu)
+    grads = torch.autograd.grad(out, [src, tgt, img, vol], go)
+    for k, gr in zip(("g_source", "g_target", "g_img", "g_volume"), grads):
+        assert rel_err(gr.cpu().numpy(), g[k + "_f64"]) < GRAD_TOL, k
+
+
 def test_siddon_mask_gradients_golden(gpu):
     """mask_to_channels backward (ddrr_siddon_backward_channels) against the reference's
     autograd through its scatter_add (renderers.py:77-89): grad_out is (B, C, N)."""
