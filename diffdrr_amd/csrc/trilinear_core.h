@@ -201,6 +201,39 @@ struct LabelWeight {
     }
 };
 
+// reducefn = "max" (renderers.py:178-179): autograd routes the gradient to the arg-max sample
+// alone (the first one on ties).  Index of that sample, or -1 if the maximum is one of the
+// skipped samples outside the volume (value 0, no gradient).
+template <bool NEAREST>
+DDRR_HD int trilinear_argmax_ray(const float *__restrict__ vol, const Dims D, const float s[3],
+                                 const float t[3], float shift, float eps, int P, float amin,
+                                 float amax, bool align_corners) {
+    const GridMap g = make_gridmap(D, shift, align_corners);
+    const MarchSetup q = march_setup(D, g, s, t, eps, P, amin, amax);
+    float best = q.m_lo > 0 ? 0.f : -INFINITY;
+    int idx = -1;
+    for (int m = q.m_lo; m <= q.m_hi; ++m) {
+        const float al = fmaf(lin01(m, P, q.lstep), q.span, amin);
+        const float gx = fmaf(fmaf(al, q.d[0], s[0]), g.k[0], g.o[0]);
+        const float gy = fmaf(fmaf(al, q.d[1], s[1]), g.k[1], g.o[1]);
+        const float gz = fmaf(fmaf(al, q.d[2], s[2]), g.k[2], g.o[2]);
+        const float v = NEAREST ? fetch_nearest(vol, D, gx, gy, gz)
+                                : fetch_trilinear(vol, D, gx, gy, gz, nullptr, false);
+        if (v > best) {
+            best = v;
+            idx = m;
+        }
+    }
+    if (q.m_hi < P - 1 && 0.f > best) idx = -1;
+    return idx;
+}
+struct OneSampleWeight {
+    int m_star;
+    DDRR_HD float operator()(int m, float, const MarchSetup &) const {
+        return m == m_star ? 1.f : 0.f;
+    }
+};
+
 // Backward of the sum-reduced march for one ray.
 // gl = grad_out * ray length (the ray length alone when `wt` carries the gradient).
 template <bool NEAREST, bool WANT_VOL, class Add, class Weight = UnitWeight>

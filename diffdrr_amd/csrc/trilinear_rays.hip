@@ -160,6 +160,43 @@ __global__ __launch_bounds__(kBlock) void trilinear_samples_bwd_kernel(
     }
 }
 
+// reducefn = "max": the gradient of the arg-max sample alone (one march to find it, one for
+// its gradient).
+template <bool NEAREST, bool WANT_VOL>
+__global__ __launch_bounds__(kBlock) void trilinear_bwd_max_kernel(
+    RayArgs p, const float *__restrict__ grad_out, int n_points, const float *__restrict__ amin,
+    const float *__restrict__ amax, int align_corners, float *__restrict__ g_source,
+    float *__restrict__ g_target, float *__restrict__ g_img, float *__restrict__ g_alpha,
+    float *__restrict__ g_volume) {
+    const RayId id = ray_id(p);
+    if (id.n < 0) return;
+    float s[3], t[3];
+    load_ray(p, id, s, t);
+    const float L = p.img ? p.img[id.r] : 1.f;
+    const float g = grad_out[id.r];
+    const float a0 = amin[0], a1 = amax[0];
+    const bool ac = align_corners != 0;
+    const OneSampleWeight wt{
+        trilinear_argmax_ray<NEAREST>(p.vol, p.D, s, t, p.shift, p.eps, n_points, a0, a1, ac)};
+    MarchGrad r;
+    if (WANT_VOL)
+        r = trilinear_backward_ray<NEAREST, true>(p.vol, p.D, s, t, p.shift, p.eps, n_points, a0,
+                                                  a1, ac, g * L, AtomicAdder{g_volume}, wt);
+    else
+        r = trilinear_backward_ray<NEAREST, false>(p.vol, p.D, s, t, p.shift, p.eps, n_points, a0,
+                                                   a1, ac, g * L, NoAdd{}, wt);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (g_source) g_source[id.r * 3 + a] = r.gs[a];
+        if (g_target) g_target[id.r * 3 + a] = r.gt[a];
+    }
+    if (g_img) g_img[id.r] = g * r.sumT * ((a1 - a0) / (float)(n_points - 1));
+    if (g_alpha) {
+        g_alpha[id.r * 2 + 0] = r.g_amin;
+        g_alpha[id.r * 2 + 1] = r.g_amax;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -318,6 +355,33 @@ int ddrr_trilinear_samples_backward(const float *volume, int dx, int dy, int dz,
     else LAUNCH(false, false);
 #undef LAUNCH
     return finish("ddrr_trilinear_samples_backward");
+}
+
+int ddrr_trilinear_backward_max(const float *volume, int dx, int dy, int dz, const float *source,
+                                int src_n, const float *target, const float *img,
+                                const float *grad_out, int B, int N, float voxel_shift, float eps,
+                                int n_points, const float *alphamin, const float *alphamax,
+                                int mode_nearest, int align_corners, float *g_source,
+                                float *g_target, float *g_img, float *g_alpha, float *g_volume,
+                                void *stream) {
+    if (int rc = check_common(volume, dx, dy, dz, source, src_n, target, B, N)) return rc;
+    if (!grad_out || !alphamin || !alphamax) return fail(-1, "null grad_out / alphamin / alphamax");
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (B == 0 || N == 0) return 0;
+    const RayArgs p = make_args(volume, dx, dy, dz, source, src_n, target, img, B, N, voxel_shift,
+                                eps, 0, 0, 1, 64);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(grid_for(p)), block(kBlock);
+#define LAUNCH(NN, WV)                                                                           \
+    hipLaunchKernelGGL((trilinear_bwd_max_kernel<NN, WV>), grid, block, 0, st, p, grad_out,       \
+                       n_points, alphamin, alphamax, align_corners, g_source, g_target, g_img,    \
+                       g_alpha, g_volume)
+    if (mode_nearest && g_volume) LAUNCH(true, true);
+    else if (mode_nearest) LAUNCH(true, false);
+    else if (g_volume) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+    return finish("ddrr_trilinear_backward_max");
 }
 
 }  // extern "C"

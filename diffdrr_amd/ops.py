@@ -660,7 +660,7 @@ def trilinear_backward_channels(volume, labels_u8, source, target, img, grad_out
 def trilinear_backward(volume, source, target, img, grad_out, alphamin, alphamax, *, n_points=500,
                        voxel_shift=0.5, eps=1e-8, mode="bilinear", align_corners=False,
                        want_rays=True, want_img=True, want_alpha=True, want_volume=False,
-                       det=None, tile=None):
+                       det=None, tile=None, reducefn="sum"):
     """-> dict(g_source per ray, g_target, g_img, g_alpha (B,N,2), g_volume)"""
     B, N = _check_rays(volume, source, target, img)
     dev = volume.device
@@ -677,6 +677,14 @@ def trilinear_backward(volume, source, target, img, grad_out, alphamin, alphamax
     if _empty(B, N):
         return res
     grad_out = grad_out.contiguous()
+    if reduce_code(reducefn) == REDUCE_MAX:
+        _launch(
+            "ddrr_trilinear_backward_max", dev, volume.data_ptr(), *volume.shape,
+            source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img), grad_out.data_ptr(),
+            B, N, float(voxel_shift), float(eps), int(n_points), alphamin.data_ptr(),
+            alphamax.data_ptr(), int(mode == "nearest"), int(bool(align_corners)),
+            _ptr(g_source), _ptr(g_target), _ptr(g_img), _ptr(g_alpha), _ptr(g_volume))
+        return res
     _launch(
         "ddrr_trilinear_backward", dev, volume.data_ptr(), *volume.shape, source.data_ptr(),
         source.shape[1], target.data_ptr(), _ptr(img), grad_out.data_ptr(), B, N,

@@ -380,8 +380,6 @@ class _TrilinearFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         volume, source, target, img, alphamin, alphamax, aux = ctx.saved_tensors
         cfg = ctx.cfg
-        if cfg["reducefn"] != "sum":
-            raise NotImplementedError("Trilinear gradients are implemented for reducefn='sum'")
         need_vol, need_s, need_t, need_i, need_a0, need_a1 = ctx.needs_input_grad[:6]
         need_rays = need_s or need_t or need_i or need_a0 or need_a1
         g_vol_bricks = None
@@ -406,7 +404,7 @@ class _TrilinearFn(torch.autograd.Function):
                 eps=cfg["eps"], mode=cfg["mode"], align_corners=cfg["align_corners"],
                 want_rays=bool(need_s or need_t), want_img=bool(need_i),
                 want_alpha=bool(need_a0 or need_a1), want_volume=bool(need_vol), det=cfg["det"],
-                tile=cfg["tile"])
+                tile=cfg["tile"], reducefn=cfg["reducefn"])
         g_s = g_t = g_a0 = g_a1 = g_i = None
         if need_s:
             g_s = r["g_source"].sum(dim=1, keepdim=True) if source.shape[1] == 1 \

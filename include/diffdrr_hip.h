@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 13
+#define DDRR_ABI_VERSION 14
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -276,6 +276,16 @@ int ddrr_trilinear_samples_backward(const float *volume, int dx, int dy, int dz,
                                     int mode_nearest, int align_corners, float *g_source,
                                     float *g_target, float *g_img, float *g_alpha,
                                     float *g_volume, void *stream);
+
+/* ddrr_trilinear_backward for reducefn = "max" (renderers.py:178-179): the gradient goes to the
+ * arg-max sample of every ray alone.  Arguments and outputs as ddrr_trilinear_backward. */
+int ddrr_trilinear_backward_max(const float *volume, int dx, int dy, int dz, const float *source,
+                                int src_n, const float *target, const float *img,
+                                const float *grad_out, int B, int N, float voxel_shift, float eps,
+                                int n_points, const float *alphamin, const float *alphamax,
+                                int mode_nearest, int align_corners, float *g_source,
+                                float *g_target, float *g_img, float *g_alpha, float *g_volume,
+                                void *stream);
 
 /* Fused ray generation for the DRR case: replaces the tensor programs between a pose and
  * the renderer call -- detector.py:151-153 (pose = reorient o extrinsic applied to the

@@ -839,6 +839,56 @@ int ddrr_siddon_segments_backward(const float *volume, int dx, int dy, int dz, c
     return 0;
 }
 
+int ddrr_trilinear_backward_max(const float *volume, int dx, int dy, int dz, const float *source,
+                                int src_n, const float *target, const float *img,
+                                const float *grad_out, int B, int N, float voxel_shift, float eps,
+                                int n_points, const float *alphamin, const float *alphamax,
+                                int mode_nearest, int align_corners, float *g_source,
+                                float *g_target, float *g_img, float *g_alpha, float *g_volume,
+                                void *) {
+    const Dims D{dx, dy, dz};
+    for_each_ray(
+        source, src_n, target, img, B, N, 0, 0, 1, 64, [&](int, int, long r, const Ray &ray) {
+            const float g = grad_out[r];
+            const bool ac = align_corners != 0;
+            MarchGrad m;
+            if (mode_nearest) {
+                const OneSampleWeight wt{trilinear_argmax_ray<true>(
+                    volume, D, ray.s, ray.t, voxel_shift, eps, n_points, *alphamin, *alphamax, ac)};
+                if (g_volume)
+                    m = trilinear_backward_ray<true, true>(volume, D, ray.s, ray.t, voxel_shift,
+                                                           eps, n_points, *alphamin, *alphamax, ac,
+                                                           g * ray.L, HostAdd{g_volume}, wt);
+                else
+                    m = trilinear_backward_ray<true, false>(volume, D, ray.s, ray.t, voxel_shift,
+                                                            eps, n_points, *alphamin, *alphamax,
+                                                            ac, g * ray.L, NoAdd{}, wt);
+            } else {
+                const OneSampleWeight wt{trilinear_argmax_ray<false>(
+                    volume, D, ray.s, ray.t, voxel_shift, eps, n_points, *alphamin, *alphamax, ac)};
+                if (g_volume)
+                    m = trilinear_backward_ray<false, true>(volume, D, ray.s, ray.t, voxel_shift,
+                                                            eps, n_points, *alphamin, *alphamax,
+                                                            ac, g * ray.L, HostAdd{g_volume}, wt);
+                else
+                    m = trilinear_backward_ray<false, false>(volume, D, ray.s, ray.t, voxel_shift,
+                                                             eps, n_points, *alphamin, *alphamax,
+                                                             ac, g * ray.L, NoAdd{}, wt);
+            }
+            for (int a = 0; a < 3; ++a) {
+                if (g_source) g_source[r * 3 + a] = m.gs[a];
+                if (g_target) g_target[r * 3 + a] = m.gt[a];
+            }
+            if (g_img)
+                g_img[r] = g * m.sumT * ((*alphamax - *alphamin) / (float)(n_points - 1));
+            if (g_alpha) {
+                g_alpha[r * 2 + 0] = m.g_amin;
+                g_alpha[r * 2 + 1] = m.g_amax;
+            }
+        });
+    return 0;
+}
+
 int ddrr_trilinear_samples(const float *volume, int dx, int dy, int dz, const float *source,
                            int src_n, const float *target, const float *img, int B, int N,
                            float voxel_shift, float eps, int n_points, const float *alphamin,

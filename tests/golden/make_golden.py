@@ -182,6 +182,8 @@ def make_renderer_fixtures():
                      lambda g: random_rays(g, dims, 2, 32), 23, want_grads=False)
     renderer_fixture("trilinear_mask", lambda: R.Trilinear(), {"n_points": 40}, dims,
                      lambda g: random_rays(g, dims, 2, 32), 24, mask=mask)
+    renderer_fixture("trilinear_max", lambda: R.Trilinear(reducefn="max"), {"n_points": 37}, dims,
+                     lambda g: random_rays(g, dims, 2, 32), 28)
     renderer_fixture("trilinear_callable", lambda: R.Trilinear(reducefn=topk_sum),
                      {"n_points": 40}, dims, lambda g: random_rays(g, dims, 2, 32), 27)
     renderer_fixture("trilinear_shift0", lambda: R.Trilinear(voxel_shift=0.0), {"n_points": 40},

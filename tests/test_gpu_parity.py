@@ -174,6 +174,18 @@ def test_trilinear_golden(gpu, name, npts, rng, shift):
         assert abs(grads[5].item() / g["g_alphamax_f64"] - 1) < GRAD_TOL
 
 
+def test_trilinear_max_gradients_golden(gpu):
+    """Trilinear(reducefn="max") backward (ddrr_trilinear_backward_max) against the reference."""
+    g = golden("trilinear_max")
+    vol, src, tgt, img = (t.requires_grad_() for t in dev_inputs(g, gpu))
+    out = Trilinear(reducefn="max")(vol, src, tgt, img, n_points=37)
+    assert rel_err(out.detach().cpu().numpy(), g["out_f32"]) < FWD_TOL
+    go = torch.from_numpy(g["grad_out_f32"]).to(gpu)
+    grads = torch.autograd.grad(out, [src, tgt, img, vol], go)
+    for k, gr in zip(("g_source", "g_target", "g_img", "g_volume"), grads):
+        assert rel_err(gr.cpu().numpy(), g[k + "_f64"]) < GRAD_TOL, k
+
+
 def test_trilinear_nearest_max_golden(gpu):
     g = golden("trilinear_nearest_max")
     vol, src, tgt, img = dev_inputs(g, gpu)

@@ -473,3 +473,18 @@ def test_siddon_midpoint_lookup_gradients(emulated_ops, name, ctor, call):
     grads = torch.autograd.grad(out, [src, tgt, img, vol], f32("grad_out_f32"))
     for k, gr in zip(("g_source", "g_target", "g_img", "g_volume"), grads):
         assert rel_err(gr.numpy(), g[k + "_f64"]) < 1e-3, k
+
+
+def test_trilinear_max_gradients(emulated_ops):
+    """Trilinear(reducefn="max") is differentiable like the reference (the arg-max sample gets
+    the gradient): against the reference's autograd."""
+    from diffdrr_amd import Trilinear
+
+    g = golden("trilinear_max")
+    f32 = lambda k: torch.from_numpy(np.ascontiguousarray(g[k], dtype=np.float32))  # noqa: E731
+    vol, src, tgt, img = (f32(k).requires_grad_() for k in ("volume", "source", "target", "img_f32"))
+    out = Trilinear(reducefn="max")(vol, src, tgt, img, n_points=37)
+    assert rel_err(out.detach().numpy(), g["out_f32"]) < 1e-4
+    grads = torch.autograd.grad(out, [src, tgt, img, vol], f32("grad_out_f32"))
+    for k, gr in zip(("g_source", "g_target", "g_img", "g_volume"), grads):
+        assert rel_err(gr.numpy(), g[k + "_f64"]) < 1e-3, k
