@@ -151,6 +151,7 @@ def main():
     rot = rot0.clone().requires_grad_()
     xyz = xyz0.clone().requires_grad_()
     gathered = torch.empty(world * B, device=device) if world > 1 else None
+    pending = []  # the in-flight all_gather of the last step
 
     def step():
         rot.grad = None
@@ -159,13 +160,18 @@ def main():
         loss = ncc(base.expand(B, -1, -1, -1), img)  # (B,) one similarity per pose
         loss.sum().backward()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, loss.detach())
+            # the 4 B/pose of losses travel on RCCL's own stream while the next step renders:
+            # nothing on the compute stream waits for them before fence()
+            pending[:] = [dist.all_gather_into_tensor(gathered, loss.detach(), async_op=True)]
         return loss
 
     timer = KernelTimer()
     timer.install()
 
     def fence():
+        for work in pending:
+            work.wait()
+        pending.clear()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
