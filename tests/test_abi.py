@@ -93,3 +93,43 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "ref_loader" not in text and "/root/reference" not in text, f
+
+
+def test_argument_checks_return_errors_without_touching_a_device():
+    """Every entry validates its arguments before the first HIP call: bad calls return a
+    non-zero code and leave a message in ddrr_last_error() (no GPU needed to see that)."""
+    import ctypes
+
+    import __graft_entry__ as entry
+
+    entry.build_hip()
+    lib = _lib.DdrrLibrary(_lib.LIB_PATH)
+    c = lib.cdll
+    c.ddrr_last_error.restype = ctypes.c_char_p
+    buf = (ctypes.c_float * 64)()
+    P = ctypes.cast(buf, ctypes.c_void_p)
+    f = ctypes.c_float
+    # null volume
+    rc = c.ddrr_siddon_forward(None, 4, 4, 4, P, 1, P, P, 1, 5, f(0.5), f(1e-8), 0, 0, 0, 0, 0, 1, 64,
+                               P, None, None, None)
+    assert rc != 0 and b"null" in c.ddrr_last_error()
+    # bad dims / src_n / negative batch
+    assert c.ddrr_siddon_forward(P, 0, 4, 4, P, 1, P, P, 1, 5, f(0.5), f(1e-8), 0, 0, 0, 0, 0, 1, 64,
+                                 P, None, None, None) != 0
+    assert b"dims" in c.ddrr_last_error()
+    assert c.ddrr_siddon_forward(P, 4, 4, 4, P, 3, P, P, 1, 5, f(0.5), f(1e-8), 0, 0, 0, 0, 0, 1, 64,
+                                 P, None, None, None) != 0
+    assert b"src_n" in c.ddrr_last_error()
+    assert c.ddrr_trilinear_forward(P, 4, 4, 4, P, 1, P, P, -1, 5, f(0.5), f(1e-8), 8, P, P, 0, 0,
+                                    0, 0, 0, 1, 64, P, None) != 0
+    # the marcher needs at least two samples; the brick paths a 2x2 detector
+    assert c.ddrr_trilinear_forward(P, 4, 4, 4, P, 1, P, P, 1, 5, f(0.5), f(1e-8), 1, P, P, 0, 0, 0,
+                                    0, 0, 1, 64, P, None) != 0
+    assert b"n_points" in c.ddrr_last_error()
+    assert c.ddrr_siddon_forward_bricks(P, 4, 4, 4, P, P, P, 1, 1, 5, f(0.5), f(1e-8), P, None,
+                                        None) != 0
+    assert b"2x2" in c.ddrr_last_error()
+    # an empty batch is a valid no-op
+    assert c.ddrr_siddon_forward(P, 4, 4, 4, P, 1, P, P, 0, 5, f(0.5), f(1e-8), 0, 0, 0, 0, 0, 1, 64,
+                                 P, None, None, None) == 0
+    assert c.ddrr_pose_euler_forward(P, P, 0, 0, 1, P, 1, P, None) != 0  # repeated axis
