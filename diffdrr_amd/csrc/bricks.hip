@@ -6,6 +6,7 @@
 #include "siddon_core.h"
 #include "brick_core.h"
 #include "brick_walk.h"
+#include "record_pack.h"
 #include "tri_brick.h"
 #include "trilinear_core.h"
 
@@ -48,6 +49,7 @@ struct BrickArgs {
     float shift, eps;
     BrickLayout lay;
     unsigned aux_plane;  // elements per plane of the planar backward record (B * N)
+    float rec_q;         // > 0: the record is the packed fixed-point form (record_pack.h), scale q
     int pix_bits;        // queue entry = (pose << pix_bits) | pixel
     float t1, t2;        // length-class thresholds on the estimated crossing count
     int dbg;             // experiment switches (0 in production)
@@ -154,11 +156,21 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
     // with the record, out = L * (plane I) is formed afterwards (siddon_out_from_record_kernel)
     if (!AUX && !(p.dbg & 2)) unsafeAtomicAdd(out + r, L * I);
     if (AUX && !(p.dbg & 1)) {
-        unsafeAtomicAdd(aux + r, I);
-        unsafeAtomicAdd(aux + p.aux_plane + r, rec[0]);
-        unsafeAtomicAdd(aux + 2u * p.aux_plane + r, rec[1]);
-        unsafeAtomicAdd(aux + 3u * p.aux_plane + r, rec[2]);
-        unsafeAtomicAdd(aux + 4u * p.aux_plane + r, rec[3]);
+        if (p.rec_q > 0.f) {
+            // packed record: (S1x : S0x) and (S1z : S0z) as two 64-bit integer atomics
+            const float qa = p.rec_q / aux[5u * p.aux_plane + r];
+            unsigned long long *X = reinterpret_cast<unsigned long long *>(aux);
+            atomicAdd(X + r, (unsigned long long)record_pack(rec[0], rec[2], p.rec_q, qa));
+            atomicAdd(X + p.aux_plane + r,
+                      (unsigned long long)record_pack(rec[1], rec[3], p.rec_q, qa));
+            unsafeAtomicAdd(aux + 4u * p.aux_plane + r, I);
+        } else {
+            unsafeAtomicAdd(aux + r, I);
+            unsafeAtomicAdd(aux + p.aux_plane + r, rec[0]);
+            unsafeAtomicAdd(aux + 2u * p.aux_plane + r, rec[1]);
+            unsafeAtomicAdd(aux + 3u * p.aux_plane + r, rec[2]);
+            unsafeAtomicAdd(aux + 4u * p.aux_plane + r, rec[3]);
+        }
     }
 }
 
@@ -364,14 +376,15 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                 int pix = 0;
                 float n_est = 0.f;
                 const bool hit = valid && brick_candidate(r, local, p.det_w, pix, n_est);
-                // With the backward record (5 atomics per hit instead of 1) the length class
+                // With the float backward record (5 atomics per hit instead of 1; the packed
+                // record's 3 are cheap enough to go per lane) the length class
                 // of a hit is that of the longest hit among its 8 neighbours in candidate
                 // order (consecutive pixels of a detector row): a batch is then made of runs
                 // of >= 8 adjacent pixels and its atomics touch few cache lines -- their cost
                 // is per line, not per lane (measured: 3.55 -> 2.74 ms; without the record
                 // the per-lane classes win, 1.87 vs 2.01 ms).
                 float n_grp = hit ? n_est : 0.f;
-                if ((AUX || MODE == BRICK_TRI_FWD_AUX) && !(p.dbg & 8)) {
+                if (((AUX && p.rec_q == 0.f) || MODE == BRICK_TRI_FWD_AUX) && !(p.dbg & 8)) {
                     n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
                         0, __builtin_bit_cast(int, n_grp), 0xB1, 0xf, 0xf, true)));   // lane ^ 1
                     n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
@@ -527,6 +540,19 @@ __global__ __launch_bounds__(kBlock) void volgrad_prepare_kernel(
     }
 }
 
+// Per-ray alpha bound A and the scale q of the packed record (record_pack.h): planes 5 and 6.
+__global__ __launch_bounds__(kBlock) void record_prepare_kernel(
+    const float *__restrict__ source, const float *__restrict__ target, long R, int N, Dims D,
+    float shift, float eps, float q, float *__restrict__ aux) {
+    const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (r == 0) aux[6 * R] = q;
+    if (r >= R) return;
+    const long b = r / N;
+    const float s[3] = {source[b * 3], source[b * 3 + 1], source[b * 3 + 2]};
+    const float t[3] = {target[r * 3], target[r * 3 + 1], target[r * 3 + 2]};
+    aux[5 * R + r] = record_alpha_bound(D, s, t, shift, eps);
+}
+
 // out = L * I from plane 0 of the Siddon planar record (the record launch leaves `out` alone:
 // one atomic less per ray and brick).
 __global__ __launch_bounds__(kBlock) void siddon_out_from_record_kernel(
@@ -589,7 +615,7 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
                   const float *target, const float *img, const float *grad_out, int B, int det_h,
                   int det_w, float voxel_shift, float eps, float *out, float *aux,
                   float *g_volume, hipStream_t st, const char *who, int n_points = 0,
-                  const float *amin = nullptr, const float *amax = nullptr) {
+                  const float *amin = nullptr, const float *amax = nullptr, float rec_q = 0.f) {
     const int N = det_h * det_w;
     BrickArgs p;
     p.vol = volume;
@@ -607,6 +633,7 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
         return fail(-1, "B * N too large for one brick launch (12 B N must stay below 2^32): "
                         "split the pose batch");
     p.aux_plane = (unsigned)((long)B * N);
+    p.rec_q = rec_q;
     p.pix_bits = 1;
     while ((1L << p.pix_bits) < N) ++p.pix_bits;
     if (((long)B << p.pix_bits) > (1L << 32))
@@ -716,24 +743,33 @@ int ddrr_set_brick_classes(float t1, float t2) {
 int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
                                const float *target, const float *img, int B, int det_h,
                                int det_w, float voxel_shift, float eps, float *out, float *aux,
-                               void *stream) {
+                               float record_vmax, void *stream) {
     const int N = det_h * det_w;
     if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
     if (!out) return fail(-1, "null out pointer");
     if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
+    if (!(record_vmax >= 0.f)) return fail(-1, "record_vmax must be >= 0");
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const long R = (long)B * N;
+    const bool packed = aux && record_vmax > 0.f;
     hipError_t e = hipMemsetAsync(aux ? aux : out, 0,
                                   sizeof(float) * (size_t)R * (aux ? kBrickAuxPlanes : 1), st);
     if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    float rec_q = 0.f;
+    if (packed) {
+        rec_q = record_scale(record_vmax, Dims{dx, dy, dz});
+        hipLaunchKernelGGL(record_prepare_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, st, source, target, R, N, Dims{dx, dy, dz}, voxel_shift,
+                           eps, rec_q, aux);
+    }
     if (int rc = launch_bricks(aux ? BRICK_FWD_AUX : BRICK_FWD, volume, dx, dy, dz, source, target,
                                img, nullptr, B, det_h, det_w, voxel_shift, eps, out, aux, nullptr,
-                               st, "ddrr_siddon_forward_bricks"))
+                               st, "ddrr_siddon_forward_bricks", 0, nullptr, nullptr, rec_q))
         return rc;
     if (!aux) return 0;
     hipLaunchKernelGGL(siddon_out_from_record_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, st, aux, img, R, out);
+                       dim3(kBlock), 0, st, aux + (packed ? 4 * R : 0), img, R, out);
     return finish("ddrr_siddon_forward_bricks");
 }
 

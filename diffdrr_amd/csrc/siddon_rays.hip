@@ -4,6 +4,7 @@
 // per-segment tensor.  The volume-stationary kernels live in bricks.hip.
 #include "runtime.h"
 #include "siddon_core.h"
+#include "record_pack.h"
 #include "slab_core.h"
 #include "segments_core.h"
 
@@ -64,10 +65,20 @@ __global__ __launch_bounds__(kBlock) void siddon_bwd_rays_kernel(
     const float s[3] = {sp[0], sp[1], sp[2]}, t[3] = {tp[0], tp[1], tp[2]};
     float rec[SIDDON_AUX];
     if (planar) {
-        // record of the brick kernel: planes I, S0x, S0z, S1x, S1z of R floats each; the y
-        // components follow from sum_a S0_a = 0, sum_a S1_a = I
-        const float I = aux[r], S0x = aux[R + r], S0z = aux[2 * R + r];
-        const float S1x = aux[3 * R + r], S1z = aux[4 * R + r];
+        // record of the brick kernel: planes I, S0x, S0z, S1x, S1z of R floats each (or their
+        // packed fixed-point form, record_pack.h); the y components follow from
+        // sum_a S0_a = 0, sum_a S1_a = I
+        float I, S0x, S0z, S1x, S1z;
+        if (planar == DDRR_AUX_PACKED) {
+            const long long *X = reinterpret_cast<const long long *>(aux);
+            const float q = aux[6 * R], qa = q / aux[5 * R + r];
+            record_unpack(X[r], q, qa, S0x, S1x);
+            record_unpack(X[R + r], q, qa, S0z, S1z);
+            I = aux[4 * R + r];
+        } else {
+            I = aux[r], S0x = aux[R + r], S0z = aux[2 * R + r];
+            S1x = aux[3 * R + r], S1z = aux[4 * R + r];
+        }
         rec[0] = I;
         rec[1] = S0x;
         rec[2] = -(S0x + S0z);
@@ -477,9 +488,10 @@ int ddrr_siddon_backward_rays(const float *aux, int aux_layout, const float *gra
                               float *g_source, float *g_target, float *g_img, void *stream) {
     if (!aux || !grad_out || !source || !target) return fail(-1, "null pointer");
     if (src_n != 1 && src_n != N) return fail(-1, "src_n must be 1 or N");
-    if (aux_layout != DDRR_AUX_INTERLEAVED && aux_layout != DDRR_AUX_PLANAR)
+    if (aux_layout != DDRR_AUX_INTERLEAVED && aux_layout != DDRR_AUX_PLANAR &&
+        aux_layout != DDRR_AUX_PACKED)
         return fail(-1, "bad aux_layout");
-    if (aux_layout == DDRR_AUX_PLANAR && reduce_mode != DDRR_REDUCE_SUM)
+    if (aux_layout != DDRR_AUX_INTERLEAVED && reduce_mode != DDRR_REDUCE_SUM)
         return fail(-1, "the planar record exists for reduce sum only");
     const long R = (long)B * N;
     if (R == 0) return 0;

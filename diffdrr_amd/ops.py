@@ -169,12 +169,38 @@ def siddon_forward_slab(volume, source, target, img, det, plan, shear, *, voxel_
     return out, aux
 
 
+_vmax_cache = {}
+
+
+def volume_absmax(volume) -> float:
+    """max |volume| as a host float, cached per (storage, version): the scale of the packed
+    backward record.  One reduction and one host sync when the volume (buffer) changes."""
+    key = (volume.data_ptr(), volume._version, tuple(volume.shape), str(volume.device))
+    hit = _vmax_cache.get("key") == key
+    if not hit:
+        _vmax_cache["key"] = key
+        _vmax_cache["value"] = float(volume.detach().abs().max().item())
+    return _vmax_cache["value"]
+
+
+def _aux_layout(aux, B, N):
+    if aux.shape == (B, N, SIDDON_AUX):
+        return _lib.AUX_INTERLEAVED
+    if aux.shape == (_lib.BRICK_AUX_PLANES, B, N):
+        return _lib.AUX_PLANAR
+    if aux.shape == (_lib.PACKED_AUX_PLANES, B, N):
+        return _lib.AUX_PACKED
+    raise ValueError(f"aux has shape {tuple(aux.shape)}: neither (B,N,8), (5,B,N) nor (7,B,N)")
+
+
 def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, eps=1e-8,
-                          want_aux=False):
+                          want_aux=False, record_vmax=0.0):
     """Detector-grid Siddon (sum) through the volume-stationary brick kernel: every 32^3
     brick is staged in LDS once and all rays of all poses are traced through it.
     Requires the targets to be the affine detector grid DRR builds.
-    -> (out (B,N), aux (5,B,N) planar backward record | None)"""
+    -> (out (B,N), aux | None); aux is the (5,B,N) planar float record, or with
+    ``record_vmax`` = max |volume| > 0 the (7,B,N) packed fixed-point record (3 atomics per
+    ray and brick instead of 5, bit-reproducible; csrc/record_pack.h)."""
     B, N = _check_rays(volume, source, target, img)
     H, W = int(det[0]), int(det[1])
     if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
@@ -182,14 +208,16 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
     volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
     img = None if img is None else img.contiguous()
     out = torch.empty(B, N, dtype=torch.float32, device=volume.device)
-    aux = torch.empty(_lib.BRICK_AUX_PLANES, B, N, dtype=torch.float32, device=volume.device) \
+    packed = bool(want_aux and record_vmax and record_vmax > 0.0)
+    planes = _lib.PACKED_AUX_PLANES if packed else _lib.BRICK_AUX_PLANES
+    aux = torch.empty(planes, B, N, dtype=torch.float32, device=volume.device) \
         if want_aux else None
     if _empty(B, N):
         return out, aux
     _launch(
         "ddrr_siddon_forward_bricks", volume.device, volume.data_ptr(), *volume.shape,
         source.data_ptr(), target.data_ptr(), _ptr(img), B, H, W, float(voxel_shift), float(eps),
-        out.data_ptr(), _ptr(aux))
+        out.data_ptr(), _ptr(aux), float(record_vmax) if packed else 0.0)
     return out, aux
 
 
@@ -198,12 +226,7 @@ def siddon_backward_rays(aux, grad_out, source, target, img, *, eps=1e-8, reduce
     """aux: (B,N,8) interleaved record (generic / slab forward) or (5,B,N) planar record
     (brick forward).  -> (g_source (B,N,3) per ray, g_target (B,N,3), g_img (B,N) | None)"""
     B, N, _ = target.shape
-    if aux.shape == (B, N, SIDDON_AUX):
-        layout = _lib.AUX_INTERLEAVED
-    elif aux.shape == (_lib.BRICK_AUX_PLANES, B, N):
-        layout = _lib.AUX_PLANAR
-    else:
-        raise ValueError(f"aux has shape {tuple(aux.shape)}: neither (B,N,8) nor (5,B,N)")
+    layout = _aux_layout(aux, B, N)
     grad_out = grad_out.contiguous()
     g_source = torch.empty(B, N, 3, dtype=torch.float32, device=target.device)
     g_target = torch.empty(B, N, 3, dtype=torch.float32, device=target.device)
@@ -295,12 +318,7 @@ def siddon_backward_pose(aux, grad_out, source, target, img, Mw, Ainv, P, *, eps
     """dLoss/dMw (B,3,4): the renderer's ray gradients chained through the ray generation
     and reduced per pose in one kernel (reduce sum)."""
     B, N, _ = target.shape
-    if aux.shape == (B, N, SIDDON_AUX):
-        layout = _lib.AUX_INTERLEAVED
-    elif aux.shape == (_lib.BRICK_AUX_PLANES, B, N):
-        layout = _lib.AUX_PLANAR
-    else:
-        raise ValueError(f"aux has shape {tuple(aux.shape)}: neither (B,N,8) nor (5,B,N)")
+    layout = _aux_layout(aux, B, N)
     gMw = torch.zeros(B, 3, 4, dtype=torch.float32, device=target.device)
     if B == 0:
         return gMw

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 14
+#define DDRR_ABI_VERSION 15
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -59,6 +59,8 @@ extern "C" {
 #define DDRR_AUX_INTERLEAVED 0 /* (B, N, 8): ddrr_siddon_forward, ddrr_siddon_forward_slab */
 #define DDRR_AUX_PLANAR 1      /* (5, B, N) planes I, S0x, S0z, S1x, S1z: ddrr_siddon_forward_bricks */
 #define DDRR_BRICK_AUX_PLANES 5
+#define DDRR_AUX_PACKED 2      /* (7, B, N): fixed-point record, csrc/record_pack.h: ddrr_siddon_forward_bricks(record_vmax > 0) */
+#define DDRR_PACKED_AUX_PLANES 7
 #define DDRR_TRI_AUX_PLANES 7   /* sum T, sum dT_xyz, sum alpha dT_xyz: ddrr_trilinear_forward_bricks */
 
 int ddrr_abi_version(void);
@@ -100,11 +102,15 @@ int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const 
  * volume is read from HBM once per call, whatever B.  The image equals
  * ddrr_siddon_forward's up to fp32 summation order (which is not deterministic here).
  * aux: NULL, or a (DDRR_BRICK_AUX_PLANES, B, N) planar backward record (zero-filled and
- * accumulated by the call) for ddrr_siddon_backward_rays(aux_layout = DDRR_AUX_PLANAR). */
+ * accumulated by the call) for ddrr_siddon_backward_rays(aux_layout = DDRR_AUX_PLANAR).
+ * record_vmax: 0, or max |volume| (> 0): aux is then (DDRR_PACKED_AUX_PLANES, B, N) and receives
+ * the record in 32-bit fixed point, two fields per 64-bit integer atomic (3 atomics per ray and
+ * brick instead of 5; exact, order-independent sums; resolution 2 vmax (dx+dy+dz+3) / 2^30 per
+ * brick piece) for aux_layout = DDRR_AUX_PACKED. */
 int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
                                const float *target, const float *img, int B, int det_h,
                                int det_w, float voxel_shift, float eps, float *out, float *aux,
-                               void *stream);
+                               float record_vmax, void *stream);
 
 /* Volume gradient for the DRR case of ddrr_siddon_forward_bricks (reduce sum), also
  * volume-stationary: each 32^3 brick of g_volume is accumulated in LDS (ds_add_f32) from

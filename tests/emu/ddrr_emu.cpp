@@ -19,6 +19,7 @@
 #include "../../diffdrr_amd/csrc/brick_core.h"
 #include "../../diffdrr_amd/csrc/brick_walk.h"
 #include "../../diffdrr_amd/csrc/raygen_core.h"
+#include "../../diffdrr_amd/csrc/record_pack.h"
 #include "../../diffdrr_amd/csrc/segments_core.h"
 #include "../../diffdrr_amd/csrc/tri_brick.h"
 #include "../../diffdrr_amd/csrc/slab_core.h"
@@ -235,6 +236,24 @@ int tri_owner_host(int dx, int dy, int dz, const float *source, const float *tar
 }
 }  // namespace
 
+// The brick kernel's record of ray r as the interleaved 8 floats (planar float planes, or the
+// packed fixed-point form of record_pack.h).
+static void planar_record(const float *aux, int aux_layout, long R, long r, float rec[SIDDON_AUX]) {
+    float I, S0x, S0z, S1x, S1z;
+    if (aux_layout == DDRR_AUX_PACKED) {
+        const long long *X = reinterpret_cast<const long long *>(aux);
+        const float q = aux[6 * R], qa = q / aux[5 * R + r];
+        record_unpack(X[r], q, qa, S0x, S1x);
+        record_unpack(X[R + r], q, qa, S0z, S1z);
+        I = aux[4 * R + r];
+    } else {
+        I = aux[r], S0x = aux[R + r], S0z = aux[2 * R + r];
+        S1x = aux[3 * R + r], S1z = aux[4 * R + r];
+    }
+    const float v[SIDDON_AUX] = {I, S0x, -(S0x + S0z), S0z, S1x, I - (S1x + S1z), S1z, 0.f};
+    memcpy(rec, v, sizeof(v));
+}
+
 extern "C" {
 
 int ddrr_abi_version(void) { return DDRR_ABI_VERSION; }
@@ -436,12 +455,22 @@ int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const 
 int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
                                const float *target, const float *img, int B, int det_h,
                                int det_w, float voxel_shift, float eps, float *out, float *aux,
-                               void *) {
+                               float record_vmax, void *) {
     const Dims D{dx, dy, dz};
     const int N = det_h * det_w;
     const long plane = (long)B * N;
     memset(out, 0, sizeof(float) * (size_t)B * N);
     if (aux) memset(aux, 0, sizeof(float) * (size_t)DDRR_BRICK_AUX_PLANES * B * N);
+    // packed fixed-point record (record_pack.h): planes 5 (A per ray) and 6 (q) first
+    const bool packed = aux && record_vmax > 0.f;
+    const float rec_q = packed ? record_scale(record_vmax, D) : 0.f;
+    long long *packedX = reinterpret_cast<long long *>(aux);
+    if (packed) {
+        aux[6 * plane] = rec_q;
+        for (long r = 0; r < plane; ++r)
+            aux[5 * plane + r] = record_alpha_bound(D, source + (r / N) * 3, target + r * 3,
+                                                    voxel_shift, eps);
+    }
     const BrickGrid bg = brick_grid(D);
     const BrickLayout lay{33, 32 * 33 + 1};
     std::vector<float> brick((size_t)brick_floats(lay));
@@ -469,7 +498,12 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                                                       voxel_shift, eps, I, rec);
             if (!hit) return;  // phase A's margin let a non-crossing ray through
             out[r] += (img ? img[r] : 1.f) * I;
-            if (aux) {
+            if (packed) {
+                const float qa = rec_q / aux[5 * plane + r];
+                packedX[r] += record_pack(rec[0], rec[2], rec_q, qa);
+                packedX[plane + r] += record_pack(rec[1], rec[3], rec_q, qa);
+                aux[4 * plane + r] += I;
+            } else if (aux) {
                 aux[r] += I;
                 for (int k = 0; k < 4; ++k) aux[(k + 1) * plane + r] += rec[k];
             }
@@ -626,15 +660,10 @@ int ddrr_siddon_backward_rays(const float *aux, int aux_layout, const float *gra
                  [&](int, int, long r, const Ray &ray) {
                      float gs[3], gt[3];
                      float planar[SIDDON_AUX];
-                     if (aux_layout == DDRR_AUX_PLANAR) {
-                         const float I = aux[r], S0x = aux[R + r], S0z = aux[2 * R + r];
-                         const float S1x = aux[3 * R + r], S1z = aux[4 * R + r];
-                         const float v[SIDDON_AUX] = {I, S0x, -(S0x + S0z), S0z,
-                                                      S1x, I - (S1x + S1z), S1z, 0.f};
-                         memcpy(planar, v, sizeof(v));
-                     }
+                     if (aux_layout != DDRR_AUX_INTERLEAVED)
+                         planar_record(aux, aux_layout, R, r, planar);
                      const float *rec =
-                         aux_layout == DDRR_AUX_PLANAR ? planar : aux + r * SIDDON_AUX;
+                         aux_layout != DDRR_AUX_INTERLEAVED ? planar : aux + r * SIDDON_AUX;
                      if (reduce_mode == DDRR_REDUCE_SUM)
                          siddon_backward_ray<REDUCE_SUM>(rec, ray.s, ray.t, eps,
                                                          grad_out[r] * ray.L, gs, gt);
@@ -1083,12 +1112,8 @@ int ddrr_siddon_backward_pose(const float *aux, int aux_layout, const float *gra
         for (int n = 0; n < N; ++n) {
             const long r = (long)b * N + n;
             float rec[SIDDON_AUX];
-            if (aux_layout == DDRR_AUX_PLANAR) {
-                const float I = aux[r], S0x = aux[R + r], S0z = aux[2 * R + r];
-                const float S1x = aux[3 * R + r], S1z = aux[4 * R + r];
-                const float v[SIDDON_AUX] = {I, S0x, -(S0x + S0z), S0z,
-                                             S1x, I - (S1x + S1z), S1z, 0.f};
-                memcpy(rec, v, sizeof(v));
+            if (aux_layout != DDRR_AUX_INTERLEAVED) {
+                planar_record(aux, aux_layout, R, r, rec);
             } else {
                 memcpy(rec, aux + r * SIDDON_AUX, sizeof(rec));
             }

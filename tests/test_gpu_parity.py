@@ -832,3 +832,23 @@ def test_fused_euler_pose_on_gpu(gpu):
     a = drr(rot0, xyz0, parameterization="euler_angles", convention="ZXY")
     b = drr(convert(rot0, xyz0, parameterization="euler_angles", convention="ZXY"))
     assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+
+
+def test_packed_record_on_gpu(gpu, big):
+    """Opt-in fixed-point record (csrc/record_pack.h) at 512^3 / 256^2: the same ray gradients
+    as the fp32 record up to its resolution, and bit-identical from run to run (integer
+    atomics), which the fp32 record is not."""
+    drr, s, t, L = big
+    V = drr.density
+    vmax = ops.volume_absmax(V)
+    out_f, aux_f = ops.siddon_forward_bricks(V, s, t, L, (256, 256), want_aux=True)
+    out_p, aux_p = ops.siddon_forward_bricks(V, s, t, L, (256, 256), want_aux=True,
+                                             record_vmax=vmax)
+    assert aux_p.shape[0] == 7 and rel_err(out_p.cpu().numpy(), out_f.cpu().numpy()) < 1e-6
+    go = torch.rand(out_f.shape, device=gpu, generator=torch.Generator(gpu).manual_seed(5))
+    gf = ops.siddon_backward_rays(aux_f, go, s, t, L)
+    gp = ops.siddon_backward_rays(aux_p, go, s, t, L)
+    for a, b in zip(gp, gf):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
+    _, aux_p2 = ops.siddon_forward_bricks(V, s, t, L, (256, 256), want_aux=True, record_vmax=vmax)
+    assert torch.equal(aux_p[:4].view(torch.int32), aux_p2[:4].view(torch.int32))

@@ -28,8 +28,8 @@ print(f"# {torch.cuda.get_device_name(0)}  volume {D}^3  detector {H}^2")
 base = rays(drr, torch.zeros(1, 3, device=dev), torch.tensor([[0.0, 850.0, 0.0]], device=dev))
 sets = {}
 for case in a.cases.split(","):
-    aux = case.endswith("aux")
-    name = case[:-3] if aux else case
+    aux = case.endswith("aux") or case.endswith("auxp")
+    name = case[:-4] if case.endswith("auxp") else (case[:-3] if aux else case)
     if name.startswith("base"):
         B = int(name[4:])
         s, t, L = (x.expand(B, *x.shape[1:]).contiguous() for x in base)
@@ -53,7 +53,8 @@ for lay, dbg, cl in itertools.product(a.layouts.split(","), a.dbg.split(","), a.
         _, _, nv = ops.siddon_forward(V, s, t, L, count_voxels=True, det=(H, H))
         nvox = int(nv.sum())
         alg = 4 * nvox + B * H * H * 20 + 12 * B
-        med, best = timeit(lambda: ops.siddon_forward_bricks(V, s, t, L, (H, H), want_aux=aux))
+        vm = ops.volume_absmax(V) if case.endswith("auxp") else 0.0
+        med, best = timeit(lambda: ops.siddon_forward_bricks(V, s, t, L, (H, H), want_aux=aux, record_vmax=vm))
         ref = ops.siddon_forward(V, s, t, L, det=(H, H))[0]
         out = ops.siddon_forward_bricks(V, s, t, L, (H, H), want_aux=aux)[0]
         err = ((out - ref).abs().max() / ref.abs().max()).item()
