@@ -3,6 +3,8 @@
 // every pose through them; Siddon forward (+ backward record), Siddon and trilinear volume
 // gradients, trilinear forward (+ record); and the elementwise kernels that consume the records.
 #include "runtime.h"
+
+#include <mutex>
 #include "siddon_core.h"
 #include "brick_core.h"
 #include "brick_walk.h"
@@ -652,37 +654,45 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     }
     const size_t lds = brick_lds_bytes(p.lay);
     hipError_t e;
-    static bool attr_set = false;  // raise the dynamic-LDS limit once per process
-    if (!attr_set) {
-        const void *fns[6] = {reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_FWD_AUX>),
-                              reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_FWD>),
-                              reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_FWD_AUX>),
-                              reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_VOLGRAD>),
-                              reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_FWD>),
-                              reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_VOLGRAD>)};
-        for (const void *fn : fns)
-            if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024)) != hipSuccess)
-                return fail_hip(e, "hipFuncSetAttribute");
-        attr_set = true;
-    }
-    // one brick counter per launch, from a small per-device ring (launches in flight on
-    // different streams must not share one); zeroed on the launch's stream
+    // Per-device state, created on first use under a lock (the entry points may be called
+    // from several host threads): the raised dynamic-LDS limit of the brick kernels, the CU
+    // count, and a small ring of brick counters -- one per launch, so that launches in flight
+    // on different streams never share one; it is zeroed on the launch's stream.
     constexpr int kRing = 64, kMaxDev = 64;
+    static std::mutex mu;
+    static bool attr_set[kMaxDev] = {false};
     static int *ring[kMaxDev] = {nullptr};
     static int n_cu[kMaxDev] = {0};
     static unsigned slot[kMaxDev] = {0};
     int dev = 0;
     if ((e = hipGetDevice(&dev)) != hipSuccess) return fail_hip(e, "hipGetDevice");
     if (dev < 0 || dev >= kMaxDev) return fail(-1, "device index out of range");
-    if (!ring[dev]) {
-        if ((e = hipMalloc(reinterpret_cast<void **>(&ring[dev]), kRing * 4 * sizeof(int))) != hipSuccess)
-            return fail_hip(e, "hipMalloc(brick counters)");
-        if ((e = hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev)) !=
-            hipSuccess)
-            return fail_hip(e, "hipDeviceGetAttribute");
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!attr_set[dev]) {
+            const void *fns[6] = {
+                reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_FWD_AUX>),
+                reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_FWD>),
+                reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_FWD_AUX>),
+                reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_VOLGRAD>),
+                reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_FWD>),
+                reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_VOLGRAD>)};
+            for (const void *fn : fns)
+                if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             160 * 1024)) != hipSuccess)
+                    return fail_hip(e, "hipFuncSetAttribute");
+            attr_set[dev] = true;
+        }
+        if (!ring[dev]) {
+            if ((e = hipMalloc(reinterpret_cast<void **>(&ring[dev]),
+                               kRing * 4 * sizeof(int))) != hipSuccess)
+                return fail_hip(e, "hipMalloc(brick counters)");
+            if ((e = hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount,
+                                           dev)) != hipSuccess)
+                return fail_hip(e, "hipDeviceGetAttribute");
+        }
+        p.work = ring[dev] + 4 * (slot[dev]++ % kRing);  // {brick counter, wmax bits, n_sum, -}
     }
-    p.work = ring[dev] + 4 * (slot[dev]++ % kRing);  // {brick counter, wmax bits, n_sum, -}
     if ((e = hipMemsetAsync(p.work, 0, 4 * sizeof(int), st)) != hipSuccess)
         return fail_hip(e, "hipMemsetAsync");
     if (mode == BRICK_VOLGRAD || mode == BRICK_TRI_VOLGRAD) {
