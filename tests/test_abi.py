@@ -133,3 +133,54 @@ def test_argument_checks_return_errors_without_touching_a_device():
     assert c.ddrr_siddon_forward(P, 4, 4, 4, P, 1, P, P, 0, 5, f(0.5), f(1e-8), 0, 0, 0, 0, 0, 1, 64,
                                  P, None, None, None) == 0
     assert c.ddrr_pose_euler_forward(P, P, 0, 0, 1, P, 1, P, None) != 0  # repeated axis
+
+
+def test_brick_kernels_fit_their_register_budget():
+    """The brick kernels run 1024-thread workgroups = 4 waves per SIMD, i.e. 128 vector
+    registers per lane; a change that makes the compiler spill (scratch memory in the walk)
+    costs 10-50 % and is silent.  Read the kernel descriptors of the built code objects: no
+    private segment, at most 128 VGPRs, for every instance of siddon_brick_kernel."""
+    import struct
+
+    import __graft_entry__ as entry
+
+    entry.build_hip()
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not available")
+    data = open(_lib.LIB_PATH, "rb").read()
+    kernels = {}
+    for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data):
+        off = m.start()
+        n = struct.unpack_from("<Q", data, off + 24)[0]
+        p = off + 32
+        for _ in range(n):
+            o, size, tl = struct.unpack_from("<QQQ", data, p)
+            p += 24
+            triple = data[p:p + tl].decode()
+            p += tl
+            if "gfx950" not in triple:
+                continue
+            path = os.path.join(ROOT, "tests", "emu", "_co.elf")
+            with open(path, "wb") as f:
+                f.write(data[off + o:off + o + size])
+            notes = subprocess.run([readelf, "--notes", path], capture_output=True, text=True).stdout
+            os.remove(path)
+            name, scratch = None, None
+            for line in notes.splitlines():  # kernel-level keys come in alphabetical order
+                m2 = re.match(r"\s+\.(name|private_segment_fixed_size|vgpr_count):\s+(\S+)", line)
+                if not m2:
+                    continue
+                key, val = m2.groups()
+                if key == "name" and val.startswith("_Z"):
+                    name, scratch = val, None
+                elif key == "private_segment_fixed_size":
+                    scratch = int(val)
+                elif key == "vgpr_count" and name is not None and scratch is not None:
+                    kernels[name] = (scratch, int(val))
+                    name = None
+    bricks = {k: v for k, v in kernels.items() if "siddon_brick_kernel" in k}
+    assert len(bricks) == 6, sorted(kernels)
+    for name, (scratch, vgpr) in bricks.items():
+        assert scratch == 0, (name, scratch)
+        assert vgpr <= 128, (name, vgpr)
