@@ -234,7 +234,7 @@ def main():
             f"{ms_per_step - fwd_ms - bwd_ms:.3f} ms | voxels/ray {n_vox / (B * H * H):.1f} "
             f"| {alg_bytes / B / 1e6:.1f} MB algorithmic per DRR")
         result = {
-            "metric": "DRRs/sec fwd+bwd, 512^3 vol -> 256^2 det, batched poses",
+            "metric": f"DRRs/sec fwd+bwd, {D}^3 vol -> {H}^2 det, batched poses",  # BASELINE.json's at the defaults
             "value": total_drrs / dt,
             "unit": "DRRs/s",
             "n_gpus": world,
