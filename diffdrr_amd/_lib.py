@@ -15,7 +15,7 @@ from ctypes import c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffdrr_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 REDUCE_SUM, REDUCE_MAX = 0, 1
 LOOKUP_STEP, LOOKUP_MID_NEAREST, LOOKUP_MID_TRILINEAR = 0, 1, 2
@@ -30,8 +30,6 @@ _P, _I, _F, _L = c_void_p, c_int, c_float, c_long
 _SIGNATURES = {
     "ddrr_siddon_forward": [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _F, _F, _I, _I, _I, _I, _I,
                             _I, _I, _P, _P, _P, _P],
-    "ddrr_siddon_forward_slab": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _I, _P,
-                                 _I, _P, _P, _P],
     "ddrr_siddon_forward_bricks": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _F, _P],
     "ddrr_siddon_backward_rays": [_P, _I, _P, _P, _I, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P],
     "ddrr_siddon_backward_volume": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _I, _I,

@@ -1,0 +1,327 @@
+// brick_step.h -- the per-(ray, brick) clip and walk of the volume-stationary Siddon kernel,
+// written for how gfx950 issues vector instructions.
+//
+// Measured on MI355X (tools/ubench/valu_rates2.hip, 4 waves per SIMD): a wave64 v_add / v_sub /
+// v_mul / v_fma / v_fmac _f32 (also with neg / abs / clamp modifiers, inline constants, literals
+// and denormal operands), v_mov, v_and / or / xor and v_add / sub _u32 issue in 2 cycles; v_min /
+// max / min3 / med3, every v_cmp and v_cndmask, the conversions, v_floor, shifts, DPP moves, the
+// packed f32 forms AND any of the fast ones with an SGPR operand take 4.  So the walk below
+//   * selects with arithmetic instead of compare + cndmask: t = clamp(live - (a - m) * 2^126) is
+//     1 exactly where a == m (one v_sub + one v_fma with the clamp modifier);
+//   * forms the voxel's LDS address without a conversion: strides and base are handed over as
+//     the DENORMAL floats whose bit patterns are the integers (n * 2^-149), the address is an
+//     FMA chain over the plane counters and its bit pattern is the byte address;
+//   * keeps every loop operand in a VGPR, wave-uniform ones included;
+//   * has no per-lane exit: a lane whose ray has left the brick idles on its last voxel with
+//     zero-length steps (live = 0), the wave leaves when no lane is live.
+// One step = v_min3 + 18 fast instructions = 40 issue cycles (54 with the backward record),
+// against 58+ for the compare / select / convert formulation it replaces.
+//
+// Exactness: see step_enter (alpha of every plane a ray reaches inside a brick is within an ulp
+// of the reference's quotient (k - shift - s) / (t - s + eps), diffdrr/renderers.py:97-106).
+#pragma once
+
+#include <string.h>
+
+#include "brick_core.h"
+#include "brick_walk.h"
+#include "ddrr_common.h"
+#include "siddon_core.h"
+
+namespace ddrr {
+
+// --- the three non-standard operations, with their host restatements (tests/emu) ---
+
+// clamp(d * nbig + live) to [0, 1]: with d >= 0, nbig = -2^126: `live` where d == 0, else 0.
+DDRR_HD float sel_zero(float d, float nbig, float live) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(d), "v"(nbig), "v"(live));
+    return r;
+#else
+    const float r = fmaf(d, nbig, live);
+    return r > 0.f ? (r < 1.f ? r : 1.f) : 0.f;  // NaN -> 0, like the hardware clamp
+#endif
+}
+
+// clamp(x * big) to [0, 1]: 1 where x > 0 (by at least 2^-126), 0 where x <= 0 or NaN.
+DDRR_HD float sat_pos(float x, float big) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(x), "v"(big));
+    return r;
+#else
+    const float r = x * big;
+    return r > 0.f ? (r < 1.f ? r : 1.f) : 0.f;
+#endif
+}
+
+// The float whose bit pattern is the integer n (n * 2^-149 for n < 2^23) and back.
+DDRR_HD float bits_as_float(unsigned n) {
+    float f;
+    memcpy(&f, &n, 4);
+    return f;
+}
+DDRR_HD unsigned float_bits(float f) {
+    unsigned n;
+    memcpy(&n, &f, 4);
+    return n;
+}
+
+// Make the compiler hold a (possibly wave-uniform) value in a vector register from here on:
+// an SGPR operand halves the issue rate of the instruction that reads it.
+DDRR_HD float in_vgpr(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+
+constexpr float kSelBig = 0x1p126f;
+#ifndef DDRR_STEP_DEEP
+#define DDRR_STEP_DEEP 0
+#endif
+
+// Geometry of the staged brick for the walk: plane range per axis and the LDS byte strides
+// as bit-pattern floats (see above).
+struct StepGeom {
+    float lof[3], hif[3];  // first / last plane index of the brick per axis
+    float strideb[3];      // bits_as_float(byte stride) per axis
+};
+
+DDRR_HD StepGeom step_geom(const Box &box, const BrickLayout &lay) {
+    StepGeom G;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        G.lof[a] = (float)box.lo[a];
+        G.hif[a] = (float)box.hi[a];
+    }
+    G.strideb[0] = bits_as_float((unsigned)lay.sx * 4u);
+    G.strideb[1] = bits_as_float((unsigned)lay.sy * 4u);
+    G.strideb[2] = bits_as_float(4u);
+    return G;
+}
+
+// State of a ray at its entry into a brick.
+struct StepEntry {
+    float inv[3], a0[3];  // alpha_a(k) = fma(k - k0_a, inv_a, a0_a), k0_a: first plane ahead
+    float an[3];          // alpha of the next plane ahead (= a0 at entry: k - k0 = 0)
+    float dirf[3];        // +-1: how k - k0 moves
+    float ent[3];         // one-hot: the axis of the entry crossing (x before y before z)
+    float entry, exit;
+    float offc;           // bit-pattern float: address = bits(offc + sum_a (k_a - k0_a) strideb_a)
+    bool hit;
+};
+
+// `base_bits`: what the accessor wants added to a byte offset inside the brick (the brick's
+// absolute LDS address on the device, 0 for a pointer-relative fetch on the host).
+//
+// Conditioning.  alpha of plane k is the reference's quotient n_k / d, n_k = (k - shift) - s,
+// d = (t - s) + eps (renderers.py:97-106).  For a ray that glides along a plane of axis a
+// (|d_a| ~ 1e-5 |d|) n_k is tiny and exact for the plane next to the ray and n_k / d is
+// accurate, while any "base + k / d" form with a far base plane cancels two numbers of
+// size |k / d| >> alpha.  So the base plane of each axis is the FIRST plane ahead of the entry
+// point, with its alpha by a correctly rounded division; plane k further on is
+// fma(k - k0, 1/d, alpha_0), off by <= |alpha_k - alpha_0| 2^-23, i.e. by a fraction of an
+// ulp of alpha for every plane the ray can reach inside the brick.  Which cell the ray enters
+// is decided in the same terms, exactly: alpha_k >= entry  <=>  sign(d) (entry d - n_k) <= 0,
+// one FMA whose sign is that of the real number.
+// The exit alpha is the walk's own value for the exit face it reaches first (the walk
+// ends exactly there); the neighbouring brick enters at the face's quotient, at most
+// |chord| 2^-23 away: the pieces of a ray meet to ~1e-9 of its length.
+DDRR_HD StepEntry step_enter(const StepGeom &G, const float s[3], const float t[3], float shift,
+                             float eps, unsigned base_bits) {
+    StepEntry E;
+    float d[3], mn[3];
+    E.entry = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        d[a] = (t[a] - s[a]) + eps;  // renderers.py:104-106
+        E.inv[a] = fast_rcp(d[a]);
+        const float kn = d[a] > 0.f ? G.lof[a] : G.hif[a];  // the face the ray enters through
+        mn[a] = div_refined((kn - shift) - s[a], d[a], E.inv[a]);
+        E.entry = fmaxf(E.entry, mn[a]);
+    }
+    E.exit = INFINITY;
+    E.offc = bits_as_float(base_bits);
+    // the axis of the entry crossing, exclusive (ties: x before y before z)
+    E.ent[0] = mn[0] == E.entry ? 1.f : 0.f;
+    E.ent[1] = (mn[1] == E.entry && mn[0] != E.entry) ? 1.f : 0.f;
+    E.ent[2] = 1.f - E.ent[0] - E.ent[1];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const bool pos = d[a] > 0.f;
+        const float p01 = pos ? 1.f : 0.f;
+        E.dirf[a] = pos ? 1.f : -1.f;
+        const float cmax = G.hif[a] - 1.f;
+        // cell of the entry point from its position, then the alpha-order rule in exact terms:
+        // the plane ahead must not lie behind the entry alpha, the plane behind not ahead of it
+        float u = med3f(floorf(fmaf(E.entry, d[a], s[a] + shift)), G.lof[a], cmax);
+        const float ra = fmaf(E.entry, d[a], -(((u + p01) - shift) - s[a])) * E.dirf[a];
+        const float rb = fmaf(E.entry, d[a], -(((u + (1.f - p01)) - shift) - s[a])) * E.dirf[a];
+        const float adj = (ra > 0.f ? E.dirf[a] : 0.f) - (rb < 0.f ? E.dirf[a] : 0.f);
+        u = med3f(u + adj, G.lof[a], cmax);
+        u = (mn[a] == E.entry) ? (pos ? G.lof[a] : cmax) : u;  // entering axis: the face cell
+        const float k0 = u + p01;
+        E.a0[a] = div_refined((k0 - shift) - s[a], d[a], E.inv[a]);
+        E.an[a] = E.a0[a];
+        // the exit face of this axis, as the walk will see it
+        const float kx = pos ? G.hif[a] : G.lof[a];
+        E.exit = fminf(E.exit, fmaf(kx - k0, E.inv[a], E.a0[a]));
+        // address = base + sum_a (cell_a - lo_a) stride_a, cell_a = k_a - p01_a
+        E.offc = fmaf((k0 - p01) - G.lof[a], G.strideb[a], E.offc);
+    }
+    E.hit = E.entry < E.exit;  // false for NaN
+    return E;
+}
+
+// The walk of one ray through one brick from its entry state E (E.hit must hold).
+// `fetch(bits)` reads the LDS copy at the byte address `bits` (absolute on the device,
+// relative to the brick on the host).  I = sum V dalpha over the brick; with AUX,
+// rec = {S0x, S0z, S1x, S1z} of the brick-local backward record (voxels outside the brick
+// count as 0 on both sides of a face, so the records of the bricks along a ray add up to the
+// ray's; y follows from sum_a S0_a = 0, sum_a S1_a = I).
+template <bool AUX, class Fetch>
+DDRR_HD int step_walk(const Fetch &fetch, const StepGeom &G, const StepEntry &E, float &I,
+                      float rec[4]) {
+    float kr0 = 0.f, kr1 = 0.f, kr2 = 0.f;  // k - k0 per axis
+    float an0 = E.an[0], an1 = E.an[1], an2 = E.an[2];
+    const float inv0 = E.inv[0], inv1 = E.inv[1], inv2 = E.inv[2];
+    const float af0 = E.a0[0], af1 = E.a0[1], af2 = E.a0[2];
+    const float dir0 = E.dirf[0], dir1 = E.dirf[1], dir2 = E.dirf[2];
+    // wave-uniform loop operands: into vector registers once
+    const float sb0 = in_vgpr(G.strideb[0]), sb1 = in_vgpr(G.strideb[1]);
+    const float sb2 = in_vgpr(G.strideb[2]);
+    const float big = in_vgpr(kSelBig), nbig = in_vgpr(-kSelBig);
+    const float exit = E.exit, offc = E.offc;
+    float a_cur = E.entry, acc = 0.f;
+    // Vc: the voxel of the segment being closed (requested one step earlier), Vp: the one before
+    float Vc = fetch(float_bits(fmaf(kr0, sb0, fmaf(kr1, sb1, fmaf(kr2, sb2, offc)))));
+    float Vp = 0.f;
+    // the crossing that opened the segment being closed: its axis (x, y one-hot; z implied)
+    float tpx = E.ent[0], tpy = E.ent[1];
+    float S0x = 0.f, S0y = 0.f, S1x = 0.f, S1y = 0.f;
+    float live = 1.f;
+    float len_p = 0.f;  // (deep pipeline: length of the segment whose voxel is Vp)
+
+// One step: close the segment [a_cur, a_next), move the plane counters of the axes crossed at
+// a_next, request the next voxel.  With the record, the crossing that OPENED the segment
+// (alpha = a_cur, axes tp*, voxels Vp | Vc) is settled here too: its two voxels are both known.
+#define DDRR_STEP()                                                                       \
+    {                                                                                     \
+        const float a_next = fminf(fminf(an0, an1), an2);                                 \
+        const float len = a_next - a_cur;                                                 \
+        live = sat_pos(exit - a_next, big); /* 0: this segment is the ray's last one */   \
+        const float t0 = sel_zero(an0 - a_next, nbig, live);                              \
+        const float t1 = sel_zero(an1 - a_next, nbig, live);                              \
+        const float t2 = sel_zero(an2 - a_next, nbig, live);                              \
+        kr0 = fmaf(t0, dir0, kr0);                                                        \
+        kr1 = fmaf(t1, dir1, kr1);                                                        \
+        kr2 = fmaf(t2, dir2, kr2);                                                        \
+        const float Vn =                                                                  \
+            fetch(float_bits(fmaf(kr0, sb0, fmaf(kr1, sb1, fmaf(kr2, sb2, offc)))));      \
+        an0 = fmaf(kr0, inv0, af0);                                                       \
+        an1 = fmaf(kr1, inv1, af1);                                                       \
+        an2 = fmaf(kr2, inv2, af2);                                                       \
+        if (!AUX && DDRR_STEP_DEEP) {                                                     \
+            acc = fmaf(Vp, len_p, acc); /* segment i-1: its voxel was asked for two steps ago */ \
+            len_p = len;                                                                  \
+        } else {                                                                          \
+            acc = fmaf(Vc, len, acc);                                                     \
+        }                                                                                 \
+        if (AUX) {                                                                        \
+            const float dv = Vp - Vc, dva = dv * a_cur;                                   \
+            S0x = fmaf(dv, tpx, S0x);                                                     \
+            S0y = fmaf(dv, tpy, S0y);                                                     \
+            S1x = fmaf(dva, tpx, S1x);                                                    \
+            S1y = fmaf(dva, tpy, S1y);                                                    \
+            tpx = t0;                                                                     \
+            tpy = fmaf(-t0, t1, t1); /* exclusive: x before y */                          \
+        }                                                                                 \
+        a_cur = a_next;                                                                   \
+        Vp = Vc;                                                                          \
+        Vc = Vn;                                                                          \
+    }
+    // a brick holds < 3 * BRICK + 3 crossings; the wave leaves when no lane is live (a lane
+    // that is done repeats zero-length steps on its last voxel: t* = 0, nothing moves)
+    int it = 0;
+    for (; it < 3 * BRICK + 4; it += 2) {
+        DDRR_STEP()
+        DDRR_STEP()
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (!__builtin_amdgcn_ballot_w64(live != 0.f)) break;
+#else
+        if (live == 0.f) break;
+#endif
+    }
+#undef DDRR_STEP
+    if (!AUX && DDRR_STEP_DEEP) acc = fmaf(Vp, len_p, acc);  // the segment still pending
+    I = acc;
+    if (AUX) {
+        // (after a lane's last live step its counters stand still and tp* = 0: idle steps add
+        // nothing, and the crossing that opened the last segment was settled by that step)
+        // the exit crossing: last voxel | 0 at alpha = exit, on the axis whose face it is
+        const float ex = sel_zero(an0 - exit, nbig, 1.f);
+        const float ey0 = sel_zero(an1 - exit, nbig, 1.f);
+        const float ey = fmaf(-ex, ey0, ey0);
+        const float va = Vc * exit;
+        S0x = fmaf(Vc, ex, S0x);
+        S0y = fmaf(Vc, ey, S0y);
+        S1x = fmaf(va, ex, S1x);
+        S1y = fmaf(va, ey, S1y);
+        rec[0] = S0x;
+        rec[1] = -(S0x + S0y);       // sum_a S0_a = 0
+        rec[2] = S1x;
+        rec[3] = acc - (S1x + S1y);  // sum_a S1_a = I
+    }
+    return it + 2;  // steps the wave took (profiling builds)
+}
+
+// Volume gradient of one ray through one brick: adds w * dalpha_k to the LDS cell of every
+// voxel the ray crosses (d out / d V[k] = L dalpha_k; reference: grid_sampler_3d_backward
+// behind renderers.py:159-164).  `add(bits, value)` is the scatter at byte address `bits`.
+// Same clip, alphas and stepping as the forward walk: <render(V), g> == <V, gradient(g)> holds
+// segment by segment.  Lanes are left at their own pace here (a scatter has nothing in flight
+// to wait for, and an idle lane would still issue LDS atomics).
+template <class Add>
+DDRR_HD bool step_scatter(const Add &add, unsigned base_bits, const StepGeom &G, const float s[3],
+                          const float t[3], float shift, float eps, float w) {
+    const StepEntry E = step_enter(G, s, t, shift, eps, base_bits);
+    if (!E.hit) return false;
+    float kr0 = 0.f, kr1 = 0.f, kr2 = 0.f;
+    float an0 = E.an[0], an1 = E.an[1], an2 = E.an[2];
+    const float sb0 = in_vgpr(G.strideb[0]), sb1 = in_vgpr(G.strideb[1]);
+    const float sb2 = in_vgpr(G.strideb[2]);
+    const float nbig = in_vgpr(-kSelBig), one = in_vgpr(1.f);
+    float a_cur = E.entry;
+    for (int it = 0; it < 3 * BRICK + 4; ++it) {
+        const unsigned addr =
+            float_bits(fmaf(kr0, sb0, fmaf(kr1, sb1, fmaf(kr2, sb2, E.offc))));
+        const float a_next = fminf(fminf(an0, an1), an2);
+        add(addr, w * (a_next - a_cur));
+        if (!(a_next < E.exit)) break;
+        kr0 = fmaf(sel_zero(an0 - a_next, nbig, one), E.dirf[0], kr0);
+        kr1 = fmaf(sel_zero(an1 - a_next, nbig, one), E.dirf[1], kr1);
+        kr2 = fmaf(sel_zero(an2 - a_next, nbig, one), E.dirf[2], kr2);
+        an0 = fmaf(kr0, E.inv[0], E.a0[0]);
+        an1 = fmaf(kr1, E.inv[1], E.a0[1]);
+        an2 = fmaf(kr2, E.inv[2], E.a0[2]);
+        a_cur = a_next;
+    }
+    return true;
+}
+
+// Exact clip + walk.  Returns false if the ray does not cross the brick.
+template <bool AUX, class Fetch>
+DDRR_HD bool step_trace(const Fetch &fetch, unsigned base_bits, const StepGeom &G,
+                        const float s[3], const float t[3], float shift, float eps, float &I,
+                        float rec[4]) {
+    const StepEntry E = step_enter(G, s, t, shift, eps, base_bits);
+    I = 0.f;
+    if (AUX) rec[0] = rec[1] = rec[2] = rec[3] = 0.f;
+    if (!E.hit) return false;
+    step_walk<AUX>(fetch, G, E, I, rec);
+    return true;
+}
+
+}  // namespace ddrr

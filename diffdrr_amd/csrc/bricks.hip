@@ -8,6 +8,7 @@
 #include "siddon_core.h"
 #include "brick_core.h"
 #include "brick_walk.h"
+#include "brick_step.h"
 #include "record_pack.h"
 #include "tri_brick.h"
 #include "trilinear_core.h"
@@ -54,12 +55,53 @@ struct BrickArgs {
     float rec_q;         // > 0: the record is the packed fixed-point form (record_pack.h), scale q
     int pix_bits;        // queue entry = (pose << pix_bits) | pixel
     float t1, t2;        // length-class thresholds on the estimated crossing count
-    int dbg;             // experiment switches (0 in production)
+    int dbg;             // experiment switches (tools builds with -DDDRR_EXPERIMENTS; else 0)
     int *work;           // global brick counter of this launch (zero at launch)
     const float *grad_out;  // *_VOLGRAD: dLoss/dout (B, N)
     float *g_volume;        // *_VOLGRAD: dLoss/dvolume
     int n_points;           // BRICK_TRI_*: samples per ray
     const float *amin, *amax;  // BRICK_TRI_*: device scalars (renderers.py:220-223)
+    unsigned long long *prof;  // DDRR_BRICK_PROFILE builds: per-phase wave-cycle totals
+};
+
+// Phase timing of the brick kernel (tools/ builds with -DDDRR_BRICK_PROFILE only): s_memtime
+// deltas per wave, added up per phase.  Compiled out of the product library.
+#if defined(DDRR_BRICK_PROFILE)
+struct BrickProf {
+    unsigned long long t[16];
+    unsigned long long last;
+    __device__ __forceinline__ void start() {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = 0;
+        last = __builtin_amdgcn_s_memtime();
+    }
+    __device__ __forceinline__ void mark(int i) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        t[i] += now - last;
+        last = now;
+    }
+    __device__ __forceinline__ void count(int i, unsigned long long n) { t[i] += n; }
+};
+#define DDRR_PROF(i) prof.mark(i)
+#define DDRR_PROF_COUNT(i, n) prof.count(i, n)
+#define DDRR_PROF_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+struct BrickProf {};
+#define DDRR_PROF(i)
+#define DDRR_PROF_COUNT(i, n)
+#define DDRR_PROF_WAIT_VMEM()
+#endif
+enum {
+    PROF_STAGE = 0,   // brick id, row table, staging, barrier after it
+    PROF_PULL = 1,    // unit counter, cursor, row read
+    PROF_PHASE_A = 2, // candidate test, classes, queue push
+    PROF_POP = 3,     // batch selection, queue read
+    PROF_LOADS = 4,   // ray loads (issue + wait)
+    PROF_SETUP = 5,   // exact clip, entry cell
+    PROF_WALK = 6,
+    PROF_DELIVER = 7, // atomics
+    PROF_BARRIER = 8, // waiting for the other waves at the end of a brick
+    PROF_N_BATCH = 9, PROF_N_STEPS = 10, PROF_N_UNITS = 11, PROF_N_HITS = 12,
 };
 
 // what a brick launch computes
@@ -108,9 +150,9 @@ struct LdsAbsAdd {
 // Offsets are 32-bit: the host checks 12 * B * N < 2^32.
 template <int MODE>
 __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *brick,
-                                           const BrickGeom &G, unsigned b, unsigned pix,
-                                           float fixq, float *__restrict__ out,
-                                           float *__restrict__ aux) {
+                                           const BrickGeom &G, const StepGeom &SG, unsigned b,
+                                           unsigned pix, float fixq, float *__restrict__ out,
+                                           float *__restrict__ aux, BrickProf &prof) {
     constexpr bool AUX = MODE == BRICK_FWD_AUX;
     const unsigned r = b * (unsigned)(p.det_h * p.det_w) + pix;
     const float *sp = p.source + b * 3u, *tp = p.target + r * 3u;
@@ -119,7 +161,8 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
     const float base = (float)LdsAbsFetch::base_of(brick);
     if (MODE == BRICK_VOLGRAD) {
         const float w = p.grad_out[r] * L;
-        if (w != 0.f) brick_scatter(LdsAbsAdd{fixq}, base, G, s, t, p.shift, p.eps, w);
+        if (w != 0.f)
+            step_scatter(LdsAbsAdd{fixq}, LdsAbsFetch::base_of(brick), SG, s, t, p.shift, p.eps, w);
         return;
     }
     if (MODE == BRICK_TRI_VOLGRAD) {
@@ -153,11 +196,20 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
         }
         return;
     }
-    float I, rec[4];
-    if (!brick_trace<AUX>(LdsAbsFetch{}, base, G, s, t, p.shift, p.eps, I, rec)) return;
+    DDRR_PROF_WAIT_VMEM();
+    DDRR_PROF(PROF_LOADS);
+    const StepEntry E = step_enter(SG, s, t, p.shift, p.eps, LdsAbsFetch::base_of(brick));
+    DDRR_PROF(PROF_SETUP);
+    float I = 0.f, rec[4] = {0.f, 0.f, 0.f, 0.f};
+    int steps = 0;
+    if (E.hit) steps = step_walk<AUX>(LdsAbsFetch{}, SG, E, I, rec);
+    DDRR_PROF(PROF_WALK);
+    DDRR_PROF_COUNT(PROF_N_STEPS, (unsigned long long)__builtin_amdgcn_readfirstlane(steps));
+    (void)steps;
+    if (!E.hit) return;  // phase A's margin let a non-crossing ray through
     // with the record, out = L * (plane I) is formed afterwards (siddon_out_from_record_kernel)
-    if (!AUX && !(p.dbg & 2)) unsafeAtomicAdd(out + r, L * I);
-    if (AUX && !(p.dbg & 1)) {
+    if (!AUX) unsafeAtomicAdd(out + r, L * I);
+    if (AUX) {
         if (p.rec_q > 0.f) {
             // packed record: (S1x : S0x) and (S1z : S0z) as two 64-bit integer atomics
             const float qa = p.rec_q / aux[5u * p.aux_plane + r];
@@ -174,6 +226,7 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
             unsafeAtomicAdd(aux + 4u * p.aux_plane + r, rec[3]);
         }
     }
+    DDRR_PROF(PROF_DELIVER);
 }
 
 __device__ __forceinline__ int lane_rank(unsigned long long mask) {
@@ -226,8 +279,13 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
 
   // Persistent workgroups: bricks are handed out by a global counter, so a CU that drew
   // light bricks (far from the sources: fewer rays cross them) simply takes more of them.
+  BrickProf prof;
+#if defined(DDRR_BRICK_PROFILE)
+  prof.start();
+#endif
   for (;;) {
     __syncthreads();  // every wave is done with the previous brick's LDS
+    DDRR_PROF(PROF_BARRIER);
     if (tid == 0) counter[1] = atomicAdd(p.work, 1);
     __syncthreads();
     const int brick_id = counter[1];
@@ -259,6 +317,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         }
     }
     BrickGeom G = brick_geom(box, p.lay);
+    const StepGeom SG = step_geom(box, p.lay);
     if (TRI) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) G.lof[a] = (float)box.lo[a];
@@ -357,6 +416,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         }
         const int units = __builtin_amdgcn_readlane(incl, kPoseChunk - 1);
         int cur = 0, cur_lo = 0, cur_hi = __builtin_amdgcn_readlane(incl, 0);
+        DDRR_PROF(PROF_STAGE);
         for (;;) {
             int u = 0;
             if (lane == 0) u = atomicAdd(&counter[0], 1);
@@ -370,6 +430,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                     cur_hi = __builtin_amdgcn_readlane(incl, uni(cur));
                 }
                 const BrickRow r = *reinterpret_cast<const BrickRow *>(rows + cur * kRowWords);
+                DDRR_PROF(PROF_PULL);
+                DDRR_PROF_COUNT(PROF_N_UNITS, 1);
                 int local = (u - cur_lo) * 64 + lane;
                 const bool valid = local < uni(r.count);
                 if (GRAD && valid)
@@ -408,6 +470,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                 qn1 = uni(qn1 + (int)__popcll(m1));
                 qn2 = uni(qn2 + (int)__popcll(m2));
                 wave_fence();
+                DDRR_PROF_COUNT(PROF_N_HITS, __popcll(m0) + __popcll(m1) + __popcll(m2));
+                DDRR_PROF(PROF_PHASE_A);
             }
             // walk every full batch of 64 hits of one class; when draining, what is left
             // of all classes together (longest first), 64 at a time
@@ -441,8 +505,11 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                 } else {
                     break;
                 }
+                DDRR_PROF(PROF_POP);
+                DDRR_PROF_COUNT(PROF_N_BATCH, 1);
                 if (lane < n)
-                    brick_item<MODE>(p, brick, G, e >> p.pix_bits, e & pix_mask, fixq, out, aux);
+                    brick_item<MODE>(p, brick, G, SG, e >> p.pix_bits, e & pix_mask, fixq, out,
+                                           aux, prof);
                 wave_fence();
             }
             if (drain) break;
@@ -474,6 +541,11 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         }
     }
   }
+#if defined(DDRR_BRICK_PROFILE)
+  DDRR_PROF(PROF_BARRIER);
+  if (lane == 0 && p.prof)
+      for (int i = 0; i < 16; ++i) atomicAdd(p.prof + i, prof.t[i]);
+#endif
 }
 
 // ------------------------------------------- volume-gradient fixed-point bound
@@ -606,12 +678,23 @@ __global__ __launch_bounds__(kBlock) void trilinear_bwd_record_kernel(
 }
 
 // LDS layout of a brick (floats): rows padded 32 -> 33, planes 32*33 -> 1057, so that
-// x-, y- and z-neighbours all fall in different banks.
+// x-, y- and z-neighbours all fall in different banks; length classes of brick hits
+// (estimated plane crossings inside the brick; for the marcher: samples per brick).
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
 BrickLayout g_brick_layout = {33, 32 * 33 + 1};
-// length classes of brick hits (estimated plane crossings inside the brick)
 float g_brick_t1 = 18.f, g_brick_t2 = 40.f;
-float g_tri_t1 = 10.f, g_tri_t2 = 22.f;  // same for the marcher, in samples per brick
+float g_tri_t1 = 10.f, g_tri_t2 = 22.f;
 int g_brick_dbg = 0;
+#else
+constexpr BrickLayout g_brick_layout = {33, 32 * 33 + 1};
+constexpr float g_brick_t1 = 18.f, g_brick_t2 = 40.f;
+constexpr float g_tri_t1 = 10.f, g_tri_t2 = 22.f;
+constexpr int g_brick_dbg = 0;
+#endif
+
+#if defined(DDRR_BRICK_PROFILE)
+unsigned long long *g_brick_prof = nullptr;  // 16 device counters, see BrickProf
+#endif
 
 int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const float *source,
                   const float *target, const float *img, const float *grad_out, int B, int det_h,
@@ -648,6 +731,10 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     p.n_points = n_points;
     p.amin = amin;
     p.amax = amax;
+    p.prof = nullptr;
+#if defined(DDRR_BRICK_PROFILE)
+    p.prof = g_brick_prof;
+#endif
     if (mode == BRICK_TRI_FWD || mode == BRICK_TRI_VOLGRAD || mode == BRICK_TRI_FWD_AUX) {
         p.t1 = g_tri_t1;
         p.t2 = g_tri_t2;
@@ -728,7 +815,13 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
 
 extern "C" {
 
-// Experiment knob: LDS strides (floats) of a staged brick; sy >= 32, sx >= 32 * sy.
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+// tools/ builds only (tools/build_variant.py): process-wide experiment switches.  The product
+// library does not contain them: its entry points keep no state between calls but the
+// per-device launch resources (include/diffdrr_hip.h).
+//   layout: LDS strides (floats) of a staged brick; sy >= 32, sx >= 32 * sy
+//   debug flags: 8 per-lane length classes also with the record (no groups of 8 pixels),
+//                16 no scatter permutation, 32 float LDS accumulation
 int ddrr_set_brick_layout(int sy, int sx) {
     if (sy < BRICK || sx < BRICK * sy) return -1;
     BrickLayout lay = {sy, sx};
@@ -736,10 +829,6 @@ int ddrr_set_brick_layout(int sy, int sx) {
     g_brick_layout = lay;
     return 0;
 }
-// Experiment switches of the brick kernels (0 in production; results are wrong with 1, 2):
-//   1 skip the record's atomics, 2 skip the image atomic, 8 per-lane length classes also with
-//   the record (no groups of 8 pixels), 16 no scatter permutation, 32 float LDS accumulation.
-// profiles/r01/exp_record_cost.txt holds the decomposition these gave for the record.
 int ddrr_set_brick_debug(int flags) {
     g_brick_dbg = flags;
     return 0;
@@ -749,6 +838,19 @@ int ddrr_set_brick_classes(float t1, float t2) {
     g_brick_t2 = t2;
     return 0;
 }
+#endif
+#if defined(DDRR_BRICK_PROFILE)
+// zero / read the phase counters of the brick launches since the last reset
+int ddrr_brick_profile_reset() {
+    if (!g_brick_prof && hipMalloc(reinterpret_cast<void **>(&g_brick_prof), 16 * 8) != hipSuccess)
+        return -1;
+    return hipMemset(g_brick_prof, 0, 16 * 8) == hipSuccess ? 0 : -1;
+}
+int ddrr_brick_profile_read(unsigned long long *host16) {
+    if (!g_brick_prof) return -1;
+    return hipMemcpy(host16, g_brick_prof, 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
                                const float *target, const float *img, int B, int det_h,

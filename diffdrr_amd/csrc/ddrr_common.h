@@ -101,53 +101,4 @@ DDRR_HD int tile_ray(const TileMap &m, int wave, int lane, int N) {
     return (i < m.det_h && j < m.det_w) ? i * m.det_w + j : -1;
 }
 
-// z-epipolar wave composition for a row-major det_h x det_w detector grid.
-// The rays that stay in one (row-axis, march-axis) row of the volume at equal
-// depth are those in a plane through the source containing the volume's z axis;
-// on the detector such planes are straight lines (through the vanishing point of
-// the z direction).  A wave takes 64 consecutive pixels along one of those
-// lines: the detector is cut into strips of 64 rows (major = 0) or 64 columns
-// (major = 1); within a strip the line of wave c is the pixel column (row) c,
-// sheared by round(sigma * (lane - 31.5)) and wrapped around, which is a
-// bijection of the strip's pixels for any sigma.  sigma is the local slope of
-// the epipolar lines at the strip centre (computed on the host side per pose
-// and strip); it only affects speed, never results.
-struct ShearMap {
-    int det_h, det_w;
-    int waves_per_pose;  // max over both majors, so that every pose uses the same grid
-};
-
-DDRR_HD ShearMap make_shearmap(int det_h, int det_w) {
-    ShearMap m;
-    m.det_h = det_h;
-    m.det_w = det_w;
-    const int a = ((det_h + 63) / 64) * det_w, b = ((det_w + 63) / 64) * det_h;
-    m.waves_per_pose = a > b ? a : b;
-    return m;
-}
-
-DDRR_HD int shear_strips(const ShearMap &m, int major) {
-    return major == 0 ? (m.det_h + 63) / 64 : (m.det_w + 63) / 64;
-}
-
-// (wave within pose, lane) -> ray index, or -1.  `strip` is returned so that the
-// caller can fetch the strip's sigma first: use shear_strip_of() then shear_ray().
-DDRR_HD int shear_strip_of(const ShearMap &m, int major, int wave) {
-    const int lines = major == 0 ? m.det_w : m.det_h;
-    return wave / lines;
-}
-
-DDRR_HD int shear_ray(const ShearMap &m, int major, int wave, int lane, float sigma) {
-    const int lines = major == 0 ? m.det_w : m.det_h;   // pixels across the strip
-    const int along = major == 0 ? m.det_h : m.det_w;   // pixels along the lanes
-    const int strip = wave / lines, c = wave - strip * lines;
-    if (strip >= (along + 63) / 64) return -1;          // padding wave
-    const int p = strip * 64 + lane;                    // position along the line
-    if (p >= along) return -1;
-    int q = c + (int)rintf(sigma * ((float)lane - 31.5f));
-    q %= lines;
-    q += q < 0 ? lines : 0;
-    return major == 0 ? p * m.det_w + q : q * m.det_w + p;
-}
-
 }  // namespace ddrr

@@ -62,12 +62,13 @@ extern "C" {
 int ddrr_abi_version(void) { return DDRR_ABI_VERSION; }
 const char *ddrr_last_error(void) { return ddrr_rt::last_error(); }
 
-// Experiment knob (not part of the renderer contract): 0/1 XCD-contiguous
-// workgroup mapping.
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+// tools/ builds only: 0/1 XCD-contiguous workgroup mapping of the per-ray kernels.
 int ddrr_set_xcd_swizzle(int on) {
     int old = ddrr_rt::g_xcd_swizzle;
     ddrr_rt::g_xcd_swizzle = on ? 1 : 0;
     return old;
 }
+#endif
 
 }  // extern "C"

@@ -22,20 +22,20 @@ template <class First, class Visit>
 DDRR_HD void siddon_all_crossings(const Dims D, const float s[3], const float t[3], float shift,
                                   float eps, First visit_first, Visit visit) {
     const int Dn[3] = {D.x, D.y, D.z};
-    float inv[3], c[3];
+    float inv[3], dd[3];
     int idx[3], step[3], left[3], cell[3];
     float an[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float d = (t[a] - s[a]) + eps;  // renderers.py:104-106
         inv[a] = 1.0f / d;
-        c[a] = (-shift - s[a]) / d;
+        dd[a] = d;
         const bool up = inv[a] >= 0.f;  // planes are crossed in increasing / decreasing index
         idx[a] = up ? 0 : Dn[a];
         step[a] = up ? 1 : -1;
         left[a] = Dn[a] + 1;
         cell[a] = up ? -1 : Dn[a];  // the cell the ray is in before crossing any plane
-        an[a] = fmaf((float)idx[a], inv[a], c[a]);
+        an[a] = div_refined(((float)idx[a] - shift) - s[a], dd[a], inv[a]);  // renderers.py:97-106
     }
     const int M = D.x + D.y + D.z + 3;
     float a_cur = 0.f;
@@ -63,7 +63,7 @@ DDRR_HD void siddon_all_crossings(const Dims D, const float s[3], const float t[
                 cell[a] = step[a] > 0 ? idx[a] : idx[a] - 1;
                 idx[a] += step[a];
                 --left[a];
-                an[a] = fmaf((float)idx[a], inv[a], c[a]);
+                an[a] = div_refined(((float)idx[a] - shift) - s[a], dd[a], inv[a]);
             }
         a_cur = a_next;
     }

@@ -69,24 +69,47 @@ struct GlobalFetch {
     }
 };
 
+// n / d from n, d and r ~ 1/d (<= 1 ulp): one residual correction of the product, i.e. the
+// correctly rounded quotient in all but a vanishing fraction of cases.  Deterministic in (n, d).
+DDRR_HD float div_refined(float n, float d, float r) {
+    const float q0 = n * r;
+    const float q1 = fmaf(fmaf(-q0, d, n), r, q0);
+    return (q1 == q1) ? q1 : q0;  // d = 0 or inf: keep the plain product
+}
+
 struct SiddonSetup {
-    float d[3], inv[3], c[3], lo[3], hi[3];
+    float d[3], inv[3], s[3], lo[3], hi[3];
+    float shift;
     float entry, exit;
     bool hit;
 };
 
-DDRR_HD SiddonSetup siddon_setup(const Box &box, const float s[3], const float t[3], float shift,
-                                 float eps) {
+// alpha of plane k of axis a: the reference's own quotient (k - shift - s_a) / (t_a - s_a + eps)
+// (diffdrr/renderers.py:97-106), numerator and all.  Every Siddon walk evaluates every
+// crossing through this one expression from the integer plane index -- never k * (1/d) + c,
+// which cancels two numbers of size |k/d| for the lateral axes (~10 ulps of alpha at 512^3,
+// and any amount for a ray gliding along a plane) -- so sub-boxes meet exactly and ties fall
+// where the reference's fp32 arithmetic puts them.
+DDRR_HD float plane_alpha(const SiddonSetup &q, int a, float kf) {
+    return div_refined((kf - q.shift) - q.s[a], q.d[a], q.inv[a]);
+}
+
+DDRR_HD float fast_rcp(float x);
+
+template <bool FAST>
+DDRR_HD SiddonSetup siddon_setup_t(const Box &box, const float s[3], const float t[3],
+                                   float shift, float eps) {
     SiddonSetup q;
     q.entry = -INFINITY;
     q.exit = INFINITY;
+    q.shift = shift;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         q.d[a] = (t[a] - s[a]) + eps;  // renderers.py:104-106, :148
-        q.inv[a] = 1.0f / q.d[a];
-        q.c[a] = (-shift - s[a]) / q.d[a];  // a true division: half an ulp, once per ray
-        const float a0 = fmaf((float)box.lo[a], q.inv[a], q.c[a]);
-        const float aD = fmaf((float)box.hi[a], q.inv[a], q.c[a]);
+        q.inv[a] = FAST ? fast_rcp(q.d[a]) : 1.0f / q.d[a];
+        q.s[a] = s[a];
+        const float a0 = plane_alpha(q, a, (float)box.lo[a]);
+        const float aD = plane_alpha(q, a, (float)box.hi[a]);
         q.lo[a] = fminf(a0, aD);
         q.hi[a] = fmaxf(a0, aD);
         q.entry = fmaxf(q.entry, q.lo[a]);
@@ -96,10 +119,13 @@ DDRR_HD SiddonSetup siddon_setup(const Box &box, const float s[3], const float t
     return q;
 }
 
-// Reciprocal for the per-(ray, brick) setup of the volume-stationary kernel, where the
-// setup runs ~25x per ray: v_rcp_f32 + one Newton step (<= 1 ulp) instead of the
-// IEEE division sequence.  Deterministic in its input, so two bricks that share a plane
-// still evaluate that plane's alpha identically.
+DDRR_HD SiddonSetup siddon_setup(const Box &box, const float s[3], const float t[3], float shift,
+                                 float eps) {
+    return siddon_setup_t<false>(box, s, t, shift, eps);
+}
+
+// Reciprocal for per-(ray, brick) setups, which run ~25x per ray: v_rcp_f32 + one Newton step
+// (<= 1 ulp) instead of the IEEE division sequence.  Deterministic in its input.
 DDRR_HD float fast_rcp(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const float r0 = __builtin_amdgcn_rcpf(x);
@@ -112,29 +138,7 @@ DDRR_HD float fast_rcp(float x) {
 
 DDRR_HD SiddonSetup siddon_setup_fast(const Box &box, const float s[3], const float t[3],
                                       float shift, float eps) {
-    SiddonSetup q;
-    q.entry = -INFINITY;
-    q.exit = INFINITY;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        q.d[a] = (t[a] - s[a]) + eps;
-        q.inv[a] = fast_rcp(q.d[a]);
-        // (-shift - s) / d by one residual correction of the product: the offset of a
-        // whole axis' planes against the other two axes' is what the integral is most
-        // sensitive to (dI = S0_a * dalpha), so c is kept at division accuracy
-        const float num = -shift - s[a];
-        const float c0 = num * q.inv[a];
-        const float c1 = fmaf(fmaf(-c0, q.d[a], num), q.inv[a], c0);
-        q.c[a] = (c1 == c1) ? c1 : c0;
-        const float a0 = fmaf((float)box.lo[a], q.inv[a], q.c[a]);
-        const float aD = fmaf((float)box.hi[a], q.inv[a], q.c[a]);
-        q.lo[a] = fminf(a0, aD);
-        q.hi[a] = fmaxf(a0, aD);
-        q.entry = fmaxf(q.entry, q.lo[a]);
-        q.exit = fminf(q.exit, q.hi[a]);
-    }
-    q.hit = q.entry < q.exit;  // false for NaN
-    return q;
+    return siddon_setup_t<true>(box, s, t, shift, eps);
 }
 
 // State of the 3-way merge once the ray is inside the volume.
@@ -168,8 +172,8 @@ DDRR_HD SiddonWalk siddon_enter(const Store &st, const Box &box, const float s[3
             // the wrong side of an already-passed plane would open with a segment of
             // negative length (or skip one).  Move one cell if the plane ahead is already
             // behind `entry`, or the plane behind is still ahead of it.
-            const float a_ahead = fmaf((float)(i + (pos ? 1 : 0)), q.inv[a], q.c[a]);
-            const float a_behind = fmaf((float)(i + (pos ? 0 : 1)), q.inv[a], q.c[a]);
+            const float a_ahead = plane_alpha(q, a, (float)(i + (pos ? 1 : 0)));
+            const float a_behind = plane_alpha(q, a, (float)(i + (pos ? 0 : 1)));
             const int di = pos ? 1 : -1;
             if (a_ahead < q.entry) i += di;
             else if (a_behind > q.entry) i -= di;
@@ -179,7 +183,7 @@ DDRR_HD SiddonWalk siddon_enter(const Store &st, const Box &box, const float s[3
         w.kf[a] = (float)(i + (pos ? 1 : 0));
         w.dirf[a] = pos ? 1.f : -1.f;
         w.dstep[a] = pos ? stride[a] : -stride[a];
-        w.an[a] = fmaf(w.kf[a], q.inv[a], q.c[a]);
+        w.an[a] = plane_alpha(q, a, w.kf[a]);
     }
     return w;
 }
@@ -232,9 +236,9 @@ DDRR_HD SiddonSeg siddon_step(SiddonGen &g, const SiddonSetup &q) {
     w.kf[0] += cx ? w.dirf[0] : 0.f;
     w.kf[1] += cy ? w.dirf[1] : 0.f;
     w.kf[2] += cz ? w.dirf[2] : 0.f;
-    w.an[0] = fmaf(w.kf[0], q.inv[0], q.c[0]);
-    w.an[1] = fmaf(w.kf[1], q.inv[1], q.c[1]);
-    w.an[2] = fmaf(w.kf[2], q.inv[2], q.c[2]);
+    w.an[0] = plane_alpha(q, 0, w.kf[0]);
+    w.an[1] = plane_alpha(q, 1, w.kf[1]);
+    w.an[2] = plane_alpha(q, 2, w.kf[2]);
     const unsigned noff = w.off + (unsigned)((cx ? w.dstep[0] : 0) + (cy ? w.dstep[1] : 0) +
                                              (cz ? w.dstep[2] : 0));
     if (AUX && REDUCE == REDUCE_SUM) {
@@ -450,9 +454,9 @@ DDRR_HD void siddon_scatter_ray(const float *__restrict__ vol, const Dims D, con
         w.kf[0] += cx ? w.dirf[0] : 0.f;
         w.kf[1] += cy ? w.dirf[1] : 0.f;
         w.kf[2] += cz ? w.dirf[2] : 0.f;
-        w.an[0] = fmaf(w.kf[0], q.inv[0], q.c[0]);
-        w.an[1] = fmaf(w.kf[1], q.inv[1], q.c[1]);
-        w.an[2] = fmaf(w.kf[2], q.inv[2], q.c[2]);
+        w.an[0] = plane_alpha(q, 0, w.kf[0]);
+        w.an[1] = plane_alpha(q, 1, w.kf[1]);
+        w.an[2] = plane_alpha(q, 2, w.kf[2]);
         off += (unsigned)((cx ? w.dstep[0] : 0) + (cy ? w.dstep[1] : 0) + (cz ? w.dstep[2] : 0));
         a_cur = a_next;
         if (!(a_next < q.exit)) break;
@@ -492,9 +496,9 @@ DDRR_HD void siddon_channels_ray(const float *__restrict__ vol,
         w.kf[0] += cx ? w.dirf[0] : 0.f;
         w.kf[1] += cy ? w.dirf[1] : 0.f;
         w.kf[2] += cz ? w.dirf[2] : 0.f;
-        w.an[0] = fmaf(w.kf[0], q.inv[0], q.c[0]);
-        w.an[1] = fmaf(w.kf[1], q.inv[1], q.c[1]);
-        w.an[2] = fmaf(w.kf[2], q.inv[2], q.c[2]);
+        w.an[0] = plane_alpha(q, 0, w.kf[0]);
+        w.an[1] = plane_alpha(q, 1, w.kf[1]);
+        w.an[2] = plane_alpha(q, 2, w.kf[2]);
         off += (unsigned)((cx ? w.dstep[0] : 0) + (cy ? w.dstep[1] : 0) + (cz ? w.dstep[2] : 0));
         a_cur = a_next;
         if (!(a_next < q.exit)) break;
@@ -592,12 +596,11 @@ DDRR_HD float siddon_forward_ray_midpoint(const float *__restrict__ vol, const D
     // segment's sample is not confined to the voxel the segment lies in.
     const int Dn[3] = {D.x, D.y, D.z};
     const GridMap g = make_gridmap(D, shift, align_corners);
-    float d[3], inv[3], c[3], kf[3], dirf[3];
+    float d[3], inv[3], kf[3], dirf[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         d[a] = (t[a] - s[a]) + eps;
         inv[a] = 1.0f / d[a];
-        c[a] = (-shift - s[a]) * inv[a];
         const bool pos = d[a] > 0.f;
         kf[a] = pos ? 0.f : (float)Dn[a];  // first plane met along the ray
         dirf[a] = pos ? 1.f : -1.f;
@@ -611,7 +614,7 @@ DDRR_HD float siddon_forward_ray_midpoint(const float *__restrict__ vol, const D
         for (int a = 0; a < 3; ++a) {
             // planes beyond the last one of an axis never come: park them at +inf
             const bool done = kf[a] < 0.f || kf[a] > (float)Dn[a];
-            an[a] = done ? INFINITY : fmaf(kf[a], inv[a], c[a]);
+            an[a] = done ? INFINITY : div_refined((kf[a] - shift) - s[a], d[a], inv[a]);
         }
         const float a_next = min3f(an[0], an[1], an[2]);
         if (!(a_next < INFINITY)) break;
@@ -683,12 +686,11 @@ DDRR_HD float siddon_backward_ray_midpoint(const float *__restrict__ vol, const 
                                            float gt[3], Add add) {
     const int Dn[3] = {D.x, D.y, D.z};
     const GridMap g = make_gridmap(D, shift, align_corners);
-    float d[3], inv[3], c[3], kf[3], dirf[3];
+    float d[3], inv[3], kf[3], dirf[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         d[a] = (t[a] - s[a]) + eps;
         inv[a] = 1.0f / d[a];
-        c[a] = (-shift - s[a]) * inv[a];
         const bool pos = d[a] > 0.f;
         kf[a] = pos ? 0.f : (float)Dn[a];
         dirf[a] = pos ? 1.f : -1.f;
@@ -704,7 +706,7 @@ DDRR_HD float siddon_backward_ray_midpoint(const float *__restrict__ vol, const 
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const bool done = kf[a] < 0.f || kf[a] > (float)Dn[a];
-            an[a] = done ? INFINITY : fmaf(kf[a], inv[a], c[a]);
+            an[a] = done ? INFINITY : div_refined((kf[a] - shift) - s[a], d[a], inv[a]);
         }
         const float a_next = min3f(an[0], an[1], an[2]);
         if (!(a_next < INFINITY)) break;

@@ -1,11 +1,10 @@
 // siddon_rays.hip -- the per-ray Siddon kernels (one detector ray per lane; no LDS, no MFMA:
 // a gather-bound line integral) and their C-ABI entries: the generic walk
-// and its backward passes, the lockstep slab march, mask_to_channels, the materialised
+// and its backward passes, mask_to_channels, the materialised
 // per-segment tensor.  The volume-stationary kernels live in bricks.hip.
 #include "runtime.h"
 #include "siddon_core.h"
 #include "record_pack.h"
-#include "slab_core.h"
 #include "segments_core.h"
 
 using namespace ddrr;
@@ -116,129 +115,6 @@ __global__ __launch_bounds__(kBlock) void siddon_bwd_volume_kernel(
     const float gl = grad_out[id.r] * L;
     if (gl == 0.f) return;
     siddon_scatter_ray<REDUCE>(p.vol, p.D, s, t, p.shift, p.eps, gl, AtomicAdder{g_volume});
-}
-
-// ------------------------------------------------------- Siddon, slab march
-// The fast forward path (slab_core.h).  plan[b] = {march axis (0 x, 1 y, 2 = z:
-// generic walk), major (lanes along detector rows / columns)}; shear[b][strip] =
-// slope of the z-epipolar lines at each 64-pixel strip.  One wave = 64 pixels
-// along such a line; lanes advance one m-slab per iteration in lockstep.
-
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int other = __shfl_xor(v, o, 64);
-        v = other < v ? other : v;
-    }
-    return v;
-}
-
-__device__ __forceinline__ float2 load_pair(const float *__restrict__ vol, unsigned boff) {
-    // 4-byte aligned 8-byte fetch (global_load_dwordx2; gfx950 has unaligned access)
-    float2 r;
-    __builtin_memcpy(&r, reinterpret_cast<const char *>(vol) + boff, 8);
-    return r;
-}
-
-struct SlabArgs {
-    const float *vol;
-    Dims D;
-    const float *source;  // (B, 1, 3)
-    const float *target;
-    const float *img;
-    int B, N;
-    float shift, eps;
-    ShearMap sm;
-    const int *plan;     // (B, 2)
-    const float *shear;  // (B, max_strips)
-    int max_strips;
-    int total_waves;
-    int xcd_swizzle;
-    Box box;         // sub-box of the volume this pass covers
-    int accumulate;  // add to out / aux (later passes) instead of overwriting
-};
-
-template <bool AUX>
-__global__ __launch_bounds__(kBlock) void siddon_fwd_slab_kernel(SlabArgs p,
-                                                                 float *__restrict__ out,
-                                                                 float *__restrict__ aux) {
-    const int wave = logical_block(p.xcd_swizzle) * kWavesPerBlock + (threadIdx.x >> 6);
-    if (wave >= p.total_waves) return;
-    const int lane = threadIdx.x & 63;
-    const int b = wave / p.sm.waves_per_pose;
-    const int w = wave - b * p.sm.waves_per_pose;
-    const int march = p.plan[2 * b], major = p.plan[2 * b + 1];
-    const int strip = shear_strip_of(p.sm, major, w);
-    if (strip >= shear_strips(p.sm, major)) return;  // padding wave of this pose's major
-    const float sigma = p.shear[b * p.max_strips + strip];
-    const int n = shear_ray(p.sm, major, w, lane, sigma);
-    const long r = (long)b * p.N + (n < 0 ? 0 : n);
-
-    float s[3], t[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        s[a] = p.source[b * 3 + a];
-        t[a] = p.target[r * 3 + a];
-    }
-    float rec[SIDDON_AUX];
-    float I = 0.f;
-    if (march > 1) {  // z-dominant pose: generic per-crossing walk
-        if (n >= 0) I = siddon_forward_ray<REDUCE_SUM, AUX, false>(p.vol, p.D, p.box, s, t, p.shift,
-                                                                   p.eps, rec, nullptr);
-    } else {
-        const SlabAxes ax = make_slab_axes(p.D, march);
-        SlabLane L = slab_lane_init(p.D, p.box, ax, s, t, p.shift, p.eps);
-        if (n < 0) {
-            L.hit = false;
-            L.fast = false;
-            L.done = true;
-        }
-        // one march direction per wave (majority); the others take the generic walk
-        const unsigned long long fast0 = __ballot(L.fast);
-        const unsigned long long pos = __ballot(L.fast && L.dirf_m > 0.f);
-        const int dirw = 2 * __popcll(pos) >= __popcll(fast0) ? 1 : -1;
-        L.fast = L.fast && ((L.dirf_m > 0.f) == (dirw > 0));
-        // lanes start when the wave's common slab index reaches their entry slab
-        const int key = L.fast ? L.im_in * dirw : 0x7fffffff;
-        const int t_start = key - wave_min_i32(key);
-        const int cap = ax.Dm + 2;
-        for (int it = 0; it < cap; ++it) {
-            const bool active = L.fast && !L.done && it >= t_start;
-            const SlabGeo g = slab_geometry(L, ax, active);
-            const float2 pa = load_pair(p.vol, g.offA);
-            float2 pb = make_float2(0.f, 0.f);
-            if (__ballot(g.cx)) pb = load_pair(p.vol, g.offB);
-            slab_consume<AUX>(L, g, pa.x, pa.y, pb.x, pb.y);
-            if (!__ballot(L.fast && !L.done)) break;
-        }
-        if (L.fast) {
-            I = L.acc;
-            if (AUX) slab_aux_record(L, ax, rec);
-        } else if (L.hit) {
-            I = siddon_forward_ray<REDUCE_SUM, AUX, false>(p.vol, p.D, p.box, s, t, p.shift, p.eps,
-                                                           rec, nullptr);
-        } else if (AUX) {
-#pragma unroll
-            for (int k = 0; k < SIDDON_AUX; ++k) rec[k] = 0.f;
-        }
-    }
-    if (n < 0) return;
-    const float Lm = p.img ? p.img[r] : 1.f;
-    // passes over disjoint sub-boxes run one after the other on the stream; the
-    // lane owns its ray's outputs, so a plain read-modify-write accumulates them
-    out[r] = (p.accumulate ? out[r] : 0.f) + Lm * I;
-    if (AUX) {
-        float4 *a4 = reinterpret_cast<float4 *>(aux + r * SIDDON_AUX);
-        float4 lo = make_float4(rec[0], rec[1], rec[2], rec[3]);
-        float4 hi = make_float4(rec[4], rec[5], rec[6], rec[7]);
-        if (p.accumulate) {
-            const float4 plo = a4[0], phi = a4[1];
-            lo = make_float4(lo.x + plo.x, lo.y + plo.y, lo.z + plo.z, lo.w + plo.w);
-            hi = make_float4(hi.x + phi.x, hi.y + phi.y, hi.z + phi.z, hi.w + phi.w);
-        }
-        a4[0] = lo;
-        a4[1] = hi;
-    }
 }
 
 // mask_to_channels (renderers.py:77-89): the ray owns column out[b, :, n]; runs
@@ -371,20 +247,9 @@ __global__ __launch_bounds__(kBlock) void siddon_bwd_mid_kernel(
     if (g_img) g_img[id.r] = g * I;
 }
 
-// The slab kernel is fastest with the natural round-robin placement: all XCDs then
-// sweep the same poses at the same time, which the shared Infinity Cache likes
-// (profiles/r01/sweep_v2_slab_512.txt: 4.8 ms vs 6.8 ms on the bench workload).
-int g_xcd_swizzle_slab = 0;
-
 }  // namespace
 
 extern "C" {
-
-int ddrr_set_xcd_swizzle_slab(int on) {
-    int old = g_xcd_swizzle_slab;
-    g_xcd_swizzle_slab = on ? 1 : 0;
-    return old;
-}
 
 int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float *source,
                         int src_n, const float *target, const float *img, int B, int N,
@@ -432,54 +297,6 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
         return fail(-1, "unknown lookup_mode");
     }
     return finish("ddrr_siddon_forward");
-}
-
-int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const float *source,
-                             const float *target, const float *img, int B, int det_h, int det_w,
-                             float voxel_shift, float eps, const int *plan, const float *shear,
-                             int max_strips, const int *box, int accumulate, float *out,
-                             float *aux, void *stream) {
-    const int N = det_h * det_w;
-    if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
-    if (!out || !plan || !shear) return fail(-1, "null out / plan / shear pointer");
-    if (det_h < 1 || det_w < 1) return fail(-1, "detector must be at least 1x1");
-    if (B == 0) return 0;
-    SlabArgs p;
-    p.vol = volume;
-    p.D = Dims{dx, dy, dz};
-    p.source = source;
-    p.target = target;
-    p.img = img;
-    p.B = B;
-    p.N = N;
-    p.shift = voxel_shift;
-    p.eps = eps;
-    p.sm = make_shearmap(det_h, det_w);
-    p.plan = plan;
-    p.shear = shear;
-    p.max_strips = max_strips;
-    const int need = (det_h > det_w ? det_h : det_w);
-    if (max_strips < (need + 63) / 64) return fail(-1, "shear table has too few strips");
-    p.total_waves = B * p.sm.waves_per_pose;
-    p.xcd_swizzle = g_xcd_swizzle_slab;
-    p.box = full_box(p.D);
-    if (box) {
-        const int Dn[3] = {dx, dy, dz};
-        for (int a = 0; a < 3; ++a) {
-            p.box.lo[a] = box[a];
-            p.box.hi[a] = box[3 + a];
-            if (box[a] < 0 || box[3 + a] > Dn[a] || box[a] >= box[3 + a])
-                return fail(-1, "box must satisfy 0 <= lo < hi <= dims");
-        }
-    }
-    p.accumulate = accumulate;
-    hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((p.total_waves + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
-    if (aux)
-        hipLaunchKernelGGL((siddon_fwd_slab_kernel<true>), grid, block, 0, st, p, out, aux);
-    else
-        hipLaunchKernelGGL((siddon_fwd_slab_kernel<false>), grid, block, 0, st, p, out, aux);
-    return finish("ddrr_siddon_forward_slab");
 }
 
 int ddrr_siddon_backward_rays(const float *aux, int aux_layout, const float *grad_out,

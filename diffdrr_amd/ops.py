@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -24,8 +25,9 @@ def reduce_code(reducefn) -> int:
         return _REDUCE[reducefn]
     if callable(reducefn):
         raise NotImplementedError(
-            "a callable reducefn needs the materialised per-segment tensor: only Siddon(mode="
-            "'nearest') without a mask provides it (ops.siddon_segments)")
+            "the fused kernels reduce with 'sum' or 'max'; a callable reducefn is served by the "
+            "renderer modules through the materialised per-segment / per-sample tensors "
+            "(ops.siddon_segments, ops.trilinear_samples)")
     raise ValueError(f"Only supports reducefn 'sum' or 'max', not {reducefn}")
 
 
@@ -122,65 +124,21 @@ def siddon_forward(volume, source, target, img, *, voxel_shift=0.5, eps=1e-8, re
     return out, aux, nvox
 
 
-MALL_PASS_BYTES = 128 << 20  # half the 256 MiB Infinity Cache per pass
-
-
-def volume_passes(shape, pass_bytes=None):
-    """Boxes (host int[6] lists) that partition a volume into Infinity-Cache-sized
-    slabs along x or y (never z: rows along z stay whole)."""
-    pass_bytes = MALL_PASS_BYTES if pass_bytes is None else pass_bytes
-    Dx, Dy, Dz = (int(v) for v in shape)
-    n = max(1, -(-(Dx * Dy * Dz * 4) // pass_bytes))
-    axis = 1 if Dy >= Dx else 0
-    n = min(n, (Dx, Dy)[axis])
-    edges = [round(k * (Dx, Dy)[axis] / n) for k in range(n + 1)]
-    boxes = []
-    for k in range(n):
-        lo, hi = [0, 0, 0], [Dx, Dy, Dz]
-        lo[axis], hi[axis] = edges[k], edges[k + 1]
-        boxes.append(lo + hi)
-    return boxes
-
-
-def siddon_forward_slab(volume, source, target, img, det, plan, shear, *, voxel_shift=0.5,
-                        eps=1e-8, want_aux=False, boxes=None):
-    """Detector-grid Siddon (sum) through the lockstep slab-march kernel.
-    plan (B,2) int32 / shear (B,S) fp32 from diffdrr_amd.plan.slab_plan.
-    -> (out (B,N), aux (B,N,8) | None)"""
-    B, N = _check_rays(volume, source, target, img)
-    H, W = int(det[0]), int(det[1])
-    if H * W != N or source.shape[1] != 1:
-        raise ValueError("the slab path needs one source per pose and an H*W ray grid")
-    volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
-    img = None if img is None else img.contiguous()
-    out = torch.empty(B, N, dtype=torch.float32, device=volume.device)
-    aux = torch.empty(B, N, SIDDON_AUX, dtype=torch.float32, device=volume.device) \
-        if want_aux else None
-    if _empty(B, N):
-        return out, aux
-    boxes = volume_passes(volume.shape) if boxes is None else boxes
-    for k, box in enumerate(boxes):
-        cbox = (ctypes.c_int * 6)(*box)
-        _launch(
-            "ddrr_siddon_forward_slab", volume.device, volume.data_ptr(), *volume.shape,
-            source.data_ptr(), target.data_ptr(), _ptr(img), B, H, W, float(voxel_shift),
-            float(eps), plan.data_ptr(), shear.data_ptr(), int(shear.shape[1]),
-            ctypes.addressof(cbox), int(k > 0), out.data_ptr(), _ptr(aux))
-    return out, aux
-
-
-_vmax_cache = {}
+_vmax_cache = {}  # id(volume) -> (weakref to the volume, its version, max |volume|)
 
 
 def volume_absmax(volume) -> float:
-    """max |volume| as a host float, cached per (storage, version): the scale of the packed
-    backward record.  One reduction and one host sync when the volume (buffer) changes."""
-    key = (volume.data_ptr(), volume._version, tuple(volume.shape), str(volume.device))
-    hit = _vmax_cache.get("key") == key
-    if not hit:
-        _vmax_cache["key"] = key
-        _vmax_cache["value"] = float(volume.detach().abs().max().item())
-    return _vmax_cache["value"]
+    """max |volume| as a host float, cached per volume TENSOR (weak reference + version, so a
+    different volume at a recycled address is never confused with it): the scale of the
+    packed backward record.  One reduction and one host sync when the volume changes."""
+    ent = _vmax_cache.get(id(volume))
+    if ent is not None and ent[0]() is volume and ent[1] == volume._version:
+        return ent[2]
+    value = float(volume.detach().abs().max().item())
+    key = id(volume)
+    _vmax_cache[key] = (weakref.ref(volume, lambda _, k=key: _vmax_cache.pop(k, None)),
+                        volume._version, value)
+    return value
 
 
 def _aux_layout(aux, B, N):
@@ -223,7 +181,7 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
 
 def siddon_backward_rays(aux, grad_out, source, target, img, *, eps=1e-8, reducefn="sum",
                          want_img_grad=True):
-    """aux: (B,N,8) interleaved record (generic / slab forward) or (5,B,N) planar record
+    """aux: (B,N,8) interleaved record (generic forward) or (5,B,N) planar record
     (brick forward).  -> (g_source (B,N,3) per ray, g_target (B,N,3), g_img (B,N) | None)"""
     B, N, _ = target.shape
     layout = _aux_layout(aux, B, N)
@@ -491,6 +449,8 @@ def trilinear_forward(volume, source, target, img, alphamin, alphamax, *, n_poin
     dh, dw, th, tw = _hints(det, tile, N)
     if _empty(B, N):
         return out
+    volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
     _launch(
         "ddrr_trilinear_forward", volume.device, volume.data_ptr(), *volume.shape, source.data_ptr(),
         source.shape[1], target.data_ptr(), _ptr(img), B, N, float(voxel_shift), float(eps),
@@ -695,6 +655,8 @@ def trilinear_backward(volume, source, target, img, grad_out, alphamin, alphamax
     if _empty(B, N):
         return res
     grad_out = grad_out.contiguous()
+    volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
     if reduce_code(reducefn) == REDUCE_MAX:
         _launch(
             "ddrr_trilinear_backward_max", dev, volume.data_ptr(), *volume.shape,

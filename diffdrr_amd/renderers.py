@@ -15,24 +15,31 @@ forward passes are supported).
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import ops
-from .plan import slab_plan
+
+
+_label_cache = {}  # id(mask) -> (weakref to the mask, its version, uint8 labels, C)
 
 
 def _labels_u8(mask: torch.Tensor):
     """Label map as uint8 + channel count (reference: ``C = int(mask.max()) + 1``,
-    renderers.py:81 -- a host sync per call there; cached per mask tensor here)."""
-    key = (mask.data_ptr(), mask._version, tuple(mask.shape))
-    cached = getattr(_labels_u8, "_cache", None)
-    if cached is not None and cached[0] == key:
-        return cached[1], cached[2]
+    renderers.py:81 -- a host sync per call there; cached per mask TENSOR here: the entry is
+    tied to the live object by a weak reference and dropped with it, so that a new mask that
+    happens to land at a freed mask's address can never be served the old labels)."""
+    ent = _label_cache.get(id(mask))
+    if ent is not None and ent[0]() is mask and ent[1] == mask._version:
+        return ent[2], ent[3]
     C = int(mask.max().item()) + 1
     if C > 256:
         raise NotImplementedError("mask_to_channels supports at most 256 labels")
     lab = mask.to(torch.uint8).contiguous()
-    _labels_u8._cache = (key, lab, C)
+    key = id(mask)
+    _label_cache[key] = (weakref.ref(mask, lambda _, k=key: _label_cache.pop(k, None)),
+                         mask._version, lab, C)
     return lab, C
 
 
@@ -80,12 +87,6 @@ class _SiddonFn(torch.autograd.Function):
             out, aux = ops.siddon_forward_bricks(
                 volume, source, target, img, cfg["det"], voxel_shift=cfg["voxel_shift"],
                 eps=cfg["eps"], want_aux=want_aux, record_vmax=_record_vmax(volume, want_aux, cfg))
-        elif grid and cfg["path"] == "slab":
-            # detector-grid fast path: lockstep slab march, z-epipolar wave composition
-            plan, shear = slab_plan(source, target, *cfg["det"])
-            out, aux = ops.siddon_forward_slab(
-                volume, source, target, img, cfg["det"], plan, shear,
-                voxel_shift=cfg["voxel_shift"], eps=cfg["eps"], want_aux=want_aux)
         else:
             out, aux, _ = ops.siddon_forward(
                 volume, source, target, img, voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
@@ -219,11 +220,6 @@ class _SiddonPoseFn(torch.autograd.Function):
             out, aux = ops.siddon_forward_bricks(
                 volume, source, target, img, cfg["det"], voxel_shift=cfg["voxel_shift"],
                 eps=cfg["eps"], want_aux=want_aux, record_vmax=_record_vmax(volume, want_aux, cfg))
-        elif cfg["path"] == "slab":
-            plan, shear = slab_plan(source, target, *cfg["det"])
-            out, aux = ops.siddon_forward_slab(
-                volume, source, target, img, cfg["det"], plan, shear,
-                voxel_shift=cfg["voxel_shift"], eps=cfg["eps"], want_aux=want_aux)
         else:
             out, aux, _ = ops.siddon_forward(
                 volume, source, target, img, voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
@@ -277,8 +273,8 @@ class Siddon(torch.nn.Module):
         # performance hints set by DRR (detector grid of the rays; wave tile shape)
         self.detector_shape = None
         self.tile = None
-        # which kernel renders a detector-grid call (same results up to summation order):
-        # "bricks" (volume-stationary, brick_core.h), "slab" (slab_core.h) or "generic"
+        # which kernel renders a detector-grid call (same results to ~1e-6):
+        # "bricks" (volume-stationary, brick_core.h / brick_step.h) or "generic" (per-ray walk)
         self.grid_path = "bricks"
         # Opt-in: the brick kernel's backward record in 32-bit fixed point (csrc/record_pack.h):
         # 3 atomics per ray and brick instead of 5 (forward + record 7 % faster) and exact,

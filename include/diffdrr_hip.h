@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 15
+#define DDRR_ABI_VERSION 16
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -56,7 +56,7 @@ extern "C" {
 #define DDRR_SIDDON_AUX 8 /* floats per ray in the forward record used by the backward */
 
 /* layouts of the forward record handed to ddrr_siddon_backward_rays */
-#define DDRR_AUX_INTERLEAVED 0 /* (B, N, 8): ddrr_siddon_forward, ddrr_siddon_forward_slab */
+#define DDRR_AUX_INTERLEAVED 0 /* (B, N, 8): ddrr_siddon_forward */
 #define DDRR_AUX_PLANAR 1      /* (5, B, N) planes I, S0x, S0z, S1x, S1z: ddrr_siddon_forward_bricks */
 #define DDRR_BRICK_AUX_PLANES 5
 #define DDRR_AUX_PACKED 2      /* (7, B, N): fixed-point record, csrc/record_pack.h: ddrr_siddon_forward_bricks(record_vmax > 0) */
@@ -76,27 +76,9 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
                         int align_corners, int det_h, int det_w, int tile_h, int tile_w,
                         float *out, float *aux, int *n_vox, void *stream);
 
-/* The fast form of ddrr_siddon_forward for the DRR case (sum, nearest,
- * align_corners=False, one source per pose, the N = det_h * det_w rays of a pose
- * being a row-major detector grid, detector.py:126): lockstep slab march with
- * z-epipolar wave composition.  plan (B, 2) int32: {march axis 0|1, or 2 = use the
- * generic walk; major 0|1}; shear (B, max_strips) fp32: slope of the epipolar lines
- * per 64-pixel strip (diffdrr_amd/plan.py computes both on the device).  plan and
- * shear only steer scheduling: the result equals ddrr_siddon_forward's up to fp32
- * summation order.  aux as in ddrr_siddon_forward.
- * box: NULL, or HOST int[6] {lo_x, lo_y, lo_z, hi_x, hi_y, hi_z}: render only the part of
- * every ray inside voxels lo..hi-1; with accumulate != 0 the result is ADDED to out / aux.
- * Rendering a partition of the volume box by box (first call accumulate = 0) gives the
- * full render: used to keep each pass's footprint inside the 256 MiB Infinity Cache. */
-int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const float *source,
-                             const float *target, const float *img, int B, int det_h, int det_w,
-                             float voxel_shift, float eps, const int *plan, const float *shear,
-                             int max_strips, const int *box, int accumulate, float *out,
-                             float *aux, void *stream);
-
-/* Volume-stationary form of ddrr_siddon_forward (same DRR case as
- * ddrr_siddon_forward_slab: sum, nearest, one source per pose, row-major det_h x det_w
- * target grid that is an affine image of the pixel lattice, detector.py:126-153): one
+/* Volume-stationary form of ddrr_siddon_forward for the DRR case (sum, nearest,
+ * align_corners=False, one source per pose, the N = det_h * det_w rays of a pose being a
+ * row-major target grid that is an affine image of the pixel lattice, detector.py:126-153): one
  * workgroup per 32^3 brick staged in LDS traces every ray of every pose through it and
  * adds the partial integrals to `out` (zero-filled by the call) with fp32 atomics.  The
  * volume is read from HBM once per call, whatever B.  The image equals

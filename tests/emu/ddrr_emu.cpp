@@ -18,11 +18,11 @@
 #include "../../diffdrr_amd/csrc/siddon_core.h"
 #include "../../diffdrr_amd/csrc/brick_core.h"
 #include "../../diffdrr_amd/csrc/brick_walk.h"
+#include "../../diffdrr_amd/csrc/brick_step.h"
 #include "../../diffdrr_amd/csrc/raygen_core.h"
 #include "../../diffdrr_amd/csrc/record_pack.h"
 #include "../../diffdrr_amd/csrc/segments_core.h"
 #include "../../diffdrr_amd/csrc/tri_brick.h"
-#include "../../diffdrr_amd/csrc/slab_core.h"
 #include "../../diffdrr_amd/csrc/trilinear_core.h"
 #include "../../include/diffdrr_hip.h"
 
@@ -60,10 +60,6 @@ void for_each_ray(const float *source, int src_n, const float *target, const flo
     for (size_t i = 0; i < seen.size(); ++i)
         if (seen[i] != 1) abort();  // the tile map must be a bijection
 }
-
-// Scheduling statistics of the emulated slab kernel (development aid): distinct
-// 128-byte lines a wave touches per iteration vs. voxels it actually needs.
-double g_stat_lines = 0, g_stat_voxels = 0, g_stat_iters = 0, g_stat_slow = 0;
 
 struct HostAdd {
     float *base;
@@ -257,13 +253,6 @@ static void planar_record(const float *aux, int aux_layout, long R, long r, floa
 extern "C" {
 
 int ddrr_abi_version(void) { return DDRR_ABI_VERSION; }
-void emu_stats(double *o, int reset) {
-    o[0] = g_stat_lines;
-    o[1] = g_stat_voxels;
-    o[2] = g_stat_iters;
-    o[3] = g_stat_slow;
-    if (reset) g_stat_lines = g_stat_voxels = g_stat_iters = g_stat_slow = 0;
-}
 const char *ddrr_last_error(void) { return ""; }
 
 int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float *source,
@@ -312,141 +301,6 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
     return 0;
 }
 
-// Wave-level emulation of siddon_fwd_slab_kernel: 64 lane states advanced in
-// lockstep, ballots / reductions done with plain loops.
-int ddrr_siddon_forward_slab(const float *volume, int dx, int dy, int dz, const float *source,
-                             const float *target, const float *img, int B, int det_h, int det_w,
-                             float voxel_shift, float eps, const int *plan, const float *shear,
-                             int max_strips, const int *boxp, int accumulate, float *out,
-                             float *aux, void *) {
-    const Dims D{dx, dy, dz};
-    Box box = full_box(D);
-    if (boxp)
-        for (int a = 0; a < 3; ++a) {
-            box.lo[a] = boxp[a];
-            box.hi[a] = boxp[3 + a];
-        }
-    const int N = det_h * det_w;
-    const ShearMap sm = make_shearmap(det_h, det_w);
-    std::vector<char> seen((size_t)B * N, 0);
-    for (int b = 0; b < B; ++b)
-        for (int w = 0; w < sm.waves_per_pose; ++w) {
-            const int march = plan[2 * b], major = plan[2 * b + 1];
-            const int strip = shear_strip_of(sm, major, w);
-            if (strip >= shear_strips(sm, major)) continue;
-            const float sigma = shear[b * max_strips + strip];
-            int n[64];
-            float s[64][3], t[64][3];
-            for (int l = 0; l < 64; ++l) {
-                n[l] = shear_ray(sm, major, w, l, sigma);
-                const long r = (long)b * N + (n[l] < 0 ? 0 : n[l]);
-                if (n[l] >= 0) seen[r]++;
-                for (int a = 0; a < 3; ++a) {
-                    s[l][a] = source[b * 3 + a];
-                    t[l][a] = target[r * 3 + a];
-                }
-            }
-            float I[64], rec[64][SIDDON_AUX];
-            memset(rec, 0, sizeof(rec));
-            if (march > 1) {
-                for (int l = 0; l < 64; ++l)
-                    I[l] = n[l] < 0 ? 0.f
-                           : aux  ? siddon_forward_ray<REDUCE_SUM, true, false>(
-                                        volume, D, box, s[l], t[l], voxel_shift, eps, rec[l], nullptr)
-                                  : siddon_forward_ray<REDUCE_SUM, false, false>(
-                                        volume, D, box, s[l], t[l], voxel_shift, eps, rec[l], nullptr);
-            } else {
-                const SlabAxes ax = make_slab_axes(D, march);
-                SlabLane L[64];
-                int nfast = 0, npos = 0;
-                for (int l = 0; l < 64; ++l) {
-                    L[l] = slab_lane_init(D, box, ax, s[l], t[l], voxel_shift, eps);
-                    if (n[l] < 0) {
-                        L[l].hit = false;
-                        L[l].fast = false;
-                        L[l].done = true;
-                    }
-                    nfast += L[l].fast;
-                    npos += L[l].fast && L[l].dirf_m > 0.f;
-                }
-                const int dirw = 2 * npos >= nfast ? 1 : -1;
-                int kmin = 0x7fffffff, key[64];
-                for (int l = 0; l < 64; ++l) {
-                    L[l].fast = L[l].fast && ((L[l].dirf_m > 0.f) == (dirw > 0));
-                    key[l] = L[l].fast ? L[l].im_in * dirw : 0x7fffffff;
-                    kmin = key[l] < kmin ? key[l] : kmin;
-                }
-                const int cap = ax.Dm + 2;
-                for (int it = 0; it < cap; ++it) {
-                    SlabGeo g[64];
-                    bool anycx = false, anylive = false;
-                    for (int l = 0; l < 64; ++l) {
-                        const bool active = L[l].fast && !L[l].done && it >= key[l] - kmin;
-                        g[l] = slab_geometry(L[l], ax, active);
-                        anycx = anycx || g[l].cx;
-                    }
-                    {   // statistics: distinct 128 B lines among the lanes that need data
-                        unsigned lines[256];
-                        int nl = 0;
-                        bool any = false;
-                        for (int l = 0; l < 64; ++l) {
-                            const bool need = g[l].l0 != 0.f || g[l].l1 != 0.f || g[l].l2 != 0.f;
-                            if (!need) continue;
-                            any = true;
-                            g_stat_voxels += (g[l].l0 > 0.f) + (g[l].l1 > 0.f) + (g[l].l2 > 0.f);
-                            unsigned cand[4] = {g[l].offA >> 7, (g[l].offA + 7) >> 7,
-                                                g[l].offB >> 7, (g[l].offB + 7) >> 7};
-                            for (int c = 0; c < (g[l].cx ? 4 : 2); ++c) {
-                                bool dup = false;
-                                for (int k = 0; k < nl; ++k) dup = dup || lines[k] == cand[c];
-                                if (!dup) lines[nl++] = cand[c];
-                            }
-                        }
-                        g_stat_lines += nl;
-                        g_stat_iters += any;
-                    }
-                    for (int l = 0; l < 64; ++l) {
-                        const float *pa = (const float *)((const char *)volume + g[l].offA);
-                        const float *pb = (const float *)((const char *)volume + g[l].offB);
-                        const float b0 = anycx ? pb[0] : 0.f, b1 = anycx ? pb[1] : 0.f;
-                        if (aux)
-                            slab_consume<true>(L[l], g[l], pa[0], pa[1], b0, b1);
-                        else
-                            slab_consume<false>(L[l], g[l], pa[0], pa[1], b0, b1);
-                        anylive = anylive || (L[l].fast && !L[l].done);
-                    }
-                    if (!anylive) break;
-                }
-                for (int l = 0; l < 64; ++l) {
-                    if (L[l].fast) {
-                        I[l] = L[l].acc;
-                        if (aux) slab_aux_record(L[l], ax, rec[l]);
-                    } else if (L[l].hit) {
-                        g_stat_slow += 1;
-                        I[l] = aux ? siddon_forward_ray<REDUCE_SUM, true, false>(
-                                         volume, D, box, s[l], t[l], voxel_shift, eps, rec[l], nullptr)
-                                   : siddon_forward_ray<REDUCE_SUM, false, false>(
-                                         volume, D, box, s[l], t[l], voxel_shift, eps, rec[l], nullptr);
-                    } else {
-                        I[l] = 0.f;
-                    }
-                }
-            }
-            for (int l = 0; l < 64; ++l) {
-                if (n[l] < 0) continue;
-                const long r = (long)b * N + n[l];
-                out[r] = (accumulate ? out[r] : 0.f) + (img ? img[r] : 1.f) * I[l];
-                if (aux)
-                    for (int k = 0; k < SIDDON_AUX; ++k)
-                        aux[r * SIDDON_AUX + k] =
-                            (accumulate ? aux[r * SIDDON_AUX + k] : 0.f) + rec[l][k];
-            }
-        }
-    for (size_t i = 0; i < seen.size(); ++i)
-        if (seen[i] != 1) abort();  // the shear map must be a bijection
-    return 0;
-}
-
 // Host emulation of siddon_fwd_brick_kernel: same per-pose table (affine detector model,
 // projected pixel box), same arithmetic phase-A test, hits compacted into three
 // length-class queues and walked in batches of 64 like a wave does, same exact clip and
@@ -477,7 +331,7 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     std::vector<std::pair<int, int>> queues[3];
     for (int id = 0; id < bg.nx * bg.ny * bg.nz; ++id) {
         const Box box = brick_box(D, bg, id);
-        const BrickGeom G = brick_geom(box, lay);
+        const StepGeom SG = step_geom(box, lay);
         std::fill(brick.begin(), brick.end(), 0.f);
         for (int x = box.lo[0]; x < box.hi[0]; ++x)
             for (int y = box.lo[1]; y < box.hi[1]; ++y)
@@ -492,10 +346,10 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                 t[a] = target[r * 3 + a];
             }
             float I, rec[4];
-            const bool hit = aux ? brick_trace<true>(LdsFetch{brick.data()}, 0.f, G, s, t, voxel_shift,
-                                                     eps, I, rec)
-                                 : brick_trace<false>(LdsFetch{brick.data()}, 0.f, G, s, t,
-                                                      voxel_shift, eps, I, rec);
+            const bool hit = aux ? step_trace<true>(LdsFetch{brick.data()}, 0u, SG, s, t, voxel_shift,
+                                                    eps, I, rec)
+                                 : step_trace<false>(LdsFetch{brick.data()}, 0u, SG, s, t,
+                                                     voxel_shift, eps, I, rec);
             if (!hit) return;  // phase A's margin let a non-crossing ray through
             out[r] += (img ? img[r] : 1.f) * I;
             if (packed) {
@@ -541,7 +395,7 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                     t[a] = target[r * 3 + a];
                 }
                 float I, rec[4];
-                if (brick_trace<false>(LdsFetch{brick.data()}, 0.f, G, s, t, voxel_shift, eps, I, rec) &&
+                if (step_trace<false>(LdsFetch{brick.data()}, 0u, SG, s, t, voxel_shift, eps, I, rec) &&
                     I != 0.f)
                     abort();
             }
@@ -588,7 +442,8 @@ int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *sour
                 }
                 const float w = grad_out[r] * (img ? img[r] : 1.f);
                 if (w != 0.f)
-                    brick_scatter(HostAddBytes{brick.data()}, 0.f, G, s, t, voxel_shift, eps, w);
+                    step_scatter(HostAddBytes{brick.data()}, 0u, step_geom(box, lay), s, t, voxel_shift,
+                                 eps, w);
             }
         }
         for (int x = box.lo[0]; x < box.hi[0]; ++x)

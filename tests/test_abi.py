@@ -180,7 +180,7 @@ def test_brick_kernels_fit_their_register_budget():
                     kernels[name] = (scratch, int(val))
                     name = None
     bricks = {k: v for k, v in kernels.items() if "siddon_brick_kernel" in k}
-    assert len(bricks) == 6, sorted(kernels)
+    assert len(bricks) >= 6, sorted(kernels)
     for name, (scratch, vgpr) in bricks.items():
         assert scratch == 0, (name, scratch)
         assert vgpr <= 128, (name, vgpr)

@@ -184,7 +184,7 @@ def test_trilinear_nearest_max(emu_lib):
     assert rel_err(out, g["out_f32"].reshape(B, N)) < FWD_TOL
 
 
-# ------------------------------------------------------------ slab march path
+# ---------------------------------------------------- pose classes, both Siddon walks
 
 SLAB_POSES = [
     ("base", [0.0, 0.0, 0.0], [0.0, 850.0, 0.0]),
@@ -201,16 +201,15 @@ SLAB_POSES = [
 
 
 @pytest.mark.parametrize("D,H,W,delx", [(64, 40, 40, 3.0), (48, 70, 33, 2.0)])
-def test_slab_march_vs_oracle_and_generic(emulated_ops, D, H, W, delx):
-    """Lockstep slab march (csrc/slab_core.h) through the wave-level emulation: every
-    pose class (march along x / y, z-dominant fallback, non-dominant rays, source inside
-    the volume) against the fp32 oracle, and its backward record against the generic
-    walk's."""
+def test_generic_and_brick_walks_vs_oracle(emulated_ops, D, H, W, delx):
+    """The per-ray walk (siddon_core.h) and the volume-stationary brick walk (brick_step.h)
+    on every pose class (beam along x / y / z, oblique, source inside the volume, volume
+    behind the source) and on a volume that is not a multiple of the brick edge: images
+    against the fp32 oracle, backward records against the fp64 oracle."""
     import torch
 
     from diffdrr_amd import DRR, convert
     from diffdrr_amd.data import synthetic_subject
-    from diffdrr_amd.plan import slab_plan
 
     ops = emulated_ops
     drr = DRR(synthetic_subject(D, kind="noise", seed=0), sdd=1020.0, height=H, width=W,
@@ -224,62 +223,59 @@ def test_slab_march_vs_oracle_and_generic(emulated_ops, D, H, W, delx):
         s = drr.affine_inverse(source).contiguous()
         t = drr.affine_inverse(target).contiguous()
     V = drr.density
-    plan, shear = slab_plan(s, t, H, W)
-    assert set(plan[:, 0].tolist()) == {0, 1, 2}  # all three march classes are exercised
-    out, aux = ops.siddon_forward_slab(V, s, t, L, (H, W), plan, shear, want_aux=True)
     gen, aux_gen, _ = ops.siddon_forward(V, s, t, L, want_aux=True)
-    ref = oracle.siddon(V.numpy(), s.numpy(), t.numpy(), L.numpy())["out"].reshape(out.shape)
-    for b, (name, _, _) in enumerate(SLAB_POSES):
-        assert rel_err(out[b].numpy(), ref[b]) < 5e-5, name
-        assert rel_err(out[b].numpy(), gen[b].numpy()) < 1e-6, name
-        close = (aux[b] - aux_gen[b]).abs().amax(-1) <= 1e-4 * aux_gen[b].abs().max()
-        # records differ only in which axis an exact tie is attributed to (poses with the
-        # source on a symmetry plane of the volume have many exact ties)
-        assert close.float().mean().item() > (0.9 if name in ("base", "diag45") else 0.98), name
-        assert torch.allclose(aux[b, :, 0], aux_gen[b, :, 0], rtol=1e-5, atol=1e-6), name
-    # Infinity-Cache passes: rendering a partition of the volume box by box and adding up
-    # reproduces the single-pass image and backward record (split along y, then along x)
-    Dx, Dy, Dz = V.shape
-    for boxes in (ops.volume_passes(V.shape, pass_bytes=V.numel() * 4 // 3 - 64),
-                  [[0, 0, 0, 11, Dy, Dz], [11, 0, 0, 30, Dy, Dz], [30, 0, 0, Dx, Dy, Dz]],
-                  [[0, 0, 0, Dx, Dy, 7], [0, 0, 7, Dx, Dy, Dz]]):
-        assert len(boxes) >= 2
-        outp, auxp = ops.siddon_forward_slab(V, s, t, L, (H, W), plan, shear, want_aux=True,
-                                             boxes=boxes)
-        assert rel_err(outp.numpy(), out.numpy()) < 1e-5
-        closep = (auxp - aux).abs().amax(-1) <= 1e-4 * aux.abs().max()
-        assert closep.float().mean().item() > 0.97
+    a32 = (V.numpy(), s.numpy(), t.numpy(), L.numpy())
+    ref = oracle.siddon(*a32)["out"].reshape(gen.shape)
     # volume-stationary brick kernel: per-brick pieces of every ray, added up
     outb, auxb = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True)
     outb0, none = ops.siddon_forward_bricks(V, s, t, L, (H, W))
     assert none is None and rel_err(outb0.numpy(), outb.numpy()) < 1e-6
     for b, (name, _, _) in enumerate(SLAB_POSES):
-        assert rel_err(outb[b].numpy(), out[b].numpy()) < 1e-5, name
+        assert rel_err(gen[b].numpy(), ref[b]) < 5e-5, name
+        assert rel_err(outb[b].numpy(), ref[b]) < 5e-5, name
+        # both walks evaluate every crossing as the reference's quotient (k - shift - s) / d
+        # (the brick walk via the first plane ahead of each brick entry); the sums are grouped
+        # differently (per brick), which is what is left of the difference
+        assert rel_err(outb[b].numpy(), gen[b].numpy()) < 2e-5, name
+        assert rel_err(auxb[0, b].numpy(), aux_gen[b, :, 0].numpy()) < 2e-5, name
     # the planar record gives the same ray gradients as the generic walk's record
-    go = torch.rand(out.shape, generator=torch.Generator().manual_seed(3))
+    go = torch.rand(gen.shape, generator=torch.Generator().manual_seed(3))
     gsb, gtb, gib = ops.siddon_backward_rays(auxb, go, s, t, L)
     gsg, gtg, gig = ops.siddon_backward_rays(aux_gen, go, s, t, L)
-    assert rel_err(gib.numpy(), gig.numpy()) < 1e-5
+    assert rel_err(gib.numpy(), gig.numpy()) < 2e-5
+    # yardstick: the fp64 oracle, allowance: what the reference's own fp32 arithmetic (the fp32
+    # oracle) loses against it.  Single rays differ where a crossing pair ties in fp32 and is
+    # attributed to different axes; the walks' alphas are within an ulp of the reference's
+    # quotient, so they flip where the reference's fp32 flips.
+    o32 = oracle.siddon(*a32, grad_out=go.numpy())["g_target"]
+    o64 = oracle.siddon(*(x.astype(np.float64) for x in a32),
+                        grad_out=go.numpy().astype(np.float64))["g_target"]
     for b, (name, _, _) in enumerate(SLAB_POSES):
-        # per-pose sums (what the pose gradient is made of); single rays differ where a
-        # crossing pair ties in fp32 and is attributed to different axes
-        assert rel_err(gtb[b].sum(0).numpy(), gtg[b].sum(0).numpy()) < 2e-3, name
-        close = (gtb[b] - gtg[b]).abs().amax(-1) <= 1e-3 * gtg[b].abs().max()
-        assert close.float().mean().item() > (0.9 if name in ("base", "diag45") else 0.97), name
-    # the plan never changes results: flip majors, shears and march axes
-    p2 = plan.clone()
-    p2[:, 0] = (p2[:, 0] + 1) % 3
-    p2[:, 1] = 1 - p2[:, 1]
-    out2, _ = ops.siddon_forward_slab(V, s, t, L, (H, W), p2, shear * -1.7 + 0.3)
-    assert rel_err(out2.numpy(), out.numpy()) < 1e-6
+        scale = np.abs(o64[b]).max()
+        close = lambda g: float((np.abs(np.asarray(g[b]) - o64[b]).max(-1) <= 1e-3 * scale).mean())  # noqa
+        for mine in (gtb, gtg):
+            assert close(mine) > 0.9, name
+            if name in ("base", "diag45"):
+                continue  # source on a symmetry plane: exact ties everywhere, attribution arbitrary
+            # (rotZ / tilt: the detector's central column looks down the volume's central edge,
+            # x- and y-planes tie exactly there: ~1 % of the rays)
+            assert close(mine) >= close(o32) - 0.02, name
+            # per-pose sums (what the pose gradient is made of); where exact ties dominate
+            # the sum the attribution is a convention the two walks share
+            assert rel_err(mine[b].sum(0).numpy(), o64[b].sum(0)) < \
+                2 * rel_err(o32[b].sum(0), o64[b].sum(0)) + 2e-3 or \
+                rel_err(gtb[b].sum(0).numpy(), gtg[b].sum(0).numpy()) < 2e-3, name
 
 
-def test_gliding_rays_partition_exactly(emulated_ops):
+def test_gliding_rays_vs_fp64(emulated_ops):
     """Rays that glide along a voxel plane (one direction component ~1e-5 of the others,
     position within 1e-5 voxel of the plane): a position error of 1e-5 voxel is an alpha
-    error of any size there, so a sub-box walk that picked its entry cell from the position
-    alone opened with a negative-length segment (found at 512^3: one pixel off by 4e-4).
-    Rendering a partition of the volume box by box must reproduce the single-pass image."""
+    error of any size there.  The walks evaluate every crossing as the reference's quotient
+    (k - shift - s) / d from the integer plane index and pick entry cells by the order of
+    those alphas, never from positions alone (found at 512^3: one pixel off by 4e-4 with
+    alpha = fma(k, 1/d, c)).  Yardstick: the fp64 oracle -- the reference's OWN fp32
+    arithmetic (the fp32 oracle) is ~3e-2 off on these rays, because it rounds segment
+    midpoints to voxels."""
     import torch
 
     ops = emulated_ops
@@ -298,31 +294,20 @@ def test_gliding_rays_partition_exactly(emulated_ops):
     idx = torch.arange(n)
     s[idx, axis] = plane - 0.5 + off - tilt / 2
     t[idx, axis] = plane - 0.5 + off + tilt / 2
-    # one "pose" whose source differs per ray is not the slab layout: use B = n poses of 1x... no:
-    # the slab entry point takes one source per pose, so make every ray its own pose with a 2x2 grid
+    # every ray its own "pose" with a 2x2 detector of identical targets (the brick entry point
+    # takes one source per pose and a detector grid)
     src = s.view(n, 1, 3).contiguous()
     tgt = t.view(n, 1, 3).expand(n, 4, 3).contiguous()
     L = torch.ones(n, 4)
-    plan = torch.zeros(n, 2, dtype=torch.int32)
-    plan[:, 0] = 2  # generic walk inside the slab entry point (it honours the box)
-    shear = torch.zeros(n, 1)
-    one, aux1 = ops.siddon_forward_slab(V, src, tgt, L, (2, 2), plan, shear, want_aux=True,
-                                        boxes=[[0, 0, 0, D, D, D]])
-    assert one.abs().max() > 0
-    cuts = [0, 13, 32, 33, 51, D]
-    for ax in range(3):
-        boxes = []
-        for lo, hi in zip(cuts[:-1], cuts[1:]):
-            b = [0, 0, 0, D, D, D]
-            b[ax], b[3 + ax] = lo, hi
-            boxes.append(b)
-        many, auxm = ops.siddon_forward_slab(V, src, tgt, L, (2, 2), plan, shear, want_aux=True,
-                                             boxes=boxes)
-        assert rel_err(many.numpy(), one.numpy()) < 2e-6, ax
-        assert rel_err(auxm[..., 0].numpy(), aux1[..., 0].numpy()) < 2e-6, ax
-    # and the brick kernel (32^3 bricks: 27 of them here) on the same rays
-    bricks, _ = ops.siddon_forward_bricks(V, src, tgt, L, (2, 2))
-    assert rel_err(bricks.numpy(), one.numpy()) < 5e-6
+    a64 = (V.numpy().astype(np.float64), src.numpy().astype(np.float64),
+           tgt.numpy()[:, :1].astype(np.float64), np.ones((n, 1)))
+    ref64 = oracle.siddon(*a64)["out"].reshape(n)
+    assert np.abs(ref64).max() > 0
+    one, _, _ = ops.siddon_forward(V, src, tgt, L)
+    bricks, _ = ops.siddon_forward_bricks(V, src, tgt, L, (2, 2))  # 32^3 bricks: 27 of them
+    for k in range(4):
+        assert rel_err(one.numpy()[:, k], ref64) < 1e-5
+        assert rel_err(bricks.numpy()[:, k], ref64) < 1e-5
 
 
 def test_volume_gradient_bricks_equals_rewalk(emulated_ops):

@@ -57,9 +57,14 @@ def _check_bricks_against_oracle(gpu, D, det, delx, B, seed):
     for img in (out, plain):
         mine = img.cpu().numpy().reshape(B, 1, N)
         for b in range(B):  # per image, as the north star states it
-            assert rel_err(mine[b], ref32["out"][b]) < FWD_TOL, b
-            assert rel_err(mine[b], ref64["out"][b]) < 2 * rel_err(ref32["out"][b], ref64["out"][b]) \
-                + 2e-6, b
+            r32, r64 = ref32["out"][b].astype(np.float64), ref64["out"][b]
+            scale = np.abs(r32).max()
+            # within 1e-4 of the reference's fp32 image -- except where that image itself is
+            # further than that from the exact one (a ray gliding along a voxel plane: the fp32
+            # reference was 3e-4 off at one pixel of the 512^3 scene, the kernel 8e-5)
+            assert (np.abs(mine[b] - r32) <= FWD_TOL * scale + 2 * np.abs(r32 - r64)).all(), b
+            # and no further from the exact image than the reference's fp32 arithmetic
+            assert rel_err(mine[b], r64) < 2 * rel_err(r32, r64) + 2e-6, b
     gs, gt, gi = ops.siddon_backward_rays(aux, go, s, t, L)
     gs = gs.double().sum(1, keepdim=True).cpu().numpy()
     for mine, key in ((gs, "g_source"), (gt.cpu().numpy(), "g_target"),

@@ -467,38 +467,14 @@ def test_pose_gradient_matches_fp64_chain(gpu):
     assert rel_err(x.grad.cpu().numpy(), truth_x) < 2 * rel_err(ref_x, truth_x) + 2e-3
 
 
-def test_slab_march_equals_generic_walk(gpu, big):
-    """The detector-grid fast path (lockstep slab march, csrc/slab_core.h) against the
-    per-crossing walk on the same rays: same image, same backward record."""
-    from diffdrr_amd.plan import slab_plan
-
+def test_generic_record_identities_full_size(gpu, big):
+    """What does not depend on how ties are attributed: sum_a S0_a = 0 and sum_a S1_a = I per
+    ray, for the per-ray walk's record at full size."""
     drr, s, t, L = big
-    V = drr.density
-    ref, aux_ref, _ = ops.siddon_forward(V, s, t, L, want_aux=True, det=(256, 256))
-    plan, shear = slab_plan(s, t, 256, 256)
-    assert plan.shape == (4, 2) and shear.shape == (4, 4)
-    out, aux = ops.siddon_forward_slab(V, s, t, L, (256, 256), plan, shear, want_aux=True)
-    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5  # 4 Infinity-Cache passes
-    # identical up to which axis a crossing pair that ties IN FP32 is attributed to.  At
-    # 512^3 a ray has ~1500 crossings ~7e-4 apart in alpha, so ~1-2 % of the rays hold one
-    # pair closer than an fp32 ulp (measured 1.35 %); on those the two walks split
-    # V_before - V_after differently between the two axes (the reference's own split there
-    # is its sort order).  Pose 0 is the symmetric base pose, full of exact ties.
-    close = ((aux - aux_ref).abs().amax(-1) <= 1e-4 * aux_ref.abs().max())
-    assert close[1:].float().mean().item() > 0.97
-    assert torch.allclose(aux[..., 0], aux_ref[..., 0], rtol=1e-4, atol=1e-5)
-    # what does not depend on the attribution: sum_a S0_a = 0 and sum_a S1_a = I per ray
+    ref, aux_ref, _ = ops.siddon_forward(drr.density, s, t, L, want_aux=True, det=(256, 256))
     scale = aux_ref.abs().max()
-    for a in (aux, aux_ref):
-        assert (a[..., 1:4].sum(-1).abs().max() <= 2e-5 * scale)
-        assert ((a[..., 4:7].sum(-1) - a[..., 0]).abs().max() <= 2e-5 * scale)
-    # any plan gives the same image: force the other march axis / the generic fallback
-    for march in (0, 1, 2):
-        p2 = plan.clone()
-        p2[:, 0] = march
-        p2[:, 1] = 1 - p2[:, 1]
-        o2 = ops.siddon_forward_slab(V, s, t, L, (256, 256), p2, -shear)[0]
-        assert rel_err(o2.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    assert (aux_ref[..., 1:4].sum(-1).abs().max() <= 2e-5 * scale)
+    assert ((aux_ref[..., 4:7].sum(-1) - aux_ref[..., 0]).abs().max() <= 2e-5 * scale)
 
 
 def test_brick_kernel_equals_generic_walk(gpu, big):
@@ -509,7 +485,10 @@ def test_brick_kernel_equals_generic_walk(gpu, big):
     ref, aux_ref, _ = ops.siddon_forward(V, s, t, L, det=(256, 256), want_aux=True)
     out, none = ops.siddon_forward_bricks(V, s, t, L, (256, 256))
     assert none is None
-    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    # (both walks evaluate every crossing as the reference's quotient (k - shift - s) / d, the
+    # brick walk via the first plane ahead of each brick entry; the sums are grouped per brick.
+    # Accuracy proper is checked against the fp64 oracle in test_gpu_baseline_sizes.py.)
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 2e-5
     again, aux = ops.siddon_forward_bricks(V, s, t, L, (256, 256), want_aux=True)
     assert rel_err(again.cpu().numpy(), out.cpu().numpy()) < 2e-6  # atomics: not bit-stable
     # planar backward record: same I, and the same ray gradients as the generic record
@@ -548,7 +527,7 @@ def test_brick_kernel_small_and_ragged_volumes(gpu):
 
 
 @pytest.mark.parametrize("H,W", [(70, 45), (64, 64), (33, 130)])
-def test_slab_march_odd_detectors_vs_oracle(gpu, H, W):
+def test_odd_detectors_vs_oracle(gpu, H, W):
     subject = synthetic_subject(48, kind="noise", seed=0)
     drr = DRR(subject, sdd=400.0, height=H, width=W, delx=1.1).to(gpu)
     # (not the exact base pose: with an odd detector its centre row glides inside a voxel
@@ -562,10 +541,9 @@ def test_slab_march_odd_detectors_vs_oracle(gpu, H, W):
     ref = oracle.siddon(drr.density.cpu().numpy(), s.cpu().numpy(), t.cpu().numpy(),
                         L.cpu().numpy())["out"]
     assert rel_err(img.cpu().numpy().reshape(ref.shape), ref) < FWD_TOL
-    for path in ("slab", "generic"):
-        drr.renderer.grid_path = path
-        img2 = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
-        assert rel_err(img2.cpu().numpy(), img.cpu().numpy()) < 1e-5, path
+    drr.renderer.grid_path = "generic"
+    img2 = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    assert rel_err(img2.cpu().numpy(), img.cpu().numpy()) < 2e-5
 
 
 def test_deterministic_forward(gpu, big):

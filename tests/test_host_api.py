@@ -155,7 +155,9 @@ def test_drr_mask_to_channels_and_patches(emulated_ops):
     drr.fuse_ray_generation = False
     with torch.no_grad():
         general = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
-    assert torch.equal(patched, general)  # Siddon is per-ray independent: exact
+    # Siddon is per-ray independent: patches change nothing but the kernel that renders them
+    # (ray lists: the generic walk; the whole detector: the brick walk, other alpha arithmetic)
+    assert rel_err(patched.numpy(), general.numpy()) < 2e-5
 
 
 def test_drr_odd_detector_pa(emulated_ops):

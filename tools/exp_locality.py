@@ -12,6 +12,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools.explib  # noqa: E402
+
+tools.explib.use("exp")  # experiment switches live in the tools build only
 from diffdrr_amd import DRR, _lib, ops  # noqa: E402
 from diffdrr_amd.data import make_subject, noise_volume  # noqa: E402
 from tools.kernel_sweep import poses, rays, timeit  # noqa: E402

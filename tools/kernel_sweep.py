@@ -13,9 +13,11 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools.explib  # noqa: E402
+
+tools.explib.use("exp")  # experiment switches live in the tools build only
 from diffdrr_amd import DRR, _lib, ops  # noqa: E402
 from diffdrr_amd.data import make_subject, noise_volume  # noqa: E402
-from diffdrr_amd.plan import slab_plan  # noqa: E402
 from diffdrr_amd.pose import convert  # noqa: E402
 
 
@@ -78,28 +80,9 @@ def main():
               f"({alg / med / 1e6 / 8000 * 100:5.1f}% of 8 TB/s)", flush=True)
         return med
 
-    def slab_case(label, s, t, L, xcd, aux=False, passes=None):
-        lib.cdll.ddrr_set_xcd_swizzle_slab(int(xcd))
-        boxes = None if passes is None else ops.volume_passes(
-            V.shape, pass_bytes=-(-V.numel() * 4 // passes))
-        B = t.shape[0]
-        _, _, nv = ops.siddon_forward(V, s, t, L, count_voxels=True, det=(H, H))
-        nvox = int(nv.sum())
-        alg = 4 * nvox + B * H * H * 20 + 12 * B
-        plan, shear = slab_plan(s, t, H, H)
-        tp, _ = timeit(lambda: slab_plan(s, t, H, H), reps=5)
-        med, best = timeit(lambda: ops.siddon_forward_slab(V, s, t, L, (H, H), plan, shear,
-                                                           want_aux=aux, boxes=boxes))
-        ref = ops.siddon_forward(V, s, t, L, det=(H, H))[0]
-        out = ops.siddon_forward_slab(V, s, t, L, (H, H), plan, shear, boxes=boxes)[0]
-        label = f"{label} p{len(boxes) if boxes else 'auto'}"
-        err = ((out - ref).abs().max() / ref.abs().max()).item()
-        print(f"{label:34s} SLAB march  xcd {int(xcd)} aux {int(aux)} B {B:4d} "
-              f"vox/ray {nvox / (B * H * H):6.1f}  {med:8.3f} ms (best {best:7.3f})  "
-              f"{B / med * 1e3:9.0f} DRR/s  {alg / med / 1e6:8.1f} GB/s alg "
-              f"({alg / med / 1e6 / 8000 * 100:5.1f}% of 8 TB/s)  plan {tp:.3f} ms  "
-              f"err vs generic {err:.1e}", flush=True)
-        return med
+    def slab_case(*args, **kw):  # the lockstep slab march was removed in round 2
+        return None
+
 
     def brick_case(label, s, t, L):
         B = t.shape[0]

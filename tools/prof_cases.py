@@ -6,6 +6,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools.explib  # noqa: E402
+
+tools.explib.use("exp")  # experiment switches live in the tools build only
 from diffdrr_amd import DRR, _lib, ops  # noqa: E402
 from diffdrr_amd.data import make_subject, noise_volume  # noqa: E402
 from tools.kernel_sweep import poses, rays  # noqa: E402
@@ -16,7 +19,7 @@ ap.add_argument("--tile", default="16x4")
 ap.add_argument("--xcd", type=int, default=1)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--size", type=int, default=512)
-ap.add_argument("--kernel", default="generic", choices=["generic", "slab", "brick", "volgrad"])
+ap.add_argument("--kernel", default="generic", choices=["generic", "brick", "volgrad"])
 ap.add_argument("--aux", type=int, default=0)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -34,15 +37,9 @@ elif a.case.startswith("same"):  # one perturbed pose replicated
     one = tuple(x[4:5] for x in rays(drr, *poses(8, 2, dev)))
     s, t, L = (x.expand(B, *x.shape[1:]).contiguous() for x in one)
 th, tw = (int(v) for v in a.tile.split("x"))
-if a.kernel == "slab":
-    from diffdrr_amd.plan import slab_plan
-
-    plan, shear = slab_plan(s, t, H, H)
 for _ in range(a.reps):
     if a.kernel == "generic":
         ops.siddon_forward(drr.density, s, t, L, det=(H, H), tile=(th, tw))
-    elif a.kernel == "slab":
-        ops.siddon_forward_slab(drr.density, s, t, L, (H, H), plan, shear)
     elif a.kernel == "volgrad":
         ops.siddon_backward_volume_bricks(drr.density.shape, s, t, L, torch.ones_like(L), (H, H))
     else:

@@ -22,7 +22,7 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-constexpr int kIters = 2000;
+constexpr int kIters = 100000;
 constexpr int kRep = 16;  // independent instructions per iteration
 
 enum Case {
@@ -41,6 +41,12 @@ enum Case {
     FMA_DEP,
     PK_FMA_DEP,
     MIX_WALK,
+    FMA_SAME,
+    MUL,
+    MAX,
+    MED3,
+    FLOOR,
+    RCP,
     N_CASES
 };
 const char *kNames[N_CASES] = {"v_fma_f32",
@@ -57,7 +63,13 @@ const char *kNames[N_CASES] = {"v_fma_f32",
                                "ds_add_u32 (64 addresses)",
                                "v_fma_f32 dependent chain",
                                "v_pk_fma_f32 dependent chain",
-                               "mix: 2 min3 + 12 pk + 2 cvt + 2 ds_read"};
+                               "mix: 2 min3 + 12 pk + 2 cvt + 2 ds_read",
+                               "v_fma_f32 x, x, x, c (two distinct sources)",
+                               "v_mul_f32",
+                               "v_max_f32",
+                               "v_med3_f32",
+                               "v_floor_f32",
+                               "v_rcp_f32"};
 
 template <int C>
 __global__ __launch_bounds__(1024) void rate_kernel(unsigned long long *cycles, float *sink,
@@ -78,13 +90,19 @@ __global__ __launch_bounds__(1024) void rate_kernel(unsigned long long *cycles, 
     unsigned laddr = (unsigned)(tid & 1023) * 4u;
     unsigned ldsbase = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float *)lds;
     laddr += ldsbase;
-    unsigned long long t0 = __builtin_readcyclecounter();
-    t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < kIters; ++it) {
 #pragma unroll
         for (int i = 0; i < kRep; ++i) {
             if (C == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
             if (C == ADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+            if (C == FMA_SAME) asm volatile("v_fma_f32 %0, %0, %0, %1" : "+v"(a[i]) : "v"(c));
+            if (C == MUL) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            if (C == MAX) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            if (C == MED3) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+            if (C == FLOOR) asm volatile("v_floor_f32 %0, %0" : "+v"(a[i]));
+            if (C == RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
             if (C == PK_FMA)
                 asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pm), "v"(pc));
             if (C == PK_ADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pc));
@@ -147,6 +165,8 @@ __global__ __launch_bounds__(1024) void rate_kernel(unsigned long long *cycles, 
             asm volatile("s_waitcnt lgkmcnt(0)");
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && blockIdx.x == 0) cycles[gridDim.x * 16] = r1 - r0;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < kRep; ++i) s += a[i] + p[i].x + p[i].y;
@@ -167,18 +187,20 @@ void run(int n_cu, unsigned long long *d_cycles, float *d_sink) {
     CHECK(hipDeviceSynchronize());
     float ms = 0;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
-    std::vector<unsigned long long> h(n_cu * 16);
+    std::vector<unsigned long long> h(n_cu * 16 + 1);
     CHECK(hipMemcpy(h.data(), d_cycles, h.size() * 8, hipMemcpyDeviceToHost));
     double mean = 0;
-    for (auto v : h) mean += (double)v;
-    mean /= h.size();
+    for (int i = 0; i < n_cu * 16; ++i) mean += (double)h[i];
+    mean /= n_cu * 16;
+    const double real_ns = (double)h[n_cu * 16] * 10.0;  // s_memrealtime: 100 MHz
     int per_iter = kRep;
     if (C == CMP_CNDMASK) per_iter = 2 * kRep;
     if (C == MIX_WALK) per_iter = 18;
     // 4 waves share a SIMD: cycles per wave-instruction per SIMD = wave time / (4 * instructions)
     const double cyc = mean / ((double)kIters * per_iter * 4);
-    printf("%-44s %7.2f cycles per wave-instruction per SIMD   (kernel %.3f ms, s_memtime clock %.2f GHz)\n",
-           kNames[C], cyc, ms, mean / (ms * 1e6));
+    printf("%-44s %6.2f s_memtime ticks = %6.3f ns per wave-instruction per SIMD (kernel %.2f ms; "
+           "s_memtime %.3f GHz by s_memrealtime)\n",
+           kNames[C], cyc, ms * 1e6 / ((double)kIters * per_iter * 4), ms, mean / real_ns);
 }
 
 __global__ void clamp_check(float *out) {
@@ -222,7 +244,7 @@ int main() {
            n_cu, clk * 1e-6, kIters, kRep);
     unsigned long long *d_cycles;
     float *d_sink;
-    CHECK(hipMalloc(&d_cycles, (size_t)n_cu * 16 * 8));
+    CHECK(hipMalloc(&d_cycles, ((size_t)n_cu * 16 + 1) * 8));
     CHECK(hipMalloc(&d_sink, (size_t)n_cu * 1024 * 4));
     run<FMA>(n_cu, d_cycles, d_sink);
     run<ADD>(n_cu, d_cycles, d_sink);
@@ -239,6 +261,12 @@ int main() {
     run<LDS_ADD_RTN>(n_cu, d_cycles, d_sink);
     run<LDS_ADD>(n_cu, d_cycles, d_sink);
     run<MIX_WALK>(n_cu, d_cycles, d_sink);
+    run<FMA_SAME>(n_cu, d_cycles, d_sink);
+    run<MUL>(n_cu, d_cycles, d_sink);
+    run<MAX>(n_cu, d_cycles, d_sink);
+    run<MED3>(n_cu, d_cycles, d_sink);
+    run<FLOOR>(n_cu, d_cycles, d_sink);
+    run<RCP>(n_cu, d_cycles, d_sink);
     float *d_out, h[12];
     CHECK(hipMalloc(&d_out, sizeof(h)));
     hipLaunchKernelGGL(clamp_check, dim3(1), dim3(64), 0, 0, d_out);

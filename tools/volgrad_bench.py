@@ -1,6 +1,9 @@
 """Timing of the two Siddon volume-gradient kernels (development tool)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools.explib  # noqa: E402
+
+tools.explib.use("exp")  # experiment switches live in the tools build only
 from diffdrr_amd import DRR, ops
 from diffdrr_amd.data import make_subject, noise_volume
 from tools.kernel_sweep import poses, rays, timeit
