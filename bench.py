@@ -1,21 +1,33 @@
-"""bench.py -- DRRs/sec forward+backward on the BASELINE.json workload.
+"""bench.py -- DRRs/sec on the BASELINE.json workloads.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config headline|2|3|4|5]
 
-Workload (BASELINE.json `metric`; SURVEY.md section 8d common scene): 512^3 fp32 volume
-resident in HBM, 256x256 detector (delx 2.4, sdd 1020, AP), Siddon renderer, a
-batch of 32 perturbed poses per GPU per step.  One step = pose parameters ->
-`convert` -> fused ray generation (HIP) -> HIP Siddon forward (+ backward record) ->
-per-pose NCC against a fixed target image -> backward to the 6-DoF pose parameters
-(HIP pose-gradient kernel + autograd through the 4x4 pose chain).  With N > 1 every rank
-renders its own 32 poses (weak scaling, volume replicated) and the per-pose
-losses are all-gathered over RCCL each step.
+`--config headline` (default; BASELINE.json `metric`; SURVEY.md section 8d common scene): 512^3
+fp32 volume resident in HBM, 256x256 detector (delx 2.4, sdd 1020, AP), Siddon renderer, a batch
+of 32 perturbed poses per GPU per step.  One step = pose parameters -> fused Euler pose kernel ->
+fused ray generation -> HIP Siddon forward (+ backward record) -> per-pose NCC against a fixed
+target image -> backward to the 6-DoF pose parameters.  With N > 1 every rank renders its own 32
+poses (weak scaling, volume replicated) and the per-pose losses are all-gathered over RCCL.
+Other configs (BASELINE.json `configs`):
+  2  the same step at 256^3 -> 256^2, B = 32            (configs[1])
+  3  512^3 -> 512^2 trilinear march, 512 samples per ray, forward + backward incl. the volume
+     gradient, B = 1                                     (configs[2])
+  4  2D/3D registration loop 512^3 -> 256^2, B = 1, NCC, Adam (configs[3]); metric: iterations/s
+  5  4096 candidate poses, forward + per-pose NCC, pose-sharded over the ranks (strong
+     scaling), all_gather of the losses                  (configs[4])
+
+N > 1 without a launcher: the script re-executes itself under `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU, RCCL); under a
+launcher (RANK / WORLD_SIZE set) it uses the ranks it is given.  `n_gpus` in the result is the
+world size RCCL actually has.
 
 Rank 0 prints ONE JSON line on stdout: the driver's contract plus
-  "roofline":     the Siddon forward kernel's algorithmic HBM-read rate, timed
-                  with HIP events around every launch inside the timed region,
-  "cpu_baseline": the CPU oracle (a port of the reference's algorithm, OpenMP)
-                  on a bounded sample of the same workload, rank 0, N = 1 only.
+  "roofline":     the dominant kernel's algorithmic byte rate (SURVEY.md section 8d formulas),
+                  timed with HIP events around every launch inside the timed region,
+  "cpu_baseline": the CPU oracle (a port of the reference's algorithm, OpenMP) on a bounded
+                  sample of the same workload, rank 0, N = 1 only,
+  "parity":       the step's images / ray gradients for the sampled poses against the oracle's
+                  fp32 and fp64 renders of the same poses (the cpu_baseline leg's outputs).
 Diagnostics go to stderr.
 """
 from __future__ import annotations
@@ -24,6 +36,7 @@ import argparse
 import json
 import math
 import os
+import socket
 import sys
 import time
 
@@ -31,10 +44,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-from diffdrr_amd import DRR, NormalizedCrossCorrelation2d, ops  # noqa: E402
-from diffdrr_amd.data import make_subject, noise_volume  # noqa: E402
-from diffdrr_amd.pose import convert  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6290 measured copy ceiling
 
@@ -55,225 +64,441 @@ class KernelTimer:
     """HIP-event timing of every C-ABI launch inside the timed region, on the stream
     the kernels run on (ops._launch launches on torch's current stream)."""
 
-    def __init__(self):
+    def __init__(self, ops, on_gpu=True):
         self.enabled = False
         self.events = {}
+        self.ops = ops
+        self.on_gpu = on_gpu
         self._orig = ops._launch
 
     def install(self):
         def timed(name, device, *args):
-            if self.enabled:
+            if self.enabled and self.on_gpu:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
                 self._orig(name, device, *args)
                 e1.record()
                 self.events.setdefault(name, []).append((e0, e1))
+            elif self.enabled:  # (host clock: the cpu harness test)
+                t0 = time.perf_counter()
+                self._orig(name, device, *args)
+                self.events.setdefault(name, []).append((t0, time.perf_counter()))
             else:
                 self._orig(name, device, *args)
 
-        ops._launch = timed
+        self.ops._launch = timed
 
     def total_ms(self, name):
         ev = self.events.get(name, [])
-        return sum(a.elapsed_time(b) for a, b in ev), len(ev)
+        if self.on_gpu:
+            return sum(a.elapsed_time(b) for a, b in ev), len(ev)
+        return sum((b - a) * 1e3 for a, b in ev), len(ev)
 
 
-def cpu_baseline(drr, rot, xyz, budget_s=12.0):
-    """Oracle (C port of the reference algorithm, OpenMP over rays) forward +
-    analytic backward on a bounded sample of the same workload."""
-    import numpy as np
-
-    import oracle
+def voxel_rays(drr, rot, xyz):
+    from diffdrr_amd.pose import convert
 
     with torch.no_grad():
         pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
         source, target = drr.detector(pose, None)
-        L = (target - source).norm(dim=-1)
-        s = drr.affine_inverse(source).cpu().numpy()
-        t = drr.affine_inverse(target).cpu().numpy()
-        L = L.cpu().numpy()
+        L = (target - source).norm(dim=-1).contiguous()
+        return (drr.affine_inverse(source).contiguous(), drr.affine_inverse(target).contiguous(), L)
+
+
+def cpu_baseline_and_parity(drr, rot, xyz, images, det, budget_s=12.0, n_parity=2):
+    """Oracle (C port of the reference algorithm, OpenMP over rays) forward + analytic backward
+    on a bounded sample of the step's poses: the timing is `cpu_baseline`; its outputs for the
+    first poses (plus an fp64 render of them) are the yardstick of `parity`."""
+    import numpy as np
+
+    import oracle
+    from diffdrr_amd import ops
+
+    s_d, t_d, L_d = voxel_rays(drr, rot, xyz)
+    s, t, L = s_d.cpu().numpy(), t_d.cpu().numpy(), L_d.cpu().numpy()
     vol = drr.density.cpu().numpy()
+    D = vol.shape[0]
     cores = os.cpu_count() or 1
-    N = t.shape[1]
+    B, N = t.shape[0], t.shape[1]
     go = np.ones((1, N), np.float32)
     # calibrate on a strip of rays, then size the sample to ~budget_s
     n0 = 4096
     t0 = time.perf_counter()
     oracle.siddon(vol, s[:1], t[:1, :n0], L[:1, :n0], grad_out=go[:, :n0])
     per_ray = (time.perf_counter() - t0) / n0
-    n_drr = max(1, min(rot.shape[0], int(budget_s / (per_ray * N))))
+    n_drr = max(1, min(B, int(budget_s / (per_ray * N))))
+    refs = []
     t0 = time.perf_counter()
     for b in range(n_drr):
-        oracle.siddon(vol, s[b:b + 1], t[b:b + 1], L[b:b + 1], grad_out=go)
+        refs.append(oracle.siddon(vol, s[b:b + 1], t[b:b + 1], L[b:b + 1], grad_out=go))
     dt = time.perf_counter() - t0
-    return {
+    baseline = {
         "value": n_drr / dt, "unit": "DRRs/s", "cores": cores, "kind": "port",
-        "sample": f"{n_drr} of the step's poses, 512^3 -> 256x256 Siddon fwd + analytic bwd "
+        "sample": f"{n_drr} of the step's poses, {D}^3 -> {det}x{det} Siddon fwd + analytic bwd "
                   f"(oracle/drr_oracle.c, OpenMP {cores} threads, {dt:.1f} s)",
     }
+    # parity: the images the timed step produced and the brick kernel's ray gradients for the
+    # same poses, against the oracle's fp32 (reference arithmetic) and fp64 (exact) renders
+    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - b).max() / np.abs(b).max())  # noqa
+    n_par = min(n_parity, n_drr)
+    fwd32, fwd64, ref_fwd64, g64, ref_g64 = [], [], [], [], []
+    vol64 = vol.astype(np.float64)
+    for b in range(n_par):
+        r64 = oracle.siddon(vol64, s[b:b + 1].astype(np.float64), t[b:b + 1].astype(np.float64),
+                            L[b:b + 1].astype(np.float64), grad_out=go.astype(np.float64))
+        mine = images[b].reshape(-1).cpu().numpy()
+        r32 = refs[b]["out"].reshape(-1)
+        fwd32.append(rel(mine, r32.astype(np.float64)))
+        fwd64.append(rel(mine, r64["out"].reshape(-1)))
+        ref_fwd64.append(rel(r32, r64["out"].reshape(-1)))
+        _, aux = ops.siddon_forward_bricks(drr.density, s_d[b:b + 1], t_d[b:b + 1], L_d[b:b + 1],
+                                           (det, det), want_aux=True)
+        _, gt, _ = ops.siddon_backward_rays(aux, torch.ones(1, N, device=s_d.device),
+                                            s_d[b:b + 1], t_d[b:b + 1], L_d[b:b + 1])
+        g64.append(rel(gt.cpu().numpy(), r64["g_target"]))
+        ref_g64.append(rel(refs[b]["g_target"], r64["g_target"]))
+    parity = {
+        "poses": n_par,
+        "oracle": "oracle/drr_oracle.c (C restatement of diffdrr/renderers.py:34-183, pinned to "
+                  "the reference's fixtures): fp32 = the reference's arithmetic, fp64 = exact",
+        "fwd_rel_err": max(fwd32),                    # max |ours - ref32| / max |ref32|, worst pose
+        "fwd_rel_err_vs_fp64": max(fwd64),
+        "ref_fp32_fwd_rel_err_vs_fp64": max(ref_fwd64),
+        "grad_rel_err_vs_fp64": max(g64),             # d out / d target per ray, worst pose
+        "ref_fp32_grad_rel_err_vs_fp64": max(ref_g64),
+        "tolerance": "fwd_rel_err <= 1e-4; *_vs_fp64 <= 2 x the reference's own fp32 error (+1e-3 "
+                     "for gradients)",
+    }
+    return baseline, parity
+
+
+def free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def traffic_record(kind):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (they
+    cannot be collected from inside the process): newest profiles/rNN/traffic.json."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for r in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        path = os.path.join(pdir, r, "traffic.json")
+        if os.path.exists(path):
+            with open(path) as f:
+                rec = json.load(f)
+            if kind in rec:
+                best = (rec[kind]["hbm_bytes_per_launch"], f"profiles/{r}/traffic.json")
+    return best
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="poses per GPU per step")
-    ap.add_argument("--size", type=int, default=512, help="volume edge (voxels)")
-    ap.add_argument("--det", type=int, default=256, help="detector edge (pixels)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="headline", choices=["headline", "2", "3", "4", "5"])
+    ap.add_argument("--batch", type=int, default=None, help="poses per GPU per step")
+    ap.add_argument("--size", type=int, default=None, help="volume edge (voxels)")
+    ap.add_argument("--det", type=int, default=None, help="detector edge (pixels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                    help="cpu: harness test only (gloo ranks; the kernels are whatever "
+                         "DDRR_BENCH_HOOK routes diffdrr_amd.ops to, see tests/test_dist_gloo.py)")
     args = ap.parse_args()
+    on_gpu = args.device == "cuda"
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # no launcher: start one rank per GPU ourselves (RCCL needs one process per device)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        os.execvpe(cmd[0], cmd, env)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    device = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    if on_gpu:
+        torch.cuda.set_device(device)
+    if os.environ.get("DDRR_BENCH_HOOK"):  # test harness only: e.g. route ops to the host emulation
+        import importlib
+
+        importlib.import_module(os.environ["DDRR_BENCH_HOOK"])
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" == RCCL on ROCm
+        if on_gpu:
+            dist.init_process_group(backend="nccl", device_id=device)  # "nccl" == RCCL on ROCm
+        else:
+            dist.init_process_group(backend="gloo")
+        world = dist.get_world_size()
+    if world != args.gpus and rank == 0:
+        log(f"note: --gpus {args.gpus}, process group has {world} ranks; reporting n_gpus={world}")
 
-    D, H, B = args.size, args.det, args.batch
+    from diffdrr_amd import DRR, NormalizedCrossCorrelation2d, Registration, ops
+    from diffdrr_amd import dist as ddist
+    from diffdrr_amd.data import make_subject, noise_volume, synthetic_subject
+
+    cfg = args.config
+    D = args.size or (256 if cfg == "2" else 512)
+    H = args.det or (512 if cfg == "3" else 256)
+    B = args.batch or {"headline": 32, "2": 32, "3": 1, "4": 1, "5": 4096}[cfg]
+    # every default timed region lasts >= ~1 s on one MI355X
+    steps = args.steps if args.steps is not None else {"headline": 400, "2": 800, "3": 400, "4": 1500, "5": 5}[cfg]
+    warmup = args.warmup if args.warmup is not None else {"headline": 10, "2": 10, "3": 10, "4": 20, "5": 1}[cfg]
     delx = 2.4 * (256 / H) * (D / 512)  # the detector always spans the volume's shadow
-    subject = make_subject(noise_volume(D, seed=0), spacing=(1.0, 1.0, 1.0), orientation="AP")
-    drr = DRR(subject, sdd=1020.0, height=H, delx=delx, renderer="siddon").to(device)
-    ncc = NormalizedCrossCorrelation2d()
-    rot0, xyz0 = perturbed_poses(B, seed=2 + rank, device=device)
-    with torch.no_grad():
-        base = drr(torch.zeros(1, 3, device=device), torch.tensor([[0.0, 850.0, 0.0]],
-                                                                  device=device),
-                   parameterization="euler_angles", convention="ZXY")
-    rot = rot0.clone().requires_grad_()
-    xyz = xyz0.clone().requires_grad_()
-    gathered = torch.empty(world * B, device=device) if world > 1 else None
-    pending = []  # the in-flight all_gather of the last step
-
-    def step():
-        rot.grad = None
-        xyz.grad = None
-        img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
-        loss = ncc(base.expand(B, -1, -1, -1), img)  # (B,) one similarity per pose
-        loss.sum().backward()
-        if world > 1:
-            # the 4 B/pose of losses travel on RCCL's own stream while the next step renders:
-            # nothing on the compute stream waits for them before fence()
-            pending[:] = [dist.all_gather_into_tensor(gathered, loss.detach(), async_op=True)]
-        return loss
-
-    timer = KernelTimer()
+    timer = KernelTimer(ops, on_gpu)
     timer.install()
+    ncc = NormalizedCrossCorrelation2d()
 
-    def fence():
+    def fence(pending=()):
         for work in pending:
             work.wait()
-        pending.clear()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    extra = {}
+    images = None
+    if cfg in ("headline", "2"):
+        subject = make_subject(noise_volume(D, seed=0), spacing=(1.0, 1.0, 1.0), orientation="AP")
+        drr = DRR(subject, sdd=1020.0, height=H, delx=delx, renderer="siddon").to(device)
+        rot0, xyz0 = perturbed_poses(B, seed=2 + rank, device=device)
+        with torch.no_grad():
+            base = drr(torch.zeros(1, 3, device=device), torch.tensor([[0.0, 850.0, 0.0]], device=device),
+                       parameterization="euler_angles", convention="ZXY")
+        rot = rot0.clone().requires_grad_()
+        xyz = xyz0.clone().requires_grad_()
+        gathered = torch.empty(world * B, device=device) if world > 1 else None
+        pending = []  # the in-flight all_gather of the last step
+        keep = {}
+
+        def step():
+            rot.grad = None
+            xyz.grad = None
+            img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+            loss = ncc(base.expand(B, -1, -1, -1), img)  # (B,) one similarity per pose
+            loss.sum().backward()
+            keep["img"] = img
+            if world > 1:
+                # the 4 B/pose of losses travel on RCCL's own stream while the next step renders:
+                # nothing on the compute stream waits for them before fence()
+                pending[:] = [dist.all_gather_into_tensor(gathered, loss.detach(), async_op=True)]
+            return loss
+
+        units_per_step, unit, scaling = world * B, "DRRs/s", "weak"
+        metric = f"DRRs/sec fwd+bwd, {D}^3 vol -> {H}^2 det, batched poses"
+        workload = (f"{D}^3 fp32 noise volume -> {H}x{H} detector, Siddon forward + backward w.r.t. "
+                    f"6-DoF pose (euler ZXY) through NCC, {B} perturbed poses per GPU per step")
+        dominant = "ddrr_siddon_forward_bricks"
+    elif cfg == "3":
+        subject = make_subject(noise_volume(D, seed=0), spacing=(1.0, 1.0, 1.0), orientation="AP")
+        drr = DRR(subject, sdd=1020.0, height=H, delx=delx, renderer="trilinear").to(device)
+        drr.density.requires_grad_()   # reconstruction: the volume is the parameter
+        rot0, xyz0 = perturbed_poses(B, seed=2 + rank, device=device)
+        go = torch.rand(B, 1, H, H, generator=torch.Generator().manual_seed(7)).to(device)
+        pending, keep = [], {}
+        P = 512
+
+        def step():
+            drr.density.grad = None
+            img = drr(rot0, xyz0, parameterization="euler_angles", convention="ZXY", n_points=P)
+            (img * go).sum().backward()
+            keep["img"] = img
+            return img.detach().sum().reshape(1)
+
+        units_per_step, unit, scaling = world * B, "DRRs/s", "weak"
+        metric = f"DRRs/sec fwd+bwd incl. volume gradient, {D}^3 vol -> {H}^2 det, trilinear {P} samples/ray"
+        workload = (f"{D}^3 fp32 noise volume -> {H}x{H} detector, trilinear march {P} samples per ray, "
+                    f"forward + backward w.r.t. the volume, {B} pose(s) per GPU per step")
+        dominant = "ddrr_trilinear_forward_bricks"
+    elif cfg == "4":
+        drr = DRR(synthetic_subject(D, kind="phantom", seed=0), sdd=1020.0, height=H, delx=delx,
+                  stop_gradients_through_grid_sample=True).to(device)
+        true_rot = torch.zeros(1, 3, device=device)
+        true_xyz = torch.tensor([[0.0, 850.0, 0.0]], device=device)
+        with torch.no_grad():
+            gt = drr(true_rot, true_xyz, parameterization="euler_angles", convention="ZXY")
+        g = torch.Generator().manual_seed(1 + rank)
+        r0 = true_rot + ((torch.rand(1, 3, generator=g) - 0.5) * 0.4).to(device)   # +-0.2 rad
+        x0 = true_xyz + ((torch.rand(1, 3, generator=g) - 0.5) * 60.0).to(device)  # +-30 mm
+        state = {}
+
+        def restart():
+            state["reg"] = Registration(drr, r0.clone(), x0.clone(), parameterization="euler_angles",
+                                        convention="ZXY")
+            state["opt"] = torch.optim.Adam([{"params": [state["reg"]._rotation], "lr": 1e-1},
+                                             {"params": [state["reg"]._translation], "lr": 5e0}],
+                                            maximize=True)
+            state["it"] = 0
+
+        restart()
+        pending, keep = [], {}
+
+        def step():
+            # every 100 iterations the loop restarts from the perturbed pose: the timed region is
+            # the registration loop at its working rate, converged or not
+            if state["it"] == 100:
+                restart()
+            state["opt"].zero_grad()
+            loss = ncc(gt, state["reg"]()).sum()
+            loss.backward()
+            state["opt"].step()
+            state["it"] += 1
+            return loss.detach().reshape(1)
+
+        units_per_step, unit, scaling = world, "iterations/s", "weak"
+        metric = f"registration iterations/sec, {D}^3 vol -> {H}^2 det, SE(3) gradient ascent on NCC"
+        workload = (f"{D}^3 fp32 phantom volume -> {H}x{H} detector, Siddon "
+                    f"(stop_gradients_through_grid_sample), Registration + NCC + Adam(1e-1 / 5e0), "
+                    f"one pose per GPU, restart every 100 iterations")
+        dominant = "ddrr_siddon_forward_bricks"
+    else:  # "5": the candidate-pose sweep, sharded (strong scaling)
+        subject = make_subject(noise_volume(D, seed=0), spacing=(1.0, 1.0, 1.0), orientation="AP")
+        drr = DRR(subject, sdd=1020.0, height=H, delx=delx, renderer="siddon").to(device)
+        rot0, xyz0 = perturbed_poses(B, seed=2, device=device)  # the same candidates on every rank
+        with torch.no_grad():
+            fixed = drr(torch.zeros(1, 3, device=device), torch.tensor([[0.0, 850.0, 0.0]], device=device),
+                        parameterization="euler_angles", convention="ZXY")
+        pending, keep = [], {}
+
+        def step():
+            vals = ddist.sweep(drr, ncc, fixed, rot0, xyz0, chunk=512)  # all_gather inside
+            keep["vals"] = vals
+            return vals
+
+        units_per_step, unit, scaling = B, "DRRs/s", "strong"
+        metric = f"DRRs/sec forward + per-pose NCC, {D}^3 vol -> {H}^2 det, {B} candidate poses sharded"
+        workload = (f"{D}^3 fp32 noise volume -> {H}x{H} detector, Siddon forward + NCC of {B} candidate "
+                    f"poses sharded over the ranks, all_gather of the per-pose similarities")
+        dominant = "ddrr_siddon_forward_bricks"
+
+    for _ in range(warmup):
         step()
-    fence()
+    fence(pending)
+    pending.clear()
     timer.enabled = True
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
+    for _ in range(steps):
+        last = step()
+    fence(pending)
     dt = time.perf_counter() - t0
     timer.enabled = False
-    assert torch.isfinite(loss).all() and torch.isfinite(rot.grad).all()
+    assert torch.isfinite(last).all()
+    if cfg in ("headline", "2"):
+        assert torch.isfinite(rot.grad).all() and torch.isfinite(xyz.grad).all()
+        images = keep["img"].detach()
 
     t_max = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     dt = t_max.item()
-    total_drrs = world * B * args.steps
 
     if rank == 0:
-        # algorithmic bytes of one forward launch (SURVEY.md section 8d):
-        #   4 B per visited voxel + 20 B per ray (target 12 + img 4 + out 4) + 12 B per source
+        ms_per_step = dt / steps * 1e3
+        # the dominant kernel: every launch of it in the timed region, HIP events on its stream
+        names = [n for n in timer.events if n == dominant] or \
+            [max(timer.events, key=lambda n: timer.total_ms(n)[0])]
+        k_name = names[0]
+        k_total, k_n = timer.total_ms(k_name)
+        k_ms = k_total / max(1, k_n)   # per launch
+        per_step = k_n / steps
+        bwd_ms = sum(timer.total_ms(n)[0] for n in timer.events if "backward" in n) / steps
+        # algorithmic bytes of ONE launch (SURVEY.md section 8d)
         with torch.no_grad():
-            pose = convert(rot0, xyz0, parameterization="euler_angles", convention="ZXY")
-            source, target = drr.detector(pose, None)
-            L = (target - source).norm(dim=-1).contiguous()
-            s_v = drr.affine_inverse(source).contiguous()
-            t_v = drr.affine_inverse(target).contiguous()
-            _, _, nvox = ops.siddon_forward(drr.density, s_v, t_v, L, count_voxels=True,
-                                            det=(H, H))
-        n_vox = int(nvox.sum().item())
-        alg_bytes = 4 * n_vox + B * H * H * 20 + 12 * B
-        # the forward of one step = every launch of the dominant forward entry point in that
-        # step (the slab march renders the volume in Infinity-Cache-sized passes, one launch
-        # each); bytes and time are both per step, so achieved = bytes / time of a forward
-        fwd_name = max((n for n in timer.events if "forward" in n),
-                       key=lambda n: timer.total_ms(n)[0])
-        fwd_total, n_fwd = timer.total_ms(fwd_name)
-        fwd_ms = fwd_total / args.steps
-        bwd_ms = sum(timer.total_ms(n)[0] for n in timer.events if "backward" in n) / args.steps
-        achieved = alg_bytes / (fwd_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this very command
-        # (they cannot be collected from inside the process); only for the workload they
-        # were measured on
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-        if (D, H, B) == (512, 256, 32) and fwd_name == "ddrr_siddon_forward_bricks" \
-                and os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f)["forward_record"]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-        ms_per_step = dt / args.steps * 1e3
-        log(f"[bench] step {ms_per_step:.3f} ms | {fwd_name} {fwd_ms:.3f} ms/step in "
-            f"{n_fwd // args.steps} launch(es) | backward kernels {bwd_ms:.3f} ms | raygen "
-            f"{timer.total_ms('ddrr_raygen_forward')[0] / args.steps:.3f} ms | host+torch remainder "
-            f"{ms_per_step - fwd_ms - bwd_ms:.3f} ms | voxels/ray {n_vox / (B * H * H):.1f} "
-            f"| {alg_bytes / B / 1e6:.1f} MB algorithmic per DRR")
+            if cfg == "3":
+                from diffdrr_amd.renderers import get_alpha_minmax
+
+                s_v, t_v, L_v = voxel_rays(drr, rot0, xyz0)
+                lo, hi = get_alpha_minmax(s_v, t_v, torch.tensor(drr.density.shape, device=device), 0.5, 1e-8)
+                a0, a1 = lo.min(), hi.max()
+                n_in = 0
+                d = t_v - s_v + 1e-8
+                for m0 in range(0, P, 32):  # samples whose 8-cell touches the volume
+                    al = a0 + (torch.arange(m0, min(P, m0 + 32), device=device) / (P - 1)) * (a1 - a0)
+                    x = s_v[:, :, None, :] + al[None, None, :, None] * d[:, :, None, :]
+                    inside = ((x > -1) & (x < D)).all(-1)
+                    n_in += int(inside.sum().item())
+                launch_units = B
+                alg_bytes = 32 * n_in + B * H * H * 20
+                per_unit = f"{n_in / (B * H * H):.1f} samples in the volume per ray x 32 B + 20 B per ray"
+                traffic_kind = "trilinear_forward"
+            else:
+                nposes = {"headline": B, "2": B, "4": 1, "5": min(512, -(-B // world))}[cfg]
+                if cfg == "4":
+                    s_v, t_v, L_v = voxel_rays(drr, r0, x0)
+                elif cfg == "5":
+                    s_v, t_v, L_v = voxel_rays(drr, rot0[:nposes], xyz0[:nposes])
+                else:
+                    s_v, t_v, L_v = voxel_rays(drr, rot0, xyz0)
+                nv_total = 0
+                for a in range(0, nposes, 64):
+                    _, _, nvox = ops.siddon_forward(drr.density.detach(), s_v[a:a + 64], t_v[a:a + 64],
+                                                    L_v[a:a + 64], count_voxels=True, det=(H, H))
+                    nv_total += int(nvox.sum().item())
+                launch_units = nposes
+                alg_bytes = 4 * nv_total + nposes * H * H * 20 + 12 * nposes
+                per_unit = (f"{nv_total / (nposes * H * H):.1f} voxels per ray x 4 B + 20 B per ray "
+                            f"(target 12 + img 4 + out 4) + 12 B per source")
+                traffic_kind = "forward_record" if cfg in ("headline", "2", "4") else "forward"
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        traffic = traffic_record(traffic_kind) if (D, H) == (512, 256) and cfg in ("headline", "5") else None
+        log(f"[bench] config {cfg}: step {ms_per_step:.3f} ms | {k_name} {k_ms:.3f} ms per launch, "
+            f"{per_step:.1f} launch(es) per step | backward kernels {bwd_ms:.3f} ms per step | "
+            f"{per_unit} | {alg_bytes / launch_units / 1e6:.1f} MB algorithmic per DRR")
         result = {
-            "metric": f"DRRs/sec fwd+bwd, {D}^3 vol -> {H}^2 det, batched poses",  # BASELINE.json's at the defaults
-            "value": total_drrs / dt,
-            "unit": "DRRs/s",
+            "metric": metric,
+            "value": units_per_step * steps / dt,
+            "unit": unit,
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
+            "steps": steps,
+            "warmup": warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{D}^3 fp32 noise volume -> {H}x{H} detector, Siddon forward + "
-                            f"backward w.r.t. 6-DoF pose (euler ZXY) through NCC, "
-                            f"{B} perturbed poses per GPU per step",
+                "workload": workload,
+                "baseline_config": cfg,
                 "volume": f"{D}x{D}x{D} f32 ({D ** 3 * 4 / 2 ** 20:.0f} MiB, replicated per GPU)",
                 "detector": f"{H}x{H}",
-                "batch_per_gpu": B,
-                "global_batch": B * world,
-                "parallelism": f"pose-sharded x{world}, all_gather of per-pose losses (RCCL)"
-                               if world > 1 else "single GPU",
+                "batch_per_gpu": B if scaling == "weak" else -(-B // world),
+                "global_batch": B * world if scaling == "weak" else B,
+                "parallelism": (f"pose-sharded x{world}, all_gather of per-pose values (RCCL)"
+                                if world > 1 else "single GPU"),
             },
             "roofline": {
-                "kernel": fwd_name,
+                "kernel": k_name,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_source": traffic_src,
+                "traffic": traffic[0] if traffic else None,
+                "traffic_source": (traffic[1] + " (separate rocprofv3 --pmc passes of this command, "
+                                   "committed; not measured in this run)") if traffic else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "kernel_ms": fwd_ms,
-                "launches_per_step": n_fwd // args.steps,
-                "launches_timed": n_fwd,
+                "algorithmic_bytes_per_unit": per_unit,
+                "units_per_launch": launch_units,
+                "kernel_ms": k_ms,
+                "launches_per_step": per_step,
+                "launches_timed": k_n,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(drr, rot0, xyz0)
+        if world == 1 and not args.no_cpu_baseline and cfg in ("headline", "2"):
+            result["cpu_baseline"], result["parity"] = cpu_baseline_and_parity(
+                drr, rot0, xyz0, images, H)
+        result.update(extra)
         print(json.dumps(result), flush=True)
 
     if world > 1:

@@ -101,3 +101,35 @@ def test_pose_sharded_sweep_world2_matches_single_process(emulated_ops):
     for _, vals, _ in got:  # every rank holds the full, identical result
         assert torch.allclose(torch.tensor(vals), ref, rtol=0, atol=1e-6)
     assert ref.shape == (7,) and torch.isfinite(ref).all()
+
+
+@pytest.mark.parametrize("config,extra", [("headline", ["--batch", "3"]), ("5", ["--batch", "7"])])
+def test_bench_harness_spawns_its_ranks(config, extra):
+    """`python bench.py --gpus 2` with no launcher starts two ranks itself (torch.distributed.run,
+    127.0.0.1), runs its step on both and rank 0 prints the contract's JSON line with the world
+    size the process group really has.  CPU stand-in: gloo + the host emulation of the kernels
+    (bench.py --device cpu, tests/bench_emu_hook.py); tiny sizes."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, DDRR_BENCH_HOOK="bench_emu_hook",
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests"), ROOT,
+                                           os.environ.get("PYTHONPATH", "")]))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "cpu",
+           "--config", config, "--size", "24", "--det", "16", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", *extra]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1
+    assert out["value"] > 0 and out["unit"] == "DRRs/s" and out["higher_is_better"] is True
+    if config == "headline":
+        assert out["scaling"] == "weak" and out["config"]["global_batch"] == 6
+        assert abs(out["value"] - 6 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    else:
+        assert out["scaling"] == "strong" and out["config"]["global_batch"] == 7
+    assert out["roofline"]["kernel"] == "ddrr_siddon_forward_bricks" and out["roofline"]["frac"] > 0
