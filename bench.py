@@ -330,36 +330,40 @@ def main():
         g = torch.Generator().manual_seed(1 + rank)
         r0 = true_rot + ((torch.rand(1, 3, generator=g) - 0.5) * 0.4).to(device)   # +-0.2 rad
         x0 = true_xyz + ((torch.rand(1, 3, generator=g) - 0.5) * 60.0).to(device)  # +-30 mm
-        state = {}
+        # Adam (registration.ipynb:569 learning rates); capturable: the whole iteration is one
+        # HIP graph (diffdrr_amd.registration.GraphedIteration), falling back to the eager loop
+        from diffdrr_amd import GraphedIteration
 
-        def restart():
-            state["reg"] = Registration(drr, r0.clone(), x0.clone(), parameterization="euler_angles",
-                                        convention="ZXY")
-            state["opt"] = torch.optim.Adam([{"params": [state["reg"]._rotation], "lr": 1e-1},
-                                             {"params": [state["reg"]._translation], "lr": 5e0}],
-                                            maximize=True)
-            state["it"] = 0
-
-        restart()
+        reg = Registration(drr, r0.clone(), x0.clone(), parameterization="euler_angles", convention="ZXY")
+        opt = torch.optim.Adam([{"params": [reg._rotation], "lr": 1e-1},
+                                {"params": [reg._translation], "lr": 5e0}], maximize=True,
+                               capturable=on_gpu)
         pending, keep = [], {}
+        try:
+            if not on_gpu:
+                raise RuntimeError("no HIP graphs on the cpu harness")
+            graphed = GraphedIteration(reg, ncc, opt, gt)
+            extra["registration"] = {"hip_graph": True}
+        except Exception as exc:  # noqa: BLE001
+            log(f"[bench] config 4: eager loop ({type(exc).__name__}: {exc})")
+            graphed = None
+            extra["registration"] = {"hip_graph": False}
 
         def step():
-            # every 100 iterations the loop restarts from the perturbed pose: the timed region is
-            # the registration loop at its working rate, converged or not
-            if state["it"] == 100:
-                restart()
-            state["opt"].zero_grad()
-            loss = ncc(gt, state["reg"]()).sum()
+            # (the loop keeps running at the optimum once converged: same work per iteration)
+            if graphed is not None:
+                return graphed().reshape(1)
+            opt.zero_grad()
+            loss = ncc(gt, reg()).sum()
             loss.backward()
-            state["opt"].step()
-            state["it"] += 1
+            opt.step()
             return loss.detach().reshape(1)
 
         units_per_step, unit, scaling = world, "iterations/s", "weak"
         metric = f"registration iterations/sec, {D}^3 vol -> {H}^2 det, SE(3) gradient ascent on NCC"
         workload = (f"{D}^3 fp32 phantom volume -> {H}x{H} detector, Siddon "
                     f"(stop_gradients_through_grid_sample), Registration + NCC + Adam(1e-1 / 5e0), "
-                    f"one pose per GPU, restart every 100 iterations")
+                    f"one pose per GPU, one HIP graph per iteration")
         dominant = "ddrr_siddon_forward_bricks"
     else:  # "5": the candidate-pose sweep, sharded (strong scaling)
         subject = make_subject(noise_volume(D, seed=0), spacing=(1.0, 1.0, 1.0), orientation="AP")
@@ -396,6 +400,12 @@ def main():
     if cfg in ("headline", "2"):
         assert torch.isfinite(rot.grad).all() and torch.isfinite(xyz.grad).all()
         images = keep["img"].detach()
+    if cfg == "4":
+        extra["registration"].update(
+            ncc_after=float(last.item()), iterations=warmup + steps,
+            rot_error_rad=float((reg.rotation.detach() - true_rot).abs().max().item()),
+            xyz_error_mm=float((reg.translation.detach() - true_xyz).abs().max().item()),
+            start="U(+-0.2 rad, +-30 mm) from the true pose")
 
     t_max = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:

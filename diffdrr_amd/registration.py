@@ -38,3 +38,47 @@ class Registration(nn.Module):
     @property
     def translation(self):
         return self._translation
+
+
+class GraphedIteration:
+    """One registration iteration -- render, similarity, backward, optimizer step -- captured
+    once as a HIP graph and replayed: the loop of reference
+    ``notebooks/tutorials/registration.ipynb:240-316`` without the ~0.5 ms of Python / autograd
+    / launch overhead per iteration that dwarfs its ~0.25 ms of GPU work at 512^3 -> 256^2
+    (``profiles/r01/config4_registration_v2.txt``).
+
+        step = GraphedIteration(reg, criterion, optimizer, target)
+        for it in range(n):
+            loss = step()          # replays the graph; `loss` is a device tensor (no sync)
+
+    The optimizer must not synchronise in ``step()`` (``torch.optim.SGD``; Adam with
+    ``capturable=True``).  Everything the iteration touches keeps its address: the parameters
+    of ``reg`` and the optimizer state are updated in place, ``target`` is read in place.
+    ``maximize`` / learning rates are whatever the optimizer was built with."""
+
+    def __init__(self, reg: Registration, criterion, optimizer, target: torch.Tensor,
+                 warmup: int = 3, **render_kwargs):
+        self.reg, self.criterion, self.optimizer, self.target = reg, criterion, optimizer, target
+        self.render_kwargs = render_kwargs
+
+        def iteration():
+            optimizer.zero_grad(set_to_none=True)
+            loss = criterion(target, reg(**render_kwargs)).sum()
+            loss.backward()
+            optimizer.step()
+            return loss.detach()
+
+        # warm up on a side stream (first-call costs and lazy initialisations must not be captured)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                iteration()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = iteration()
+
+    def __call__(self) -> torch.Tensor:
+        self.graph.replay()
+        return self.loss

@@ -207,3 +207,42 @@ def test_config4_registration_trajectory_on_gpu(gpu, stop):
     # is enough.  What must hold is the optimisation: same level of similarity, still rising.
     assert abs(losses[-1] - g[f"losses_{tag}"][-1]) < 1e-2
     assert min(losses[5:]) > g[f"losses_{tag}"][3] - 5e-3 and losses[-1] > losses[1]
+
+
+def test_graphed_registration_iteration_equals_eager_loop(gpu):
+    """diffdrr_amd.GraphedIteration (one HIP graph per registration iteration) against the eager
+    loop it captures: same losses, same parameters (SGD, the tutorial's learning rates)."""
+    from diffdrr_amd import GraphedIteration
+    from diffdrr_amd.data import synthetic_subject
+
+    drr = DRR(synthetic_subject(96, kind="phantom", seed=0), sdd=1020.0, height=64, delx=4.0,
+              stop_gradients_through_grid_sample=True).to(gpu)
+    true_rot = torch.zeros(1, 3, device=gpu)
+    true_xyz = torch.tensor([[0.0, 850.0, 0.0]], device=gpu)
+    with torch.no_grad():
+        gt = drr(true_rot, true_xyz, parameterization="euler_angles", convention="ZXY")
+    r0 = true_rot + torch.tensor([[0.08, -0.05, 0.06]], device=gpu)
+    x0 = true_xyz + torch.tensor([[8.0, -5.0, 6.0]], device=gpu)
+    crit = NormalizedCrossCorrelation2d()
+
+    def make():
+        reg = Registration(drr, r0.clone(), x0.clone(), parameterization="euler_angles", convention="ZXY")
+        opt = torch.optim.SGD([{"params": [reg._rotation], "lr": 5e-2},
+                               {"params": [reg._translation], "lr": 1e2}], maximize=True)
+        return reg, opt
+
+    reg_e, opt_e = make()
+    eager = []
+    for _ in range(3 + 12):  # GraphedIteration warms up with 3 real iterations
+        opt_e.zero_grad()
+        loss = crit(gt, reg_e()).sum()
+        loss.backward()
+        opt_e.step()
+        eager.append(loss.item())
+    reg_g, opt_g = make()
+    step = GraphedIteration(reg_g, crit, opt_g, gt, warmup=3)
+    graphed = [step().item() for _ in range(11)]
+    # (capture itself runs no iteration: after the 3 warm-up iterations the graph continues
+    # with iteration 4; atomics make sums order-dependent in the last bits)
+    assert np.allclose(graphed, eager[3:14], atol=2e-4), (graphed, eager[3:14])
+    assert graphed[-1] > graphed[0]
