@@ -109,7 +109,7 @@ class DRR(nn.Module):
                 calibration: RigidTransform = None, mask_to_channels: bool = False,
                 degrees: bool = False, **kwargs):
         """Render DRRs for a batch of poses (``RigidTransform`` or raw parameters)."""
-        fused = self._fused_ok(mask_to_channels, kwargs)
+        fused = self._fused_ok(mask_to_channels, kwargs, calibration)
         if (fused and parameterization == "euler_angles" and len(args) == 2
                 and all(torch.is_tensor(a) and a.dim() == 2 and a.shape[-1] == 3
                         and a.dtype == torch.float32 and ops.on_device(a) for a in args)):
@@ -127,11 +127,16 @@ class DRR(nn.Module):
             return self.reshape_transform(self._render_fused(pose, calibration),
                                           batch_size=len(pose))
         source, target = self.detector(pose, calibration)
-        if self.checkpoint_gradients:
-            img = checkpoint(self.render, self.density, source, target, mask_to_channels,
-                             **kwargs, use_reentrant=False)
-        else:
-            img = self.render(self.density, source, target, mask_to_channels, **kwargs)
+        # (rays straight out of the Detector: a row-major affine grid by construction)
+        self._rays_from_detector = True
+        try:
+            if self.checkpoint_gradients:
+                img = checkpoint(self.render, self.density, source, target, mask_to_channels,
+                                 **kwargs, use_reentrant=False)
+            else:
+                img = self.render(self.density, source, target, mask_to_channels, **kwargs)
+        finally:
+            self._rays_from_detector = False
         return self.reshape_transform(img, batch_size=len(pose))
 
     # The DRR case end to end on the GPU: pose -> rays -> line integrals without the
@@ -139,9 +144,12 @@ class DRR(nn.Module):
     # in the same order as `detector(...)` + `render(...)` (reference detector.py:144-154,
     # drr.py:191-227); used whenever nothing asks for a feature only the general path has.
     fuse_ray_generation = True
+    _rays_from_detector = False  # set around the render call of forward()
 
-    def _fused_ok(self, mask_to_channels, kwargs):
+    def _fused_ok(self, mask_to_channels, kwargs, cal=None):
         r = self.renderer
+        if cal is not None and getattr(getattr(cal, "matrix", None), "requires_grad", False):
+            return False  # gradients w.r.t. the intrinsics flow through Detector.forward only
         return (self.fuse_ray_generation and isinstance(r, Siddon) and r.supports_pose_entry()
                 and ops.on_device(self.density) and self.density.dtype == torch.float32
                 and not mask_to_channels and not kwargs and not self.checkpoint_gradients
@@ -183,6 +191,14 @@ class DRR(nn.Module):
         kwargs["mask"] = self.mask if mask_to_channels else None
         full_grid = (self.detector.n_subsample is None and self.patch_size is None and
                      target.shape[1] == self.detector.height * self.detector.width)
+        # `detector_shape` is a CONTRACT with the renderer, not a hint: the volume-stationary
+        # kernels cull rays with an affine model of the detector grid.  Rays that forward() got
+        # from the Detector satisfy it by construction; rays handed to render() directly (the
+        # tutorials do, reconstruction.ipynb:122) are checked once (one reduction, one sync) and
+        # rendered by the per-ray kernels if they are not such a grid (permuted, subsampled ...).
+        if full_grid and not self._rays_from_detector and ops.on_device(target):
+            full_grid = ops.rays_form_detector_grid(source, target, self.detector.height,
+                                                    self.detector.width)
         self.renderer.detector_shape = \
             (self.detector.height, self.detector.width) if full_grid else None
         if self.patch_size is None:

@@ -95,6 +95,26 @@ def _empty(B, N):
     return B == 0 or N == 0
 
 
+def rays_form_detector_grid(source, target, det_h, det_w, tol=2e-3) -> bool:
+    """Whether ``target`` (B, det_h * det_w, 3) is, per pose, the row-major affine grid
+    ``t00 + i e_i + j e_j`` the volume-stationary kernels assume (they cull candidate rays with
+    that model; rays that do not follow it would be dropped silently), within ``tol`` voxels.
+    One fused reduction and ONE host sync: meant for ray lists of unknown provenance
+    (``DRR.render`` called directly); rays that come out of ``Detector.forward`` are such a grid
+    by construction (reference detector.py:126, 147-153) and are not checked."""
+    B, N, _ = target.shape
+    if N != det_h * det_w or min(det_h, det_w) < 2 or source.shape[1] != 1:
+        return False
+    t = target.detach().reshape(B, det_h, det_w, 3)
+    t00 = t[:, :1, :1]
+    ei = (t[:, -1:, :1] - t00) / (det_h - 1)
+    ej = (t[:, :1, -1:] - t00) / (det_w - 1)
+    i = torch.arange(det_h, device=t.device, dtype=t.dtype).view(1, det_h, 1, 1)
+    j = torch.arange(det_w, device=t.device, dtype=t.dtype).view(1, 1, det_w, 1)
+    dev = (t00 + i * ei + j * ej - t).abs().amax()
+    return bool((dev <= tol).item())
+
+
 def _hints(det, tile, N):
     if det is None or det[0] * det[1] != N:
         return 0, 0, 1, 64

@@ -7,11 +7,12 @@ HIP kernels of ``libdiffdrr_hip.so`` through ``torch.autograd.Function``s, so a
 ``DRR`` module (ours or the reference's) differentiates
 w.r.t. pose, ray endpoints and the volume exactly as before.
 
-Unsupported corners raise instead of silently diverging: callable ``reducefn``
-(the per-segment tensor is never materialised), fp64, CPU tensors, and
-gradients through the rarely used Siddon ``mode="bilinear"`` /
-``align_corners=True`` / ``reducefn="max"``-with-Trilinear variants (their
-forward passes are supported).
+Every combination the reference accepts is rendered and differentiated by kernels: sum / max /
+callable ``reducefn`` (the latter over the materialised per-segment / per-sample tensor),
+``mode`` nearest / bilinear, any ``align_corners``, ``mask`` channels, per-ray sources.  What
+raises instead of silently diverging: CPU tensors (there is no CPU fallback) and dtypes other
+than float32 / float64 (float64 modules render through the fp64 instantiation of the per-ray
+kernels, like ``DRR.to(torch.float64)`` in the reference, drr.py:71-75).
 """
 from __future__ import annotations
 

@@ -522,3 +522,94 @@ def test_record_pack_roundtrip():
     lo_sum = ((packed & 0xFFFFFFFF).astype(np.uint32)).astype(np.int32).astype(np.int64)
     hi_sum = (packed - lo_sum) // 2**32
     assert np.array_equal(lo_sum, lo.sum(1)) and np.array_equal(hi_sum, hi.sum(1))
+
+
+# ------------------------------------------------ regressions from the round-1 review
+
+def _small_drr(renderer="siddon", **kw):
+    from diffdrr_amd.data import synthetic_subject
+
+    return DRR(synthetic_subject(40, kind="noise", seed=0, n_labels=5), sdd=400.0, height=22,
+               width=30, delx=1.8, renderer=renderer, **kw)
+
+
+def test_render_with_permuted_rays_is_not_taken_for_a_detector_grid(emulated_ops):
+    """`DRR.render` is public (reconstruction.ipynb:122 calls it): rays that are NOT the
+    row-major detector grid must not reach the volume-stationary kernels, which cull rays with
+    an affine model of that grid -- permuted rays render to the same values, permuted."""
+    drr = _small_drr()
+    rot = torch.tensor([[0.3, -0.2, 0.4]])
+    xyz = torch.tensor([[5.0, 250.0, -3.0]])
+    pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    source, target = drr.detector(pose, None)
+    with torch.no_grad():
+        ref = drr.render(drr.density, source, target)
+        assert drr.renderer.detector_shape == (22, 30)      # a true grid: checked, accepted
+        perm = torch.randperm(target.shape[1], generator=torch.Generator().manual_seed(0))
+        out = drr.render(drr.density, source, target[:, perm])
+        assert drr.renderer.detector_shape is None            # not a grid: per-ray kernels
+    assert rel_err(out.numpy(), ref[..., perm].numpy()) < 2e-5
+    assert not emulated_ops.rays_form_detector_grid(source, target[:, perm], 22, 30)
+    assert emulated_ops.rays_form_detector_grid(source, target, 22, 30)
+
+
+def test_mask_label_cache_is_tied_to_the_mask_object(emulated_ops):
+    """A new mask that lands at a freed mask's address must not be served the old labels."""
+    from diffdrr_amd.renderers import _labels_u8
+
+    seen = []
+    for trial in range(20):
+        n = 3 + trial % 5
+        mask = torch.randint(0, n, (6, 6, 6), generator=torch.Generator().manual_seed(trial)).float()
+        mask[0, 0, 0] = n - 1
+        lab, C = _labels_u8(mask)
+        assert C == n and torch.equal(lab.float(), mask)
+        seen.append(C)
+        del mask, lab
+    a = torch.zeros(4, 4, 4)
+    lab0, C0 = _labels_u8(a)
+    a[0, 0, 0] = 2                      # in-place change: the version moves
+    lab1, C1 = _labels_u8(a)
+    assert (C0, C1) == (1, 3)
+
+
+@pytest.mark.parametrize("renderer", ["siddon", "trilinear"])
+def test_non_contiguous_volume_views(emulated_ops, renderer):
+    """A permuted view of a volume renders like its contiguous copy (the kernels take raw
+    pointers: every entry point makes its inputs contiguous)."""
+    from diffdrr_amd import Siddon, Trilinear
+
+    drr = _small_drr(renderer)
+    pose = convert(torch.tensor([[0.2, 0.1, -0.3]]), torch.tensor([[2.0, 240.0, 4.0]]),
+                   parameterization="euler_angles", convention="ZXY")
+    source, target = drr.detector(pose, None)
+    img = (target - source).norm(dim=-1).unsqueeze(1)
+    s, t = drr.affine_inverse(source), drr.affine_inverse(target)
+    vol = drr.density
+    view = vol.permute(2, 1, 0).contiguous().permute(2, 1, 0)   # same values, other strides
+    assert not view.is_contiguous() and torch.equal(view, vol)
+    mod = Siddon() if renderer == "siddon" else Trilinear()
+    kw = {} if renderer == "siddon" else {"n_points": 40}
+    with torch.no_grad():
+        assert rel_err(mod(view, s, t, img, **kw).numpy(), mod(vol, s, t, img, **kw).numpy()) < 1e-6
+    v = view.clone().requires_grad_()
+    mod(v.permute(0, 1, 2), s, t, img, **kw).sum().backward()
+    assert torch.isfinite(v.grad).all() and v.grad.abs().max() > 0
+
+
+def test_calibration_that_requires_grad_takes_the_general_path(emulated_ops):
+    """Gradients w.r.t. a user calibration flow through Detector.forward (reference
+    detector.py:147-150): the fused pose entry must step aside for them."""
+    from diffdrr_amd import RigidTransform
+
+    drr = _small_drr()
+    rot = torch.tensor([[0.1, 0.2, -0.1]])
+    xyz = torch.tensor([[1.0, 250.0, 2.0]])
+    M = drr.detector.calibration.matrix.detach().clone().requires_grad_()
+    img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY",
+              calibration=RigidTransform(M))
+    img.sum().backward()
+    assert M.grad is not None and M.grad.abs().max() > 0
+    with torch.no_grad():
+        plain = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    assert rel_err(img.detach().numpy(), plain.numpy()) < 2e-5
