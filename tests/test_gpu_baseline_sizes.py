@@ -246,3 +246,15 @@ def test_graphed_registration_iteration_equals_eager_loop(gpu):
     # with iteration 4; atomics make sums order-dependent in the last bits)
     assert np.allclose(graphed, eager[3:14], atol=2e-4), (graphed, eager[3:14])
     assert graphed[-1] > graphed[0]
+
+
+def test_hu_to_density_on_the_gpu(gpu):
+    """The HU -> density ingest (reference data.py:214-227) on device tensors: bit-identical to
+    the fixture made from the reference's own source."""
+    from diffdrr_amd.data import transform_hu_to_density
+
+    g = golden("hu_to_density")
+    vol = torch.from_numpy(g["volume"]).to(gpu)
+    for m in (1.0, 2.5):
+        out = transform_hu_to_density(vol, m)
+        assert out.is_cuda and np.array_equal(out.cpu().numpy(), g[f"density_{m}"])

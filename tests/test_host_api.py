@@ -613,3 +613,14 @@ def test_calibration_that_requires_grad_takes_the_general_path(emulated_ops):
     with torch.no_grad():
         plain = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
     assert rel_err(img.detach().numpy(), plain.numpy()) < 2e-5
+
+
+def test_hu_to_density_matches_reference():
+    """Ingest: HU -> [0, 1] density (reference data.py:214-227), bit for bit, on the fixture
+    made from the reference's own source (tests/golden/make_golden_ingest.py)."""
+    from diffdrr_amd.data import transform_hu_to_density
+
+    g = golden("hu_to_density")
+    vol = T(g["volume"])
+    for m in (1.0, 2.5):
+        assert np.array_equal(transform_hu_to_density(vol, m).numpy(), g[f"density_{m}"])
