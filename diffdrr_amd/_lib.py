@@ -11,11 +11,11 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_float, c_int, c_long, c_void_p
+from ctypes import c_double, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffdrr_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 REDUCE_SUM, REDUCE_MAX = 0, 1
 LOOKUP_STEP, LOOKUP_MID_NEAREST, LOOKUP_MID_TRILINEAR = 0, 1, 2
@@ -24,7 +24,7 @@ AUX_INTERLEAVED, AUX_PLANAR, AUX_PACKED = 0, 1, 2
 BRICK_AUX_PLANES = 5
 PACKED_AUX_PLANES = 7  # fixed-point record (csrc/record_pack.h)
 
-_P, _I, _F, _L = c_void_p, c_int, c_float, c_long
+_P, _I, _F, _L, _D = c_void_p, c_int, c_float, c_long, c_double
 
 # name -> argtypes, in the order of include/diffdrr_hip.h
 _SIGNATURES = {
@@ -71,6 +71,13 @@ _SIGNATURES = {
     "ddrr_ncc_backward": [_P, _L, _P, _P, _P, _I, _I, _P, _P, _P],
     "ddrr_raygen_forward": [_P, _P, _P, _I, _I, _P, _P, _P, _P],
     "ddrr_siddon_backward_pose": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P, _P],
+    "ddrr_siddon_forward_f64": [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _D, _D, _I, _P, _P, _P],
+    "ddrr_siddon_backward_f64": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _I, _D, _D, _P, _P, _P,
+                                 _P, _P],
+    "ddrr_trilinear_forward_f64": [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _D, _D, _I, _P, _P, _P,
+                                   _P],
+    "ddrr_trilinear_backward_f64": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _D, _D, _I, _P, _P,
+                                    _P, _P, _P, _P, _P, _P],
 }
 EXPORTS = ["ddrr_abi_version", "ddrr_last_error", *_SIGNATURES]
 

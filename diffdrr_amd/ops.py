@@ -67,14 +67,15 @@ def _launch(name, device, *args):
         _lib.get_lib().call(name, *args, torch.cuda.current_stream().cuda_stream)
 
 
-def _check_rays(volume, source, target, img):
+def _check_rays(volume, source, target, img, dtype=torch.float32):
     _require_gpu(volume)
     for name, t in (("volume", volume), ("source", source), ("target", target), ("img", img)):
         if t is None:
             continue
-        if t.dtype != torch.float32:
-            raise NotImplementedError(f"{name} must be float32 (got {t.dtype}): the HIP kernels "
-                                      "are fp32 like the reference's default")
+        if t.dtype != dtype:
+            raise NotImplementedError(
+                f"{name} must be {dtype} here (got {t.dtype}): the tuned kernels are fp32 like the "
+                "reference's default; float64 modules render through the *_f64 entry points")
         if t.device != volume.device:
             raise RuntimeError(f"{name} is on {t.device}, volume on {volume.device}")
     if volume.dim() != 3:
@@ -691,4 +692,84 @@ def trilinear_backward(volume, source, target, img, grad_out, alphamin, alphamax
         float(voxel_shift), float(eps), int(n_points), alphamin.data_ptr(),
         alphamax.data_ptr(), int(mode == "nearest"), int(bool(align_corners)), dh, dw, th, tw,
         _ptr(g_source), _ptr(g_target), _ptr(g_img), _ptr(g_alpha), _ptr(g_volume))
+    return res
+
+
+# ---------------------------------------------------------------- double precision
+# (`DRR(...).to(torch.float64)`, reference drr.py:71-75: per-ray kernels of csrc/f64_rays.hip)
+
+def siddon_forward_f64(volume, source, target, img, *, voxel_shift=0.5, eps=1e-8, reducefn="sum",
+                       want_aux=False):
+    """-> (out (B,N) float64, aux (B,N,8) float64 | None)"""
+    B, N = _check_rays(volume, source, target, img, torch.float64)
+    volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    out = torch.empty(B, N, dtype=torch.float64, device=volume.device)
+    aux = torch.empty(B, N, SIDDON_AUX, dtype=torch.float64, device=volume.device) \
+        if want_aux else None
+    if not _empty(B, N):
+        _launch("ddrr_siddon_forward_f64", volume.device, volume.data_ptr(), *volume.shape,
+                source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img), B, N,
+                float(voxel_shift), float(eps), reduce_code(reducefn), out.data_ptr(), _ptr(aux))
+    return out, aux
+
+
+def siddon_backward_f64(volume_shape, source, target, img, grad_out, aux, *, voxel_shift=0.5,
+                        eps=1e-8, want_rays=True, want_img=True, want_volume=False):
+    """-> (g_source per ray (B,N,3), g_target (B,N,3), g_img (B,N), g_volume), None where not asked"""
+    B, N, _ = target.shape
+    dev = target.device
+    new = lambda *s: torch.empty(*s, dtype=torch.float64, device=dev)  # noqa: E731
+    g_source = new(B, N, 3) if want_rays else None
+    g_target = new(B, N, 3) if want_rays else None
+    g_img = new(B, N) if want_img else None
+    Dx, Dy, Dz = (int(v) for v in volume_shape)
+    g_volume = torch.zeros(Dx, Dy, Dz, dtype=torch.float64, device=dev) if want_volume else None
+    if not _empty(B, N):
+        source, target, grad_out = source.contiguous(), target.contiguous(), grad_out.contiguous()
+        img = None if img is None else img.contiguous()
+        _launch("ddrr_siddon_backward_f64", dev, Dx, Dy, Dz, source.data_ptr(), source.shape[1],
+                target.data_ptr(), _ptr(img), grad_out.data_ptr(), _ptr(aux), B, N,
+                float(voxel_shift), float(eps), _ptr(g_source), _ptr(g_target), _ptr(g_img),
+                _ptr(g_volume))
+    return g_source, g_target, g_img, g_volume
+
+
+def trilinear_forward_f64(volume, source, target, img, alphamin, alphamax, *, n_points=500,
+                          voxel_shift=0.5, eps=1e-8):
+    B, N = _check_rays(volume, source, target, img, torch.float64)
+    volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    out = torch.empty(B, N, dtype=torch.float64, device=volume.device)
+    if not _empty(B, N):
+        _launch("ddrr_trilinear_forward_f64", volume.device, volume.data_ptr(), *volume.shape,
+                source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img), B, N,
+                float(voxel_shift), float(eps), int(n_points), alphamin.data_ptr(),
+                alphamax.data_ptr(), out.data_ptr())
+    return out
+
+
+def trilinear_backward_f64(volume, source, target, img, grad_out, alphamin, alphamax, *,
+                           n_points=500, voxel_shift=0.5, eps=1e-8, want_rays=True, want_img=True,
+                           want_alpha=True, want_volume=False):
+    """-> dict(g_source per ray, g_target, g_img, g_alpha (B,N,2), g_volume)"""
+    B, N = _check_rays(volume, source, target, img, torch.float64)
+    dev = volume.device
+    new = lambda *s: torch.empty(*s, dtype=torch.float64, device=dev)  # noqa: E731
+    res = {"g_source": new(B, N, 3) if want_rays else None,
+           "g_target": new(B, N, 3) if want_rays else None,
+           "g_img": new(B, N) if want_img else None,
+           "g_alpha": new(B, N, 2) if want_alpha else None,
+           "g_volume": torch.zeros_like(volume, memory_format=torch.contiguous_format)
+           if want_volume else None}
+    if not _empty(B, N):
+        volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
+        img = None if img is None else img.contiguous()
+        grad_out = grad_out.contiguous()
+        _launch("ddrr_trilinear_backward_f64", dev, volume.data_ptr(), *volume.shape,
+                source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img),
+                grad_out.data_ptr(), B, N, float(voxel_shift), float(eps), int(n_points),
+                alphamin.data_ptr(), alphamax.data_ptr(), _ptr(res["g_source"]),
+                _ptr(res["g_target"]), _ptr(res["g_img"]), _ptr(res["g_alpha"]),
+                _ptr(res["g_volume"]))
     return res

@@ -139,6 +139,76 @@ class _SiddonFn(torch.autograd.Function):
         return g_vol, g_s, g_t, g_i, None
 
 
+class _SiddonF64Fn(torch.autograd.Function):
+    """The Siddon renderer in double precision (csrc/f64_rays.hip): what a reference module
+    moved `.to(torch.float64)` computes (drr.py:71-75).  mode="nearest", align_corners=False;
+    reducefn sum (differentiable) or max (forward)."""
+
+    @staticmethod
+    def forward(ctx, volume, source, target, img, cfg):
+        need_rays = any(ctx.needs_input_grad[1:4])
+        out, aux = ops.siddon_forward_f64(
+            volume, source, target, img, voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
+            reducefn=cfg["reducefn"], want_aux=bool(need_rays and cfg["reducefn"] == "sum"))
+        ctx.cfg = cfg
+        ctx.save_for_backward(volume, source, target, img, aux)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        volume, source, target, img, aux = ctx.saved_tensors
+        cfg = ctx.cfg
+        if cfg["reducefn"] != "sum":
+            raise NotImplementedError("float64 gradients are implemented for reducefn='sum'")
+        need_vol, need_s, need_t, need_i = ctx.needs_input_grad[:4]
+        stop = cfg["stop_gradients"]
+        gs, gt, gi, gv = ops.siddon_backward_f64(
+            volume.shape, source, target, img, grad_out.contiguous(), aux,
+            voxel_shift=cfg["voxel_shift"], eps=cfg["eps"], want_rays=bool(need_s or need_t),
+            want_img=bool(need_i and not stop), want_volume=bool(need_vol and not stop))
+        g_s = None
+        if need_s:
+            g_s = gs.sum(dim=1, keepdim=True) if source.shape[1] == 1 else gs
+        return gv, g_s, (gt if need_t else None), (gi.view_as(img) if gi is not None else None), None
+
+
+class _TrilinearF64Fn(torch.autograd.Function):
+    """The marcher in double precision (csrc/f64_rays.hip): mode="bilinear", reducefn sum,
+    align_corners=False."""
+
+    @staticmethod
+    def forward(ctx, volume, source, target, img, alphamin, alphamax, cfg):
+        out = ops.trilinear_forward_f64(volume, source, target, img, alphamin, alphamax,
+                                        n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"],
+                                        eps=cfg["eps"])
+        ctx.cfg = cfg
+        ctx.save_for_backward(volume, source, target, img, alphamin, alphamax)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        volume, source, target, img, alphamin, alphamax = ctx.saved_tensors
+        cfg = ctx.cfg
+        need_vol, need_s, need_t, need_i, need_a0, need_a1 = ctx.needs_input_grad[:6]
+        r = ops.trilinear_backward_f64(
+            volume, source, target, img, grad_out, alphamin, alphamax, n_points=cfg["n_points"],
+            voxel_shift=cfg["voxel_shift"], eps=cfg["eps"], want_rays=bool(need_s or need_t),
+            want_img=bool(need_i), want_alpha=bool(need_a0 or need_a1), want_volume=bool(need_vol))
+        g_s = g_t = g_a0 = g_a1 = g_i = None
+        if need_s:
+            g_s = r["g_source"].sum(dim=1, keepdim=True) if source.shape[1] == 1 \
+                else r["g_source"]
+        if need_t:
+            g_t = r["g_target"]
+        if need_i:
+            g_i = r["g_img"].view_as(img)
+        if need_a0 or need_a1:
+            ga = r["g_alpha"].sum(dim=(0, 1))
+            g_a0 = ga[0].reshape(alphamin.shape) if need_a0 else None
+            g_a1 = ga[1].reshape(alphamax.shape) if need_a1 else None
+        return r["g_volume"], g_s, g_t, g_i, g_a0, g_a1, None
+
+
 class _SiddonChannelsFn(torch.autograd.Function):
     """mask_to_channels (renderers.py:77-89): out (B,C,N), channel c = the line integral over
     the voxels labelled c.  Backward: one ddrr_siddon_backward_channels launch (the ray is
@@ -316,6 +386,8 @@ class Siddon(torch.nn.Module):
     def forward(self, volume, source, target, img, align_corners=False, mask=None):
         B, N, _ = target.shape
         if callable(self.reducefn) and not isinstance(self.reducefn, str):
+            if volume.dtype == torch.float64:
+                raise NotImplementedError("float64 rendering covers reducefn 'sum' and 'max'")
             # a user reduction over the per-segment tensor (renderers.py:175-183,
             # introduction.ipynb:506-529): the tensor is materialised for it
             if self.mode != "nearest" or align_corners or mask is not None:
@@ -326,6 +398,14 @@ class Siddon(torch.nn.Module):
             terms = _SiddonSegmentsFn.apply(volume, source, target, img.reshape(B, N), cfg)
             return self.reducefn(terms).unsqueeze(1)
         cfg = self._cfg(align_corners)
+        if volume.dtype == torch.float64:
+            # a module moved .to(torch.float64) (reference drr.py:71-75): the fp64 kernels
+            if mask is not None or cfg["lookup"] != "step":
+                raise NotImplementedError("float64 rendering covers mode='nearest', "
+                                          "align_corners=False without a mask")
+            out = _SiddonF64Fn.apply(volume, source.to(volume), target.to(volume),
+                                     img.reshape(B, N).to(volume), cfg)
+            return out.unsqueeze(1)
         if mask is None:
             out = _SiddonFn.apply(volume, source, target, img.reshape(B, N), cfg)
             return out.unsqueeze(1)
@@ -550,6 +630,16 @@ class Trilinear(torch.nn.Module):
             alphamin, alphamax = lo.min(), hi.max()
         alphamin = torch.as_tensor(alphamin, dtype=volume.dtype, device=volume.device)
         alphamax = torch.as_tensor(alphamax, dtype=volume.dtype, device=volume.device)
+        if volume.dtype == torch.float64:
+            if user_reduce or mask is not None or self.mode != "bilinear" or align_corners \
+                    or self.reducefn != "sum":
+                raise NotImplementedError("float64 marching covers mode='bilinear', reducefn="
+                                          "'sum', align_corners=False without a mask")
+            fcfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift, "eps": self.eps}
+            out = _TrilinearF64Fn.apply(volume, source.to(volume), target.to(volume),
+                                        img.reshape(B, N).to(volume), alphamin.reshape(1),
+                                        alphamax.reshape(1), fcfg)
+            return out.unsqueeze(1)
         if user_reduce:
             # a user reduction over the per-sample tensor (renderers.py:236-240)
             if mask is not None:

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 16
+#define DDRR_ABI_VERSION 17
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -318,6 +318,41 @@ int ddrr_ncc_forward(const float *x1, long x1_stride, const float *x2, int B, in
 /* Gradient of ddrr_ncc_forward w.r.t. x2 (and x1 unless shared); either may be NULL. */
 int ddrr_ncc_backward(const float *x1, long x1_stride, const float *x2, const float *stats,
                       const float *g_out, int B, int N, float *g_x1, float *g_x2, void *stream);
+
+/* ---- double precision ---------------------------------------------------------------------
+ * The reference computes in the dtype its module holds: `DRR(...).to(torch.float64)` renders and
+ * differentiates in fp64 (drr.py:71-75; renderers.py:34-76, 205-241 follow their inputs' dtype).
+ * Same semantics as the fp32 entry points above, all pointers `double`; per-ray kernels (any
+ * ray list), for accuracy rather than speed:
+ *   Siddon     mode="nearest", align_corners=False, reducefn sum | max (forward);
+ *              aux: NULL or a (B, N, 8) record {I, S0_xyz, S1_xyz, -} of the sum for _backward
+ *   _backward  g_source (B, N, 3) per ray, g_target (B, N, 3), g_img (B, N) from the record;
+ *              g_volume (Dx, Dy, Dz), accumulated with atomics into a zero-filled array, by a
+ *              second walk; any of the four may be NULL
+ *   Trilinear  mode="bilinear", align_corners=False, reducefn sum; alphamin / alphamax: device
+ *              scalars (renderers.py:220-223); _backward additionally g_alpha (B, N, 2) per ray
+ *              (d / d alphamin, d / d alphamax: sum over rays on the caller's side). */
+int ddrr_siddon_forward_f64(const double *volume, int dx, int dy, int dz, const double *source,
+                            int src_n, const double *target, const double *img, int B, int N,
+                            double voxel_shift, double eps, int reduce_mode, double *out,
+                            double *aux, void *stream);
+int ddrr_siddon_backward_f64(int dx, int dy, int dz, const double *source, int src_n,
+                             const double *target, const double *img, const double *grad_out,
+                             const double *aux, int B, int N, double voxel_shift, double eps,
+                             double *g_source, double *g_target, double *g_img, double *g_volume,
+                             void *stream);
+int ddrr_trilinear_forward_f64(const double *volume, int dx, int dy, int dz, const double *source,
+                               int src_n, const double *target, const double *img, int B, int N,
+                               double voxel_shift, double eps, int n_points,
+                               const double *alphamin, const double *alphamax, double *out,
+                               void *stream);
+int ddrr_trilinear_backward_f64(const double *volume, int dx, int dy, int dz,
+                                const double *source, int src_n, const double *target,
+                                const double *img, const double *grad_out, int B, int N,
+                                double voxel_shift, double eps, int n_points,
+                                const double *alphamin, const double *alphamax, double *g_source,
+                                double *g_target, double *g_img, double *g_alpha, double *g_volume,
+                                void *stream);
 
 #ifdef __cplusplus
 }

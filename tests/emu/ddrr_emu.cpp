@@ -24,6 +24,7 @@
 #include "../../diffdrr_amd/csrc/segments_core.h"
 #include "../../diffdrr_amd/csrc/tri_brick.h"
 #include "../../diffdrr_amd/csrc/trilinear_core.h"
+#include "../../diffdrr_amd/csrc/f64_core.h"
 #include "../../include/diffdrr_hip.h"
 
 using namespace ddrr;
@@ -1034,6 +1035,103 @@ int ddrr_pose_euler_backward(const float *rot, const float *xyz, int a0, int a1,
     for (int b = 0; b < B; ++b)
         pose_euler_backward(rot + b * 3, xyz + b * 3, axes, reorient34, gMw + b * 12, g_rot + b * 3,
                             g_xyz + b * 3);
+    return 0;
+}
+
+// ---- double precision (csrc/f64_rays.hip): the same per-ray cores, host loops
+static void ray64(const double *source, int src_n, const double *target, long r, int N, double s[3],
+                  double t[3]) {
+    const long b = r / N, n = r - b * N;
+    for (int a = 0; a < 3; ++a) {
+        s[a] = source[(b * src_n + (src_n == 1 ? 0 : n)) * 3 + a];
+        t[a] = target[r * 3 + a];
+    }
+}
+
+int ddrr_siddon_forward_f64(const double *volume, int dx, int dy, int dz, const double *source,
+                            int src_n, const double *target, const double *img, int B, int N,
+                            double voxel_shift, double eps, int reduce_mode, double *out,
+                            double *aux, void *) {
+    const Dims D{dx, dy, dz};
+    for (long r = 0; r < (long)B * N; ++r) {
+        double s[3], t[3];
+        ray64(source, src_n, target, r, N, s, t);
+        out[r] = (img ? img[r] : 1.0) *
+                 ddrr64::siddon_forward_ray(volume, D, s, t, voxel_shift, eps,
+                                            reduce_mode == DDRR_REDUCE_MAX,
+                                            aux ? aux + r * ddrr64::kAux : nullptr);
+    }
+    return 0;
+}
+
+int ddrr_siddon_backward_f64(int dx, int dy, int dz, const double *source, int src_n,
+                             const double *target, const double *img, const double *grad_out,
+                             const double *aux, int B, int N, double voxel_shift, double eps,
+                             double *g_source, double *g_target, double *g_img, double *g_volume,
+                             void *) {
+    const Dims D{dx, dy, dz};
+    for (long r = 0; r < (long)B * N; ++r) {
+        double s[3], t[3];
+        ray64(source, src_n, target, r, N, s, t);
+        const double g = grad_out[r], L = img ? img[r] : 1.0;
+        if (aux && (g_source || g_target || g_img)) {
+            double gs[3], gt[3];
+            ddrr64::siddon_backward_ray(aux + r * ddrr64::kAux, s, t, eps, g * L, gs, gt);
+            for (int a = 0; a < 3; ++a) {
+                if (g_source) g_source[r * 3 + a] = gs[a];
+                if (g_target) g_target[r * 3 + a] = gt[a];
+            }
+            if (g_img) g_img[r] = g * aux[r * ddrr64::kAux];
+        }
+        if (g_volume && g * L != 0.0)
+            ddrr64::siddon_scatter_ray(D, s, t, voxel_shift, eps, g * L,
+                                       [&](long idx, double v) { g_volume[idx] += v; });
+    }
+    return 0;
+}
+
+int ddrr_trilinear_forward_f64(const double *volume, int dx, int dy, int dz, const double *source,
+                               int src_n, const double *target, const double *img, int B, int N,
+                               double voxel_shift, double eps, int n_points,
+                               const double *alphamin, const double *alphamax, double *out,
+                               void *) {
+    const Dims D{dx, dy, dz};
+    const double a0 = alphamin[0], a1 = alphamax[0];
+    for (long r = 0; r < (long)B * N; ++r) {
+        double s[3], t[3];
+        ray64(source, src_n, target, r, N, s, t);
+        out[r] = (img ? img[r] : 1.0) * ((a1 - a0) / (double)(n_points - 1)) *
+                 ddrr64::trilinear_forward_ray(volume, D, s, t, voxel_shift, eps, n_points, a0, a1);
+    }
+    return 0;
+}
+
+int ddrr_trilinear_backward_f64(const double *volume, int dx, int dy, int dz,
+                                const double *source, int src_n, const double *target,
+                                const double *img, const double *grad_out, int B, int N,
+                                double voxel_shift, double eps, int n_points,
+                                const double *alphamin, const double *alphamax, double *g_source,
+                                double *g_target, double *g_img, double *g_alpha, double *g_volume,
+                                void *) {
+    const Dims D{dx, dy, dz};
+    const double a0 = alphamin[0], a1 = alphamax[0];
+    for (long r = 0; r < (long)B * N; ++r) {
+        double s[3], t[3], gs[3], gt[3], ga[2];
+        ray64(source, src_n, target, r, N, s, t);
+        const double g = grad_out[r], L = img ? img[r] : 1.0;
+        const double sumT = ddrr64::trilinear_backward_ray(
+            volume, D, s, t, voxel_shift, eps, n_points, a0, a1, g * L, gs, gt, ga,
+            g_volume != nullptr, [&](long idx, double v) { g_volume[idx] += v; });
+        for (int a = 0; a < 3; ++a) {
+            if (g_source) g_source[r * 3 + a] = gs[a];
+            if (g_target) g_target[r * 3 + a] = gt[a];
+        }
+        if (g_img) g_img[r] = g * ((a1 - a0) / (double)(n_points - 1)) * sumT;
+        if (g_alpha) {
+            g_alpha[r * 2] = ga[0];
+            g_alpha[r * 2 + 1] = ga[1];
+        }
+    }
     return 0;
 }
 

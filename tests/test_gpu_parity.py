@@ -573,8 +573,54 @@ def test_empty_and_ragged_inputs(gpu):
     assert torch.allclose(a, Siddon()(vol, s, t, one), rtol=1e-5, atol=1e-6)
     with pytest.raises(NotImplementedError):
         Siddon(mode="bilinear", reducefn=lambda x: x.sum(-1))(vol, s, t, one)
-    with pytest.raises(NotImplementedError):
-        Siddon()(vol.double(), s.double(), t.double(), torch.ones(1, 1, 1, device=gpu).double())
+    # float64 inputs render in double (csrc/f64_rays.hip), like the reference module .to(float64)
+    d = Siddon()(vol.double(), s.double(), t.double(), torch.ones(1, 1, 1, device=gpu).double())
+    assert d.dtype == torch.float64
+    assert abs(d.item() - Siddon()(vol, s, t, one).item()) < 1e-5
+    with pytest.raises(NotImplementedError):  # mixed dtypes are not guessed at
+        ops.siddon_forward(vol.double(), s, t, None)
+
+
+@pytest.mark.parametrize("name", ["siddon_sum", "siddon_sum_oblique", "siddon_per_ray_source"])
+def test_siddon_float64_golden(gpu, name):
+    """fp64 kernels on the GPU against the reference's own fp64 outputs and autograd gradients."""
+    g = golden(name)
+    vol, src, tgt = (torch.from_numpy(g[k].astype(np.float64)).to(gpu).requires_grad_()
+                     for k in ("volume", "source", "target"))
+    B, N, _ = tgt.shape
+    img = torch.from_numpy(g["img_f64"].reshape(B, 1, N)).to(gpu).requires_grad_()
+    out = Siddon()(vol, src, tgt, img)
+    assert out.dtype == torch.float64
+    assert rel_err(out.detach().cpu().numpy(), g["out_f64"]) < 1e-12
+    gs, gt, gi, gv = torch.autograd.grad(out, (src, tgt, img, vol),
+                                         torch.from_numpy(g["grad_out_f64"]).to(gpu))
+    for mine, key in ((gs, "g_source_f64"), (gt, "g_target_f64"), (gi, "g_img_f64"), (gv, "g_volume_f64")):
+        assert rel_err(mine.cpu().numpy(), g[key]) < 1e-10, key
+
+
+def test_trilinear_float64_golden_and_drr_module(gpu):
+    g = golden("trilinear_global_range")
+    vol, src, tgt = (torch.from_numpy(g[k].astype(np.float64)).to(gpu).requires_grad_()
+                     for k in ("volume", "source", "target"))
+    B, N, _ = tgt.shape
+    img = torch.from_numpy(g["img_f64"].reshape(B, 1, N)).to(gpu).requires_grad_()
+    out = Trilinear()(vol, src, tgt, img, n_points=41)
+    assert rel_err(out.detach().cpu().numpy(), g["out_f64"]) < 1e-6  # (fp32 linspace table, see f64_core.h)
+    gs, gt, gi, gv = torch.autograd.grad(out, (src, tgt, img, vol),
+                                         torch.from_numpy(g["grad_out_f64"]).to(gpu))
+    for mine, key in ((gs, "g_source_f64"), (gt, "g_target_f64"), (gi, "g_img_f64"), (gv, "g_volume_f64")):
+        assert rel_err(mine.cpu().numpy(), g[key]) < 1e-5, key
+    # the whole module in double, like the reference's `DRR(...).to(torch.float64)`
+    gm = golden("drr_module")
+    drr = DRR(_subject_a(gm), renderer="siddon", **_geo(gm)).to(gpu).to(torch.float64)
+    rot = torch.from_numpy(gm["rot"]).double().to(gpu).requires_grad_()
+    xyz = torch.from_numpy(gm["xyz"]).double().to(gpu).requires_grad_()
+    im = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    assert im.dtype == torch.float64
+    assert rel_err(im.detach().cpu().numpy(), gm["siddon_img_f32"]) < FWD_TOL
+    im.backward(torch.from_numpy(gm["siddon_grad_out_f32"]).double().to(gpu))
+    assert rel_err(rot.grad.cpu().numpy(), gm["siddon_g_rot_f64"]) < 1e-6
+    assert rel_err(xyz.grad.cpu().numpy(), gm["siddon_g_xyz_f64"]) < 1e-6
 
 
 @pytest.mark.parametrize("stop", [False, True])
