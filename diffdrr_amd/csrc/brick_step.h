@@ -14,7 +14,7 @@
 //   * keeps every loop operand in a VGPR, wave-uniform ones included;
 //   * has no per-lane exit: a lane whose ray has left the brick idles on its last voxel with
 //     zero-length steps (live = 0), the wave leaves when no lane is live.
-// One step = v_min3 + 18 fast instructions = 40 issue cycles (54 with the backward record),
+// One step = v_min3 + 17 fast instructions = 38 issue cycles (52 with the backward record),
 // against 58+ for the compare / select / convert formulation it replaces.
 //
 // Exactness: see step_enter (alpha of every plane a ray reaches inside a brick is within an ulp
@@ -41,18 +41,6 @@ DDRR_HD float sel_zero(float d, float nbig, float live) {
 #else
     const float r = fmaf(d, nbig, live);
     return r > 0.f ? (r < 1.f ? r : 1.f) : 0.f;  // NaN -> 0, like the hardware clamp
-#endif
-}
-
-// clamp(x * big) to [0, 1]: 1 where x > 0 (by at least 2^-126), 0 where x <= 0 or NaN.
-DDRR_HD float sat_pos(float x, float big) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    float r;
-    asm("v_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(x), "v"(big));
-    return r;
-#else
-    const float r = x * big;
-    return r > 0.f ? (r < 1.f ? r : 1.f) : 0.f;
 #endif
 }
 
@@ -109,6 +97,7 @@ struct StepEntry {
     float dirf[3];        // +-1: how k - k0 moves
     float ent[3];         // one-hot: the axis of the entry crossing (x before y before z)
     float entry, exit;
+    float lbig;           // 2^(125 - exponent of the largest |alpha| in the brick), see step_walk
     float offc;           // bit-pattern float: address = bits(offc + sum_a (k_a - k0_a) strideb_a)
     bool hit;
 };
@@ -172,6 +161,14 @@ DDRR_HD StepEntry step_enter(const StepGeom &G, const float s[3], const float t[
         E.offc = fmaf((k0 - p01) - G.lof[a], G.strideb[a], E.offc);
     }
     E.hit = E.entry < E.exit;  // false for NaN
+    // scale of the "is this the last segment" test, per ray: the whole line through source and
+    // target is integrated, so alpha may be of any magnitude; with m = max(|entry|, |exit|) in
+    // [2^e, 2^(e+1)), lbig = 2^(125 - e) keeps exit * lbig finite and (exit - a) * lbig >= 1 for
+    // every float a below exit
+    // (exponent field of 2^(125 - e) is 379 - biased exponent of m; capped at 2^127 for tiny m)
+    const float m = fmaxf(fabsf(E.entry), fabsf(E.exit));
+    const unsigned field = 379u - ((float_bits(m) >> 23) & 0xffu);
+    E.lbig = bits_as_float((field < 254u ? field : 254u) << 23);
     return E;
 }
 
@@ -192,8 +189,9 @@ DDRR_HD int step_walk(const Fetch &fetch, const StepGeom &G, const StepEntry &E,
     // wave-uniform loop operands: into vector registers once
     const float sb0 = in_vgpr(G.strideb[0]), sb1 = in_vgpr(G.strideb[1]);
     const float sb2 = in_vgpr(G.strideb[2]);
-    const float big = in_vgpr(kSelBig), nbig = in_vgpr(-kSelBig);
+    const float nbig = in_vgpr(-kSelBig);
     const float exit = E.exit, offc = E.offc;
+    const float nlbig = -E.lbig, exit_big = exit * E.lbig;
     float a_cur = E.entry, acc = 0.f;
     // Vc: the voxel of the segment being closed (requested one step earlier), Vp: the one before
     float Vc = fetch(float_bits(fmaf(kr0, sb0, fmaf(kr1, sb1, fmaf(kr2, sb2, offc)))));
@@ -211,7 +209,8 @@ DDRR_HD int step_walk(const Fetch &fetch, const StepGeom &G, const StepEntry &E,
     {                                                                                     \
         const float a_next = fminf(fminf(an0, an1), an2);                                 \
         const float len = a_next - a_cur;                                                 \
-        live = sat_pos(exit - a_next, big); /* 0: this segment is the ray's last one */   \
+        live = sel_zero(a_next, nlbig, exit_big); /* clamp((exit - a_next) lbig): 0 on the */ \
+        /* ray's last segment; both products are exact, the sum rounds once */            \
         const float t0 = sel_zero(an0 - a_next, nbig, live);                              \
         const float t1 = sel_zero(an1 - a_next, nbig, live);                              \
         const float t2 = sel_zero(an2 - a_next, nbig, live);                              \

@@ -481,27 +481,57 @@ DDRR_HD void siddon_channels_ray(const float *__restrict__ vol,
     unsigned off = w.off;  // bytes
     int cur = -1;
     const int cap = D.x + D.y + D.z + 3;
-    for (int it = 0; it < cap; ++it) {
+    // Two voxels (value + label) ahead of the one being consumed are in flight: where the ray
+    // goes next does not depend on what it reads, and a gather that waits for each voxel before
+    // asking for the next runs at the memory latency (0.98 ms for the 119-label example render
+    // at 200x200 against 0.21 ms for the plain per-ray render; profiles/r02/channels.txt).
+    // A "slot" holds a requested voxel and the length of the segment it will be charged.
+    struct Slot {
+        float v, seg;
+        int lab;
+    };
+    bool live = true;
+    auto request = [&](Slot &sl) {
+        // closes the segment that starts at a_cur, requests its voxel, steps to the next one
         const float a_next = min3f(w.an[0], w.an[1], w.an[2]);
-        const float seg = a_next - a_cur;
+        sl.seg = live ? a_next - a_cur : 0.f;
+        sl.lab = live ? (int)labels[off >> 2] : -1;
+        sl.v = live ? vox(vol, off) : 0.f;
         const bool cx = w.an[0] <= a_next, cy = w.an[1] <= a_next, cz = w.an[2] <= a_next;
-        const int lab = labels[off >> 2];
-        const float v = vox(vol, off);
-        if (lab != cur) {
+        const bool more = live && a_next < q.exit;
+        if (more) {
+            w.kf[0] += cx ? w.dirf[0] : 0.f;
+            w.kf[1] += cy ? w.dirf[1] : 0.f;
+            w.kf[2] += cz ? w.dirf[2] : 0.f;
+            w.an[0] = plane_alpha(q, 0, w.kf[0]);
+            w.an[1] = plane_alpha(q, 1, w.kf[1]);
+            w.an[2] = plane_alpha(q, 2, w.kf[2]);
+            off += (unsigned)((cx ? w.dstep[0] : 0) + (cy ? w.dstep[1] : 0) + (cz ? w.dstep[2] : 0));
+        }
+        a_cur = a_next;
+        live = more;
+    };
+    auto consume = [&](const Slot &sl) {
+        if (sl.lab < 0) return;  // nothing was requested: the ray had ended
+        if (sl.lab != cur) {
             if (cur >= 0) flush(cur, run);
-            cur = lab;
+            cur = sl.lab;
             run = 0.f;
         }
-        run = fmaf(v, seg, run);
-        w.kf[0] += cx ? w.dirf[0] : 0.f;
-        w.kf[1] += cy ? w.dirf[1] : 0.f;
-        w.kf[2] += cz ? w.dirf[2] : 0.f;
-        w.an[0] = plane_alpha(q, 0, w.kf[0]);
-        w.an[1] = plane_alpha(q, 1, w.kf[1]);
-        w.an[2] = plane_alpha(q, 2, w.kf[2]);
-        off += (unsigned)((cx ? w.dstep[0] : 0) + (cy ? w.dstep[1] : 0) + (cz ? w.dstep[2] : 0));
-        a_cur = a_next;
-        if (!(a_next < q.exit)) break;
+        run = fmaf(sl.v, sl.seg, run);
+    };
+    Slot s0, s1;
+    request(s0);
+    request(s1);
+    for (int it = 0; it < cap; it += 2) {
+        Slot n0, n1;
+        request(n0);
+        request(n1);
+        consume(s0);
+        consume(s1);
+        s0 = n0;
+        s1 = n1;
+        if (s0.lab < 0) break;  // the slots ahead are empty: everything is consumed
     }
     if (cur >= 0) flush(cur, run);
 }
