@@ -54,6 +54,10 @@ def test_library_builds_loads_and_exports_every_symbol():
                           text=True, check=True).stdout
     for name in _declared():
         assert re.search(rf"\bT {name}\b", syms), name
+    # ... and nothing else: experiment switches (ddrr_set_*, the phase profile) exist only in
+    # the development builds of tools/explib.py, never in the product library
+    exported = set(re.findall(r"\bT (ddrr_\w+)", syms))
+    assert exported == set(_declared()), exported ^ set(_declared())
 
 
 def test_library_contains_gfx950_code_object():
