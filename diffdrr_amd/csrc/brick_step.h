@@ -66,9 +66,6 @@ DDRR_HD float in_vgpr(float x) {
 }
 
 constexpr float kSelBig = 0x1p126f;
-#ifndef DDRR_STEP_DEEP
-#define DDRR_STEP_DEEP 0
-#endif
 
 // Geometry of the staged brick for the walk: plane range per axis and the LDS byte strides
 // as bit-pattern floats (see above).
@@ -200,7 +197,6 @@ DDRR_HD int step_walk(const Fetch &fetch, const StepGeom &G, const StepEntry &E,
     float tpx = E.ent[0], tpy = E.ent[1];
     float S0x = 0.f, S0y = 0.f, S1x = 0.f, S1y = 0.f;
     float live = 1.f;
-    float len_p = 0.f;  // (deep pipeline: length of the segment whose voxel is Vp)
 
 // One step: close the segment [a_cur, a_next), move the plane counters of the axes crossed at
 // a_next, request the next voxel.  With the record, the crossing that OPENED the segment
@@ -222,12 +218,7 @@ DDRR_HD int step_walk(const Fetch &fetch, const StepGeom &G, const StepEntry &E,
         an0 = fmaf(kr0, inv0, af0);                                                       \
         an1 = fmaf(kr1, inv1, af1);                                                       \
         an2 = fmaf(kr2, inv2, af2);                                                       \
-        if (!AUX && DDRR_STEP_DEEP) {                                                     \
-            acc = fmaf(Vp, len_p, acc); /* segment i-1: its voxel was asked for two steps ago */ \
-            len_p = len;                                                                  \
-        } else {                                                                          \
-            acc = fmaf(Vc, len, acc);                                                     \
-        }                                                                                 \
+        acc = fmaf(Vc, len, acc);                                                         \
         if (AUX) {                                                                        \
             const float dv = Vp - Vc, dva = dv * a_cur;                                   \
             S0x = fmaf(dv, tpx, S0x);                                                     \
@@ -254,7 +245,6 @@ DDRR_HD int step_walk(const Fetch &fetch, const StepGeom &G, const StepEntry &E,
 #endif
     }
 #undef DDRR_STEP
-    if (!AUX && DDRR_STEP_DEEP) acc = fmaf(Vp, len_p, acc);  // the segment still pending
     I = acc;
     if (AUX) {
         // (after a lane's last live step its counters stand still and tp* = 0: idle steps add
@@ -274,6 +264,77 @@ DDRR_HD int step_walk(const Fetch &fetch, const StepGeom &G, const StepEntry &E,
         rec[3] = acc - (S1x + S1y);  // sum_a S1_a = I
     }
     return it + 2;  // steps the wave took (profiling builds)
+}
+
+// mask_to_channels on the bricks (reference renderers.py:77-89).  The staged word of a voxel
+// holds its value rounded to a 16-bit mantissa in the upper 24 bits and its label in the low
+// 8: one LDS read per step serves both, and the brick needs no second plane in LDS (there
+// is no room for one: 132 KiB of 160 are the values).  Rounding to nearest at 2^-17
+// relative per voxel is of the size of fp32 accumulation error over a ray (measured:
+// channel sum vs plain render 6e-6 of the image scale; the parity tolerance is 1e-4).
+DDRR_HD float pack_voxel_label(float v, unsigned lab) {
+    const unsigned b = float_bits(v);
+    const bool special = (b & 0x7f800000u) == 0x7f800000u;  // inf / nan: keep the class
+    const unsigned r = special ? (b | ((b & 0x007fffffu) ? 0x00400000u : 0u)) : b + 0x80u;
+    return bits_as_float((r & 0xffffff00u) | (lab & 0xffu));
+}
+
+// The walk of step_walk<false> over packed words: the integral of a run of voxels with one
+// label is summed in a register and handed to `flush(label, sum)` when the label changes and
+// at the end.  (A lane that is done idles on its last voxel: same label, zero length.)
+template <class Fetch, class Flush>
+DDRR_HD void step_walk_channels(const Fetch &fetch, const StepGeom &G, const StepEntry &E,
+                                const Flush &flush) {
+    float kr0 = 0.f, kr1 = 0.f, kr2 = 0.f;
+    float an0 = E.an[0], an1 = E.an[1], an2 = E.an[2];
+    const float inv0 = E.inv[0], inv1 = E.inv[1], inv2 = E.inv[2];
+    const float af0 = E.a0[0], af1 = E.a0[1], af2 = E.a0[2];
+    const float dir0 = E.dirf[0], dir1 = E.dirf[1], dir2 = E.dirf[2];
+    const float sb0 = in_vgpr(G.strideb[0]), sb1 = in_vgpr(G.strideb[1]);
+    const float sb2 = in_vgpr(G.strideb[2]);
+    const float nbig = in_vgpr(-kSelBig);
+    const float offc = E.offc;
+    const float nlbig = -E.lbig, exit_big = E.exit * E.lbig;
+    float a_cur = E.entry, run = 0.f, live = 1.f;
+    float Vc = fetch(float_bits(fmaf(kr0, sb0, fmaf(kr1, sb1, fmaf(kr2, sb2, offc)))));
+    unsigned cur = float_bits(Vc) & 0xffu;
+#define DDRR_STEP()                                                                       \
+    {                                                                                     \
+        const float a_next = fminf(fminf(an0, an1), an2);                                 \
+        const float len = a_next - a_cur;                                                 \
+        live = sel_zero(a_next, nlbig, exit_big);                                         \
+        const float t0 = sel_zero(an0 - a_next, nbig, live);                              \
+        const float t1 = sel_zero(an1 - a_next, nbig, live);                              \
+        const float t2 = sel_zero(an2 - a_next, nbig, live);                              \
+        kr0 = fmaf(t0, dir0, kr0);                                                        \
+        kr1 = fmaf(t1, dir1, kr1);                                                        \
+        kr2 = fmaf(t2, dir2, kr2);                                                        \
+        const float Vn =                                                                  \
+            fetch(float_bits(fmaf(kr0, sb0, fmaf(kr1, sb1, fmaf(kr2, sb2, offc)))));      \
+        an0 = fmaf(kr0, inv0, af0);                                                       \
+        an1 = fmaf(kr1, inv1, af1);                                                       \
+        an2 = fmaf(kr2, inv2, af2);                                                       \
+        const unsigned w = float_bits(Vc), lab = w & 0xffu;                               \
+        if (lab != cur) {                                                                 \
+            flush(cur, run);                                                              \
+            run = 0.f;                                                                    \
+            cur = lab;                                                                    \
+        }                                                                                 \
+        run = fmaf(bits_as_float(w & 0xffffff00u), len, run);                             \
+        a_cur = a_next;                                                                   \
+        Vc = Vn;                                                                          \
+    }
+    for (int it = 0; it < 3 * BRICK + 4; it += 2) {
+        DDRR_STEP()
+        DDRR_STEP()
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (!__builtin_amdgcn_ballot_w64(live != 0.f)) break;
+#else
+        if (live == 0.f) break;
+#endif
+    }
+#undef DDRR_STEP
+    flush(cur, run);
 }
 
 // Volume gradient of one ray through one brick: adds w * dalpha_k to the LDS cell of every

@@ -62,6 +62,8 @@ struct BrickArgs {
     int n_points;           // BRICK_TRI_*: samples per ray
     const float *amin, *amax;  // BRICK_TRI_*: device scalars (renderers.py:220-223)
     unsigned long long *prof;  // DDRR_BRICK_PROFILE builds: per-phase wave-cycle totals
+    const unsigned char *labels;  // BRICK_CHANNELS: label of every voxel
+    int n_channels;               // BRICK_CHANNELS: out is (B, n_channels, N)
 };
 
 // Phase timing of the brick kernel (tools/ builds with -DDDRR_BRICK_PROFILE only): s_memtime
@@ -111,6 +113,7 @@ constexpr int BRICK_VOLGRAD = 2;  // g_volume (the brick in LDS is the accumulat
 constexpr int BRICK_TRI_FWD = 3;      // trilinear marcher: out
 constexpr int BRICK_TRI_VOLGRAD = 4;  // trilinear marcher: g_volume
 constexpr int BRICK_TRI_FWD_AUX = 5;  // trilinear marcher: planar backward record (out follows from it)
+constexpr int BRICK_CHANNELS = 6;     // out (B, C, N): one line integral per label (mask_to_channels)
 
 inline size_t brick_lds_bytes(const BrickLayout &lay) {
     return (size_t)brick_floats(lay) * 4 + (size_t)kBrickWaves * kBuckets * kQueueCap * 4 +
@@ -141,6 +144,18 @@ struct LdsAbsAdd {
         (void)addr;
         (void)v;
 #endif
+    }
+};
+
+// A finished label run of a ray's walk through a brick goes to the ray's output column
+// (B, C, N): one fire-and-forget atomic per run.  32-bit offsets: the host checks B C N < 2^30.
+struct BrickColumnFlush {
+    float *out;
+    unsigned col;  // b * C * N + pixel
+    unsigned N, C;
+    float L;
+    __device__ __forceinline__ void operator()(unsigned lab, float run) const {
+        if (lab < C) unsafeAtomicAdd(out + (col + __umul24(lab, N)), L * run);
     }
 };
 #endif
@@ -200,6 +215,13 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
     DDRR_PROF(PROF_LOADS);
     const StepEntry E = step_enter(SG, s, t, p.shift, p.eps, LdsAbsFetch::base_of(brick));
     DDRR_PROF(PROF_SETUP);
+    if (MODE == BRICK_CHANNELS) {
+        const unsigned N = (unsigned)(p.det_h * p.det_w), C = (unsigned)p.n_channels;
+        if (E.hit)
+            step_walk_channels(LdsAbsFetch{}, SG, E, BrickColumnFlush{out, b * C * N + pix, N, C, L});
+        DDRR_PROF(PROF_WALK);
+        return;
+    }
     float I = 0.f, rec[4] = {0.f, 0.f, 0.f, 0.f};
     int steps = 0;
     if (E.hit) steps = step_walk<AUX>(LdsAbsFetch{}, SG, E, I, rec);
@@ -265,7 +287,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     unsigned *myq = queue + wave * kBuckets * kQueueCap;
     const unsigned pix_mask = (1u << p.pix_bits) - 1u;
     const int n_chunks = (p.B + kPoseChunk - 1) / kPoseChunk;
-    const bool vec_ok = (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.vol) & 15) == 0;
+    const bool vec_ok = (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.vol) & 15) == 0 &&
+                        (MODE != BRICK_CHANNELS || (reinterpret_cast<uintptr_t>(p.labels) & 3) == 0);
     const bool vec_out = GRAD && (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.g_volume) & 15) == 0;
     // fixed-point scale of the LDS accumulator (volume-gradient modes): the largest sum a
     // voxel can receive is n_sum (contributions) * wmax (each) -- volgrad_prepare_kernel
@@ -335,8 +358,13 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         // store, so a brick costs one memory round trip instead of eight.
         constexpr int kQuads = BRICK * BRICK * 8 / kBrickThreads;
         static_assert(kQuads * kBrickThreads == BRICK * BRICK * 8, "brick staging");
-        const int q4 = (tid & 7) * 4, z = box.lo[2] + q4;
+        // (recomputed per brick from an opaque copy of the thread id: hoisted out of the brick
+        // loop these few values are what tips the channel instance into scratch spills)
+        int tid_here = tid;
+        asm volatile("" : "+v"(tid_here));
+        const int q4 = (tid_here & 7) * 4, z = box.lo[2] + q4;
         float *const d0 = brick + q4;
+        constexpr bool LABELS = MODE == BRICK_CHANNELS;
         const bool stage_vec = ch == 0 && !GRAD && !TRI && vec_ok;
         // z and D.z are multiples of 4: a quad is wholly inside or wholly outside
         const bool in_z = z + 4 <= box.hi[2];
@@ -349,30 +377,43 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
             *reinterpret_cast<BrickRow *>(rows + tid * kRowWords) = r;
         }
         if (tid == 0) counter[0] = 0;
-        float4 q[kQuads];
+        // (with labels: two rounds of four quads -- all eight at once plus their labels do not
+        // fit the register budget next to the kernel's loop invariants)
+        constexpr int kRounds = LABELS ? 2 : 1, kPer = kQuads / kRounds;
         if (stage_vec) {
 #pragma unroll
-            for (int it = 0; it < kQuads; ++it) {
-                const int row = (tid >> 3) + it * (kBrickThreads >> 3);
-                const int lx = row / BRICK, ly = row - lx * BRICK;
-                const int x = box.lo[0] + lx, y = box.lo[1] + ly;
-                // clamped (always readable) address; what lies outside is zeroed below
-                const int xc = x < p.D.x ? x : p.D.x - 1, yc = y < p.D.y ? y : p.D.y - 1;
-                q[it] = *reinterpret_cast<const float4 *>(
-                    p.vol + ((long)xc * p.D.y + yc) * p.D.z + (in_z ? z : 0));
-            }
-        }
-        if (stage_vec) {
+            for (int h0 = 0; h0 < kQuads; h0 += kPer) {
+                float4 q[kPer];
+                unsigned ql[LABELS ? kPer : 1];  // BRICK_CHANNELS: the quads' four labels
 #pragma unroll
-            for (int it = 0; it < kQuads; ++it) {
-                const int row = (tid >> 3) + it * (kBrickThreads >> 3);
-                const int lx = row / BRICK, ly = row - lx * BRICK;
-                const bool in = in_z && box.lo[0] + lx < box.hi[0] && box.lo[1] + ly < box.hi[1];
-                float *d = d0 + lx * p.lay.sx + ly * p.lay.sy;
-                d[0] = in ? q[it].x : 0.f;
-                d[1] = in ? q[it].y : 0.f;
-                d[2] = in ? q[it].z : 0.f;
-                d[3] = in ? q[it].w : 0.f;
+                for (int i = 0; i < kPer; ++i) {
+                    const int row = (tid >> 3) + (h0 + i) * (kBrickThreads >> 3);
+                    const int lx = row / BRICK, ly = row - lx * BRICK;
+                    const int x = box.lo[0] + lx, y = box.lo[1] + ly;
+                    // clamped (always readable) address; what lies outside is zeroed below
+                    const int xc = x < p.D.x ? x : p.D.x - 1, yc = y < p.D.y ? y : p.D.y - 1;
+                    const long at = ((long)xc * p.D.y + yc) * p.D.z + (in_z ? z : 0);
+                    q[i] = *reinterpret_cast<const float4 *>(p.vol + at);
+                    if (LABELS) ql[i] = *reinterpret_cast<const unsigned *>(p.labels + at);
+                }
+#pragma unroll
+                for (int i = 0; i < kPer; ++i) {
+                    const int row = (tid >> 3) + (h0 + i) * (kBrickThreads >> 3);
+                    const int lx = row / BRICK, ly = row - lx * BRICK;
+                    const bool in = in_z && box.lo[0] + lx < box.hi[0] && box.lo[1] + ly < box.hi[1];
+                    float *d = d0 + lx * p.lay.sx + ly * p.lay.sy;
+                    if (LABELS) {
+                        q[i].x = pack_voxel_label(q[i].x, ql[i]);
+                        q[i].y = pack_voxel_label(q[i].y, ql[i] >> 8);
+                        q[i].z = pack_voxel_label(q[i].z, ql[i] >> 16);
+                        q[i].w = pack_voxel_label(q[i].w, ql[i] >> 24);
+                    }
+                    d[0] = in ? q[i].x : 0.f;
+                    d[1] = in ? q[i].y : 0.f;
+                    d[2] = in ? q[i].z : 0.f;
+                    d[3] = in ? q[i].w : 0.f;
+                }
+                if (LABELS) __builtin_amdgcn_sched_barrier(0);  // keep the rounds apart
             }
         } else if (ch == 0) {
             // general path (halo bricks of the trilinear marcher, unaligned volumes, and the
@@ -392,6 +433,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                     for (int k = 0; k < 4; ++k) {
                         const bool in = in_xy && z + k >= 0 && z + k < box.hi[2];
                         v[it][k] = in ? g[z + k] : 0.f;
+                        if (LABELS && in)
+                            v[it][k] = pack_voxel_label(v[it][k], (p.labels + (g - p.vol))[z + k]);
                     }
                 }
 #pragma unroll
@@ -700,7 +743,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
                   const float *target, const float *img, const float *grad_out, int B, int det_h,
                   int det_w, float voxel_shift, float eps, float *out, float *aux,
                   float *g_volume, hipStream_t st, const char *who, int n_points = 0,
-                  const float *amin = nullptr, const float *amax = nullptr, float rec_q = 0.f) {
+                  const float *amin = nullptr, const float *amax = nullptr, float rec_q = 0.f,
+                  const unsigned char *labels = nullptr, int n_channels = 0) {
     const int N = det_h * det_w;
     BrickArgs p;
     p.vol = volume;
@@ -732,6 +776,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     p.amin = amin;
     p.amax = amax;
     p.prof = nullptr;
+    p.labels = labels;
+    p.n_channels = n_channels;
 #if defined(DDRR_BRICK_PROFILE)
     p.prof = g_brick_prof;
 #endif
@@ -757,7 +803,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     {
         std::lock_guard<std::mutex> lock(mu);
         if (!attr_set[dev]) {
-            const void *fns[6] = {
+            const void *fns[7] = {
+                reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_CHANNELS>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_FWD_AUX>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_FWD>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_FWD_AUX>),
@@ -806,6 +853,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_FWD>, grid, block, lds, st, p, out, aux);
     else if (mode == BRICK_FWD_AUX)
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_FWD_AUX>, grid, block, lds, st, p, out, aux);
+    else if (mode == BRICK_CHANNELS)
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_CHANNELS>, grid, block, lds, st, p, out, aux);
     else
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_VOLGRAD>, grid, block, lds, st, p, out, aux);
     return finish(who);
@@ -883,6 +932,26 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     hipLaunchKernelGGL(siddon_out_from_record_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
                        dim3(kBlock), 0, st, aux + (packed ? 4 * R : 0), img, R, out);
     return finish("ddrr_siddon_forward_bricks");
+}
+
+int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char *labels, int dx,
+                                        int dy, int dz, const float *source, const float *target,
+                                        const float *img, int B, int det_h, int det_w, int C,
+                                        float voxel_shift, float eps, float *out, void *stream) {
+    const int N = det_h * det_w;
+    if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
+    if (!labels || !out || C < 1) return fail(-1, "null labels/out or C < 1");
+    if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
+    if ((long)B * C * N >= (1L << 30) || N >= (1 << 24))
+        return fail(-1, "B * C * N must stay below 2^30 (and N below 2^24) for one channel launch "
+                        "on the bricks: split the pose batch or use ddrr_siddon_forward_channels");
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C * N, st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    return launch_bricks(BRICK_CHANNELS, volume, dx, dy, dz, source, target, img, nullptr, B, det_h,
+                         det_w, voxel_shift, eps, out, nullptr, nullptr, st,
+                         "ddrr_siddon_forward_channels_bricks", 0, nullptr, nullptr, 0.f, labels, C);
 }
 
 int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *source,

@@ -116,7 +116,7 @@ class DRR(nn.Module):
             # pose parameters -> world matrix in one kernel (pose.py euler_world_pose)
             Mw = euler_world_pose(args[0], args[1], convention, self.detector._reorient,
                                   degrees=degrees)
-            return self.reshape_transform(self._render_fused_Mw(Mw, calibration),
+            return self.reshape_transform(self._render_fused_Mw(Mw, calibration, mask_to_channels),
                                           batch_size=len(Mw))
         if parameterization is None:
             pose = args[0]
@@ -124,7 +124,7 @@ class DRR(nn.Module):
             pose = convert(*args, parameterization=parameterization, convention=convention,
                            degrees=degrees)
         if fused:
-            return self.reshape_transform(self._render_fused(pose, calibration),
+            return self.reshape_transform(self._render_fused(pose, calibration, mask_to_channels),
                                           batch_size=len(pose))
         source, target = self.detector(pose, calibration)
         # (rays straight out of the Detector: a row-major affine grid by construction)
@@ -152,15 +152,16 @@ class DRR(nn.Module):
             return False  # gradients w.r.t. the intrinsics flow through Detector.forward only
         return (self.fuse_ray_generation and isinstance(r, Siddon) and r.supports_pose_entry()
                 and ops.on_device(self.density) and self.density.dtype == torch.float32
-                and not mask_to_channels and not kwargs and not self.checkpoint_gradients
+                and (not mask_to_channels or getattr(self, "mask", None) is not None)
+                and not kwargs and not self.checkpoint_gradients
                 and self.patch_size is None and self.detector.n_subsample is None
                 and min(self.detector.height, self.detector.width) >= 2)
 
-    def _render_fused(self, pose, calibration):
+    def _render_fused(self, pose, calibration, mask_to_channels=False):
         Mw = (pose.matrix @ self.detector._reorient)[:, :3, :]   # reorient.compose(extrinsic)
-        return self._render_fused_Mw(Mw, calibration)
+        return self._render_fused_Mw(Mw, calibration, mask_to_channels)
 
-    def _render_fused_Mw(self, Mw, calibration):
+    def _render_fused_Mw(self, Mw, calibration, mask_to_channels=False):
         det = self.detector
         if calibration is None:
             # the calibrated detector points only change with the intrinsics: cached per
@@ -178,7 +179,9 @@ class DRR(nn.Module):
         Ainv = self._affine_inverse[0, :3, :] if self._affine_inverse.dim() == 3 \
             else self._affine_inverse[:3, :]
         self.renderer.detector_shape = (det.height, det.width)
-        return self.renderer.render_poses(self.density, Mw, P, Ainv)
+        self.renderer.trust_detector_shape = True
+        return self.renderer.render_poses(self.density, Mw, P, Ainv,
+                                          mask=self.mask if mask_to_channels else None)
 
     def render(self, density: torch.Tensor, source: torch.Tensor, target: torch.Tensor,
                mask_to_channels: bool = False, **kwargs):
@@ -201,6 +204,7 @@ class DRR(nn.Module):
                                                     self.detector.width)
         self.renderer.detector_shape = \
             (self.detector.height, self.detector.width) if full_grid else None
+        self.renderer.trust_detector_shape = True  # generated or checked right here
         if self.patch_size is None:
             return self.renderer(density, source, target, img, **kwargs)
         partials = [

@@ -366,6 +366,33 @@ def siddon_forward_channels(volume, labels_u8, n_channels, source, target, img, 
     return out
 
 
+def siddon_forward_channels_bricks(volume, labels_u8, n_channels, source, target, img, det, *,
+                                   voxel_shift=0.5, eps=1e-8):
+    """:func:`siddon_forward_channels` for a detector grid on the volume-stationary brick
+    kernel (the label rides in the low byte of the staged voxel word).  -> (B, C, N)"""
+    B, N = _check_rays(volume, source, target, img)
+    H, W = int(det[0]), int(det[1])
+    if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
+        raise ValueError("the brick path needs one source per pose and an H*W >= 2x2 ray grid")
+    if labels_u8.dtype != torch.uint8 or labels_u8.shape != volume.shape:
+        raise ValueError("labels must be a uint8 tensor of the volume's shape")
+    out = torch.empty(B, n_channels, N, dtype=torch.float32, device=volume.device)
+    if _empty(B, N):
+        return out
+    labels_u8, volume = labels_u8.contiguous(), volume.contiguous()
+    source, target = source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    _launch("ddrr_siddon_forward_channels_bricks", volume.device, volume.data_ptr(),
+            labels_u8.data_ptr(), *volume.shape, source.data_ptr(), target.data_ptr(), _ptr(img),
+            B, H, W, int(n_channels), float(voxel_shift), float(eps), out.data_ptr())
+    return out
+
+
+def channels_fit_bricks(B, C, N):
+    """One brick launch addresses the (B, C, N) result with 32-bit byte offsets."""
+    return B * C * N < 2 ** 30 and N < 2 ** 24
+
+
 def siddon_backward_midpoint(volume, source, target, img, grad_out, *, voxel_shift=0.5, eps=1e-8,
                              lookup="mid_nearest", align_corners=False, want_rays=True,
                              want_img=True, want_volume=False):

@@ -23,6 +23,19 @@ import torch
 from . import ops
 
 
+def _grid_or_none(renderer, source, target):
+    """``renderer.detector_shape`` if the rays really are that row-major affine grid, else None.
+    The shape is a CONTRACT (the volume-stationary kernels cull rays with an affine model of
+    the grid): ``diffdrr_amd.DRR`` sets it only for rays it generated or checked itself and
+    marks it trusted; set by anyone else (a renderer swapped into the reference's ``DRR``,
+    INTEGRATION.md) it is checked here, once per call (one reduction, one host sync), and the
+    per-ray kernels render whatever does not satisfy it."""
+    det = renderer.detector_shape
+    if det is None or renderer.trust_detector_shape:
+        return det
+    return det if ops.rays_form_detector_grid(source, target, int(det[0]), int(det[1])) else None
+
+
 _label_cache = {}  # id(mask) -> (weakref to the mask, its version, uint8 labels, C)
 
 
@@ -217,9 +230,7 @@ class _SiddonChannelsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, volume, source, target, img, labels, C, cfg):
-        out = ops.siddon_forward_channels(
-            volume, labels, C, source.contiguous(), target.contiguous(), img.contiguous(),
-            voxel_shift=cfg["voxel_shift"], eps=cfg["eps"], det=cfg["det"], tile=cfg["tile"])
+        out = _channels_forward(volume, labels, C, source, target, img, cfg)
         ctx.cfg = cfg
         ctx.save_for_backward(volume, source, target, img, labels)
         return out
@@ -315,6 +326,60 @@ class _SiddonPoseFn(torch.autograd.Function):
         return g_vol, g_M, None, None, None
 
 
+def _channels_forward(volume, labels, C, source, target, img, cfg):
+    """(B, C, N) channel render: the volume-stationary kernel for a detector grid (the label
+    rides in the staged voxel word), the per-ray channel kernel otherwise."""
+    B, N = target.shape[:2]
+    grid = (cfg["det"] is not None and cfg["det"][0] * cfg["det"][1] == N
+            and source.shape[1] == 1 and min(cfg["det"]) >= 2)
+    if grid and cfg["path"] == "bricks" and ops.channels_fit_bricks(B, C, N):
+        return ops.siddon_forward_channels_bricks(
+            volume, labels, C, source, target, img, cfg["det"],
+            voxel_shift=cfg["voxel_shift"], eps=cfg["eps"])
+    return ops.siddon_forward_channels(
+        volume, labels, C, source.contiguous(), target.contiguous(), img.contiguous(),
+        voxel_shift=cfg["voxel_shift"], eps=cfg["eps"], det=cfg["det"], tile=cfg["tile"])
+
+
+class _SiddonPoseChannelsFn(torch.autograd.Function):
+    """``_SiddonPoseFn`` with a mask: world pose per DRR -> (B, C, N) channel images without the
+    ray tensors passing through PyTorch ops in the forward.  Backward: the channel backward
+    kernel (per-ray endpoint gradients), chained to dLoss/dMw through the adjoint of the ray
+    generation (raygen_core.h: raygen_ray_adjoint, restated on the (B, N, 3) tensors)."""
+
+    @staticmethod
+    def forward(ctx, volume, Mw, P, Ainv, labels, C, cfg):
+        source, target, img = ops.raygen_forward(Mw, Ainv, P)
+        out = _channels_forward(volume, labels, C, source, target, img, cfg)
+        ctx.cfg = cfg
+        ctx.save_for_backward(volume, Mw, P, Ainv, source, target, img, labels)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        volume, Mw, P, Ainv, source, target, img, labels = ctx.saved_tensors
+        cfg = ctx.cfg
+        need_vol, need_M = ctx.needs_input_grad[:2]
+        stop = cfg["stop_gradients"]
+        gs, gt, gi, gv = ops.siddon_backward_channels(
+            volume, labels, source, target, img, grad_out, voxel_shift=cfg["voxel_shift"],
+            eps=cfg["eps"], want_rays=bool(need_M), want_img=bool(need_M and not stop),
+            want_volume=bool(need_vol and not stop), det=cfg["det"], tile=cfg["tile"])
+        g_M = None
+        if need_M:
+            A, R = Ainv[:, :3], Mw[:, :, :3]
+            g_tw = gt @ A                                   # transpose of Ainv's 3x3 block
+            g_sw = gs.sum(dim=1) @ A
+            if gi is not None:                              # img = ||tw - sw||
+                ku = (gi / img.clamp_min(1e-30)).unsqueeze(-1) * (P @ R.transpose(1, 2))
+                g_tw = g_tw + ku
+                g_sw = g_sw - ku.sum(dim=1)
+            g_R = torch.einsum("bna,nj->baj", g_tw, P)
+            g_T = g_tw.sum(dim=1) + g_sw                    # tw and sw both carry the translation
+            g_M = torch.cat([g_R, g_T.unsqueeze(-1)], dim=-1)
+        return gv, g_M, None, None, None, None, None
+
+
 class Siddon(torch.nn.Module):
     """Differentiable X-ray renderer: Siddon's exact ray tracing (reference
     renderers.py:11-91) as one fused gfx950 kernel per call."""
@@ -341,8 +406,10 @@ class Siddon(torch.nn.Module):
         self.reducefn = reducefn
         self.voxel_shift = voxel_shift
         self.eps = eps
-        # performance hints set by DRR (detector grid of the rays; wave tile shape)
+        # set by DRR: the detector grid the rays form (a contract, see _grid_or_none) and the
+        # wave tile shape (a hint)
         self.detector_shape = None
+        self.trust_detector_shape = False
         self.tile = None
         # which kernel renders a detector-grid call (same results to ~1e-6):
         # "bricks" (volume-stationary, brick_core.h / brick_step.h) or "generic" (per-ray walk)
@@ -357,7 +424,7 @@ class Siddon(torch.nn.Module):
     def dims(self, volume):
         return torch.tensor(volume.shape).to(volume)
 
-    def _cfg(self, align_corners):
+    def _cfg(self, align_corners, det="unchecked"):
         if self.mode == "bilinear":
             lookup = "mid_trilinear"
         elif align_corners:
@@ -368,19 +435,23 @@ class Siddon(torch.nn.Module):
         return {"voxel_shift": self.voxel_shift, "eps": self.eps, "reducefn": self.reducefn,
                 "lookup": lookup, "align_corners": bool(align_corners),
                 "stop_gradients": self.stop_gradients_through_grid_sample,
-                "det": self.detector_shape, "tile": self.tile, "path": self.grid_path,
+                "det": self.detector_shape if det == "unchecked" else det, "tile": self.tile,
+                "path": self.grid_path,
                 "packed_record": self.packed_record}
 
     def supports_pose_entry(self):
         """Whether ``render_poses`` (the fused DRR entry) computes what ``forward`` would."""
         return self.mode == "nearest" and self.reducefn == "sum"
 
-    def render_poses(self, volume, Mw, P, Ainv):
+    def render_poses(self, volume, Mw, P, Ainv, mask=None):
         """The DRR case without materialising the ray tensors in PyTorch: ``Mw`` (B,3,4)
         world pose per DRR (extrinsic o reorient), ``P`` (N,3) calibrated detector points,
-        ``Ainv`` (3,4) world -> voxel.  Equals ``forward(volume, *rays(Mw, P, Ainv))``;
-        -> (B, 1, N)."""
+        ``Ainv`` (3,4) world -> voxel.  Equals ``forward(volume, *rays(Mw, P, Ainv), mask=mask)``;
+        -> (B, 1, N), or (B, C, N) with a mask."""
         cfg = self._cfg(False)
+        if mask is not None:
+            labels, C = _labels_u8(mask)
+            return _SiddonPoseChannelsFn.apply(volume, Mw, P, Ainv, labels, C, cfg)
         return _SiddonPoseFn.apply(volume, Mw, P, Ainv, cfg).unsqueeze(1)
 
     def forward(self, volume, source, target, img, align_corners=False, mask=None):
@@ -397,7 +468,7 @@ class Siddon(torch.nn.Module):
                    "stop_gradients": self.stop_gradients_through_grid_sample}
             terms = _SiddonSegmentsFn.apply(volume, source, target, img.reshape(B, N), cfg)
             return self.reducefn(terms).unsqueeze(1)
-        cfg = self._cfg(align_corners)
+        cfg = self._cfg(align_corners, _grid_or_none(self, source, target))
         if volume.dtype == torch.float64:
             # a module moved .to(torch.float64) (reference drr.py:71-75): the fp64 kernels
             if mask is not None or cfg["lookup"] != "step":
@@ -611,6 +682,7 @@ class Trilinear(torch.nn.Module):
         self.voxel_shift = voxel_shift
         self.eps = eps
         self.detector_shape = None
+        self.trust_detector_shape = False  # see _grid_or_none
         self.tile = None
         self.use_bricks = True  # detector-grid calls: volume-stationary kernels (tri_brick.h)
 
@@ -620,6 +692,7 @@ class Trilinear(torch.nn.Module):
     def forward(self, volume, source, target, img, n_points=500, align_corners=False, mask=None,
                 alphamin=None, alphamax=None):
         B, N, _ = target.shape
+        det = _grid_or_none(self, source, target)
         user_reduce = callable(self.reducefn) and not isinstance(self.reducefn, str)
         if not user_reduce:
             ops.reduce_code(self.reducefn)
@@ -656,14 +729,13 @@ class Trilinear(torch.nn.Module):
                     "mask_to_channels needs mode='bilinear' and reducefn='sum'")
             labels, C = _labels_u8(mask)
             ccfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift, "eps": self.eps,
-                    "align_corners": bool(align_corners), "det": self.detector_shape,
-                    "tile": self.tile}
+                    "align_corners": bool(align_corners), "det": det, "tile": self.tile}
             return _TrilinearChannelsFn.apply(volume, source, target, img.reshape(B, N), alphamin,
                                               alphamax, labels, C, ccfg)
         cfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift, "eps": self.eps,
                "reducefn": self.reducefn, "mode": self.mode,
-               "align_corners": bool(align_corners), "det": self.detector_shape,
-               "tile": self.tile, "bricks": self.use_bricks}
+               "align_corners": bool(align_corners), "det": det, "tile": self.tile,
+               "bricks": self.use_bricks}
         out = _TrilinearFn.apply(volume, source, target, img.reshape(B, N), alphamin, alphamax,
                                  cfg)
         return out.unsqueeze(1)

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 17
+#define DDRR_ABI_VERSION 18
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -142,6 +142,16 @@ int ddrr_siddon_forward_channels(const float *volume, const unsigned char *label
                                  const float *img, int B, int N, int C, float voxel_shift,
                                  float eps, int det_h, int det_w, int tile_h, int tile_w,
                                  float *out, void *stream);
+
+/* The same render for the DRR case (one source per pose, row-major det_h x det_w target grid)
+ * on the volume-stationary brick kernel: the label travels in the low 8 bits of the staged
+ * voxel word, the value keeps a 16-bit mantissa (rounded to nearest, 2^-17 relative per voxel:
+ * channel sums agree with the plain render to ~1e-5 of the image scale).  out (B, C, N) is
+ * fully written; B * C * N < 2^30.  The backward is ddrr_siddon_backward_channels. */
+int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char *labels, int dx,
+                                        int dy, int dz, const float *source, const float *target,
+                                        const float *img, int B, int det_h, int det_w, int C,
+                                        float voxel_shift, float eps, float *out, void *stream);
 
 /* Backward of ddrr_siddon_forward_channels: what autograd of renderers.py:77-89 (scatter_add
  * of the weighted segments into channels) returns for grad_out (B, C, N).  Outputs as in

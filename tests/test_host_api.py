@@ -283,7 +283,7 @@ def test_fused_entry_is_skipped_when_a_general_feature_is_asked_for(emulated_ops
 
     drr = DRR(synthetic_subject(24, kind="phantom", seed=0), sdd=300.0, height=12, delx=2.0)
     assert drr._fused_ok(False, {})
-    assert not drr._fused_ok(True, {})                       # mask_to_channels
+    assert not drr._fused_ok(True, {})                       # mask_to_channels without a mask
     assert not drr._fused_ok(False, {"align_corners": True})  # renderer kwargs
     drr.renderer.reducefn = "max"
     assert not drr._fused_ok(False, {})
@@ -293,6 +293,39 @@ def test_fused_entry_is_skipped_when_a_general_feature_is_asked_for(emulated_ops
     drr3 = DRR(synthetic_subject(24, kind="phantom", seed=0), sdd=300.0, height=12, delx=2.0,
                patch_size=6)
     assert not drr3._fused_ok(False, {})
+
+
+@pytest.mark.parametrize("stop", [False, True])
+def test_fused_mask_to_channels_equals_the_general_path(emulated_ops, stop):
+    """`mask_to_channels=True` through the fused entry (pose -> rays -> channel images in
+    kernels, the ray-generation adjoint restated on tensors in the backward) against the
+    general path (Detector.forward + render + autograd of the torch ops in between): images,
+    pose gradients and the volume gradient."""
+    from diffdrr_amd import DRR
+    from diffdrr_amd.data import synthetic_subject
+
+    res = {}
+    for fused in (True, False):
+        drr = DRR(synthetic_subject((24, 30, 20), kind="phantom", seed=3, n_labels=6), sdd=300.0,
+                  height=14, width=11, delx=2.0, stop_gradients_through_grid_sample=stop)
+        drr.fuse_ray_generation = fused
+        assert drr._fused_ok(True, {}) == fused
+        drr.density.requires_grad_()
+        rot = torch.tensor([[0.2, -0.1, 0.3], [0.0, 0.4, -0.2]], requires_grad=True)
+        xyz = torch.tensor([[3.0, 210.0, -2.0], [-4.0, 190.0, 5.0]], requires_grad=True)
+        ch = drr(rot, xyz, parameterization="euler_angles", convention="ZXY",
+                 mask_to_channels=True)
+        w = torch.rand(ch.shape, generator=torch.Generator().manual_seed(4))
+        (ch * w).sum().backward()
+        res[fused] = (ch.detach(), rot.grad, xyz.grad,
+                      None if stop else drr.density.grad.clone())
+    a, b = res[True], res[False]
+    assert a[0].shape == (2, 6, 14, 11)
+    assert rel_err(a[0].numpy(), b[0].numpy()) < 1e-5
+    assert rel_err(a[1].numpy(), b[1].numpy()) < 2e-3
+    assert rel_err(a[2].numpy(), b[2].numpy()) < 2e-3
+    if not stop:  # (the two paths' rays differ in the last bit: segment lengths to ~1e-5)
+        assert rel_err(a[3].numpy(), b[3].numpy()) < 1e-4
 
 
 def test_fused_ncc_equals_pytorch_formula(emulated_ops):
@@ -551,6 +584,43 @@ def test_render_with_permuted_rays_is_not_taken_for_a_detector_grid(emulated_ops
     assert rel_err(out.numpy(), ref[..., perm].numpy()) < 2e-5
     assert not emulated_ops.rays_form_detector_grid(source, target[:, perm], 22, 30)
     assert emulated_ops.rays_form_detector_grid(source, target, 22, 30)
+
+
+@pytest.mark.parametrize("renderer", ["siddon", "trilinear"])
+def test_swapped_in_renderer_checks_the_detector_shape_it_is_given(emulated_ops, renderer):
+    """A renderer whose `detector_shape` was set by someone else than `diffdrr_amd.DRR` (the
+    swap into the reference's DRR) checks the promise per call: rays that are
+    not that grid go to the per-ray kernels instead of being culled by the grid model."""
+    import diffdrr_amd
+
+    drr = _small_drr(renderer)
+    pose = convert(torch.tensor([[0.3, -0.2, 0.4]]), torch.tensor([[5.0, 250.0, -3.0]]),
+                   parameterization="euler_angles", convention="ZXY")
+    source, target = drr.detector(pose, None)
+    img = (target - source).norm(dim=-1).unsqueeze(1)
+    s, t = drr.affine_inverse(source), drr.affine_inverse(target)
+    mod = diffdrr_amd.Siddon() if renderer == "siddon" else diffdrr_amd.Trilinear()
+    kw = {} if renderer == "siddon" else {"n_points": 60}
+    calls = []
+    real = emulated_ops.rays_form_detector_grid
+    emulated_ops.rays_form_detector_grid = lambda *a, **k: calls.append(1) or real(*a, **k)
+    try:
+        with torch.no_grad():
+            plain = mod(drr.density, s, t, img, **kw)
+            assert not calls                                  # no shape promised: nothing to check
+            mod.detector_shape = (22, 30)
+            grid = mod(drr.density, s, t, img, **kw)
+            assert len(calls) == 1
+            perm = torch.randperm(t.shape[1], generator=torch.Generator().manual_seed(1))
+            out = mod(drr.density, s, t[:, perm], img[..., perm], **kw)
+            assert len(calls) == 2
+            mod.trust_detector_shape = True                   # what diffdrr_amd.DRR does
+            mod(drr.density, s, t, img, **kw)
+            assert len(calls) == 2
+    finally:
+        emulated_ops.rays_form_detector_grid = real
+    assert rel_err(grid.numpy(), plain.numpy()) < 3e-5
+    assert rel_err(out.numpy(), plain[..., perm].numpy()) < 3e-5
 
 
 def test_mask_label_cache_is_tied_to_the_mask_object(emulated_ops):

@@ -32,12 +32,38 @@ for B in (1, 8):
         plain, _ = timeit(lambda: drr(rot, xyz, parameterization="euler_angles", convention="ZXY"))
         drr.renderer.grid_path = "generic"
         plain_g, _ = timeit(lambda: drr(rot, xyz, parameterization="euler_angles", convention="ZXY"))
+        chan_g, _ = timeit(lambda: drr(rot, xyz, parameterization="euler_angles", convention="ZXY",
+                                       mask_to_channels=True))
+        cg = drr(rot, xyz, parameterization="euler_angles", convention="ZXY", mask_to_channels=True)
         drr.renderer.grid_path = "bricks"
         chan, _ = timeit(lambda: drr(rot, xyz, parameterization="euler_angles", convention="ZXY",
                                      mask_to_channels=True))
         a = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
         c = drr(rot, xyz, parameterization="euler_angles", convention="ZXY", mask_to_channels=True)
     err = ((c.sum(1, keepdim=True) - a).abs().max() / a.abs().max()).item()
+    err_g = ((c - cg).abs().max() / cg.abs().max()).item()
     print(f"B {B}: plain render (bricks) {plain:7.3f} ms | plain render (per-ray walk) {plain_g:7.3f} ms | "
-          f"{C}-channel render {chan:7.3f} ms = {chan / plain:5.2f} x bricks, {chan / plain_g:5.2f} x per-ray | "
-          f"channel sum vs plain {err:.1e}", flush=True)
+          f"{C}-channel render: bricks {chan:7.3f} ms = {chan / plain:5.2f} x plain bricks, per-ray "
+          f"kernel {chan_g:7.3f} ms | channel sum vs plain {err:.1e}, bricks vs per-ray channels "
+          f"{err_g:.1e}", flush=True)
+
+# the kernels alone (rays precomputed, labels converted): what the entry points cost
+from diffdrr_amd import convert, ops  # noqa: E402
+from diffdrr_amd.renderers import _labels_u8  # noqa: E402
+
+labels, _ = _labels_u8(drr.mask)
+for B in (1, 8):
+    rot = torch.zeros(B, 3, device=dev) + torch.linspace(0, 0.3, B, device=dev)[:, None]
+    xyz = torch.tensor([[0.0, 850.0, 0.0]], device=dev).expand(B, 3).contiguous()
+    with torch.no_grad():
+        pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+        source, target = drr.detector(pose, None)
+        L = (target - source).norm(dim=-1).contiguous()
+        s_, t_ = drr.affine_inverse(source).contiguous(), drr.affine_inverse(target).contiguous()
+        k_plain, _ = timeit(lambda: ops.siddon_forward_bricks(drr.density, s_, t_, L, (H, H)))
+        k_chb, _ = timeit(lambda: ops.siddon_forward_channels_bricks(drr.density, labels, C, s_, t_,
+                                                                      L, (H, H)))
+        k_chr, _ = timeit(lambda: ops.siddon_forward_channels(drr.density, labels, C, s_, t_, L,
+                                                              det=(H, H)))
+    print(f"B {B} entry points only: plain bricks {k_plain:7.3f} ms | channels on bricks {k_chb:7.3f} ms "
+          f"= {k_chb / k_plain:5.2f} x | per-ray channel kernel {k_chr:7.3f} ms", flush=True)
