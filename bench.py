@@ -337,7 +337,7 @@ def main():
         reg = Registration(drr, r0.clone(), x0.clone(), parameterization="euler_angles", convention="ZXY")
         opt = torch.optim.Adam([{"params": [reg._rotation], "lr": 1e-1},
                                 {"params": [reg._translation], "lr": 5e0}], maximize=True,
-                               capturable=on_gpu)
+                               capturable=on_gpu, fused=on_gpu)  # fused: one kernel per group
         pending, keep = [], {}
         try:
             if not on_gpu:
@@ -362,7 +362,7 @@ def main():
         units_per_step, unit, scaling = world, "iterations/s", "weak"
         metric = f"registration iterations/sec, {D}^3 vol -> {H}^2 det, SE(3) gradient ascent on NCC"
         workload = (f"{D}^3 fp32 phantom volume -> {H}x{H} detector, Siddon "
-                    f"(stop_gradients_through_grid_sample), Registration + NCC + Adam(1e-1 / 5e0), "
+                    f"(stop_gradients_through_grid_sample), Registration + NCC + torch.optim.Adam(1e-1 / 5e0, fused), "
                     f"one pose per GPU, one HIP graph per iteration")
         dominant = "ddrr_siddon_forward_bricks"
     else:  # "5": the candidate-pose sweep, sharded (strong scaling)
