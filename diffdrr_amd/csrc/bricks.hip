@@ -104,6 +104,9 @@ enum {
     PROF_DELIVER = 7, // atomics
     PROF_BARRIER = 8, // waiting for the other waves at the end of a brick
     PROF_N_BATCH = 9, PROF_N_STEPS = 10, PROF_N_UNITS = 11, PROF_N_HITS = 12,
+    PROF_CLAIM = 13,   // (part of staging) brick id known
+    PROF_ROWS = 14,    // (part of staging) row table written
+    PROF_STORE = 15,   // (part of staging) brick stored to LDS; PROF_STAGE then is the barrier + prefix
 };
 
 // what a brick launch computes
@@ -313,6 +316,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     __syncthreads();
     const int brick_id = counter[1];
     if (brick_id >= n_bricks) break;
+    DDRR_PROF(PROF_CLAIM);
     // `box`: the voxels staged in LDS; `cells`: the planes the candidates are clipped against
     Box box;
     BoxF cells;
@@ -377,6 +381,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
             *reinterpret_cast<BrickRow *>(rows + tid * kRowWords) = r;
         }
         if (tid == 0) counter[0] = 0;
+        DDRR_PROF(PROF_ROWS);
         // (with labels: two rounds of four quads -- all eight at once plus their labels do not
         // fit the register budget next to the kernel's loop invariants)
         constexpr int kRounds = LABELS ? 2 : 1, kPer = kQuads / kRounds;
@@ -447,6 +452,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                 }
             }
         }
+        DDRR_PROF(PROF_STORE);
         __syncthreads();
         // units per pose -> inclusive prefix, held by every wave in registers (lane k: pose k)
         int incl = lane < nb ? (reinterpret_cast<const BrickRow *>(rows + lane * kRowWords)->count +

@@ -34,7 +34,7 @@ dev = torch.device("cuda:0")
 D, H = a.size, a.det
 drr = DRR(make_subject(noise_volume(D, 0)), sdd=1020.0, height=H, delx=2.4 * (256 / H) * (D / 512)).to(dev)
 V = drr.density
-NAMES = ["stage+sync", "unit pull", "phase A", "batch pop", "ray loads", "setup", "walk", "deliver",
+NAMES = ["barrier+prefix", "unit pull", "phase A", "batch pop", "ray loads", "setup", "walk", "deliver",
          "barrier wait", "#batches", "#wave-steps", "#units", "#hits"]
 for case in a.cases.split(","):
     aux = case.endswith("aux")
@@ -53,8 +53,10 @@ for case in a.cases.split(","):
     buf = (ctypes.c_ulonglong * 16)()
     lib.cdll.ddrr_brick_profile_read(buf)
     v = list(buf)
-    tot = sum(v[:9])
+    tot = sum(v[:9]) + sum(v[13:16])
     print(f"## {case}: kernel {med:.3f} ms (profiling build); {tot / 4096:.0f} ticks per wave")
+    for i, n in zip((13, 14, 15), ("  claim", "  rows/issue", "  LDS store")):
+        print(f"  {n:14s} {100 * v[i] / tot:5.1f} %")
     for i, n in enumerate(NAMES):
         if i < 9:
             print(f"  {n:14s} {100 * v[i] / tot:5.1f} %")

@@ -15,7 +15,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tools.explib  # noqa: E402
 
-tools.explib.use("exp")  # experiment switches live in the tools build only
+if __name__ == "__main__":
+    # the experiment switches of main() live in the tools build only; importing this module for
+    # its helpers (poses, rays, timeit) leaves the caller on the product library
+    tools.explib.use("exp")
 from diffdrr_amd import DRR, _lib, ops  # noqa: E402
 from diffdrr_amd.data import make_subject, noise_volume  # noqa: E402
 from diffdrr_amd.pose import convert  # noqa: E402
