@@ -116,16 +116,18 @@ class DRR(nn.Module):
             # pose parameters -> world matrix in one kernel (pose.py euler_world_pose)
             Mw = euler_world_pose(args[0], args[1], convention, self.detector._reorient,
                                   degrees=degrees)
-            return self.reshape_transform(self._render_fused_Mw(Mw, calibration, mask_to_channels),
-                                          batch_size=len(Mw))
+            return self.reshape_transform(
+                self._render_fused_Mw(Mw, calibration, mask_to_channels, **kwargs),
+                batch_size=len(Mw))
         if parameterization is None:
             pose = args[0]
         else:
             pose = convert(*args, parameterization=parameterization, convention=convention,
                            degrees=degrees)
         if fused:
-            return self.reshape_transform(self._render_fused(pose, calibration, mask_to_channels),
-                                          batch_size=len(pose))
+            return self.reshape_transform(
+                self._render_fused(pose, calibration, mask_to_channels, **kwargs),
+                batch_size=len(pose))
         source, target = self.detector(pose, calibration)
         # (rays straight out of the Detector: a row-major affine grid by construction)
         self._rays_from_detector = True
@@ -150,18 +152,21 @@ class DRR(nn.Module):
         r = self.renderer
         if cal is not None and getattr(getattr(cal, "matrix", None), "requires_grad", False):
             return False  # gradients w.r.t. the intrinsics flow through Detector.forward only
-        return (self.fuse_ray_generation and isinstance(r, Siddon) and r.supports_pose_entry()
+        # (the marcher's fused entry takes its one everyday keyword, n_points)
+        kw_ok = not kwargs or (isinstance(r, Trilinear) and set(kwargs) == {"n_points"})
+        return (self.fuse_ray_generation and isinstance(r, (Siddon, Trilinear))
+                and r.supports_pose_entry()
                 and ops.on_device(self.density) and self.density.dtype == torch.float32
                 and (not mask_to_channels or getattr(self, "mask", None) is not None)
-                and not kwargs and not self.checkpoint_gradients
+                and kw_ok and not self.checkpoint_gradients
                 and self.patch_size is None and self.detector.n_subsample is None
                 and min(self.detector.height, self.detector.width) >= 2)
 
-    def _render_fused(self, pose, calibration, mask_to_channels=False):
+    def _render_fused(self, pose, calibration, mask_to_channels=False, **kwargs):
         Mw = (pose.matrix @ self.detector._reorient)[:, :3, :]   # reorient.compose(extrinsic)
-        return self._render_fused_Mw(Mw, calibration, mask_to_channels)
+        return self._render_fused_Mw(Mw, calibration, mask_to_channels, **kwargs)
 
-    def _render_fused_Mw(self, Mw, calibration, mask_to_channels=False):
+    def _render_fused_Mw(self, Mw, calibration, mask_to_channels=False, **kwargs):
         det = self.detector
         if calibration is None:
             # the calibrated detector points only change with the intrinsics: cached per
@@ -181,7 +186,7 @@ class DRR(nn.Module):
         self.renderer.detector_shape = (det.height, det.width)
         self.renderer.trust_detector_shape = True
         return self.renderer.render_poses(self.density, Mw, P, Ainv,
-                                          mask=self.mask if mask_to_channels else None)
+                                          mask=self.mask if mask_to_channels else None, **kwargs)
 
     def render(self, density: torch.Tensor, source: torch.Tensor, target: torch.Tensor,
                mask_to_channels: bool = False, **kwargs):

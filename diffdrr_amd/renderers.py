@@ -341,43 +341,38 @@ def _channels_forward(volume, labels, C, source, target, img, cfg):
         voxel_shift=cfg["voxel_shift"], eps=cfg["eps"], det=cfg["det"], tile=cfg["tile"])
 
 
-class _SiddonPoseChannelsFn(torch.autograd.Function):
-    """``_SiddonPoseFn`` with a mask: world pose per DRR -> (B, C, N) channel images without the
-    ray tensors passing through PyTorch ops in the forward.  Backward: the channel backward
-    kernel (per-ray endpoint gradients), chained to dLoss/dMw through the adjoint of the ray
-    generation (raygen_core.h: raygen_ray_adjoint, restated on the (B, N, 3) tensors)."""
+class _RaygenFn(torch.autograd.Function):
+    """Fused ray generation as a differentiable op: world pose per DRR ``Mw`` (B,3,4), calibrated
+    detector points ``P`` (N,3), world -> voxel ``Ainv`` (3,4)  ->  voxel-space source (B,1,3),
+    target (B,N,3) and world ray length (B,N) in one kernel (ddrr_raygen_forward: reference
+    detector.py:151-153, drr.py:201-205) instead of ~80 small tensor ops.  Backward: the adjoint
+    of raygen_core.h's raygen_ray_adjoint restated on the (B, N, 3) tensors -> dLoss/dMw.
+    (``_SiddonPoseFn`` fuses that adjoint into its pose-gradient kernel; this op serves the
+    renderers whose backward yields per-ray endpoint gradients: channels, the marcher.)"""
 
     @staticmethod
-    def forward(ctx, volume, Mw, P, Ainv, labels, C, cfg):
+    def forward(ctx, Mw, P, Ainv):
         source, target, img = ops.raygen_forward(Mw, Ainv, P)
-        out = _channels_forward(volume, labels, C, source, target, img, cfg)
-        ctx.cfg = cfg
-        ctx.save_for_backward(volume, Mw, P, Ainv, source, target, img, labels)
-        return out
+        ctx.save_for_backward(Mw, P, Ainv, img)
+        ctx.set_materialize_grads(False)  # an unused output's gradient arrives as None
+        return source, target, img
 
     @staticmethod
-    def backward(ctx, grad_out):
-        volume, Mw, P, Ainv, source, target, img, labels = ctx.saved_tensors
-        cfg = ctx.cfg
-        need_vol, need_M = ctx.needs_input_grad[:2]
-        stop = cfg["stop_gradients"]
-        gs, gt, gi, gv = ops.siddon_backward_channels(
-            volume, labels, source, target, img, grad_out, voxel_shift=cfg["voxel_shift"],
-            eps=cfg["eps"], want_rays=bool(need_M), want_img=bool(need_M and not stop),
-            want_volume=bool(need_vol and not stop), det=cfg["det"], tile=cfg["tile"])
-        g_M = None
-        if need_M:
-            A, R = Ainv[:, :3], Mw[:, :, :3]
-            g_tw = gt @ A                                   # transpose of Ainv's 3x3 block
-            g_sw = gs.sum(dim=1) @ A
-            if gi is not None:                              # img = ||tw - sw||
-                ku = (gi / img.clamp_min(1e-30)).unsqueeze(-1) * (P @ R.transpose(1, 2))
-                g_tw = g_tw + ku
-                g_sw = g_sw - ku.sum(dim=1)
-            g_R = torch.einsum("bna,nj->baj", g_tw, P)
-            g_T = g_tw.sum(dim=1) + g_sw                    # tw and sw both carry the translation
-            g_M = torch.cat([g_R, g_T.unsqueeze(-1)], dim=-1)
-        return gv, g_M, None, None, None, None, None
+    def backward(ctx, gs, gt, gi):
+        Mw, P, Ainv, img = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        A, R = Ainv[:, :3], Mw[:, :, :3]
+        B, N = img.shape
+        g_tw = gt @ A if gt is not None else Mw.new_zeros(B, N, 3)  # transpose of Ainv's 3x3 block
+        g_sw = gs.sum(dim=1) @ A if gs is not None else Mw.new_zeros(B, 3)
+        if gi is not None:                                  # img = ||tw - sw||
+            ku = (gi / img.clamp_min(1e-30)).unsqueeze(-1) * (P @ R.transpose(1, 2))
+            g_tw = g_tw + ku
+            g_sw = g_sw - ku.sum(dim=1)
+        g_R = torch.einsum("bna,nj->baj", g_tw, P)
+        g_T = g_tw.sum(dim=1) + g_sw                        # tw and sw both carry the translation
+        return torch.cat([g_R, g_T.unsqueeze(-1)], dim=-1), None, None
 
 
 class Siddon(torch.nn.Module):
@@ -451,7 +446,8 @@ class Siddon(torch.nn.Module):
         cfg = self._cfg(False)
         if mask is not None:
             labels, C = _labels_u8(mask)
-            return _SiddonPoseChannelsFn.apply(volume, Mw, P, Ainv, labels, C, cfg)
+            source, target, img = _RaygenFn.apply(Mw, P, Ainv)
+            return _SiddonChannelsFn.apply(volume, source, target, img, labels, C, cfg)
         return _SiddonPoseFn.apply(volume, Mw, P, Ainv, cfg).unsqueeze(1)
 
     def forward(self, volume, source, target, img, align_corners=False, mask=None):
@@ -688,6 +684,16 @@ class Trilinear(torch.nn.Module):
 
     def dims(self, volume):
         return torch.tensor(volume.shape).to(volume)
+
+    def supports_pose_entry(self):
+        """Whether ``render_poses`` (the fused DRR entry) computes what ``forward`` would."""
+        return self.mode == "bilinear" and self.reducefn == "sum"
+
+    def render_poses(self, volume, Mw, P, Ainv, mask=None, n_points=500):
+        """The DRR case with the rays generated by one kernel (see ``Siddon.render_poses``);
+        equals ``forward(volume, *rays(Mw, P, Ainv), n_points=n_points, mask=mask)``."""
+        source, target, img = _RaygenFn.apply(Mw, P, Ainv)
+        return self.forward(volume, source, target, img, n_points=n_points, mask=mask)
 
     def forward(self, volume, source, target, img, n_points=500, align_corners=False, mask=None,
                 alphamin=None, alphamax=None):

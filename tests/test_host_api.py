@@ -289,6 +289,9 @@ def test_fused_entry_is_skipped_when_a_general_feature_is_asked_for(emulated_ops
     assert not drr._fused_ok(False, {})
     drr2 = DRR(synthetic_subject(24, kind="phantom", seed=0), sdd=300.0, height=12, delx=2.0,
                renderer="trilinear")
+    assert drr2._fused_ok(False, {}) and drr2._fused_ok(False, {"n_points": 50})
+    assert not drr2._fused_ok(False, {"n_points": 50, "align_corners": True})
+    drr2.renderer.mode = "nearest"
     assert not drr2._fused_ok(False, {})
     drr3 = DRR(synthetic_subject(24, kind="phantom", seed=0), sdd=300.0, height=12, delx=2.0,
                patch_size=6)
@@ -326,6 +329,36 @@ def test_fused_mask_to_channels_equals_the_general_path(emulated_ops, stop):
     assert rel_err(a[2].numpy(), b[2].numpy()) < 2e-3
     if not stop:  # (the two paths' rays differ in the last bit: segment lengths to ~1e-5)
         assert rel_err(a[3].numpy(), b[3].numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("mask", [False, True])
+def test_fused_trilinear_entry_equals_the_general_path(emulated_ops, mask):
+    """The marcher through the fused entry (pose -> rays in kernels, the differentiable
+    ray-generation op of renderers.py) against the general path: images, pose gradients --
+    including the path through the batch-global marching range -- and the volume gradient."""
+    from diffdrr_amd import DRR
+    from diffdrr_amd.data import synthetic_subject
+
+    res = {}
+    for fused in (True, False):
+        drr = DRR(synthetic_subject((24, 30, 20), kind="phantom", seed=3, n_labels=5), sdd=300.0,
+                  height=14, width=11, delx=2.0, renderer="trilinear")
+        drr.fuse_ray_generation = fused
+        assert drr._fused_ok(mask, {"n_points": 70}) == fused
+        drr.density.requires_grad_()
+        rot = torch.tensor([[0.2, -0.1, 0.3], [0.0, 0.4, -0.2]], requires_grad=True)
+        xyz = torch.tensor([[3.0, 210.0, -2.0], [-4.0, 190.0, 5.0]], requires_grad=True)
+        img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY", n_points=70,
+                  mask_to_channels=mask)
+        w = torch.rand(img.shape, generator=torch.Generator().manual_seed(4))
+        (img * w).sum().backward()
+        res[fused] = (img.detach(), rot.grad, xyz.grad, drr.density.grad.clone())
+    a, b = res[True], res[False]
+    assert a[0].shape == (2, 5 if mask else 1, 14, 11)
+    assert rel_err(a[0].numpy(), b[0].numpy()) < 1e-5
+    assert rel_err(a[1].numpy(), b[1].numpy()) < 2e-3
+    assert rel_err(a[2].numpy(), b[2].numpy()) < 2e-3
+    assert rel_err(a[3].numpy(), b[3].numpy()) < 1e-4
 
 
 def test_fused_ncc_equals_pytorch_formula(emulated_ops):
