@@ -23,6 +23,28 @@ DDRR_HD float lin01(int m, int P, float lstep) {
     return m < P / 2 ? (float)m * lstep : 1.0f - (float)(P - 1 - m) * lstep;
 }
 
+// The marching range of one ray: first / last intersection with the volume enlarged by one
+// voxel, clipped to [0, 1] (reference renderers.py:124-140, the same operations in the same
+// order: IEEE division of (plane - s) by (t - s) + eps; far plane at dims + 1 - shift).
+DDRR_HD void ray_alpha_range(const Dims D, const float s[3], const float t[3], float shift,
+                             float eps, float &amin, float &amax) {
+    const float hi[3] = {(float)D.x + 1.f - shift, (float)D.y + 1.f - shift,
+                         (float)D.z + 1.f - shift};
+    amin = -INFINITY;
+    amax = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float sdd = (t[a] - s[a]) + eps;
+        const float a0 = (-shift - s[a]) / sdd, a1 = (hi[a] - s[a]) / sdd;
+        // (torch.minimum / maximum propagate NaN; fminf / fmaxf drop it: a NaN here is a ray
+        // with s == t on an axis, which the march handles by its own clip)
+        amin = fmaxf(amin, fminf(a0, a1));
+        amax = fminf(amax, fmaxf(a0, a1));
+    }
+    amin = fmaxf(amin, 0.f);
+    amax = fminf(amax, 1.f);
+}
+
 struct MarchSetup {
     float d[3];
     float span, step, lstep;

@@ -199,7 +199,63 @@ __global__ __launch_bounds__(kBlock) void trilinear_bwd_max_kernel(
 
 }  // namespace
 
+// Batch-global marching range (renderers.py:220-223): min over all rays of alphamin, max of
+// alphamax, one integer atomic per wave on the floats' bit patterns.  alphamin >= +0: unsigned
+// order is float order, range[0] starts at +inf.  alphamax <= 1 may be negative (every ray
+// leaves the volume behind the source): non-negative values compete as signed ints (max),
+// negative ones as unsigned ints (min: the least negative wins, any non-negative beats them);
+// range[1] starts at -inf.
+__global__ __launch_bounds__(kBlock) void alpha_range_kernel(const float *__restrict__ source,
+                                                             int src_n,
+                                                             const float *__restrict__ target,
+                                                             long R, int N, Dims D, float shift,
+                                                             float eps, unsigned *range) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (long r = (long)blockIdx.x * kBlock + threadIdx.x; r < R; r += (long)gridDim.x * kBlock) {
+        const long b = r / N, n = r - b * N;
+        const float *sp = source + (b * src_n + (src_n == 1 ? 0 : n)) * 3, *tp = target + r * 3;
+        const float s[3] = {sp[0], sp[1], sp[2]}, t[3] = {tp[0], tp[1], tp[2]};
+        float a0, a1;
+        ddrr::ray_alpha_range(D, s, t, shift, eps, a0, a1);
+        lo = fminf(lo, a0);
+        hi = fmaxf(hi, a1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(range, __float_as_uint(lo + 0.f));  // (-0 + 0 = +0)
+        if (hi >= 0.f)
+            atomicMax(reinterpret_cast<int *>(range + 1), __float_as_int(hi));
+        else
+            atomicMin(range + 1, __float_as_uint(hi));
+    }
+}
+
 extern "C" {
+
+int ddrr_trilinear_alpha_range(const float *source, int src_n, const float *target, int B, int N,
+                               int dx, int dy, int dz, float voxel_shift, float eps,
+                               float *range2, void *stream) {
+    if (!source || !target || !range2) return fail(-1, "null pointer");
+    if (dx < 1 || dy < 1 || dz < 1) return fail(-1, "volume dims must be positive");
+    if (B < 1 || N < 1) return fail(-1, "the marching range of an empty ray batch is undefined");
+    if (src_n != 1 && src_n != N) return fail(-1, "src_n must be 1 or N");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned init[2] = {0x7f800000u, 0xff800000u};  // +inf, -inf
+    hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(range2), (int)init[0], 1, st);
+    if (e == hipSuccess)
+        e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(range2 + 1), (int)init[1], 1, st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetD32Async");
+    const long R = (long)B * N;
+    const long blocks = (R + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(alpha_range_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)),
+                       dim3(kBlock), 0, st, source, src_n, target, R, N, Dims{dx, dy, dz},
+                       voxel_shift, eps, reinterpret_cast<unsigned *>(range2));
+    return finish("ddrr_trilinear_alpha_range");
+}
 
 int ddrr_trilinear_forward(const float *volume, int dx, int dy, int dz, const float *source,
                            int src_n, const float *target, const float *img, int B, int N,

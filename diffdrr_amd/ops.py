@@ -488,6 +488,21 @@ def siddon_backward_channels(volume, labels_u8, source, target, img, grad_out, *
     return g_source, g_target, g_img, g_volume
 
 
+def trilinear_alpha_range(source, target, volume_shape, *, voxel_shift=0.5, eps=1e-8):
+    """The batch-global marching range of reference renderers.py:220-223 in one pass over the
+    rays (no gradient flows through it).  -> (alphamin, alphamax), 0-dim device tensors."""
+    _require_gpu(target)
+    B, N, _ = target.shape
+    if source.dtype != torch.float32 or target.dtype != torch.float32:
+        raise NotImplementedError("trilinear_alpha_range needs float32 rays")
+    source, target = source.contiguous(), target.contiguous()
+    rng = torch.empty(2, dtype=torch.float32, device=target.device)
+    _launch("ddrr_trilinear_alpha_range", target.device, source.data_ptr(), source.shape[1],
+            target.data_ptr(), B, N, *(int(v) for v in volume_shape), float(voxel_shift),
+            float(eps), rng.data_ptr())
+    return rng[0], rng[1]
+
+
 def trilinear_forward(volume, source, target, img, alphamin, alphamax, *, n_points=500,
                       voxel_shift=0.5, eps=1e-8, reducefn="sum", mode="bilinear",
                       align_corners=False, det=None, tile=None):

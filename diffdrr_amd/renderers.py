@@ -703,10 +703,18 @@ class Trilinear(torch.nn.Module):
         if not user_reduce:
             ops.reduce_code(self.reducefn)
         if alphamin is None or alphamax is None:
-            # the reference's batch-global marching range (renderers.py:220-223)
-            lo, hi = get_alpha_minmax(source, target, self.dims(volume), self.voxel_shift,
-                                      self.eps)
-            alphamin, alphamax = lo.min(), hi.max()
+            # the reference's batch-global marching range (renderers.py:220-223): one kernel
+            # when nothing differentiates through it, tensor ops otherwise (autograd routes
+            # d/d alphamin, d/d alphamax to the arg-min / arg-max ray)
+            need_grad = torch.is_grad_enabled() and (source.requires_grad or target.requires_grad)
+            if (not need_grad and volume.dtype == torch.float32 and B > 0 and N > 0
+                    and ops.on_device(target)):
+                alphamin, alphamax = ops.trilinear_alpha_range(
+                    source, target, volume.shape, voxel_shift=self.voxel_shift, eps=self.eps)
+            else:
+                lo, hi = get_alpha_minmax(source, target, self.dims(volume), self.voxel_shift,
+                                          self.eps)
+                alphamin, alphamax = lo.min(), hi.max()
         alphamin = torch.as_tensor(alphamin, dtype=volume.dtype, device=volume.device)
         alphamax = torch.as_tensor(alphamax, dtype=volume.dtype, device=volume.device)
         if volume.dtype == torch.float64:

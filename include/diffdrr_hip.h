@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 18
+#define DDRR_ABI_VERSION 19
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -179,6 +179,15 @@ int ddrr_siddon_segments_backward(const float *volume, int dx, int dy, int dz, c
                                   const float *grad_terms, int B, int N, float voxel_shift,
                                   float eps, float *g_source, float *g_target, float *g_img,
                                   float *g_volume, void *stream);
+
+/* The batch-global marching range Trilinear.forward computes when alphamin / alphamax are not
+ * given (renderers.py:220-223 over _get_alpha_minmax :124-140): range2[0] = min over all rays of
+ * the first intersection with the volume (clipped to >= 0), range2[1] = max of the last
+ * (clipped to <= 1).  One pass over the rays; for ray lists that need no gradient through the
+ * range (the module falls back to tensor ops when they do). */
+int ddrr_trilinear_alpha_range(const float *source, int src_n, const float *target, int B, int N,
+                               int dx, int dy, int dz, float voxel_shift, float eps,
+                               float *range2, void *stream);
 
 /* Trilinear.forward, mask=None (renderers.py:205-241).  alphamin/alphamax are
  * DEVICE scalars (renderers.py:220-223 evaluated by the caller, or the

@@ -906,6 +906,24 @@ int ddrr_trilinear_forward_channels(const float *volume, const unsigned char *la
     return 0;
 }
 
+int ddrr_trilinear_alpha_range(const float *source, int src_n, const float *target, int B, int N,
+                               int dx, int dy, int dz, float voxel_shift, float eps,
+                               float *range2, void *) {
+    const Dims D{dx, dy, dz};
+    float lo = INFINITY, hi = -INFINITY;
+    for (long r = 0; r < (long)B * N; ++r) {
+        const long b = r / N, n = r - b * N;
+        const float *s = source + (b * src_n + (src_n == 1 ? 0 : n)) * 3, *t = target + r * 3;
+        float a0, a1;
+        ray_alpha_range(D, s, t, voxel_shift, eps, a0, a1);
+        lo = fminf(lo, a0);
+        hi = fmaxf(hi, a1);
+    }
+    range2[0] = lo;
+    range2[1] = hi;
+    return 0;
+}
+
 int ddrr_trilinear_forward(const float *volume, int dx, int dy, int dz, const float *source,
                            int src_n, const float *target, const float *img, int B, int N,
                            float voxel_shift, float eps, int n_points, const float *alphamin,

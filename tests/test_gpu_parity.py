@@ -146,6 +146,27 @@ def test_siddon_mask_gradients_golden(gpu):
         assert rel_err(gr.cpu().numpy(), g[name + "_f64"]) < GRAD_TOL, name
 
 
+def test_alpha_range_kernel(gpu):
+    """ddrr_trilinear_alpha_range against the tensor ops it replaces (reference
+    renderers.py:124-140, 220-223) on the device: oblique rays, per-ray sources, rays parallel
+    to an axis, all rays missing (negative alphamax), 300k rays (many blocks)."""
+    from diffdrr_amd.renderers import get_alpha_minmax
+
+    g = torch.Generator().manual_seed(0)
+    dims = (120, 100, 140)
+    for trial, (B, N) in enumerate([(3, 50), (2, 777), (1, 300000), (4, 64), (2, 100)]):
+        src = (torch.rand(B, 1 if trial % 2 else N, 3, generator=g) * 600 - 300).to(gpu)
+        tgt = (torch.rand(B, N, 3, generator=g) * 400 - 100).to(gpu)
+        if trial == 3:
+            tgt[:, :7, 0] = src[:, :1, 0] if src.shape[1] == 1 else src[:, :7, 0]
+        if trial == 4:
+            tgt = tgt + 5000.0
+        lo, hi = get_alpha_minmax(src, tgt, torch.tensor(dims, device=gpu).float(), 0.5, 1e-8)
+        a0, a1 = ops.trilinear_alpha_range(src, tgt, dims)
+        assert abs(a0.item() - lo.min().item()) <= 1e-7 * max(1.0, abs(lo.min().item())), trial
+        assert abs(a1.item() - hi.max().item()) <= 1e-7 * max(1.0, abs(hi.max().item())), trial
+
+
 @pytest.mark.parametrize("D,kind", [((96, 70, 133), "phantom"), ((64, 64, 61), "noise")])
 def test_siddon_channels_on_bricks_vs_oracle(gpu, D, kind):
     """mask_to_channels on the volume-stationary kernel (ddrr_siddon_forward_channels_bricks:

@@ -361,6 +361,46 @@ def test_fused_trilinear_entry_equals_the_general_path(emulated_ops, mask):
     assert rel_err(a[3].numpy(), b[3].numpy()) < 1e-4
 
 
+def test_alpha_range_kernel_equals_the_tensor_ops(emulated_ops):
+    """ddrr_trilinear_alpha_range (one pass, taken when nothing differentiates through the
+    marching range) against get_alpha_minmax + min / max (reference renderers.py:124-140,
+    220-223): bit-equal -- same IEEE operations -- on oblique rays, per-ray sources, rays
+    parallel to an axis, rays that miss the volume; and Trilinear.forward renders the same
+    image either way (fixture of the unmodified reference)."""
+    from diffdrr_amd import Trilinear
+    from diffdrr_amd.renderers import get_alpha_minmax
+
+    g = torch.Generator().manual_seed(0)
+    dims = (12, 10, 14)
+    for trial in range(6):
+        B, N = 3, 50
+        src = torch.rand(B, 1 if trial % 2 else N, 3, generator=g) * 60 - 30
+        tgt = torch.rand(B, N, 3, generator=g) * 40 - 10
+        if trial == 2:
+            tgt[:, :7, 0] = src[:, :1, 0] if src.shape[1] == 1 else src[:, :7, 0]   # d_x = eps
+        if trial == 3:
+            tgt = tgt + 500.0                                                       # all miss
+        lo, hi = get_alpha_minmax(src, tgt, torch.tensor(dims).float(), 0.5, 1e-8)
+        a0, a1 = emulated_ops.trilinear_alpha_range(src, tgt, dims)
+        assert a0.item() == lo.min().item() and a1.item() == hi.max().item(), trial
+    gold = golden("trilinear_global_range")
+    f32 = lambda k: torch.from_numpy(np.ascontiguousarray(gold[k], dtype=np.float32))  # noqa: E731
+    vol, s, t, img = (f32(k) for k in ("volume", "source", "target", "img_f32"))
+    calls = []
+    real = emulated_ops.trilinear_alpha_range
+    emulated_ops.trilinear_alpha_range = lambda *a, **k: calls.append(1) or real(*a, **k)
+    try:
+        with torch.no_grad():
+            out = Trilinear()(vol, s, t, img, n_points=41)
+        assert calls == [1]
+        out_g = Trilinear()(vol, s, t.clone().requires_grad_(), img, n_points=41)  # tensor ops
+        assert calls == [1]
+    finally:
+        emulated_ops.trilinear_alpha_range = real
+    assert rel_err(out.numpy(), gold["out_f32"]) < 1e-4
+    assert torch.equal(out, out_g.detach())
+
+
 def test_fused_ncc_equals_pytorch_formula(emulated_ops):
     """The fused NCC kernels (ddrr_ncc_forward / _backward, reference metrics.py:21-44)
     against the module's PyTorch formula: values and gradients, paired and with a fixed
