@@ -243,6 +243,10 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
             atomicAdd(X + p.aux_plane + r,
                       (unsigned long long)record_pack(rec[1], rec[3], p.rec_q, qa));
             unsafeAtomicAdd(aux + 4u * p.aux_plane + r, I);
+        } else if (p.dbg & 64) {
+            // (experiment builds: the record's delivery with one atomic instead of five -- what the
+            // kernel would cost if the atomics were free; the record is wrong)
+            unsafeAtomicAdd(aux + r, I + rec[0] + rec[1] + rec[2] + rec[3]);
         } else {
             unsafeAtomicAdd(aux + r, I);
             unsafeAtomicAdd(aux + p.aux_plane + r, rec[0]);
