@@ -331,7 +331,6 @@ DDRR_HD void step_walk_channels(const Fetch &fetch, const StepGeom &G, const Ste
         a_cur = a_next;                                                                   \
         Vc = Vn;                                                                          \
     }
-#pragma unroll 2
     for (int it = 0; it < 3 * BRICK + 4; it += 2) {
         DDRR_STEP()
         DDRR_STEP()
