@@ -162,6 +162,18 @@ DDRR_HD int scatter_perm(int local, int k, int count, float inv_count) {
     return (int)(((long)local * k) % count);
 }
 
+// With a float backward record a brick kernel is bound by its atomics, which cost per 64-byte
+// request at the memory side (0.4 ms per record plane at 512^3 / 32 poses): candidate rows that
+// start and end on 8-pixel boundaries make every lane group of 8 one 32-byte-aligned run of each
+// plane -- 1.0 request per group and plane instead of 1.44 -- at the price of ~30 % more
+// candidates to test (measured: forward + record 2.00 -> 1.83 ms).
+DDRR_HD PixBox align_pixbox_rows(PixBox pb, int det_w) {
+    if (pb.j1 < pb.j0 || pb.i1 < pb.i0) return pb;
+    pb.j0 &= ~7;
+    pb.j1 = (pb.j1 | 7) < det_w ? (pb.j1 | 7) : det_w - 1;
+    return pb;
+}
+
 // margin (voxels) by which phase A inflates the brick: covers the affine model's distance
 // from the stored targets, so a ray with a real chord in the brick is never rejected
 constexpr float kBrickMargin = 0.01f;

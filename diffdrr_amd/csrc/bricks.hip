@@ -355,6 +355,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     }
     const float nscale = (TRI || TRI_OWNER) ? (float)(p.n_points - 1) / (p.amax[0] - p.amin[0]) : 0.f;
     int qn0 = 0, qn1 = 0, qn2 = 0;  // hits waiting per length class (wave-uniform)
+    // the float backward records: length classes per group of 8 lanes = 8 adjacent pixels (below)
+    const bool GROUPED = ((AUX && p.rec_q == 0.f) || MODE == BRICK_TRI_FWD_AUX) && !(p.dbg & 8);
 
     for (int ch = 0; ch < n_chunks; ++ch) {
         const int b0 = ch * kPoseChunk;
@@ -379,7 +381,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         if (tid < nb) {
             const PoseGrid pg = pose_grid(p.source + (long)(b0 + tid) * 3,
                                           p.target + (long)(b0 + tid) * N * 3, p.det_h, p.det_w);
-            const PixBox pb = project_brick_grid(pg, p.det_h, p.det_w, cells, p.shift);
+            PixBox pb = project_brick_grid(pg, p.det_h, p.det_w, cells, p.shift);
+            if (GROUPED) pb = align_pixbox_rows(pb, p.det_w);
             BrickRow r = brick_row(pg, pb, cells, p.shift, p.eps, nscale);
             if (GRAD && !(p.dbg & 16)) r.perm_k = scatter_perm_k(r.w, r.count);
             *reinterpret_cast<BrickRow *>(rows + tid * kRowWords) = r;
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                 // is per line, not per lane (measured: 3.55 -> 2.74 ms; without the record
                 // the per-lane classes win, 1.87 vs 2.01 ms).
                 float n_grp = hit ? n_est : 0.f;
-                if (((AUX && p.rec_q == 0.f) || MODE == BRICK_TRI_FWD_AUX) && !(p.dbg & 8)) {
+                if (GROUPED) {
                     n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
                         0, __builtin_bit_cast(int, n_grp), 0xB1, 0xf, 0xf, true)));   // lane ^ 1
                     n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(

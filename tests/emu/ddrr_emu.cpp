@@ -112,7 +112,8 @@ int tri_bricks_host(const float *volume, int dx, int dy, int dz, const float *so
         for (int b = 0; b < B; ++b) {
             const PoseGrid pg = pose_grid(source + (long)b * 3, target + (long)b * N * 3, det_h,
                                           det_w);
-            const PixBox pb = project_brick_grid(pg, det_h, det_w, cells, voxel_shift);
+            PixBox pb = project_brick_grid(pg, det_h, det_w, cells, voxel_shift);
+            if (aux) pb = align_pixbox_rows(pb, det_w);  // as the kernel does with a float record
             const BrickRow row = brick_row(pg, pb, cells, voxel_shift, eps, nscale);
             std::vector<char> cand((size_t)N, 0);
             auto ray = [&](int pix, float s[3], float t[3]) {
@@ -367,7 +368,8 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
         for (int b = 0; b < B; ++b) {
             const PoseGrid pg = pose_grid(source + (long)b * 3, target + (long)b * N * 3, det_h,
                                           det_w);
-            const PixBox pb = project_brick_grid(pg, det_h, det_w, boxf(box), voxel_shift);
+            PixBox pb = project_brick_grid(pg, det_h, det_w, boxf(box), voxel_shift);
+            if (aux && !packed) pb = align_pixbox_rows(pb, det_w);  // as the kernel does
             const BrickRow row = brick_row(pg, pb, boxf(box), voxel_shift, eps, 0.f);
             // phase A must never lose a ray the exact clip accepts: check EVERY pixel of the
             // pose against the exact clip, inside and outside the projected pixel box
