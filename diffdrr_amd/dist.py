@@ -56,6 +56,23 @@ def sweep(drr, metric, fixed, rotations, translations, *, parameterization="eule
     P = rotations.shape[0]
     lo, hi = shard_bounds(P, rank, world)
     dev = drr.density.device
+    if getattr(drr.renderer, "batch_global_range", False) and "alphamin" not in render_kwargs:
+        # The marcher's sample positions depend on a marching range it takes over the whole batch
+        # of a call (reference renderers.py:220-223): left alone, a sweep's values would depend
+        # on how the candidates are cut into chunks and ranks.  One range for the whole
+        # candidate list instead: every rank reduces its slice, one all_reduce each way.
+        pose_kw = dict(parameterization=parameterization, convention=convention)
+        big = torch.finfo(torch.float32).max
+        amin = torch.full((), big, device=dev)
+        amax = torch.full((), -big, device=dev)
+        for a in range(lo, hi, chunk):
+            b = min(hi, a + chunk)
+            r0, r1 = drr.marching_range(rotations[a:b].to(dev), translations[a:b].to(dev), **pose_kw)
+            amin, amax = torch.minimum(amin, r0), torch.maximum(amax, r1)
+        if world > 1:
+            dist.all_reduce(amin, op=dist.ReduceOp.MIN)
+            dist.all_reduce(amax, op=dist.ReduceOp.MAX)
+        render_kwargs = dict(render_kwargs, alphamin=amin, alphamax=amax)
     vals = []
     for a in range(lo, hi, chunk):
         b = min(hi, a + chunk)

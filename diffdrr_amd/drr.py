@@ -153,7 +153,8 @@ class DRR(nn.Module):
         if cal is not None and getattr(getattr(cal, "matrix", None), "requires_grad", False):
             return False  # gradients w.r.t. the intrinsics flow through Detector.forward only
         # (the marcher's fused entry takes its one everyday keyword, n_points)
-        kw_ok = not kwargs or (isinstance(r, Trilinear) and set(kwargs) == {"n_points"})
+        kw_ok = not kwargs or (isinstance(r, Trilinear)
+                               and set(kwargs) <= {"n_points", "alphamin", "alphamax"})
         return (self.fuse_ray_generation and isinstance(r, (Siddon, Trilinear))
                 and r.supports_pose_entry()
                 and ops.on_device(self.density) and self.density.dtype == torch.float32
@@ -187,6 +188,26 @@ class DRR(nn.Module):
         self.renderer.trust_detector_shape = True
         return self.renderer.render_poses(self.density, Mw, P, Ainv,
                                           mask=self.mask if mask_to_channels else None, **kwargs)
+
+    @torch.no_grad()
+    def marching_range(self, *args, parameterization: str = None, convention: str = None,
+                       calibration: RigidTransform = None, degrees: bool = False):
+        """(alphamin, alphamax), 0-dim tensors: the marcher's batch-global range (reference
+        renderers.py:220-223) of the rays of these poses, without rendering them -- what a
+        caller passes back as ``alphamin=`` / ``alphamax=`` to render several batches on one
+        common range (``diffdrr_amd.dist.sweep`` does, so that a sharded sweep does not depend
+        on the world size)."""
+        pose = args[0] if parameterization is None else convert(
+            *args, parameterization=parameterization, convention=convention, degrees=degrees)
+        source, target = self.detector(pose, calibration)
+        source, target = self.affine_inverse(source), self.affine_inverse(target)
+        r = self.renderer
+        if ops.on_device(target) and target.dtype == torch.float32:
+            return ops.trilinear_alpha_range(source, target, self.density.shape,
+                                             voxel_shift=r.voxel_shift, eps=r.eps)
+        from .renderers import get_alpha_minmax
+        lo, hi = get_alpha_minmax(source, target, r.dims(self.density), r.voxel_shift, r.eps)
+        return lo.min(), hi.max()
 
     def render(self, density: torch.Tensor, source: torch.Tensor, target: torch.Tensor,
                mask_to_channels: bool = False, **kwargs):

@@ -685,15 +685,21 @@ class Trilinear(torch.nn.Module):
     def dims(self, volume):
         return torch.tensor(volume.shape).to(volume)
 
+    # the marching range is taken over the whole batch of a call unless it is passed in
+    # (reference renderers.py:220-223); diffdrr_amd.dist.sweep pins it for a sharded sweep
+    batch_global_range = True
+
     def supports_pose_entry(self):
         """Whether ``render_poses`` (the fused DRR entry) computes what ``forward`` would."""
         return self.mode == "bilinear" and self.reducefn == "sum"
 
-    def render_poses(self, volume, Mw, P, Ainv, mask=None, n_points=500):
+    def render_poses(self, volume, Mw, P, Ainv, mask=None, n_points=500, alphamin=None,
+                     alphamax=None):
         """The DRR case with the rays generated by one kernel (see ``Siddon.render_poses``);
-        equals ``forward(volume, *rays(Mw, P, Ainv), n_points=n_points, mask=mask)``."""
+        equals ``forward(volume, *rays(Mw, P, Ainv), n_points=n_points, mask=mask, ...)``."""
         source, target, img = _RaygenFn.apply(Mw, P, Ainv)
-        return self.forward(volume, source, target, img, n_points=n_points, mask=mask)
+        return self.forward(volume, source, target, img, n_points=n_points, mask=mask,
+                            alphamin=alphamin, alphamax=alphamax)
 
     def forward(self, volume, source, target, img, n_points=500, align_corners=False, mask=None,
                 alphamin=None, alphamax=None):

@@ -20,12 +20,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _scene():
+def _scene(renderer="siddon"):
     from diffdrr_amd import DRR, NormalizedCrossCorrelation2d
     from diffdrr_amd.data import synthetic_subject
 
     drr = DRR(synthetic_subject(24, kind="phantom", seed=0), sdd=300.0, height=20, width=16,
-              delx=2.0)
+              delx=2.0, renderer=renderer)
     g = torch.Generator().manual_seed(5)
     P = 7  # ragged over 2 ranks: 4 + 3
     rot = (torch.rand(P, 3, generator=g) - 0.5) * 0.6
@@ -46,18 +46,19 @@ def _patch_ops():
     ops._launch = lambda name, device, *a: emu.call(name, *a, None)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, renderer="siddon"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     _patch_ops()
     from diffdrr_amd import dist as ddist
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        drr, ncc, rot, xyz = _scene()
+        drr, ncc, rot, xyz = _scene(renderer)
+        kw = {"n_points": 60} if renderer == "trilinear" else {}
         with torch.no_grad():
             fixed = drr(torch.zeros(1, 3), torch.tensor([[0.0, 150.0, 0.0]]),
-                        parameterization="euler_angles", convention="ZXY")
-        vals = ddist.sweep(drr, ncc, fixed, rot, xyz, chunk=3)
+                        parameterization="euler_angles", convention="ZXY", **kw)
+        vals = ddist.sweep(drr, ncc, fixed, rot, xyz, chunk=3, **kw)
         lo, hi = ddist.shard_bounds(rot.shape[0], rank, world)
         q.put((rank, vals.tolist(), (lo, hi)))
         dist.barrier()
@@ -101,6 +102,44 @@ def test_pose_sharded_sweep_world2_matches_single_process(emulated_ops):
     for _, vals, _ in got:  # every rank holds the full, identical result
         assert torch.allclose(torch.tensor(vals), ref, rtol=0, atol=1e-6)
     assert ref.shape == (7,) and torch.isfinite(ref).all()
+
+
+@pytest.mark.timeout(300)
+def test_trilinear_sweep_does_not_depend_on_world_size_or_chunking(emulated_ops):
+    """The marcher's sample positions depend on a marching range taken over the batch of a call
+    (reference renderers.py:220-223).  `dist.sweep` pins one range for the whole candidate
+    list (local reduction + all_reduce MIN / MAX), so a sharded sweep equals the single-process
+    one and neither depends on the chunk size -- unlike rendering the chunks naively."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, "trilinear")) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from diffdrr_amd import dist as ddist
+
+    drr, ncc, rot, xyz = _scene("trilinear")
+    kw = dict(parameterization="euler_angles", convention="ZXY", n_points=60)
+    with torch.no_grad():
+        fixed = drr(torch.zeros(1, 3), torch.tensor([[0.0, 150.0, 0.0]]), **kw)
+        one = ddist.sweep(drr, ncc, fixed, rot, xyz, chunk=3, n_points=60)
+        other_chunks = ddist.sweep(drr, ncc, fixed, rot, xyz, chunk=7, n_points=60)
+        # what the pinning avoids: every chunk on its own range
+        naive = torch.cat([ncc(fixed.expand(b - a, -1, -1, -1), drr(rot[a:b], xyz[a:b], **kw))
+                           for a, b in ((0, 3), (3, 6), (6, 7))])
+    for _, vals, _ in got:
+        assert torch.allclose(torch.tensor(vals), one, rtol=0, atol=1e-6)
+    assert torch.allclose(other_chunks, one, rtol=0, atol=1e-6)
+    assert (naive - one).abs().max() > 1e-6  # (the ranges really differ between chunks)
+    # the range the sweep used is the range of the whole list
+    r0, r1 = drr.marching_range(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    parts = [drr.marching_range(rot[a:b], xyz[a:b], parameterization="euler_angles",
+                                convention="ZXY") for a, b in ((0, 4), (4, 7))]
+    assert r0 == min(p[0] for p in parts) and r1 == max(p[1] for p in parts)
 
 
 @pytest.mark.parametrize("config,extra", [("headline", ["--batch", "3"]), ("5", ["--batch", "7"])])
