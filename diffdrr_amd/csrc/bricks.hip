@@ -120,7 +120,7 @@ constexpr int BRICK_CHANNELS = 6;     // out (B, C, N): one line integral per la
 
 inline size_t brick_lds_bytes(const BrickLayout &lay) {
     return (size_t)brick_floats(lay) * 4 + (size_t)kBrickWaves * kBuckets * kQueueCap * 4 +
-           (size_t)(kPoseChunk * kRowWords + 2) * 4;
+           (size_t)(kPoseChunk * kRowWords + 4) * 4;
 }
 
 #if defined(__HIPCC__)
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     float *brick = reinterpret_cast<float *>(smem_raw);
     unsigned *queue = reinterpret_cast<unsigned *>(brick + brick_floats(p.lay));
     float *rows = reinterpret_cast<float *>(queue + kBrickWaves * kBuckets * kQueueCap);
-    int *counter = reinterpret_cast<int *>(rows + kPoseChunk * kRowWords);  // [0] unit, [1] brick
+    int *counter = reinterpret_cast<int *>(rows + kPoseChunk * kRowWords);  // [0] unit, [1] brick, [2] brick not empty
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const BrickGrid bg = TRI ? tri_brick_grid(p.D) : brick_grid(p.D);
@@ -316,7 +316,10 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
   for (;;) {
     __syncthreads();  // every wave is done with the previous brick's LDS
     DDRR_PROF(PROF_BARRIER);
-    if (tid == 0) counter[1] = atomicAdd(p.work, 1);
+    if (tid == 0) {
+        counter[1] = atomicAdd(p.work, 1);
+        counter[2] = 0;  // "a staged voxel is non-zero"
+    }
     __syncthreads();
     const int brick_id = counter[1];
     if (brick_id >= n_bricks) break;
@@ -355,6 +358,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     }
     const float nscale = (TRI || TRI_OWNER) ? (float)(p.n_points - 1) / (p.amax[0] - p.amin[0]) : 0.f;
     int qn0 = 0, qn1 = 0, qn2 = 0;  // hits waiting per length class (wave-uniform)
+    bool brick_empty = false;        // every staged voxel is zero (set with the first chunk)
     // the float backward records: length classes per group of 8 lanes = 8 adjacent pixels (below)
     const bool GROUPED = ((AUX && p.rec_q == 0.f) || MODE == BRICK_TRI_FWD_AUX) && !(p.dbg & 8);
 
@@ -388,6 +392,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
             *reinterpret_cast<BrickRow *>(rows + tid * kRowWords) = r;
         }
         if (tid == 0) counter[0] = 0;
+        unsigned nz = 0u;  // OR of the bits of every voxel this thread stages
         DDRR_PROF(PROF_ROWS);
         // (with labels: two rounds of four quads -- all eight at once plus their labels do not
         // fit the register budget next to the kernel's loop invariants)
@@ -424,6 +429,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                     d[1] = in ? q[i].y : 0.f;
                     d[2] = in ? q[i].z : 0.f;
                     d[3] = in ? q[i].w : 0.f;
+                    nz |= __float_as_uint(d[0]) | __float_as_uint(d[1]) | __float_as_uint(d[2]) |
+                          __float_as_uint(d[3]);
                 }
                 if (LABELS) __builtin_amdgcn_sched_barrier(0);  // keep the rounds apart
             }
@@ -455,12 +462,22 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                     const int lx = row / BRICK, ly = row - lx * BRICK;
                     float *d = d0 + lx * p.lay.sx + ly * p.lay.sy;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) d[k] = v[it][k];
+                    for (int k = 0; k < 4; ++k) {
+                        d[k] = v[it][k];
+                        nz |= __float_as_uint(v[it][k]);
+                    }
                 }
             }
         }
         DDRR_PROF(PROF_STORE);
+        // Empty space: a brick of zeros (air around the patient: HU -> density maps it to exactly
+        // 0, reference data.py:214-227) adds nothing to any line integral, record or channel, so
+        // none of its candidates is looked at.  (Sign and, for the channel words, label bits do
+        // not make a voxel non-zero; the volume-gradient modes have no such shortcut.)
+        constexpr unsigned kValueBits = MODE == BRICK_CHANNELS ? 0x7fffff00u : 0x7fffffffu;
+        if (!GRAD && ch == 0 && (nz & kValueBits) != 0u) counter[2] = 1;  // (cleared with the claim)
         __syncthreads();
+        if (!GRAD && ch == 0) brick_empty = counter[2] == 0;
         // units per pose -> inclusive prefix, held by every wave in registers (lane k: pose k)
         int incl = lane < nb ? (reinterpret_cast<const BrickRow *>(rows + lane * kRowWords)->count +
                                 63) >> 6
@@ -470,7 +487,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
             const int up = __shfl_up(incl, o, 64);
             incl += lane >= o ? up : 0;
         }
-        const int units = __builtin_amdgcn_readlane(incl, kPoseChunk - 1);
+        const int units = brick_empty ? 0 : __builtin_amdgcn_readlane(incl, kPoseChunk - 1);
         int cur = 0, cur_lo = 0, cur_hi = __builtin_amdgcn_readlane(incl, 0);
         DDRR_PROF(PROF_STAGE);
         for (;;) {

@@ -146,6 +146,54 @@ def test_siddon_mask_gradients_golden(gpu):
         assert rel_err(gr.cpu().numpy(), g[name + "_f64"]) < GRAD_TOL, name
 
 
+def test_empty_bricks_are_skipped_without_changing_anything(gpu):
+    """A CT is mostly air, which the HU -> density transform maps to exactly 0 (reference
+    data.py:214-227): the brick kernels do not look at the candidates of a brick whose staged
+    voxels are all zero.  Volume with a dense blob, a slab of -0.0 and zeros elsewhere: images,
+    backward record, channels and the marcher against the per-ray kernels, which know no such
+    shortcut, and against the oracle."""
+    from diffdrr_amd import ops as O
+
+    D, H, W = (96, 128, 70), 40, 52
+    g = torch.Generator().manual_seed(3)
+    vol = torch.zeros(D)
+    vol[50:90, 20:70, 30:66] = torch.rand(40, 50, 36, generator=g)
+    vol[:, 100:104, :] = -0.0
+    labels = torch.zeros(D, dtype=torch.uint8)
+    labels[40:, :, :] = 3
+    labels[60:80, 30:50, :] = 7
+    drr = DRR(make_subject(vol, (1.0, 1.0, 1.0), "AP", None), sdd=600.0, height=H, width=W,
+              delx=3.0).to(gpu)
+    # (no pose on a symmetry plane: exact ties are attributed by convention, test_emu_vs_oracle)
+    rot = torch.tensor([[0.3, 0.2, -0.1], [1.2, 0.1, 0.0], [-0.4, 0.05, 0.6]], device=gpu)
+    xyz = torch.tensor([[5.0, 400.0, -3.0], [0.0, 380.0, 0.0], [-7.0, 420.0, 4.0]], device=gpu)
+    with torch.no_grad():
+        pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+        source, target = drr.detector(pose, None)
+        L = (target - source).norm(dim=-1).contiguous()
+        s = drr.affine_inverse(source).contiguous()
+        t = drr.affine_inverse(target).contiguous()
+    V, lab = drr.density, labels.to(gpu)
+    out, aux = O.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True)
+    gen, aux_gen, _ = O.siddon_forward(V, s, t, L, want_aux=True)
+    ref = oracle.siddon(V.cpu().numpy(), s.cpu().numpy(), t.cpu().numpy(), L.cpu().numpy())["out"]
+    assert rel_err(out.cpu().numpy(), ref.reshape(out.shape)) < FWD_TOL
+    assert rel_err(out.cpu().numpy(), gen.cpu().numpy()) < 2e-5
+    go = torch.rand(out.shape, device=gpu, generator=torch.Generator(gpu).manual_seed(1))
+    gb = O.siddon_backward_rays(aux, go, s, t, L)
+    gg = O.siddon_backward_rays(aux_gen, go, s, t, L)
+    for a, b in zip(gb, gg):
+        assert rel_err(a.sum(1).cpu().numpy(), b.sum(1).cpu().numpy()) < 2e-3
+    ch = O.siddon_forward_channels_bricks(V, lab, 8, s, t, L, (H, W))
+    chr_ = O.siddon_forward_channels(V, lab, 8, s, t, L)
+    assert rel_err(ch.cpu().numpy(), chr_.cpu().numpy()) < 3e-5
+    a0, a1 = O.trilinear_alpha_range(s, t, V.shape)
+    tri = O.trilinear_forward_bricks(V, s, t, L, a0, a1, (H, W), n_points=200)
+    trr = O.trilinear_forward(V, s, t, L, a0, a1, n_points=200)
+    assert rel_err(tri.cpu().numpy(), trr.cpu().numpy()) < 2e-5
+    assert out.abs().max() > 1.0  # (the scene is not empty)
+
+
 def test_alpha_range_kernel(gpu):
     """ddrr_trilinear_alpha_range against the tensor ops it replaces (reference
     renderers.py:124-140, 220-223) on the device: oblique rays, per-ray sources, rays parallel
