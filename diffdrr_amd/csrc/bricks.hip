@@ -900,7 +900,8 @@ extern "C" {
 // per-device launch resources (include/diffdrr_hip.h).
 //   layout: LDS strides (floats) of a staged brick; sy >= 32, sx >= 32 * sy
 //   debug flags: 8 per-lane length classes also with the record (no groups of 8 pixels),
-//                16 no scatter permutation, 32 float LDS accumulation
+//                16 no scatter permutation, 32 float LDS accumulation,
+//                64 the float record delivered with one atomic instead of five (timing only: wrong record)
 int ddrr_set_brick_layout(int sy, int sx) {
     if (sy < BRICK || sx < BRICK * sy) return -1;
     BrickLayout lay = {sy, sx};
