@@ -154,11 +154,16 @@ struct LdsAbsAdd {
 // (B, C, N): one fire-and-forget atomic per run.  32-bit offsets: the host checks B C N < 2^30.
 struct BrickColumnFlush {
     float *out;
-    unsigned col;  // b * C * N + pixel
-    unsigned N, C;
+    unsigned colb;  // byte offset of (b, 0, pixel): 4 (b C N + pixel)
+    unsigned N4, C;  // byte stride between channels
     float L;
     __device__ __forceinline__ void operator()(unsigned lab, float run) const {
-        if (lab < C) unsafeAtomicAdd(out + (col + __umul24(lab, N)), L * run);
+        // (a 32-bit byte offset from the wave-uniform base: one multiply-add and the atomic's
+        // scalar-base addressing instead of 64-bit index arithmetic per flush)
+        if (lab < C)
+            unsafeAtomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(out) +
+                                                      (colb + __umul24(lab, N4))),
+                            L * run);
     }
 };
 #endif
@@ -221,7 +226,8 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
     if (MODE == BRICK_CHANNELS) {
         const unsigned N = (unsigned)(p.det_h * p.det_w), C = (unsigned)p.n_channels;
         if (E.hit)
-            step_walk_channels(LdsAbsFetch{}, SG, E, BrickColumnFlush{out, b * C * N + pix, N, C, L});
+            step_walk_channels(LdsAbsFetch{}, SG, E,
+                               BrickColumnFlush{out, (b * C * N + pix) * 4u, N * 4u, C, L});
         DDRR_PROF(PROF_WALK);
         return;
     }
@@ -973,8 +979,8 @@ int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char
     if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
     if (!labels || !out || C < 1) return fail(-1, "null labels/out or C < 1");
     if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
-    if ((long)B * C * N >= (1L << 30) || N >= (1 << 24))
-        return fail(-1, "B * C * N must stay below 2^30 (and N below 2^24) for one channel launch "
+    if ((long)B * C * N >= (1L << 30) || N >= (1 << 22))
+        return fail(-1, "B * C * N must stay below 2^30 (and N below 2^22) for one channel launch "
                         "on the bricks: split the pose batch or use ddrr_siddon_forward_channels");
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;

@@ -390,7 +390,7 @@ def siddon_forward_channels_bricks(volume, labels_u8, n_channels, source, target
 
 def channels_fit_bricks(B, C, N):
     """One brick launch addresses the (B, C, N) result with 32-bit byte offsets."""
-    return B * C * N < 2 ** 30 and N < 2 ** 24
+    return B * C * N < 2 ** 30 and N < 2 ** 22
 
 
 def siddon_backward_midpoint(volume, source, target, img, grad_out, *, voxel_shift=0.5, eps=1e-8,

@@ -147,7 +147,7 @@ int ddrr_siddon_forward_channels(const float *volume, const unsigned char *label
  * on the volume-stationary brick kernel: the label travels in the low 8 bits of the staged
  * voxel word, the value keeps a 16-bit mantissa (rounded to nearest, 2^-17 relative per voxel:
  * channel sums agree with the plain render to ~1e-5 of the image scale).  out (B, C, N) is
- * fully written; B * C * N < 2^30.  The backward is ddrr_siddon_backward_channels. */
+ * fully written; B * C * N < 2^30, N < 2^22.  The backward is ddrr_siddon_backward_channels. */
 int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char *labels, int dx,
                                         int dy, int dz, const float *source, const float *target,
                                         const float *img, int B, int det_h, int det_w, int C,
