@@ -10,6 +10,7 @@
 #include "brick_walk.h"
 #include "brick_step.h"
 #include "record_pack.h"
+#include "record_layout.h"
 #include "tri_brick.h"
 #include "trilinear_core.h"
 
@@ -40,7 +41,6 @@ constexpr int kBrickWaves = kBrickThreads / 64;
 constexpr int kPoseChunk = 32;
 constexpr int kQueueCap = 128;
 constexpr int kBuckets = 3;
-constexpr int kBrickAuxPlanes = 5;  // I, S0x, S0z, S1x, S1z (y follows from the sums)
 
 struct BrickArgs {
     const float *vol;
@@ -168,16 +168,106 @@ struct BrickColumnFlush {
 };
 #endif
 
+constexpr int kRor8 = 0x128;  // DPP row_ror:8: lane ^ 8 within each row of 16
+
+// The float backward record of one batch of hits, delivered to the blocked layout of
+// record_layout.h.  Called by ALL lanes of the wave (ok: the lane holds a hit): lane l swaps
+// plane 1 (3) of its hit against plane 0 (2) of lane l ^ 8's, so that the lower half of a
+// 16-lane row carries planes 0 | 1 of its eight hits and the upper half those of its own eight --
+// when the eight are one run of adjacent pixels (they are: length classes are formed per run of 8)
+// each half row is one contiguous 64-byte line: 2 + 2 + 1 atomic instructions as before, but
+// whole lines instead of half lines.  v = {I, S0x, S0z, S1x, S1z}.
+__device__ __forceinline__ void deliver_record_blocked(float *__restrict__ aux, bool ok,
+                                                       unsigned r, const float v[5]) {
+    const unsigned lo = rec_off01(r) | (ok ? 0u : 0x80000000u);  // (sign bit: nothing to add)
+    const int o0 = (int)lo, o1 = (int)(lo + 8u);
+    // X: lanes 0-7 of a row own plane 0 | lanes 8-15 their partner's plane 1
+    // Y: lanes 0-7 their partner's plane 0 | lanes 8-15 own plane 1
+    const int xo = __builtin_amdgcn_update_dpp(o0, o1, kRor8, 0xf, 0xC, false);
+    const int yo = __builtin_amdgcn_update_dpp(o1, o0, kRor8, 0xf, 0x3, false);
+    auto swap_hi = [](float own, float other) {  // lanes 8-15 <- partner's `other`
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+            __builtin_bit_cast(int, own), __builtin_bit_cast(int, other), kRor8, 0xf, 0xC, false));
+    };
+    auto swap_lo = [](float own, float other) {  // lanes 0-7 <- partner's `other`
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+            __builtin_bit_cast(int, own), __builtin_bit_cast(int, other), kRor8, 0xf, 0x3, false));
+    };
+    const float x01 = swap_hi(v[0], v[1]), y01 = swap_lo(v[1], v[0]);
+    const float x23 = swap_hi(v[2], v[3]), y23 = swap_lo(v[3], v[2]);
+    if (xo >= 0) {
+        unsafeAtomicAdd(aux + xo, x01);
+        unsafeAtomicAdd(aux + xo + 16, x23);
+    }
+    if (yo >= 0) {
+        unsafeAtomicAdd(aux + yo, y01);
+        unsafeAtomicAdd(aux + yo + 16, y23);
+    }
+    if (ok) unsafeAtomicAdd(aux + rec_off4(r), v[4]);
+}
+
 // Phase B for one queue entry: load the real ray, clip, walk; add to the image (forward)
-// or scatter into the LDS accumulator (volume gradient).
+// or scatter into the LDS accumulator (volume gradient).  Called by every lane of the wave;
+// `active`: the lane holds a queue entry.
 // Offsets are 32-bit: the host checks 12 * B * N < 2^32.
 template <int MODE>
 __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *brick,
-                                           const BrickGeom &G, const StepGeom &SG, unsigned b,
-                                           unsigned pix, float fixq, float *__restrict__ out,
-                                           float *__restrict__ aux, BrickProf &prof) {
+                                           const BrickGeom &G, const StepGeom &SG, bool active,
+                                           unsigned b, unsigned pix, float fixq,
+                                           float *__restrict__ out, float *__restrict__ aux,
+                                           BrickProf &prof) {
     constexpr bool AUX = MODE == BRICK_FWD_AUX;
     const unsigned r = b * (unsigned)(p.det_h * p.det_w) + pix;
+    if (AUX) {
+        // the walk under the lanes that hold an entry, the record's delivery by all of them
+        float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        bool ok = false;
+        if (active) {
+            const float *sp = p.source + b * 3u, *tp = p.target + r * 3u;
+            const float s[3] = {sp[0], sp[1], sp[2]}, t[3] = {tp[0], tp[1], tp[2]};
+            DDRR_PROF_WAIT_VMEM();
+            DDRR_PROF(PROF_LOADS);
+            const StepEntry E = step_enter(SG, s, t, p.shift, p.eps, LdsAbsFetch::base_of(brick));
+            DDRR_PROF(PROF_SETUP);
+            int steps = 0;
+            if (E.hit) steps = step_walk<true>(LdsAbsFetch{}, SG, E, v[0], v + 1);
+            DDRR_PROF(PROF_WALK);
+            DDRR_PROF_COUNT(PROF_N_STEPS, (unsigned long long)__builtin_amdgcn_readfirstlane(steps));
+            (void)steps;
+            ok = E.hit;  // (phase A's margin lets a few non-crossing rays through)
+        }
+        // with the record, out = L * (plane I) is formed afterwards (siddon_out_from_record_kernel)
+        if (p.rec_q > 0.f) {
+            if (ok) {
+                // packed record: (S1x : S0x) and (S1z : S0z) as two 64-bit integer atomics
+                const float qa = p.rec_q / aux[5u * p.aux_plane + r];
+                unsigned long long *X = reinterpret_cast<unsigned long long *>(aux);
+                atomicAdd(X + r, (unsigned long long)record_pack(v[1], v[3], p.rec_q, qa));
+                atomicAdd(X + p.aux_plane + r,
+                          (unsigned long long)record_pack(v[2], v[4], p.rec_q, qa));
+                unsafeAtomicAdd(aux + 4u * p.aux_plane + r, v[0]);
+            }
+        } else if (p.dbg & 64) {
+            // (experiment builds: the record's delivery with one atomic instead of five -- what the
+            // kernel would cost if the atomics were free; the record is wrong)
+            if (ok) unsafeAtomicAdd(aux + r, v[0] + v[1] + v[2] + v[3] + v[4]);
+        } else if (p.dbg & 128) {
+            // (experiment builds: the blocked layout without the lane swap: half lines)
+            if (ok) {
+                const unsigned o = rec_off01(r);
+                unsafeAtomicAdd(aux + o, v[0]);
+                unsafeAtomicAdd(aux + o + 8, v[1]);
+                unsafeAtomicAdd(aux + o + 16, v[2]);
+                unsafeAtomicAdd(aux + o + 24, v[3]);
+                unsafeAtomicAdd(aux + rec_off4(r), v[4]);
+            }
+        } else {
+            deliver_record_blocked(aux, ok, r, v);
+        }
+        DDRR_PROF(PROF_DELIVER);
+        return;
+    }
+    if (!active) return;
     const float *sp = p.source + b * 3u, *tp = p.target + r * 3u;
     const float s[3] = {sp[0], sp[1], sp[2]}, t[3] = {tp[0], tp[1], tp[2]};
     const float L = p.img ? p.img[r] : 1.f;
@@ -233,34 +323,12 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
     }
     float I = 0.f, rec[4] = {0.f, 0.f, 0.f, 0.f};
     int steps = 0;
-    if (E.hit) steps = step_walk<AUX>(LdsAbsFetch{}, SG, E, I, rec);
+    if (E.hit) steps = step_walk<false>(LdsAbsFetch{}, SG, E, I, rec);
     DDRR_PROF(PROF_WALK);
     DDRR_PROF_COUNT(PROF_N_STEPS, (unsigned long long)__builtin_amdgcn_readfirstlane(steps));
     (void)steps;
     if (!E.hit) return;  // phase A's margin let a non-crossing ray through
-    // with the record, out = L * (plane I) is formed afterwards (siddon_out_from_record_kernel)
-    if (!AUX) unsafeAtomicAdd(out + r, L * I);
-    if (AUX) {
-        if (p.rec_q > 0.f) {
-            // packed record: (S1x : S0x) and (S1z : S0z) as two 64-bit integer atomics
-            const float qa = p.rec_q / aux[5u * p.aux_plane + r];
-            unsigned long long *X = reinterpret_cast<unsigned long long *>(aux);
-            atomicAdd(X + r, (unsigned long long)record_pack(rec[0], rec[2], p.rec_q, qa));
-            atomicAdd(X + p.aux_plane + r,
-                      (unsigned long long)record_pack(rec[1], rec[3], p.rec_q, qa));
-            unsafeAtomicAdd(aux + 4u * p.aux_plane + r, I);
-        } else if (p.dbg & 64) {
-            // (experiment builds: the record's delivery with one atomic instead of five -- what the
-            // kernel would cost if the atomics were free; the record is wrong)
-            unsafeAtomicAdd(aux + r, I + rec[0] + rec[1] + rec[2] + rec[3]);
-        } else {
-            unsafeAtomicAdd(aux + r, I);
-            unsafeAtomicAdd(aux + p.aux_plane + r, rec[0]);
-            unsafeAtomicAdd(aux + 2u * p.aux_plane + r, rec[1]);
-            unsafeAtomicAdd(aux + 3u * p.aux_plane + r, rec[2]);
-            unsafeAtomicAdd(aux + 4u * p.aux_plane + r, rec[3]);
-        }
-    }
+    unsafeAtomicAdd(out + r, L * I);
     DDRR_PROF(PROF_DELIVER);
 }
 
@@ -586,9 +654,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                 }
                 DDRR_PROF(PROF_POP);
                 DDRR_PROF_COUNT(PROF_N_BATCH, 1);
-                if (lane < n)
-                    brick_item<MODE>(p, brick, G, SG, e >> p.pix_bits, e & pix_mask, fixq, out,
-                                           aux, prof);
+                brick_item<MODE>(p, brick, G, SG, lane < n, e >> p.pix_bits, e & pix_mask, fixq,
+                                 out, aux, prof);
                 wave_fence();
             }
             if (drain) break;
@@ -708,10 +775,12 @@ __global__ __launch_bounds__(kBlock) void record_prepare_kernel(
 
 // out = L * I from plane 0 of the Siddon planar record (the record launch leaves `out` alone:
 // one atomic less per ray and brick).
+// (blocked: the float record of record_layout.h; else plane I of the packed record)
 __global__ __launch_bounds__(kBlock) void siddon_out_from_record_kernel(
-    const float *__restrict__ aux, const float *__restrict__ img, long R, float *__restrict__ out) {
+    const float *__restrict__ aux, int blocked, const float *__restrict__ img, long R,
+    float *__restrict__ out) {
     const long r = (long)blockIdx.x * kBlock + threadIdx.x;
-    if (r < R) out[r] = (img ? img[r] : 1.f) * aux[r];
+    if (r < R) out[r] = (img ? img[r] : 1.f) * aux[blocked ? rec_index(r, 0) : r];
 }
 
 // out = L * step * sumT from plane 0 of the marcher's planar record (the record launch
@@ -951,8 +1020,9 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     hipStream_t st = (hipStream_t)stream;
     const long R = (long)B * N;
     const bool packed = aux && record_vmax > 0.f;
-    hipError_t e = hipMemsetAsync(aux ? aux : out, 0,
-                                  sizeof(float) * (size_t)R * (aux ? kBrickAuxPlanes : 1), st);
+    // (the packed record's planes 5, 6 are written by record_prepare_kernel)
+    const size_t fill = !aux ? (size_t)R : (packed ? (size_t)R * 5 : (size_t)rec_blocked_floats(R));
+    hipError_t e = hipMemsetAsync(aux ? aux : out, 0, sizeof(float) * fill, st);
     if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
     float rec_q = 0.f;
     if (packed) {
@@ -967,7 +1037,7 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
         return rc;
     if (!aux) return 0;
     hipLaunchKernelGGL(siddon_out_from_record_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, st, aux + (packed ? 4 * R : 0), img, R, out);
+                       dim3(kBlock), 0, st, aux + (packed ? 4 * R : 0), packed ? 0 : 1, img, R, out);
     return finish("ddrr_siddon_forward_bricks");
 }
 

@@ -4,6 +4,7 @@
 #include "siddon_core.h"
 #include "raygen_core.h"
 #include "record_pack.h"
+#include "record_layout.h"
 
 using namespace ddrr;
 using namespace ddrr_rt;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(kBlock) void raygen_fwd_kernel(
 constexpr int kPoseRaysPerBlock = 4096;
 
 __global__ __launch_bounds__(kBlock) void siddon_bwd_pose_kernel(
-    const float *__restrict__ aux, int planar, const float *__restrict__ grad_out,
+    const float *__restrict__ aux, int layout, const float *__restrict__ grad_out,
     const float *__restrict__ source_v, const float *__restrict__ target_v,
     const float *__restrict__ img, const float *__restrict__ Mw, const float *__restrict__ Ainv,
     const float *__restrict__ P, int B, int N, float eps, int with_img_path,
@@ -60,18 +61,15 @@ __global__ __launch_bounds__(kBlock) void siddon_bwd_pose_kernel(
     for (int n = blockIdx.x * kPoseRaysPerBlock + threadIdx.x; n < n_end; n += kBlock) {
         const long r = (long)b * N + n;
         float rec[SIDDON_AUX];
-        if (planar) {
-            float I, S0x, S0z, S1x, S1z;
-            if (planar == DDRR_AUX_PACKED) {
-                const long long *X = reinterpret_cast<const long long *>(aux);
-                const float q = aux[6 * R], qa = q / aux[5 * R + r];
-                record_unpack(X[r], q, qa, S0x, S1x);
-                record_unpack(X[R + r], q, qa, S0z, S1z);
-                I = aux[4 * R + r];
-            } else {
-                I = aux[r], S0x = aux[R + r], S0z = aux[2 * R + r];
-                S1x = aux[3 * R + r], S1z = aux[4 * R + r];
-            }
+        if (layout == DDRR_AUX_BLOCKED) {
+            rec_blocked_load(aux, r, rec);
+        } else if (layout == DDRR_AUX_PACKED) {
+            float S0x, S0z, S1x, S1z;
+            const long long *X = reinterpret_cast<const long long *>(aux);
+            const float q = aux[6 * R], qa = q / aux[5 * R + r];
+            record_unpack(X[r], q, qa, S0x, S1x);
+            record_unpack(X[R + r], q, qa, S0z, S1z);
+            const float I = aux[4 * R + r];
             rec[0] = I, rec[1] = S0x, rec[2] = -(S0x + S0z), rec[3] = S0z;
             rec[4] = S1x, rec[5] = I - (S1x + S1z), rec[6] = S1z, rec[7] = 0.f;
         } else {
@@ -250,7 +248,7 @@ int ddrr_siddon_backward_pose(const float *aux, int aux_layout, const float *gra
                               float eps, int with_img_path, float *gMw, void *stream) {
     if (!aux || !grad_out || !source_v || !target_v || !img || !Mw || !Ainv || !P || !gMw)
         return fail(-1, "null pointer");
-    if (aux_layout != DDRR_AUX_INTERLEAVED && aux_layout != DDRR_AUX_PLANAR &&
+    if (aux_layout != DDRR_AUX_INTERLEAVED && aux_layout != DDRR_AUX_BLOCKED &&
         aux_layout != DDRR_AUX_PACKED)
         return fail(-1, "bad aux_layout");
     if (B < 0 || N < 0) return fail(-1, "negative batch or ray count");

@@ -5,6 +5,7 @@
 #include "runtime.h"
 #include "siddon_core.h"
 #include "record_pack.h"
+#include "record_layout.h"
 #include "segments_core.h"
 
 using namespace ddrr;
@@ -53,7 +54,7 @@ template <int REDUCE>
 __global__ __launch_bounds__(kBlock) void siddon_bwd_rays_kernel(
     const float *__restrict__ aux, const float *__restrict__ grad_out,
     const float *__restrict__ source, int src_n, const float *__restrict__ target,
-    const float *__restrict__ img, long R, int N, float eps, int planar,
+    const float *__restrict__ img, long R, int N, float eps, int layout,
     float *__restrict__ g_source, float *__restrict__ g_target, float *__restrict__ g_img) {
     const long r = (long)blockIdx.x * kBlock + threadIdx.x;
     if (r >= R) return;
@@ -63,21 +64,18 @@ __global__ __launch_bounds__(kBlock) void siddon_bwd_rays_kernel(
     const float *tp = target + r * 3;
     const float s[3] = {sp[0], sp[1], sp[2]}, t[3] = {tp[0], tp[1], tp[2]};
     float rec[SIDDON_AUX];
-    if (planar) {
-        // record of the brick kernel: planes I, S0x, S0z, S1x, S1z of R floats each (or their
-        // packed fixed-point form, record_pack.h); the y components follow from
-        // sum_a S0_a = 0, sum_a S1_a = I
-        float I, S0x, S0z, S1x, S1z;
-        if (planar == DDRR_AUX_PACKED) {
-            const long long *X = reinterpret_cast<const long long *>(aux);
-            const float q = aux[6 * R], qa = q / aux[5 * R + r];
-            record_unpack(X[r], q, qa, S0x, S1x);
-            record_unpack(X[R + r], q, qa, S0z, S1z);
-            I = aux[4 * R + r];
-        } else {
-            I = aux[r], S0x = aux[R + r], S0z = aux[2 * R + r];
-            S1x = aux[3 * R + r], S1z = aux[4 * R + r];
-        }
+    if (layout == DDRR_AUX_BLOCKED) {
+        // float record of the brick kernel (record_layout.h): I, S0x, S0z, S1x, S1z; the y
+        // components follow from sum_a S0_a = 0, sum_a S1_a = I
+        rec_blocked_load(aux, r, rec);
+    } else if (layout == DDRR_AUX_PACKED) {
+        // its packed fixed-point form (record_pack.h): planes of R elements
+        float S0x, S0z, S1x, S1z;
+        const long long *X = reinterpret_cast<const long long *>(aux);
+        const float q = aux[6 * R], qa = q / aux[5 * R + r];
+        record_unpack(X[r], q, qa, S0x, S1x);
+        record_unpack(X[R + r], q, qa, S0z, S1z);
+        const float I = aux[4 * R + r];
         rec[0] = I;
         rec[1] = S0x;
         rec[2] = -(S0x + S0z);
@@ -305,11 +303,11 @@ int ddrr_siddon_backward_rays(const float *aux, int aux_layout, const float *gra
                               float *g_source, float *g_target, float *g_img, void *stream) {
     if (!aux || !grad_out || !source || !target) return fail(-1, "null pointer");
     if (src_n != 1 && src_n != N) return fail(-1, "src_n must be 1 or N");
-    if (aux_layout != DDRR_AUX_INTERLEAVED && aux_layout != DDRR_AUX_PLANAR &&
+    if (aux_layout != DDRR_AUX_INTERLEAVED && aux_layout != DDRR_AUX_BLOCKED &&
         aux_layout != DDRR_AUX_PACKED)
         return fail(-1, "bad aux_layout");
     if (aux_layout != DDRR_AUX_INTERLEAVED && reduce_mode != DDRR_REDUCE_SUM)
-        return fail(-1, "the planar record exists for reduce sum only");
+        return fail(-1, "the brick kernel's records exist for reduce sum only");
     const long R = (long)B * N;
     if (R == 0) return 0;
     const dim3 grid((unsigned)((R + kBlock - 1) / kBlock)), block(kBlock);

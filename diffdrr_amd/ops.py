@@ -162,14 +162,30 @@ def volume_absmax(volume) -> float:
     return value
 
 
+def record_blocks(B, N) -> int:
+    """16-ray blocks of the brick kernel's float backward record (csrc/record_layout.h)."""
+    return -(-(B * N) // _lib.REC_BLOCK_RAYS)
+
+
 def _aux_layout(aux, B, N):
     if aux.shape == (B, N, SIDDON_AUX):
         return _lib.AUX_INTERLEAVED
-    if aux.shape == (_lib.BRICK_AUX_PLANES, B, N):
-        return _lib.AUX_PLANAR
+    if aux.shape == (record_blocks(B, N), _lib.REC_BLOCK_FLOATS):
+        return _lib.AUX_BLOCKED
     if aux.shape == (_lib.PACKED_AUX_PLANES, B, N):
         return _lib.AUX_PACKED
-    raise ValueError(f"aux has shape {tuple(aux.shape)}: neither (B,N,8), (5,B,N) nor (7,B,N)")
+    raise ValueError(f"aux has shape {tuple(aux.shape)}: neither (B,N,8), the blocked record "
+                     f"(ceil(B N / 16), 80) nor the packed one (7,B,N)")
+
+
+def record_planes(aux, B, N):
+    """The blocked float record of :func:`siddon_forward_bricks` as (5, B, N) planes
+    I, S0x, S0z, S1x, S1z (a copy; for inspection and tests)."""
+    R = B * N
+    blk = aux.reshape(-1, 5, 16)  # lines: [g0 p0|p1] [g0 p2|p3] [g1 p0|p1] [g1 p2|p3] [p4 x16]
+    pairs = blk[:, :4].reshape(-1, 2, 2, 2, 8)        # block, group, line of group, plane in line, ray
+    p03 = pairs.permute(2, 3, 0, 1, 4).reshape(4, -1)  # plane = 2 * line + plane-in-line
+    return torch.cat([p03, blk[:, 4].reshape(1, -1)])[:, :R].reshape(5, B, N)
 
 
 def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, eps=1e-8,
@@ -177,9 +193,10 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
     """Detector-grid Siddon (sum) through the volume-stationary brick kernel: every 32^3
     brick is staged in LDS once and all rays of all poses are traced through it.
     Requires the targets to be the affine detector grid DRR builds.
-    -> (out (B,N), aux | None); aux is the (5,B,N) planar float record, or with
-    ``record_vmax`` = max |volume| > 0 the (7,B,N) packed fixed-point record (3 atomics per
-    ray and brick instead of 5, bit-reproducible; csrc/record_pack.h)."""
+    -> (out (B,N), aux | None); aux is the blocked float record (ceil(B N / 16), 80)
+    (csrc/record_layout.h; :func:`record_planes` unpacks it), or with ``record_vmax`` =
+    max |volume| > 0 the (7,B,N) packed fixed-point record (3 atomics per ray and brick
+    instead of 5, bit-reproducible; csrc/record_pack.h)."""
     B, N = _check_rays(volume, source, target, img)
     H, W = int(det[0]), int(det[1])
     if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
@@ -188,9 +205,11 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
     img = None if img is None else img.contiguous()
     out = torch.empty(B, N, dtype=torch.float32, device=volume.device)
     packed = bool(want_aux and record_vmax and record_vmax > 0.0)
-    planes = _lib.PACKED_AUX_PLANES if packed else _lib.BRICK_AUX_PLANES
-    aux = torch.empty(planes, B, N, dtype=torch.float32, device=volume.device) \
-        if want_aux else None
+    aux = None
+    if want_aux:
+        shape = (_lib.PACKED_AUX_PLANES, B, N) if packed else \
+            (record_blocks(B, N), _lib.REC_BLOCK_FLOATS)
+        aux = torch.empty(*shape, dtype=torch.float32, device=volume.device)
     if _empty(B, N):
         return out, aux
     _launch(
@@ -202,8 +221,8 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
 
 def siddon_backward_rays(aux, grad_out, source, target, img, *, eps=1e-8, reducefn="sum",
                          want_img_grad=True):
-    """aux: (B,N,8) interleaved record (generic forward) or (5,B,N) planar record
-    (brick forward).  -> (g_source (B,N,3) per ray, g_target (B,N,3), g_img (B,N) | None)"""
+    """aux: (B,N,8) interleaved record (generic forward) or the blocked / packed record of
+    the brick forward.  -> (g_source (B,N,3) per ray, g_target (B,N,3), g_img (B,N) | None)"""
     B, N, _ = target.shape
     layout = _aux_layout(aux, B, N)
     grad_out = grad_out.contiguous()

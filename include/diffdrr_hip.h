@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 19
+#define DDRR_ABI_VERSION 20
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -57,8 +57,11 @@ extern "C" {
 
 /* layouts of the forward record handed to ddrr_siddon_backward_rays */
 #define DDRR_AUX_INTERLEAVED 0 /* (B, N, 8): ddrr_siddon_forward */
-#define DDRR_AUX_PLANAR 1      /* (5, B, N) planes I, S0x, S0z, S1x, S1z: ddrr_siddon_forward_bricks */
-#define DDRR_BRICK_AUX_PLANES 5
+#define DDRR_AUX_BLOCKED 1     /* (ceil(B N / 16), 80): I, S0x, S0z, S1x, S1z of 16 consecutive rays per
+                                * block, one or two planes of 8 / 16 rays per 64-byte line
+                                * (csrc/record_layout.h): ddrr_siddon_forward_bricks */
+#define DDRR_REC_BLOCK_RAYS 16
+#define DDRR_REC_BLOCK_FLOATS 80
 #define DDRR_AUX_PACKED 2      /* (7, B, N): fixed-point record, csrc/record_pack.h: ddrr_siddon_forward_bricks(record_vmax > 0) */
 #define DDRR_PACKED_AUX_PLANES 7
 #define DDRR_TRI_AUX_PLANES 7   /* sum T, sum dT_xyz, sum alpha dT_xyz: ddrr_trilinear_forward_bricks */
@@ -83,8 +86,10 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
  * adds the partial integrals to `out` (zero-filled by the call) with fp32 atomics.  The
  * volume is read from HBM once per call, whatever B.  The image equals
  * ddrr_siddon_forward's up to fp32 summation order (which is not deterministic here).
- * aux: NULL, or a (DDRR_BRICK_AUX_PLANES, B, N) planar backward record (zero-filled and
- * accumulated by the call) for ddrr_siddon_backward_rays(aux_layout = DDRR_AUX_PLANAR).
+ * aux: NULL, or the blocked backward record, DDRR_REC_BLOCK_FLOATS * ceil(B N / DDRR_REC_BLOCK_RAYS)
+ * floats (zero-filled and accumulated by the call) for ddrr_siddon_backward_rays /
+ * ddrr_siddon_backward_pose (aux_layout = DDRR_AUX_BLOCKED): a run of 8 adjacent pixels adds whole
+ * 64-byte lines to it (the record's atomics are executed at the memory side, per line).
  * record_vmax: 0, or max |volume| (> 0): aux is then (DDRR_PACKED_AUX_PLANES, B, N) and receives
  * the record in 32-bit fixed point, two fields per 64-bit integer atomic (3 atomics per ray and
  * brick instead of 5; exact, order-independent sums; resolution 2 vmax (dx+dy+dz+3) / 2^30 per

@@ -21,6 +21,7 @@
 #include "../../diffdrr_amd/csrc/brick_step.h"
 #include "../../diffdrr_amd/csrc/raygen_core.h"
 #include "../../diffdrr_amd/csrc/record_pack.h"
+#include "../../diffdrr_amd/csrc/record_layout.h"
 #include "../../diffdrr_amd/csrc/segments_core.h"
 #include "../../diffdrr_amd/csrc/tri_brick.h"
 #include "../../diffdrr_amd/csrc/trilinear_core.h"
@@ -234,20 +235,19 @@ int tri_owner_host(int dx, int dy, int dz, const float *source, const float *tar
 }
 }  // namespace
 
-// The brick kernel's record of ray r as the interleaved 8 floats (planar float planes, or the
-// packed fixed-point form of record_pack.h).
+// The brick kernel's record of ray r as the interleaved 8 floats (the blocked float record of
+// record_layout.h, or the packed fixed-point form of record_pack.h).
 static void planar_record(const float *aux, int aux_layout, long R, long r, float rec[SIDDON_AUX]) {
-    float I, S0x, S0z, S1x, S1z;
-    if (aux_layout == DDRR_AUX_PACKED) {
-        const long long *X = reinterpret_cast<const long long *>(aux);
-        const float q = aux[6 * R], qa = q / aux[5 * R + r];
-        record_unpack(X[r], q, qa, S0x, S1x);
-        record_unpack(X[R + r], q, qa, S0z, S1z);
-        I = aux[4 * R + r];
-    } else {
-        I = aux[r], S0x = aux[R + r], S0z = aux[2 * R + r];
-        S1x = aux[3 * R + r], S1z = aux[4 * R + r];
+    if (aux_layout == DDRR_AUX_BLOCKED) {
+        rec_blocked_load(aux, r, rec);
+        return;
     }
+    float I, S0x, S0z, S1x, S1z;
+    const long long *X = reinterpret_cast<const long long *>(aux);
+    const float q = aux[6 * R], qa = q / aux[5 * R + r];
+    record_unpack(X[r], q, qa, S0x, S1x);
+    record_unpack(X[R + r], q, qa, S0z, S1z);
+    I = aux[4 * R + r];
     const float v[SIDDON_AUX] = {I, S0x, -(S0x + S0z), S0z, S1x, I - (S1x + S1z), S1z, 0.f};
     memcpy(rec, v, sizeof(v));
 }
@@ -316,9 +316,10 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     const int N = det_h * det_w;
     const long plane = (long)B * N;
     memset(out, 0, sizeof(float) * (size_t)B * N);
-    if (aux) memset(aux, 0, sizeof(float) * (size_t)DDRR_BRICK_AUX_PLANES * B * N);
     // packed fixed-point record (record_pack.h): planes 5 (A per ray) and 6 (q) first
     const bool packed = aux && record_vmax > 0.f;
+    if (aux)
+        memset(aux, 0, sizeof(float) * (packed ? (size_t)5 * B * N : (size_t)rec_blocked_floats(plane)));
     const float rec_q = packed ? record_scale(record_vmax, D) : 0.f;
     long long *packedX = reinterpret_cast<long long *>(aux);
     if (packed) {
@@ -360,8 +361,8 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                 packedX[plane + r] += record_pack(rec[1], rec[3], rec_q, qa);
                 aux[4 * plane + r] += I;
             } else if (aux) {
-                aux[r] += I;
-                for (int k = 0; k < 4; ++k) aux[(k + 1) * plane + r] += rec[k];
+                aux[rec_index(r, 0)] += I;
+                for (int k = 0; k < 4; ++k) aux[rec_index(r, k + 1)] += rec[k];
             }
         };
         for (auto &qk : queues) qk.clear();

@@ -292,7 +292,8 @@ def test_generic_and_brick_walks_vs_oracle(emulated_ops, D, H, W, delx):
         # (the brick walk via the first plane ahead of each brick entry); the sums are grouped
         # differently (per brick), which is what is left of the difference
         assert rel_err(outb[b].numpy(), gen[b].numpy()) < 2e-5, name
-        assert rel_err(auxb[0, b].numpy(), aux_gen[b, :, 0].numpy()) < 2e-5, name
+        planes = ops.record_planes(auxb, *gen.shape)  # blocked record -> (5, B, N)
+        assert rel_err(planes[0, b].numpy(), aux_gen[b, :, 0].numpy()) < 2e-5, name
     # the planar record gives the same ray gradients as the generic walk's record
     go = torch.rand(gen.shape, generator=torch.Generator().manual_seed(3))
     gsb, gtb, gib = ops.siddon_backward_rays(auxb, go, s, t, L)
