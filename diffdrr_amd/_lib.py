@@ -22,6 +22,7 @@ LOOKUP_STEP, LOOKUP_MID_NEAREST, LOOKUP_MID_TRILINEAR = 0, 1, 2
 SIDDON_AUX = 8
 AUX_INTERLEAVED, AUX_BLOCKED, AUX_PACKED = 0, 1, 2
 REC_BLOCK_RAYS, REC_BLOCK_FLOATS = 16, 80  # blocked float record (csrc/record_layout.h)
+BRICKS_F32, BRICKS_Q16 = 0, 1  # how a brick is held in LDS (ddrr_siddon_forward_bricks)
 PACKED_AUX_PLANES = 7  # fixed-point record (csrc/record_pack.h)
 
 _P, _I, _F, _L, _D = c_void_p, c_int, c_float, c_long, c_double
@@ -30,7 +31,8 @@ _P, _I, _F, _L, _D = c_void_p, c_int, c_float, c_long, c_double
 _SIGNATURES = {
     "ddrr_siddon_forward": [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _F, _F, _I, _I, _I, _I, _I,
                             _I, _I, _P, _P, _P, _P],
-    "ddrr_siddon_forward_bricks": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _F, _P],
+    "ddrr_siddon_forward_bricks": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _F, _I,
+                                   _P, _I, _P],
     "ddrr_siddon_backward_rays": [_P, _I, _P, _P, _I, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P],
     "ddrr_siddon_backward_volume": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _I, _I,
                                     _I, _I, _I, _P, _P],

@@ -1,0 +1,185 @@
+// brick_shared.h -- what the translation units of the volume-stationary kernels share
+// (bricks.hip: every mode on 32^3 fp32 bricks; bricks_fwd.hip: the configurable Siddon forward /
+// forward + record kernel): launch arguments, the per-phase profile of tools builds, wave
+// helpers, and the delivery of the float backward record.
+#pragma once
+
+#include "runtime.h"
+#include "brick_core.h"
+#include "brick_walk.h"
+#include "record_layout.h"
+
+namespace ddrr_brick {
+
+using namespace ddrr;
+
+constexpr int kQueueCap = 128;  // entries per wave and length class (63 waiting + 64 arriving)
+constexpr int kBuckets = 3;     // length classes
+
+struct BrickArgs {
+    const float *vol;
+    Dims D;
+    const float *source;  // (B, 1, 3)
+    const float *target;  // (B, N, 3), row-major det_h x det_w grid
+    const float *img;
+    int B, det_h, det_w;
+    float shift, eps;
+    BrickLayout lay;
+    unsigned aux_plane;  // elements per plane of the planar backward record (B * N)
+    float rec_q;         // > 0: the record is the packed fixed-point form (record_pack.h), scale q
+    int pix_bits;        // queue entry = (pose << pix_bits) | pixel
+    float t1, t2;        // length-class thresholds on the estimated crossing count
+    int dbg;             // experiment switches (tools builds with -DDDRR_EXPERIMENTS; else 0)
+    int *work;           // global brick counter of this launch (zero at launch)
+    const float *grad_out;  // *_VOLGRAD: dLoss/dout (B, N)
+    float *g_volume;        // *_VOLGRAD: dLoss/dvolume
+    int n_points;           // BRICK_TRI_*: samples per ray
+    const float *amin, *amax;  // BRICK_TRI_*: device scalars (renderers.py:220-223)
+    unsigned long long *prof;  // DDRR_BRICK_PROFILE builds: per-phase wave-cycle totals
+    const unsigned char *labels;  // BRICK_CHANNELS: label of every voxel
+    int n_channels;               // BRICK_CHANNELS: out is (B, n_channels, N)
+    const float *ranges;          // 16-bit bricks: (vmin, vmax) per brick (bricks_fwd.hip)
+    int ranges_valid;             // ... already computed for this volume
+};
+
+// Phase timing of the brick kernel (tools/ builds with -DDDRR_BRICK_PROFILE only): s_memtime
+// deltas per wave, added up per phase.  Compiled out of the product library.
+#if defined(DDRR_BRICK_PROFILE)
+struct BrickProf {
+    unsigned long long t[16];
+    unsigned long long last;
+    __device__ __forceinline__ void start() {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = 0;
+        last = __builtin_amdgcn_s_memtime();
+    }
+    __device__ __forceinline__ void mark(int i) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        t[i] += now - last;
+        last = now;
+    }
+    __device__ __forceinline__ void count(int i, unsigned long long n) { t[i] += n; }
+};
+#define DDRR_PROF(i) prof.mark(i)
+#define DDRR_PROF_COUNT(i, n) prof.count(i, n)
+#define DDRR_PROF_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+struct BrickProf {};
+#define DDRR_PROF(i)
+#define DDRR_PROF_COUNT(i, n)
+#define DDRR_PROF_WAIT_VMEM()
+#endif
+enum {
+    PROF_STAGE = 0,   // brick id, row table, staging, barrier after it
+    PROF_PULL = 1,    // unit counter, cursor, row read
+    PROF_PHASE_A = 2, // candidate test, classes, queue push
+    PROF_POP = 3,     // batch selection, queue read
+    PROF_LOADS = 4,   // ray loads (issue + wait)
+    PROF_SETUP = 5,   // exact clip, entry cell
+    PROF_WALK = 6,
+    PROF_DELIVER = 7, // atomics
+    PROF_BARRIER = 8, // waiting for the other waves at the end of a brick
+    PROF_N_BATCH = 9, PROF_N_STEPS = 10, PROF_N_UNITS = 11, PROF_N_HITS = 12,
+    PROF_CLAIM = 13,   // (part of staging) brick id known
+    PROF_ROWS = 14,    // (part of staging) row table written
+    PROF_STORE = 15,   // (part of staging) brick stored to LDS; PROF_STAGE then is the barrier + prefix
+};
+
+// what a brick launch computes
+constexpr int BRICK_FWD = 0;      // out
+constexpr int BRICK_FWD_AUX = 1;  // out + planar backward record
+constexpr int BRICK_VOLGRAD = 2;  // g_volume (the brick in LDS is the accumulator)
+constexpr int BRICK_TRI_FWD = 3;      // trilinear marcher: out
+constexpr int BRICK_TRI_VOLGRAD = 4;  // trilinear marcher: g_volume
+constexpr int BRICK_TRI_FWD_AUX = 5;  // trilinear marcher: planar backward record (out follows from it)
+constexpr int BRICK_CHANNELS = 6;     // out (B, C, N): one line integral per label (mask_to_channels)
+
+
+#if defined(__HIPCC__)
+constexpr int kRor8 = 0x128;  // DPP row_ror:8: lane ^ 8 within each row of 16
+
+// The float backward record of one batch of hits, delivered to the blocked layout of
+// record_layout.h.  Called by ALL lanes of the wave (ok: the lane holds a hit): lane l swaps
+// plane 1 (3) of its hit against plane 0 (2) of lane l ^ 8's, so that the lower half of a
+// 16-lane row carries planes 0 | 1 of its eight hits and the upper half those of its own eight --
+// when the eight are one run of adjacent pixels (they are: length classes are formed per run of 8)
+// each half row is one contiguous 64-byte line: 2 + 2 + 1 atomic instructions as before, but
+// whole lines instead of half lines.  v = {I, S0x, S0z, S1x, S1z}.
+__device__ __forceinline__ void deliver_record_blocked(float *__restrict__ aux, bool ok,
+                                                       unsigned r, const float v[5]) {
+    const unsigned lo = rec_off01(r) | (ok ? 0u : 0x80000000u);  // (sign bit: nothing to add)
+    const int o0 = (int)lo, o1 = (int)(lo + 8u);
+    // X: lanes 0-7 of a row own plane 0 | lanes 8-15 their partner's plane 1
+    // Y: lanes 0-7 their partner's plane 0 | lanes 8-15 own plane 1
+    const int xo = __builtin_amdgcn_update_dpp(o0, o1, kRor8, 0xf, 0xC, false);
+    const int yo = __builtin_amdgcn_update_dpp(o1, o0, kRor8, 0xf, 0x3, false);
+    auto swap_hi = [](float own, float other) {  // lanes 8-15 <- partner's `other`
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+            __builtin_bit_cast(int, own), __builtin_bit_cast(int, other), kRor8, 0xf, 0xC, false));
+    };
+    auto swap_lo = [](float own, float other) {  // lanes 0-7 <- partner's `other`
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+            __builtin_bit_cast(int, own), __builtin_bit_cast(int, other), kRor8, 0xf, 0x3, false));
+    };
+    const float x01 = swap_hi(v[0], v[1]), y01 = swap_lo(v[1], v[0]);
+    const float x23 = swap_hi(v[2], v[3]), y23 = swap_lo(v[3], v[2]);
+    if (xo >= 0) {
+        unsafeAtomicAdd(aux + xo, x01);
+        unsafeAtomicAdd(aux + xo + 16, x23);
+    }
+    if (yo >= 0) {
+        unsafeAtomicAdd(aux + yo, y01);
+        unsafeAtomicAdd(aux + yo + 16, y23);
+    }
+    if (ok) unsafeAtomicAdd(aux + rec_off4(r), v[4]);
+}
+
+__device__ __forceinline__ int lane_rank(unsigned long long mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+#endif  // __HIPCC__
+
+// Per-device launch resources of the brick kernels (bricks.hip): the CU count and this launch's
+// brick counter {brick id, wmax bits, n_sum, -}, zeroed on `st`.  Returns 0 or an error code.
+int brick_launch_resources(hipStream_t st, int &n_cu, int *&work);
+
+// The 32^3 fp32 launch path of bricks.hip (every mode); bricks_fwd.hip falls back to it.
+int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const float *source,
+                  const float *target, const float *img, const float *grad_out, int B, int det_h,
+                  int det_w, float voxel_shift, float eps, float *out, float *aux,
+                  float *g_volume, hipStream_t st, const char *who, int n_points = 0,
+                  const float *amin = nullptr, const float *amax = nullptr, float rec_q = 0.f,
+                  const unsigned char *labels = nullptr, int n_channels = 0);
+
+// The configurable Siddon forward / forward + record kernel (bricks_fwd.hip).  variant:
+// DDRR_BRICKS_F32 / DDRR_BRICKS_Q16; volumes it cannot stage with 16-byte loads take launch_bricks.
+// brick_ranges: DDRR_BRICKS_Q16 workspace (2 floats per 32^3 brick), ranges_valid: it already
+// holds this volume's ranges.
+int launch_fwd_bricks(int variant, float *brick_ranges, int ranges_valid, const float *volume,
+                      int dx, int dy, int dz, const float *source, const float *target,
+                      const float *img, int B, int det_h, int det_w, float voxel_shift, float eps,
+                      float *out, float *aux, float rec_q, hipStream_t st, const char *who);
+
+// experiment switches (tools builds: mutable; product: constants)
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+extern float g_brick_t1, g_brick_t2;
+extern int g_brick_dbg;
+extern int g_brick_variant;
+#else
+constexpr float g_brick_t1 = 18.f, g_brick_t2 = 40.f;
+constexpr int g_brick_dbg = 0;
+#endif
+#if defined(DDRR_BRICK_PROFILE)
+extern unsigned long long *g_brick_prof;  // 16 device counters, see BrickProf
+#endif
+
+}  // namespace ddrr_brick

@@ -175,9 +175,11 @@ DDRR_HD StepEntry step_enter(const StepGeom &G, const float s[3], const float t[
 // rec = {S0x, S0z, S1x, S1z} of the brick-local backward record (voxels outside the brick
 // count as 0 on both sides of a face, so the records of the bricks along a ray add up to the
 // ray's; y follows from sum_a S0_a = 0, sum_a S1_a = I).
-template <bool AUX, class Fetch>
+// MAXSTEPS: a bound on the crossings inside the brick (+ slack); exit_axis: NULL, or with AUX
+// two floats receiving the one-hot (x, y; z implied) axis of the exit crossing.
+template <bool AUX, int MAXSTEPS = 3 * BRICK + 4, class Fetch>
 DDRR_HD int step_walk(const Fetch &fetch, const StepGeom &G, const StepEntry &E, float &I,
-                      float rec[4]) {
+                      float rec[4], float *exit_axis = nullptr) {
     float kr0 = 0.f, kr1 = 0.f, kr2 = 0.f;  // k - k0 per axis
     float an0 = E.an[0], an1 = E.an[1], an2 = E.an[2];
     const float inv0 = E.inv[0], inv1 = E.inv[1], inv2 = E.inv[2];
@@ -242,7 +244,7 @@ DDRR_HD int step_walk(const Fetch &fetch, const StepGeom &G, const StepEntry &E,
     // the packed forms cost register shuffles on top.  Together 1.39 -> 1.30 ms forward.)
     int it = 0;
 #pragma unroll 2
-    for (; it < 3 * BRICK + 4; it += 2) {
+    for (; it < MAXSTEPS; it += 2) {
         DDRR_STEP()
         DDRR_STEP()
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -269,8 +271,101 @@ DDRR_HD int step_walk(const Fetch &fetch, const StepGeom &G, const StepEntry &E,
         rec[1] = -(S0x + S0y);       // sum_a S0_a = 0
         rec[2] = S1x;
         rec[3] = acc - (S1x + S1y);  // sum_a S1_a = I
+        if (exit_axis) {
+            // (for the quantised bricks: they finish the record themselves, q16_finish)
+            rec[1] = S0y;
+            rec[3] = S1y;
+            exit_axis[0] = ex;
+            exit_axis[1] = ey;
+        }
     }
     return it + 2;  // steps the wave took (profiling builds)
+}
+
+// ---------------------------------------------------------------- 16-bit quantised bricks
+// A brick staged as 16-bit block-quantised voxels (one (vmin, step) pair per brick,
+// V ~ vmin + q step, q = 0 .. 65535) takes half the LDS of the fp32 brick, so two workgroups
+// fit a CU and one's staging and end-of-brick barrier overlap the other's walk.  The walk is
+// step_walk itself, unchanged and at no extra instruction: `ds_read_u16` leaves q in the low
+// half of the register, which read as a float is the DENORMAL q 2^-149 -- gfx950 multiplies
+// denormals at full rate -- and every alpha of the entry state is pre-scaled by 2^64
+// (q16_scale_entry), so that the products q 2^-149 * len 2^64 = q len 2^-85 are normal numbers
+// accumulated without loss.  q16_finish turns the sums over q back into sums over V.
+constexpr float kQ16AlphaScale = 0x1p64f;  // K
+constexpr float kQ16Unscale = 0x1p85f;     // 2^149 / K
+
+struct Q16Range {
+    float vmin, step;      // V ~ vmin + q * step
+    float inv_step;        // 65535 / (vmax - vmin), 0 for a constant brick
+};
+
+DDRR_HD Q16Range q16_range(float vmin, float vmax) {
+    Q16Range r;
+    const float range = vmax - vmin;
+    r.vmin = vmin;
+    // a brick holding inf / nan poisons the rays through it (as the values themselves would)
+    r.step = range * (1.0f / 65535.0f);
+    r.inv_step = range > 0.f ? 65535.0f / range : 0.f;
+    if (!(range >= 0.f) || !(range < INFINITY)) {
+        r.vmin = NAN;
+        r.step = NAN;
+        r.inv_step = 0.f;
+    }
+    return r;
+}
+
+// q of a voxel: round to nearest by adding 2^23 (the sum's low 16 bits are the integer)
+DDRR_HD unsigned q16_encode(float v, const Q16Range &r) {
+    const float f = fmaf(v - r.vmin, r.inv_step, 8388608.0f);
+    return float_bits(f) & 0xffffu;  // (nan -> some value: the range already poisons the brick)
+}
+
+// Scale every alpha of an entry state by K = 2^64 (exact: powers of two, no alpha of a ray
+// that meets the volume is within 2^63 of the fp32 range).
+DDRR_HD void q16_scale_entry(StepEntry &E) {
+    const float K = kQ16AlphaScale;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        E.inv[a] *= K;
+        E.a0[a] *= K;
+        E.an[a] *= K;
+    }
+    E.entry *= K;
+    E.exit *= K;
+    const float m = fmaxf(fabsf(E.entry), fabsf(E.exit));
+    const unsigned field = 379u - ((float_bits(m) >> 23) & 0xffu);
+    E.lbig = bits_as_float((field < 254u ? field : 254u) << 23);
+}
+
+// Fetch of a 16-bit voxel relative to the brick (host emulation; the device fetches by absolute
+// LDS address, bricks_fwd.hip LdsAbsFetch16).
+struct LdsFetch16 {
+    const unsigned short *brick;
+    DDRR_HD float operator()(unsigned boff) const { return bits_as_float(brick[boff >> 1]); }
+};
+
+// From the walk over q (step_walk on a scaled entry state; rec = {S0x, S0y, S1x, S1y} of q,
+// exit_axis from the walk) to the brick-local integral and record of V = vmin + q step inside
+// the brick, 0 outside: interior crossings see differences (vmin cancels), the entry and exit
+// crossings see the values themselves.  rec <- {S0x, S0z, S1x, S1z}.
+template <bool AUX>
+DDRR_HD void q16_finish(const Q16Range &r, const StepEntry &E, const float exit_axis[2], float &I,
+                        float rec[4]) {
+    const float iK = 1.0f / kQ16AlphaScale;
+    const float cs = r.step * kQ16Unscale;             // sums of q 2^-149 alpha K -> V alpha
+    const float entry = E.entry * iK, exit = E.exit * iK;
+    I = fmaf(I, cs, r.vmin * (exit - entry));
+    if (AUX) {
+        const float K = kQ16AlphaScale;
+        const float s0x = fmaf(rec[0] * K, cs, r.vmin * (exit_axis[0] - E.ent[0]));
+        const float s0y = fmaf(rec[1] * K, cs, r.vmin * (exit_axis[1] - E.ent[1]));
+        const float s1x = fmaf(rec[2], cs, r.vmin * fmaf(exit, exit_axis[0], -entry * E.ent[0]));
+        const float s1y = fmaf(rec[3], cs, r.vmin * fmaf(exit, exit_axis[1], -entry * E.ent[1]));
+        rec[0] = s0x;
+        rec[1] = -(s0x + s0y);     // sum_a S0_a = 0
+        rec[2] = s1x;
+        rec[3] = I - (s1x + s1y);  // sum_a S1_a = I
+    }
 }
 
 // mask_to_channels on the bricks (reference renderers.py:77-89).  The staged word of a voxel
@@ -375,6 +470,22 @@ DDRR_HD bool step_scatter(const Add &add, unsigned base_bits, const StepGeom &G,
         an2 = fmaf(kr2, E.inv[2], E.a0[2]);
         a_cur = a_next;
     }
+    return true;
+}
+
+// Exact clip + walk of a 16-bit brick (G: its byte strides as bit-pattern floats).
+template <bool AUX, int MAXSTEPS, class Fetch>
+DDRR_HD bool step_trace_q16(const Fetch &fetch, unsigned base_bits, const StepGeom &G,
+                            const Q16Range &range, const float s[3], const float t[3], float shift,
+                            float eps, float &I, float rec[4]) {
+    StepEntry E = step_enter(G, s, t, shift, eps, base_bits);
+    I = 0.f;
+    if (AUX) rec[0] = rec[1] = rec[2] = rec[3] = 0.f;
+    if (!E.hit) return false;
+    q16_scale_entry(E);
+    float ex[2] = {0.f, 0.f};
+    step_walk<AUX, MAXSTEPS>(fetch, G, E, I, rec, ex);
+    q16_finish<AUX>(range, E, ex, I, rec);
     return true;
 }
 

@@ -12,10 +12,12 @@
 #include "record_pack.h"
 #include "record_layout.h"
 #include "tri_brick.h"
+#include "brick_shared.h"
 #include "trilinear_core.h"
 
 using namespace ddrr;
 using namespace ddrr_rt;
+using namespace ddrr_brick;
 
 namespace {
 
@@ -39,84 +41,6 @@ namespace {
 constexpr int kBrickThreads = 1024;
 constexpr int kBrickWaves = kBrickThreads / 64;
 constexpr int kPoseChunk = 32;
-constexpr int kQueueCap = 128;
-constexpr int kBuckets = 3;
-
-struct BrickArgs {
-    const float *vol;
-    Dims D;
-    const float *source;  // (B, 1, 3)
-    const float *target;  // (B, N, 3), row-major det_h x det_w grid
-    const float *img;
-    int B, det_h, det_w;
-    float shift, eps;
-    BrickLayout lay;
-    unsigned aux_plane;  // elements per plane of the planar backward record (B * N)
-    float rec_q;         // > 0: the record is the packed fixed-point form (record_pack.h), scale q
-    int pix_bits;        // queue entry = (pose << pix_bits) | pixel
-    float t1, t2;        // length-class thresholds on the estimated crossing count
-    int dbg;             // experiment switches (tools builds with -DDDRR_EXPERIMENTS; else 0)
-    int *work;           // global brick counter of this launch (zero at launch)
-    const float *grad_out;  // *_VOLGRAD: dLoss/dout (B, N)
-    float *g_volume;        // *_VOLGRAD: dLoss/dvolume
-    int n_points;           // BRICK_TRI_*: samples per ray
-    const float *amin, *amax;  // BRICK_TRI_*: device scalars (renderers.py:220-223)
-    unsigned long long *prof;  // DDRR_BRICK_PROFILE builds: per-phase wave-cycle totals
-    const unsigned char *labels;  // BRICK_CHANNELS: label of every voxel
-    int n_channels;               // BRICK_CHANNELS: out is (B, n_channels, N)
-};
-
-// Phase timing of the brick kernel (tools/ builds with -DDDRR_BRICK_PROFILE only): s_memtime
-// deltas per wave, added up per phase.  Compiled out of the product library.
-#if defined(DDRR_BRICK_PROFILE)
-struct BrickProf {
-    unsigned long long t[16];
-    unsigned long long last;
-    __device__ __forceinline__ void start() {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t[i] = 0;
-        last = __builtin_amdgcn_s_memtime();
-    }
-    __device__ __forceinline__ void mark(int i) {
-        const unsigned long long now = __builtin_amdgcn_s_memtime();
-        t[i] += now - last;
-        last = now;
-    }
-    __device__ __forceinline__ void count(int i, unsigned long long n) { t[i] += n; }
-};
-#define DDRR_PROF(i) prof.mark(i)
-#define DDRR_PROF_COUNT(i, n) prof.count(i, n)
-#define DDRR_PROF_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#else
-struct BrickProf {};
-#define DDRR_PROF(i)
-#define DDRR_PROF_COUNT(i, n)
-#define DDRR_PROF_WAIT_VMEM()
-#endif
-enum {
-    PROF_STAGE = 0,   // brick id, row table, staging, barrier after it
-    PROF_PULL = 1,    // unit counter, cursor, row read
-    PROF_PHASE_A = 2, // candidate test, classes, queue push
-    PROF_POP = 3,     // batch selection, queue read
-    PROF_LOADS = 4,   // ray loads (issue + wait)
-    PROF_SETUP = 5,   // exact clip, entry cell
-    PROF_WALK = 6,
-    PROF_DELIVER = 7, // atomics
-    PROF_BARRIER = 8, // waiting for the other waves at the end of a brick
-    PROF_N_BATCH = 9, PROF_N_STEPS = 10, PROF_N_UNITS = 11, PROF_N_HITS = 12,
-    PROF_CLAIM = 13,   // (part of staging) brick id known
-    PROF_ROWS = 14,    // (part of staging) row table written
-    PROF_STORE = 15,   // (part of staging) brick stored to LDS; PROF_STAGE then is the barrier + prefix
-};
-
-// what a brick launch computes
-constexpr int BRICK_FWD = 0;      // out
-constexpr int BRICK_FWD_AUX = 1;  // out + planar backward record
-constexpr int BRICK_VOLGRAD = 2;  // g_volume (the brick in LDS is the accumulator)
-constexpr int BRICK_TRI_FWD = 3;      // trilinear marcher: out
-constexpr int BRICK_TRI_VOLGRAD = 4;  // trilinear marcher: g_volume
-constexpr int BRICK_TRI_FWD_AUX = 5;  // trilinear marcher: planar backward record (out follows from it)
-constexpr int BRICK_CHANNELS = 6;     // out (B, C, N): one line integral per label (mask_to_channels)
 
 inline size_t brick_lds_bytes(const BrickLayout &lay) {
     return (size_t)brick_floats(lay) * 4 + (size_t)kBrickWaves * kBuckets * kQueueCap * 4 +
@@ -167,44 +91,6 @@ struct BrickColumnFlush {
     }
 };
 #endif
-
-constexpr int kRor8 = 0x128;  // DPP row_ror:8: lane ^ 8 within each row of 16
-
-// The float backward record of one batch of hits, delivered to the blocked layout of
-// record_layout.h.  Called by ALL lanes of the wave (ok: the lane holds a hit): lane l swaps
-// plane 1 (3) of its hit against plane 0 (2) of lane l ^ 8's, so that the lower half of a
-// 16-lane row carries planes 0 | 1 of its eight hits and the upper half those of its own eight --
-// when the eight are one run of adjacent pixels (they are: length classes are formed per run of 8)
-// each half row is one contiguous 64-byte line: 2 + 2 + 1 atomic instructions as before, but
-// whole lines instead of half lines.  v = {I, S0x, S0z, S1x, S1z}.
-__device__ __forceinline__ void deliver_record_blocked(float *__restrict__ aux, bool ok,
-                                                       unsigned r, const float v[5]) {
-    const unsigned lo = rec_off01(r) | (ok ? 0u : 0x80000000u);  // (sign bit: nothing to add)
-    const int o0 = (int)lo, o1 = (int)(lo + 8u);
-    // X: lanes 0-7 of a row own plane 0 | lanes 8-15 their partner's plane 1
-    // Y: lanes 0-7 their partner's plane 0 | lanes 8-15 own plane 1
-    const int xo = __builtin_amdgcn_update_dpp(o0, o1, kRor8, 0xf, 0xC, false);
-    const int yo = __builtin_amdgcn_update_dpp(o1, o0, kRor8, 0xf, 0x3, false);
-    auto swap_hi = [](float own, float other) {  // lanes 8-15 <- partner's `other`
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-            __builtin_bit_cast(int, own), __builtin_bit_cast(int, other), kRor8, 0xf, 0xC, false));
-    };
-    auto swap_lo = [](float own, float other) {  // lanes 0-7 <- partner's `other`
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-            __builtin_bit_cast(int, own), __builtin_bit_cast(int, other), kRor8, 0xf, 0x3, false));
-    };
-    const float x01 = swap_hi(v[0], v[1]), y01 = swap_lo(v[1], v[0]);
-    const float x23 = swap_hi(v[2], v[3]), y23 = swap_lo(v[3], v[2]);
-    if (xo >= 0) {
-        unsafeAtomicAdd(aux + xo, x01);
-        unsafeAtomicAdd(aux + xo + 16, x23);
-    }
-    if (yo >= 0) {
-        unsafeAtomicAdd(aux + yo, y01);
-        unsafeAtomicAdd(aux + yo + 16, y23);
-    }
-    if (ok) unsafeAtomicAdd(aux + rec_off4(r), v[4]);
-}
 
 // Phase B for one queue entry: load the real ray, clip, walk; add to the image (forward)
 // or scatter into the LDS accumulator (volume gradient).  Called by every lane of the wave;
@@ -330,18 +216,6 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
     if (!E.hit) return;  // phase A's margin let a non-crossing ray through
     unsafeAtomicAdd(out + r, L * I);
     DDRR_PROF(PROF_DELIVER);
-}
-
-__device__ __forceinline__ int lane_rank(unsigned long long mask) {
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-}
-
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-__device__ __forceinline__ void wave_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
 }
 
 template <int MODE>
@@ -830,26 +704,62 @@ __global__ __launch_bounds__(kBlock) void trilinear_bwd_record_kernel(
 // (estimated plane crossings inside the brick; for the marcher: samples per brick).
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
 BrickLayout g_brick_layout = {33, 32 * 33 + 1};
-float g_brick_t1 = 18.f, g_brick_t2 = 40.f;
 float g_tri_t1 = 10.f, g_tri_t2 = 22.f;
-int g_brick_dbg = 0;
 #else
 constexpr BrickLayout g_brick_layout = {33, 32 * 33 + 1};
-constexpr float g_brick_t1 = 18.f, g_brick_t2 = 40.f;
 constexpr float g_tri_t1 = 10.f, g_tri_t2 = 22.f;
-constexpr int g_brick_dbg = 0;
 #endif
 
+}  // namespace
+
+namespace ddrr_brick {
+
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+float g_brick_t1 = 18.f, g_brick_t2 = 40.f;
+int g_brick_dbg = 0;
+int g_brick_variant = -2;
+#endif
 #if defined(DDRR_BRICK_PROFILE)
 unsigned long long *g_brick_prof = nullptr;  // 16 device counters, see BrickProf
 #endif
 
+// Per-device state, created on first use under a lock (the entry points may be called from
+// several host threads): the CU count and a small ring of brick counters -- one per launch, so
+// that launches in flight on different streams never share one; zeroed on the launch's stream.
+int brick_launch_resources(hipStream_t st, int &n_cu_out, int *&work) {
+    constexpr int kRing = 64, kMaxDev = 64;
+    static std::mutex mu;
+    static int *ring[kMaxDev] = {nullptr};
+    static int n_cu[kMaxDev] = {0};
+    static unsigned slot[kMaxDev] = {0};
+    hipError_t e;
+    int dev = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return fail_hip(e, "hipGetDevice");
+    if (dev < 0 || dev >= kMaxDev) return fail(-1, "device index out of range");
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!ring[dev]) {
+            if ((e = hipMalloc(reinterpret_cast<void **>(&ring[dev]),
+                               kRing * 4 * sizeof(int))) != hipSuccess)
+                return fail_hip(e, "hipMalloc(brick counters)");
+            if ((e = hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount,
+                                           dev)) != hipSuccess)
+                return fail_hip(e, "hipDeviceGetAttribute");
+        }
+        work = ring[dev] + 4 * (slot[dev]++ % kRing);  // {brick counter, wmax bits, n_sum, -}
+        n_cu_out = n_cu[dev];
+    }
+    if ((e = hipMemsetAsync(work, 0, 4 * sizeof(int), st)) != hipSuccess)
+        return fail_hip(e, "hipMemsetAsync");
+    return 0;
+}
+
 int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const float *source,
                   const float *target, const float *img, const float *grad_out, int B, int det_h,
                   int det_w, float voxel_shift, float eps, float *out, float *aux,
-                  float *g_volume, hipStream_t st, const char *who, int n_points = 0,
-                  const float *amin = nullptr, const float *amax = nullptr, float rec_q = 0.f,
-                  const unsigned char *labels = nullptr, int n_channels = 0) {
+                  float *g_volume, hipStream_t st, const char *who, int n_points,
+                  const float *amin, const float *amax, float rec_q,
+                  const unsigned char *labels, int n_channels) {
     const int N = det_h * det_w;
     BrickArgs p;
     p.vol = volume;
@@ -883,6 +793,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     p.prof = nullptr;
     p.labels = labels;
     p.n_channels = n_channels;
+    p.ranges = nullptr;
+    p.ranges_valid = 0;
 #if defined(DDRR_BRICK_PROFILE)
     p.prof = g_brick_prof;
 #endif
@@ -892,16 +804,10 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     }
     const size_t lds = brick_lds_bytes(p.lay);
     hipError_t e;
-    // Per-device state, created on first use under a lock (the entry points may be called
-    // from several host threads): the raised dynamic-LDS limit of the brick kernels, the CU
-    // count, and a small ring of brick counters -- one per launch, so that launches in flight
-    // on different streams never share one; it is zeroed on the launch's stream.
-    constexpr int kRing = 64, kMaxDev = 64;
+    // the raised dynamic-LDS limit of the brick kernels, once per device
+    constexpr int kMaxDev = 64;
     static std::mutex mu;
     static bool attr_set[kMaxDev] = {false};
-    static int *ring[kMaxDev] = {nullptr};
-    static int n_cu[kMaxDev] = {0};
-    static unsigned slot[kMaxDev] = {0};
     int dev = 0;
     if ((e = hipGetDevice(&dev)) != hipSuccess) return fail_hip(e, "hipGetDevice");
     if (dev < 0 || dev >= kMaxDev) return fail(-1, "device index out of range");
@@ -922,18 +828,9 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
                     return fail_hip(e, "hipFuncSetAttribute");
             attr_set[dev] = true;
         }
-        if (!ring[dev]) {
-            if ((e = hipMalloc(reinterpret_cast<void **>(&ring[dev]),
-                               kRing * 4 * sizeof(int))) != hipSuccess)
-                return fail_hip(e, "hipMalloc(brick counters)");
-            if ((e = hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount,
-                                           dev)) != hipSuccess)
-                return fail_hip(e, "hipDeviceGetAttribute");
-        }
-        p.work = ring[dev] + 4 * (slot[dev]++ % kRing);  // {brick counter, wmax bits, n_sum, -}
     }
-    if ((e = hipMemsetAsync(p.work, 0, 4 * sizeof(int), st)) != hipSuccess)
-        return fail_hip(e, "hipMemsetAsync");
+    int n_cu_dev = 0;
+    if (int rc = brick_launch_resources(st, n_cu_dev, p.work)) return rc;
     if (mode == BRICK_VOLGRAD || mode == BRICK_TRI_VOLGRAD) {
         const int tri = mode == BRICK_TRI_VOLGRAD;
         int bx = (N + kBlock - 1) / kBlock;
@@ -945,7 +842,7 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     const BrickGrid bg = (mode == BRICK_TRI_FWD || mode == BRICK_TRI_FWD_AUX) ? tri_brick_grid(p.D)
                                                                               : brick_grid(p.D);
     const int n_bricks = bg.nx * bg.ny * bg.nz;
-    const dim3 grid(n_bricks < n_cu[dev] ? n_bricks : n_cu[dev]), block(kBrickThreads);
+    const dim3 grid(n_bricks < n_cu_dev ? n_bricks : n_cu_dev), block(kBrickThreads);
     if (mode == BRICK_TRI_FWD)
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_FWD>, grid, block, lds, st, p, out, aux);
     else if (mode == BRICK_TRI_FWD_AUX)
@@ -965,7 +862,7 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     return finish(who);
 }
 
-}  // namespace
+}  // namespace ddrr_brick
 
 extern "C" {
 
@@ -1010,12 +907,17 @@ int ddrr_brick_profile_read(unsigned long long *host16) {
 int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
                                const float *target, const float *img, int B, int det_h,
                                int det_w, float voxel_shift, float eps, float *out, float *aux,
-                               float record_vmax, void *stream) {
+                               float record_vmax, int brick_storage, float *brick_ranges,
+                               int ranges_valid, void *stream) {
     const int N = det_h * det_w;
     if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
     if (!out) return fail(-1, "null out pointer");
     if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
     if (!(record_vmax >= 0.f)) return fail(-1, "record_vmax must be >= 0");
+    if (brick_storage != DDRR_BRICKS_F32 && brick_storage != DDRR_BRICKS_Q16)
+        return fail(-1, "brick_storage must be DDRR_BRICKS_F32 or DDRR_BRICKS_Q16");
+    if (brick_storage == DDRR_BRICKS_Q16 && !brick_ranges)
+        return fail(-1, "DDRR_BRICKS_Q16 needs the brick_ranges workspace");
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const long R = (long)B * N;
@@ -1031,9 +933,9 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                            dim3(kBlock), 0, st, source, target, R, N, Dims{dx, dy, dz}, voxel_shift,
                            eps, rec_q, aux);
     }
-    if (int rc = launch_bricks(aux ? BRICK_FWD_AUX : BRICK_FWD, volume, dx, dy, dz, source, target,
-                               img, nullptr, B, det_h, det_w, voxel_shift, eps, out, aux, nullptr,
-                               st, "ddrr_siddon_forward_bricks", 0, nullptr, nullptr, rec_q))
+    if (int rc = launch_fwd_bricks(brick_storage, brick_ranges, ranges_valid, volume, dx, dy, dz,
+                                   source, target, img, B, det_h, det_w, voxel_shift, eps, out, aux,
+                                   rec_q, st, "ddrr_siddon_forward_bricks"))
         return rc;
     if (!aux) return 0;
     hipLaunchKernelGGL(siddon_out_from_record_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),

@@ -1,0 +1,598 @@
+// bricks_fwd.hip -- the Siddon forward / forward + record kernel of the DRR path on
+// volume-stationary bricks, with the brick's shape, storage and the workgroup size as
+// compile-time configuration (bricks.hip keeps every other mode on 32^3 fp32 bricks).
+//
+// Same orchestration as siddon_brick_kernel (bricks.hip): persistent workgroups pull bricks
+// from a global counter; per brick the voxels are staged in LDS, every pose's candidate pixels
+// are tested arithmetically (phase A), the hits are compacted into per-wave length-class
+// queues and walked from LDS 64 at a time (phase B); partial integrals (and the backward
+// record) are combined with fp32 atomics.  What is configurable:
+//   * Q16: the brick is staged as 16-bit block-quantised voxels (brick_step.h: one (vmin, step)
+//     pair per brick, found while staging; the walk reads them as denormal floats at no extra
+//     instruction).  A 32^3 brick then takes 66 KiB instead of 132, so TWO 512-thread
+//     workgroups share a CU and one's staging / end-of-brick barrier overlaps the other's walk
+//     -- or one workgroup holds a brick of twice the volume (longer visits per hit);
+//   * BX x BY x BZ: the brick's extent (anisotropic bricks give longer visits to rays along
+//     the long axis);
+//   * THREADS: 1024 (one workgroup per CU) or 512 (two).
+// Reference: diffdrr/renderers.py:34-76, 94-113 (Siddon.forward, mask=None, sum, nearest).
+#include "runtime.h"
+
+#include <mutex>
+#include "siddon_core.h"
+#include "brick_core.h"
+#include "brick_walk.h"
+#include "brick_step.h"
+#include "record_pack.h"
+#include "record_layout.h"
+#include "brick_shared.h"
+
+using namespace ddrr;
+using namespace ddrr_rt;
+using namespace ddrr_brick;
+
+namespace {
+
+template <int BX_, int BY_, int BZ_, int THREADS_, bool Q16_, int ROWPAD_ = -1>
+struct FwdCfg {
+    static constexpr int BX = BX_, BY = BY_, BZ = BZ_, THREADS = THREADS_, WAVES = THREADS_ / 64;
+    static constexpr bool Q16 = Q16_;
+    static constexpr int ES = Q16 ? 2 : 4;  // bytes per staged voxel
+    // rows and planes padded by one element so that x-, y- and z-neighbours fall in different
+    // banks (ROWPAD_ = 0: no row padding, where the LDS budget of a half CU has no room for it)
+    static constexpr int ROWPAD = ROWPAD_ < 0 ? ES : ROWPAD_;
+    static constexpr int SY = BZ * ES + ROWPAD;  // byte strides
+    static constexpr int SX = BY * SY + ES;
+    static constexpr int BRICK_BYTES = (BX * SX + 15) / 16 * 16;
+    static constexpr int WGS_PER_CU = 1024 / THREADS;
+    // poses per row-table chunk: what the LDS left by the brick and the queues holds
+    static constexpr int LDS_BUDGET = 160 * 1024 / WGS_PER_CU;
+    static constexpr int ROW_ROOM =
+        (LDS_BUDGET - BRICK_BYTES - WAVES * kBuckets * kQueueCap * 4 - 16) / (20 * 4);
+    static constexpr int CHUNK = ROW_ROOM >= 32 ? 32 : ROW_ROOM;
+    static constexpr int LDS = BRICK_BYTES + WAVES * kBuckets * kQueueCap * 4 + CHUNK * 20 * 4 + 16;
+    static constexpr int MAXSTEPS = BX + BY + BZ + 4;
+    static_assert(CHUNK >= 8, "no room for the row table");
+    static_assert(BZ % 4 == 0 && (BX * BY * (BZ / 4)) % THREADS == 0, "staging");
+};
+
+// A row of the per-(pose, brick) table phase A reads, without the fields only the other modes
+// use (brick_walk.h BrickRow): 20 words.
+struct FwdRow {
+    float D0[3], ei[3], ej[3], P0[3], P1[3];
+    float inv_w;
+    int i0, j0, w, count;
+};
+static_assert(sizeof(FwdRow) == 80, "FwdRow");
+
+__device__ __forceinline__ FwdRow fwd_row(const BrickRow &r) {
+    FwdRow f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        f.D0[a] = r.D0[a];
+        f.ei[a] = r.ei[a];
+        f.ej[a] = r.ej[a];
+        f.P0[a] = r.P0[a];
+        f.P1[a] = r.P1[a];
+    }
+    f.inv_w = r.inv_w;
+    f.i0 = r.i0;
+    f.j0 = r.j0;
+    f.w = r.w;
+    f.count = r.count;
+    return f;
+}
+
+__device__ __forceinline__ BrickRow brick_row_of(const FwdRow &f) {
+    BrickRow r;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        r.D0[a] = f.D0[a];
+        r.ei[a] = f.ei[a];
+        r.ej[a] = f.ej[a];
+        r.P0[a] = f.P0[a];
+        r.P1[a] = f.P1[a];
+    }
+    r.inv_w = f.inv_w;
+    r.nscale = 0.f;
+    r.i0 = f.i0;
+    r.j0 = f.j0;
+    r.w = f.w;
+    r.count = f.count;
+    r.perm_k = 1;
+    return r;
+}
+
+// Fetch of a 16-bit voxel by absolute LDS byte address: q in the low half of the register =
+// the denormal float q 2^-149 (brick_step.h).
+struct LdsAbsFetch16 {
+    __device__ __forceinline__ float operator()(unsigned addr) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned q =
+            *(const __attribute__((address_space(3))) unsigned short *)(unsigned long long)addr;
+        return __uint_as_float(q);
+#else
+        (void)addr;
+        return 0.f;
+#endif
+    }
+};
+
+template <class C>
+__device__ __forceinline__ Box cfg_brick_box(const Dims D, int nby, int nbz, int id) {
+    const int bz = id % nbz, by = (id / nbz) % nby, bx = id / (nbz * nby);
+    Box b;
+    b.lo[0] = bx * C::BX;
+    b.lo[1] = by * C::BY;
+    b.lo[2] = bz * C::BZ;
+    b.hi[0] = b.lo[0] + C::BX < D.x ? b.lo[0] + C::BX : D.x;
+    b.hi[1] = b.lo[1] + C::BY < D.y ? b.lo[1] + C::BY : D.y;
+    b.hi[2] = b.lo[2] + C::BZ < D.z ? b.lo[2] + C::BZ : D.z;
+    return b;
+}
+
+// Phase B for one batch entry (all lanes call; `active`: the lane holds an entry).
+template <bool AUX, class C>
+__device__ __forceinline__ void fwd_item(const BrickArgs &p, unsigned lds_base,
+                                         const StepGeom &SG, const Q16Range &range, bool active,
+                                         unsigned b, unsigned pix, float *__restrict__ out,
+                                         float *__restrict__ aux, BrickProf &prof) {
+    const unsigned r = b * (unsigned)(p.det_h * p.det_w) + pix;
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    bool ok = false;
+    if (active) {
+        const float *sp = p.source + b * 3u, *tp = p.target + r * 3u;
+        const float s[3] = {sp[0], sp[1], sp[2]}, t[3] = {tp[0], tp[1], tp[2]};
+        const float L = (!AUX && p.img) ? p.img[r] : 1.f;
+        DDRR_PROF_WAIT_VMEM();
+        DDRR_PROF(PROF_LOADS);
+        StepEntry E = step_enter(SG, s, t, p.shift, p.eps, lds_base);
+        if (C::Q16) q16_scale_entry(E);
+        DDRR_PROF(PROF_SETUP);
+        int steps = 0;
+        float ex[2] = {0.f, 0.f};
+        if (E.hit) {
+            if (C::Q16) {
+                steps = step_walk<AUX, C::MAXSTEPS>(LdsAbsFetch16{}, SG, E, v[0], v + 1, ex);
+                q16_finish<AUX>(range, E, ex, v[0], v + 1);
+            } else {
+                steps = step_walk<AUX, C::MAXSTEPS>(LdsAbsFetch{}, SG, E, v[0], v + 1);
+            }
+        }
+        DDRR_PROF(PROF_WALK);
+        DDRR_PROF_COUNT(PROF_N_STEPS, (unsigned long long)__builtin_amdgcn_readfirstlane(steps));
+        (void)steps;
+        ok = E.hit;  // (phase A's margin lets a few non-crossing rays through)
+        if (!AUX && ok) unsafeAtomicAdd(out + r, L * v[0]);
+    }
+    if (AUX) {
+        // with the record, out = L * (plane I) is formed afterwards (siddon_out_from_record)
+        if (p.rec_q > 0.f) {
+            if (ok) {
+                // packed record: (S1x : S0x) and (S1z : S0z) as two 64-bit integer atomics
+                const float qa = p.rec_q / aux[5u * p.aux_plane + r];
+                unsigned long long *X = reinterpret_cast<unsigned long long *>(aux);
+                atomicAdd(X + r, (unsigned long long)record_pack(v[1], v[3], p.rec_q, qa));
+                atomicAdd(X + p.aux_plane + r,
+                          (unsigned long long)record_pack(v[2], v[4], p.rec_q, qa));
+                unsafeAtomicAdd(aux + 4u * p.aux_plane + r, v[0]);
+            }
+        } else {
+            deliver_record_blocked(aux, ok, r, v);
+        }
+    }
+    DDRR_PROF(PROF_DELIVER);
+}
+
+template <bool AUX, class C>
+__global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void
+siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict__ aux) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned char *brick = smem_raw;
+    unsigned *queue = reinterpret_cast<unsigned *>(smem_raw + C::BRICK_BYTES);
+    FwdRow *rows = reinterpret_cast<FwdRow *>(queue + C::WAVES * kBuckets * kQueueCap);
+    int *counter = reinterpret_cast<int *>(rows + C::CHUNK);  // [0] unit, [1] brick, [2] non-zero
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nbx = (p.D.x + C::BX - 1) / C::BX, nby = (p.D.y + C::BY - 1) / C::BY;
+    const int nbz = (p.D.z + C::BZ - 1) / C::BZ;
+    const int n_bricks = nbx * nby * nbz;
+    const int N = p.det_h * p.det_w;
+    unsigned *myq = queue + wave * kBuckets * kQueueCap;  // wave-private (see bricks.hip)
+    const unsigned pix_mask = (1u << p.pix_bits) - 1u;
+    // chunks of at most C::CHUNK poses, of equal size
+    const int n_chunks = (p.B + C::CHUNK - 1) / C::CHUNK;
+    const int chunk = (p.B + n_chunks - 1) / n_chunks;
+    const unsigned lds_base = LdsAbsFetch::base_of(reinterpret_cast<const float *>(brick));
+    const bool GROUPED = AUX && p.rec_q == 0.f && !(p.dbg & 8);
+
+    BrickProf prof;
+#if defined(DDRR_BRICK_PROFILE)
+    prof.start();
+#endif
+    for (;;) {
+        __syncthreads();  // every wave is done with the previous brick's LDS
+        DDRR_PROF(PROF_BARRIER);
+        if (tid == 0) {
+            counter[1] = atomicAdd(p.work, 1);
+            counter[2] = 0;
+        }
+        __syncthreads();
+        const int brick_id = counter[1];
+        if (brick_id >= n_bricks) break;
+        DDRR_PROF(PROF_CLAIM);
+        const Box box = cfg_brick_box<C>(p.D, nby, nbz, brick_id);
+        const BoxF cells = boxf(box);
+        StepGeom SG;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            SG.lof[a] = (float)box.lo[a];
+            SG.hif[a] = (float)box.hi[a];
+        }
+        SG.strideb[0] = bits_as_float((unsigned)C::SX);
+        SG.strideb[1] = bits_as_float((unsigned)C::SY);
+        SG.strideb[2] = bits_as_float((unsigned)C::ES);
+        int qn0 = 0, qn1 = 0, qn2 = 0;  // hits waiting per length class (wave-uniform)
+        bool brick_empty = false;
+        Q16Range range = {0.f, 0.f, 0.f};
+
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const int b0 = ch * chunk;
+            const int nb = p.B - b0 < chunk ? p.B - b0 : chunk;
+            const bool last_chunk = ch == n_chunks - 1;
+            if (ch > 0) __syncthreads();  // previous chunk's table no longer in use
+            if (tid < nb) {
+                const PoseGrid pg = pose_grid(p.source + (long)(b0 + tid) * 3,
+                                              p.target + (long)(b0 + tid) * N * 3, p.det_h, p.det_w);
+                PixBox pb = project_brick_grid(pg, p.det_h, p.det_w, cells, p.shift);
+                if (GROUPED) pb = align_pixbox_rows(pb, p.det_w);
+                rows[tid] = fwd_row(brick_row(pg, pb, cells, p.shift, p.eps, 0.f));
+            }
+            if (tid == 0) counter[0] = 0;
+            DDRR_PROF(PROF_ROWS);
+            if (ch == 0) {
+                // Stage the brick: a thread owns NQ quads of 4 voxels along z, PER of them in
+                // flight at a time (all of a round's loads are issued before its first LDS store).
+                constexpr int QZ = C::BZ / 4, NQ = C::BX * C::BY * QZ / C::THREADS;
+                constexpr int PER = NQ > 8 ? 8 : NQ;
+                static_assert(NQ % PER == 0, "staging rounds");
+                constexpr int ROWS_PER_PASS = C::THREADS / QZ;
+                const int qz4 = (tid % QZ) * 4, row0 = tid / QZ;
+                const int z = box.lo[2] + qz4;
+                const bool in_z = z + 4 <= box.hi[2];  // (z and D.z are multiples of 4)
+                if (C::Q16) {
+                    // the brick's value range: found by brick_range_kernel before this launch
+                    const float lo = p.ranges[2 * brick_id], hi = p.ranges[2 * brick_id + 1];
+                    range = q16_range(lo, hi);
+                    brick_empty = lo == 0.f && hi == 0.f;
+                }
+                unsigned nz = 0u;
+#pragma unroll
+                for (int h0 = 0; h0 < NQ; h0 += PER) {
+                    float4 q[PER];
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) {
+                        const int row = row0 + (h0 + i) * ROWS_PER_PASS;
+                        const int lx = row / C::BY, ly = row - lx * C::BY;
+                        const int x = box.lo[0] + lx, y = box.lo[1] + ly;
+                        // clamped (always readable) address; what lies outside is zeroed below
+                        const int xc = x < p.D.x ? x : p.D.x - 1, yc = y < p.D.y ? y : p.D.y - 1;
+                        const long at = ((long)xc * p.D.y + yc) * p.D.z + (in_z ? z : 0);
+                        q[i] = *reinterpret_cast<const float4 *>(p.vol + at);
+                    }
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) {
+                        const int row = row0 + (h0 + i) * ROWS_PER_PASS;
+                        const int lx = row / C::BY, ly = row - lx * C::BY;
+                        const bool in = in_z && box.lo[0] + lx < box.hi[0] && box.lo[1] + ly < box.hi[1];
+                        if (!in) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (C::Q16) {
+                            unsigned short *d = reinterpret_cast<unsigned short *>(
+                                brick + lx * C::SX + ly * C::SY + qz4 * 2);
+                            d[0] = (unsigned short)q16_encode(q[i].x, range);
+                            d[1] = (unsigned short)q16_encode(q[i].y, range);
+                            d[2] = (unsigned short)q16_encode(q[i].z, range);
+                            d[3] = (unsigned short)q16_encode(q[i].w, range);
+                        } else {
+                            float *df = reinterpret_cast<float *>(brick + lx * C::SX + ly * C::SY +
+                                                                  qz4 * 4);
+                            df[0] = q[i].x;
+                            df[1] = q[i].y;
+                            df[2] = q[i].z;
+                            df[3] = q[i].w;
+                            nz |= __float_as_uint(q[i].x) | __float_as_uint(q[i].y) |
+                                  __float_as_uint(q[i].z) | __float_as_uint(q[i].w);
+                        }
+                    }
+                }
+                // Empty space: a brick of zeros adds nothing to any integral or record
+                if (!C::Q16 && (nz & 0x7fffffffu) != 0u) counter[2] = 1;  // (cleared with the claim)
+            }
+            DDRR_PROF(PROF_STORE);
+            __syncthreads();
+            if (!C::Q16 && ch == 0) brick_empty = counter[2] == 0;
+            // units per pose -> inclusive prefix, held by every wave in registers (lane k: pose k)
+            int incl = lane < nb ? (rows[lane].count + 63) >> 6 : 0;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                const int up = __shfl_up(incl, o, 64);
+                incl += lane >= o ? up : 0;
+            }
+            const int units = brick_empty ? 0 : __builtin_amdgcn_readlane(incl, 31);
+            int cur = 0, cur_lo = 0, cur_hi = __builtin_amdgcn_readlane(incl, 0);
+            DDRR_PROF(PROF_STAGE);
+            for (;;) {
+                int u = 0;
+                if (lane == 0) u = atomicAdd(&counter[0], 1);
+                u = uni(u);
+                const bool drain = u >= units;  // no unit left in this chunk
+                if (drain && !last_chunk) break;
+                if (!drain) {
+                    while (u >= cur_hi) {  // units arrive in increasing order: forward cursor
+                        ++cur;
+                        cur_lo = cur_hi;
+                        cur_hi = __builtin_amdgcn_readlane(incl, uni(cur));
+                    }
+                    const BrickRow r = brick_row_of(rows[cur]);
+                    DDRR_PROF(PROF_PULL);
+                    DDRR_PROF_COUNT(PROF_N_UNITS, 1);
+                    const int local = (u - cur_lo) * 64 + lane;
+                    const bool valid = local < uni(r.count);
+                    int pix = 0;
+                    float n_est = 0.f;
+                    const bool hit = valid && brick_candidate(r, local, p.det_w, pix, n_est);
+                    // float record: classes per run of 8 adjacent pixels (see bricks.hip)
+                    float n_grp = hit ? n_est : 0.f;
+                    if (GROUPED) {
+                        n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                            0, __builtin_bit_cast(int, n_grp), 0xB1, 0xf, 0xf, true)));   // lane ^ 1
+                        n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                            0, __builtin_bit_cast(int, n_grp), 0x4E, 0xf, 0xf, true)));   // lane ^ 2
+                        n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                            0, __builtin_bit_cast(int, n_grp), 0x141, 0xf, 0xf, true)));  // 7 - lane
+                    }
+                    const bool c0 = n_grp < p.t1, c1 = !c0 && n_grp < p.t2;
+                    const unsigned long long m0 = __ballot(hit && c0);
+                    const unsigned long long m1 = __ballot(hit && c1);
+                    const unsigned long long m2 = __ballot(hit && !c0 && !c1);
+                    if (hit) {
+                        const int r0 = lane_rank(m0), r1 = lane_rank(m1), r2 = lane_rank(m2);
+                        const int slot = c0 ? qn0 + r0 : (c1 ? kQueueCap + qn1 + r1
+                                                             : 2 * kQueueCap + qn2 + r2);
+                        myq[slot] = ((unsigned)(b0 + cur) << p.pix_bits) | (unsigned)pix;
+                    }
+                    qn0 = uni(qn0 + (int)__popcll(m0));
+                    qn1 = uni(qn1 + (int)__popcll(m1));
+                    qn2 = uni(qn2 + (int)__popcll(m2));
+                    wave_fence();
+                    DDRR_PROF_COUNT(PROF_N_HITS, __popcll(m0) + __popcll(m1) + __popcll(m2));
+                    DDRR_PROF(PROF_PHASE_A);
+                }
+                // walk every full batch of 64 hits of one class; when draining, what is left
+                // of all classes together (longest first), 64 at a time
+                for (;;) {
+                    int k = -1, n = 0;
+                    if (qn0 >= 64) k = 0, n = 64;
+                    else if (qn1 >= 64) k = 1, n = 64;
+                    else if (qn2 >= 64) k = 2, n = 64;
+                    unsigned e = 0;
+                    if (k >= 0) {
+                        const int base = (k == 0 ? qn0 : (k == 1 ? qn1 : qn2)) - 64;
+                        qn0 -= k == 0 ? 64 : 0;
+                        qn1 -= k == 1 ? 64 : 0;
+                        qn2 -= k == 2 ? 64 : 0;
+                        e = myq[k * kQueueCap + base + lane];
+                    } else if (drain && qn0 + qn1 + qn2 > 0) {
+                        // virtual queue [class 2 | class 1 | class 0], taken from the front
+                        const int tot = qn0 + qn1 + qn2;
+                        n = tot < 64 ? tot : 64;
+                        const int i2 = lane, i1 = lane - qn2, i0 = lane - qn2 - qn1;
+                        if (lane < n)
+                            e = i2 < qn2 ? myq[2 * kQueueCap + qn2 - 1 - i2]
+                                         : (i1 < qn1 ? myq[kQueueCap + qn1 - 1 - i1]
+                                                     : myq[qn0 - 1 - i0]);
+                        const int t2 = qn2 < n ? qn2 : n;
+                        const int t1 = qn1 < n - t2 ? qn1 : n - t2;
+                        qn2 -= t2;
+                        qn1 -= t1;
+                        qn0 -= n - t2 - t1;
+                    } else {
+                        break;
+                    }
+                    DDRR_PROF(PROF_POP);
+                    DDRR_PROF_COUNT(PROF_N_BATCH, 1);
+                    fwd_item<AUX, C>(p, lds_base, SG, range, lane < n, e >> p.pix_bits,
+                                     e & pix_mask, out, aux, prof);
+                    wave_fence();
+                }
+                if (drain) break;
+            }
+        }
+    }
+#if defined(DDRR_BRICK_PROFILE)
+    DDRR_PROF(PROF_BARRIER);
+    if (lane == 0 && p.prof)
+        for (int i = 0; i < 16; ++i) atomicAdd(p.prof + i, prof.t[i]);
+#endif
+}
+
+// (vmin, vmax) of every brick of a BX x BY x BZ grid, the input of the 16-bit staging
+// (q16_range).  One workgroup per brick; a brick holding a NaN reports vmax = NaN.
+__global__ __launch_bounds__(256) void brick_range_kernel(const float *__restrict__ vol, Dims D,
+                                                          int BX, int BY, int BZ, int nby, int nbz,
+                                                          float *__restrict__ ranges) {
+    __shared__ float red[2][4];
+    const int id = blockIdx.x;
+    const int bz = id % nbz, by = (id / nbz) % nby, bx = id / (nbz * nby);
+    const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
+    const int nx = min(BX, D.x - x0), ny = min(BY, D.y - y0), nz = min(BZ, D.z - z0);
+    float tmin = INFINITY, tmax = -INFINITY;
+    bool bad = false;
+    const int QZ = BZ / 4, quads = nx * ny * QZ;
+    for (int k = threadIdx.x; k < quads; k += 256) {
+        const int qz = k % QZ, row = k / QZ, ly = row % ny, lx = row / ny;
+        if (qz * 4 >= nz) continue;  // (nz is a multiple of 4)
+        const float4 v = *reinterpret_cast<const float4 *>(
+            vol + ((long)(x0 + lx) * D.y + (y0 + ly)) * D.z + z0 + qz * 4);
+        tmin = fminf(fminf(fminf(tmin, v.x), fminf(v.y, v.z)), v.w);
+        tmax = fmaxf(fmaxf(fmaxf(tmax, v.x), fmaxf(v.y, v.z)), v.w);
+        const float sum = (v.x + v.y) + (v.z + v.w);
+        bad = bad || sum != sum;  // (min / max drop NaNs)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        tmin = fminf(tmin, __shfl_xor(tmin, o, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
+    }
+    bad = __ballot(bad) != 0ull;
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[0][wave] = tmin;
+        red[1][wave] = bad ? NAN : tmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float lo = INFINITY, hi = -INFINITY;
+        bool nan = false;
+        for (int w = 0; w < 4; ++w) {
+            lo = fminf(lo, red[0][w]);
+            hi = fmaxf(hi, red[1][w]);
+            nan = nan || red[1][w] != red[1][w];
+        }
+        if (!(lo <= hi)) lo = hi = 0.f;  // (no voxel)
+        ranges[2 * id] = lo;
+        ranges[2 * id + 1] = nan ? NAN : hi;
+    }
+}
+
+template <bool AUX, class C>
+int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t st) {
+    static_assert(C::LDS <= C::LDS_BUDGET, "LDS budget");
+    constexpr int kMaxDev = 64;
+    static std::mutex mu;
+    static bool attr_set[kMaxDev] = {false};
+    hipError_t e;
+    int dev = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return fail_hip(e, "hipGetDevice");
+    if (dev < 0 || dev >= kMaxDev) return fail(-1, "device index out of range");
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!attr_set[dev]) {
+            if ((e = hipFuncSetAttribute(
+                     reinterpret_cast<const void *>(&siddon_fwd_brick_kernel<AUX, C>),
+                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS)) != hipSuccess)
+                return fail_hip(e, "hipFuncSetAttribute");
+            attr_set[dev] = true;
+        }
+    }
+    const int nbx = (p.D.x + C::BX - 1) / C::BX, nby = (p.D.y + C::BY - 1) / C::BY;
+    const int nbz = (p.D.z + C::BZ - 1) / C::BZ;
+    const int n_bricks = nbx * nby * nbz, slots = n_cu * C::WGS_PER_CU;
+    if (C::Q16) {
+        if (!p.ranges) return fail(-1, "DDRR_BRICKS_Q16 needs the brick_ranges workspace");
+        if (!p.ranges_valid)
+            hipLaunchKernelGGL(brick_range_kernel, dim3(n_bricks), dim3(256), 0, st, p.vol, p.D, C::BX,
+                               C::BY, C::BZ, nby, nbz, const_cast<float *>(p.ranges));
+    }
+    const dim3 grid(n_bricks < slots ? n_bricks : slots), block(C::THREADS);
+    hipLaunchKernelGGL((siddon_fwd_brick_kernel<AUX, C>), grid, block, C::LDS, st, p, out, aux);
+    return 0;
+}
+
+// brick variants (DDRR_BRICKS_* of include/diffdrr_hip.h; the others exist in tools builds)
+using CfgF32 = FwdCfg<32, 32, 32, 1024, false>;        // 32^3 fp32, one workgroup per CU
+using CfgQ16x2 = FwdCfg<32, 32, 32, 512, true>;        // 32^3 16-bit, two workgroups per CU
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+using CfgQ16x1 = FwdCfg<32, 32, 32, 1024, true>;       // 32^3 16-bit, one workgroup per CU
+using CfgF32Half = FwdCfg<32, 32, 16, 512, false, 0>;  // 32x32x16 fp32 halves, two workgroups
+using CfgQ16X64 = FwdCfg<64, 32, 32, 1024, true>;      // double bricks, 16-bit
+using CfgQ16Z64 = FwdCfg<32, 32, 64, 1024, true>;
+using CfgQ16Y64 = FwdCfg<32, 64, 32, 1024, true>;
+using CfgF32Y64 = FwdCfg<16, 64, 32, 1024, false>;     // anisotropic fp32 bricks
+using CfgF32X64 = FwdCfg<64, 16, 32, 1024, false>;
+using CfgF32Z64 = FwdCfg<16, 32, 64, 1024, false>;
+#endif
+
+}  // namespace
+
+namespace ddrr_brick {
+
+// variant: DDRR_BRICKS_F32 (0) or DDRR_BRICKS_Q16 (1); tools builds know more (g_brick_variant)
+int launch_fwd_bricks(int variant, float *brick_ranges, int ranges_valid, const float *volume,
+                      int dx, int dy, int dz, const float *source, const float *target,
+                      const float *img, int B, int det_h, int det_w, float voxel_shift, float eps,
+                      float *out, float *aux, float rec_q, hipStream_t st, const char *who) {
+    const int N = det_h * det_w;
+    // the configurable kernel stages with 16-byte loads; anything else takes the general kernel
+    const bool vec_ok = (dz & 3) == 0 && (reinterpret_cast<uintptr_t>(volume) & 15) == 0;
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+    if (g_brick_variant != -2) {  // (-2: no override, -1: bricks.hip)
+        variant = g_brick_variant;
+        ranges_valid = 0;  // (the variants differ in their brick grids)
+    }
+#endif
+    if (!vec_ok || variant < 0)
+        return launch_bricks(aux ? BRICK_FWD_AUX : BRICK_FWD, volume, dx, dy, dz, source, target, img,
+                             nullptr, B, det_h, det_w, voxel_shift, eps, out, aux, nullptr, st, who,
+                             0, nullptr, nullptr, rec_q);
+    BrickArgs p = {};
+    p.vol = volume;
+    p.D = Dims{dx, dy, dz};
+    p.source = source;
+    p.target = target;
+    p.img = img;
+    p.B = B;
+    p.det_h = det_h;
+    p.det_w = det_w;
+    p.shift = voxel_shift;
+    p.eps = eps;
+    if ((long)B * N * 12 >= (1L << 32))
+        return fail(-1, "B * N too large for one brick launch (12 B N must stay below 2^32): "
+                        "split the pose batch");
+    p.aux_plane = (unsigned)((long)B * N);
+    p.rec_q = rec_q;
+    p.ranges = brick_ranges;
+    p.ranges_valid = ranges_valid;
+    p.pix_bits = 1;
+    while ((1L << p.pix_bits) < N) ++p.pix_bits;
+    if (((long)B << p.pix_bits) > (1L << 32))
+        return fail(-1, "B * 2^ceil(log2 N) exceeds 2^32: split the pose batch");
+    p.t1 = g_brick_t1;
+    p.t2 = g_brick_t2;
+    p.dbg = g_brick_dbg;
+#if defined(DDRR_BRICK_PROFILE)
+    p.prof = g_brick_prof;
+#endif
+    int n_cu = 0;
+    if (int rc = brick_launch_resources(st, n_cu, p.work)) return rc;
+    int rc = 0;
+#define DDRR_LAUNCH(C) (aux ? launch_cfg<true, C>(p, n_cu, out, aux, st) \
+                            : launch_cfg<false, C>(p, n_cu, out, aux, st))
+    switch (variant) {
+        case 0: rc = DDRR_LAUNCH(CfgF32); break;
+        case 1: rc = DDRR_LAUNCH(CfgQ16x2); break;
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+        case 2: rc = DDRR_LAUNCH(CfgQ16x1); break;
+        case 3: rc = DDRR_LAUNCH(CfgF32Half); break;
+        case 4: rc = DDRR_LAUNCH(CfgQ16X64); break;
+        case 5: rc = DDRR_LAUNCH(CfgQ16Z64); break;
+        case 6: rc = DDRR_LAUNCH(CfgQ16Y64); break;
+        case 7: rc = DDRR_LAUNCH(CfgF32Y64); break;
+        case 8: rc = DDRR_LAUNCH(CfgF32X64); break;
+        case 9: rc = DDRR_LAUNCH(CfgF32Z64); break;
+#endif
+        default: return fail(-1, "unknown brick variant");
+    }
+#undef DDRR_LAUNCH
+    if (rc) return rc;
+    return finish(who);
+}
+
+}  // namespace ddrr_brick
+
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+extern "C" int ddrr_set_brick_variant(int v) {
+    ddrr_brick::g_brick_variant = v;
+    return 0;
+}
+#endif

@@ -188,15 +188,41 @@ def record_planes(aux, B, N):
     return torch.cat([p03, blk[:, 4].reshape(1, -1)])[:, :R].reshape(5, B, N)
 
 
+_BRICK_STORAGE = {"f32": _lib.BRICKS_F32, "q16": _lib.BRICKS_Q16}
+_range_cache = {}  # id(volume) -> (weakref to the volume, its version, (min, max) per brick)
+
+
+def brick_ranges(volume):
+    """Workspace of the 16-bit brick staging (include/diffdrr_hip.h DDRR_BRICKS_Q16): 2 floats
+    per 32^3 brick, cached per volume TENSOR and version -- the kernel fills it on the first
+    launch after the volume changed (one pass over the volume) and reuses it afterwards.
+    (In-place edits that bypass the version counter, ``volume.data[...] = x``, are not seen.)
+    -> (tensor, valid)"""
+    ent = _range_cache.get(id(volume))
+    if ent is not None and ent[0]() is volume and ent[1] == volume._version \
+            and ent[2].device == volume.device:
+        return ent[2], 1
+    n = 1
+    for d in volume.shape:
+        n *= -(-int(d) // 32)
+    buf = torch.empty(2 * n, dtype=torch.float32, device=volume.device)
+    key = id(volume)
+    _range_cache[key] = (weakref.ref(volume, lambda _, k=key: _range_cache.pop(k, None)),
+                         volume._version, buf)
+    return buf, 0
+
+
 def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, eps=1e-8,
-                          want_aux=False, record_vmax=0.0):
+                          want_aux=False, record_vmax=0.0, storage="f32"):
     """Detector-grid Siddon (sum) through the volume-stationary brick kernel: every 32^3
     brick is staged in LDS once and all rays of all poses are traced through it.
     Requires the targets to be the affine detector grid DRR builds.
     -> (out (B,N), aux | None); aux is the blocked float record (ceil(B N / 16), 80)
     (csrc/record_layout.h; :func:`record_planes` unpacks it), or with ``record_vmax`` =
     max |volume| > 0 the (7,B,N) packed fixed-point record (3 atomics per ray and brick
-    instead of 5, bit-reproducible; csrc/record_pack.h)."""
+    instead of 5, bit-reproducible; csrc/record_pack.h).
+    ``storage``: "f32" stages the volume's own values, "q16" a 16-bit block quantisation per
+    32^3 brick (include/diffdrr_hip.h DDRR_BRICKS_Q16: two workgroups per CU)."""
     B, N = _check_rays(volume, source, target, img)
     H, W = int(det[0]), int(det[1])
     if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
@@ -204,6 +230,7 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
     volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
     img = None if img is None else img.contiguous()
     out = torch.empty(B, N, dtype=torch.float32, device=volume.device)
+    ranges, valid = brick_ranges(volume) if storage == "q16" else (None, 0)
     packed = bool(want_aux and record_vmax and record_vmax > 0.0)
     aux = None
     if want_aux:
@@ -215,7 +242,8 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
     _launch(
         "ddrr_siddon_forward_bricks", volume.device, volume.data_ptr(), *volume.shape,
         source.data_ptr(), target.data_ptr(), _ptr(img), B, H, W, float(voxel_shift), float(eps),
-        out.data_ptr(), _ptr(aux), float(record_vmax) if packed else 0.0)
+        out.data_ptr(), _ptr(aux), float(record_vmax) if packed else 0.0,
+        _BRICK_STORAGE[storage], _ptr(ranges), int(valid))
     return out, aux
 
 

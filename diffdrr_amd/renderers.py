@@ -100,7 +100,8 @@ class _SiddonFn(torch.autograd.Function):
             # detector-grid fast path: volume-stationary LDS bricks (volume read once)
             out, aux = ops.siddon_forward_bricks(
                 volume, source, target, img, cfg["det"], voxel_shift=cfg["voxel_shift"],
-                eps=cfg["eps"], want_aux=want_aux, record_vmax=_record_vmax(volume, want_aux, cfg))
+                eps=cfg["eps"], want_aux=want_aux, record_vmax=_record_vmax(volume, want_aux, cfg),
+                storage=cfg.get("storage", "f32"))
         else:
             out, aux, _ = ops.siddon_forward(
                 volume, source, target, img, voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
@@ -301,7 +302,8 @@ class _SiddonPoseFn(torch.autograd.Function):
         if cfg["path"] == "bricks":
             out, aux = ops.siddon_forward_bricks(
                 volume, source, target, img, cfg["det"], voxel_shift=cfg["voxel_shift"],
-                eps=cfg["eps"], want_aux=want_aux, record_vmax=_record_vmax(volume, want_aux, cfg))
+                eps=cfg["eps"], want_aux=want_aux, record_vmax=_record_vmax(volume, want_aux, cfg),
+                storage=cfg.get("storage", "f32"))
         else:
             out, aux, _ = ops.siddon_forward(
                 volume, source, target, img, voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
@@ -415,6 +417,10 @@ class Siddon(torch.nn.Module):
         # resolves 2 max|V| (Dx+Dy+Dz+3) / 2^30, ~10x coarser than fp32 accumulation, hence off
         # by default: the default record is fp32 like the reference's arithmetic.
         self.packed_record = False
+        # How the brick kernel holds a brick in LDS (include/diffdrr_hip.h): "f32" the volume's
+        # own values; "q16" a 16-bit block quantisation per 32^3 brick (|error| per voxel <=
+        # brick range / 131070, fp32 arithmetic): two workgroups per CU instead of one.
+        self.brick_storage = "f32"
 
     def dims(self, volume):
         return torch.tensor(volume.shape).to(volume)
@@ -432,7 +438,7 @@ class Siddon(torch.nn.Module):
                 "stop_gradients": self.stop_gradients_through_grid_sample,
                 "det": self.detector_shape if det == "unchecked" else det, "tile": self.tile,
                 "path": self.grid_path,
-                "packed_record": self.packed_record}
+                "packed_record": self.packed_record, "storage": self.brick_storage}
 
     def supports_pose_entry(self):
         """Whether ``render_poses`` (the fused DRR entry) computes what ``forward`` would."""

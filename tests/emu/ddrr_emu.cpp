@@ -311,8 +311,13 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
 int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
                                const float *target, const float *img, int B, int det_h,
                                int det_w, float voxel_shift, float eps, float *out, float *aux,
-                               float record_vmax, void *) {
+                               float record_vmax, int brick_storage, float *brick_ranges,
+                               int /*ranges_valid*/, void *) {
     const Dims D{dx, dy, dz};
+    const bool q16 = brick_storage == DDRR_BRICKS_Q16;
+    // 16-bit bricks (bricks_fwd.hip CfgQ16x2): rows and planes padded by one element
+    const int qsy = 32 * 2 + 2, qsx = 32 * qsy + 2;
+    std::vector<unsigned short> qbrick((size_t)qsx * 32 / 2);
     const int N = det_h * det_w;
     const long plane = (long)B * N;
     memset(out, 0, sizeof(float) * (size_t)B * N);
@@ -336,11 +341,32 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
         const Box box = brick_box(D, bg, id);
         const StepGeom SG = step_geom(box, lay);
         std::fill(brick.begin(), brick.end(), 0.f);
+        float vmin = INFINITY, vmax = -INFINITY;
         for (int x = box.lo[0]; x < box.hi[0]; ++x)
             for (int y = box.lo[1]; y < box.hi[1]; ++y)
-                for (int z = box.lo[2]; z < box.hi[2]; ++z)
-                    brick[(x - box.lo[0]) * lay.sx + (y - box.lo[1]) * lay.sy + (z - box.lo[2])] =
-                        volume[((long)x * dy + y) * dz + z];
+                for (int z = box.lo[2]; z < box.hi[2]; ++z) {
+                    const float v = volume[((long)x * dy + y) * dz + z];
+                    brick[(x - box.lo[0]) * lay.sx + (y - box.lo[1]) * lay.sy + (z - box.lo[2])] = v;
+                    vmin = fminf(vmin, v);
+                    vmax = v != v ? v : fmaxf(vmax, v);
+                }
+        Q16Range range = q16_range(vmin, vmax);
+        StepGeom SGq = SG;
+        if (q16) {
+            if (brick_ranges) {
+                brick_ranges[2 * id] = vmin;
+                brick_ranges[2 * id + 1] = vmax;
+            }
+            SGq.strideb[0] = bits_as_float((unsigned)qsx);
+            SGq.strideb[1] = bits_as_float((unsigned)qsy);
+            SGq.strideb[2] = bits_as_float(2u);
+            std::fill(qbrick.begin(), qbrick.end(), (unsigned short)0);
+            for (int x = box.lo[0]; x < box.hi[0]; ++x)
+                for (int y = box.lo[1]; y < box.hi[1]; ++y)
+                    for (int z = box.lo[2]; z < box.hi[2]; ++z)
+                        qbrick[((x - box.lo[0]) * qsx + (y - box.lo[1]) * qsy) / 2 + (z - box.lo[2])] =
+                            (unsigned short)q16_encode(volume[((long)x * dy + y) * dz + z], range);
+        }
         auto item = [&](int b, int pix) {
             const long r = (long)b * N + pix;
             float s[3], t[3];
@@ -349,10 +375,17 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                 t[a] = target[r * 3 + a];
             }
             float I, rec[4];
-            const bool hit = aux ? step_trace<true>(LdsFetch{brick.data()}, 0u, SG, s, t, voxel_shift,
-                                                    eps, I, rec)
-                                 : step_trace<false>(LdsFetch{brick.data()}, 0u, SG, s, t,
-                                                     voxel_shift, eps, I, rec);
+            bool hit;
+            if (q16)
+                hit = aux ? step_trace_q16<true, 100>(LdsFetch16{qbrick.data()}, 0u, SGq, range, s, t,
+                                                      voxel_shift, eps, I, rec)
+                          : step_trace_q16<false, 100>(LdsFetch16{qbrick.data()}, 0u, SGq, range, s,
+                                                       t, voxel_shift, eps, I, rec);
+            else
+                hit = aux ? step_trace<true>(LdsFetch{brick.data()}, 0u, SG, s, t, voxel_shift,
+                                             eps, I, rec)
+                          : step_trace<false>(LdsFetch{brick.data()}, 0u, SG, s, t,
+                                              voxel_shift, eps, I, rec);
             if (!hit) return;  // phase A's margin let a non-crossing ray through
             out[r] += (img ? img[r] : 1.f) * I;
             if (packed) {

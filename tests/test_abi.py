@@ -131,8 +131,12 @@ def test_argument_checks_return_errors_without_touching_a_device():
                                     0, 0, 1, 64, P, None) != 0
     assert b"n_points" in c.ddrr_last_error()
     assert c.ddrr_siddon_forward_bricks(P, 4, 4, 4, P, P, P, 1, 1, 5, f(0.5), f(1e-8), P, None,
-                                        f(0.0), None) != 0
+                                        f(0.0), 0, None, 0, None) != 0
     assert b"2x2" in c.ddrr_last_error()
+    # 16-bit bricks need their range workspace
+    assert c.ddrr_siddon_forward_bricks(P, 4, 4, 4, P, P, P, 1, 4, 5, f(0.5), f(1e-8), P, None,
+                                        f(0.0), 1, None, 0, None) != 0
+    assert b"brick_ranges" in c.ddrr_last_error()
     # an empty batch is a valid no-op
     assert c.ddrr_siddon_forward(P, 4, 4, 4, P, 1, P, P, 0, 5, f(0.5), f(1e-8), 0, 0, 0, 0, 0, 1, 64,
                                  P, None, None, None) == 0
@@ -183,7 +187,8 @@ def test_brick_kernels_fit_their_register_budget():
                 elif key == "vgpr_count" and name is not None and scratch is not None:
                     kernels[name] = (scratch, int(val))
                     name = None
-    bricks = {k: v for k, v in kernels.items() if "siddon_brick_kernel" in k}
+    bricks = {k: v for k, v in kernels.items()
+              if "siddon_brick_kernel" in k or "siddon_fwd_brick_kernel" in k}
     assert len(bricks) >= 6, sorted(kernels)
     for name, (scratch, vgpr) in bricks.items():
         assert scratch == 0, (name, scratch)

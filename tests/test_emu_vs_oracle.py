@@ -299,6 +299,20 @@ def test_generic_and_brick_walks_vs_oracle(emulated_ops, D, H, W, delx):
     gsb, gtb, gib = ops.siddon_backward_rays(auxb, go, s, t, L)
     gsg, gtg, gig = ops.siddon_backward_rays(aux_gen, go, s, t, L)
     assert rel_err(gib.numpy(), gig.numpy()) < 2e-5
+    # 16-bit block-quantised bricks (brick_step.h q16_*): the same walk over q = 0 .. 65535 read
+    # as denormal floats, alphas scaled by 2^64; |V - (vmin + q step)| <= range / 131070 per voxel
+    outq, auxq = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True, storage="q16")
+    outq0, _ = ops.siddon_forward_bricks(V, s, t, L, (H, W), storage="q16")
+    assert rel_err(outq0.numpy(), outq.numpy()) < 1e-6
+    gsq, gtq, giq = ops.siddon_backward_rays(auxq, go, s, t, L)
+    for b, (name, _, _) in enumerate(SLAB_POSES):
+        assert rel_err(outq[b].numpy(), ref[b]) < 5e-5, name
+        assert rel_err(outq[b].numpy(), outb[b].numpy()) < 1e-5, name
+        # the record of the quantised volume: the same crossings, voxel values 1e-5 apart
+        assert rel_err(giq[b].numpy(), gib[b].numpy()) < 1e-5, name
+        same = (gtq[b] - gtb[b]).abs().amax(-1) <= 1e-3 * gtb[b].abs().max()
+        assert same.float().mean().item() > 0.995, name
+        assert rel_err(gtq[b].sum(0).numpy(), gtb[b].sum(0).numpy()) < 2e-3, name
     # yardstick: the fp64 oracle, allowance: what the reference's own fp32 arithmetic (the fp32
     # oracle) loses against it.  Single rays differ where a crossing pair ties in fp32 and is
     # attributed to different axes; the walks' alphas are within an ulp of the reference's

@@ -619,10 +619,17 @@ def test_brick_kernel_equals_generic_walk(gpu, big):
     assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 2e-5
     again, aux = ops.siddon_forward_bricks(V, s, t, L, (256, 256), want_aux=True)
     assert rel_err(again.cpu().numpy(), out.cpu().numpy()) < 2e-6  # atomics: not bit-stable
-    # planar backward record: same I, and the same ray gradients as the generic record
-    # except on the ~1 % of rays holding a crossing pair that ties in fp32
-    assert aux.shape == (5, 4, 256 * 256)
-    assert torch.allclose(aux[0], aux_ref[..., 0], rtol=1e-4, atol=1e-5)
+    # blocked backward record (csrc/record_layout.h): same I, and the same ray gradients as the
+    # generic record except on the ~1 % of rays holding a crossing pair that ties in fp32
+    assert aux.shape == (4 * 256 * 256 // 16, 80)
+    planes = ops.record_planes(aux, 4, 256 * 256)
+    assert torch.allclose(planes[0], aux_ref[..., 0], rtol=1e-4, atol=1e-5)
+    # S0x, S0z, S1x, S1z of the interleaved record {I, S0xyz, S1xyz}: the planes are the ones
+    # the layout says they are (ties aside: compare where the rays agree)
+    for k, col in ((1, 1), (2, 3), (3, 4), (4, 6)):
+        scale_k = aux_ref[..., col].abs().max()
+        same = (planes[k] - aux_ref[..., col]).abs() <= 1e-3 * scale_k
+        assert same.float().mean().item() > 0.97, k
     go = torch.rand(out.shape, device=gpu, generator=torch.Generator(gpu).manual_seed(0))
     gsb, gtb, gib = ops.siddon_backward_rays(aux, go, s, t, L)
     gsg, gtg, gig = ops.siddon_backward_rays(aux_ref, go, s, t, L)

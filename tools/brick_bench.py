@@ -20,7 +20,12 @@ ap.add_argument("--det", type=int, default=256)
 ap.add_argument("--layouts", default="33:1057")
 ap.add_argument("--cases", default="pert32,pert32aux,base32,pert1,pert8,pert128")
 ap.add_argument("--dbg", default="0")
-ap.add_argument("--classes", default="14:34")
+ap.add_argument("--classes", default="18:40")
+ap.add_argument("--variants", default="-2",
+                help="bricks_fwd.hip variants: -2 product default, -1 the general 32^3 fp32 kernel of "
+                     "bricks.hip, 0 32^3 fp32, 1 32^3 16-bit x 2 workgroups per CU, 2 32^3 16-bit x 1, "
+                     "3 32x32x16 fp32 x 2, 4-6 double 16-bit bricks (x, z, y long), 7-9 anisotropic fp32 "
+                     "bricks 16x64x32, 64x16x32, 16x32x64")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 D, H = a.size, a.det
@@ -40,13 +45,17 @@ for case in a.cases.split(","):
         s, t, L = rays(drr, *poses(int(name[4:]), 2, dev))
     sets[case] = (s, t, L, aux)
 import itertools
-for lay, dbg, cl in itertools.product(a.layouts.split(","), a.dbg.split(","), a.classes.split(",")):
+for lay, dbg, cl, var in itertools.product(a.layouts.split(","), a.dbg.split(","), a.classes.split(","),
+                                           a.variants.split(",")):
     sy, sx = (int(v) for v in lay.split(":"))
+    var = int(var)
+    lib.cdll.ddrr_set_brick_variant(var)
+    storage = "q16" if var in (1, 2, 4, 5, 6) else "f32"
     lib.cdll.ddrr_set_brick_debug(int(dbg))
     t1, t2 = (float(v) for v in cl.split(":"))
     import ctypes
     lib.cdll.ddrr_set_brick_classes(ctypes.c_float(t1), ctypes.c_float(t2))
-    lay = f"{lay} dbg{dbg} cls{cl}"
+    lay = f"{lay} dbg{dbg} cls{cl} var{var:2d}"
     rc = lib.cdll.ddrr_set_brick_layout(sy, sx)
     if rc != 0:
         print(f"layout {lay}: rejected")
@@ -57,10 +66,11 @@ for lay, dbg, cl in itertools.product(a.layouts.split(","), a.dbg.split(","), a.
         nvox = int(nv.sum())
         alg = 4 * nvox + B * H * H * 20 + 12 * B
         vm = ops.volume_absmax(V) if case.endswith("auxp") else 0.0
-        med, best = timeit(lambda: ops.siddon_forward_bricks(V, s, t, L, (H, H), want_aux=aux, record_vmax=vm))
+        med, best = timeit(lambda: ops.siddon_forward_bricks(V, s, t, L, (H, H), want_aux=aux, record_vmax=vm,
+                                                             storage=storage))
         ref = ops.siddon_forward(V, s, t, L, det=(H, H))[0]
-        out = ops.siddon_forward_bricks(V, s, t, L, (H, H), want_aux=aux)[0]
+        out = ops.siddon_forward_bricks(V, s, t, L, (H, H), want_aux=aux, storage=storage)[0]
         err = ((out - ref).abs().max() / ref.abs().max()).item()
-        print(f"layout {lay:26s} {case:12s} B {B:4d} vox/ray {nvox / (B * H * H):6.1f}  {med:8.3f} ms "
+        print(f"layout {lay:32s} {case:12s} B {B:4d} vox/ray {nvox / (B * H * H):6.1f}  {med:8.3f} ms "
               f"(best {best:7.3f})  {B / med * 1e3:9.0f} DRR/s  {alg / med / 1e6:8.1f} GB/s alg "
               f"({alg / med / 1e6 / 8000 * 100:5.1f}% of 8 TB/s)  err vs generic {err:.1e}", flush=True)
