@@ -527,8 +527,10 @@ int launch_fwd_bricks(int variant, float *brick_ranges, int ranges_valid, const 
     const bool vec_ok = (dz & 3) == 0 && (reinterpret_cast<uintptr_t>(volume) & 15) == 0;
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
     if (g_brick_variant != -2) {  // (-2: no override, -1: bricks.hip)
+        static int last_variant = -100;
         variant = g_brick_variant;
-        ranges_valid = 0;  // (the variants differ in their brick grids)
+        if (variant != last_variant) ranges_valid = 0;  // (the variants differ in their brick grids)
+        last_variant = variant;
     }
 #endif
     if (!vec_ok || variant < 0)

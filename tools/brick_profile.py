@@ -18,6 +18,7 @@ ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--det", type=int, default=256)
 ap.add_argument("--cases", default="pert32,pert32aux")
 ap.add_argument("--build-only", action="store_true")
+ap.add_argument("--variants", default="-2", help="bricks_fwd.hip variants (see tools/brick_bench.py)")
 a = ap.parse_args()
 
 import tools.explib  # noqa: E402
@@ -36,7 +37,12 @@ drr = DRR(make_subject(noise_volume(D, 0)), sdd=1020.0, height=H, delx=2.4 * (25
 V = drr.density
 NAMES = ["barrier+prefix", "unit pull", "phase A", "batch pop", "ray loads", "setup", "walk", "deliver",
          "barrier wait", "#batches", "#wave-steps", "#units", "#hits"]
-for case in a.cases.split(","):
+import itertools  # noqa: E402
+
+for var, case in itertools.product(a.variants.split(","), a.cases.split(",")):
+    var = int(var)
+    lib.cdll.ddrr_set_brick_variant(var)
+    storage = "q16" if var in (1, 2, 4, 5, 6) else "f32"
     aux = case.endswith("aux")
     name = case[:-3] if aux else case
     if name.startswith("base"):
@@ -45,7 +51,7 @@ for case in a.cases.split(","):
         s, t, L = (x.expand(B, *x.shape[1:]).contiguous() for x in one)
     else:
         s, t, L = rays(drr, *poses(int(name[4:]), 2, dev))
-    fn = lambda: ops.siddon_forward_bricks(V, s, t, L, (H, H), want_aux=aux)  # noqa: E731
+    fn = lambda: ops.siddon_forward_bricks(V, s, t, L, (H, H), want_aux=aux, storage=storage)  # noqa: E731
     med, best = timeit(fn)
     lib.cdll.ddrr_brick_profile_reset()
     fn()
@@ -54,7 +60,8 @@ for case in a.cases.split(","):
     lib.cdll.ddrr_brick_profile_read(buf)
     v = list(buf)
     tot = sum(v[:9]) + sum(v[13:16])
-    print(f"## {case}: kernel {med:.3f} ms (profiling build); {tot / 4096:.0f} ticks per wave")
+    waves = 4096  # (every variant runs 4096 waves: 256 x 16 or 512 x 8)
+    print(f"## variant {var} {case}: kernel {med:.3f} ms (profiling build); {tot / 4096:.0f} ticks per wave")
     for i, n in zip((13, 14, 15), ("  claim", "  rows/issue", "  LDS store")):
         print(f"  {n:14s} {100 * v[i] / tot:5.1f} %")
     for i, n in enumerate(NAMES):
