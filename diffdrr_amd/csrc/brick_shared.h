@@ -174,6 +174,7 @@ int launch_fwd_bricks(int variant, float *brick_ranges, int ranges_valid, const 
 extern float g_brick_t1, g_brick_t2;
 extern int g_brick_dbg;
 extern int g_brick_variant;
+extern float g_brick_sq_width;
 #else
 constexpr float g_brick_t1 = 18.f, g_brick_t2 = 40.f;
 constexpr int g_brick_dbg = 0;

@@ -718,6 +718,7 @@ namespace ddrr_brick {
 float g_brick_t1 = 18.f, g_brick_t2 = 40.f;
 int g_brick_dbg = 0;
 int g_brick_variant = -2;
+float g_brick_sq_width = 8.f;
 #endif
 #if defined(DDRR_BRICK_PROFILE)
 unsigned long long *g_brick_prof = nullptr;  // 16 device counters, see BrickProf

@@ -184,6 +184,68 @@ __device__ __forceinline__ void fwd_item(const BrickArgs &p, unsigned lds_base,
     DDRR_PROF(PROF_DELIVER);
 }
 
+// Stage brick `brick_id` (voxels `box`) in LDS: a thread owns NQ quads of 4 voxels along z, PER
+// of them in flight at a time (all of a round's loads are issued before its first LDS store).
+// 16-bit bricks: `range` / `brick_empty` from the ranges brick_range_kernel left; fp32 bricks:
+// counter[2] is raised if any staged voxel is non-zero (read after the next barrier).
+template <class C>
+__device__ __forceinline__ void fwd_stage_brick(const BrickArgs &p, unsigned char *brick,
+                                                const Box &box, int brick_id, int tid,
+                                                Q16Range &range, bool &brick_empty, int *counter) {
+    constexpr int QZ = C::BZ / 4, NQ = C::BX * C::BY * QZ / C::THREADS;
+    constexpr int PER = NQ > 8 ? 8 : NQ;
+    static_assert(NQ % PER == 0, "staging rounds");
+    constexpr int ROWS_PER_PASS = C::THREADS / QZ;
+    const int qz4 = (tid % QZ) * 4, row0 = tid / QZ;
+    const int z = box.lo[2] + qz4;
+    const bool in_z = z + 4 <= box.hi[2];  // (z and D.z are multiples of 4)
+    if (C::Q16) {
+        const float lo = p.ranges[2 * brick_id], hi = p.ranges[2 * brick_id + 1];
+        range = q16_range(lo, hi);
+        brick_empty = lo == 0.f && hi == 0.f;
+    }
+    unsigned nz = 0u;
+#pragma unroll
+    for (int h0 = 0; h0 < NQ; h0 += PER) {
+        float4 q[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int row = row0 + (h0 + i) * ROWS_PER_PASS;
+            const int lx = row / C::BY, ly = row - lx * C::BY;
+            const int x = box.lo[0] + lx, y = box.lo[1] + ly;
+            // clamped (always readable) address; what lies outside is zeroed below
+            const int xc = x < p.D.x ? x : p.D.x - 1, yc = y < p.D.y ? y : p.D.y - 1;
+            const long at = ((long)xc * p.D.y + yc) * p.D.z + (in_z ? z : 0);
+            q[i] = *reinterpret_cast<const float4 *>(p.vol + at);
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int row = row0 + (h0 + i) * ROWS_PER_PASS;
+            const int lx = row / C::BY, ly = row - lx * C::BY;
+            const bool in = in_z && box.lo[0] + lx < box.hi[0] && box.lo[1] + ly < box.hi[1];
+            if (!in) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (C::Q16) {
+                unsigned short *d =
+                    reinterpret_cast<unsigned short *>(brick + lx * C::SX + ly * C::SY + qz4 * 2);
+                d[0] = (unsigned short)q16_encode(q[i].x, range);
+                d[1] = (unsigned short)q16_encode(q[i].y, range);
+                d[2] = (unsigned short)q16_encode(q[i].z, range);
+                d[3] = (unsigned short)q16_encode(q[i].w, range);
+            } else {
+                float *df = reinterpret_cast<float *>(brick + lx * C::SX + ly * C::SY + qz4 * 4);
+                df[0] = q[i].x;
+                df[1] = q[i].y;
+                df[2] = q[i].z;
+                df[3] = q[i].w;
+                nz |= __float_as_uint(q[i].x) | __float_as_uint(q[i].y) |
+                      __float_as_uint(q[i].z) | __float_as_uint(q[i].w);
+            }
+        }
+    }
+    // Empty space: a brick of zeros adds nothing to any integral or record
+    if (!C::Q16 && (nz & 0x7fffffffu) != 0u) counter[2] = 1;  // (cleared with the claim)
+}
+
 template <bool AUX, class C>
 __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict__ aux) {
@@ -250,64 +312,7 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
             }
             if (tid == 0) counter[0] = 0;
             DDRR_PROF(PROF_ROWS);
-            if (ch == 0) {
-                // Stage the brick: a thread owns NQ quads of 4 voxels along z, PER of them in
-                // flight at a time (all of a round's loads are issued before its first LDS store).
-                constexpr int QZ = C::BZ / 4, NQ = C::BX * C::BY * QZ / C::THREADS;
-                constexpr int PER = NQ > 8 ? 8 : NQ;
-                static_assert(NQ % PER == 0, "staging rounds");
-                constexpr int ROWS_PER_PASS = C::THREADS / QZ;
-                const int qz4 = (tid % QZ) * 4, row0 = tid / QZ;
-                const int z = box.lo[2] + qz4;
-                const bool in_z = z + 4 <= box.hi[2];  // (z and D.z are multiples of 4)
-                if (C::Q16) {
-                    // the brick's value range: found by brick_range_kernel before this launch
-                    const float lo = p.ranges[2 * brick_id], hi = p.ranges[2 * brick_id + 1];
-                    range = q16_range(lo, hi);
-                    brick_empty = lo == 0.f && hi == 0.f;
-                }
-                unsigned nz = 0u;
-#pragma unroll
-                for (int h0 = 0; h0 < NQ; h0 += PER) {
-                    float4 q[PER];
-#pragma unroll
-                    for (int i = 0; i < PER; ++i) {
-                        const int row = row0 + (h0 + i) * ROWS_PER_PASS;
-                        const int lx = row / C::BY, ly = row - lx * C::BY;
-                        const int x = box.lo[0] + lx, y = box.lo[1] + ly;
-                        // clamped (always readable) address; what lies outside is zeroed below
-                        const int xc = x < p.D.x ? x : p.D.x - 1, yc = y < p.D.y ? y : p.D.y - 1;
-                        const long at = ((long)xc * p.D.y + yc) * p.D.z + (in_z ? z : 0);
-                        q[i] = *reinterpret_cast<const float4 *>(p.vol + at);
-                    }
-#pragma unroll
-                    for (int i = 0; i < PER; ++i) {
-                        const int row = row0 + (h0 + i) * ROWS_PER_PASS;
-                        const int lx = row / C::BY, ly = row - lx * C::BY;
-                        const bool in = in_z && box.lo[0] + lx < box.hi[0] && box.lo[1] + ly < box.hi[1];
-                        if (!in) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (C::Q16) {
-                            unsigned short *d = reinterpret_cast<unsigned short *>(
-                                brick + lx * C::SX + ly * C::SY + qz4 * 2);
-                            d[0] = (unsigned short)q16_encode(q[i].x, range);
-                            d[1] = (unsigned short)q16_encode(q[i].y, range);
-                            d[2] = (unsigned short)q16_encode(q[i].z, range);
-                            d[3] = (unsigned short)q16_encode(q[i].w, range);
-                        } else {
-                            float *df = reinterpret_cast<float *>(brick + lx * C::SX + ly * C::SY +
-                                                                  qz4 * 4);
-                            df[0] = q[i].x;
-                            df[1] = q[i].y;
-                            df[2] = q[i].z;
-                            df[3] = q[i].w;
-                            nz |= __float_as_uint(q[i].x) | __float_as_uint(q[i].y) |
-                                  __float_as_uint(q[i].z) | __float_as_uint(q[i].w);
-                        }
-                    }
-                }
-                // Empty space: a brick of zeros adds nothing to any integral or record
-                if (!C::Q16 && (nz & 0x7fffffffu) != 0u) counter[2] = 1;  // (cleared with the claim)
-            }
+            if (ch == 0) fwd_stage_brick<C>(p, brick, box, brick_id, tid, range, brick_empty, counter);
             DDRR_PROF(PROF_STORE);
             __syncthreads();
             if (!C::Q16 && ch == 0) brick_empty = counter[2] == 0;
@@ -416,6 +421,286 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
 #endif
 }
 
+// ------------------------------------------------------------------ shared length-class rings
+// The same kernel with the hit queues SHARED by the workgroup: NCLS length classes (equal
+// width in estimated crossings) instead of 3, each a ring of CAP entries in LDS with two
+// counters: tail[c], tickets handed out, and head[c], batches of 64 taken -- in order.
+//   * A wave's push reserves the tickets of all its classes with one LDS atomic (lane c adds
+//     the unit's count of class c to tail[c]; with the float record the first hit of each run of
+//     8 pixels reserves for its run, so that runs stay together) and stores ticket t's entry in
+//     slot t mod CAP -- once head[c] says the slot's previous ticket, t - CAP, has been taken.
+//   * The push whose reservation completes a batch (tickets 64 k .. 64 k + 63) owns it: when
+//     head[c] == k it waits for the 64 slots to be written, takes them (reads, marks EMPTY),
+//     sets head[c] = k + 1 and walks them.  A push takes ALL the batches it owns before it walks
+//     the first one, so that nobody waits for a walk.
+//   * Every wait is for a push that reserved EARLIER (a writer for the owner of a batch CAP
+//     tickets back; an owner for the writers of its batch and the owner of the batch before):
+//     the oldest unfinished push never waits, so there is no cycle, whatever CAP.  The spins are
+//     bounded all the same (kSqSpinCap): a logic error ends in a NaN image, not a hang.
+//   * When the units of the last chunk are gone the waves meet at a barrier; what is left (< 64
+//     per class) is handed out 64 at a time, longest class first.
+// With 16 waves feeding one set of rings a class fills 16x faster than a per-wave queue: twelve
+// classes cost < 12 partial batches per brick (48 with the 3 per-wave queues), and a batch
+// holds rays within one class width of each other.
+constexpr unsigned kSqEmpty = 0xffffffffu;
+constexpr int kSqSpinCap = 1 << 22;
+
+template <int NCLS_, class C>
+struct SqCfg {
+    static constexpr int NCLS = NCLS_;
+    // ring entries per class: the power of two that fits the per-wave queues' LDS
+    static constexpr int ROOM = C::WAVES * kBuckets * kQueueCap / NCLS;
+    static constexpr int CAP = ROOM >= 1024 ? 1024 : (ROOM >= 512 ? 512 : (ROOM >= 256 ? 256 : 128));
+    static_assert(ROOM >= 128, "ring too small");
+    // (the row table and the control words lie behind the rings exactly as behind the queues)
+    static constexpr int LDS = C::LDS + 64 + 8 * NCLS;
+};
+
+template <bool AUX, class C, int NCLS>
+__global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void
+siddon_fwd_brick_sq_kernel(BrickArgs p, float *__restrict__ out, float *__restrict__ aux) {
+    using S = SqCfg<NCLS, C>;
+    constexpr int CAP = S::CAP;
+    static_assert(NCLS * 63 <= 64 * C::WAVES, "the leftovers of a brick: one batch per wave at most");
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned char *brick = smem_raw;
+    unsigned *ring = reinterpret_cast<unsigned *>(smem_raw + C::BRICK_BYTES);  // [NCLS][CAP]
+    FwdRow *rows = reinterpret_cast<FwdRow *>(ring + C::WAVES * kBuckets * kQueueCap);
+    int *counter = reinterpret_cast<int *>(rows + C::CHUNK);  // [0] unit, [1] brick, [2] non-zero
+    volatile int *tail = counter + 4;                         // [NCLS] tickets handed out
+    volatile int *head = tail + NCLS;                         // [NCLS] batches taken (in order)
+    volatile int *fault = head + NCLS;                        // a spin ran into its bound
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nbx = (p.D.x + C::BX - 1) / C::BX, nby = (p.D.y + C::BY - 1) / C::BY;
+    const int nbz = (p.D.z + C::BZ - 1) / C::BZ;
+    const int n_bricks = nbx * nby * nbz;
+    const int N = p.det_h * p.det_w;
+    const unsigned pix_mask = (1u << p.pix_bits) - 1u;
+    const int n_chunks = (p.B + C::CHUNK - 1) / C::CHUNK;
+    const int chunk = (p.B + n_chunks - 1) / n_chunks;
+    const unsigned lds_base = LdsAbsFetch::base_of(reinterpret_cast<const float *>(brick));
+    const bool GROUPED = AUX && p.rec_q == 0.f && !(p.dbg & 8);
+    const float inv_width = 1.0f / p.t1;  // class = estimated crossings / width
+
+    for (int i = tid; i < NCLS * CAP; i += C::THREADS) ring[i] = kSqEmpty;
+    if (tid == 0) *fault = 0;
+
+    BrickProf prof;
+#if defined(DDRR_BRICK_PROFILE)
+    prof.start();
+#endif
+    // take the 64 entries of batch k of class c (lane l: ticket 64 k + l); in order
+    auto take_batch = [&](int c, int k) -> unsigned {
+        int spin = 0;
+        while (head[c] != k && ++spin < kSqSpinCap) {
+        }
+        volatile unsigned *slot = ring + c * CAP + ((64 * k + lane) & (CAP - 1));
+        unsigned e = *slot;
+        while (__ballot(e == kSqEmpty) && ++spin < kSqSpinCap) e = *slot;
+        if (spin >= kSqSpinCap) *fault = 1;
+        *slot = kSqEmpty;
+        wave_fence();
+        if (lane == 0) head[c] = k + 1;  // (LDS operations of a wave are performed in order)
+        return e;
+    };
+    auto walk_entries = [&](unsigned e, const StepGeom &SG, const Q16Range &range) {
+        DDRR_PROF(PROF_POP);
+        DDRR_PROF_COUNT(PROF_N_BATCH, 1);
+        fwd_item<AUX, C>(p, lds_base, SG, range, e != kSqEmpty, e >> p.pix_bits, e & pix_mask, out,
+                         aux, prof);
+    };
+
+    for (;;) {
+        __syncthreads();  // every wave is done with the previous brick's LDS
+        DDRR_PROF(PROF_BARRIER);
+        if (tid == 0) {
+            counter[1] = atomicAdd(p.work, 1);
+            counter[2] = 0;
+        }
+        if (tid < NCLS) {
+            tail[tid] = 0;
+            head[tid] = 0;
+        }
+        __syncthreads();
+        const int brick_id = counter[1];
+        if (brick_id >= n_bricks) break;
+        DDRR_PROF(PROF_CLAIM);
+        const Box box = cfg_brick_box<C>(p.D, nby, nbz, brick_id);
+        const BoxF cells = boxf(box);
+        StepGeom SG;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            SG.lof[a] = (float)box.lo[a];
+            SG.hif[a] = (float)box.hi[a];
+        }
+        SG.strideb[0] = bits_as_float((unsigned)C::SX);
+        SG.strideb[1] = bits_as_float((unsigned)C::SY);
+        SG.strideb[2] = bits_as_float((unsigned)C::ES);
+        bool brick_empty = false;
+        Q16Range range = {0.f, 0.f, 0.f};
+
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const int b0 = ch * chunk;
+            const int nb = p.B - b0 < chunk ? p.B - b0 : chunk;
+            const bool last_chunk = ch == n_chunks - 1;
+            if (ch > 0) __syncthreads();  // previous chunk's table no longer in use
+            if (tid < nb) {
+                const PoseGrid pg = pose_grid(p.source + (long)(b0 + tid) * 3,
+                                              p.target + (long)(b0 + tid) * N * 3, p.det_h, p.det_w);
+                PixBox pb = project_brick_grid(pg, p.det_h, p.det_w, cells, p.shift);
+                if (GROUPED) pb = align_pixbox_rows(pb, p.det_w);
+                rows[tid] = fwd_row(brick_row(pg, pb, cells, p.shift, p.eps, 0.f));
+            }
+            if (tid == 0) counter[0] = 0;
+            DDRR_PROF(PROF_ROWS);
+            if (ch == 0) fwd_stage_brick<C>(p, brick, box, brick_id, tid, range, brick_empty, counter);
+            DDRR_PROF(PROF_STORE);
+            __syncthreads();
+            if (!C::Q16 && ch == 0) brick_empty = counter[2] == 0;
+            int incl = lane < nb ? (rows[lane].count + 63) >> 6 : 0;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                const int up = __shfl_up(incl, o, 64);
+                incl += lane >= o ? up : 0;
+            }
+            const int units = brick_empty ? 0 : __builtin_amdgcn_readlane(incl, 31);
+            int cur = 0, cur_lo = 0, cur_hi = __builtin_amdgcn_readlane(incl, 0);
+            DDRR_PROF(PROF_STAGE);
+            for (;;) {
+                int u = 0;
+                if (lane == 0) u = atomicAdd(&counter[0], 1);
+                u = uni(u);
+                if (u >= units) break;  // no unit left in this chunk
+                while (u >= cur_hi) {   // units arrive in increasing order: forward cursor
+                    ++cur;
+                    cur_lo = cur_hi;
+                    cur_hi = __builtin_amdgcn_readlane(incl, uni(cur));
+                }
+                const BrickRow r = brick_row_of(rows[cur]);
+                DDRR_PROF(PROF_PULL);
+                DDRR_PROF_COUNT(PROF_N_UNITS, 1);
+                const int local = (u - cur_lo) * 64 + lane;
+                const bool valid = local < uni(r.count);
+                int pix = 0;
+                float n_est = 0.f;
+                const bool hit = valid && brick_candidate(r, local, p.det_w, pix, n_est);
+                float n_grp = hit ? n_est : 0.f;
+                if (GROUPED) {  // float record: classes per run of 8 adjacent pixels (bricks.hip)
+                    n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                        0, __builtin_bit_cast(int, n_grp), 0xB1, 0xf, 0xf, true)));   // lane ^ 1
+                    n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                        0, __builtin_bit_cast(int, n_grp), 0x4E, 0xf, 0xf, true)));   // lane ^ 2
+                    n_grp = fmaxf(n_grp, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                        0, __builtin_bit_cast(int, n_grp), 0x141, 0xf, 0xf, true)));  // 7 - lane
+                }
+                int cls = (int)(n_grp * inv_width);
+                cls = cls < NCLS - 1 ? cls : NCLS - 1;
+                cls = cls > 0 ? cls : 0;
+                const unsigned long long hits = __ballot(hit);
+                DDRR_PROF_COUNT(PROF_N_HITS, __popcll(hits));
+                // Tickets: `own_cls` / `own_batch` on the lanes whose reservation completed a batch
+                int ticket = 0, own_cls = 0, own_batch = 0;
+                bool owns = false;
+                if (!GROUPED) {
+                    // per class present in the unit: its hits' ranks, its count on lane c
+                    int cnt_mine = 0, rank = 0;
+                    unsigned long long rem = hits;
+                    while (rem) {
+                        const int c = __builtin_amdgcn_readlane(cls, __ffsll((long long)rem) - 1);
+                        const unsigned long long m = __ballot(hit && cls == c);
+                        cnt_mine = lane == c ? (int)__popcll(m) : cnt_mine;
+                        rank = cls == c ? lane_rank(m) : rank;
+                        rem &= ~m;
+                    }
+                    int first = 0;  // one LDS atomic reserves for all classes: lane c, class c
+                    if (lane < NCLS && cnt_mine > 0) first = atomicAdd((int *)&tail[lane], cnt_mine);
+                    owns = lane < NCLS && cnt_mine > 0 && ((first + cnt_mine) >> 6) != (first >> 6);
+                    own_cls = lane;
+                    own_batch = first >> 6;
+                    ticket = __shfl(first, cls, 64) + rank;
+                } else {
+                    // float record: the hits of a run of 8 pixels share a class and stay together
+                    const unsigned half = lane < 32 ? (unsigned)hits : (unsigned)(hits >> 32);
+                    const unsigned grp = (half >> (lane & 24)) & 0xffu;  // hits of my run of 8
+                    const int n_run = __popc(grp), before = __popc(grp & ((1u << (lane & 7)) - 1u));
+                    const bool leader = hit && before == 0;
+                    int first = 0;
+                    if (leader) first = atomicAdd((int *)&tail[cls], n_run);
+                    owns = leader && ((first + n_run) >> 6) != (first >> 6);
+                    own_cls = cls;
+                    own_batch = first >> 6;
+                    const int lead_lane = (lane & ~7) + (__ffs(grp | 0x100u) - 1);
+                    ticket = __shfl(first, lead_lane & 63, 64) + before;
+                }
+                if (hit) {
+                    // slot t mod CAP is free once batch (t - CAP) / 64 has been taken
+                    const int need = (ticket >> 6) - CAP / 64 + 1;
+                    int spin = 0;
+                    while (head[cls] < need && ++spin < kSqSpinCap) {
+                    }
+                    if (spin >= kSqSpinCap) *fault = 1;
+                    const_cast<volatile unsigned *>(ring)[cls * CAP + (ticket & (CAP - 1))] =
+                        ((unsigned)(b0 + cur) << p.pix_bits) | (unsigned)pix;
+                }
+                wave_fence();
+                DDRR_PROF(PROF_PHASE_A);
+                // the batches this push completed are this wave's: take them all, then walk them
+                unsigned long long own = __ballot(owns);
+                while (own) {
+                    unsigned e[4];
+                    int n_own = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        e[j] = kSqEmpty;
+                        if (own) {
+                            const int l = __ffsll((long long)own) - 1;
+                            own &= own - 1;
+                            e[j] = take_batch(__builtin_amdgcn_readlane(own_cls, l),
+                                              __builtin_amdgcn_readlane(own_batch, l));
+                            n_own = j + 1;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < n_own) walk_entries(e[j], SG, range);
+                }
+            }
+            if (!last_chunk) continue;
+            // every push of this brick has been made: hand out what is left, longest class first
+            __syncthreads();
+            DDRR_PROF(PROF_BARRIER);
+            int left_before = 0;  // leftovers of the classes above c
+            unsigned e = kSqEmpty;
+            const int pos = 64 * wave + lane;
+#pragma unroll 1
+            for (int c = NCLS - 1; c >= 0; --c) {
+                const int tl = tail[c], left = tl & 63;  // (every complete batch has been taken)
+                const int i = pos - left_before;
+                if (i >= 0 && i < left) {
+                    unsigned *slot = ring + c * CAP + ((tl - left + i) & (CAP - 1));
+                    e = *slot;
+                    *slot = kSqEmpty;
+                }
+                left_before += left;
+            }
+            if (64 * wave < left_before) {
+                DDRR_PROF(PROF_POP);
+                DDRR_PROF_COUNT(PROF_N_BATCH, 1);
+                fwd_item<AUX, C>(p, lds_base, SG, range, e != kSqEmpty, e >> p.pix_bits, e & pix_mask,
+                                 out, aux, prof);
+            }
+        }
+    }
+#if defined(DDRR_BRICK_PROFILE)
+    DDRR_PROF(PROF_BARRIER);
+    if (lane == 0 && p.prof)
+        for (int i = 0; i < 16; ++i) atomicAdd(p.prof + i, prof.t[i]);
+#endif
+    // (a spin that ran into its bound: poison the result instead of returning a wrong image)
+    if (tid == 0 && *fault) (AUX ? aux : out)[0] = NAN;
+}
+
 // (vmin, vmax) of every brick of a BX x BY x BZ grid, the input of the 16-bit staging
 // (q16_range).  One workgroup per brick; a brick holding a NaN reports vmax = NaN.
 __global__ __launch_bounds__(256) void brick_range_kernel(const float *__restrict__ vol, Dims D,
@@ -499,6 +784,41 @@ int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t
     return 0;
 }
 
+template <bool AUX, class C, int NCLS>
+int launch_sq(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t st) {
+    using S = SqCfg<NCLS, C>;
+    static_assert(S::LDS <= C::LDS_BUDGET, "LDS budget");
+    constexpr int kMaxDev = 64;
+    static std::mutex mu;
+    static bool attr_set[kMaxDev] = {false};
+    hipError_t e;
+    int dev = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return fail_hip(e, "hipGetDevice");
+    if (dev < 0 || dev >= kMaxDev) return fail(-1, "device index out of range");
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!attr_set[dev]) {
+            if ((e = hipFuncSetAttribute(
+                     reinterpret_cast<const void *>(&siddon_fwd_brick_sq_kernel<AUX, C, NCLS>),
+                     hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS)) != hipSuccess)
+                return fail_hip(e, "hipFuncSetAttribute");
+            attr_set[dev] = true;
+        }
+    }
+    const int nbx = (p.D.x + C::BX - 1) / C::BX, nby = (p.D.y + C::BY - 1) / C::BY;
+    const int nbz = (p.D.z + C::BZ - 1) / C::BZ;
+    const int n_bricks = nbx * nby * nbz, slots = n_cu * C::WGS_PER_CU;
+    if (C::Q16) {
+        if (!p.ranges) return fail(-1, "DDRR_BRICKS_Q16 needs the brick_ranges workspace");
+        if (!p.ranges_valid)
+            hipLaunchKernelGGL(brick_range_kernel, dim3(n_bricks), dim3(256), 0, st, p.vol, p.D, C::BX,
+                               C::BY, C::BZ, nby, nbz, const_cast<float *>(p.ranges));
+    }
+    const dim3 grid(n_bricks < slots ? n_bricks : slots), block(C::THREADS);
+    hipLaunchKernelGGL((siddon_fwd_brick_sq_kernel<AUX, C, NCLS>), grid, block, S::LDS, st, p, out, aux);
+    return 0;
+}
+
 // brick variants (DDRR_BRICKS_* of include/diffdrr_hip.h; the others exist in tools builds)
 using CfgF32 = FwdCfg<32, 32, 32, 1024, false>;        // 32^3 fp32, one workgroup per CU
 using CfgQ16x2 = FwdCfg<32, 32, 32, 512, true>;        // 32^3 16-bit, two workgroups per CU
@@ -565,6 +885,9 @@ int launch_fwd_bricks(int variant, float *brick_ranges, int ranges_valid, const 
 #if defined(DDRR_BRICK_PROFILE)
     p.prof = g_brick_prof;
 #endif
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+    if (variant >= 16) p.t1 = g_brick_sq_width;  // shared rings: t1 = class width
+#endif
     int n_cu = 0;
     if (int rc = brick_launch_resources(st, n_cu, p.work)) return rc;
     int rc = 0;
@@ -582,6 +905,16 @@ int launch_fwd_bricks(int variant, float *brick_ranges, int ranges_valid, const 
         case 7: rc = DDRR_LAUNCH(CfgF32Y64); break;
         case 8: rc = DDRR_LAUNCH(CfgF32X64); break;
         case 9: rc = DDRR_LAUNCH(CfgF32Z64); break;
+        // workgroup-shared length-class rings: 16 + v: 12 classes, 32 + v: 8 classes
+#define DDRR_LAUNCH_SQ(C, K) (aux ? launch_sq<true, C, K>(p, n_cu, out, aux, st) \
+                                  : launch_sq<false, C, K>(p, n_cu, out, aux, st))
+        case 16: rc = DDRR_LAUNCH_SQ(CfgF32, 12); break;
+        case 18: rc = DDRR_LAUNCH_SQ(CfgQ16x1, 12); break;
+        case 20: rc = DDRR_LAUNCH_SQ(CfgQ16X64, 12); break;
+        case 21: rc = DDRR_LAUNCH_SQ(CfgQ16Z64, 12); break;
+        case 32: rc = DDRR_LAUNCH_SQ(CfgF32, 8); break;
+        case 36: rc = DDRR_LAUNCH_SQ(CfgQ16X64, 8); break;
+#undef DDRR_LAUNCH_SQ
 #endif
         default: return fail(-1, "unknown brick variant");
     }
@@ -595,6 +928,10 @@ int launch_fwd_bricks(int variant, float *brick_ranges, int ranges_valid, const 
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
 extern "C" int ddrr_set_brick_variant(int v) {
     ddrr_brick::g_brick_variant = v;
+    return 0;
+}
+extern "C" int ddrr_set_brick_sq_width(float w) {
+    ddrr_brick::g_brick_sq_width = w;
     return 0;
 }
 #endif

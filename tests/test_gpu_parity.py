@@ -909,7 +909,7 @@ def test_brick_kernels_many_poses_multi_chunk(gpu):
     ref, aux_ref, _ = ops.siddon_forward(V, s, t, L, want_aux=True)
     out, aux = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True)
     assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5
-    assert torch.allclose(aux[0], aux_ref[..., 0], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(ops.record_planes(aux, B, H * W)[0], aux_ref[..., 0], rtol=1e-4, atol=1e-5)
     go = torch.rand(B, H * W, device=gpu, generator=torch.Generator(gpu).manual_seed(1))
     gref = ops.siddon_backward_volume(V, s, t, L, go)
     gout = ops.siddon_backward_volume_bricks(V.shape, s, t, L, go, (H, W))

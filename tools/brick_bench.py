@@ -21,6 +21,7 @@ ap.add_argument("--layouts", default="33:1057")
 ap.add_argument("--cases", default="pert32,pert32aux,base32,pert1,pert8,pert128")
 ap.add_argument("--dbg", default="0")
 ap.add_argument("--classes", default="18:40")
+ap.add_argument("--sqw", default="8", help="class width(s) of the shared rings (variants >= 16)")
 ap.add_argument("--variants", default="-2",
                 help="bricks_fwd.hip variants: -2 product default, -1 the general 32^3 fp32 kernel of "
                      "bricks.hip, 0 32^3 fp32, 1 32^3 16-bit x 2 workgroups per CU, 2 32^3 16-bit x 1, "
@@ -45,17 +46,21 @@ for case in a.cases.split(","):
         s, t, L = rays(drr, *poses(int(name[4:]), 2, dev))
     sets[case] = (s, t, L, aux)
 import itertools
-for lay, dbg, cl, var in itertools.product(a.layouts.split(","), a.dbg.split(","), a.classes.split(","),
-                                           a.variants.split(",")):
+import ctypes
+for lay, dbg, cl, var, sqw in itertools.product(a.layouts.split(","), a.dbg.split(","), a.classes.split(","),
+                                                a.variants.split(","), a.sqw.split(",")):
     sy, sx = (int(v) for v in lay.split(":"))
     var = int(var)
+    if var < 16 and sqw != a.sqw.split(",")[0]:
+        continue
     lib.cdll.ddrr_set_brick_variant(var)
-    storage = "q16" if var in (1, 2, 4, 5, 6) else "f32"
+    lib.cdll.ddrr_set_brick_sq_width(ctypes.c_float(float(sqw)))
+    storage = "q16" if var >= 0 and var % 16 in (1, 2, 4, 5, 6) else "f32"
     lib.cdll.ddrr_set_brick_debug(int(dbg))
     t1, t2 = (float(v) for v in cl.split(":"))
     import ctypes
     lib.cdll.ddrr_set_brick_classes(ctypes.c_float(t1), ctypes.c_float(t2))
-    lay = f"{lay} dbg{dbg} cls{cl} var{var:2d}"
+    lay = f"dbg{dbg} cls{cl if var < 16 else sqw} var{var:2d}"
     rc = lib.cdll.ddrr_set_brick_layout(sy, sx)
     if rc != 0:
         print(f"layout {lay}: rejected")
@@ -71,6 +76,14 @@ for lay, dbg, cl, var in itertools.product(a.layouts.split(","), a.dbg.split(","
         ref = ops.siddon_forward(V, s, t, L, det=(H, H))[0]
         out = ops.siddon_forward_bricks(V, s, t, L, (H, H), want_aux=aux, storage=storage)[0]
         err = ((out - ref).abs().max() / ref.abs().max()).item()
-        print(f"layout {lay:32s} {case:12s} B {B:4d} vox/ray {nvox / (B * H * H):6.1f}  {med:8.3f} ms "
+        if aux:  # the record: per-pose sums of the target gradients against the generic walk's
+            _, gaux, _ = ops.siddon_forward(V, s[:4], t[:4], L[:4], want_aux=True, det=(H, H))
+            _, baux = ops.siddon_forward_bricks(V, s[:4], t[:4], L[:4], (H, H), want_aux=True, storage=storage)
+            go = torch.ones_like(L[:4])
+            g1 = ops.siddon_backward_rays(gaux, go, s[:4], t[:4], L[:4])[1].double().sum(1)
+            g2 = ops.siddon_backward_rays(baux, go, s[:4], t[:4], L[:4])[1].double().sum(1)
+            err = max(err, -((g1 - g2).abs().max() / g1.abs().max()).item())  # (negative: gradient error)
+            lay = lay + f" gerr {((g1 - g2).abs().max() / g1.abs().max()).item():.1e}"
+        print(f"{lay:40s} {case:12s} B {B:4d} vox/ray {nvox / (B * H * H):6.1f}  {med:8.3f} ms "
               f"(best {best:7.3f})  {B / med * 1e3:9.0f} DRR/s  {alg / med / 1e6:8.1f} GB/s alg "
               f"({alg / med / 1e6 / 8000 * 100:5.1f}% of 8 TB/s)  err vs generic {err:.1e}", flush=True)
