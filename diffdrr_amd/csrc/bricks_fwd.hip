@@ -8,13 +8,16 @@
 // queues and walked from LDS 64 at a time (phase B); partial integrals (and the backward
 // record) are combined with fp32 atomics.  What is configurable:
 //   * Q16: the brick is staged as 16-bit block-quantised voxels (brick_step.h: one (vmin, step)
-//     pair per brick, found while staging; the walk reads them as denormal floats at no extra
-//     instruction).  A 32^3 brick then takes 66 KiB instead of 132, so TWO 512-thread
-//     workgroups share a CU and one's staging / end-of-brick barrier overlaps the other's walk
-//     -- or one workgroup holds a brick of twice the volume (longer visits per hit);
-//   * BX x BY x BZ: the brick's extent (anisotropic bricks give longer visits to rays along
-//     the long axis);
-//   * THREADS: 1024 (one workgroup per CU) or 512 (two).
+//     pair per brick, from a pass over the volume that the caller caches; the walk reads them
+//     as denormal floats at no extra instruction).  A brick of TWICE the volume then fits the
+//     LDS of a CU: 32 x 32 x 64 voxels in 130 KiB, 17 % fewer (ray, brick) pairs, i.e. less of
+//     the per-hit work (exact clip, ray loads, queueing, record atomics) per voxel visited:
+//     forward 1.30 -> 1.21 ms, forward + record 1.82 -> 1.70 ms at 512^3 / 32 poses;
+//   * BX x BY x BZ, THREADS: brick extent and workgroup size.  Measured and not adopted
+//     (profiles/r03, tools builds keep them as variants): two 512-thread workgroups per CU on
+//     32^3 16-bit bricks or on 32 x 32 x 16 fp32 half bricks (their barrier waits halve, their
+//     staging time doubles: no gain), anisotropic fp32 bricks 16 x 64 x 32 ... (3-8 % slower on
+//     mixed poses), workgroup-shared rings of 12 length classes (see below).
 // Reference: diffdrr/renderers.py:34-76, 94-113 (Siddon.forward, mask=None, sum, nearest).
 #include "runtime.h"
 
@@ -820,13 +823,13 @@ int launch_sq(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t 
 }
 
 // brick variants (DDRR_BRICKS_* of include/diffdrr_hip.h; the others exist in tools builds)
-using CfgF32 = FwdCfg<32, 32, 32, 1024, false>;        // 32^3 fp32, one workgroup per CU
-using CfgQ16x2 = FwdCfg<32, 32, 32, 512, true>;        // 32^3 16-bit, two workgroups per CU
+using CfgF32 = FwdCfg<32, 32, 32, 1024, false>;        // DDRR_BRICKS_F32: 32^3 fp32
+using CfgQ16Z64 = FwdCfg<32, 32, 64, 1024, true>;      // DDRR_BRICKS_Q16: 32x32x64 16-bit
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+using CfgQ16x2 = FwdCfg<32, 32, 32, 512, true>;        // 32^3 16-bit, two workgroups per CU
 using CfgQ16x1 = FwdCfg<32, 32, 32, 1024, true>;       // 32^3 16-bit, one workgroup per CU
 using CfgF32Half = FwdCfg<32, 32, 16, 512, false, 0>;  // 32x32x16 fp32 halves, two workgroups
 using CfgQ16X64 = FwdCfg<64, 32, 32, 1024, true>;      // double bricks, 16-bit
-using CfgQ16Z64 = FwdCfg<32, 32, 64, 1024, true>;
 using CfgQ16Y64 = FwdCfg<32, 64, 32, 1024, true>;
 using CfgF32Y64 = FwdCfg<16, 64, 32, 1024, false>;     // anisotropic fp32 bricks
 using CfgF32X64 = FwdCfg<64, 16, 32, 1024, false>;
@@ -893,14 +896,20 @@ int launch_fwd_bricks(int variant, float *brick_ranges, int ranges_valid, const 
     int rc = 0;
 #define DDRR_LAUNCH(C) (aux ? launch_cfg<true, C>(p, n_cu, out, aux, st) \
                             : launch_cfg<false, C>(p, n_cu, out, aux, st))
+    // (length-class thresholds: flat within 1.5 % around these, profiles/r03)
+    if (variant == DDRR_BRICKS_Q16 || variant == 5) {
+        p.t1 = g_brick_t1 * (22.f / 18.f);
+        p.t2 = g_brick_t2 * (48.f / 40.f);
+    }
     switch (variant) {
-        case 0: rc = DDRR_LAUNCH(CfgF32); break;
-        case 1: rc = DDRR_LAUNCH(CfgQ16x2); break;
+        case DDRR_BRICKS_F32: rc = DDRR_LAUNCH(CfgF32); break;
+        case DDRR_BRICKS_Q16: rc = DDRR_LAUNCH(CfgQ16Z64); break;
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
         case 2: rc = DDRR_LAUNCH(CfgQ16x1); break;
+        case 10: rc = DDRR_LAUNCH(CfgQ16x2); break;
         case 3: rc = DDRR_LAUNCH(CfgF32Half); break;
         case 4: rc = DDRR_LAUNCH(CfgQ16X64); break;
-        case 5: rc = DDRR_LAUNCH(CfgQ16Z64); break;
+        case 5: rc = DDRR_LAUNCH(CfgQ16Z64); break;  // (= DDRR_BRICKS_Q16)
         case 6: rc = DDRR_LAUNCH(CfgQ16Y64); break;
         case 7: rc = DDRR_LAUNCH(CfgF32Y64); break;
         case 8: rc = DDRR_LAUNCH(CfgF32X64); break;

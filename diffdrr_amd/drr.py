@@ -184,10 +184,16 @@ class DRR(nn.Module):
             P = calibration(det.target)[0].detach()          # (N,3) detector.py:147-150
         Ainv = self._affine_inverse[0, :3, :] if self._affine_inverse.dim() == 3 \
             else self._affine_inverse[:3, :]
+        # the grid contract holds for THIS call only (rays generated right here): a later direct
+        # `drr.renderer(...)` call with rays of its own is checked again (renderers._grid_or_none)
         self.renderer.detector_shape = (det.height, det.width)
         self.renderer.trust_detector_shape = True
-        return self.renderer.render_poses(self.density, Mw, P, Ainv,
-                                          mask=self.mask if mask_to_channels else None, **kwargs)
+        try:
+            return self.renderer.render_poses(self.density, Mw, P, Ainv,
+                                              mask=self.mask if mask_to_channels else None,
+                                              **kwargs)
+        finally:
+            self.renderer.trust_detector_shape = False
 
     @torch.no_grad()
     def marching_range(self, *args, parameterization: str = None, convention: str = None,
@@ -230,15 +236,20 @@ class DRR(nn.Module):
                                                     self.detector.width)
         self.renderer.detector_shape = \
             (self.detector.height, self.detector.width) if full_grid else None
-        self.renderer.trust_detector_shape = True  # generated or checked right here
-        if self.patch_size is None:
-            return self.renderer(density, source, target, img, **kwargs)
-        partials = [
-            self.renderer(density, source, t, i, **kwargs)
-            for t, i in zip(target.chunk(self.n_patches, dim=1),
-                            img.chunk(self.n_patches, dim=-1))
-        ]
-        return torch.cat(partials, dim=-1)
+        self.renderer.trust_detector_shape = True  # generated or checked right here ...
+        try:
+            if self.patch_size is None:
+                return self.renderer(density, source, target, img, **kwargs)
+            partials = [
+                self.renderer(density, source, t, i, **kwargs)
+                for t, i in zip(target.chunk(self.n_patches, dim=1),
+                                img.chunk(self.n_patches, dim=-1))
+            ]
+            return torch.cat(partials, dim=-1)
+        finally:
+            # ... and for this call only: rays handed to `drr.renderer(...)` directly afterwards
+            # (the trilinear tutorial does) are verified again before the brick kernels see them
+            self.renderer.trust_detector_shape = False
 
     # ------------------------------------------------------------ intrinsics
     def set_intrinsics_(self, sdd: float = None, height: int = None, width: int = None,

@@ -106,6 +106,8 @@ def rays_form_detector_grid(source, target, det_h, det_w, tol=2e-3) -> bool:
     B, N, _ = target.shape
     if N != det_h * det_w or min(det_h, det_w) < 2 or source.shape[1] != 1:
         return False
+    if target.numel() == 0:
+        return False  # (an empty batch: the per-ray entry points return empty results)
     t = target.detach().reshape(B, det_h, det_w, 3)
     t00 = t[:, :1, :1]
     ei = (t[:, -1:, :1] - t00) / (det_h - 1)
@@ -113,7 +115,10 @@ def rays_form_detector_grid(source, target, det_h, det_w, tol=2e-3) -> bool:
     i = torch.arange(det_h, device=t.device, dtype=t.dtype).view(1, det_h, 1, 1)
     j = torch.arange(det_w, device=t.device, dtype=t.dtype).view(1, 1, det_w, 1)
     dev = (t00 + i * ei + j * ej - t).abs().amax()
-    return bool((dev <= tol).item())
+    # a grid, not a line or a point: the pixel steps span a plane (|e_i x e_j| well above the
+    # tolerance; all targets equal, or all on one line, is not a detector)
+    area = torch.linalg.cross(ei.reshape(B, 3), ej.reshape(B, 3)).norm(dim=-1).amin()
+    return bool(((dev <= tol) & (area > tol * tol)).item())
 
 
 def _hints(det, tile, N):

@@ -54,12 +54,22 @@ class GraphedIteration:
     The optimizer must not synchronise in ``step()`` (``torch.optim.SGD``; Adam with
     ``capturable=True``).  Everything the iteration touches keeps its address: the parameters
     of ``reg`` and the optimizer state are updated in place, ``target`` is read in place.
-    ``maximize`` / learning rates are whatever the optimizer was built with."""
+    ``maximize`` / learning rates are whatever the optimizer was built with.
+
+    Construction has no side effects on the optimisation: the ``warmup`` eager iterations and
+    the capture itself (which runs the iteration once more) are undone -- parameters and
+    optimizer state are restored to what they were -- so that ``step()`` number k is iteration
+    k of the loop, as in the reference's.  ``iterations_done`` counts the replays."""
 
     def __init__(self, reg: Registration, criterion, optimizer, target: torch.Tensor,
                  warmup: int = 3, **render_kwargs):
         self.reg, self.criterion, self.optimizer, self.target = reg, criterion, optimizer, target
         self.render_kwargs = render_kwargs
+        self.iterations_done = 0
+        params = [p for g in optimizer.param_groups for p in g["params"]]
+        saved_params = [p.detach().clone() for p in params]
+        saved_state = {p: {k: v.detach().clone() for k, v in optimizer.state.get(p, {}).items()
+                           if torch.is_tensor(v)} for p in params}
 
         def iteration():
             optimizer.zero_grad(set_to_none=True)
@@ -78,7 +88,19 @@ class GraphedIteration:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = iteration()
+        # undo warm-up and capture: same parameter values, same optimizer state, IN PLACE (the
+        # graph holds the addresses of both).  State the warm-up created is zeroed, which is what
+        # a first step starts from (Adam's moments and step count, SGD's momentum buffer).
+        with torch.no_grad():
+            for p, v in zip(params, saved_params):
+                p.copy_(v)
+                p.grad = None
+                for name, val in optimizer.state.get(p, {}).items():
+                    if torch.is_tensor(val):
+                        old = saved_state[p].get(name)
+                        val.copy_(old) if old is not None else val.zero_()
 
     def __call__(self) -> torch.Tensor:
         self.graph.replay()
+        self.iterations_done += 1
         return self.loss

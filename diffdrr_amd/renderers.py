@@ -7,12 +7,21 @@ HIP kernels of ``libdiffdrr_hip.so`` through ``torch.autograd.Function``s, so a
 ``DRR`` module (ours or the reference's) differentiates
 w.r.t. pose, ray endpoints and the volume exactly as before.
 
-Every combination the reference accepts is rendered and differentiated by kernels: sum / max /
-callable ``reducefn`` (the latter over the materialised per-segment / per-sample tensor),
-``mode`` nearest / bilinear, any ``align_corners``, ``mask`` channels, per-ray sources.  What
-raises instead of silently diverging: CPU tensors (there is no CPU fallback) and dtypes other
-than float32 / float64 (float64 modules render through the fp64 instantiation of the per-ray
-kernels, like ``DRR.to(torch.float64)`` in the reference, drr.py:71-75).
+float32 (the reference's default dtype): every combination the reference accepts is rendered
+and differentiated by kernels -- sum / max / callable ``reducefn`` (the latter over the
+materialised per-segment / per-sample tensor), ``mode`` nearest / bilinear, any
+``align_corners``, ``mask`` channels, per-ray sources.
+
+float64 (a module moved ``.to(torch.float64)``, reference drr.py:71-75) is covered for the
+configurations the fp64 kernels exist for (csrc/f64_rays.hip): Siddon ``mode="nearest"``,
+``align_corners=False``, ``reducefn`` sum (forward + backward) or max (forward); Trilinear
+``mode="bilinear"``, ``reducefn="sum"``, ``align_corners=False``.  float64 with a mask, a
+callable ``reducefn``, the midpoint lookups (``align_corners=True``, Siddon
+``mode="bilinear"``), Trilinear ``mode="nearest"`` / max, or the max backward raises
+``NotImplementedError`` (the reference computes them); INTEGRATION.md lists the same.
+
+What raises instead of silently diverging: CPU tensors (there is no CPU fallback), the float64
+combinations above, and dtypes other than float32 / float64.
 """
 from __future__ import annotations
 
@@ -82,6 +91,13 @@ def _record_vmax(volume, want_aux, cfg):
     return ops.volume_absmax(volume)
 
 
+def _brick_storage(volume, cfg):
+    """How the brick kernel stages the volume (Siddon.brick_storage).  A volume that is being
+    optimised changes every step: its 16-bit ranges would be recomputed per launch (one more
+    pass over the volume), and its gradient is taken w.r.t. the exact values: fp32 bricks."""
+    return "f32" if volume.requires_grad else cfg.get("storage", "f32")
+
+
 class _SiddonFn(torch.autograd.Function):
     """out (B,N) = img * sum_k V_k dalpha_k (or max_k).  Inputs: volume, source,
     target, img.  Backward: ddrr_siddon_backward_rays from the 8-float forward
@@ -101,7 +117,7 @@ class _SiddonFn(torch.autograd.Function):
             out, aux = ops.siddon_forward_bricks(
                 volume, source, target, img, cfg["det"], voxel_shift=cfg["voxel_shift"],
                 eps=cfg["eps"], want_aux=want_aux, record_vmax=_record_vmax(volume, want_aux, cfg),
-                storage=cfg.get("storage", "f32"))
+                storage=_brick_storage(volume, cfg))
         else:
             out, aux, _ = ops.siddon_forward(
                 volume, source, target, img, voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
@@ -303,7 +319,7 @@ class _SiddonPoseFn(torch.autograd.Function):
             out, aux = ops.siddon_forward_bricks(
                 volume, source, target, img, cfg["det"], voxel_shift=cfg["voxel_shift"],
                 eps=cfg["eps"], want_aux=want_aux, record_vmax=_record_vmax(volume, want_aux, cfg),
-                storage=cfg.get("storage", "f32"))
+                storage=_brick_storage(volume, cfg))
         else:
             out, aux, _ = ops.siddon_forward(
                 volume, source, target, img, voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
@@ -334,7 +350,8 @@ def _channels_forward(volume, labels, C, source, target, img, cfg):
     B, N = target.shape[:2]
     grid = (cfg["det"] is not None and cfg["det"][0] * cfg["det"][1] == N
             and source.shape[1] == 1 and min(cfg["det"]) >= 2)
-    if grid and cfg["path"] == "bricks" and ops.channels_fit_bricks(B, C, N):
+    if grid and cfg["path"] == "bricks" and cfg.get("channels_on_bricks", True) \
+            and ops.channels_fit_bricks(B, C, N):
         return ops.siddon_forward_channels_bricks(
             volume, labels, C, source, target, img, cfg["det"],
             voxel_shift=cfg["voxel_shift"], eps=cfg["eps"])
@@ -417,10 +434,19 @@ class Siddon(torch.nn.Module):
         # resolves 2 max|V| (Dx+Dy+Dz+3) / 2^30, ~10x coarser than fp32 accumulation, hence off
         # by default: the default record is fp32 like the reference's arithmetic.
         self.packed_record = False
-        # How the brick kernel holds a brick in LDS (include/diffdrr_hip.h): "f32" the volume's
-        # own values; "q16" a 16-bit block quantisation per 32^3 brick (|error| per voxel <=
-        # brick range / 131070, fp32 arithmetic): two workgroups per CU instead of one.
-        self.brick_storage = "f32"
+        # How the brick kernel holds a brick in LDS (include/diffdrr_hip.h DDRR_BRICKS_*):
+        # "q16": 16-bit block quantisation, one (min, step) pair per 32 x 32 x 64 brick -- |error|
+        # per voxel <= the brick's value range / 131070, all arithmetic fp32; measured image
+        # error against the fp64 oracle at 512^3: 5e-6 of the image scale, the same as with fp32
+        # bricks (the reference's own fp32 arithmetic: 6e-5) -- in exchange for bricks of twice
+        # the volume: 6-7 % faster.  "f32": the volume's own values in 32^3 bricks (always used
+        # for a volume that requires grad).
+        self.brick_storage = "q16"
+        # mask_to_channels of a detector-grid call on the brick kernel: the label rides in the low
+        # byte of the staged voxel word, the value keeps a 16-bit mantissa (2^-17 relative per
+        # voxel; channel sums agree with the plain render to 1e-5 of the image scale,
+        # tests/test_gpu_parity.py).  False: the per-ray channel kernel on exact fp32 values.
+        self.channels_on_bricks = True
 
     def dims(self, volume):
         return torch.tensor(volume.shape).to(volume)
@@ -438,7 +464,8 @@ class Siddon(torch.nn.Module):
                 "stop_gradients": self.stop_gradients_through_grid_sample,
                 "det": self.detector_shape if det == "unchecked" else det, "tile": self.tile,
                 "path": self.grid_path,
-                "packed_record": self.packed_record, "storage": self.brick_storage}
+                "packed_record": self.packed_record, "storage": self.brick_storage,
+                "channels_on_bricks": self.channels_on_bricks}
 
     def supports_pose_entry(self):
         """Whether ``render_poses`` (the fused DRR entry) computes what ``forward`` would."""

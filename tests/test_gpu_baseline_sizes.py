@@ -40,7 +40,7 @@ def _oracle_pair(vol, s, t, L, go):
     return ref32, ref64
 
 
-def _check_bricks_against_oracle(gpu, D, det, delx, B, seed):
+def _check_bricks_against_oracle(gpu, D, det, delx, B, seed, storage="f32"):
     drr, rot, xyz = scene(D, det, delx, B, gpu, seed=seed)
     # (pose 0 of `scene` is the exact base pose, a measure-zero case for gradients: tied
     # crossings on the symmetry planes; make it generic like the others)
@@ -52,19 +52,25 @@ def _check_bricks_against_oracle(gpu, D, det, delx, B, seed):
     go = torch.randn(B, N, generator=torch.Generator().manual_seed(5)).to(gpu)
     ref32, ref64 = _oracle_pair(V.cpu().numpy(), s, t, L, go)
 
-    out, aux = ops.siddon_forward_bricks(V, s, t, L, (det, det), want_aux=True)
-    plain, _ = ops.siddon_forward_bricks(V, s, t, L, (det, det))
+    out, aux = ops.siddon_forward_bricks(V, s, t, L, (det, det), want_aux=True, storage=storage)
+    plain, _ = ops.siddon_forward_bricks(V, s, t, L, (det, det), storage=storage)
+    exempt = 0
     for img in (out, plain):
         mine = img.cpu().numpy().reshape(B, 1, N)
         for b in range(B):  # per image, as the north star states it
             r32, r64 = ref32["out"][b].astype(np.float64), ref64["out"][b]
             scale = np.abs(r32).max()
-            # within 1e-4 of the reference's fp32 image -- except where that image itself is
-            # further than that from the exact one (a ray gliding along a voxel plane: the fp32
-            # reference was 3e-4 off at one pixel of the 512^3 scene, the kernel 8e-5)
-            assert (np.abs(mine[b] - r32) <= FWD_TOL * scale + 2 * np.abs(r32 - r64)).all(), b
+            # the north star's plain bound, 1e-4 of the image scale against the reference's fp32
+            # image, at every pixel where that image is itself within 1e-4 of the exact one; the
+            # others (a ray gliding along a voxel plane: the fp32 reference was 3e-4 off at one
+            # pixel of the 512^3 scene) are held to the exact image instead, and counted
+            ref_ok = np.abs(r32 - r64) <= FWD_TOL * scale
+            assert (np.abs(mine[b] - r32)[ref_ok] <= FWD_TOL * scale).all(), b
+            assert (np.abs(mine[b] - r64)[~ref_ok] <= FWD_TOL * scale).all(), b
+            exempt += int((~ref_ok).sum())
             # and no further from the exact image than the reference's fp32 arithmetic
             assert rel_err(mine[b], r64) < 2 * rel_err(r32, r64) + 2e-6, b
+    assert exempt <= 1e-4 * 2 * B * N, exempt  # (pixels where the fp32 reference is > 1e-4 off)
     gs, gt, gi = ops.siddon_backward_rays(aux, go, s, t, L)
     gs = gs.double().sum(1, keepdim=True).cpu().numpy()
     for mine, key in ((gs, "g_source"), (gt.cpu().numpy(), "g_target"),
@@ -78,14 +84,19 @@ def _check_bricks_against_oracle(gpu, D, det, delx, B, seed):
     return drr, rot, xyz
 
 
-def test_config2_bricks_vs_oracle_256_cubed_batch_32(gpu):
-    """BASELINE configs[1]: 256^3 volume, 256x256 detector, 32 poses, forward + backward."""
-    _check_bricks_against_oracle(gpu, 256, 256, 1.2, 32, seed=1)
+@pytest.mark.parametrize("storage", ["f32", "q16"])
+def test_config2_bricks_vs_oracle_256_cubed_batch_32(gpu, storage):
+    """BASELINE configs[1]: 256^3 volume, 256x256 detector, 32 poses, forward + backward; with
+    the volume's own fp32 values and with the 16-bit block-quantised bricks (the module's
+    default, Siddon.brick_storage)."""
+    _check_bricks_against_oracle(gpu, 256, 256, 1.2, 32 if storage == "f32" else 8, seed=1,
+                                 storage=storage)
 
 
-def test_headline_bricks_vs_oracle_512_cubed(gpu):
+@pytest.mark.parametrize("storage", ["f32", "q16"])
+def test_headline_bricks_vs_oracle_512_cubed(gpu, storage):
     """BASELINE metric: 512^3 volume, 256x256 detector (bench.py's geometry), 3 poses."""
-    _check_bricks_against_oracle(gpu, 512, 256, 2.4, 3, seed=4)
+    _check_bricks_against_oracle(gpu, 512, 256, 2.4, 3, seed=4, storage=storage)
 
 
 def _pose_gradient_errors(drr, rot, xyz, W):
@@ -233,7 +244,7 @@ def test_graphed_registration_iteration_equals_eager_loop(gpu):
 
     reg_e, opt_e = make()
     eager = []
-    for _ in range(3 + 12):  # GraphedIteration warms up with 3 real iterations
+    for _ in range(12):
         opt_e.zero_grad()
         loss = crit(gt, reg_e()).sum()
         loss.backward()
@@ -241,10 +252,13 @@ def test_graphed_registration_iteration_equals_eager_loop(gpu):
         eager.append(loss.item())
     reg_g, opt_g = make()
     step = GraphedIteration(reg_g, crit, opt_g, gt, warmup=3)
-    graphed = [step().item() for _ in range(11)]
-    # (capture itself runs no iteration: after the 3 warm-up iterations the graph continues
-    # with iteration 4; atomics make sums order-dependent in the last bits)
-    assert np.allclose(graphed, eager[3:14], atol=2e-4), (graphed, eager[3:14])
+    # construction (3 eager warm-up iterations + the capture) leaves parameters and optimizer state
+    # as they were: replay k is iteration k of the loop
+    assert torch.equal(reg_g._rotation.detach(), r0) and torch.equal(reg_g._translation.detach(), x0)
+    graphed = [step().item() for _ in range(12)]
+    assert step.iterations_done == 12
+    # (atomics make sums order-dependent in the last bits)
+    assert np.allclose(graphed, eager, atol=2e-4), (graphed, eager)
     assert graphed[-1] > graphed[0]
 
 

@@ -24,9 +24,10 @@ ap.add_argument("--classes", default="18:40")
 ap.add_argument("--sqw", default="8", help="class width(s) of the shared rings (variants >= 16)")
 ap.add_argument("--variants", default="-2",
                 help="bricks_fwd.hip variants: -2 product default, -1 the general 32^3 fp32 kernel of "
-                     "bricks.hip, 0 32^3 fp32, 1 32^3 16-bit x 2 workgroups per CU, 2 32^3 16-bit x 1, "
-                     "3 32x32x16 fp32 x 2, 4-6 double 16-bit bricks (x, z, y long), 7-9 anisotropic fp32 "
-                     "bricks 16x64x32, 64x16x32, 16x32x64")
+                     "bricks.hip, 0 32^3 fp32 (DDRR_BRICKS_F32), 1 = 5 32x32x64 16-bit (DDRR_BRICKS_Q16), "
+                     "2 32^3 16-bit, 10 32^3 16-bit x 2 workgroups per CU, 3 32x32x16 fp32 x 2, 4 / 6 double "
+                     "16-bit bricks long in x / y, 7-9 anisotropic fp32 bricks 16x64x32, 64x16x32, 16x32x64; "
+                     "16 + v / 32 + v: workgroup-shared rings of 12 / 8 length classes")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 D, H = a.size, a.det
@@ -55,7 +56,7 @@ for lay, dbg, cl, var, sqw in itertools.product(a.layouts.split(","), a.dbg.spli
         continue
     lib.cdll.ddrr_set_brick_variant(var)
     lib.cdll.ddrr_set_brick_sq_width(ctypes.c_float(float(sqw)))
-    storage = "q16" if var >= 0 and var % 16 in (1, 2, 4, 5, 6) else "f32"
+    storage = "q16" if var >= 0 and var % 16 in (1, 2, 4, 5, 6, 10) else "f32"
     lib.cdll.ddrr_set_brick_debug(int(dbg))
     t1, t2 = (float(v) for v in cl.split(":"))
     import ctypes

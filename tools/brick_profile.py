@@ -42,7 +42,7 @@ import itertools  # noqa: E402
 for var, case in itertools.product(a.variants.split(","), a.cases.split(",")):
     var = int(var)
     lib.cdll.ddrr_set_brick_variant(var)
-    storage = "q16" if var >= 0 and var % 16 in (1, 2, 4, 5, 6) else "f32"
+    storage = "q16" if var >= 0 and var % 16 in (1, 2, 4, 5, 6, 10) else "f32"
     aux = case.endswith("aux")
     name = case[:-3] if aux else case
     if name.startswith("base"):
