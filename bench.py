@@ -23,11 +23,17 @@ world size RCCL actually has.
 
 Rank 0 prints ONE JSON line on stdout: the driver's contract plus
   "roofline":     the dominant kernel's algorithmic byte rate (SURVEY.md section 8d formulas),
-                  timed with HIP events around every launch inside the timed region,
+                  timed with HIP events around every launch inside the timed region;
+                  "roofline.forward": the forward-only kernel (the north star's target) on the
+                  step's own poses, 30 launches after the timed region; "roofline.kernels": every
+                  renderer kernel of the step with its own algorithmic bytes,
   "cpu_baseline": the CPU oracle (a port of the reference's algorithm, OpenMP) on a bounded
-                  sample of the same workload, rank 0, N = 1 only,
-  "parity":       the step's images / ray gradients for the sampled poses against the oracle's
-                  fp32 and fp64 renders of the same poses (the cpu_baseline leg's outputs).
+                  sample of the same workload, rank 0, N = 1 only; "reference_cpu": the
+                  UNMODIFIED reference on CPU torch, measured in the build container (it does
+                  not exist on the GPU box), with its core count and source file,
+  "parity":       images of the timed step, and the 6-DoF pose gradients its backward produced,
+                  for sampled poses against the oracle's fp32 (the reference's arithmetic) and
+                  fp64 (exact) chains; the same on a phantom volume (absolute bound).
 Diagnostics go to stderr.
 """
 from __future__ import annotations
@@ -106,14 +112,64 @@ def voxel_rays(drr, rot, xyz):
         return (drr.affine_inverse(source).contiguous(), drr.affine_inverse(target).contiguous(), L)
 
 
-def cpu_baseline_and_parity(drr, rot, xyz, images, det, budget_s=12.0, n_parity=2):
+def _ncc_grad64(fixed, img, eps=1e-5):
+    """d NCC(fixed, img) / d img in float64 (reference metrics.py:21-44)."""
+    import numpy as np
+
+    a, b = fixed.astype(np.float64).ravel(), img.astype(np.float64).ravel()
+    s1, s2 = np.sqrt(a.var() + eps), np.sqrt(b.var() + eps)
+    z1, z2 = (a - a.mean()) / s1, (b - b.mean()) / s2
+    return (z1 - z2 * (z1 * z2).mean()) / (a.size * s2)
+
+
+class OracleChain:
+    """(g_rot, g_xyz) of sum(weights * DRR) for one pose through the ORACLE: rays generated in
+    float64 torch on the CPU exactly as DRR.forward does (convert -> Detector -> affine_inverse),
+    the oracle's analytic ray gradients (fp32 = the reference's arithmetic, fp64 = exact) chained
+    back to the pose parameters by autograd of that float64 ray generation."""
+
+    def __init__(self, drr):
+        import copy
+
+        import numpy as np
+
+        from diffdrr_amd.pose import RigidTransform
+
+        self.detector = copy.deepcopy(drr.detector).cpu().double()
+        self.affine_inverse = RigidTransform(drr._affine_inverse.detach().cpu().double())
+        self.vol = {np.float32: drr.density.detach().cpu().numpy()}
+        self.vol[np.float64] = self.vol[np.float32].astype(np.float64)
+
+    def __call__(self, rot_b, xyz_b, weights, dtype):
+        import numpy as np
+
+        import oracle
+        from diffdrr_amd.pose import convert
+
+        r64 = rot_b.detach().cpu().double().reshape(1, 3).requires_grad_()
+        x64 = xyz_b.detach().cpu().double().reshape(1, 3).requires_grad_()
+        pose = convert(r64, x64, parameterization="euler_angles", convention="ZXY")
+        source, target = self.detector(pose, None)
+        L = (target - source).norm(dim=-1)
+        s, t = self.affine_inverse(source), self.affine_inverse(target)
+        o = oracle.siddon(self.vol[dtype], s.detach().numpy().astype(dtype),
+                          t.detach().numpy().astype(dtype), L.detach().numpy().astype(dtype),
+                          grad_out=np.asarray(weights, dtype).reshape(1, -1))
+        as64 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64))  # noqa: E731
+        ((as64(o["g_source"]) * s).sum() + (as64(o["g_target"]) * t).sum()
+         + (as64(o["g_img"]).reshape(L.shape) * L).sum()).backward()
+        return r64.grad.numpy().ravel(), x64.grad.numpy().ravel(), o["out"].reshape(-1)
+
+
+def cpu_baseline_and_parity(drr, rot, xyz, images, g_rot, g_xyz, base, det, budget_s=12.0, n_parity=2):
     """Oracle (C port of the reference algorithm, OpenMP over rays) forward + analytic backward
-    on a bounded sample of the step's poses: the timing is `cpu_baseline`; its outputs for the
-    first poses (plus an fp64 render of them) are the yardstick of `parity`."""
+    on a bounded sample of the step's poses: the timing is `cpu_baseline`.  `parity`: the images
+    the timed step produced and the pose gradients its backward left in rot.grad / xyz.grad,
+    for the first poses, against the oracle chains in fp32 (the reference's arithmetic) and
+    fp64 (exact)."""
     import numpy as np
 
     import oracle
-    from diffdrr_amd import ops
 
     s_d, t_d, L_d = voxel_rays(drr, rot, xyz)
     s, t, L = s_d.cpu().numpy(), t_d.cpu().numpy(), L_d.cpu().numpy()
@@ -128,49 +184,83 @@ def cpu_baseline_and_parity(drr, rot, xyz, images, det, budget_s=12.0, n_parity=
     oracle.siddon(vol, s[:1], t[:1, :n0], L[:1, :n0], grad_out=go[:, :n0])
     per_ray = (time.perf_counter() - t0) / n0
     n_drr = max(1, min(B, int(budget_s / (per_ray * N))))
-    refs = []
     t0 = time.perf_counter()
     for b in range(n_drr):
-        refs.append(oracle.siddon(vol, s[b:b + 1], t[b:b + 1], L[b:b + 1], grad_out=go))
+        oracle.siddon(vol, s[b:b + 1], t[b:b + 1], L[b:b + 1], grad_out=go)
     dt = time.perf_counter() - t0
     baseline = {
         "value": n_drr / dt, "unit": "DRRs/s", "cores": cores, "kind": "port",
         "sample": f"{n_drr} of the step's poses, {D}^3 -> {det}x{det} Siddon fwd + analytic bwd "
                   f"(oracle/drr_oracle.c, OpenMP {cores} threads, {dt:.1f} s)",
     }
-    # parity: the images the timed step produced and the brick kernel's ray gradients for the
-    # same poses, against the oracle's fp32 (reference arithmetic) and fp64 (exact) renders
-    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - b).max() / np.abs(b).max())  # noqa
-    n_par = min(n_parity, n_drr)
-    fwd32, fwd64, ref_fwd64, g64, ref_g64 = [], [], [], [], []
-    vol64 = vol.astype(np.float64)
-    for b in range(n_par):
-        r64 = oracle.siddon(vol64, s[b:b + 1].astype(np.float64), t[b:b + 1].astype(np.float64),
-                            L[b:b + 1].astype(np.float64), grad_out=go.astype(np.float64))
-        mine = images[b].reshape(-1).cpu().numpy()
-        r32 = refs[b]["out"].reshape(-1)
-        fwd32.append(rel(mine, r32.astype(np.float64)))
-        fwd64.append(rel(mine, r64["out"].reshape(-1)))
-        ref_fwd64.append(rel(r32, r64["out"].reshape(-1)))
-        _, aux = ops.siddon_forward_bricks(drr.density, s_d[b:b + 1], t_d[b:b + 1], L_d[b:b + 1],
-                                           (det, det), want_aux=True)
-        _, gt, _ = ops.siddon_backward_rays(aux, torch.ones(1, N, device=s_d.device),
-                                            s_d[b:b + 1], t_d[b:b + 1], L_d[b:b + 1])
-        g64.append(rel(gt.cpu().numpy(), r64["g_target"]))
-        ref_g64.append(rel(refs[b]["g_target"], r64["g_target"]))
-    parity = {
-        "poses": n_par,
-        "oracle": "oracle/drr_oracle.c (C restatement of diffdrr/renderers.py:34-183, pinned to "
-                  "the reference's fixtures): fp32 = the reference's arithmetic, fp64 = exact",
-        "fwd_rel_err": max(fwd32),                    # max |ours - ref32| / max |ref32|, worst pose
-        "fwd_rel_err_vs_fp64": max(fwd64),
-        "ref_fp32_fwd_rel_err_vs_fp64": max(ref_fwd64),
-        "grad_rel_err_vs_fp64": max(g64),             # d out / d target per ray, worst pose
-        "ref_fp32_grad_rel_err_vs_fp64": max(ref_g64),
-        "tolerance": "fwd_rel_err <= 1e-4; *_vs_fp64 <= 2 x the reference's own fp32 error (+1e-3 "
-                     "for gradients)",
-    }
+    parity = pose_parity(drr, rot, xyz, images, g_rot, g_xyz, base, min(n_parity, B))
     return baseline, parity
+
+
+def pose_parity(drr, rot, xyz, images, g_rot, g_xyz, base, n_par):
+    """Images and 6-DoF pose gradients of a step (loss = sum of per-pose NCC against `base`)
+    against the oracle chains.  rel err = max |a - b| / max |b| (image-normalised)."""
+    import numpy as np
+
+    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - b).max() / (np.abs(b).max() + 1e-300))  # noqa
+    fx = base.reshape(-1).cpu().numpy()
+    chain = OracleChain(drr)
+    out = {k: 0.0 for k in ("fwd_rel_err", "fwd_rel_err_vs_fp64", "ref_fp32_fwd_rel_err_vs_fp64",
+                            "pose_grad_rel_err_vs_fp64", "ref_fp32_pose_grad_rel_err_vs_fp64")}
+    for b in range(n_par):
+        mine = images[b].reshape(-1).cpu().numpy()
+        # d loss / d image of this pose, at the exact image (the step's own weights differ from
+        # these by the image error, 1e-5)
+        _, _, img64 = chain(rot[b], xyz[b], np.zeros(mine.size), np.float64)
+        W = _ncc_grad64(fx, img64)
+        gr64, gx64, img64 = chain(rot[b], xyz[b], W, np.float64)
+        gr32, gx32, img32 = chain(rot[b], xyz[b], W, np.float32)
+        out["fwd_rel_err"] = max(out["fwd_rel_err"], rel(mine, img32.astype(np.float64)))
+        out["fwd_rel_err_vs_fp64"] = max(out["fwd_rel_err_vs_fp64"], rel(mine, img64))
+        out["ref_fp32_fwd_rel_err_vs_fp64"] = max(out["ref_fp32_fwd_rel_err_vs_fp64"], rel(img32, img64))
+        truth = np.concatenate([gr64, gx64 * 100.0])  # (mm -> comparable scale with radians)
+        ours = np.concatenate([g_rot[b].cpu().numpy(), g_xyz[b].cpu().numpy() * 100.0])
+        ref = np.concatenate([gr32, gx32 * 100.0])
+        out["pose_grad_rel_err_vs_fp64"] = max(out["pose_grad_rel_err_vs_fp64"], rel(ours, truth))
+        out["ref_fp32_pose_grad_rel_err_vs_fp64"] = max(out["ref_fp32_pose_grad_rel_err_vs_fp64"],
+                                                         rel(ref, truth))
+    out["poses"] = n_par
+    return out
+
+
+def sweep_parity(drr, fixed, rot, xyz, images, vals, picks, eps=1e-5):
+    """Sampled poses of a sweep launch against the oracle: the launch's images vs the oracle's
+    fp32 / fp64 renders, its per-pose NCC vs NCC (float64) of the oracle's images."""
+    import numpy as np
+
+    import oracle
+
+    def ncc64(a, b):
+        z = lambda x: (x - x.mean()) / np.sqrt(x.var() + eps)  # noqa: E731
+        return float((z(a.astype(np.float64)) * z(b.astype(np.float64))).mean())
+
+    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - b).max() / np.abs(b).max())  # noqa
+    vol = drr.density.cpu().numpy()
+    fx = fixed.reshape(-1).cpu().numpy()
+    res = {"poses": [int(b) for b in picks], "fwd_rel_err": 0.0, "fwd_rel_err_vs_fp64": 0.0,
+           "ref_fp32_fwd_rel_err_vs_fp64": 0.0, "ncc_abs_err": 0.0, "ncc_abs_err_vs_fp64": 0.0}
+    for b in picks:
+        s, t, L = voxel_rays(drr, rot[b:b + 1], xyz[b:b + 1])
+        a32 = (vol, s.cpu().numpy(), t.cpu().numpy(), L.cpu().numpy())
+        r32 = oracle.siddon(*a32)["out"].reshape(-1)
+        r64 = oracle.siddon(*(a.astype(np.float64) for a in a32))["out"].reshape(-1)
+        mine = images[b].reshape(-1).cpu().numpy()
+        res["fwd_rel_err"] = max(res["fwd_rel_err"], rel(mine, r32.astype(np.float64)))
+        res["fwd_rel_err_vs_fp64"] = max(res["fwd_rel_err_vs_fp64"], rel(mine, r64))
+        res["ref_fp32_fwd_rel_err_vs_fp64"] = max(res["ref_fp32_fwd_rel_err_vs_fp64"], rel(r32, r64))
+        v = float(vals[b].item())
+        res["ncc_abs_err"] = max(res["ncc_abs_err"], abs(v - ncc64(fx, r32)))
+        res["ncc_abs_err_vs_fp64"] = max(res["ncc_abs_err_vs_fp64"], abs(v - ncc64(fx, r64)))
+    return res
+
+
+REFERENCE_CPU = {  # the UNMODIFIED reference on CPU torch (tools/ref_cpu_baseline.py, build container)
+    512: {"value": 0.071, "forward_only": 0.208}, 256: {"value": 0.192, "forward_only": 0.468}}
 
 
 def free_port():
@@ -204,6 +294,8 @@ def main():
     ap.add_argument("--size", type=int, default=None, help="volume edge (voxels)")
     ap.add_argument("--det", type=int, default=None, help="detector edge (pixels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--storage", default=None, choices=["q16", "f32"],
+                    help="Siddon.brick_storage (default: the module's default, q16)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                     help="cpu: harness test only (gloo ranks; the kernels are whatever "
                          "DDRR_BENCH_HOOK routes diffdrr_amd.ops to, see tests/test_dist_gloo.py)")
@@ -256,21 +348,33 @@ def main():
     timer.install()
     ncc = NormalizedCrossCorrelation2d()
 
+    fence_wait = {"all_gather_s": 0.0, "barrier_s": 0.0}
+
     def fence(pending=()):
+        t_a = time.perf_counter()
         for work in pending:
             work.wait()
         if on_gpu:
             torch.cuda.synchronize()
+        t_b = time.perf_counter()
         if world > 1:
             dist.barrier()
         if on_gpu:
             torch.cuda.synchronize()
+        # (what this rank waited for its own work + the losses' all_gather, and then for the others)
+        fence_wait["all_gather_s"], fence_wait["barrier_s"] = t_b - t_a, time.perf_counter() - t_b
 
     extra = {}
     images = None
+
+    def set_storage(d):
+        if args.storage is not None and hasattr(d.renderer, "brick_storage"):
+            d.renderer.brick_storage = args.storage
+        return d
+
     if cfg in ("headline", "2"):
         subject = make_subject(noise_volume(D, seed=0), spacing=(1.0, 1.0, 1.0), orientation="AP")
-        drr = DRR(subject, sdd=1020.0, height=H, delx=delx, renderer="siddon").to(device)
+        drr = set_storage(DRR(subject, sdd=1020.0, height=H, delx=delx, renderer="siddon").to(device))
         rot0, xyz0 = perturbed_poses(B, seed=2 + rank, device=device)
         with torch.no_grad():
             base = drr(torch.zeros(1, 3, device=device), torch.tensor([[0.0, 850.0, 0.0]], device=device),
@@ -321,8 +425,8 @@ def main():
                     f"forward + backward w.r.t. the volume, {B} pose(s) per GPU per step")
         dominant = "ddrr_trilinear_forward_bricks"
     elif cfg == "4":
-        drr = DRR(synthetic_subject(D, kind="phantom", seed=0), sdd=1020.0, height=H, delx=delx,
-                  stop_gradients_through_grid_sample=True).to(device)
+        drr = set_storage(DRR(synthetic_subject(D, kind="phantom", seed=0), sdd=1020.0, height=H, delx=delx,
+                              stop_gradients_through_grid_sample=True).to(device))
         true_rot = torch.zeros(1, 3, device=device)
         true_xyz = torch.tensor([[0.0, 850.0, 0.0]], device=device)
         with torch.no_grad():
@@ -367,7 +471,7 @@ def main():
         dominant = "ddrr_siddon_forward_bricks"
     else:  # "5": the candidate-pose sweep, sharded (strong scaling)
         subject = make_subject(noise_volume(D, seed=0), spacing=(1.0, 1.0, 1.0), orientation="AP")
-        drr = DRR(subject, sdd=1020.0, height=H, delx=delx, renderer="siddon").to(device)
+        drr = set_storage(DRR(subject, sdd=1020.0, height=H, delx=delx, renderer="siddon").to(device))
         rot0, xyz0 = perturbed_poses(B, seed=2, device=device)  # the same candidates on every rank
         with torch.no_grad():
             fixed = drr(torch.zeros(1, 3, device=device), torch.tensor([[0.0, 850.0, 0.0]], device=device),
@@ -410,6 +514,22 @@ def main():
     t_max = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        # per-rank picture for the scaling run: timed region, dominant kernel, waits inside fence()
+        k_tot, k_cnt = timer.total_ms(dominant)
+        mine = torch.tensor([dt, k_tot / max(1, k_cnt), fence_wait["all_gather_s"], fence_wait["barrier_s"]],
+                            device=device, dtype=torch.float64)
+        every = torch.empty(world * 4, device=device, dtype=torch.float64)
+        dist.all_gather_into_tensor(every, mine)
+        every = every.reshape(world, 4).cpu()
+        extra["ranks"] = {
+            "timed_region_s": {"min": every[:, 0].min().item(), "max": every[:, 0].max().item()},
+            "kernel_ms": {"min": every[:, 1].min().item(), "max": every[:, 1].max().item()},
+            "final_fence_wait_own_work_and_all_gather_s": {"min": every[:, 2].min().item(),
+                                                           "max": every[:, 2].max().item()},
+            "final_fence_wait_barrier_s": {"min": every[:, 3].min().item(), "max": every[:, 3].max().item()},
+        }
+        if rank == 0:
+            log(f"[bench] ranks: {extra['ranks']}")
     dt = t_max.item()
 
     if rank == 0:
@@ -474,6 +594,47 @@ def main():
                 traffic_kind = "forward_record" if cfg in ("headline", "2", "4") else "forward"
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         traffic = traffic_record(traffic_kind) if (D, H) == (512, 256) and cfg in ("headline", "5") else None
+        # every renderer kernel of the step with its own algorithmic bytes
+        kernels = []
+        for name in timer.events:
+            tot, cnt = timer.total_ms(name)
+            if not cnt:
+                continue
+            ent = {"kernel": name, "kernel_ms": tot / cnt, "launches_per_step": cnt / steps_k}
+            if name == k_name:
+                ent.update(algorithmic_bytes_per_launch=alg_bytes, frac=achieved / HBM_PEAK_GBS)
+            elif cfg == "3" and name == "ddrr_trilinear_backward_volume_bricks":
+                vb = (32 + 64) * n_in  # 8 corner reads + 8 corner read-modify-writes per sample
+                ent.update(algorithmic_bytes_per_launch=vb, bound="LDS atomics (VALU issue)",
+                           algorithmic_bytes_per_unit="(32 + 64) B per sample in the volume",
+                           frac=vb / (tot / cnt * 1e-3) / 1e9 / HBM_PEAK_GBS)
+            kernels.append(ent)
+        kernels.sort(key=lambda e: -e["kernel_ms"] * e["launches_per_step"])
+        # the north star's target kernel, forward ONLY, on the step's own poses: 30 launches after
+        # the timed region (the step itself runs forward + record)
+        forward = None
+        if on_gpu and cfg in ("headline", "2", "5"):
+            with torch.no_grad():
+                fr, fx = (rot0, xyz0) if cfg != "5" else (rot0[:nposes], xyz0[:nposes])
+                for _ in range(3):
+                    drr(fr, fx, parameterization="euler_angles", convention="ZXY")
+                before = len(timer.events.get(dominant, []))
+                timer.enabled = True
+                for _ in range(30):
+                    drr(fr, fx, parameterization="euler_angles", convention="ZXY")
+                torch.cuda.synchronize()
+                timer.enabled = False
+                ev = timer.events[dominant][before:]
+                f_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+                del timer.events[dominant][before:]
+            forward = {"kernel": dominant + " (aux = NULL: forward only)", "kernel_ms": f_ms,
+                       "launches_timed": len(ev), "poses_per_launch": int(fr.shape[0]),
+                       "algorithmic_bytes_per_launch": alg_bytes,
+                       "achieved": alg_bytes / (f_ms * 1e-3) / 1e9,
+                       "frac": alg_bytes / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "target_frac": 0.70}
+            log(f"[bench] forward only: {f_ms:.3f} ms per launch of {fr.shape[0]} poses = "
+                f"{forward['frac'] * 100:.1f} % of the 8 TB/s roofline")
         log(f"[bench] config {cfg}: step {ms_per_step:.3f} ms | {k_name} {k_ms:.3f} ms per launch, "
             f"{per_step:.1f} launch(es) per step | backward kernels {bwd_ms:.3f} ms per step | "
             f"{per_unit} | {alg_bytes / launch_units / 1e6:.1f} MB algorithmic per DRR")
@@ -517,11 +678,59 @@ def main():
                 "kernel_timing": kernel_timing,
                 "launches_per_step": per_step,
                 "launches_timed": k_n,
+                "forward": forward,
+                "kernels": kernels,
             },
         }
+        storage = getattr(drr.renderer, "brick_storage", None)
+        if storage is not None:
+            result["config"]["brick_storage"] = (
+                "q16: bricks staged as 16-bit block-quantised voxels, one (min, step) per 32x32x64 "
+                "brick, |error| <= brick range / 131070 per voxel, fp32 arithmetic (parity block: "
+                "measured in this run)" if storage == "q16" else "f32: the volume's own values")
         if world == 1 and not args.no_cpu_baseline and cfg in ("headline", "2"):
             result["cpu_baseline"], result["parity"] = cpu_baseline_and_parity(
-                drr, rot0, xyz0, images, H)
+                drr, rot0, xyz0, images, rot.grad, xyz.grad, base, H)
+            result["parity"]["oracle"] = (
+                "oracle/drr_oracle.c (C restatement of diffdrr/renderers.py:34-183, pinned to the "
+                "reference's fixtures): fp32 = the reference's arithmetic, fp64 = exact; pose "
+                "gradients: the oracle's analytic ray gradients chained through float64 ray "
+                "generation to (rot, xyz[mm] x 100) of the timed step's own backward")
+            result["parity"]["tolerance"] = (
+                "fwd_rel_err <= 1e-4; *_vs_fp64 <= 2 x the reference's own fp32 error + 1e-3")
+            # the same check where gradients are not tie-breaking noise: a phantom volume, absolute bound
+            ph = set_storage(DRR(synthetic_subject(D, kind="phantom", seed=0), sdd=1020.0, height=H,
+                                 delx=delx, renderer="siddon").to(device))
+            n_ph = 2
+            r_ph = rot0[:n_ph].clone().requires_grad_()
+            x_ph = xyz0[:n_ph].clone().requires_grad_()
+            with torch.no_grad():
+                base_ph = ph(torch.zeros(1, 3, device=device), torch.tensor([[0.0, 850.0, 0.0]], device=device),
+                             parameterization="euler_angles", convention="ZXY")
+            img_ph = ph(r_ph, x_ph, parameterization="euler_angles", convention="ZXY")
+            ncc(base_ph.expand(n_ph, -1, -1, -1), img_ph).sum().backward()
+            pp = pose_parity(ph, rot0[:n_ph], xyz0[:n_ph], img_ph.detach(), r_ph.grad, x_ph.grad, base_ph, n_ph)
+            pp["volume"] = f"{D}^3 phantom (smooth ellipsoids), same detector and poses"
+            pp["tolerance"] = "pose_grad_rel_err_vs_fp64 <= 1e-3 (absolute bound), fwd_rel_err <= 1e-4"
+            result["parity"]["phantom"] = pp
+            del ph
+        if world == 1 and not args.no_cpu_baseline and cfg == "5" and on_gpu:
+            with torch.no_grad():
+                imgs = drr(rot0[:nposes], xyz0[:nposes], parameterization="euler_angles", convention="ZXY")
+            result["parity"] = sweep_parity(drr, fixed, rot0, xyz0, imgs, keep["vals"],
+                                            (0, nposes // 2, nposes - 1))
+            result["parity"]["tolerance"] = "fwd_rel_err <= 1e-4; ncc_abs_err <= 1e-4"
+            del imgs
+        if cfg in ("headline", "2", "5") and D in REFERENCE_CPU:
+            fwd_only = cfg == "5"
+            result["reference_cpu"] = {
+                "value": REFERENCE_CPU[D]["forward_only" if fwd_only else "value"], "unit": "DRRs/s",
+                "cores": 8, "kind": "reference",
+                "what": ("the UNMODIFIED reference (diffdrr.drr.DRR, CPU torch, 8 threads) on the same "
+                         f"{D}^3 -> 256^2 scene, " + ("forward" if fwd_only else "forward + backward to the pose")
+                         + ", one pose per call; measured in the build container: /root/reference does "
+                         "not exist on the GPU box"),
+                "source": "profiles/r02/ref_cpu_baseline.txt (tools/ref_cpu_baseline.py)"}
         result.update(extra)
         print(json.dumps(result), flush=True)
 

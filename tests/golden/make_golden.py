@@ -366,9 +366,59 @@ def make_registration_fixture():
     save("registration", **arrays)
 
 
+def make_swap_fixture():
+    """The renderer seam of the reference (drr.py:94-101, 209-224) at a size where the
+    volume-stationary kernels have several bricks: the world-space rays an UNMODIFIED
+    ``diffdrr.drr.DRR`` hands to ``DRR.render``, and what the reference's own renderers return
+    for them -- image and autograd gradients w.r.t. those rays.  The GPU test
+    (tests/test_gpu_parity.py::test_reference_rays_through_swapped_renderers) feeds the same
+    rays to ``diffdrr_amd.Siddon`` / ``Trilinear`` as a swapped-in renderer would get them."""
+    dims, spacing = (40, 44, 36), (1.5, 1.25, 1.75)
+    subject, vol, affine = synthetic_subject(dims, spacing, 70, "AP")
+    # (smooth part + noise: gradients that are not all tie-breaking)
+    zz, yy, xx = torch.meshgrid(*[torch.linspace(-1, 1, d) for d in dims], indexing="ij")
+    vol = 0.5 * vol + torch.exp(-3 * (zz ** 2 + yy ** 2 + xx ** 2))
+    subject = ref.Subject(volume=ref.ScalarImage(vol.unsqueeze(0), affine),
+                          density=ref.ScalarImage(vol.unsqueeze(0), affine), mask=None,
+                          reorient=subject.reorient, fiducials=None)
+    geo = dict(sdd=500.0, height=40, width=36, delx=2.0)
+    rot = torch.tensor([[0.05, 0.02, -0.03], [0.6, -0.4, 0.3], [-0.9, 0.2, 0.7]])
+    xyz = torch.tensor([[2.0, 330.0, -1.0], [6.0, 300.0, -5.0], [-9.0, 360.0, 4.0]])
+    arrays = {"volume": npy(vol), "affine": affine, "rot": npy(rot), "xyz": npy(xyz),
+              **{"geo_" + k: np.asarray(v) for k, v in geo.items()}}
+    for renderer, kw in (("siddon", {}), ("trilinear", {"n_points": 80})):
+        drr = ref.DRR(subject, renderer=renderer, **geo)
+        pose = ref.convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+        source, target = drr.detector(pose, None)
+        source = source.detach().clone().requires_grad_()
+        target = target.detach().clone().requires_grad_()
+        img = drr.render(drr.density, source, target, **kw)      # (B, 1, N)
+        go = torch.randn(img.shape, generator=torch.Generator().manual_seed(71))
+        gs, gt = torch.autograd.grad(img, (source, target), go)
+        if renderer == "siddon":
+            arrays.update(source=npy(source), target=npy(target),
+                          affine_inverse=npy(drr.affine_inverse.matrix[0]), grad_out=npy(go))
+        arrays.update({f"{renderer}_img": npy(img), f"{renderer}_g_source": npy(gs),
+                       f"{renderer}_g_target": npy(gt)})
+        # the same call in float64 (module .to(float64), the same fp32 rays): the yardstick for
+        # gradients, which the reference's own fp32 arithmetic misses by up to 6e-3 here
+        drr64 = ref.DRR(subject, renderer=renderer, **geo).to(F64)
+        s64 = source.detach().to(F64).requires_grad_()
+        t64 = target.detach().to(F64).requires_grad_()
+        img64 = drr64.render(drr64.density, s64, t64, **kw)
+        gs64, gt64 = torch.autograd.grad(img64, (s64, t64), go.to(F64))
+        arrays.update({f"{renderer}_img_f64": npy(img64), f"{renderer}_g_source_f64": npy(gs64),
+                       f"{renderer}_g_target_f64": npy(gt64)})
+    save("reference_drr_rays", **arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if sys.argv[1:] == ["swap"]:
+        make_swap_fixture()
+        sys.exit(0)
     make_renderer_fixtures()
     make_drr_fixtures()
     make_pose_fixtures()
     make_registration_fixture()
+    make_swap_fixture()

@@ -99,6 +99,65 @@ def test_headline_bricks_vs_oracle_512_cubed(gpu, storage):
     _check_bricks_against_oracle(gpu, 512, 256, 2.4, 3, seed=4, storage=storage)
 
 
+def sweep_parity(drr, fixed, rot, xyz, images, vals, picks, eps=1e-5):
+    """Sampled poses of a sweep launch against the oracle: image-normalised error of the launch's
+    images vs the oracle's fp32 / fp64 renders of the same rays, and the launch's per-pose NCC
+    against NCC (reference metrics.py:21-44, in float64) of the oracle's images."""
+    def ncc64(a, b):
+        z = lambda x: (x - x.mean()) / np.sqrt(x.var() + eps)  # noqa: E731
+        return float((z(a.astype(np.float64)) * z(b.astype(np.float64))).mean())
+
+    vol = drr.density.cpu().numpy()
+    fx = fixed.reshape(-1).cpu().numpy()
+    res = {"poses": list(picks), "fwd_rel_err": 0.0, "fwd_rel_err_vs_fp64": 0.0,
+           "ref_fp32_fwd_rel_err_vs_fp64": 0.0, "ncc_abs_err": 0.0, "ncc_abs_err_vs_fp64": 0.0}
+    for b in picks:
+        s, t, L = voxel_rays(drr, rot[b:b + 1], xyz[b:b + 1])
+        a32 = (vol, s.cpu().numpy(), t.cpu().numpy(), L.cpu().numpy())
+        r32 = oracle.siddon(*a32)["out"].reshape(-1)
+        r64 = oracle.siddon(*(a.astype(np.float64) for a in a32))["out"].reshape(-1)
+        mine = images[b].reshape(-1).cpu().numpy()
+        res["fwd_rel_err"] = max(res["fwd_rel_err"], rel_err(mine, r32))
+        res["fwd_rel_err_vs_fp64"] = max(res["fwd_rel_err_vs_fp64"], rel_err(mine, r64))
+        res["ref_fp32_fwd_rel_err_vs_fp64"] = max(res["ref_fp32_fwd_rel_err_vs_fp64"], rel_err(r32, r64))
+        v = float(vals[b].item())
+        res["ncc_abs_err"] = max(res["ncc_abs_err"], abs(v - ncc64(fx, r32)))
+        res["ncc_abs_err_vs_fp64"] = max(res["ncc_abs_err_vs_fp64"], abs(v - ncc64(fx, r64)))
+    return res
+
+
+def test_config5_sweep_launch_vs_oracle(gpu):
+    """BASELINE configs[4] at one GPU's launch shape: 512 candidate poses in ONE forward launch
+    at 512^3 -> 256^2 (bench.py --config 5's candidates and chunk size), through
+    diffdrr_amd.dist.sweep; the first, a middle and the last pose of the launch (first / middle /
+    last pose-table chunk of the brick kernel) against the oracle, and their NCC values against
+    NCC of the oracle's images (reference pattern: notebooks/tutorials/metrics.ipynb:97-175,
+    diffdrr/metrics.py:21-44)."""
+    import math
+
+    from diffdrr_amd import dist as ddist
+    from diffdrr_amd.data import make_subject, noise_volume
+
+    drr = DRR(make_subject(noise_volume(512, seed=0), spacing=(1.0, 1.0, 1.0), orientation="AP"),
+              sdd=1020.0, height=256, delx=2.4, renderer="siddon").to(gpu)
+    g = torch.Generator().manual_seed(2)  # bench.py perturbed_poses(4096, seed=2)[:512]
+    rot = ((torch.rand(4096, 3, generator=g) - 0.5) * (math.pi / 2))[:512].to(gpu)
+    xyz = (torch.tensor([0.0, 850.0, 0.0]) + (torch.rand(4096, 3, generator=g) - 0.5) * 60.0)[:512].to(gpu)
+    ncc = NormalizedCrossCorrelation2d()
+    with torch.no_grad():
+        fixed = drr(torch.zeros(1, 3, device=gpu), torch.tensor([[0.0, 850.0, 0.0]], device=gpu),
+                    parameterization="euler_angles", convention="ZXY")
+        vals = ddist.sweep(drr, ncc, fixed, rot, xyz, chunk=512)       # one launch of 512 poses
+        images = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    assert vals.shape == (512,) and torch.isfinite(vals).all()
+    res = sweep_parity(drr, fixed, rot, xyz, images, vals, (0, 255, 511))
+    print(f"[config 5 launch] {res}")
+    assert res["fwd_rel_err"] < FWD_TOL
+    assert res["fwd_rel_err_vs_fp64"] < 2 * res["ref_fp32_fwd_rel_err_vs_fp64"] + 2e-6
+    # NCC of noise-volume DRRs against the AP view is ~0.1; the image error moves it by ~1e-5
+    assert res["ncc_abs_err"] < 1e-4 and res["ncc_abs_err_vs_fp64"] < 1e-4
+
+
 def _pose_gradient_errors(drr, rot, xyz, W):
     """(rot, xyz) gradient of sum(W * DRR): the module on the GPU (fused pose entry, brick
     kernel + record, ddrr_siddon_backward_pose) and the reference's fp32 arithmetic (fp32

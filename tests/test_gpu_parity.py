@@ -895,6 +895,16 @@ def test_volume_gradient_bricks_fixed_point_and_float_paths(gpu):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("renderer", ["siddon", "trilinear"])
+def test_reference_rays_through_swapped_renderers(gpu, renderer):
+    """INTEGRATION.md section 2 on the device: the world-space rays of an unmodified reference
+    ``DRR`` (committed fixture) through ``diffdrr_amd.Siddon`` / ``Trilinear`` with an untrusted
+    ``detector_shape``, image and ray gradients against the reference's own."""
+    from conftest import check_reference_rays_through_swapped_renderer
+
+    check_reference_rays_through_swapped_renderer(renderer, gpu, ops)
+
+
 def test_brick_kernels_many_poses_multi_chunk(gpu):
     """More poses than one pose-table chunk (32): the brick kernels walk the batch in chunks
     with leftovers carried across them; B = 75 -> 3 chunks, against the per-ray kernels."""

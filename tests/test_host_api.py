@@ -729,6 +729,15 @@ def test_detector_grid_trust_ends_with_the_drr_call(emulated_ops, renderer):
     assert not emulated_ops.rays_form_detector_grid(s[:0], t[:0], 22, 30)
 
 
+@pytest.mark.parametrize("renderer", ["siddon", "trilinear"])
+def test_reference_rays_through_swapped_renderers_on_the_host(emulated_ops, renderer):
+    """tests/golden/reference_drr_rays.npz through the product's modules on the host emulation
+    (the GPU twin: tests/test_gpu_parity.py::test_reference_rays_through_swapped_renderers)."""
+    from conftest import check_reference_rays_through_swapped_renderer
+
+    check_reference_rays_through_swapped_renderer(renderer, torch.device("cpu"), emulated_ops)
+
+
 def test_mask_label_cache_is_tied_to_the_mask_object(emulated_ops):
     """A new mask that lands at a freed mask's address must not be served the old labels."""
     from diffdrr_amd.renderers import _labels_u8
