@@ -140,7 +140,12 @@ class OracleChain:
         self.vol = {np.float32: drr.density.detach().cpu().numpy()}
         self.vol[np.float64] = self.vol[np.float32].astype(np.float64)
 
-    def __call__(self, rot_b, xyz_b, weights, dtype):
+    def __call__(self, rot_b, xyz_b, rays32, weights, dtype):
+        """rays32: the fp32 voxel-space rays (s, t, L) the kernels rendered for this pose -- the
+        oracle renders exactly those (in `dtype` arithmetic); the float64 ray generation only
+        supplies the Jacobian d rays / d pose.  (On a noise volume an image changes by 1e-4 of its
+        scale at single pixels when ray endpoints move by one fp32 ulp: rays gliding along voxel
+        planes.  Parity is about the renderer, so both sides get the same rays.)"""
         import numpy as np
 
         import oracle
@@ -152,8 +157,7 @@ class OracleChain:
         source, target = self.detector(pose, None)
         L = (target - source).norm(dim=-1)
         s, t = self.affine_inverse(source), self.affine_inverse(target)
-        o = oracle.siddon(self.vol[dtype], s.detach().numpy().astype(dtype),
-                          t.detach().numpy().astype(dtype), L.detach().numpy().astype(dtype),
+        o = oracle.siddon(self.vol[dtype], *(np.asarray(a, dtype) for a in rays32),
                           grad_out=np.asarray(weights, dtype).reshape(1, -1))
         as64 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64))  # noqa: E731
         ((as64(o["g_source"]) * s).sum() + (as64(o["g_target"]) * t).sum()
@@ -211,11 +215,18 @@ def pose_parity(drr, rot, xyz, images, g_rot, g_xyz, base, n_par):
         mine = images[b].reshape(-1).cpu().numpy()
         # d loss / d image of this pose, at the exact image (the step's own weights differ from
         # these by the image error, 1e-5)
-        _, _, img64 = chain(rot[b], xyz[b], np.zeros(mine.size), np.float64)
+        rays32 = tuple(a.cpu().numpy() for a in voxel_rays(drr, rot[b:b + 1], xyz[b:b + 1]))
+        _, _, img64 = chain(rot[b], xyz[b], rays32, np.zeros(mine.size), np.float64)
         W = _ncc_grad64(fx, img64)
-        gr64, gx64, img64 = chain(rot[b], xyz[b], W, np.float64)
-        gr32, gx32, img32 = chain(rot[b], xyz[b], W, np.float32)
-        out["fwd_rel_err"] = max(out["fwd_rel_err"], rel(mine, img32.astype(np.float64)))
+        gr64, gx64, img64 = chain(rot[b], xyz[b], rays32, W, np.float64)
+        gr32, gx32, img32 = chain(rot[b], xyz[b], rays32, W, np.float32)
+        # against the reference's fp32 image where that image is itself within 1e-4 of the exact
+        # one (rays gliding along voxel planes: the fp32 reference is up to 6e-4 off at single
+        # pixels of these scenes); everywhere against the exact image
+        ok = np.abs(img32 - img64) <= 1e-4 * np.abs(img32).max()
+        out["fwd_rel_err"] = max(out["fwd_rel_err"],
+                                 float(np.abs(mine - img32)[ok].max() / np.abs(img32).max()))
+        out["ref_off_pixels"] = out.get("ref_off_pixels", 0) + int((~ok).sum())
         out["fwd_rel_err_vs_fp64"] = max(out["fwd_rel_err_vs_fp64"], rel(mine, img64))
         out["ref_fp32_fwd_rel_err_vs_fp64"] = max(out["ref_fp32_fwd_rel_err_vs_fp64"], rel(img32, img64))
         truth = np.concatenate([gr64, gx64 * 100.0])  # (mm -> comparable scale with radians)
@@ -250,7 +261,9 @@ def sweep_parity(drr, fixed, rot, xyz, images, vals, picks, eps=1e-5):
         r32 = oracle.siddon(*a32)["out"].reshape(-1)
         r64 = oracle.siddon(*(a.astype(np.float64) for a in a32))["out"].reshape(-1)
         mine = images[b].reshape(-1).cpu().numpy()
-        res["fwd_rel_err"] = max(res["fwd_rel_err"], rel(mine, r32.astype(np.float64)))
+        ok = np.abs(r32 - r64) <= 1e-4 * np.abs(r32).max()  # (the fp32 reference itself within 1e-4)
+        res["fwd_rel_err"] = max(res["fwd_rel_err"], float(np.abs(mine - r32)[ok].max() / np.abs(r32).max()))
+        res["ref_off_pixels"] = res.get("ref_off_pixels", 0) + int((~ok).sum())
         res["fwd_rel_err_vs_fp64"] = max(res["fwd_rel_err_vs_fp64"], rel(mine, r64))
         res["ref_fp32_fwd_rel_err_vs_fp64"] = max(res["ref_fp32_fwd_rel_err_vs_fp64"], rel(r32, r64))
         v = float(vals[b].item())
@@ -697,7 +710,9 @@ def main():
                 "gradients: the oracle's analytic ray gradients chained through float64 ray "
                 "generation to (rot, xyz[mm] x 100) of the timed step's own backward")
             result["parity"]["tolerance"] = (
-                "fwd_rel_err <= 1e-4; *_vs_fp64 <= 2 x the reference's own fp32 error + 1e-3")
+                "fwd_rel_err <= 1e-4 (at the pixels where the fp32 reference is itself within 1e-4 of "
+                "fp64; ref_off_pixels counts the others), fwd_rel_err_vs_fp64 <= 1e-4 everywhere; "
+                "pose_grad_rel_err_vs_fp64 <= 2 x the reference's own fp32 error + 1e-3")
             # the same check where gradients are not tie-breaking noise: a phantom volume, absolute bound
             ph = set_storage(DRR(synthetic_subject(D, kind="phantom", seed=0), sdd=1020.0, height=H,
                                  delx=delx, renderer="siddon").to(device))

@@ -117,7 +117,9 @@ def sweep_parity(drr, fixed, rot, xyz, images, vals, picks, eps=1e-5):
         r32 = oracle.siddon(*a32)["out"].reshape(-1)
         r64 = oracle.siddon(*(a.astype(np.float64) for a in a32))["out"].reshape(-1)
         mine = images[b].reshape(-1).cpu().numpy()
-        res["fwd_rel_err"] = max(res["fwd_rel_err"], rel_err(mine, r32))
+        ok = np.abs(r32 - r64) <= 1e-4 * np.abs(r32).max()  # (the fp32 reference itself within 1e-4)
+        res["fwd_rel_err"] = max(res["fwd_rel_err"], float(np.abs(mine - r32)[ok].max() / np.abs(r32).max()))
+        res["ref_off_pixels"] = res.get("ref_off_pixels", 0) + int((~ok).sum())
         res["fwd_rel_err_vs_fp64"] = max(res["fwd_rel_err_vs_fp64"], rel_err(mine, r64))
         res["ref_fp32_fwd_rel_err_vs_fp64"] = max(res["ref_fp32_fwd_rel_err_vs_fp64"], rel_err(r32, r64))
         v = float(vals[b].item())
@@ -152,7 +154,8 @@ def test_config5_sweep_launch_vs_oracle(gpu):
     assert vals.shape == (512,) and torch.isfinite(vals).all()
     res = sweep_parity(drr, fixed, rot, xyz, images, vals, (0, 255, 511))
     print(f"[config 5 launch] {res}")
-    assert res["fwd_rel_err"] < FWD_TOL
+    assert res["fwd_rel_err"] < FWD_TOL and res["fwd_rel_err_vs_fp64"] < FWD_TOL
+    assert res["ref_off_pixels"] <= 1e-4 * 3 * 256 * 256  # (fp32 reference > 1e-4 off: gliding rays)
     assert res["fwd_rel_err_vs_fp64"] < 2 * res["ref_fp32_fwd_rel_err_vs_fp64"] + 2e-6
     # NCC of noise-volume DRRs against the AP view is ~0.1; the image error moves it by ~1e-5
     assert res["ncc_abs_err"] < 1e-4 and res["ncc_abs_err_vs_fp64"] < 1e-4
