@@ -10,6 +10,7 @@ __version__ = "0.1.0"
 from .detector import Detector  # noqa: F401
 from .drr import DRR  # noqa: F401
 from .metrics import (  # noqa: F401
+    GradientNormalizedCrossCorrelation2d,
     MultiscaleNormalizedCrossCorrelation2d,
     NormalizedCrossCorrelation2d,
 )

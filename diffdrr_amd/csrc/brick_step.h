@@ -243,6 +243,17 @@ DDRR_HD int step_walk(const Fetch &fetch, const StepGeom &G, const StepEntry &E,
     // The build also passes -fno-slp-vectorize: v_pk_*_f32 issue at half rate on gfx950, and
     // the packed forms cost register shuffles on top.  Together 1.39 -> 1.30 ms forward.)
     int it = 0;
+#if defined(DDRR_WALK_CHECK4)
+#pragma unroll 1
+    for (; it < MAXSTEPS; it += 4) {
+        DDRR_STEP()
+        DDRR_STEP()
+        DDRR_STEP()
+        DDRR_STEP()
+        if (!__builtin_amdgcn_ballot_w64(live != 0.f)) break;
+    }
+    if (false)
+#endif
 #pragma unroll 2
     for (; it < MAXSTEPS; it += 2) {
         DDRR_STEP()

@@ -139,14 +139,39 @@ template <bool AUX, class C>
 __device__ __forceinline__ void fwd_item(const BrickArgs &p, unsigned lds_base,
                                          const StepGeom &SG, const Q16Range &range, bool active,
                                          unsigned b, unsigned pix, float *__restrict__ out,
-                                         float *__restrict__ aux, BrickProf &prof) {
+                                         float *__restrict__ aux, BrickProf &prof,
+                                         const FwdRow *rows = nullptr, int b0 = 0) {
     const unsigned r = b * (unsigned)(p.det_h * p.det_w) + pix;
     float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     bool ok = false;
     if (active) {
         const float *sp = p.source + b * 3u, *tp = p.target + r * 3u;
-        const float s[3] = {sp[0], sp[1], sp[2]}, t[3] = {tp[0], tp[1], tp[2]};
-        const float L = (!AUX && p.img) ? p.img[r] : 1.f;
+        float s[3], t[3], L = 1.f;
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+        if ((p.dbg & 256) && rows) {
+            // (timing experiment: NO ray loads -- the ray from the pose's affine detector model in
+            // the LDS row table, target = s + D0 + i ei + j ej; results differ in the last bits)
+            const FwdRow &w = rows[b - b0];
+            const float fi = floorf(((float)pix + 0.5f) / (float)p.det_w);
+            const float fj = (float)pix - fi * (float)p.det_w;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                s[a] = (float)(a == 0 ? SG.lof[0] : (a == 1 ? SG.lof[1] : SG.lof[2])) - 0.01f - p.shift -
+                       w.P0[a];  // P0 = (lo - margin) - shift - s
+                t[a] = s[a] + (fmaf(fj, w.ej[a], fmaf(fi, w.ei[a], w.D0[a])) - p.eps);
+            }
+            L = sqrtf((t[0] - s[0]) * (t[0] - s[0]) + (t[1] - s[1]) * (t[1] - s[1]) +
+                      (t[2] - s[2]) * (t[2] - s[2]));
+        } else
+#endif
+        {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                s[a] = sp[a];
+                t[a] = tp[a];
+            }
+            L = (!AUX && p.img) ? p.img[r] : 1.f;
+        }
         DDRR_PROF_WAIT_VMEM();
         DDRR_PROF(PROF_LOADS);
         StepEntry E = step_enter(SG, s, t, p.shift, p.eps, lds_base);
@@ -410,7 +435,7 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
                     DDRR_PROF(PROF_POP);
                     DDRR_PROF_COUNT(PROF_N_BATCH, 1);
                     fwd_item<AUX, C>(p, lds_base, SG, range, lane < n, e >> p.pix_bits,
-                                     e & pix_mask, out, aux, prof);
+                                     e & pix_mask, out, aux, prof, rows, b0);
                     wave_fence();
                 }
                 if (drain) break;

@@ -5,6 +5,7 @@
 #include "raygen_core.h"
 #include "record_pack.h"
 #include "record_layout.h"
+#include "sobel_core.h"
 
 using namespace ddrr;
 using namespace ddrr_rt;
@@ -226,9 +227,51 @@ __global__ __launch_bounds__(kBlock) void ncc_bwd_kernel(
     if (g_x1) g_x1[(long)b * N + n] = g * (z2 - z1 * ncc) / s1;
 }
 
+// ------------------------------------------------- Sobel pair (gradient NCC)
+// out (B, 2, H, W) = {Gx, Gy} * img (B, H, W), zero padding (sobel_core.h); one pixel per thread
+__global__ __launch_bounds__(kBlock) void sobel_fwd_kernel(const float *__restrict__ img, int H,
+                                                           int W, float *__restrict__ out) {
+    const int b = blockIdx.y, n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= H * W) return;
+    const int i = n / W, j = n - i * W;
+    float gx, gy;
+    sobel_pixel(img + (long)b * H * W, H, W, i, j, gx, gy);
+    out[((long)b * 2) * H * W + n] = gx;
+    out[((long)b * 2 + 1) * H * W + n] = gy;
+}
+
+__global__ __launch_bounds__(kBlock) void sobel_bwd_kernel(const float *__restrict__ g, int H, int W,
+                                                           float *__restrict__ g_img) {
+    const int b = blockIdx.y, n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= H * W) return;
+    const int i = n / W, j = n - i * W;
+    const float *gx = g + ((long)b * 2) * H * W;
+    g_img[(long)b * H * W + n] = sobel_pixel_adjoint(gx, gx + (long)H * W, H, W, i, j);
+}
+
 }  // namespace
 
 extern "C" {
+
+int ddrr_sobel_forward(const float *img, int B, int H, int W, float *out, void *stream) {
+    if (!img || !out) return fail(-1, "null pointer");
+    if (B < 0 || H < 1 || W < 1) return fail(-1, "bad batch / image size");
+    if (B == 0) return 0;
+    if (B > 65535) return fail(-1, "at most 65535 images per call");
+    hipLaunchKernelGGL(sobel_fwd_kernel, dim3((H * W + kBlock - 1) / kBlock, B), dim3(kBlock), 0,
+                       (hipStream_t)stream, img, H, W, out);
+    return finish("ddrr_sobel_forward");
+}
+
+int ddrr_sobel_backward(const float *g_out, int B, int H, int W, float *g_img, void *stream) {
+    if (!g_out || !g_img) return fail(-1, "null pointer");
+    if (B < 0 || H < 1 || W < 1) return fail(-1, "bad batch / image size");
+    if (B == 0) return 0;
+    if (B > 65535) return fail(-1, "at most 65535 images per call");
+    hipLaunchKernelGGL(sobel_bwd_kernel, dim3((H * W + kBlock - 1) / kBlock, B), dim3(kBlock), 0,
+                       (hipStream_t)stream, g_out, H, W, g_img);
+    return finish("ddrr_sobel_backward");
+}
 
 int ddrr_raygen_forward(const float *Mw, const float *Ainv, const float *P, int B, int N,
                         float *source_v, float *target_v, float *img, void *stream) {

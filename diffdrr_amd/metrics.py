@@ -1,8 +1,9 @@
-"""Image similarity used by the registration / sweep paths.
+"""Image similarities of the registration / sweep paths.
 
-Only normalised cross-correlation is on the path BASELINE.json's configs 4-5
-exercise (reference ``diffdrr/metrics.py:16-63``); gradient-NCC, mutual
-information and the geodesic pose metrics are out of scope.
+Normalised cross-correlation -- whole-image, patch-wise, multiscale -- and its gradient
+variant (reference ``diffdrr/metrics.py:16-104``); mutual information and the geodesic pose
+metrics are out of scope.  Pinned to ``tests/golden/metrics.npz``, values
+and autograd gradients of the unmodified reference.
 """
 from __future__ import annotations
 
@@ -75,13 +76,81 @@ class NormalizedCrossCorrelation2d(torch.nn.Module):
         return (x - mu) / var.sqrt()
 
 
+class _SobelFn(torch.autograd.Function):
+    """(B, 1, H, W) -> (B, 2, H, W) Sobel responses, zero padding: ddrr_sobel_forward / its
+    adjoint ddrr_sobel_backward (reference metrics.py:69-94, torch.nn.Conv2d(1, 2, 3, padding=1))."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.sobel_forward(x[:, 0])
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.sobel_backward(g).unsqueeze(1)
+
+
+def gaussian_blur(img, kernel_size, sigma):
+    """torchvision.transforms.functional.gaussian_blur as the reference's ``Sobel`` calls it
+    (metrics.py:66, 88-92; torchvision is a third-party dependency that is neither vendored by
+    the reference nor installed here: restated from its published algorithm): taps exp(-x^2 / 2 sigma^2) on
+    linspace(-(k-1)/2, (k-1)/2, k), normalised, separable, REFLECT padding by k // 2.  A few tensor
+    ops on (B, 1, H, W) images; differentiable by autograd."""
+    half = (kernel_size - 1) * 0.5
+    x = torch.linspace(-half, half, steps=kernel_size, dtype=img.dtype, device=img.device)
+    k1 = torch.exp(-0.5 * (x / sigma).pow(2))
+    k1 = k1 / k1.sum()
+    c = img.shape[-3]
+    kernel = torch.mm(k1[:, None], k1[None, :]).expand(c, 1, kernel_size, kernel_size)
+    pad = [kernel_size // 2] * 4
+    return torch.nn.functional.conv2d(torch.nn.functional.pad(img, pad, mode="reflect"), kernel, groups=c)
+
+
+class Sobel(torch.nn.Module):
+    """Optional Gaussian blur, then the x / y Sobel responses (reference metrics.py:69-94)."""
+
+    def __init__(self, sigma: float):
+        super().__init__()
+        self.sigma = sigma
+
+    def forward(self, img):
+        x = img
+        if self.sigma > 0:
+            x = gaussian_blur(img, int(6 * self.sigma + 1) | 1, self.sigma)
+        if (x.shape[1] == 1 and ops.on_device(x) and x.dtype == torch.float32):
+            return _SobelFn.apply(x)
+        Gx = torch.tensor([[1, 0, -1], [2, 0, -2], [1, 0, -1]], dtype=x.dtype, device=x.device)
+        Gy = torch.tensor([[1, 2, 1], [0, 0, 0], [-1, -2, -1]], dtype=x.dtype, device=x.device)
+        return torch.nn.functional.conv2d(x, torch.stack([Gx, Gy]).unsqueeze(1), padding=1)
+
+
+class GradientNormalizedCrossCorrelation2d(NormalizedCrossCorrelation2d):
+    """NCC between the image gradients of two batches of images (reference metrics.py:97-104):
+    the Sobel pair by one kernel each way, the two channels' whole-image NCCs by the fused NCC
+    kernels (their mean is the reference's sum over (c, h, w) / (c h w))."""
+
+    def __init__(self, patch_size=None, sigma=1.0, **kwargs):
+        super().__init__(patch_size, **kwargs)
+        self.sobel = Sobel(sigma)
+
+    def forward(self, x1, x2):
+        g1, g2 = self.sobel(x1), self.sobel(x2)
+        b, c, h, w = g2.shape
+        if (self.patch_size is None and c == 2 and ops.on_device(g2) and g1.shape == g2.shape
+                and g2.dtype == torch.float32):
+            # every channel is z-scored on its own: 2 B single-channel pairs for the fused kernels
+            val = _NCCFn.apply(g1.reshape(b * c, h * w), g2.reshape(b * c, h * w), self.eps)
+            return val.reshape(b, c).mean(dim=1)
+        return super().forward(g1, g2)
+
+
 class MultiscaleNormalizedCrossCorrelation2d(torch.nn.Module):
     """Weighted sum of NCCs at several patch sizes (``None`` = whole image)."""
 
     def __init__(self, patch_sizes=[None], patch_weights=[1.0], eps=1e-5):
         super().__init__()
         assert len(patch_sizes) == len(patch_weights), "Each scale must have a weight"
-        self.nccs = [NormalizedCrossCorrelation2d(p, eps) for p in patch_sizes]
+        # (like the reference, metrics.py:53-55, the members keep the default eps)
+        self.nccs = [NormalizedCrossCorrelation2d(p) for p in patch_sizes]
         self.patch_weights = patch_weights
 
     def forward(self, x1, x2):

@@ -320,6 +320,27 @@ def ncc_backward(x1, x2, stats, g_out, want_x1, want_x2):
     return g_x1, g_x2
 
 
+def sobel_forward(img):
+    """img (B, H, W) -> (B, 2, H, W): the Sobel x / y responses (reference metrics.py:69-94)."""
+    _require_gpu(img)
+    B, H, W = img.shape
+    img = img.contiguous()
+    out = torch.empty(B, 2, H, W, dtype=torch.float32, device=img.device)
+    if B:
+        _launch("ddrr_sobel_forward", img.device, img.data_ptr(), B, H, W, out.data_ptr())
+    return out
+
+
+def sobel_backward(g_out):
+    """Adjoint of :func:`sobel_forward`: g_out (B, 2, H, W) -> (B, H, W)."""
+    B, _, H, W = g_out.shape
+    g_out = g_out.contiguous()
+    g_img = torch.empty(B, H, W, dtype=torch.float32, device=g_out.device)
+    if B:
+        _launch("ddrr_sobel_backward", g_out.device, g_out.data_ptr(), B, H, W, g_img.data_ptr())
+    return g_img
+
+
 def raygen_forward(Mw, Ainv, P):
     """Fused ray generation (detector.py:151-153 + drr.py:201-205).  Mw (B,3,4) world pose
     per DRR, Ainv (3,4) world -> voxel, P (N,3) calibrated detector points.

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 20
+#define DDRR_ABI_VERSION 21
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -356,6 +356,13 @@ int ddrr_ncc_forward(const float *x1, long x1_stride, const float *x2, int B, in
 /* Gradient of ddrr_ncc_forward w.r.t. x2 (and x1 unless shared); either may be NULL. */
 int ddrr_ncc_backward(const float *x1, long x1_stride, const float *x2, const float *stats,
                       const float *g_out, int B, int N, float *g_x1, float *g_x2, void *stream);
+
+/* The Sobel pair in front of GradientNormalizedCrossCorrelation2d (reference metrics.py:69-94:
+ * Conv2d(1, 2, 3, padding=1) with Gx = [[1,0,-1],[2,0,-2],[1,0,-1]], Gy = [[1,2,1],[0,0,0],
+ * [-1,-2,-1]], zero padding): img (B, H, W) -> out (B, 2, H, W), and its adjoint g_out (B, 2, H, W)
+ * -> g_img (B, H, W).  The similarity itself is ddrr_ncc_forward over the 2 B channel images. */
+int ddrr_sobel_forward(const float *img, int B, int H, int W, float *out, void *stream);
+int ddrr_sobel_backward(const float *g_out, int B, int H, int W, float *g_img, void *stream);
 
 /* ---- double precision ---------------------------------------------------------------------
  * The reference computes in the dtype its module holds: `DRR(...).to(torch.float64)` renders and

@@ -125,6 +125,40 @@ def check_reference_rays_through_swapped_renderer(renderer, device, ops):
     assert close(gt) >= close(rt) - 0.01 and close(gt) > 0.97
 
 
+def check_metrics_against_reference(device):
+    """diffdrr_amd.metrics against tests/golden/metrics.npz: values and autograd gradients of the
+    UNMODIFIED reference's NormalizedCrossCorrelation2d (whole image / patch_size),
+    MultiscaleNormalizedCrossCorrelation2d and GradientNormalizedCrossCorrelation2d
+    (diffdrr/metrics.py:21-104).  Yardstick: the reference in float64; allowance: twice what the
+    reference's own float32 evaluation loses, + 2e-6 (values) / 2e-5 of the largest gradient."""
+    import torch
+
+    from diffdrr_amd import metrics as M
+
+    g = golden("metrics")
+    T = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).to(device)  # noqa: E731
+    w = T(g["w"])
+    cases = {
+        "ncc": M.NormalizedCrossCorrelation2d(),
+        "ncc_patch5": M.NormalizedCrossCorrelation2d(patch_size=5),
+        "multiscale": M.MultiscaleNormalizedCrossCorrelation2d([None, 7], [0.5, 0.5]),
+        "gncc_sigma0": M.GradientNormalizedCrossCorrelation2d(sigma=0.0),
+        "gncc_sigma1": M.GradientNormalizedCrossCorrelation2d(sigma=1.0),
+        "gncc_patch7_sigma0": M.GradientNormalizedCrossCorrelation2d(patch_size=7, sigma=0.0),
+    }
+    assert rel_err(M.Sobel(0.0)(T(g["a"])).cpu().numpy(), g["sobel_a"]) < 1e-6
+    for name, crit in cases.items():
+        x1, x2 = T(g["a"]).requires_grad_(), T(g["b"]).requires_grad_()
+        val = crit(x1, x2)
+        (val * w).sum().backward()
+        v64 = g[f"{name}_f64"]
+        assert np.abs(val.detach().cpu().numpy() - v64).max() <= \
+            2 * np.abs(g[f"{name}_f32"] - v64).max() + 2e-6, name
+        for mine, key in ((x1.grad, "g1"), (x2.grad, "g2")):
+            e64, r32 = g[f"{name}_{key}_f64"], g[f"{name}_{key}_f32"]
+            assert rel_err(mine.cpu().numpy(), e64) < 2 * rel_err(r32, e64) + 2e-5, (name, key)
+
+
 def has_gpu():
     try:
         import torch

@@ -23,6 +23,7 @@
 #include "../../diffdrr_amd/csrc/record_pack.h"
 #include "../../diffdrr_amd/csrc/record_layout.h"
 #include "../../diffdrr_amd/csrc/segments_core.h"
+#include "../../diffdrr_amd/csrc/sobel_core.h"
 #include "../../diffdrr_amd/csrc/tri_brick.h"
 #include "../../diffdrr_amd/csrc/trilinear_core.h"
 #include "../../diffdrr_amd/csrc/f64_core.h"
@@ -1079,6 +1080,24 @@ int ddrr_siddon_backward_pose(const float *aux, int aux_layout, const float *gra
         }
         memcpy(gMw + (long)b * 12, acc, sizeof(acc));
     }
+    return 0;
+}
+
+int ddrr_sobel_forward(const float *img, int B, int H, int W, float *out, void *) {
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < W; ++j)
+                sobel_pixel(img + (long)b * H * W, H, W, i, j, out[((long)b * 2) * H * W + i * W + j],
+                            out[((long)b * 2 + 1) * H * W + i * W + j]);
+    return 0;
+}
+
+int ddrr_sobel_backward(const float *g, int B, int H, int W, float *g_img, void *) {
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < W; ++j)
+                g_img[(long)b * H * W + i * W + j] = sobel_pixel_adjoint(
+                    g + ((long)b * 2) * H * W, g + ((long)b * 2 + 1) * H * W, H, W, i, j);
     return 0;
 }
 

@@ -412,13 +412,56 @@ def make_swap_fixture():
     save("reference_drr_rays", **arrays)
 
 
+def make_metrics_fixture():
+    """Image similarities of the reference (diffdrr/metrics.py:21-104) with autograd gradients:
+    NormalizedCrossCorrelation2d whole-image and patch-wise, the multiscale sum, and
+    GradientNormalizedCrossCorrelation2d (Sobel :69-94) without blur (sigma = 0: the reference's
+    own code only) and with the default sigma = 1 (whose Gaussian is torchvision's
+    ``gaussian_blur``, absent here and restated in oracle/ref_shims from its published
+    algorithm)."""
+    g = torch.Generator().manual_seed(80)
+    B, H, W = 3, 24, 20
+    # smooth structure + noise, a shifted / rescaled partner: similarities well away from 0 and 1
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+    base = torch.stack([torch.exp(-3 * ((yy - 0.2 * k) ** 2 + (xx + 0.1 * k) ** 2)) for k in range(B)])
+    a = (base + 0.15 * torch.rand(B, H, W, generator=g)).unsqueeze(1)
+    b = (1.7 * base.roll(1, dims=-1) + 0.3 + 0.2 * torch.rand(B, H, W, generator=g)).unsqueeze(1)
+    w = torch.rand(B, generator=g)  # weights of the per-pair values in the scalar loss
+    arrays = {"a": npy(a), "b": npy(b), "w": npy(w)}
+    M = ref.metrics
+    cases = {
+        "ncc": M.NormalizedCrossCorrelation2d(),
+        "ncc_patch5": M.NormalizedCrossCorrelation2d(patch_size=5),
+        "multiscale": M.MultiscaleNormalizedCrossCorrelation2d([None, 7], [0.5, 0.5]),
+        "gncc_sigma0": M.GradientNormalizedCrossCorrelation2d(sigma=0.0),
+        "gncc_sigma1": M.GradientNormalizedCrossCorrelation2d(sigma=1.0),
+        "gncc_patch7_sigma0": M.GradientNormalizedCrossCorrelation2d(patch_size=7, sigma=0.0),
+    }
+    for name, crit in cases.items():
+        for dtype, tag in ((F32, "f32"), (F64, "f64")):
+            crit = crit.to(dtype) if hasattr(crit, "to") else crit
+            x1 = a.to(dtype).clone().requires_grad_()
+            x2 = b.to(dtype).clone().requires_grad_()
+            val = crit(x1, x2)
+            g1, g2 = torch.autograd.grad((val * w.to(dtype)).sum(), (x1, x2))
+            arrays.update({f"{name}_{tag}": npy(val), f"{name}_g1_{tag}": npy(g1),
+                           f"{name}_g2_{tag}": npy(g2)})
+    sob = M.Sobel(0.0)
+    arrays["sobel_a"] = npy(sob(a))
+    save("metrics", **arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     if sys.argv[1:] == ["swap"]:
         make_swap_fixture()
+        sys.exit(0)
+    if sys.argv[1:] == ["metrics"]:
+        make_metrics_fixture()
         sys.exit(0)
     make_renderer_fixtures()
     make_drr_fixtures()
     make_pose_fixtures()
     make_registration_fixture()
     make_swap_fixture()
+    make_metrics_fixture()

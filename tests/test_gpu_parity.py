@@ -905,6 +905,15 @@ def test_reference_rays_through_swapped_renderers(gpu, renderer):
     check_reference_rays_through_swapped_renderer(renderer, gpu, ops)
 
 
+def test_metrics_match_reference_on_the_gpu(gpu):
+    """ddrr_ncc_* and ddrr_sobel_* through diffdrr_amd.metrics against the reference's values and
+    autograd gradients (tests/golden/metrics.npz: NCC whole image / patch / multiscale,
+    gradient-NCC with and without the Gaussian)."""
+    from conftest import check_metrics_against_reference
+
+    check_metrics_against_reference(gpu)
+
+
 def test_brick_kernels_many_poses_multi_chunk(gpu):
     """More poses than one pose-table chunk (32): the brick kernels walk the batch in chunks
     with leftovers carried across them; B = 75 -> 3 chunks, against the per-ray kernels."""

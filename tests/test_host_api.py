@@ -209,6 +209,15 @@ def test_ncc_matches_reference():
                    g["ncc_ab_patch5"]) < 1e-5
 
 
+def test_metrics_match_reference_values_and_gradients(emulated_ops):
+    """NCC (whole image, patch-wise, multiscale) and gradient-NCC against the fixture made from the
+    unmodified reference's metrics.py (host emulation of the Sobel / NCC kernels; GPU twin:
+    tests/test_gpu_parity.py::test_metrics_match_reference_on_the_gpu)."""
+    from conftest import check_metrics_against_reference
+
+    check_metrics_against_reference(torch.device("cpu"))
+
+
 @pytest.mark.parametrize("storage", ["f32", "q16"])
 @pytest.mark.parametrize("stop", [False, True])
 def test_registration_trajectory_matches_reference(emulated_ops, stop, storage):
