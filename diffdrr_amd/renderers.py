@@ -52,18 +52,32 @@ def _labels_u8(mask: torch.Tensor):
     """Label map as uint8 + channel count (reference: ``C = int(mask.max()) + 1``,
     renderers.py:81 -- a host sync per call there; cached per mask TENSOR here: the entry is
     tied to the live object by a weak reference and dropped with it, so that a new mask that
-    happens to land at a freed mask's address can never be served the old labels)."""
+    happens to land at a freed mask's address can never be served the old labels).
+    -> list of (uint8 labels, channels, first channel kept) chunks: the kernels take one byte
+    per label, so a map with more than 256 labels is rendered ~255 labels at a time and the
+    channel blocks are concatenated (the reference takes any ``mask.max()``).  The first chunk
+    holds labels 0 .. 254 as they are (255 = a label of a later chunk: no channel); later chunks
+    hold their labels as 1 .. n with 0 = everything else -- including the marcher's samples
+    outside the volume, which the lookup's zero padding gives label 0 -- and drop channel 0."""
     ent = _label_cache.get(id(mask))
     if ent is not None and ent[0]() is mask and ent[1] == mask._version:
-        return ent[2], ent[3]
+        return ent[2]
     C = int(mask.max().item()) + 1
-    if C > 256:
-        raise NotImplementedError("mask_to_channels supports at most 256 labels")
-    lab = mask.to(torch.uint8).contiguous()
+    if C <= 256:
+        chunks = [(mask.to(torch.uint8).contiguous(), C, 0)]
+    else:
+        lab = mask.to(torch.int64)
+        chunks = [(torch.where(lab < 255, lab, torch.full_like(lab, 255)).to(torch.uint8).contiguous(),
+                   255, 0)]
+        for c0 in range(255, C, 254):
+            n = min(254, C - c0)
+            inside = (lab >= c0) & (lab < c0 + n)
+            chunks.append((torch.where(inside, lab - c0 + 1, torch.zeros_like(lab))
+                           .to(torch.uint8).contiguous(), n + 1, 1))
     key = id(mask)
     _label_cache[key] = (weakref.ref(mask, lambda _, k=key: _label_cache.pop(k, None)),
-                         mask._version, lab, C)
-    return lab, C
+                         mask._version, chunks)
+    return chunks
 
 
 def _volume_gradient(volume, source, target, img, grad_out, cfg):
@@ -478,9 +492,9 @@ class Siddon(torch.nn.Module):
         -> (B, 1, N), or (B, C, N) with a mask."""
         cfg = self._cfg(False)
         if mask is not None:
-            labels, C = _labels_u8(mask)
             source, target, img = _RaygenFn.apply(Mw, P, Ainv)
-            return _SiddonChannelsFn.apply(volume, source, target, img, labels, C, cfg)
+            return torch.cat([_SiddonChannelsFn.apply(volume, source, target, img, labels, C, cfg)[:, k0:]
+                              for labels, C, k0 in _labels_u8(mask)], dim=1)
         return _SiddonPoseFn.apply(volume, Mw, P, Ainv, cfg).unsqueeze(1)
 
     def forward(self, volume, source, target, img, align_corners=False, mask=None):
@@ -513,8 +527,9 @@ class Siddon(torch.nn.Module):
         if cfg["lookup"] != "step" or self.reducefn != "sum":
             raise NotImplementedError(
                 "mask_to_channels needs mode='nearest', align_corners=False, reducefn='sum'")
-        labels, C = _labels_u8(mask)
-        return _SiddonChannelsFn.apply(volume, source, target, img.reshape(B, N), labels, C, cfg)
+        return torch.cat([_SiddonChannelsFn.apply(volume, source, target, img.reshape(B, N), labels,
+                                                  C, cfg)[:, k0:]
+                          for labels, C, k0 in _labels_u8(mask)], dim=1)
 
 
 def get_alpha_minmax(source, target, dims, voxel_shift, eps):
@@ -780,11 +795,11 @@ class Trilinear(torch.nn.Module):
             if self.mode != "bilinear" or self.reducefn != "sum":
                 raise NotImplementedError(
                     "mask_to_channels needs mode='bilinear' and reducefn='sum'")
-            labels, C = _labels_u8(mask)
             ccfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift, "eps": self.eps,
                     "align_corners": bool(align_corners), "det": det, "tile": self.tile}
-            return _TrilinearChannelsFn.apply(volume, source, target, img.reshape(B, N), alphamin,
-                                              alphamax, labels, C, ccfg)
+            return torch.cat([_TrilinearChannelsFn.apply(volume, source, target, img.reshape(B, N),
+                                                         alphamin, alphamax, labels, C, ccfg)[:, k0:]
+                              for labels, C, k0 in _labels_u8(mask)], dim=1)
         cfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift, "eps": self.eps,
                "reducefn": self.reducefn, "mode": self.mode,
                "align_corners": bool(align_corners), "det": det, "tile": self.tile,

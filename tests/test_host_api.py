@@ -756,15 +756,45 @@ def test_mask_label_cache_is_tied_to_the_mask_object(emulated_ops):
         n = 3 + trial % 5
         mask = torch.randint(0, n, (6, 6, 6), generator=torch.Generator().manual_seed(trial)).float()
         mask[0, 0, 0] = n - 1
-        lab, C = _labels_u8(mask)
+        (lab, C, _), = _labels_u8(mask)
         assert C == n and torch.equal(lab.float(), mask)
         seen.append(C)
         del mask, lab
     a = torch.zeros(4, 4, 4)
-    lab0, C0 = _labels_u8(a)
+    (lab0, C0, _), = _labels_u8(a)
     a[0, 0, 0] = 2                      # in-place change: the version moves
-    lab1, C1 = _labels_u8(a)
+    (lab1, C1, _), = _labels_u8(a)
     assert (C0, C1) == (1, 3)
+
+
+@pytest.mark.parametrize("renderer", ["siddon", "trilinear"])
+def test_more_than_256_labels_render_in_chunks(emulated_ops, renderer):
+    """The reference takes any ``mask.max()`` (renderers.py:81); the kernels take one byte per
+    label, so a map with 300 labels is rendered 255 labels at a time: same channels as the
+    plain render split by label, and differentiable."""
+    from diffdrr_amd import Siddon, Trilinear
+
+    g = torch.Generator().manual_seed(5)
+    vol = torch.rand(12, 10, 14, generator=g)
+    mask = torch.randint(0, 300, vol.shape, generator=g).float()
+    mask[0, 0, 0] = 299
+    src = torch.tensor([[[-30.0, 4.0, 6.0]]])
+    tgt = torch.stack([torch.full((40,), 45.0), torch.linspace(1, 9, 40), torch.linspace(2, 12, 40)], -1)[None]
+    img = (tgt - src).norm(dim=-1).unsqueeze(1)
+    mod = (Siddon if renderer == "siddon" else Trilinear)()
+    kw = {} if renderer == "siddon" else {"n_points": 50}
+    vol_g = vol.clone().requires_grad_()
+    out = mod(vol_g, src, tgt, img, mask=mask, **kw)
+    assert out.shape == (1, 300, 40)
+    plain = mod(vol, src, tgt, img, **kw)
+    assert rel_err(out.sum(1, keepdim=True).detach().numpy(), plain.numpy()) < 1e-5
+    # one channel against the plain render of the volume restricted to that label
+    c = int(mask[6, 5, 7].item())
+    if renderer == "siddon":
+        only = mod(vol * (mask == c), src, tgt, img, **kw)
+        assert rel_err(out[:, c:c + 1].detach().numpy(), only.numpy()) < 1e-5
+    out.sum().backward()
+    assert torch.isfinite(vol_g.grad).all() and vol_g.grad.abs().sum() > 0
 
 
 @pytest.mark.parametrize("renderer", ["siddon", "trilinear"])

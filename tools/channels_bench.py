@@ -16,19 +16,32 @@ from diffdrr_amd import DRR  # noqa: E402
 from diffdrr_amd.data import make_subject  # noqa: E402
 from tools.kernel_sweep import timeit  # noqa: E402
 
+import numpy as np  # noqa: E402
+
 dev = torch.device("cuda:0")
 dims, C, H = (512, 512, 133), 119, 200
 g = torch.Generator().manual_seed(0)
 vol = torch.rand(*dims, generator=g)
-coarse = torch.randint(0, C, (16, 16, 8), generator=g)
-mask = coarse
-for ax, d in enumerate(dims):
-    idx = (torch.arange(d) * coarse.shape[ax] // d).clamp_max(coarse.shape[ax] - 1)
-    mask = mask.index_select(ax, idx)
-mask[0, 0, 0] = C - 1
+if "--real-mask" in sys.argv:
+    # the reference's own example label map (diffdrr/data/mask.nii.gz), committed down-sampled
+    # 2 x 2 in-plane (tests/golden/make_golden_mask.py) and repeated back to 512 x 512 x 133:
+    # label runs of the original lengths; 81 % background, 90 of 119 labels present
+    fx = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                              "reference_mask_ds2.npz"))
+    mask = torch.from_numpy(fx["labels"]).repeat_interleave(2, 0).repeat_interleave(2, 1)[:512, :512]
+    assert tuple(mask.shape) == dims and int(mask.max()) == C - 1
+    what = "the reference's example label map (TotalSegmentator, 2x2 in-plane repeat of the fixture)"
+else:
+    coarse = torch.randint(0, C, (16, 16, 8), generator=g)
+    mask = coarse
+    for ax, d in enumerate(dims):
+        idx = (torch.arange(d) * coarse.shape[ax] // d).clamp_max(coarse.shape[ax] - 1)
+        mask = mask.index_select(ax, idx)
+    mask[0, 0, 0] = C - 1
+    what = "synthetic label blocks of 32 x 32 x 17 voxels"
 subject = make_subject(vol, spacing=(0.703, 0.703, 2.5), mask=mask)
 drr = DRR(subject, sdd=1020.0, height=H, delx=2.0).to(dev)
-print(f"# {torch.cuda.get_device_name(0)}: {dims} volume, {C} labels, {H}x{H} detector")
+print(f"# {torch.cuda.get_device_name(0)}: {dims} volume, {C} labels ({what}), {H}x{H} detector")
 for B in (1, 8):
     rot = torch.zeros(B, 3, device=dev) + torch.linspace(0, 0.3, B, device=dev)[:, None]
     xyz = torch.tensor([[0.0, 850.0, 0.0]], device=dev).expand(B, 3).contiguous()
@@ -55,7 +68,7 @@ for B in (1, 8):
 from diffdrr_amd import convert, ops  # noqa: E402
 from diffdrr_amd.renderers import _labels_u8  # noqa: E402
 
-labels, _ = _labels_u8(drr.mask)
+(labels, _, _), = _labels_u8(drr.mask)
 for B in (1, 8):
     rot = torch.zeros(B, 3, device=dev) + torch.linspace(0, 0.3, B, device=dev)[:, None]
     xyz = torch.tensor([[0.0, 850.0, 0.0]], device=dev).expand(B, 3).contiguous()
