@@ -21,6 +21,7 @@ ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--kernel", default="generic", choices=["generic", "brick", "volgrad"])
 ap.add_argument("--aux", type=int, default=0)
+ap.add_argument("--storage", default="q16", choices=["q16", "f32"])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 D, H = a.size, 256
@@ -43,5 +44,5 @@ for _ in range(a.reps):
     elif a.kernel == "volgrad":
         ops.siddon_backward_volume_bricks(drr.density.shape, s, t, L, torch.ones_like(L), (H, H))
     else:
-        ops.siddon_forward_bricks(drr.density, s, t, L, (H, H), want_aux=bool(a.aux))
+        ops.siddon_forward_bricks(drr.density, s, t, L, (H, H), want_aux=bool(a.aux), storage=a.storage)
 torch.cuda.synchronize()
