@@ -918,11 +918,6 @@ int launch_fwd_bricks(int variant, float *brick_ranges, int ranges_valid, const 
 #endif
     int n_cu = 0;
     if (int rc = brick_launch_resources(st, n_cu, p.work)) return rc;
-    // A small volume has too few double bricks to balance over the CUs (256^3: 256 of them, one
-    // per CU, 0.83 ms against 0.78 ms with 512 fp32 bricks handed out dynamically): fp32 bricks
-    if (variant == DDRR_BRICKS_Q16 &&
-        (long)((dx + 31) / 32) * ((dy + 31) / 32) * ((dz + 63) / 64) < 4L * n_cu)
-        variant = DDRR_BRICKS_F32;
     int rc = 0;
 #define DDRR_LAUNCH(C) (aux ? launch_cfg<true, C>(p, n_cu, out, aux, st) \
                             : launch_cfg<false, C>(p, n_cu, out, aux, st))

@@ -105,11 +105,27 @@ def _record_vmax(volume, want_aux, cfg):
     return ops.volume_absmax(volume)
 
 
+_cu_count = {}
+
+
 def _brick_storage(volume, cfg):
-    """How the brick kernel stages the volume (Siddon.brick_storage).  A volume that is being
-    optimised changes every step: its 16-bit ranges would be recomputed per launch (one more
-    pass over the volume), and its gradient is taken w.r.t. the exact values: fp32 bricks."""
-    return "f32" if volume.requires_grad else cfg.get("storage", "f32")
+    """How the brick kernel stages the volume (Siddon.brick_storage).  fp32 bricks whatever the
+    setting for a volume that is being optimised (it changes every step: its 16-bit ranges would
+    be recomputed per launch, one more pass over the volume, and its gradient is taken w.r.t. the
+    exact values) and for a volume with fewer than 4 double bricks per CU: too few to balance
+    over the persistent workgroups (256^3 = 256 bricks of 32 x 32 x 64, one per CU: 0.83 ms
+    against 0.74 ms with 512 fp32 bricks handed out dynamically)."""
+    storage = cfg.get("storage", "f32")
+    if storage != "q16" or volume.requires_grad:
+        return "f32"
+    dev = volume.device
+    if dev.type == "cuda":
+        if dev not in _cu_count:
+            _cu_count[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+        dx, dy, dz = volume.shape
+        if (-(-dx // 32)) * (-(-dy // 32)) * (-(-dz // 64)) < 4 * _cu_count[dev]:
+            return "f32"
+    return "q16"
 
 
 class _SiddonFn(torch.autograd.Function):

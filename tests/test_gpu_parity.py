@@ -664,6 +664,55 @@ def test_brick_kernel_small_and_ragged_volumes(gpu):
         assert rel_err(out.cpu().numpy(), ref) < FWD_TOL, dims
 
 
+def test_q16_bricks_small_ragged_sparse_and_many_poses(gpu):
+    """The 16-bit block-quantised bricks (32 x 32 x 64, ddrr_siddon_forward_bricks with
+    DDRR_BRICKS_Q16) where the module would not choose them -- small volumes -- for the edge cases
+    of the brick grid: partial bricks on every axis, a volume smaller than one brick, empty (all
+    zero) bricks next to full ones, a z extent that is not a multiple of 4 (the general fp32
+    kernel takes over), more poses than a pose-table chunk; against the oracle, forward and the
+    record's ray gradients; and a NaN voxel poisons the rays through its brick only."""
+    cases = (((40, 72, 36), (24, 31), 4), ((32, 32, 64), (16, 16), 4), ((5, 9, 64), (8, 8), 4),
+             ((40, 70, 33), (24, 31), 4), ((70, 40, 132), (20, 28), 75))
+    for dims, (H, W), B in cases:
+        g = torch.Generator().manual_seed(1)
+        vol = torch.rand(*dims, generator=g)
+        if dims[0] >= 40:
+            vol[: dims[0] // 2, : dims[1] // 2] = 0.0  # air: bricks of zeros are skipped
+        drr = DRR(make_subject(vol, spacing=(1.0, 1.5, 2.0)), sdd=300.0, height=H, width=W,
+                  delx=2.0).to(gpu)
+        rot = ((torch.rand(B, 3, generator=g) - 0.5) * 2.0).to(gpu)
+        xyz = (torch.tensor([0.0, 200.0, 0.0]) + (torch.rand(B, 3, generator=g) - 0.5) * 30).to(gpu)
+        s, t, L = voxel_rays(drr, rot, xyz)
+        V = drr.density
+        go = torch.rand(B, H * W, generator=g).to(gpu)
+        o = oracle.siddon(V.cpu().numpy(), s.cpu().numpy(), t.cpu().numpy(), L.cpu().numpy(),
+                          grad_out=go.cpu().numpy())
+        out, aux = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True, storage="q16")
+        plain, _ = ops.siddon_forward_bricks(V, s, t, L, (H, W), storage="q16")
+        exact, aux_f = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True, storage="f32")
+        for img in (out, plain):
+            assert rel_err(img.cpu().numpy(), o["out"].reshape(B, -1)) < FWD_TOL, dims
+            assert rel_err(img.cpu().numpy(), exact.cpu().numpy()) < 2e-5, dims
+        gq = ops.siddon_backward_rays(aux, go, s, t, L)
+        gf = ops.siddon_backward_rays(aux_f, go, s, t, L)
+        assert rel_err(gq[2].cpu().numpy(), gf[2].cpu().numpy()) < 2e-5, dims      # d / d img
+        for a, b in zip(gq[:2], gf[:2]):                                             # per-pose sums
+            assert rel_err(a.double().sum(1).cpu().numpy(), b.double().sum(1).cpu().numpy()) < 5e-3, dims
+    # a NaN voxel: every ray through its brick is NaN (documented), the others are untouched
+    vol = torch.rand(64, 64, 128, generator=torch.Generator().manual_seed(2))
+    drr = DRR(make_subject(vol, spacing=(1.0, 1.0, 1.0)), sdd=400.0, height=32, delx=3.0).to(gpu)
+    rot = torch.tensor([[0.1, 0.2, -0.1]], device=gpu)
+    xyz = torch.tensor([[1.0, 250.0, 2.0]], device=gpu)
+    s, t, L = voxel_rays(drr, rot, xyz)
+    clean, _ = ops.siddon_forward_bricks(drr.density, s, t, L, (32, 32), storage="q16")
+    bad = drr.density.clone()
+    bad[40, 40, 100] = float("nan")
+    dirty, _ = ops.siddon_forward_bricks(bad, s, t, L, (32, 32), storage="q16")
+    nan = torch.isnan(dirty)
+    assert nan.any() and not nan.all()
+    assert torch.allclose(dirty[~nan], clean[~nan], rtol=1e-5, atol=1e-5)  # (atomics: not bit-stable)
+
+
 @pytest.mark.parametrize("H,W", [(70, 45), (64, 64), (33, 130)])
 def test_odd_detectors_vs_oracle(gpu, H, W):
     subject = synthetic_subject(48, kind="noise", seed=0)
