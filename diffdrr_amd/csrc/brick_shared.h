@@ -40,6 +40,11 @@ struct BrickArgs {
     int n_channels;               // BRICK_CHANNELS: out is (B, n_channels, N)
     const float *ranges;          // 16-bit bricks: (vmin, vmax) per brick (bricks_fwd.hip)
     int ranges_valid;             // ... already computed for this volume
+    const int *order;             // bricks_fwd.hip: k-th brick handed out (NULL: k itself)
+    int *order_ws;                // ... this launch's workspace for it: order_cap weights, order_cap ints
+    int order_cap;
+    unsigned *brick_times;        // profiling builds: duration of every brick (10 ns ticks), or NULL
+    int split_t, split_s;         // ... the last split_t bricks are handed out in split_s pose parts
 };
 
 // Phase timing of the brick kernel (tools/ builds with -DDDRR_BRICK_PROFILE only): s_memtime
@@ -47,11 +52,12 @@ struct BrickArgs {
 #if defined(DDRR_BRICK_PROFILE)
 struct BrickProf {
     unsigned long long t[16];
-    unsigned long long last;
+    unsigned long long last, born;  // born: s_memrealtime (100 MHz, one clock for all XCDs)
     __device__ __forceinline__ void start() {
 #pragma unroll
         for (int i = 0; i < 16; ++i) t[i] = 0;
         last = __builtin_amdgcn_s_memtime();
+        born = __builtin_amdgcn_s_memrealtime();
     }
     __device__ __forceinline__ void mark(int i) {
         const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -150,7 +156,9 @@ __device__ __forceinline__ void wave_fence() {
 
 // Per-device launch resources of the brick kernels (bricks.hip): the CU count and this launch's
 // brick counter {brick id, wmax bits, n_sum, -}, zeroed on `st`.  Returns 0 or an error code.
-int brick_launch_resources(hipStream_t st, int &n_cu, int *&work);
+// order_ws / order_cap: this launch's workspace for the hand-out order of the bricks (bricks_fwd.hip).
+int brick_launch_resources(hipStream_t st, int &n_cu, int *&work, int **order_ws = nullptr,
+                           int *order_cap = nullptr);
 
 // The 32^3 fp32 launch path of bricks.hip (every mode); bricks_fwd.hip falls back to it.
 int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const float *source,
@@ -175,6 +183,9 @@ extern float g_brick_t1, g_brick_t2;
 extern int g_brick_dbg;
 extern int g_brick_variant;
 extern float g_brick_sq_width;
+extern const int *g_brick_order;
+extern unsigned *g_brick_times;  // profiling builds: per-brick duration, 10 ns ticks
+extern int g_brick_split_t, g_brick_split_s;
 #else
 constexpr float g_brick_t1 = 18.f, g_brick_t2 = 40.f;
 constexpr int g_brick_dbg = 0;

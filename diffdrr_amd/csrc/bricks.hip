@@ -719,6 +719,9 @@ float g_brick_t1 = 18.f, g_brick_t2 = 40.f;
 int g_brick_dbg = 0;
 int g_brick_variant = -2;
 float g_brick_sq_width = 8.f;
+const int *g_brick_order = nullptr;
+unsigned *g_brick_times = nullptr;
+int g_brick_split_t = 0, g_brick_split_s = 1;
 #endif
 #if defined(DDRR_BRICK_PROFILE)
 unsigned long long *g_brick_prof = nullptr;  // 16 device counters, see BrickProf
@@ -727,10 +730,12 @@ unsigned long long *g_brick_prof = nullptr;  // 16 device counters, see BrickPro
 // Per-device state, created on first use under a lock (the entry points may be called from
 // several host threads): the CU count and a small ring of brick counters -- one per launch, so
 // that launches in flight on different streams never share one; zeroed on the launch's stream.
-int brick_launch_resources(hipStream_t st, int &n_cu_out, int *&work) {
+int brick_launch_resources(hipStream_t st, int &n_cu_out, int *&work, int **order_ws, int *order_cap) {
     constexpr int kRing = 64, kMaxDev = 64;
+    constexpr int kOrderCap = 32768;  // bricks per launch the hand-out order is built for
     static std::mutex mu;
     static int *ring[kMaxDev] = {nullptr};
+    static int *order_ring[kMaxDev] = {nullptr};
     static int n_cu[kMaxDev] = {0};
     static unsigned slot[kMaxDev] = {0};
     hipError_t e;
@@ -747,7 +752,18 @@ int brick_launch_resources(hipStream_t st, int &n_cu_out, int *&work) {
                                            dev)) != hipSuccess)
                 return fail_hip(e, "hipDeviceGetAttribute");
         }
-        work = ring[dev] + 4 * (slot[dev]++ % kRing);  // {brick counter, wmax bits, n_sum, -}
+        if (order_ws && !order_ring[dev] &&
+            hipMalloc(reinterpret_cast<void **>(&order_ring[dev]),
+                      (size_t)kRing * 2 * kOrderCap * sizeof(int)) != hipSuccess) {
+            order_ring[dev] = nullptr;  // (no workspace: the bricks go out in id order)
+            (void)hipGetLastError();
+        }
+        const unsigned k = slot[dev]++ % kRing;
+        work = ring[dev] + 4 * k;  // {brick counter, wmax bits, n_sum, -}
+        if (order_ws) {
+            *order_ws = order_ring[dev] ? order_ring[dev] + (size_t)k * 2 * kOrderCap : nullptr;
+            *order_cap = kOrderCap;
+        }
         n_cu_out = n_cu[dev];
     }
     if ((e = hipMemsetAsync(work, 0, 4 * sizeof(int), st)) != hipSuccess)
@@ -796,6 +812,12 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     p.n_channels = n_channels;
     p.ranges = nullptr;
     p.ranges_valid = 0;
+    p.brick_times = nullptr;
+    p.order = nullptr;
+    p.order_ws = nullptr;
+    p.order_cap = 0;
+    p.split_t = 0;
+    p.split_s = 1;
 #if defined(DDRR_BRICK_PROFILE)
     p.prof = g_brick_prof;
 #endif
@@ -895,9 +917,15 @@ int ddrr_set_brick_classes(float t1, float t2) {
 #if defined(DDRR_BRICK_PROFILE)
 // zero / read the phase counters of the brick launches since the last reset
 int ddrr_brick_profile_reset() {
-    if (!g_brick_prof && hipMalloc(reinterpret_cast<void **>(&g_brick_prof), 16 * 8) != hipSuccess)
+    if (!g_brick_prof && hipMalloc(reinterpret_cast<void **>(&g_brick_prof), 20 * 8) != hipSuccess)
         return -1;
-    return hipMemset(g_brick_prof, 0, 16 * 8) == hipSuccess ? 0 : -1;
+    return hipMemset(g_brick_prof, 0, 20 * 8) == hipSuccess ? 0 : -1;
+}
+// (slots 16 .. 19: sums of the waves' start / end ticks, earliest start (inverted), latest end
+// -- bricks_fwd.hip only)
+int ddrr_brick_profile_read20(unsigned long long *host20) {
+    if (!g_brick_prof) return -1;
+    return hipMemcpy(host20, g_brick_prof, 20 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 int ddrr_brick_profile_read(unsigned long long *host16) {
     if (!g_brick_prof) return -1;

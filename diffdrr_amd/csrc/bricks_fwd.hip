@@ -290,9 +290,6 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
     const int N = p.det_h * p.det_w;
     unsigned *myq = queue + wave * kBuckets * kQueueCap;  // wave-private (see bricks.hip)
     const unsigned pix_mask = (1u << p.pix_bits) - 1u;
-    // chunks of at most C::CHUNK poses, of equal size
-    const int n_chunks = (p.B + C::CHUNK - 1) / C::CHUNK;
-    const int chunk = (p.B + n_chunks - 1) / n_chunks;
     const unsigned lds_base = LdsAbsFetch::base_of(reinterpret_cast<const float *>(brick));
     const bool GROUPED = AUX && p.rec_q == 0.f && !(p.dbg & 8);
 
@@ -308,8 +305,28 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
             counter[2] = 0;
         }
         __syncthreads();
-        const int brick_id = counter[1];
-        if (brick_id >= n_bricks) break;
+        // Work items: bricks in the order p.order hands them out (heaviest first, see
+        // brick_weight_kernel), every pose
+        const int item = counter[1];
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+        // (tools builds: the last split_t bricks go out in split_s parts of the pose batch each --
+        // measured, not adopted: the smaller batches cost more than the shorter tail gains)
+        const int n_full = n_bricks - p.split_t;
+        if (item >= n_full + p.split_t * p.split_s) break;
+        const int kth = item < n_full ? item : n_full + (item - n_full) / p.split_s;
+        const int part = item < n_full ? 0 : (item - n_full) % p.split_s;
+        const int parts = item < n_full ? 1 : p.split_s;
+        const int pose_lo = (int)((long)p.B * part / parts), pose_hi = (int)((long)p.B * (part + 1) / parts);
+#else
+        if (item >= n_bricks) break;
+        const int kth = item, pose_lo = 0, pose_hi = p.B;
+#endif
+        const int brick_id = p.order ? p.order[kth] : kth;
+#if defined(DDRR_BRICK_PROFILE)
+        const unsigned long long brick_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        const int n_chunks = (pose_hi - pose_lo + C::CHUNK - 1) / C::CHUNK;
+        const int chunk = n_chunks ? (pose_hi - pose_lo + n_chunks - 1) / n_chunks : 0;
         DDRR_PROF(PROF_CLAIM);
         const Box box = cfg_brick_box<C>(p.D, nby, nbz, brick_id);
         const BoxF cells = boxf(box);
@@ -326,9 +343,9 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
         bool brick_empty = false;
         Q16Range range = {0.f, 0.f, 0.f};
 
-        for (int ch = 0; ch < n_chunks; ++ch) {
-            const int b0 = ch * chunk;
-            const int nb = p.B - b0 < chunk ? p.B - b0 : chunk;
+        for (int ch = 0; ch < n_chunks; ++ch) {  // chunks of at most C::CHUNK poses, of equal size
+            const int b0 = pose_lo + ch * chunk;
+            const int nb = pose_hi - b0 < chunk ? pose_hi - b0 : chunk;
             const bool last_chunk = ch == n_chunks - 1;
             if (ch > 0) __syncthreads();  // previous chunk's table no longer in use
             if (tid < nb) {
@@ -441,11 +458,25 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
                 if (drain) break;
             }
         }
+#if defined(DDRR_BRICK_PROFILE)
+        __syncthreads();
+        if (tid == 0 && p.brick_times)
+            p.brick_times[brick_id] = (unsigned)(__builtin_amdgcn_s_memrealtime() - brick_t0);
+#endif
     }
 #if defined(DDRR_BRICK_PROFILE)
     DDRR_PROF(PROF_BARRIER);
-    if (lane == 0 && p.prof)
+    if (lane == 0 && p.prof) {
         for (int i = 0; i < 16; ++i) atomicAdd(p.prof + i, prof.t[i]);
+        // how long this wave lived: the launch ends with its longest-lived one (the tail)
+        // [16] sum of the waves' start ticks, [17] of their end ticks, [18] earliest start (stored
+        // inverted: the slots start at 0), [19] latest end
+        const unsigned long long died = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(p.prof + 16, prof.born);
+        atomicAdd(p.prof + 17, died);
+        atomicMax(p.prof + 18, ~prof.born);
+        atomicMax(p.prof + 19, died);
+    }
 #endif
 }
 
@@ -778,6 +809,72 @@ __global__ __launch_bounds__(256) void brick_range_kernel(const float *__restric
     }
 }
 
+// ------------------------------------------------------------------ heaviest bricks first
+// The persistent workgroups pull bricks from one counter; a launch ends when the last of them is
+// done, and with 8-16 bricks per CU a heavy brick drawn late leaves the other CUs idle for most
+// of its duration (measured: 17 % of the wave-time of a 32-pose launch was that tail).  So the
+// bricks are handed out by decreasing weight = sum over the poses of the brick's projected pixel
+// box (what phase A will enumerate): brick_weight_kernel (one wave per brick, lanes over poses),
+// brick_order_kernel (one workgroup: counting sort by 1024 weight classes).  ~5 us per launch,
+// forward 1.26 -> 1.19 ms at 32 poses, 4.39 -> 4.00 ms at 128 (profiles/r03/brick_order_split.txt).
+__global__ __launch_bounds__(256) void brick_weight_kernel(BrickArgs p, int BX, int BY, int BZ,
+                                                           int nby, int nbz, int n_bricks,
+                                                           float *__restrict__ weight) {
+    const int brick = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (brick >= n_bricks) return;
+    const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
+    BoxF cells;
+    cells.lo[0] = (float)(bx * BX), cells.lo[1] = (float)(by * BY), cells.lo[2] = (float)(bz * BZ);
+    cells.hi[0] = (float)min(bx * BX + BX, p.D.x), cells.hi[1] = (float)min(by * BY + BY, p.D.y);
+    cells.hi[2] = (float)min(bz * BZ + BZ, p.D.z);
+    const int N = p.det_h * p.det_w;
+    float w = 0.f;
+    for (int b = lane; b < p.B; b += 64) {
+        const PoseGrid pg = pose_grid(p.source + (long)b * 3, p.target + (long)b * N * 3, p.det_h, p.det_w);
+        w += (float)pixbox_count(project_brick_grid(pg, p.det_h, p.det_w, cells, p.shift));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+    if (lane == 0) weight[brick] = w;
+}
+
+constexpr int kOrderClasses = 1024;
+__global__ __launch_bounds__(1024) void brick_order_kernel(const float *__restrict__ weight,
+                                                           int n_bricks, int *__restrict__ order) {
+    __shared__ int hist[kOrderClasses];
+    __shared__ float wmax_s[16];
+    const int tid = threadIdx.x;
+    float wmax = 0.f;
+    for (int i = tid; i < n_bricks; i += 1024) wmax = fmaxf(wmax, weight[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+    if ((tid & 63) == 0) wmax_s[tid >> 6] = wmax;
+    hist[tid] = 0;
+    __syncthreads();
+    wmax = 0.f;
+    for (int k = 0; k < 16; ++k) wmax = fmaxf(wmax, wmax_s[k]);
+    const float scale = wmax > 0.f ? (float)(kOrderClasses - 1) / wmax : 0.f;
+    // class 0 = heaviest
+    for (int i = tid; i < n_bricks; i += 1024)
+        atomicAdd(&hist[kOrderClasses - 1 - (int)(weight[i] * scale)], 1);
+    __syncthreads();
+    // exclusive scan of the 1024 class counts (Hillis-Steele in place)
+    int v = hist[tid];
+    for (int o = 1; o < kOrderClasses; o <<= 1) {
+        __syncthreads();
+        const int add = tid >= o ? hist[tid - o] : 0;
+        __syncthreads();
+        hist[tid] += add;
+    }
+    __syncthreads();
+    const int excl = hist[tid] - v;
+    __syncthreads();
+    hist[tid] = excl;
+    __syncthreads();
+    for (int i = tid; i < n_bricks; i += 1024)
+        order[atomicAdd(&hist[kOrderClasses - 1 - (int)(weight[i] * scale)], 1)] = i;
+}
+
 template <bool AUX, class C>
 int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t st) {
     static_assert(C::LDS <= C::LDS_BUDGET, "LDS budget");
@@ -807,8 +904,19 @@ int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t
             hipLaunchKernelGGL(brick_range_kernel, dim3(n_bricks), dim3(256), 0, st, p.vol, p.D, C::BX,
                                C::BY, C::BZ, nby, nbz, const_cast<float *>(p.ranges));
     }
+    BrickArgs q = p;
+    if (q.order_ws && n_bricks <= q.order_cap && n_bricks > slots && !q.order && q.B >= 8) {
+        // (fewer bricks than workgroups: nothing to order; a handful of poses: the launch is
+        // latency-bound and the two small kernels cost more than the order gains)
+        float *weight = reinterpret_cast<float *>(q.order_ws);
+        int *order = q.order_ws + q.order_cap;
+        hipLaunchKernelGGL(brick_weight_kernel, dim3((n_bricks + 3) / 4), dim3(256), 0, st, q, C::BX,
+                           C::BY, C::BZ, nby, nbz, n_bricks, weight);
+        hipLaunchKernelGGL(brick_order_kernel, dim3(1), dim3(1024), 0, st, weight, n_bricks, order);
+        q.order = order;
+    }
     const dim3 grid(n_bricks < slots ? n_bricks : slots), block(C::THREADS);
-    hipLaunchKernelGGL((siddon_fwd_brick_kernel<AUX, C>), grid, block, C::LDS, st, p, out, aux);
+    hipLaunchKernelGGL((siddon_fwd_brick_kernel<AUX, C>), grid, block, C::LDS, st, q, out, aux);
     return 0;
 }
 
@@ -903,6 +1011,15 @@ int launch_fwd_bricks(int variant, float *brick_ranges, int ranges_valid, const 
     p.rec_q = rec_q;
     p.ranges = brick_ranges;
     p.ranges_valid = ranges_valid;
+    p.order = nullptr;
+    p.split_t = 0;
+    p.split_s = 1;
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+    p.brick_times = g_brick_times;
+    p.order = g_brick_order;
+    p.split_t = g_brick_split_t;
+    p.split_s = g_brick_split_s;
+#endif
     p.pix_bits = 1;
     while ((1L << p.pix_bits) < N) ++p.pix_bits;
     if (((long)B << p.pix_bits) > (1L << 32))
@@ -917,7 +1034,10 @@ int launch_fwd_bricks(int variant, float *brick_ranges, int ranges_valid, const 
     if (variant >= 16) p.t1 = g_brick_sq_width;  // shared rings: t1 = class width
 #endif
     int n_cu = 0;
-    if (int rc = brick_launch_resources(st, n_cu, p.work)) return rc;
+    if (int rc = brick_launch_resources(st, n_cu, p.work, &p.order_ws, &p.order_cap)) return rc;
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+    if (g_brick_dbg & 512) p.order_ws = nullptr;  // (bricks in id order)
+#endif
     int rc = 0;
 #define DDRR_LAUNCH(C) (aux ? launch_cfg<true, C>(p, n_cu, out, aux, st) \
                             : launch_cfg<false, C>(p, n_cu, out, aux, st))
@@ -962,6 +1082,19 @@ int launch_fwd_bricks(int variant, float *brick_ranges, int ranges_valid, const 
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
 extern "C" int ddrr_set_brick_variant(int v) {
     ddrr_brick::g_brick_variant = v;
+    return 0;
+}
+extern "C" int ddrr_set_brick_times(unsigned *device_times) {
+    ddrr_brick::g_brick_times = device_times;
+    return 0;
+}
+extern "C" int ddrr_set_brick_order(const int *device_order) {
+    ddrr_brick::g_brick_order = device_order;
+    return 0;
+}
+extern "C" int ddrr_set_brick_split(int t, int s) {
+    ddrr_brick::g_brick_split_t = t;
+    ddrr_brick::g_brick_split_s = s < 1 ? 1 : s;
     return 0;
 }
 extern "C" int ddrr_set_brick_sq_width(float w) {

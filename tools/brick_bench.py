@@ -21,6 +21,8 @@ ap.add_argument("--layouts", default="33:1057")
 ap.add_argument("--cases", default="pert32,pert32aux,base32,pert1,pert8,pert128")
 ap.add_argument("--dbg", default="0")
 ap.add_argument("--classes", default="18:40")
+ap.add_argument("--order", default="id", help="hand-out order of the bricks: id | center | weight (comma list)")
+ap.add_argument("--split", default="0:1", help="T:S -- the last T bricks are handed out in S pose parts (comma list)")
 ap.add_argument("--sqw", default="8", help="class width(s) of the shared rings (variants >= 16)")
 ap.add_argument("--variants", default="-2",
                 help="bricks_fwd.hip variants: -2 product default, -1 the general 32^3 fp32 kernel of "
@@ -48,8 +50,46 @@ for case in a.cases.split(","):
     sets[case] = (s, t, L, aux)
 import itertools
 import ctypes
-for lay, dbg, cl, var, sqw in itertools.product(a.layouts.split(","), a.dbg.split(","), a.classes.split(","),
-                                                a.variants.split(","), a.sqw.split(",")):
+
+BRICK = {0: (32, 32, 32), 2: (32, 32, 32), 10: (32, 32, 32), 3: (32, 32, 16), 4: (64, 32, 32), 5: (32, 32, 64),
+         1: (32, 32, 64), 6: (32, 64, 32), 7: (16, 64, 32), 8: (64, 16, 32), 9: (16, 32, 64)}
+
+
+def brick_order(kind, var, s_, t_):
+    """int32 device tensor: k-th brick handed out.  center: nearest to the volume centre first;
+    weight: largest sum over the poses of the projected pixel-box area first."""
+    if kind == "id" or var not in BRICK:
+        return None
+    bx, by, bz = BRICK[var]
+    n = [-(-D // b) for b in (bx, by, bz)]
+    ix, iy, iz = torch.meshgrid(*[torch.arange(k, device=dev) for k in n], indexing="ij")
+    lo = torch.stack([ix * bx, iy * by, iz * bz], -1).reshape(-1, 3).float()      # id order: z fastest
+    hi = torch.minimum(lo + torch.tensor([bx, by, bz], device=dev), torch.tensor([D, D, D], device=dev).float())
+    if kind == "center":
+        key = (((lo + hi) / 2 - D / 2) ** 2).sum(-1)
+        return torch.argsort(key).int().contiguous()
+    # weight: project the 8 corners of every brick through every pose's source onto its pixel lattice
+    B = t_.shape[0]
+    tg = t_.reshape(B, H, H, 3)
+    t00, ei, ej = tg[:, 0, 0], (tg[:, -1, 0] - tg[:, 0, 0]) / (H - 1), (tg[:, 0, -1] - tg[:, 0, 0]) / (H - 1)
+    src = s_[:, 0]
+    corners = torch.stack([torch.where(torch.tensor([(c >> a) & 1 for a in range(3)], device=dev).bool(), hi, lo)
+                           for c in range(8)], 1) - 0.5                           # (nb, 8, 3), planes at k - shift
+    w = corners[None] - src[:, None, None]                                          # (B, nb, 8, 3)
+    A = torch.stack([w, -ei[:, None, None].expand_as(w), -ej[:, None, None].expand_as(w)], -1)  # lambda w - i ei - j ej = r
+    r = (t00 - src)[:, None, None, :, None].expand(B, w.shape[1], 8, 3, 1)
+    sol = torch.linalg.solve(A, r)[..., 0]
+    i, j = sol[..., 1], sol[..., 2]
+    i0, i1 = i.amin(-1).clamp(0, H - 1), i.amax(-1).clamp(0, H - 1)
+    j0, j1 = j.amin(-1).clamp(0, H - 1), j.amax(-1).clamp(0, H - 1)
+    area = ((i1 - i0 + 1) * (j1 - j0 + 1)).sum(0)
+    return torch.argsort(area, descending=True).int().contiguous()
+
+
+keep_alive = []
+for lay, dbg, cl, var, sqw, order, split in itertools.product(
+        a.layouts.split(","), a.dbg.split(","), a.classes.split(","), a.variants.split(","), a.sqw.split(","),
+        a.order.split(","), a.split.split(",")):
     sy, sx = (int(v) for v in lay.split(":"))
     var = int(var)
     if var < 16 and sqw != a.sqw.split(",")[0]:
@@ -61,13 +101,18 @@ for lay, dbg, cl, var, sqw in itertools.product(a.layouts.split(","), a.dbg.spli
     t1, t2 = (float(v) for v in cl.split(":"))
     import ctypes
     lib.cdll.ddrr_set_brick_classes(ctypes.c_float(t1), ctypes.c_float(t2))
-    lay = f"dbg{dbg} cls{cl if var < 16 else sqw} var{var:2d}"
+    T_, S_ = (int(v) for v in split.split(":"))
+    lib.cdll.ddrr_set_brick_split(T_, S_)
+    lay = f"dbg{dbg} cls{cl if var < 16 else sqw} var{var:2d} ord {order} split {split}"
     rc = lib.cdll.ddrr_set_brick_layout(sy, sx)
     if rc != 0:
         print(f"layout {lay}: rejected")
         continue
     for case, (s, t, L, aux) in sets.items():
         B = t.shape[0]
+        tab = brick_order(order, var, s, t)
+        keep_alive.append(tab)
+        lib.cdll.ddrr_set_brick_order(ctypes.c_void_p(tab.data_ptr() if tab is not None else 0))
         _, _, nv = ops.siddon_forward(V, s, t, L, count_voxels=True, det=(H, H))
         nvox = int(nv.sum())
         alg = 4 * nvox + B * H * H * 20 + 12 * B
@@ -85,6 +130,6 @@ for lay, dbg, cl, var, sqw in itertools.product(a.layouts.split(","), a.dbg.spli
             g2 = ops.siddon_backward_rays(baux, go, s[:4], t[:4], L[:4])[1].double().sum(1)
             err = max(err, -((g1 - g2).abs().max() / g1.abs().max()).item())  # (negative: gradient error)
             lay = lay + f" gerr {((g1 - g2).abs().max() / g1.abs().max()).item():.1e}"
-        print(f"{lay:40s} {case:12s} B {B:4d} vox/ray {nvox / (B * H * H):6.1f}  {med:8.3f} ms "
+        print(f"{lay:58s} {case:12s} B {B:4d} vox/ray {nvox / (B * H * H):6.1f}  {med:8.3f} ms "
               f"(best {best:7.3f})  {B / med * 1e3:9.0f} DRR/s  {alg / med / 1e6:8.1f} GB/s alg "
               f"({alg / med / 1e6 / 8000 * 100:5.1f}% of 8 TB/s)  err vs generic {err:.1e}", flush=True)

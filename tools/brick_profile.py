@@ -56,8 +56,8 @@ for var, case in itertools.product(a.variants.split(","), a.cases.split(",")):
     lib.cdll.ddrr_brick_profile_reset()
     fn()
     torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 16)()
-    lib.cdll.ddrr_brick_profile_read(buf)
+    buf = (ctypes.c_ulonglong * 20)()
+    lib.cdll.ddrr_brick_profile_read20(buf)
     v = list(buf)
     tot = sum(v[:9]) + sum(v[13:16])
     waves = 4096  # (every variant runs 4096 waves: 256 x 16 or 512 x 8)
@@ -69,6 +69,12 @@ for var, case in itertools.product(a.variants.split(","), a.cases.split(",")):
             print(f"  {n:14s} {100 * v[i] / tot:5.1f} %")
         else:
             print(f"  {n:14s} {v[i]}")
+    if v[19]:
+        first = (~v[18]) & (2 ** 64 - 1)
+        span = v[19] - first
+        print(f"  launch span {span / 100:.1f} us (first wave start -> last wave end, 100 MHz clock); waves start on average "
+              f"{100 * (v[16] / 4096 - first) / span:.1f} % of it after the first and end {100 * (v[19] - v[17] / 4096) / span:.1f} % "
+              f"of it before the last")
     print(f"  hits per batch {v[12] / max(1, v[9]):.1f}; wave-steps per batch {v[10] / max(1, v[9]):.1f}; "
           f"walk ticks per wave-step {v[6] / max(1, v[10]):.1f}; setup ticks per batch {v[5] / max(1, v[9]):.0f}; "
           f"load ticks per batch {v[4] / max(1, v[9]):.0f}; phase A ticks per unit {v[2] / max(1, v[11]):.0f}; "
