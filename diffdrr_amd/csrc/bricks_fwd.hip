@@ -352,7 +352,7 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
                 const PoseGrid pg = pose_grid(p.source + (long)(b0 + tid) * 3,
                                               p.target + (long)(b0 + tid) * N * 3, p.det_h, p.det_w);
                 PixBox pb = project_brick_grid(pg, p.det_h, p.det_w, cells, p.shift);
-                if (GROUPED) pb = align_pixbox_rows(pb, p.det_w);
+                if (GROUPED && !(p.dbg & 1024)) pb = align_pixbox_rows(pb, p.det_w);
                 rows[tid] = fwd_row(brick_row(pg, pb, cells, p.shift, p.eps, 0.f));
             }
             if (tid == 0) counter[0] = 0;
