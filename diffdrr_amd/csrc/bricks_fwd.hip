@@ -53,7 +53,12 @@ struct FwdCfg {
     static constexpr int ROW_ROOM =
         (LDS_BUDGET - BRICK_BYTES - WAVES * kBuckets * kQueueCap * 4 - 16) / (20 * 4);
     static constexpr int CHUNK = ROW_ROOM >= 32 ? 32 : ROW_ROOM;
-    static constexpr int LDS = BRICK_BYTES + WAVES * kBuckets * kQueueCap * 4 + CHUNK * 20 * 4 + 16;
+    static constexpr int LDS_MIN = BRICK_BYTES + WAVES * kBuckets * kQueueCap * 4 + CHUNK * 20 * 4 + 16;
+    // what the waves have left in their queues at the end of a brick is pooled (one count per
+    // wave and class) where the budget has the room for the counts
+    static constexpr int POOL_BYTES = WAVES * kBuckets * 4;
+    static constexpr bool POOL = LDS_MIN + POOL_BYTES <= LDS_BUDGET && WAVES * kBuckets <= 64;
+    static constexpr int LDS = LDS_MIN + (POOL ? POOL_BYTES : 0);
     static constexpr int MAXSTEPS = BX + BY + BZ + 4;
     static_assert(CHUNK >= 8, "no room for the row table");
     static_assert(BZ % 4 == 0 && (BX * BY * (BZ / 4)) % THREADS == 0, "staging");
@@ -281,7 +286,9 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
     unsigned char *brick = smem_raw;
     unsigned *queue = reinterpret_cast<unsigned *>(smem_raw + C::BRICK_BYTES);
     FwdRow *rows = reinterpret_cast<FwdRow *>(queue + C::WAVES * kBuckets * kQueueCap);
-    int *counter = reinterpret_cast<int *>(rows + C::CHUNK);  // [0] unit, [1] brick, [2] non-zero
+    // [0] unit, [1] brick, [2] non-zero, [3] pooled batch; then the pool's counts
+    int *counter = reinterpret_cast<int *>(rows + C::CHUNK);
+    int *pool = counter + 4;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nbx = (p.D.x + C::BX - 1) / C::BX, nby = (p.D.y + C::BY - 1) / C::BY;
@@ -292,6 +299,7 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
     const unsigned pix_mask = (1u << p.pix_bits) - 1u;
     const unsigned lds_base = LdsAbsFetch::base_of(reinterpret_cast<const float *>(brick));
     const bool GROUPED = AUX && p.rec_q == 0.f && !(p.dbg & 8);
+    const bool POOLED = C::POOL && !(p.dbg & 2048);
 
     BrickProf prof;
 #if defined(DDRR_BRICK_PROFILE)
@@ -303,6 +311,7 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
         if (tid == 0) {
             counter[1] = atomicAdd(p.work, 1);
             counter[2] = 0;
+            counter[3] = 0;
         }
         __syncthreads();
         // Work items: bricks in the order p.order hands them out (heaviest first, see
@@ -340,7 +349,7 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
         SG.strideb[1] = bits_as_float((unsigned)C::SY);
         SG.strideb[2] = bits_as_float((unsigned)C::ES);
         int qn0 = 0, qn1 = 0, qn2 = 0;  // hits waiting per length class (wave-uniform)
-        bool brick_empty = false;
+        bool brick_empty = false, pool_open = false;
         Q16Range range = {0.f, 0.f, 0.f};
 
         for (int ch = 0; ch < n_chunks; ++ch) {  // chunks of at most C::CHUNK poses, of equal size
@@ -348,16 +357,21 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
             const int nb = pose_hi - b0 < chunk ? pose_hi - b0 : chunk;
             const bool last_chunk = ch == n_chunks - 1;
             if (ch > 0) __syncthreads();  // previous chunk's table no longer in use
+            // (per-chunk code: what it derives from the launch constants and the thread id is
+            // kept out of the registers the walk needs -- the compiler would hoist it out of the
+            // brick loop and spill it -- by making the inputs opaque here)
+            int det_h = p.det_h, det_w = p.det_w, tid_here = tid;
+            asm volatile("" : "+s"(det_h), "+s"(det_w), "+v"(tid_here));
             if (tid < nb) {
                 const PoseGrid pg = pose_grid(p.source + (long)(b0 + tid) * 3,
-                                              p.target + (long)(b0 + tid) * N * 3, p.det_h, p.det_w);
-                PixBox pb = project_brick_grid(pg, p.det_h, p.det_w, cells, p.shift);
-                if (GROUPED && !(p.dbg & 1024)) pb = align_pixbox_rows(pb, p.det_w);
+                                              p.target + (long)(b0 + tid) * N * 3, det_h, det_w);
+                PixBox pb = project_brick_grid(pg, det_h, det_w, cells, p.shift);
+                if (GROUPED && !(p.dbg & 1024)) pb = align_pixbox_rows(pb, det_w);
                 rows[tid] = fwd_row(brick_row(pg, pb, cells, p.shift, p.eps, 0.f));
             }
             if (tid == 0) counter[0] = 0;
             DDRR_PROF(PROF_ROWS);
-            if (ch == 0) fwd_stage_brick<C>(p, brick, box, brick_id, tid, range, brick_empty, counter);
+            if (ch == 0) fwd_stage_brick<C>(p, brick, box, brick_id, tid_here, range, brick_empty, counter);
             DDRR_PROF(PROF_STORE);
             __syncthreads();
             if (!C::Q16 && ch == 0) brick_empty = counter[2] == 0;
@@ -418,36 +432,80 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
                     DDRR_PROF_COUNT(PROF_N_HITS, __popcll(m0) + __popcll(m1) + __popcll(m2));
                     DDRR_PROF(PROF_PHASE_A);
                 }
-                // walk every full batch of 64 hits of one class; when draining, what is left
-                // of all classes together (longest first), 64 at a time
+                // Walk every full batch of 64 hits of one class.  What the waves have left at
+                // the end of the brick -- on average half a batch per class each, a quarter of
+                // the brick's batches at 32 poses -- is pooled: one list of segments (class,
+                // wave), longest class first, cut into batches of 64 that an LDS counter hands
+                // out.  Fewer, fuller, better sorted batches than every wave draining its own,
+                // and the end of the brick is balanced over the waves.
                 for (;;) {
-                    int k = -1, n = 0;
-                    if (qn0 >= 64) k = 0, n = 64;
-                    else if (qn1 >= 64) k = 1, n = 64;
-                    else if (qn2 >= 64) k = 2, n = 64;
+                    int n = 0;
                     unsigned e = 0;
-                    if (k >= 0) {
-                        const int base = (k == 0 ? qn0 : (k == 1 ? qn1 : qn2)) - 64;
-                        qn0 -= k == 0 ? 64 : 0;
-                        qn1 -= k == 1 ? 64 : 0;
-                        qn2 -= k == 2 ? 64 : 0;
-                        e = myq[k * kQueueCap + base + lane];
-                    } else if (drain && qn0 + qn1 + qn2 > 0) {
-                        // virtual queue [class 2 | class 1 | class 0], taken from the front
-                        const int tot = qn0 + qn1 + qn2;
-                        n = tot < 64 ? tot : 64;
-                        const int i2 = lane, i1 = lane - qn2, i0 = lane - qn2 - qn1;
-                        if (lane < n)
-                            e = i2 < qn2 ? myq[2 * kQueueCap + qn2 - 1 - i2]
-                                         : (i1 < qn1 ? myq[kQueueCap + qn1 - 1 - i1]
-                                                     : myq[qn0 - 1 - i0]);
-                        const int t2 = qn2 < n ? qn2 : n;
-                        const int t1 = qn1 < n - t2 ? qn1 : n - t2;
-                        qn2 -= t2;
-                        qn1 -= t1;
-                        qn0 -= n - t2 - t1;
+                    if (!pool_open) {
+                        int k = -1;
+                        if (qn0 >= 64) k = 0;
+                        else if (qn1 >= 64) k = 1;
+                        else if (qn2 >= 64) k = 2;
+                        if (k >= 0) {
+                            const int base = (k == 0 ? qn0 : (k == 1 ? qn1 : qn2)) - 64;
+                            qn0 -= k == 0 ? 64 : 0;
+                            qn1 -= k == 1 ? 64 : 0;
+                            qn2 -= k == 2 ? 64 : 0;
+                            e = myq[k * kQueueCap + base + lane];
+                            n = 64;
+                        } else if (drain && POOLED) {
+                            // (every wave gets here exactly once per brick: drain is only seen
+                            // in the last chunk)
+                            if (lane < kBuckets)
+                                pool[wave * kBuckets + lane] = lane == 0 ? qn0 : (lane == 1 ? qn1 : qn2);
+                            __syncthreads();
+                            DDRR_PROF(PROF_BARRIER);
+                            pool_open = true;
+                            continue;
+                        } else if (drain && qn0 + qn1 + qn2 > 0) {
+                            // (no room for the pool: the wave's own virtual queue
+                            // [class 2 | class 1 | class 0], taken from the front)
+                            const int tot = qn0 + qn1 + qn2;
+                            n = tot < 64 ? tot : 64;
+                            const int i2 = lane, i1 = lane - qn2, i0 = lane - qn2 - qn1;
+                            if (lane < n)
+                                e = i2 < qn2 ? myq[2 * kQueueCap + qn2 - 1 - i2]
+                                             : (i1 < qn1 ? myq[kQueueCap + qn1 - 1 - i1]
+                                                         : myq[qn0 - 1 - i0]);
+                            const int t2 = qn2 < n ? qn2 : n;
+                            const int t1 = qn1 < n - t2 ? qn1 : n - t2;
+                            qn2 -= t2;
+                            qn1 -= t1;
+                            qn0 -= n - t2 - t1;
+                        } else {
+                            break;
+                        }
                     } else {
-                        break;
+                        constexpr int NSEG = C::WAVES * kBuckets;
+                        int j = 0;
+                        if (lane == 0) j = atomicAdd(&counter[3], 1);
+                        j = uni(j) * 64;
+                        // lane s: end of segment s = (class 2 - s / WAVES, wave s % WAVES) in the list
+                        int end = lane < NSEG ? pool[(lane % C::WAVES) * kBuckets + kBuckets - 1 - lane / C::WAVES] : 0;
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const int up = __shfl_up(end, o, 64);
+                            end += lane >= o ? up : 0;
+                        }
+                        const int total = __builtin_amdgcn_readlane(end, 63);
+                        if (j >= total) break;
+                        // the segments that reach into this batch are [kf, kl]
+                        const int kf = (int)__popcll(__ballot(lane < NSEG && end <= j));
+                        const int kl = (int)__popcll(__ballot(lane < NSEG && end <= j + 63));
+                        const int g = j + lane;
+                        int seg = kf, base = kf ? __builtin_amdgcn_readlane(end, uni(kf - 1)) : 0;
+                        for (int k = kf; k < kl; ++k) {
+                            const int ek = __builtin_amdgcn_readlane(end, uni(k));
+                            if (ek <= g) seg = k + 1, base = ek;
+                        }
+                        n = total - j < 64 ? total - j : 64;
+                        if (lane < n)
+                            e = queue[((seg % C::WAVES) * kBuckets + kBuckets - 1 - seg / C::WAVES) * kQueueCap + (g - base)];
                     }
                     DDRR_PROF(PROF_POP);
                     DDRR_PROF_COUNT(PROF_N_BATCH, 1);
