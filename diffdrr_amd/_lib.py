@@ -15,7 +15,7 @@ from ctypes import c_double, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffdrr_hip.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 REDUCE_SUM, REDUCE_MAX = 0, 1
 LOOKUP_STEP, LOOKUP_MID_NEAREST, LOOKUP_MID_TRILINEAR = 0, 1, 2
@@ -85,6 +85,14 @@ _SIGNATURES = {
                                    _P],
     "ddrr_trilinear_backward_f64": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _D, _D, _I, _P, _P,
                                     _P, _P, _P, _P, _P, _P],
+    "ddrr_siddon_segments_general": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _I, _D, _D, _I, _I, _I,
+                                     _P, _P],
+    "ddrr_siddon_segments_general_backward": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _D,
+                                              _D, _I, _I, _I, _P, _P, _P, _P, _P],
+    "ddrr_trilinear_samples_general": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _I, _D, _D, _I, _P,
+                                       _P, _I, _I, _I, _P, _P],
+    "ddrr_trilinear_samples_general_backward": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _D,
+                                                _D, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
 }
 EXPORTS = ["ddrr_abi_version", "ddrr_last_error", *_SIGNATURES]
 

@@ -83,6 +83,35 @@ DDRR_HD MarchSetup march_setup(const Dims D, const GridMap &g, const float s[3],
     return q;
 }
 
+// The index coordinate of a sample by the reference's own chain of separately rounded fp32
+// tensor operations: alphas = linspace * (alphamax - alphamin) + alphamin (renderers.py:225),
+// x = s + alpha d, 2 (x + shift) / D - 1 (:148-152), then aten's un-normalise.  For the
+// discontinuous lookups (labels, mode="nearest"), where the side of a voxel boundary a sample
+// falls on is decided by exactly this arithmetic.
+DDRR_HD void march_exact_coord(const Dims D, float lin, const MarchSetup &q, float amin,
+                               const float s[3], float shift, bool align_corners, float un[3]) {
+    const float al_ref = add_rn(mul_rn(lin, q.span), amin);
+    const float Dn[3] = {(float)D.x, (float)D.y, (float)D.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = add_rn(s[a], mul_rn(al_ref, q.d[a]));
+        const float nrm = add_rn(mul_rn(2.f, add_rn(x, shift)) / Dn[a], -1.f);
+        un[a] = align_corners ? mul_rn(add_rn(nrm, 1.f) / 2.f, Dn[a] - 1.f)
+                              : add_rn(mul_rn(add_rn(nrm, 1.f), Dn[a]), -1.f) / 2.f;
+    }
+}
+
+// mode="nearest" of the marcher: the voxel lookup is as discontinuous as the label lookup, so
+// the sample's index coordinate is the reference's own chain as well (gx, gy, gz are replaced)
+#define DDRR_MARCH_NEAREST_COORD(lin)                                              \
+    if (NEAREST) {                                                                 \
+        float un_[3];                                                              \
+        march_exact_coord(D, (lin), q, amin, s, shift, align_corners, un_);        \
+        gx = un_[0];                                                               \
+        gy = un_[1];                                                               \
+        gz = un_[2];                                                               \
+    }
+
 template <int REDUCE, bool NEAREST>
 DDRR_HD float trilinear_forward_ray(const float *__restrict__ vol, const Dims D, const float s[3],
                                     const float t[3], float shift, float eps, int P, float amin,
@@ -93,9 +122,10 @@ DDRR_HD float trilinear_forward_ray(const float *__restrict__ vol, const Dims D,
     float acc = (REDUCE == REDUCE_SUM || skipped) ? 0.f : -INFINITY;
     for (int m = q.m_lo; m <= q.m_hi; ++m) {
         const float al = fmaf(lin01(m, P, q.lstep), q.span, amin);  // renderers.py:224-225
-        const float gx = fmaf(fmaf(al, q.d[0], s[0]), g.k[0], g.o[0]);
-        const float gy = fmaf(fmaf(al, q.d[1], s[1]), g.k[1], g.o[1]);
-        const float gz = fmaf(fmaf(al, q.d[2], s[2]), g.k[2], g.o[2]);
+        float gx = fmaf(fmaf(al, q.d[0], s[0]), g.k[0], g.o[0]);
+        float gy = fmaf(fmaf(al, q.d[1], s[1]), g.k[1], g.o[1]);
+        float gz = fmaf(fmaf(al, q.d[2], s[2]), g.k[2], g.o[2]);
+        DDRR_MARCH_NEAREST_COORD(lin01(m, P, q.lstep))
         const float v = NEAREST ? fetch_nearest(vol, D, gx, gy, gz)
                                 : fetch_trilinear(vol, D, gx, gy, gz, nullptr, false);
         if (REDUCE == REDUCE_SUM)
@@ -117,18 +147,9 @@ DDRR_HD float trilinear_forward_ray(const float *__restrict__ vol, const Dims D,
 DDRR_HD int march_label(const unsigned char *__restrict__ labels, const Dims D, float lin,
                         const MarchSetup &q, float amin, const float s[3], float shift,
                         bool align_corners) {
-    const float al_ref = add_rn(mul_rn(lin, q.span), amin);
-    const float Dn[3] = {(float)D.x, (float)D.y, (float)D.z};
-    float rr[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float x = add_rn(s[a], mul_rn(al_ref, q.d[a]));
-        const float nrm = add_rn(mul_rn(2.f, add_rn(x, shift)) / Dn[a], -1.f);
-        const float un = align_corners ? mul_rn(add_rn(nrm, 1.f) / 2.f, Dn[a] - 1.f)
-                                       : add_rn(mul_rn(add_rn(nrm, 1.f), Dn[a]), -1.f) / 2.f;
-        rr[a] = rintf(un);  // half-to-even == nearbyint
-    }
-    const float rx = rr[0], ry = rr[1], rz = rr[2];
+    float un[3];
+    march_exact_coord(D, lin, q, amin, s, shift, align_corners, un);
+    const float rx = rintf(un[0]), ry = rintf(un[1]), rz = rintf(un[2]);  // == nearbyint
     const bool in = rx >= 0.f && rx < (float)D.x && ry >= 0.f && ry < (float)D.y && rz >= 0.f &&
                     rz < (float)D.z;
     return in ? (int)labels[((int)rx * D.y + (int)ry) * D.z + (int)rz] : 0;
@@ -148,9 +169,10 @@ DDRR_HD void trilinear_samples_ray(const float *__restrict__ vol, const Dims D, 
         float v = 0.f;
         if (m >= q.m_lo && m <= q.m_hi) {
             const float al = fmaf(lin01(m, P, q.lstep), q.span, amin);
-            const float gx = fmaf(fmaf(al, q.d[0], s[0]), g.k[0], g.o[0]);
-            const float gy = fmaf(fmaf(al, q.d[1], s[1]), g.k[1], g.o[1]);
-            const float gz = fmaf(fmaf(al, q.d[2], s[2]), g.k[2], g.o[2]);
+            float gx = fmaf(fmaf(al, q.d[0], s[0]), g.k[0], g.o[0]);
+            float gy = fmaf(fmaf(al, q.d[1], s[1]), g.k[1], g.o[1]);
+            float gz = fmaf(fmaf(al, q.d[2], s[2]), g.k[2], g.o[2]);
+            DDRR_MARCH_NEAREST_COORD(lin01(m, P, q.lstep))
             v = NEAREST ? fetch_nearest(vol, D, gx, gy, gz)
                         : fetch_trilinear(vol, D, gx, gy, gz, nullptr, false);
         }
@@ -236,9 +258,10 @@ DDRR_HD int trilinear_argmax_ray(const float *__restrict__ vol, const Dims D, co
     int idx = -1;
     for (int m = q.m_lo; m <= q.m_hi; ++m) {
         const float al = fmaf(lin01(m, P, q.lstep), q.span, amin);
-        const float gx = fmaf(fmaf(al, q.d[0], s[0]), g.k[0], g.o[0]);
-        const float gy = fmaf(fmaf(al, q.d[1], s[1]), g.k[1], g.o[1]);
-        const float gz = fmaf(fmaf(al, q.d[2], s[2]), g.k[2], g.o[2]);
+        float gx = fmaf(fmaf(al, q.d[0], s[0]), g.k[0], g.o[0]);
+        float gy = fmaf(fmaf(al, q.d[1], s[1]), g.k[1], g.o[1]);
+        float gz = fmaf(fmaf(al, q.d[2], s[2]), g.k[2], g.o[2]);
+        DDRR_MARCH_NEAREST_COORD(lin01(m, P, q.lstep))
         const float v = NEAREST ? fetch_nearest(vol, D, gx, gy, gz)
                                 : fetch_trilinear(vol, D, gx, gy, gz, nullptr, false);
         if (v > best) {
@@ -275,9 +298,10 @@ DDRR_HD MarchGrad trilinear_backward_ray(const float *__restrict__ vol, const Di
     for (int m = q.m_lo; m <= q.m_hi; ++m) {
         const float u = lin01(m, P, q.lstep);
         const float al = fmaf(u, q.span, amin);
-        const float gx = fmaf(fmaf(al, q.d[0], s[0]), g.k[0], g.o[0]);
-        const float gy = fmaf(fmaf(al, q.d[1], s[1]), g.k[1], g.o[1]);
-        const float gz = fmaf(fmaf(al, q.d[2], s[2]), g.k[2], g.o[2]);
+        float gx = fmaf(fmaf(al, q.d[0], s[0]), g.k[0], g.o[0]);
+        float gy = fmaf(fmaf(al, q.d[1], s[1]), g.k[1], g.o[1]);
+        float gz = fmaf(fmaf(al, q.d[2], s[2]), g.k[2], g.o[2]);
+        DDRR_MARCH_NEAREST_COORD(u)
         const float w = wt(m, u, q);
         if (NEAREST) {
             sumT = fmaf(w, fetch_nearest(vol, D, gx, gy, gz), sumT);

@@ -888,3 +888,101 @@ def trilinear_backward_f64(volume, source, target, img, grad_out, alphamin, alph
                 _ptr(res["g_target"]), _ptr(res["g_img"]), _ptr(res["g_alpha"]),
                 _ptr(res["g_volume"]))
     return res
+
+
+# ---------------------------------------------------------------- the materialising general path
+# (csrc/general_rays.hip: the per-segment / per-sample tensors of the reference and their
+# autograd, float32 or float64, for the keyword combinations the fused kernels do not take)
+
+def _general_inputs(volume, source, target, img):
+    if volume.dtype not in (torch.float32, torch.float64):
+        raise TypeError(f"the general path renders float32 or float64, not {volume.dtype}")
+    B, N = _check_rays(volume, source, target, img, volume.dtype)
+    volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    return B, N, volume, source, target, img, int(volume.dtype == torch.float64)
+
+
+def siddon_segments_general(volume, source, target, img, *, voxel_shift=0.5, eps=1e-8,
+                            lookup="step", align_corners=False, raw=False):
+    """-> terms (B, M-1, N), M = Dx+Dy+Dz+3: ``img * value * interval`` per segment
+    (renderers.py:66-71), or with ``raw`` the looked-up values alone (the label lookup)."""
+    B, N, volume, source, target, img, f64 = _general_inputs(volume, source, target, img)
+    M1 = sum(volume.shape) + 2
+    terms = torch.empty(B, M1, N, dtype=volume.dtype, device=volume.device)
+    if not _empty(B, N):
+        _launch("ddrr_siddon_segments_general", volume.device, volume.data_ptr(), f64,
+                *volume.shape, source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img),
+                B, N, float(voxel_shift), float(eps), _LOOKUP[lookup], int(bool(align_corners)),
+                int(bool(raw)), terms.data_ptr())
+    return terms
+
+
+def siddon_segments_general_backward(volume, source, target, img, grad_terms, *, voxel_shift=0.5,
+                                     eps=1e-8, lookup="step", align_corners=False,
+                                     through_lookup=True, want_rays=True, want_img=True,
+                                     want_volume=False):
+    """-> (g_source per ray (B,N,3), g_target (B,N,3), g_img (B,N), g_volume), None where not asked"""
+    B, N, volume, source, target, img, f64 = _general_inputs(volume, source, target, img)
+    dev = volume.device
+    new = lambda *s: torch.empty(*s, dtype=volume.dtype, device=dev)  # noqa: E731
+    g_source = new(B, N, 3) if want_rays else None
+    g_target = new(B, N, 3) if want_rays else None
+    g_img = new(B, N) if want_img and through_lookup else None
+    g_volume = torch.zeros_like(volume, memory_format=torch.contiguous_format) \
+        if want_volume and through_lookup else None
+    if not _empty(B, N):
+        grad_terms = grad_terms.to(volume.dtype).contiguous()
+        _launch("ddrr_siddon_segments_general_backward", dev, volume.data_ptr(), f64,
+                *volume.shape, source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img),
+                grad_terms.data_ptr(), B, N, float(voxel_shift), float(eps), _LOOKUP[lookup],
+                int(bool(align_corners)), int(bool(through_lookup)), _ptr(g_source),
+                _ptr(g_target), _ptr(g_img), _ptr(g_volume))
+    elif g_img is not None:
+        g_img.zero_()
+    return g_source, g_target, g_img, g_volume
+
+
+def trilinear_samples_general(volume, source, target, img, alphamin, alphamax, *, n_points=500,
+                              voxel_shift=0.5, eps=1e-8, mode="bilinear", align_corners=False,
+                              raw=False):
+    """-> samples (B, P, N): ``img * step * value`` per sample (renderers.py:224-236), or with
+    ``raw`` the looked-up values alone (the label lookup)."""
+    B, N, volume, source, target, img, f64 = _general_inputs(volume, source, target, img)
+    samples = torch.empty(B, int(n_points), N, dtype=volume.dtype, device=volume.device)
+    if not _empty(B, N):
+        alphamin = alphamin.to(volume.dtype).reshape(1).contiguous()
+        alphamax = alphamax.to(volume.dtype).reshape(1).contiguous()
+        _launch("ddrr_trilinear_samples_general", volume.device, volume.data_ptr(), f64,
+                *volume.shape, source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img),
+                B, N, float(voxel_shift), float(eps), int(n_points), alphamin.data_ptr(),
+                alphamax.data_ptr(), int(mode == "nearest"), int(bool(align_corners)),
+                int(bool(raw)), samples.data_ptr())
+    return samples
+
+
+def trilinear_samples_general_backward(volume, source, target, img, grad_samples, alphamin,
+                                       alphamax, *, n_points=500, voxel_shift=0.5, eps=1e-8,
+                                       mode="bilinear", align_corners=False, want_rays=True,
+                                       want_img=True, want_alpha=True, want_volume=False):
+    """-> dict(g_source per ray, g_target, g_img, g_alpha (B,N,2) per ray, g_volume)"""
+    B, N, volume, source, target, img, f64 = _general_inputs(volume, source, target, img)
+    dev = volume.device
+    new = lambda *s: torch.zeros(*s, dtype=volume.dtype, device=dev)  # noqa: E731
+    res = {"g_source": new(B, N, 3) if want_rays else None,
+           "g_target": new(B, N, 3) if want_rays else None,
+           "g_img": new(B, N) if want_img else None,
+           "g_alpha": new(B, N, 2) if want_alpha else None,
+           "g_volume": torch.zeros_like(volume, memory_format=torch.contiguous_format)
+           if want_volume else None}
+    if not _empty(B, N):
+        alphamin = alphamin.to(volume.dtype).reshape(1).contiguous()
+        alphamax = alphamax.to(volume.dtype).reshape(1).contiguous()
+        grad_samples = grad_samples.to(volume.dtype).contiguous()
+        _launch("ddrr_trilinear_samples_general_backward", dev, volume.data_ptr(), f64,
+                *volume.shape, source.data_ptr(), source.shape[1], target.data_ptr(), _ptr(img),
+                grad_samples.data_ptr(), B, N, float(voxel_shift), float(eps), int(n_points),
+                alphamin.data_ptr(), alphamax.data_ptr(), int(mode == "nearest"),
+                int(bool(align_corners)), _ptr(res["g_source"]), _ptr(res["g_target"]),
+                _ptr(res["g_img"]), _ptr(res["g_alpha"]), _ptr(res["g_volume"]))
+    return res

@@ -333,6 +333,58 @@ class _SiddonSegmentsFn(torch.autograd.Function):
         return gv, g_s, g_t, g_i, None
 
 
+class _SiddonTermsFn(torch.autograd.Function):
+    """The general path: the (B, N, M-1) per-segment tensor `img * value * interval`
+    (renderers.py:66-71) for ANY lookup (mode, align_corners) in float32 or float64, with its
+    autograd (csrc/general_core.h).  What is not one of the fused kernels' cases reduces this
+    tensor with ordinary tensor ops, exactly as the reference does."""
+
+    @staticmethod
+    def forward(ctx, volume, source, target, img, cfg):
+        terms = ops.siddon_segments_general(
+            volume, source, target, img, voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
+            lookup=cfg["lookup"], align_corners=cfg["align_corners"])
+        ctx.cfg = cfg
+        ctx.save_for_backward(volume, source, target, img)
+        return terms.transpose(1, 2)
+
+    @staticmethod
+    def backward(ctx, grad):
+        volume, source, target, img = ctx.saved_tensors
+        cfg = ctx.cfg
+        need_vol, need_s, need_t, need_i = ctx.needs_input_grad[:4]
+        through = not cfg["stop_gradients"]
+        gs, gt, gi, gv = ops.siddon_segments_general_backward(
+            volume, source, target, img, grad.transpose(1, 2), voxel_shift=cfg["voxel_shift"],
+            eps=cfg["eps"], lookup=cfg["lookup"], align_corners=cfg["align_corners"],
+            through_lookup=through, want_rays=bool(need_s or need_t), want_img=bool(need_i),
+            want_volume=bool(need_vol))
+        g_s = None
+        if need_s:
+            g_s = gs.sum(dim=1, keepdim=True) if source.shape[1] == 1 else gs
+        return gv, g_s, (gt if need_t else None), \
+            (gi.view_as(img) if gi is not None and need_i else None), None
+
+
+def _scatter_channels(terms, labels, mask):
+    """mask_to_channels (renderers.py:77-89, 242-252) on materialised tensors: `terms` and the
+    integer `labels` are (B, K, N); channel c collects the terms whose label is c."""
+    B, _, N = terms.shape
+    C = int(mask.max().item()) + 1
+    return torch.zeros(B, C, N, dtype=terms.dtype, device=terms.device).scatter_add_(1, labels, terms)
+
+
+def _reduce_terms(terms, reducefn):
+    """reference `reduce` (renderers.py:175-183) over the last dim of a materialised tensor"""
+    if reducefn == "sum":
+        return terms.sum(dim=-1)
+    if reducefn == "max":
+        return terms.max(dim=-1).values
+    if callable(reducefn):
+        return reducefn(terms)
+    raise ValueError(f"Only supports reducefn 'sum' or 'max', not {reducefn}")
+
+
 class _SiddonPoseFn(torch.autograd.Function):
     """The DRR case end to end: world pose per DRR -> image.  Inputs: volume, Mw (B,3,4)
     (extrinsic o reorient), P (N,3) calibrated detector points, Ainv (3,4) world -> voxel.
@@ -481,15 +533,16 @@ class Siddon(torch.nn.Module):
     def dims(self, volume):
         return torch.tensor(volume.shape).to(volume)
 
-    def _cfg(self, align_corners, det="unchecked"):
+    def _cfg(self, align_corners, det="unchecked", reducefn=None):
         if self.mode == "bilinear":
             lookup = "mid_trilinear"
         elif align_corners:
             lookup = "mid_nearest"
         else:
             lookup = "step"
-        ops.reduce_code(self.reducefn)  # validates / raises like reference `reduce`
-        return {"voxel_shift": self.voxel_shift, "eps": self.eps, "reducefn": self.reducefn,
+        reducefn = self.reducefn if reducefn is None else reducefn
+        ops.reduce_code(reducefn)  # validates / raises like reference `reduce`
+        return {"voxel_shift": self.voxel_shift, "eps": self.eps, "reducefn": reducefn,
                 "lookup": lookup, "align_corners": bool(align_corners),
                 "stop_gradients": self.stop_gradients_through_grid_sample,
                 "det": self.detector_shape if det == "unchecked" else det, "tile": self.tile,
@@ -513,39 +566,66 @@ class Siddon(torch.nn.Module):
                               for labels, C, k0 in _labels_u8(mask)], dim=1)
         return _SiddonPoseFn.apply(volume, Mw, P, Ainv, cfg).unsqueeze(1)
 
+    def _general(self, volume, source, target, img, lookup, align_corners, mask):
+        """Every other keyword combination the reference renders (csrc/general_core.h): the
+        materialised per-segment tensor, reduced as the reference reduces it."""
+        B, N, _ = target.shape
+        dt = volume.dtype
+        source, target = source.to(dt), target.to(dt)
+        gcfg = {"voxel_shift": self.voxel_shift, "eps": self.eps, "lookup": lookup,
+                "align_corners": bool(align_corners),
+                "stop_gradients": self.stop_gradients_through_grid_sample}
+        terms = _SiddonTermsFn.apply(volume, source, target, img.reshape(B, N).to(dt), gcfg)
+        if mask is None:
+            return _reduce_terms(terms, self.reducefn).unsqueeze(1)
+        # the label of every segment: the same lookup on the label map, `.long()` (:82-84)
+        labels = ops.siddon_segments_general(
+            mask.to(dt), source.detach(), target.detach(), None, voxel_shift=self.voxel_shift,
+            eps=self.eps, lookup=lookup, align_corners=align_corners, raw=True).long()
+        return _scatter_channels(terms.transpose(1, 2), labels, mask)
+
     def forward(self, volume, source, target, img, align_corners=False, mask=None):
         B, N, _ = target.shape
-        if callable(self.reducefn) and not isinstance(self.reducefn, str):
-            if volume.dtype == torch.float64:
-                raise NotImplementedError("float64 rendering covers reducefn 'sum' and 'max'")
+        user_reduce = callable(self.reducefn) and not isinstance(self.reducefn, str)
+        f64 = volume.dtype == torch.float64
+        if self.mode == "bilinear":
+            lookup = "mid_trilinear"
+        else:
+            lookup = "mid_nearest" if align_corners else "step"
+        if mask is not None:
+            # mask_to_channels (renderers.py:77-89): the reducefn plays no part
+            if f64 or lookup != "step":
+                return self._general(volume, source, target, img, lookup, align_corners, mask)
+            cfg = self._cfg(align_corners, _grid_or_none(self, source, target), reducefn="sum")
+            return torch.cat([_SiddonChannelsFn.apply(volume, source, target, img.reshape(B, N),
+                                                      labels, C, cfg)[:, k0:]
+                              for labels, C, k0 in _labels_u8(mask)], dim=1)
+        if user_reduce:
             # a user reduction over the per-segment tensor (renderers.py:175-183,
             # introduction.ipynb:506-529): the tensor is materialised for it
-            if self.mode != "nearest" or align_corners or mask is not None:
-                raise NotImplementedError("a callable reducefn needs mode='nearest', "
-                                          "align_corners=False and no mask")
+            if f64 or lookup != "step":
+                return self._general(volume, source, target, img, lookup, align_corners, None)
             cfg = {"voxel_shift": self.voxel_shift, "eps": self.eps,
                    "stop_gradients": self.stop_gradients_through_grid_sample}
             terms = _SiddonSegmentsFn.apply(volume, source, target, img.reshape(B, N), cfg)
             return self.reducefn(terms).unsqueeze(1)
         cfg = self._cfg(align_corners, _grid_or_none(self, source, target))
-        if volume.dtype == torch.float64:
-            # a module moved .to(torch.float64) (reference drr.py:71-75): the fp64 kernels
-            if mask is not None or cfg["lookup"] != "step":
-                raise NotImplementedError("float64 rendering covers mode='nearest', "
-                                          "align_corners=False without a mask")
+        wants_grad = torch.is_grad_enabled() and any(
+            t.requires_grad for t in (volume, source, target, img))
+        if f64:
+            # a module moved .to(torch.float64) (reference drr.py:71-75): the fused fp64 kernels
+            # take the default lookup (reducefn sum, or max without gradients)
+            if lookup != "step" or (wants_grad and self.reducefn != "sum"):
+                return self._general(volume, source, target, img, lookup, align_corners, None)
             out = _SiddonF64Fn.apply(volume, source.to(volume), target.to(volume),
                                      img.reshape(B, N).to(volume), cfg)
             return out.unsqueeze(1)
-        if mask is None:
-            out = _SiddonFn.apply(volume, source, target, img.reshape(B, N), cfg)
-            return out.unsqueeze(1)
-        # mask_to_channels (renderers.py:77-89)
-        if cfg["lookup"] != "step" or self.reducefn != "sum":
-            raise NotImplementedError(
-                "mask_to_channels needs mode='nearest', align_corners=False, reducefn='sum'")
-        return torch.cat([_SiddonChannelsFn.apply(volume, source, target, img.reshape(B, N), labels,
-                                                  C, cfg)[:, k0:]
-                          for labels, C, k0 in _labels_u8(mask)], dim=1)
+        if lookup != "step" and wants_grad and (
+                self.reducefn != "sum" or self.stop_gradients_through_grid_sample):
+            # gradients of a midpoint lookup with reducefn="max" or under stop_gradients
+            return self._general(volume, source, target, img, lookup, align_corners, None)
+        out = _SiddonFn.apply(volume, source, target, img.reshape(B, N), cfg)
+        return out.unsqueeze(1)
 
 
 def get_alpha_minmax(source, target, dims, voxel_shift, eps):
@@ -728,6 +808,47 @@ class _TrilinearSamplesFn(torch.autograd.Function):
         return r["g_volume"], g_s, g_t, g_i, g_a0, g_a1, None
 
 
+class _MarchSamplesGeneralFn(torch.autograd.Function):
+    """The general path of the marcher: the (B, N, P) per-sample tensor `img * step * value`
+    (renderers.py:224-236) for any mode / align_corners in float32 or float64, with its autograd
+    (csrc/general_core.h)."""
+
+    @staticmethod
+    def forward(ctx, volume, source, target, img, alphamin, alphamax, cfg):
+        out = ops.trilinear_samples_general(
+            volume, source, target, img, alphamin, alphamax, n_points=cfg["n_points"],
+            voxel_shift=cfg["voxel_shift"], eps=cfg["eps"], mode=cfg["mode"],
+            align_corners=cfg["align_corners"])
+        ctx.cfg = cfg
+        ctx.save_for_backward(volume, source, target, img, alphamin, alphamax)
+        return out.transpose(1, 2)
+
+    @staticmethod
+    def backward(ctx, grad):
+        volume, source, target, img, alphamin, alphamax = ctx.saved_tensors
+        cfg = ctx.cfg
+        need_vol, need_s, need_t, need_i, need_a0, need_a1 = ctx.needs_input_grad[:6]
+        r = ops.trilinear_samples_general_backward(
+            volume, source, target, img, grad.transpose(1, 2), alphamin, alphamax,
+            n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
+            mode=cfg["mode"], align_corners=cfg["align_corners"],
+            want_rays=bool(need_s or need_t), want_img=bool(need_i),
+            want_alpha=bool(need_a0 or need_a1), want_volume=bool(need_vol))
+        g_s = g_t = g_a0 = g_a1 = g_i = None
+        if need_s:
+            g_s = r["g_source"].sum(dim=1, keepdim=True) if source.shape[1] == 1 \
+                else r["g_source"]
+        if need_t:
+            g_t = r["g_target"]
+        if need_i:
+            g_i = r["g_img"].view_as(img)
+        if need_a0 or need_a1:
+            ga = r["g_alpha"].sum(dim=(0, 1))
+            g_a0 = ga[0].reshape(alphamin.shape) if need_a0 else None
+            g_a1 = ga[1].reshape(alphamax.shape) if need_a1 else None
+        return r["g_volume"], g_s, g_t, g_i, g_a0, g_a1, None
+
+
 class Trilinear(torch.nn.Module):
     """Differentiable X-ray renderer: trilinear ray marching (reference
     renderers.py:186-254) as one fused gfx950 kernel per call."""
@@ -787,35 +908,47 @@ class Trilinear(torch.nn.Module):
                 alphamin, alphamax = lo.min(), hi.max()
         alphamin = torch.as_tensor(alphamin, dtype=volume.dtype, device=volume.device)
         alphamax = torch.as_tensor(alphamax, dtype=volume.dtype, device=volume.device)
-        if volume.dtype == torch.float64:
-            if user_reduce or mask is not None or self.mode != "bilinear" or align_corners \
-                    or self.reducefn != "sum":
-                raise NotImplementedError("float64 marching covers mode='bilinear', reducefn="
-                                          "'sum', align_corners=False without a mask")
+        f64 = volume.dtype == torch.float64
+        scfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift, "eps": self.eps,
+                "mode": self.mode, "align_corners": bool(align_corners)}
+
+        def samples():
+            """the materialised (B, N, P) tensor: the fp32 kernels that follow the reference's
+            fp32 rounding, or the general path in float64"""
+            if f64:
+                return _MarchSamplesGeneralFn.apply(
+                    volume, source.to(volume), target.to(volume), img.reshape(B, N).to(volume),
+                    alphamin, alphamax, scfg)
+            return _TrilinearSamplesFn.apply(volume, source, target, img.reshape(B, N), alphamin,
+                                             alphamax, scfg)
+
+        if mask is not None:
+            # mask_to_channels (renderers.py:242-252): the reducefn plays no part, the labels
+            # are looked up with mode "nearest" whatever the volume's mode
+            if not f64 and self.mode == "bilinear":
+                ccfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift,
+                        "eps": self.eps, "align_corners": bool(align_corners), "det": det,
+                        "tile": self.tile}
+                return torch.cat([_TrilinearChannelsFn.apply(
+                    volume, source, target, img.reshape(B, N), alphamin, alphamax, labels, C,
+                    ccfg)[:, k0:] for labels, C, k0 in _labels_u8(mask)], dim=1)
+            labels = ops.trilinear_samples_general(
+                mask.to(volume), source.detach().to(volume), target.detach().to(volume), None,
+                alphamin.detach(), alphamax.detach(), n_points=int(n_points),
+                voxel_shift=self.voxel_shift, eps=self.eps, mode="nearest",
+                align_corners=align_corners, raw=True).long()
+            return _scatter_channels(samples().transpose(1, 2), labels, mask)
+        if user_reduce:
+            # a user reduction over the per-sample tensor (renderers.py:236-240)
+            return self.reducefn(samples()).unsqueeze(1)
+        if f64:
+            if self.mode != "bilinear" or align_corners or self.reducefn != "sum":
+                return _reduce_terms(samples(), self.reducefn).unsqueeze(1)
             fcfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift, "eps": self.eps}
             out = _TrilinearF64Fn.apply(volume, source.to(volume), target.to(volume),
                                         img.reshape(B, N).to(volume), alphamin.reshape(1),
                                         alphamax.reshape(1), fcfg)
             return out.unsqueeze(1)
-        if user_reduce:
-            # a user reduction over the per-sample tensor (renderers.py:236-240)
-            if mask is not None:
-                raise NotImplementedError("a callable reducefn cannot be combined with a mask")
-            scfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift, "eps": self.eps,
-                    "mode": self.mode, "align_corners": bool(align_corners)}
-            samples = _TrilinearSamplesFn.apply(volume, source, target, img.reshape(B, N),
-                                                alphamin, alphamax, scfg)
-            return self.reducefn(samples).unsqueeze(1)
-        if mask is not None:
-            # mask_to_channels (renderers.py:242-252)
-            if self.mode != "bilinear" or self.reducefn != "sum":
-                raise NotImplementedError(
-                    "mask_to_channels needs mode='bilinear' and reducefn='sum'")
-            ccfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift, "eps": self.eps,
-                    "align_corners": bool(align_corners), "det": det, "tile": self.tile}
-            return torch.cat([_TrilinearChannelsFn.apply(volume, source, target, img.reshape(B, N),
-                                                         alphamin, alphamax, labels, C, ccfg)[:, k0:]
-                              for labels, C, k0 in _labels_u8(mask)], dim=1)
         cfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift, "eps": self.eps,
                "reducefn": self.reducefn, "mode": self.mode,
                "align_corners": bool(align_corners), "det": det, "tile": self.tile,

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 21
+#define DDRR_ABI_VERSION 22
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -399,6 +399,56 @@ int ddrr_trilinear_backward_f64(const double *volume, int dx, int dy, int dz,
                                 const double *alphamin, const double *alphamax, double *g_source,
                                 double *g_target, double *g_img, double *g_alpha, double *g_volume,
                                 void *stream);
+
+/* ---- the materialising general path -------------------------------------------------------
+ * Every keyword combination of the reference's renderers that the fused entry points above do
+ * not take goes through the tensors the reference itself materialises just before it reduces
+ * (renderers.py:70-71 the (B, N, M - 1) per-segment terms `img * intersection_length`,
+ * M = dx + dy + dz + 3; :235-236 the (B, N, P) per-sample terms `img * step_size`); sum / max / a
+ * callable reducefn / the mask_to_channels scatter (:77-89, :242-252) are then ordinary tensor
+ * operations on the caller's side.  That covers: Siddon with a mask, a callable reducefn, or
+ * gradients of reducefn "max" / stop_gradients_through_grid_sample TOGETHER WITH a midpoint
+ * lookup (mode="bilinear" / align_corners=True; :57-66), and all of those plus the marcher's
+ * mode="nearest" / reducefn="max" / align_corners=True for a module in float64 (drr.py:71-75).
+ *   f64            0: every pointer is `float`, 1: `double` (volume, rays, img, outputs alike)
+ *   terms          (B, M - 1, N)  -- the reference's tensor transposed, rays write coalesced;
+ *   samples        (B, P, N)
+ *   raw            1: the looked-up values themselves, without img and the interval / step
+ *                  length: the label lookup `_get_voxel(mask, ...)` (:82-84, :246-248; the
+ *                  caller truncates `.long()`)
+ *   lookup         DDRR_LOOKUP_* (STEP only with align_corners = 0); nearest: marcher mode
+ *   _backward      autograd of the (not raw) tensor for grad_terms / grad_samples of its shape:
+ *                  g_source (B, N, 3) per ray, g_target (B, N, 3), g_img (B, N), g_alpha
+ *                  (B, N, 2) per ray, g_volume (Dx, Dy, Dz) accumulated with atomics into a
+ *                  zero-filled array; any may be NULL.  through_lookup = 0: the values were
+ *                  looked up under no_grad (stop_gradients_through_grid_sample, :63-65): only
+ *                  the interval lengths carry gradient (g_img, g_volume must be NULL). */
+int ddrr_siddon_segments_general(const void *volume, int f64, int dx, int dy, int dz,
+                                 const void *source, int src_n, const void *target,
+                                 const void *img, int B, int N, double voxel_shift, double eps,
+                                 int lookup, int align_corners, int raw, void *terms,
+                                 void *stream);
+int ddrr_siddon_segments_general_backward(const void *volume, int f64, int dx, int dy, int dz,
+                                          const void *source, int src_n, const void *target,
+                                          const void *img, const void *grad_terms, int B, int N,
+                                          double voxel_shift, double eps, int lookup,
+                                          int align_corners, int through_lookup, void *g_source,
+                                          void *g_target, void *g_img, void *g_volume,
+                                          void *stream);
+int ddrr_trilinear_samples_general(const void *volume, int f64, int dx, int dy, int dz,
+                                   const void *source, int src_n, const void *target,
+                                   const void *img, int B, int N, double voxel_shift, double eps,
+                                   int n_points, const void *alphamin, const void *alphamax,
+                                   int nearest, int align_corners, int raw, void *samples,
+                                   void *stream);
+int ddrr_trilinear_samples_general_backward(const void *volume, int f64, int dx, int dy, int dz,
+                                            const void *source, int src_n, const void *target,
+                                            const void *img, const void *grad_samples, int B,
+                                            int N, double voxel_shift, double eps, int n_points,
+                                            const void *alphamin, const void *alphamax,
+                                            int nearest, int align_corners, void *g_source,
+                                            void *g_target, void *g_img, void *g_alpha,
+                                            void *g_volume, void *stream);
 
 #ifdef __cplusplus
 }

@@ -159,6 +159,94 @@ def check_metrics_against_reference(device):
             assert rel_err(mine.cpu().numpy(), e64) < 2 * rel_err(r32, e64) + 2e-5, (name, key)
 
 
+def _topk_sum(img):
+    """the callable reducefn of the fixtures (tests/golden/make_golden.py topk_sum)"""
+    return img.sort(descending=True).values[..., :6].sum(dim=-1)
+
+
+# The keyword combinations that go through the materialising general path
+# (csrc/general_core.h): (fixture, renderer, ctor kwargs, call kwargs, dtypes it is general for).
+# "f32" entries are the float32 cases no fused kernel takes; every "f64" entry is a float64
+# module outside the default fused fp64 kernels.
+GENERAL_CASES = [
+    ("siddon_bilinear_mask", "Siddon", {"mode": "bilinear"}, {}, ("f32", "f64")),
+    ("siddon_align_mask", "Siddon", {}, {"align_corners": True}, ("f32", "f64")),
+    ("siddon_mask_max", "Siddon", {"reducefn": "max"}, {}, ("f32", "f64")),
+    ("siddon_bilinear_callable", "Siddon", {"mode": "bilinear", "reducefn": _topk_sum}, {},
+     ("f32", "f64")),
+    ("siddon_align_max", "Siddon", {"reducefn": "max"}, {"align_corners": True}, ("f32", "f64")),
+    ("siddon_bilinear_max", "Siddon", {"mode": "bilinear", "reducefn": "max"}, {}, ("f32", "f64")),
+    ("siddon_bilinear_stopgrad", "Siddon",
+     {"mode": "bilinear", "stop_gradients_through_grid_sample": True}, {}, ("f32", "f64")),
+    ("siddon_max", "Siddon", {"reducefn": "max"}, {}, ("f64",)),
+    ("siddon_stopgrad", "Siddon", {"stop_gradients_through_grid_sample": True}, {}, ("f64",)),
+    ("siddon_bilinear", "Siddon", {"mode": "bilinear"}, {}, ("f64",)),
+    ("siddon_align_corners", "Siddon", {}, {"align_corners": True}, ("f64",)),
+    ("siddon_callable", "Siddon", {"reducefn": _topk_sum}, {}, ("f64",)),
+    ("siddon_mask", "Siddon", {}, {}, ("f64",)),
+    ("siddon_shift0", "Siddon", {"voxel_shift": 0.0}, {}, ("f64",)),
+    ("trilinear_nearest_mask", "Trilinear", {"mode": "nearest"}, {"n_points": 40}, ("f32", "f64")),
+    ("trilinear_mask_callable", "Trilinear", {"reducefn": _topk_sum}, {"n_points": 40},
+     ("f32", "f64")),
+    ("trilinear_align_corners", "Trilinear", {}, {"n_points": 45, "align_corners": True},
+     ("f32", "f64")),
+    ("trilinear_nearest", "Trilinear", {"mode": "nearest"}, {"n_points": 45}, ("f32", "f64")),
+    ("trilinear_nearest_max", "Trilinear", {"mode": "nearest", "reducefn": "max"},
+     {"n_points": 33}, ("f64",)),
+    ("trilinear_mask", "Trilinear", {}, {"n_points": 40}, ("f64",)),
+    ("trilinear_max", "Trilinear", {"reducefn": "max"}, {"n_points": 37}, ("f64",)),
+    ("trilinear_callable", "Trilinear", {"reducefn": _topk_sum}, {"n_points": 40}, ("f64",)),
+    ("trilinear_shift0", "Trilinear", {"voxel_shift": 0.0}, {"n_points": 40}, ("f64",)),
+]
+
+
+def general_case_ids():
+    return [(name, tag) for name, _, _, _, tags in GENERAL_CASES for tag in tags]
+
+
+def check_general_case(name, tag, device):
+    """One fixture of the unmodified reference (output + autograd gradients in float32 and
+    float64) through the product renderer in dtype `tag` on `device`."""
+    import torch
+
+    import diffdrr_amd
+
+    _, cls, ctor, call, _ = next(c for c in GENERAL_CASES if c[0] == name)
+    g = golden(name)
+    dt = torch.float32 if tag == "f32" else torch.float64
+    npdt = np.float32 if tag == "f32" else np.float64
+    leaf = lambda k: torch.from_numpy(np.ascontiguousarray(g[k], dtype=npdt)).to(device)  # noqa: E731
+    vol, src, tgt = (leaf(k).requires_grad_() for k in ("volume", "source", "target"))
+    img = leaf(f"img_{tag}").requires_grad_()
+    kw = dict(call)
+    if "mask" in g.files:
+        kw["mask"] = leaf("mask")
+    renderer = getattr(diffdrr_amd, cls)(**ctor)
+    out = renderer(vol, src, tgt, img, **kw)
+    ref = g[f"out_{tag}"]
+    assert out.dtype == dt and tuple(out.shape) == ref.shape
+    marcher = cls == "Trilinear"
+    # float64: the marcher's sample fractions are an fp32 linspace table whose aten kernel
+    # rounds a few entries one ulp away from the scalar formula (test_host_api.py): 1e-6
+    tol_out = 1e-4 if tag == "f32" else (1e-6 if marcher else 1e-10)
+    tol_grad = 2e-3 if tag == "f32" else (1e-5 if marcher else 1e-8)
+    assert rel_err(out.detach().cpu().numpy(), ref) < tol_out
+    if f"grad_out_{tag}" not in g.files:
+        return
+    grads = torch.autograd.grad(out, (src, tgt, img, vol), leaf(f"grad_out_{tag}"),
+                                allow_unused=True)
+    for key, mine in zip(("g_source", "g_target", "g_img", "g_volume"), grads):
+        k = f"{key}_{tag}"
+        if k not in g.files:  # the reference's autograd returned None (stop-gradients)
+            assert mine is None or float(mine.abs().max()) == 0.0, key
+            continue
+        want = g[k]
+        if mine is None:
+            assert float(np.abs(want).max()) == 0.0, key
+            continue
+        assert rel_err(mine.cpu().numpy(), want) < tol_grad, (key, rel_err(mine.cpu().numpy(), want))
+
+
 def has_gpu():
     try:
         import torch

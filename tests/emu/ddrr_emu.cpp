@@ -27,6 +27,7 @@
 #include "../../diffdrr_amd/csrc/tri_brick.h"
 #include "../../diffdrr_amd/csrc/trilinear_core.h"
 #include "../../diffdrr_amd/csrc/f64_core.h"
+#include "../../diffdrr_amd/csrc/general_core.h"
 #include "../../include/diffdrr_hip.h"
 
 using namespace ddrr;
@@ -1249,6 +1250,196 @@ int ddrr_trilinear_backward_f64(const double *volume, int dx, int dy, int dz,
             g_alpha[r * 2 + 1] = ga[1];
         }
     }
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- the materialising general path (csrc/general_rays.hip): the same templated cores
+namespace {
+
+template <class T>
+void gen_ray(const void *source, int src_n, const void *target, long r, int N, T s[3], T t[3]) {
+    const T *sp = static_cast<const T *>(source), *tp = static_cast<const T *>(target);
+    const long b = r / N, n = r - b * N;
+    for (int a = 0; a < 3; ++a) {
+        s[a] = sp[(b * src_n + (src_n == 1 ? 0 : n)) * 3 + a];
+        t[a] = tp[r * 3 + a];
+    }
+}
+
+template <class T, int LOOKUP>
+void gen_segments(const void *volume, Dims D, const void *source, int src_n, const void *target,
+                  const void *img, int B, int N, double shift, double eps, int ac, int raw,
+                  void *terms) {
+    const T *L = static_cast<const T *>(img);
+    const long M1 = (long)D.x + D.y + D.z + 2;
+    for (long r = 0; r < (long)B * N; ++r) {
+        T s[3], t[3];
+        gen_ray<T>(source, src_n, target, r, N, s, t);
+        const long b = r / N, n = r - b * N;
+        ddrr_gen::siddon_segments_ray<T, LOOKUP>(static_cast<const T *>(volume), D, s, t, (T)shift,
+                                                 (T)eps, ac != 0, L ? L[r] : (T)1, raw != 0,
+                                                 static_cast<T *>(terms) + b * M1 * N + n, N);
+    }
+}
+
+template <class T, int LOOKUP>
+void gen_segments_bwd(const void *volume, Dims D, const void *source, int src_n,
+                      const void *target, const void *img, const void *g_terms, int B, int N,
+                      double shift, double eps, int ac, int through, void *g_source,
+                      void *g_target, void *g_img, void *g_volume) {
+    const T *L = static_cast<const T *>(img);
+    T *gsrc = static_cast<T *>(g_source), *gtgt = static_cast<T *>(g_target);
+    T *gim = static_cast<T *>(g_img), *gvol = static_cast<T *>(g_volume);
+    const long M1 = (long)D.x + D.y + D.z + 2;
+    for (long r = 0; r < (long)B * N; ++r) {
+        T s[3], t[3], gs[3], gt[3], gi;
+        gen_ray<T>(source, src_n, target, r, N, s, t);
+        const long b = r / N, n = r - b * N;
+        ddrr_gen::siddon_segments_backward_ray<T, LOOKUP>(
+            static_cast<const T *>(volume), D, s, t, (T)shift, (T)eps, ac != 0, L ? L[r] : (T)1,
+            through != 0, static_cast<const T *>(g_terms) + b * M1 * N + n, N, gs, gt, gi,
+            gvol != nullptr, [&](long idx, T v) { gvol[idx] += v; });
+        for (int a = 0; a < 3; ++a) {
+            if (gsrc) gsrc[r * 3 + a] = gs[a];
+            if (gtgt) gtgt[r * 3 + a] = gt[a];
+        }
+        if (gim) gim[r] = gi;
+    }
+}
+
+template <class T, bool NEAREST>
+void gen_samples(const void *volume, Dims D, const void *source, int src_n, const void *target,
+                 const void *img, int B, int N, double shift, double eps, int P, const void *amin,
+                 const void *amax, int ac, int raw, void *samples) {
+    const T *L = static_cast<const T *>(img);
+    const T a0 = *static_cast<const T *>(amin), a1 = *static_cast<const T *>(amax);
+    for (long r = 0; r < (long)B * N; ++r) {
+        T s[3], t[3];
+        gen_ray<T>(source, src_n, target, r, N, s, t);
+        const long b = r / N, n = r - b * N;
+        ddrr_gen::trilinear_samples_ray<T, NEAREST>(static_cast<const T *>(volume), D, s, t,
+                                                    (T)shift, (T)eps, ac != 0, P, a0, a1,
+                                                    L ? L[r] : (T)1, raw != 0,
+                                                    static_cast<T *>(samples) + b * P * N + n, N);
+    }
+}
+
+template <class T, bool NEAREST>
+void gen_samples_bwd(const void *volume, Dims D, const void *source, int src_n, const void *target,
+                     const void *img, const void *g_samples, int B, int N, double shift,
+                     double eps, int P, const void *amin, const void *amax, int ac, void *g_source,
+                     void *g_target, void *g_img, void *g_alpha, void *g_volume) {
+    const T *L = static_cast<const T *>(img);
+    const T a0 = *static_cast<const T *>(amin), a1 = *static_cast<const T *>(amax);
+    T *gsrc = static_cast<T *>(g_source), *gtgt = static_cast<T *>(g_target);
+    T *gim = static_cast<T *>(g_img), *gal = static_cast<T *>(g_alpha);
+    T *gvol = static_cast<T *>(g_volume);
+    for (long r = 0; r < (long)B * N; ++r) {
+        T s[3], t[3], gs[3], gt[3], ga[2], gi;
+        gen_ray<T>(source, src_n, target, r, N, s, t);
+        const long b = r / N, n = r - b * N;
+        ddrr_gen::trilinear_samples_backward_ray<T, NEAREST>(
+            static_cast<const T *>(volume), D, s, t, (T)shift, (T)eps, ac != 0, P, a0, a1,
+            L ? L[r] : (T)1, static_cast<const T *>(g_samples) + b * P * N + n, N, gs, gt, ga, gi,
+            gvol != nullptr, [&](long idx, T v) { gvol[idx] += v; });
+        for (int a = 0; a < 3; ++a) {
+            if (gsrc) gsrc[r * 3 + a] = gs[a];
+            if (gtgt) gtgt[r * 3 + a] = gt[a];
+        }
+        if (gim) gim[r] = gi;
+        if (gal) {
+            gal[r * 2] = ga[0];
+            gal[r * 2 + 1] = ga[1];
+        }
+    }
+}
+
+}  // namespace
+
+#define GEN_BY_LOOKUP(FN, T, ...)                                              \
+    do {                                                                       \
+        if (lookup == DDRR_LOOKUP_STEP) FN<T, LOOKUP_STEP>(__VA_ARGS__);       \
+        else if (lookup == DDRR_LOOKUP_MID_NEAREST) FN<T, LOOKUP_MID_NEAREST>(__VA_ARGS__); \
+        else FN<T, LOOKUP_MID_TRILINEAR>(__VA_ARGS__);                         \
+    } while (0)
+
+extern "C" {
+
+int ddrr_siddon_segments_general(const void *volume, int f64, int dx, int dy, int dz,
+                                 const void *source, int src_n, const void *target,
+                                 const void *img, int B, int N, double voxel_shift, double eps,
+                                 int lookup, int align_corners, int raw, void *terms, void *) {
+    const Dims D{dx, dy, dz};
+    if (lookup == DDRR_LOOKUP_STEP && align_corners) return -1;
+    if (f64)
+        GEN_BY_LOOKUP(gen_segments, double, volume, D, source, src_n, target, img, B, N,
+                      voxel_shift, eps, align_corners, raw, terms);
+    else
+        GEN_BY_LOOKUP(gen_segments, float, volume, D, source, src_n, target, img, B, N,
+                      voxel_shift, eps, align_corners, raw, terms);
+    return 0;
+}
+
+int ddrr_siddon_segments_general_backward(const void *volume, int f64, int dx, int dy, int dz,
+                                          const void *source, int src_n, const void *target,
+                                          const void *img, const void *grad_terms, int B, int N,
+                                          double voxel_shift, double eps, int lookup,
+                                          int align_corners, int through_lookup, void *g_source,
+                                          void *g_target, void *g_img, void *g_volume, void *) {
+    const Dims D{dx, dy, dz};
+    if (lookup == DDRR_LOOKUP_STEP && align_corners) return -1;
+    if (!through_lookup && (g_volume || g_img)) return -1;
+    if (f64)
+        GEN_BY_LOOKUP(gen_segments_bwd, double, volume, D, source, src_n, target, img, grad_terms,
+                      B, N, voxel_shift, eps, align_corners, through_lookup, g_source, g_target,
+                      g_img, g_volume);
+    else
+        GEN_BY_LOOKUP(gen_segments_bwd, float, volume, D, source, src_n, target, img, grad_terms,
+                      B, N, voxel_shift, eps, align_corners, through_lookup, g_source, g_target,
+                      g_img, g_volume);
+    return 0;
+}
+
+int ddrr_trilinear_samples_general(const void *volume, int f64, int dx, int dy, int dz,
+                                   const void *source, int src_n, const void *target,
+                                   const void *img, int B, int N, double voxel_shift, double eps,
+                                   int n_points, const void *alphamin, const void *alphamax,
+                                   int nearest, int align_corners, int raw, void *samples,
+                                   void *) {
+    const Dims D{dx, dy, dz};
+#define GEN_SAMPLES(T, NN)                                                                       \
+    gen_samples<T, NN>(volume, D, source, src_n, target, img, B, N, voxel_shift, eps, n_points, \
+                       alphamin, alphamax, align_corners, raw, samples)
+    if (f64) {
+        if (nearest) GEN_SAMPLES(double, true); else GEN_SAMPLES(double, false);
+    } else {
+        if (nearest) GEN_SAMPLES(float, true); else GEN_SAMPLES(float, false);
+    }
+#undef GEN_SAMPLES
+    return 0;
+}
+
+int ddrr_trilinear_samples_general_backward(const void *volume, int f64, int dx, int dy, int dz,
+                                            const void *source, int src_n, const void *target,
+                                            const void *img, const void *grad_samples, int B,
+                                            int N, double voxel_shift, double eps, int n_points,
+                                            const void *alphamin, const void *alphamax,
+                                            int nearest, int align_corners, void *g_source,
+                                            void *g_target, void *g_img, void *g_alpha,
+                                            void *g_volume, void *) {
+    const Dims D{dx, dy, dz};
+#define GEN_SAMPLES_BWD(T, NN)                                                                   \
+    gen_samples_bwd<T, NN>(volume, D, source, src_n, target, img, grad_samples, B, N,           \
+                           voxel_shift, eps, n_points, alphamin, alphamax, align_corners,       \
+                           g_source, g_target, g_img, g_alpha, g_volume)
+    if (f64) {
+        if (nearest) GEN_SAMPLES_BWD(double, true); else GEN_SAMPLES_BWD(double, false);
+    } else {
+        if (nearest) GEN_SAMPLES_BWD(float, true); else GEN_SAMPLES_BWD(float, false);
+    }
+#undef GEN_SAMPLES_BWD
     return 0;
 }
 

@@ -451,8 +451,46 @@ def make_metrics_fixture():
     save("metrics", **arrays)
 
 
+def make_general_fixtures():
+    """The keyword combinations the fused kernels do not take (the materialising general path,
+    csrc/general_core.h): masks / callables / max / stop-gradients together with the midpoint
+    lookups, and the marcher's mode="nearest" with a mask.  Their float64 halves -- and those of
+    the fixtures above -- also pin the float64 general path."""
+    dims = (12, 10, 14)
+    R = ref
+    g = torch.Generator().manual_seed(19)
+    mask = torch.randint(0, 5, dims, generator=g).to(F32)
+    rays = lambda gg: random_rays(gg, dims, 2, 32)  # noqa: E731
+    renderer_fixture("siddon_bilinear_mask", lambda: R.Siddon(mode="bilinear"), {}, dims, rays, 40,
+                     mask=mask)
+    renderer_fixture("siddon_align_mask", lambda: R.Siddon(), {"align_corners": True}, dims, rays,
+                     41, mask=mask)
+    renderer_fixture("siddon_mask_max", lambda: R.Siddon(reducefn="max"), {}, dims, rays, 42,
+                     mask=mask)
+    renderer_fixture("siddon_bilinear_callable",
+                     lambda: R.Siddon(mode="bilinear", reducefn=topk_sum), {}, dims, rays, 43)
+    renderer_fixture("siddon_align_max", lambda: R.Siddon(reducefn="max"),
+                     {"align_corners": True}, dims, rays, 44)
+    renderer_fixture("siddon_bilinear_max", lambda: R.Siddon(mode="bilinear", reducefn="max"), {},
+                     dims, rays, 45)
+    renderer_fixture("siddon_bilinear_stopgrad",
+                     lambda: R.Siddon(mode="bilinear", stop_gradients_through_grid_sample=True),
+                     {}, dims, rays, 46)
+    renderer_fixture("trilinear_nearest_mask", lambda: R.Trilinear(mode="nearest"),
+                     {"n_points": 40}, dims, rays, 47, mask=mask)
+    renderer_fixture("trilinear_mask_callable", lambda: R.Trilinear(reducefn=topk_sum),
+                     {"n_points": 40}, dims, rays, 48, mask=mask)
+    renderer_fixture("trilinear_align_corners", lambda: R.Trilinear(),
+                     {"n_points": 45, "align_corners": True}, dims, rays, 49)
+    renderer_fixture("trilinear_nearest", lambda: R.Trilinear(mode="nearest"), {"n_points": 45},
+                     dims, rays, 50)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if sys.argv[1:] == ["general"]:
+        make_general_fixtures()
+        sys.exit(0)
     if sys.argv[1:] == ["swap"]:
         make_swap_fixture()
         sys.exit(0)
@@ -460,6 +498,7 @@ if __name__ == "__main__":
         make_metrics_fixture()
         sys.exit(0)
     make_renderer_fixtures()
+    make_general_fixtures()
     make_drr_fixtures()
     make_pose_fixtures()
     make_registration_fixture()

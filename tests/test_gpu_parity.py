@@ -12,6 +12,7 @@ import pytest
 import torch
 
 import oracle
+import conftest
 from conftest import golden, rel_err
 from diffdrr_amd import DRR, Siddon, Trilinear, convert, ops
 from diffdrr_amd.data import Image, Subject, make_subject, synthetic_subject
@@ -755,8 +756,9 @@ def test_empty_and_ragged_inputs(gpu):
     one = torch.ones(1, 1, 1, device=gpu)
     a = Siddon(reducefn=lambda x: x.sum(-1))(vol, s, t, one)
     assert torch.allclose(a, Siddon()(vol, s, t, one), rtol=1e-5, atol=1e-6)
-    with pytest.raises(NotImplementedError):
-        Siddon(mode="bilinear", reducefn=lambda x: x.sum(-1))(vol, s, t, one)
+    # ... with any lookup (the general path, csrc/general_core.h)
+    b = Siddon(mode="bilinear", reducefn=lambda x: x.sum(-1))(vol, s, t, one)
+    assert torch.allclose(b, Siddon(mode="bilinear")(vol, s, t, one), rtol=1e-5, atol=1e-6)
     # float64 inputs render in double (csrc/f64_rays.hip), like the reference module .to(float64)
     d = Siddon()(vol.double(), s.double(), t.double(), torch.ones(1, 1, 1, device=gpu).double())
     assert d.dtype == torch.float64
@@ -1084,3 +1086,12 @@ def test_packed_record_on_gpu(gpu, big):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 5e-5
     _, aux_p2 = ops.siddon_forward_bricks(V, s, t, L, (256, 256), want_aux=True, record_vmax=vmax)
     assert torch.equal(aux_p[:4].view(torch.int32), aux_p2[:4].view(torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,tag", conftest.general_case_ids())
+def test_general_path_matches_the_reference(gpu, name, tag):
+    """The materialising general path on the GPU (csrc/general_rays.hip; float32 and float64):
+    every keyword combination outside the fused kernels against fixtures of the unmodified
+    reference, outputs and autograd gradients."""
+    conftest.check_general_case(name, tag, gpu)

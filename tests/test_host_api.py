@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+import conftest
 from conftest import golden, rel_err
 from diffdrr_amd import DRR, Detector, Registration, RigidTransform, convert
 from diffdrr_amd import pose as P
@@ -912,3 +913,13 @@ def test_drr_module_in_float64(emulated_ops):
     with torch.no_grad():
         img32 = drr32(rot, xyz, parameterization="euler_angles", convention="ZXY")
     assert rel_err(img32.numpy(), img64.detach().numpy()) < 1e-4
+
+
+# ------------------------------------------------------------------ the general path
+
+@pytest.mark.parametrize("name,tag", conftest.general_case_ids())
+def test_general_path_matches_the_reference(emulated_ops, name, tag):
+    """Every keyword combination outside the fused kernels (csrc/general_core.h: masks,
+    callables, max, stop-gradients with the midpoint lookups; all of float64) against fixtures
+    of the unmodified reference: outputs and autograd gradients."""
+    conftest.check_general_case(name, tag, "cpu")
