@@ -161,6 +161,8 @@ int brick_launch_resources(hipStream_t st, int &n_cu, int *&work, int **order_ws
                            int *order_cap = nullptr);
 
 // The 32^3 fp32 launch path of bricks.hip (every mode); bricks_fwd.hip falls back to it.
+void order_bricks(BrickArgs &q, int BX, int BY, int BZ, int nby, int nbz, int n_bricks, int slots,
+                  hipStream_t st);
 int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const float *source,
                   const float *target, const float *img, const float *grad_out, int B, int det_h,
                   int det_w, float voxel_shift, float eps, float *out, float *aux,

@@ -269,8 +269,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         counter[2] = 0;  // "a staged voxel is non-zero"
     }
     __syncthreads();
-    const int brick_id = counter[1];
-    if (brick_id >= n_bricks) break;
+    if (counter[1] >= n_bricks) break;
+    const int brick_id = p.order ? p.order[counter[1]] : counter[1];  // (heaviest first)
     DDRR_PROF(PROF_CLAIM);
     // `box`: the voxels staged in LDS; `cells`: the planes the candidates are clipped against
     Box box;
@@ -853,7 +853,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
         }
     }
     int n_cu_dev = 0;
-    if (int rc = brick_launch_resources(st, n_cu_dev, p.work)) return rc;
+    if (int rc = brick_launch_resources(st, n_cu_dev, p.work, &p.order_ws, &p.order_cap)) return rc;
+    if (g_brick_dbg & 512) p.order_ws = nullptr;  // (bricks in id order)
     if (mode == BRICK_VOLGRAD || mode == BRICK_TRI_VOLGRAD) {
         const int tri = mode == BRICK_TRI_VOLGRAD;
         int bx = (N + kBlock - 1) / kBlock;
@@ -865,6 +866,10 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     const BrickGrid bg = (mode == BRICK_TRI_FWD || mode == BRICK_TRI_FWD_AUX) ? tri_brick_grid(p.D)
                                                                               : brick_grid(p.D);
     const int n_bricks = bg.nx * bg.ny * bg.nz;
+    // the Siddon modes hand their bricks out heaviest first like the forward kernels (the marcher's
+    // bricks are cells + halo with their own boxes: id order)
+    if (mode == BRICK_FWD || mode == BRICK_FWD_AUX || mode == BRICK_VOLGRAD || mode == BRICK_CHANNELS)
+        order_bricks(p, BRICK, BRICK, BRICK, bg.ny, bg.nz, n_bricks, n_cu_dev, st);
     const dim3 grid(n_bricks < n_cu_dev ? n_bricks : n_cu_dev), block(kBrickThreads);
     if (mode == BRICK_TRI_FWD)
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_FWD>, grid, block, lds, st, p, out, aux);

@@ -963,16 +963,7 @@ int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t
                                C::BY, C::BZ, nby, nbz, const_cast<float *>(p.ranges));
     }
     BrickArgs q = p;
-    if (q.order_ws && n_bricks <= q.order_cap && n_bricks > slots && !q.order && q.B >= 8) {
-        // (fewer bricks than workgroups: nothing to order; a handful of poses: the launch is
-        // latency-bound and the two small kernels cost more than the order gains)
-        float *weight = reinterpret_cast<float *>(q.order_ws);
-        int *order = q.order_ws + q.order_cap;
-        hipLaunchKernelGGL(brick_weight_kernel, dim3((n_bricks + 3) / 4), dim3(256), 0, st, q, C::BX,
-                           C::BY, C::BZ, nby, nbz, n_bricks, weight);
-        hipLaunchKernelGGL(brick_order_kernel, dim3(1), dim3(1024), 0, st, weight, n_bricks, order);
-        q.order = order;
-    }
+    order_bricks(q, C::BX, C::BY, C::BZ, nby, nbz, n_bricks, slots, st);
     const dim3 grid(n_bricks < slots ? n_bricks : slots), block(C::THREADS);
     hipLaunchKernelGGL((siddon_fwd_brick_kernel<AUX, C>), grid, block, C::LDS, st, q, out, aux);
     return 0;
@@ -1030,6 +1021,20 @@ using CfgF32Z64 = FwdCfg<16, 32, 64, 1024, false>;
 }  // namespace
 
 namespace ddrr_brick {
+
+// Heaviest bricks first (brick_weight_kernel, brick_order_kernel): fills q.order from the launch's
+// order workspace.  Not with fewer bricks than workgroups (nothing to order) or a handful of
+// poses (the launch is latency-bound and the two small kernels cost more than the order gains).
+void order_bricks(BrickArgs &q, int BX, int BY, int BZ, int nby, int nbz, int n_bricks, int slots,
+                  hipStream_t st) {
+    if (!(q.order_ws && n_bricks <= q.order_cap && n_bricks > slots && !q.order && q.B >= 8)) return;
+    float *weight = reinterpret_cast<float *>(q.order_ws);
+    int *order = q.order_ws + q.order_cap;
+    hipLaunchKernelGGL(brick_weight_kernel, dim3((n_bricks + 3) / 4), dim3(256), 0, st, q, BX, BY,
+                       BZ, nby, nbz, n_bricks, weight);
+    hipLaunchKernelGGL(brick_order_kernel, dim3(1), dim3(1024), 0, st, weight, n_bricks, order);
+    q.order = order;
+}
 
 // variant: DDRR_BRICKS_F32 (0) or DDRR_BRICKS_Q16 (1); tools builds know more (g_brick_variant)
 int launch_fwd_bricks(int variant, float *brick_ranges, int ranges_valid, const float *volume,
