@@ -3,7 +3,8 @@
 # separate PMC passes (HBM traffic) of the dominant kernel on the bench workload.
 # usage: tools/prof_bench.sh <outdir>
 OUT=$1; mkdir -p "$OUT"; export TMPDIR=/tmp; ROOT=$(pwd)
-(cd /tmp && timeout 120 rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/bench_trace" -o bench --output-format csv -- python "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline) > "$OUT/bench_trace.log" 2>&1
+# (the bench's own default step count: the same warm clocks as the HIP-event figures of the line)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/bench_trace" -o bench --output-format csv -- python "$ROOT/bench.py" --no-cpu-baseline > "$ROOT/$OUT/bench_line_under_trace.json") > "$OUT/bench_trace.log" 2>&1
 for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum"; do
   n=$(echo $c | cut -d' ' -f1)
   (cd /tmp && timeout 90 rocprofv3 --pmc $c -d "$ROOT/$OUT/pmc_$n" -o pmc --output-format csv -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline) > "$OUT/pmc_$n.log" 2>&1
@@ -15,7 +16,7 @@ out = sys.argv[1]
 rows = []
 for f in glob.glob(os.path.join(out, "bench_trace", "**", "*kernel_stats.csv"), recursive=True):
     rows = list(csv.DictReader(open(f)))
-print("## rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline (top kernels)")
+print("## rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline (top kernels)")
 for r in rows[:12]:
     print(f"{float(r['AverageNs'])/1e6:9.4f} ms avg  x{r['Calls']:>5}  {float(r['Percentage']):6.2f}%  {r['Name'][:110]}")
 cnt = defaultdict(lambda: defaultdict(list))
