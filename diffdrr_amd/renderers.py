@@ -7,21 +7,22 @@ HIP kernels of ``libdiffdrr_hip.so`` through ``torch.autograd.Function``s, so a
 ``DRR`` module (ours or the reference's) differentiates
 w.r.t. pose, ray endpoints and the volume exactly as before.
 
-float32 (the reference's default dtype): every combination the reference accepts is rendered
-and differentiated by kernels -- sum / max / callable ``reducefn`` (the latter over the
-materialised per-segment / per-sample tensor), ``mode`` nearest / bilinear, any
-``align_corners``, ``mask`` channels, per-ray sources.
+Every keyword combination the reference renders is rendered and differentiated here, in
+float32 and -- a module moved ``.to(torch.float64)``, reference drr.py:71-75 -- float64:
 
-float64 (a module moved ``.to(torch.float64)``, reference drr.py:71-75) is covered for the
-configurations the fp64 kernels exist for (csrc/f64_rays.hip): Siddon ``mode="nearest"``,
-``align_corners=False``, ``reducefn`` sum (forward + backward) or max (forward); Trilinear
-``mode="bilinear"``, ``reducefn="sum"``, ``align_corners=False``.  float64 with a mask, a
-callable ``reducefn``, the midpoint lookups (``align_corners=True``, Siddon
-``mode="bilinear"``), Trilinear ``mode="nearest"`` / max, or the max backward raises
-``NotImplementedError`` (the reference computes them); INTEGRATION.md lists the same.
+* the fused kernels take what the reference's defaults and tutorials use: sum / max, ``mode``
+  nearest / bilinear, any ``align_corners``, ``mask`` channels, per-ray sources, a callable
+  ``reducefn`` over the materialised per-segment / per-sample tensor (float32), and the default
+  sums in float64 (csrc/f64_rays.hip);
+* every other combination -- a mask, a callable, or gradients of ``reducefn="max"`` /
+  ``stop_gradients_through_grid_sample`` together with a midpoint lookup (``align_corners=True``,
+  Siddon ``mode="bilinear"``); the marcher's ``mode="nearest"`` with a mask; float64 beyond the
+  default sums -- goes through the general path (csrc/general_core.h): the tensor the reference
+  itself materialises just before it reduces, reduced by ordinary tensor ops.  As in the
+  reference, a mask makes the ``reducefn`` irrelevant (renderers.py:73-89).
 
-What raises instead of silently diverging: CPU tensors (there is no CPU fallback), the float64
-combinations above, and dtypes other than float32 / float64.
+What raises instead of silently diverging: CPU tensors (there is no CPU fallback) and dtypes
+other than float32 / float64.
 """
 from __future__ import annotations
 
