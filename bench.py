@@ -307,8 +307,8 @@ def main():
     ap.add_argument("--size", type=int, default=None, help="volume edge (voxels)")
     ap.add_argument("--det", type=int, default=None, help="detector edge (pixels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--storage", default=None, choices=["q16", "f32"],
-                    help="Siddon.brick_storage (default: the module's default, q16)")
+    ap.add_argument("--storage", default=None, choices=["q16p", "q16", "f32"],
+                    help="Siddon.brick_storage (default: the module's default, q16p)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                     help="cpu: harness test only (gloo ranks; the kernels are whatever "
                          "DDRR_BENCH_HOOK routes diffdrr_amd.ops to, see tests/test_dist_gloo.py)")
@@ -705,10 +705,16 @@ def main():
         }
         storage = getattr(drr.renderer, "brick_storage", None)
         if storage is not None:
-            result["config"]["brick_storage"] = (
-                "q16: bricks staged as 16-bit block-quantised voxels, one (min, step) per 32x32x64 "
-                "brick, |error| <= brick range / 131070 per voxel, fp32 arithmetic (parity block: "
-                "measured in this run)" if storage == "q16" else "f32: the volume's own values")
+            q16 = ("bricks staged as 16-bit block-quantised voxels, one (min, step) per 32x32x64 "
+                   "brick, |error| <= brick range / 131070 per voxel, fp32 arithmetic (parity block: "
+                   "measured in this run)")
+            result["config"]["brick_storage"] = {
+                "q16": "q16: " + q16,
+                "q16p": "q16p: " + q16 + "; staged from the volume's packed 16-bit bricks, a "
+                        "per-volume layout copy (+52 % of the volume's bytes) built by the first "
+                        "render after the volume changed (here: in the warm-up, +0.35 ms once), "
+                        "like the bricks' (min, max) table",
+            }.get(storage, "f32: the volume's own values")
         if world == 1 and not args.no_cpu_baseline and cfg in ("headline", "2"):
             result["cpu_baseline"], result["parity"] = cpu_baseline_and_parity(
                 drr, rot0, xyz0, images, rot.grad, xyz.grad, base, H)

@@ -15,14 +15,14 @@ from ctypes import c_double, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffdrr_hip.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 REDUCE_SUM, REDUCE_MAX = 0, 1
 LOOKUP_STEP, LOOKUP_MID_NEAREST, LOOKUP_MID_TRILINEAR = 0, 1, 2
 SIDDON_AUX = 8
 AUX_INTERLEAVED, AUX_BLOCKED, AUX_PACKED = 0, 1, 2
 REC_BLOCK_RAYS, REC_BLOCK_FLOATS = 16, 80  # blocked float record (csrc/record_layout.h)
-BRICKS_F32, BRICKS_Q16 = 0, 1  # how a brick is held in LDS (ddrr_siddon_forward_bricks)
+BRICKS_F32, BRICKS_Q16, BRICKS_Q16_PACKED = 0, 1, 2  # how a brick is held in LDS (ddrr_siddon_forward_bricks)
 PACKED_AUX_PLANES = 7  # fixed-point record (csrc/record_pack.h)
 
 _P, _I, _F, _L, _D = c_void_p, c_int, c_float, c_long, c_double
@@ -93,7 +93,10 @@ _SIGNATURES = {
                                        _P, _I, _I, _I, _P, _P],
     "ddrr_trilinear_samples_general_backward": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _D,
                                                 _D, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
+    "ddrr_brick_workspace_bytes": [_I, _I, _I, _I],
 }
+# (entries that return a size, not a status)
+_RESTYPES = {"ddrr_brick_workspace_bytes": c_long}
 EXPORTS = ["ddrr_abi_version", "ddrr_last_error", *_SIGNATURES]
 
 
@@ -115,7 +118,11 @@ class DdrrLibrary:
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(self.cdll, name)
             fn.argtypes = argtypes
-            fn.restype = c_int
+            fn.restype = _RESTYPES.get(name, c_int)
+
+    def query(self, name: str, *args):
+        """An entry that returns a value (``_RESTYPES``), not a status."""
+        return getattr(self.cdll, name)(*args)
 
     def call(self, name: str, *args):
         rc = getattr(self.cdll, name)(*args)

@@ -40,6 +40,7 @@ struct BrickArgs {
     int n_channels;               // BRICK_CHANNELS: out is (B, n_channels, N)
     const float *ranges;          // 16-bit bricks: (vmin, vmax) per brick (bricks_fwd.hip)
     int ranges_valid;             // ... already computed for this volume
+    const unsigned char *packed;  // 16-bit bricks: their LDS images, brick after brick (or null)
     const int *order;             // bricks_fwd.hip: k-th brick handed out (NULL: k itself)
     int *order_ws;                // ... this launch's workspace for it: order_cap weights, order_cap ints
     int order_cap;
@@ -174,7 +175,9 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
 // DDRR_BRICKS_F32 / DDRR_BRICKS_Q16; volumes it cannot stage with 16-byte loads take launch_bricks.
 // brick_ranges: DDRR_BRICKS_Q16 workspace (2 floats per 32^3 brick), ranges_valid: it already
 // holds this volume's ranges.
-int launch_fwd_bricks(int variant, float *brick_ranges, int ranges_valid, const float *volume,
+// packed: the workspace also holds the bricks' LDS images (DDRR_BRICKS_Q16_PACKED) behind the ranges.
+long brick_workspace_bytes(int dx, int dy, int dz, int brick_storage);
+int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_valid, const float *volume,
                       int dx, int dy, int dz, const float *source, const float *target,
                       const float *img, int B, int det_h, int det_w, float voxel_shift, float eps,
                       float *out, float *aux, float rec_q, hipStream_t st, const char *who);

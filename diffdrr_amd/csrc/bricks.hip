@@ -948,9 +948,10 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     if (!out) return fail(-1, "null out pointer");
     if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
     if (!(record_vmax >= 0.f)) return fail(-1, "record_vmax must be >= 0");
-    if (brick_storage != DDRR_BRICKS_F32 && brick_storage != DDRR_BRICKS_Q16)
-        return fail(-1, "brick_storage must be DDRR_BRICKS_F32 or DDRR_BRICKS_Q16");
-    if (brick_storage == DDRR_BRICKS_Q16 && !brick_ranges)
+    if (brick_storage != DDRR_BRICKS_F32 && brick_storage != DDRR_BRICKS_Q16 &&
+        brick_storage != DDRR_BRICKS_Q16_PACKED)
+        return fail(-1, "brick_storage must be DDRR_BRICKS_F32, DDRR_BRICKS_Q16 or DDRR_BRICKS_Q16_PACKED");
+    if (brick_storage != DDRR_BRICKS_F32 && !brick_ranges)
         return fail(-1, "DDRR_BRICKS_Q16 needs the brick_ranges workspace");
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -967,7 +968,9 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                            dim3(kBlock), 0, st, source, target, R, N, Dims{dx, dy, dz}, voxel_shift,
                            eps, rec_q, aux);
     }
-    if (int rc = launch_fwd_bricks(brick_storage, brick_ranges, ranges_valid, volume, dx, dy, dz,
+    const int packed_bricks = brick_storage == DDRR_BRICKS_Q16_PACKED;
+    if (int rc = launch_fwd_bricks(packed_bricks ? DDRR_BRICKS_Q16 : brick_storage, packed_bricks,
+                                   brick_ranges, ranges_valid, volume, dx, dy, dz,
                                    source, target, img, B, det_h, det_w, voxel_shift, eps, out, aux,
                                    rec_q, st, "ddrr_siddon_forward_bricks"))
         return rc;
@@ -975,6 +978,11 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     hipLaunchKernelGGL(siddon_out_from_record_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
                        dim3(kBlock), 0, st, aux + (packed ? 4 * R : 0), packed ? 0 : 1, img, R, out);
     return finish("ddrr_siddon_forward_bricks");
+}
+
+long ddrr_brick_workspace_bytes(int dx, int dy, int dz, int brick_storage) {
+    if (dx < 1 || dy < 1 || dz < 1) return 0;
+    return brick_workspace_bytes(dx, dy, dz, brick_storage);
 }
 
 int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char *labels, int dx,

@@ -279,6 +279,53 @@ __device__ __forceinline__ void fwd_stage_brick(const BrickArgs &p, unsigned cha
     if (!C::Q16 && (nz & 0x7fffffffu) != 0u) counter[2] = 1;  // (cleared with the claim)
 }
 
+// A volume that is rendered again and again (a registration, a pose sweep) can keep its 16-bit
+// bricks in HBM as they lie in LDS -- padding and all, brick after brick (brick_pack_kernel, into
+// the caller's workspace): staging is then a straight 16-byte copy of half the bytes, without the
+// conversion and without the 2-byte LDS stores of the padded rows.
+template <class C>
+__device__ __forceinline__ void fwd_stage_packed(const BrickArgs &p, unsigned char *brick,
+                                                 int brick_id, int tid, Q16Range &range,
+                                                 bool &brick_empty) {
+    constexpr int NV = C::BRICK_BYTES / 16, G = 4, FULL = NV / (G * C::THREADS);
+    const float lo = p.ranges[2 * brick_id], hi = p.ranges[2 * brick_id + 1];
+    range = q16_range(lo, hi);
+    brick_empty = lo == 0.f && hi == 0.f;
+    if (brick_empty) return;  // (nothing will read the brick)
+    const uint4 *src = reinterpret_cast<const uint4 *>(p.packed + (size_t)brick_id * C::BRICK_BYTES);
+    uint4 *dst = reinterpret_cast<uint4 *>(brick);
+    // groups of G loads in flight per thread, then what is left
+#pragma unroll
+    for (int g = 0; g < FULL; ++g) {
+        uint4 v[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) v[i] = src[(g * G + i) * C::THREADS + tid];
+#pragma unroll
+        for (int i = 0; i < G; ++i) dst[(g * G + i) * C::THREADS + tid] = v[i];
+    }
+    for (int k = FULL * G * C::THREADS + tid; k < NV; k += C::THREADS) dst[k] = src[k];
+}
+
+// One workgroup per brick: stage it exactly as the render kernel would and store the LDS image.
+template <class C>
+__global__ __launch_bounds__(C::THREADS) void brick_pack_kernel(BrickArgs p, int nby, int nbz,
+                                                                unsigned char *__restrict__ packed) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ int counter[4];
+    const int tid = threadIdx.x, brick_id = blockIdx.x;
+    constexpr int NV = C::BRICK_BYTES / 16;
+    uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
+    for (int k = tid; k < NV; k += C::THREADS) lds[k] = make_uint4(0u, 0u, 0u, 0u);  // (the padding)
+    __syncthreads();
+    const Box box = cfg_brick_box<C>(p.D, nby, nbz, brick_id);
+    Q16Range range = {0.f, 0.f, 0.f};
+    bool empty = false;
+    fwd_stage_brick<C>(p, smem_raw, box, brick_id, tid, range, empty, counter);
+    __syncthreads();
+    uint4 *dst = reinterpret_cast<uint4 *>(packed + (size_t)brick_id * C::BRICK_BYTES);
+    for (int k = tid; k < NV; k += C::THREADS) dst[k] = lds[k];
+}
+
 template <bool AUX, class C>
 __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict__ aux) {
@@ -371,7 +418,12 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
             }
             if (tid == 0) counter[0] = 0;
             DDRR_PROF(PROF_ROWS);
-            if (ch == 0) fwd_stage_brick<C>(p, brick, box, brick_id, tid_here, range, brick_empty, counter);
+            if (ch == 0) {
+                if (C::Q16 && p.packed)
+                    fwd_stage_packed<C>(p, brick, brick_id, tid_here, range, brick_empty);
+                else
+                    fwd_stage_brick<C>(p, brick, box, brick_id, tid_here, range, brick_empty, counter);
+            }
             DDRR_PROF(PROF_STORE);
             __syncthreads();
             if (!C::Q16 && ch == 0) brick_empty = counter[2] == 0;
@@ -956,11 +1008,31 @@ int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t
     const int nbx = (p.D.x + C::BX - 1) / C::BX, nby = (p.D.y + C::BY - 1) / C::BY;
     const int nbz = (p.D.z + C::BZ - 1) / C::BZ;
     const int n_bricks = nbx * nby * nbz, slots = n_cu * C::WGS_PER_CU;
-    if (C::Q16) {
+    if constexpr (C::Q16) {
         if (!p.ranges) return fail(-1, "DDRR_BRICKS_Q16 needs the brick_ranges workspace");
-        if (!p.ranges_valid)
+        if (!p.ranges_valid) {
             hipLaunchKernelGGL(brick_range_kernel, dim3(n_bricks), dim3(256), 0, st, p.vol, p.D, C::BX,
                                C::BY, C::BZ, nby, nbz, const_cast<float *>(p.ranges));
+            if (p.packed) {
+                static bool pack_attr[kMaxDev] = {false};
+                {
+                    std::lock_guard<std::mutex> lock(mu);
+                    if (!pack_attr[dev]) {
+                        if ((e = hipFuncSetAttribute(
+                                 reinterpret_cast<const void *>(&brick_pack_kernel<C>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, C::BRICK_BYTES)) !=
+                            hipSuccess)
+                            return fail_hip(e, "hipFuncSetAttribute");
+                        pack_attr[dev] = true;
+                    }
+                }
+                hipLaunchKernelGGL(brick_pack_kernel<C>, dim3(n_bricks), dim3(C::THREADS),
+                                   C::BRICK_BYTES, st, p, nby, nbz,
+                                   const_cast<unsigned char *>(p.packed));
+            }
+        }
+    } else if (p.packed) {
+        return fail(-1, "packed bricks are 16-bit bricks");
     }
     BrickArgs q = p;
     order_bricks(q, C::BX, C::BY, C::BZ, nby, nbz, n_bricks, slots, st);
@@ -1037,8 +1109,24 @@ void order_bricks(BrickArgs &q, int BX, int BY, int BZ, int nby, int nbz, int n_
 }
 
 // variant: DDRR_BRICKS_F32 (0) or DDRR_BRICKS_Q16 (1); tools builds know more (g_brick_variant)
-int launch_fwd_bricks(int variant, float *brick_ranges, int ranges_valid, const float *volume,
-                      int dx, int dy, int dz, const float *source, const float *target,
+// bytes of the caller's brick workspace: the (min, max) pairs, 2 floats per 32^3 brick (any brick
+// grid fits), then, for the packed storage, the LDS images of the 32 x 32 x 64 bricks
+static long ranges_bytes(int dx, int dy, int dz) {
+    const long n32 = (long)((dx + 31) / 32) * ((dy + 31) / 32) * ((dz + 31) / 32);
+    return (n32 * 2 * (long)sizeof(float) + 255) / 256 * 256;
+}
+
+long brick_workspace_bytes(int dx, int dy, int dz, int brick_storage) {
+    if (brick_storage == DDRR_BRICKS_F32) return 0;
+    long n = ranges_bytes(dx, dy, dz);
+    if (brick_storage == DDRR_BRICKS_Q16_PACKED)
+        n += (long)((dx + CfgQ16Z64::BX - 1) / CfgQ16Z64::BX) * ((dy + CfgQ16Z64::BY - 1) / CfgQ16Z64::BY) *
+             ((dz + CfgQ16Z64::BZ - 1) / CfgQ16Z64::BZ) * CfgQ16Z64::BRICK_BYTES;
+    return n;
+}
+
+int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_valid,
+                      const float *volume, int dx, int dy, int dz, const float *source, const float *target,
                       const float *img, int B, int det_h, int det_w, float voxel_shift, float eps,
                       float *out, float *aux, float rec_q, hipStream_t st, const char *who) {
     const int N = det_h * det_w;
@@ -1074,6 +1162,9 @@ int launch_fwd_bricks(int variant, float *brick_ranges, int ranges_valid, const 
     p.rec_q = rec_q;
     p.ranges = brick_ranges;
     p.ranges_valid = ranges_valid;
+    p.packed = packed && brick_ranges
+                   ? reinterpret_cast<const unsigned char *>(brick_ranges) + ranges_bytes(dx, dy, dz)
+                   : nullptr;
     p.order = nullptr;
     p.split_t = 0;
     p.split_s = 1;

@@ -67,6 +67,11 @@ def _launch(name, device, *args):
         _lib.get_lib().call(name, *args, torch.cuda.current_stream().cuda_stream)
 
 
+def _query(name, *args):
+    """A C-ABI entry that returns a size (no launch, no stream)."""
+    return _lib.get_lib().query(name, *args)
+
+
 def _check_rays(volume, source, target, img, dtype=torch.float32):
     _require_gpu(volume)
     for name, t in (("volume", volume), ("source", source), ("target", target), ("img", img)):
@@ -193,28 +198,33 @@ def record_planes(aux, B, N):
     return torch.cat([p03, blk[:, 4].reshape(1, -1)])[:, :R].reshape(5, B, N)
 
 
-_BRICK_STORAGE = {"f32": _lib.BRICKS_F32, "q16": _lib.BRICKS_Q16}
+_BRICK_STORAGE = {"f32": _lib.BRICKS_F32, "q16": _lib.BRICKS_Q16, "q16p": _lib.BRICKS_Q16_PACKED}
 _range_cache = {}  # id(volume) -> (weakref to the volume, its version, (min, max) per brick)
 
 
-def brick_ranges(volume):
-    """Workspace of the 16-bit brick staging (include/diffdrr_hip.h DDRR_BRICKS_Q16): 2 floats
-    per 32^3 brick, cached per volume TENSOR and version -- the kernel fills it on the first
-    launch after the volume changed (one pass over the volume) and reuses it afterwards.
-    (In-place edits that bypass the version counter, ``volume.data[...] = x``, are not seen.)
-    -> (tensor, valid)"""
-    ent = _range_cache.get(id(volume))
+def brick_workspace(volume, storage="q16"):
+    """Workspace of the 16-bit brick staging (include/diffdrr_hip.h DDRR_BRICKS_Q16 /
+    _PACKED): the bricks' (min, max) and, for "q16p", the bricks themselves as they lie in LDS
+    (+52 % of the volume's bytes).  Cached per volume TENSOR, version and storage -- the kernel
+    fills it on the first launch after the volume changed (one pass over the volume) and reuses
+    it afterwards.  (In-place edits that bypass the version counter, ``volume.data[...] = x``,
+    are not seen.)  -> (tensor, valid)"""
+    key = (id(volume), storage)
+    ent = _range_cache.get(key)
     if ent is not None and ent[0]() is volume and ent[1] == volume._version \
             and ent[2].device == volume.device:
         return ent[2], 1
-    n = 1
-    for d in volume.shape:
-        n *= -(-int(d) // 32)
-    buf = torch.empty(2 * n, dtype=torch.float32, device=volume.device)
-    key = id(volume)
+    n = int(_query("ddrr_brick_workspace_bytes", *(int(d) for d in volume.shape),
+                   _BRICK_STORAGE[storage]))
+    buf = torch.empty((n + 3) // 4, dtype=torch.float32, device=volume.device)
     _range_cache[key] = (weakref.ref(volume, lambda _, k=key: _range_cache.pop(k, None)),
                          volume._version, buf)
     return buf, 0
+
+
+def brick_ranges(volume):
+    """(kept name) the "q16" workspace of :func:`brick_workspace`"""
+    return brick_workspace(volume, "q16")
 
 
 def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, eps=1e-8,
@@ -226,8 +236,9 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
     (csrc/record_layout.h; :func:`record_planes` unpacks it), or with ``record_vmax`` =
     max |volume| > 0 the (7,B,N) packed fixed-point record (3 atomics per ray and brick
     instead of 5, bit-reproducible; csrc/record_pack.h).
-    ``storage``: "f32" stages the volume's own values, "q16" a 16-bit block quantisation per
-    32^3 brick (include/diffdrr_hip.h DDRR_BRICKS_Q16: two workgroups per CU)."""
+    ``storage``: "f32" stages the volume's own values in 32^3 bricks, "q16" a 16-bit block
+    quantisation in 32 x 32 x 64 bricks, "q16p" the same bricks from a packed copy kept in the
+    cached workspace (include/diffdrr_hip.h DDRR_BRICKS_*)."""
     B, N = _check_rays(volume, source, target, img)
     H, W = int(det[0]), int(det[1])
     if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
@@ -235,7 +246,7 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
     volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
     img = None if img is None else img.contiguous()
     out = torch.empty(B, N, dtype=torch.float32, device=volume.device)
-    ranges, valid = brick_ranges(volume) if storage == "q16" else (None, 0)
+    ranges, valid = brick_workspace(volume, storage) if storage != "f32" else (None, 0)
     packed = bool(want_aux and record_vmax and record_vmax > 0.0)
     aux = None
     if want_aux:

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 22
+#define DDRR_ABI_VERSION 23
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -98,16 +98,24 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
  * 32^3 voxels per brick.  DDRR_BRICKS_Q16: 16-bit block quantisation, one (min, step) pair per
  * brick (V ~ min + q step, q = 0 .. 65535: |error| <= (max - min of the brick) / 131070 per
  * voxel; all arithmetic stays fp32), which lets a brick of twice the volume (32 x 32 x 64) fit a
- * CU's LDS: fewer (ray, brick) pairs, 6-7 % faster.  brick_ranges: NULL for DDRR_BRICKS_F32;
- * for DDRR_BRICKS_Q16 a caller-owned workspace of 2 * ceil(dx/32) * ceil(dy/32) * ceil(dz/32)
- * floats holding the bricks' (min, max): with ranges_valid = 0 the call computes them first
- * (one pass over the volume, ~0.1 ms at 512^3), with ranges_valid = 1 it trusts what an earlier
- * call for the SAME volume contents left there (a registration or a pose sweep renders one
- * volume thousands of times).  A brick holding a NaN or an infinity yields NaN for every ray
+ * CU's LDS: fewer (ray, brick) pairs, 6-7 % faster.  DDRR_BRICKS_Q16_PACKED: the same bricks,
+ * additionally kept in the workspace as they lie in LDS (padding included, brick after brick;
+ * + 52 % of the volume's bytes): a later call stages a brick with a straight 16-byte copy of half
+ * the bytes instead of converting the fp32 volume again -- what a volume that is rendered many
+ * times wants, most of all with few poses per launch, where staging is most of the launch.
+ * brick_ranges: NULL for DDRR_BRICKS_F32; otherwise a caller-owned workspace of
+ * ddrr_brick_workspace_bytes(dx, dy, dz, brick_storage) bytes, 16-byte aligned, holding the
+ * bricks' (min, max) (and the packed bricks): with ranges_valid = 0 the call fills it first
+ * (one pass over the volume, ~0.1 ms at 512^3; ~0.3 ms with the packed bricks), with
+ * ranges_valid = 1 it trusts what an earlier call for the SAME volume contents and the same
+ * brick_storage left there (a registration or a pose sweep renders one volume thousands of
+ * times).  A brick holding a NaN or an infinity yields NaN for every ray
  * through it.  (A volume with only a few double bricks per CU balances badly: 256^3 is 6 %
  * faster on fp32 bricks; the Python layer chooses, diffdrr_amd/renderers.py.) */
 #define DDRR_BRICKS_F32 0
 #define DDRR_BRICKS_Q16 1
+#define DDRR_BRICKS_Q16_PACKED 2
+long ddrr_brick_workspace_bytes(int dx, int dy, int dz, int brick_storage);
 int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
                                const float *target, const float *img, int B, int det_h,
                                int det_w, float voxel_shift, float eps, float *out, float *aux,

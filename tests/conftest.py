@@ -71,6 +71,7 @@ def emulated_ops(emu_lib, monkeypatch):
     monkeypatch.setattr(ops, "_require_gpu", lambda volume: None)
     monkeypatch.setattr(ops, "on_device", lambda t: True)
     monkeypatch.setattr(ops, "_launch", lambda name, device, *a: emu_lib.call(name, *a, None))
+    monkeypatch.setattr(ops, "_query", lambda name, *a: emu_lib.query(name, *a))
     return ops
 
 

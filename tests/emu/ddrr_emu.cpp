@@ -310,13 +310,24 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
 // length-class queues and walked in batches of 64 like a wave does, same exact clip and
 // walk (brick_walk.h); LDS brick replaced by a local padded copy (same BrickLayout
 // strides), atomics by plain adds.
+// (the emulation keeps no packed copy: the packed storage is the same arithmetic from a
+// different staging source; the workspace is sized like the product's)
+long ddrr_brick_workspace_bytes(int dx, int dy, int dz, int brick_storage) {
+    if (brick_storage == DDRR_BRICKS_F32 || dx < 1 || dy < 1 || dz < 1) return 0;
+    const long n32 = (long)((dx + 31) / 32) * ((dy + 31) / 32) * ((dz + 31) / 32);
+    long n = (n32 * 8 + 255) / 256 * 256;
+    if (brick_storage == DDRR_BRICKS_Q16_PACKED)
+        n += (long)((dx + 31) / 32) * ((dy + 31) / 32) * ((dz + 63) / 64) * 133184;
+    return n;
+}
+
 int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
                                const float *target, const float *img, int B, int det_h,
                                int det_w, float voxel_shift, float eps, float *out, float *aux,
                                float record_vmax, int brick_storage, float *brick_ranges,
                                int /*ranges_valid*/, void *) {
     const Dims D{dx, dy, dz};
-    const bool q16 = brick_storage == DDRR_BRICKS_Q16;
+    const bool q16 = brick_storage == DDRR_BRICKS_Q16 || brick_storage == DDRR_BRICKS_Q16_PACKED;
     // 16-bit bricks (bricks_fwd.hip CfgQ16x2): rows and planes padded by one element
     const int qsy = 32 * 2 + 2, qsx = 32 * qsy + 2;
     std::vector<unsigned short> qbrick((size_t)qsx * 32 / 2);

@@ -16,7 +16,7 @@ def _declared():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(?:int|const char \*)\s*(ddrr_\w+)\s*\(([^;]*?)\)\s*;", text, re.S):
+    for m in re.finditer(r"\b(?:int|long|const char \*)\s*(ddrr_\w+)\s*\(([^;]*?)\)\s*;", text, re.S):
         args = m.group(2).strip()
         decls[m.group(1)] = 0 if args == "void" else len(args.split(","))
     return decls

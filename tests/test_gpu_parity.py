@@ -665,9 +665,11 @@ def test_brick_kernel_small_and_ragged_volumes(gpu):
         assert rel_err(out.cpu().numpy(), ref) < FWD_TOL, dims
 
 
-def test_q16_bricks_small_ragged_sparse_and_many_poses(gpu):
+@pytest.mark.parametrize("q16", ["q16", "q16p"])
+def test_q16_bricks_small_ragged_sparse_and_many_poses(gpu, q16):
     """The 16-bit block-quantised bricks (32 x 32 x 64, ddrr_siddon_forward_bricks with
-    DDRR_BRICKS_Q16) where the module would not choose them -- small volumes -- for the edge cases
+    DDRR_BRICKS_Q16, and DDRR_BRICKS_Q16_PACKED: the same bricks staged from the packed copy in
+    the workspace, first call and cached call) where the module would not choose them -- small volumes -- for the edge cases
     of the brick grid: partial bricks on every axis, a volume smaller than one brick, empty (all
     zero) bricks next to full ones, a z extent that is not a multiple of 4 (the general fp32
     kernel takes over), more poses than a pose-table chunk; against the oracle, forward and the
@@ -688,8 +690,9 @@ def test_q16_bricks_small_ragged_sparse_and_many_poses(gpu):
         go = torch.rand(B, H * W, generator=g).to(gpu)
         o = oracle.siddon(V.cpu().numpy(), s.cpu().numpy(), t.cpu().numpy(), L.cpu().numpy(),
                           grad_out=go.cpu().numpy())
-        out, aux = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True, storage="q16")
-        plain, _ = ops.siddon_forward_bricks(V, s, t, L, (H, W), storage="q16")
+        out, aux = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True, storage=q16)
+        plain, _ = ops.siddon_forward_bricks(V, s, t, L, (H, W), storage=q16)
+        assert ops.brick_workspace(V, q16)[1] == 1  # (cached: the second call reused the workspace)
         exact, aux_f = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True, storage="f32")
         for img in (out, plain):
             assert rel_err(img.cpu().numpy(), o["out"].reshape(B, -1)) < FWD_TOL, dims
@@ -705,10 +708,14 @@ def test_q16_bricks_small_ragged_sparse_and_many_poses(gpu):
     rot = torch.tensor([[0.1, 0.2, -0.1]], device=gpu)
     xyz = torch.tensor([[1.0, 250.0, 2.0]], device=gpu)
     s, t, L = voxel_rays(drr, rot, xyz)
-    clean, _ = ops.siddon_forward_bricks(drr.density, s, t, L, (32, 32), storage="q16")
+    clean, _ = ops.siddon_forward_bricks(drr.density, s, t, L, (32, 32), storage=q16)
     bad = drr.density.clone()
     bad[40, 40, 100] = float("nan")
-    dirty, _ = ops.siddon_forward_bricks(bad, s, t, L, (32, 32), storage="q16")
+    dirty, _ = ops.siddon_forward_bricks(bad, s, t, L, (32, 32), storage=q16)
+    # an in-place edit of a rendered volume is seen (the version counter invalidates the workspace)
+    bad[40, 40, 100] = 0.5
+    fixed, _ = ops.siddon_forward_bricks(bad, s, t, L, (32, 32), storage=q16)
+    assert not torch.isnan(fixed).any()
     nan = torch.isnan(dirty)
     assert nan.any() and not nan.all()
     assert torch.allclose(dirty[~nan], clean[~nan], rtol=1e-5, atol=1e-5)  # (atomics: not bit-stable)

@@ -219,7 +219,7 @@ def test_metrics_match_reference_values_and_gradients(emulated_ops):
     check_metrics_against_reference(torch.device("cpu"))
 
 
-@pytest.mark.parametrize("storage", ["f32", "q16"])
+@pytest.mark.parametrize("storage", ["f32", "q16", "q16p"])
 @pytest.mark.parametrize("stop", [False, True])
 def test_registration_trajectory_matches_reference(emulated_ops, stop, storage):
     """First SGD steps of the tutorial's registration loop: same losses and the

@@ -21,7 +21,7 @@ ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--kernel", default="generic", choices=["generic", "brick", "volgrad"])
 ap.add_argument("--aux", type=int, default=0)
-ap.add_argument("--storage", default="q16", choices=["q16", "f32"])
+ap.add_argument("--storage", default="q16p", choices=["q16p", "q16", "f32"])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 D, H = a.size, 256
