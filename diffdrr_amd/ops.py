@@ -211,15 +211,25 @@ def brick_workspace(volume, storage="q16"):
     are not seen.)  -> (tensor, valid)"""
     key = (id(volume), storage)
     ent = _range_cache.get(key)
-    if ent is not None and ent[0]() is volume and ent[1] == volume._version \
-            and ent[2].device == volume.device:
+    same = ent is not None and ent[0]() is volume and ent[2].device == volume.device
+    if same and ent[1] == volume._version:
         return ent[2], 1
-    n = int(_query("ddrr_brick_workspace_bytes", *(int(d) for d in volume.shape),
-                   _BRICK_STORAGE[storage]))
-    buf = torch.empty((n + 3) // 4, dtype=torch.float32, device=volume.device)
+    n = (int(_query("ddrr_brick_workspace_bytes", *(int(d) for d in volume.shape),
+                    _BRICK_STORAGE[storage])) + 3) // 4
+    # a volume edited in place keeps its buffer (a captured graph may hold the address) and
+    # counts the rebuild: workspace_churn() lets the renderer stop paying for it
+    buf = ent[2] if same and ent[2].numel() == n else \
+        torch.empty(n, dtype=torch.float32, device=volume.device)
     _range_cache[key] = (weakref.ref(volume, lambda _, k=key: _range_cache.pop(k, None)),
-                         volume._version, buf)
+                         volume._version, buf, (ent[3] + 1) if same else 0)
     return buf, 0
+
+
+def workspace_churn(volume, storage):
+    """How many times the workspace of this volume was rebuilt because the volume had changed
+    (0: built once): a volume that changes between renders gains nothing from a packed copy."""
+    ent = _range_cache.get((id(volume), storage))
+    return ent[3] if ent is not None and ent[0]() is volume else 0
 
 
 def brick_ranges(volume):

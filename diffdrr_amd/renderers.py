@@ -126,6 +126,10 @@ def _brick_storage(volume, cfg):
         dx, dy, dz = volume.shape
         if (-(-dx // 32)) * (-(-dy // 32)) * (-(-dz // 64)) < 4 * _cu_count[dev]:
             return "f32"
+    if ops.workspace_churn(volume, storage) >= 3:
+        # edited in place between renders again and again (a reconstruction loop on a plain
+        # tensor): every render would pay the pass over the volume that builds the workspace
+        return "f32"
     return storage
 
 

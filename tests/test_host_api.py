@@ -923,3 +923,26 @@ def test_general_path_matches_the_reference(emulated_ops, name, tag):
     callables, max, stop-gradients with the midpoint lookups; all of float64) against fixtures
     of the unmodified reference: outputs and autograd gradients."""
     conftest.check_general_case(name, tag, "cpu")
+
+
+def test_brick_workspace_follows_the_volume(emulated_ops):
+    """The per-volume workspace of the 16-bit bricks (ranges + packed copy) is rebuilt when the
+    volume is edited in place -- into the same buffer -- and a volume that keeps changing goes
+    back to fp32 bricks instead of paying the rebuild on every render."""
+    from diffdrr_amd import ops
+    from diffdrr_amd.renderers import _brick_storage
+
+    vol = torch.rand(64, 64, 128)
+    buf, valid = ops.brick_workspace(vol, "q16p")
+    assert valid == 0 and ops.brick_workspace(vol, "q16p")[1] == 1
+    vol[0, 0, 0] = 2.0
+    buf2, valid2 = ops.brick_workspace(vol, "q16p")
+    assert valid2 == 0 and buf2.data_ptr() == buf.data_ptr()
+    assert ops.workspace_churn(vol, "q16p") == 1 and ops.workspace_churn(vol, "q16") == 0
+    cfg = {"storage": "q16p"}
+    assert _brick_storage(vol, cfg) == "q16p"
+    for _ in range(2):
+        vol[0, 0, 0] += 1.0
+        ops.brick_workspace(vol, "q16p")
+    assert _brick_storage(vol, cfg) == "f32"
+    assert _brick_storage(torch.rand(64, 64, 128, requires_grad=True), cfg) == "f32"

@@ -19,6 +19,7 @@ ap.add_argument("--det", type=int, default=256)
 ap.add_argument("--cases", default="pert32,pert32aux")
 ap.add_argument("--build-only", action="store_true")
 ap.add_argument("--variants", default="-2", help="bricks_fwd.hip variants (see tools/brick_bench.py)")
+ap.add_argument("--storage", default=None, help="brick storage handed to the entry point (with --variants -2: f32 | q16 | q16p)")
 a = ap.parse_args()
 
 import tools.explib  # noqa: E402
@@ -42,7 +43,7 @@ import itertools  # noqa: E402
 for var, case in itertools.product(a.variants.split(","), a.cases.split(",")):
     var = int(var)
     lib.cdll.ddrr_set_brick_variant(var)
-    storage = "q16" if var >= 0 and var % 16 in (1, 2, 4, 5, 6, 10) else "f32"
+    storage = a.storage or ("q16" if var >= 0 and var % 16 in (1, 2, 4, 5, 6, 10) else "f32")
     aux = case.endswith("aux")
     name = case[:-3] if aux else case
     if name.startswith("base"):
