@@ -15,7 +15,7 @@ from ctypes import c_double, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffdrr_hip.so")
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 REDUCE_SUM, REDUCE_MAX = 0, 1
 LOOKUP_STEP, LOOKUP_MID_NEAREST, LOOKUP_MID_TRILINEAR = 0, 1, 2
@@ -94,6 +94,8 @@ _SIGNATURES = {
     "ddrr_trilinear_samples_general_backward": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _D,
                                                 _D, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "ddrr_brick_workspace_bytes": [_I, _I, _I, _I],
+    "ddrr_trilinear_forward_channels_bricks": [_P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _F,
+                                               _I, _P, _P, _P, _P],
 }
 # (entries that return a size, not a status)
 _RESTYPES = {"ddrr_brick_workspace_bytes": c_long}

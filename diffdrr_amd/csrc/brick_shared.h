@@ -100,6 +100,7 @@ constexpr int BRICK_TRI_FWD = 3;      // trilinear marcher: out
 constexpr int BRICK_TRI_VOLGRAD = 4;  // trilinear marcher: g_volume
 constexpr int BRICK_TRI_FWD_AUX = 5;  // trilinear marcher: planar backward record (out follows from it)
 constexpr int BRICK_CHANNELS = 6;     // out (B, C, N): one line integral per label (mask_to_channels)
+constexpr int BRICK_TRI_CHANNELS = 7; // trilinear marcher, out (B, C, N): samples by the label of their nearest voxel
 
 
 #if defined(__HIPCC__)

@@ -172,6 +172,20 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
                               p.n_points, a0, a1, w);
         return;
     }
+    if (MODE == BRICK_TRI_CHANNELS) {
+        TriGeom T;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            T.lo[a] = G.lof[a];
+            T.stridef[a] = G.stridef[a];
+        }
+        const float a0 = p.amin[0], a1 = p.amax[0];
+        const unsigned N = (unsigned)(p.det_h * p.det_w), C = (unsigned)p.n_channels;
+        const float step = (a1 - a0) / (float)(p.n_points - 1);  // renderers.py:235
+        tri_brick_march_channels(LdsAbsFetch{}, base, T, p.D, s, t, p.shift, p.eps, p.n_points, a0, a1,
+                                 BrickColumnFlush{out, (b * C * N + pix) * 4u, N * 4u, C, L * step});
+        return;
+    }
     if (MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_FWD_AUX) {
         TriGeom T;  // G.lof holds the first base cell here (set by the kernel)
 #pragma unroll
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     constexpr bool AUX = MODE == BRICK_FWD_AUX;
     // TRI: bricks of 31^3 base cells + halo (the marcher's forward); the marcher's volume
     // gradient (TRI_OWNER) runs on the plain 32^3 voxel bricks, see tri_brick.h
-    constexpr bool TRI = MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_FWD_AUX;
+    constexpr bool TRI = MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_FWD_AUX || MODE == BRICK_TRI_CHANNELS;
     constexpr bool TRI_OWNER = MODE == BRICK_TRI_VOLGRAD;
     constexpr bool GRAD = MODE == BRICK_VOLGRAD || MODE == BRICK_TRI_VOLGRAD;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -326,7 +340,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         asm volatile("" : "+v"(tid_here));
         const int q4 = (tid_here & 7) * 4, z = box.lo[2] + q4;
         float *const d0 = brick + q4;
-        constexpr bool LABELS = MODE == BRICK_CHANNELS;
+        constexpr bool LABELS = MODE == BRICK_CHANNELS || MODE == BRICK_TRI_CHANNELS;
         const bool stage_vec = ch == 0 && !GRAD && !TRI && vec_ok;
         // z and D.z are multiples of 4: a quad is wholly inside or wholly outside
         const bool in_z = z + 4 <= box.hi[2];
@@ -422,7 +436,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         // 0, reference data.py:214-227) adds nothing to any line integral, record or channel, so
         // none of its candidates is looked at.  (Sign and, for the channel words, label bits do
         // not make a voxel non-zero; the volume-gradient modes have no such shortcut.)
-        constexpr unsigned kValueBits = MODE == BRICK_CHANNELS ? 0x7fffff00u : 0x7fffffffu;
+        constexpr unsigned kValueBits = LABELS ? 0x7fffff00u : 0x7fffffffu;
         if (!GRAD && ch == 0 && (nz & kValueBits) != 0u) counter[2] = 1;  // (cleared with the claim)
         __syncthreads();
         if (!GRAD && ch == 0) brick_empty = counter[2] == 0;
@@ -821,7 +835,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
 #if defined(DDRR_BRICK_PROFILE)
     p.prof = g_brick_prof;
 #endif
-    if (mode == BRICK_TRI_FWD || mode == BRICK_TRI_VOLGRAD || mode == BRICK_TRI_FWD_AUX) {
+    if (mode == BRICK_TRI_FWD || mode == BRICK_TRI_VOLGRAD || mode == BRICK_TRI_FWD_AUX ||
+        mode == BRICK_TRI_CHANNELS) {
         p.t1 = g_tri_t1;
         p.t2 = g_tri_t2;
     }
@@ -837,7 +852,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     {
         std::lock_guard<std::mutex> lock(mu);
         if (!attr_set[dev]) {
-            const void *fns[7] = {
+            const void *fns[8] = {
+                reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_CHANNELS>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_CHANNELS>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_FWD_AUX>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_FWD>),
@@ -863,7 +879,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
                            target, img, grad_out, N, det_w, p.D, voxel_shift, eps, n_points, amin,
                            amax, p.work);
     }
-    const BrickGrid bg = (mode == BRICK_TRI_FWD || mode == BRICK_TRI_FWD_AUX) ? tri_brick_grid(p.D)
+    const BrickGrid bg = (mode == BRICK_TRI_FWD || mode == BRICK_TRI_FWD_AUX ||
+                          mode == BRICK_TRI_CHANNELS) ? tri_brick_grid(p.D)
                                                                               : brick_grid(p.D);
     const int n_bricks = bg.nx * bg.ny * bg.nz;
     // the Siddon modes hand their bricks out heaviest first like the forward kernels (the marcher's
@@ -885,6 +902,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_FWD_AUX>, grid, block, lds, st, p, out, aux);
     else if (mode == BRICK_CHANNELS)
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_CHANNELS>, grid, block, lds, st, p, out, aux);
+    else if (mode == BRICK_TRI_CHANNELS)
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_CHANNELS>, grid, block, lds, st, p, out, aux);
     else
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_VOLGRAD>, grid, block, lds, st, p, out, aux);
     return finish(who);
@@ -1003,6 +1022,31 @@ int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char
     return launch_bricks(BRICK_CHANNELS, volume, dx, dy, dz, source, target, img, nullptr, B, det_h,
                          det_w, voxel_shift, eps, out, nullptr, nullptr, st,
                          "ddrr_siddon_forward_channels_bricks", 0, nullptr, nullptr, 0.f, labels, C);
+}
+
+int ddrr_trilinear_forward_channels_bricks(const float *volume, const unsigned char *labels,
+                                           int dx, int dy, int dz, const float *source,
+                                           const float *target, const float *img, int B,
+                                           int det_h, int det_w, int C, float voxel_shift,
+                                           float eps, int n_points, const float *alphamin,
+                                           const float *alphamax, float *out, void *stream) {
+    const int N = det_h * det_w;
+    if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
+    if (!labels || !out || C < 1) return fail(-1, "null labels/out or C < 1");
+    if (!alphamin || !alphamax) return fail(-1, "null alphamin / alphamax");
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
+    if ((long)B * C * N >= (1L << 30) || N >= (1 << 22))
+        return fail(-1, "B * C * N must stay below 2^30 (and N below 2^22) for one channel launch "
+                        "on the bricks: split the pose batch or use ddrr_trilinear_forward_channels");
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C * N, st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    return launch_bricks(BRICK_TRI_CHANNELS, volume, dx, dy, dz, source, target, img, nullptr, B,
+                         det_h, det_w, voxel_shift, eps, out, nullptr, nullptr, st,
+                         "ddrr_trilinear_forward_channels_bricks", n_points, alphamin, alphamax, 0.f,
+                         labels, C);
 }
 
 int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *source,

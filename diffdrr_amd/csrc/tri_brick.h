@@ -22,6 +22,7 @@
 #pragma once
 
 #include "brick_core.h"
+#include "brick_step.h"  // the packed word format (pack_voxel_label), bit casts
 #include "ddrr_common.h"
 #include "trilinear_core.h"
 
@@ -154,6 +155,89 @@ DDRR_HD bool tri_brick_march(const Acc &acc, float base, const TriGeom &G, const
         rec[0] = Ax, rec[1] = Ay, rec[2] = Az;
         rec[3] = Bx, rec[4] = By, rec[5] = Bz;
     }
+    return true;
+}
+
+// mask_to_channels of the marcher on the bricks (renderers.py:242-252): the brick holds packed
+// words -- value with a 16-bit mantissa, the voxel's label in the low byte (brick_step.h
+// pack_voxel_label) -- and every sample of the ray whose base corner lies in the brick goes to
+// the channel of the label of its NEAREST voxel.  That lookup is discontinuous: the voxel is
+// rint() of the index coordinate by the reference's own chain of separately rounded fp32
+// operations (trilinear_core.h march_exact_coord, as in the per-ray kernel); it is one of the
+// sample's 8 corners, all staged (the halo; zeros -- label 0 -- outside the volume: the zero
+// padding).  Runs of samples with one label are summed in a register and handed to
+// `flush(label, sum of T)` when the label changes and at the end.
+template <class Acc, class Flush>
+DDRR_HD bool tri_brick_march_channels(const Acc &acc, float base, const TriGeom &G, const Dims D,
+                                      const float s[3], const float t[3], float shift, float eps,
+                                      int P, float amin, float amax, const Flush &flush) {
+    const float go = shift - 0.5f;  // align_corners = False: g = x + shift - 1/2
+    MarchSetup q;
+    float entry = -INFINITY, exit = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        q.d[a] = (t[a] - s[a]) + eps;
+        const float g0 = s[a] + go;
+        const float a1 = (G.lo[a] - g0) / q.d[a], a2 = (G.lo[a] + (float)TRI_CELLS - g0) / q.d[a];
+        entry = fmaxf(entry, fminf(a1, a2));
+        exit = fminf(exit, fmaxf(a1, a2));
+    }
+    q.span = amax - amin;
+    if (!(entry < exit) || !(q.span > 0.f)) return false;
+    const float lstep = 1.0f / (float)(P - 1), sc = (float)(P - 1) / q.span;
+    const float f0 = fminf(fmaxf(floorf((entry - amin) * sc) - 1.f, 0.f), (float)P);
+    const float f1 = fminf(fmaxf(ceilf((exit - amin) * sc) + 1.f, -1.f), (float)(P - 1));
+    if (!(f0 <= f1)) return false;
+    const int m0 = (int)f0, m1 = (int)f1;
+    const float offc = fmaf(-G.lo[0], G.stridef[0],
+                            fmaf(-G.lo[1], G.stridef[1], fmaf(-G.lo[2], G.stridef[2], base)));
+    const float sx = G.stridef[0], sy = G.stridef[1];
+    auto val = [](float w) { return bits_as_float(float_bits(w) & 0xffffff00u); };
+    int cur = -1;
+    float run = 0.f;
+    for (int m = m0; m <= m1; ++m) {
+        const float lin = lin01(m, P, lstep);
+        const float al = fmaf(lin, q.span, amin);  // renderers.py:224-225
+        const float gx = fmaf(al, q.d[0], s[0]) + go;
+        const float gy = fmaf(al, q.d[1], s[1]) + go;
+        const float gz = fmaf(al, q.d[2], s[2]) + go;
+        const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+        const bool in = fx >= G.lo[0] && fx < G.lo[0] + (float)TRI_CELLS && fy >= G.lo[1] &&
+                        fy < G.lo[1] + (float)TRI_CELLS && fz >= G.lo[2] &&
+                        fz < G.lo[2] + (float)TRI_CELLS;
+        if (!in) continue;
+        const float ax = gx - fx, ay = gy - fy, az = gz - fz;
+        const float o00 = fmaf(fx, sx, fmaf(fy, sy, fmaf(fz, 4.f, offc)));  // exact, < 2^24
+        const unsigned a00 = (unsigned)(int)o00;
+        const unsigned a10 = (unsigned)(int)(o00 + sx), a01 = (unsigned)(int)(o00 + sy);
+        const unsigned a11 = (unsigned)(int)(o00 + sx + sy);
+        const float v000 = val(acc(a00)), v001 = val(acc(a00 + 4u));
+        const float v100 = val(acc(a10)), v101 = val(acc(a10 + 4u));
+        const float v010 = val(acc(a01)), v011 = val(acc(a01 + 4u));
+        const float v110 = val(acc(a11)), v111 = val(acc(a11 + 4u));
+        const float wx0 = 1.f - ax, wy0 = 1.f - ay;
+        const float l00 = fmaf(az, v001 - v000, v000), l10 = fmaf(az, v101 - v100, v100);
+        const float l01 = fmaf(az, v011 - v010, v010), l11 = fmaf(az, v111 - v110, v110);
+        float T = (wx0 * wy0) * l00;
+        T = fmaf(ax * wy0, l10, T);
+        T = fmaf(wx0 * ay, l01, T);
+        T = fmaf(ax * ay, l11, T);
+        // the label: nearest voxel by the reference's arithmetic, among the 8 corners
+        float un[3];
+        march_exact_coord(D, lin, q, amin, s, shift, false, un);
+        const float rx = fminf(fmaxf(rintf(un[0]), fx), fx + 1.f);
+        const float ry = fminf(fmaxf(rintf(un[1]), fy), fy + 1.f);
+        const float rz = fminf(fmaxf(rintf(un[2]), fz), fz + 1.f);
+        const unsigned an = (unsigned)(int)fmaf(rx, sx, fmaf(ry, sy, fmaf(rz, 4.f, offc)));
+        const int lab = (int)(float_bits(acc(an)) & 0xffu);
+        if (lab != cur) {
+            if (cur >= 0) flush((unsigned)cur, run);
+            cur = lab;
+            run = 0.f;
+        }
+        run += T;
+    }
+    if (cur >= 0) flush((unsigned)cur, run);
     return true;
 }
 

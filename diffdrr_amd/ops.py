@@ -638,6 +638,31 @@ def trilinear_forward_channels(volume, labels_u8, n_channels, source, target, im
     return out
 
 
+def trilinear_forward_channels_bricks(volume, labels_u8, n_channels, source, target, img,
+                                      alphamin, alphamax, det, *, n_points=500, voxel_shift=0.5,
+                                      eps=1e-8):
+    """The marcher's mask_to_channels for a detector grid on the volume-stationary bricks
+    (ddrr_trilinear_forward_channels_bricks; mode "bilinear", align_corners=False).  -> (B, C, N)"""
+    B, N = _check_rays(volume, source, target, img)
+    H, W = int(det[0]), int(det[1])
+    if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
+        raise ValueError("the brick path needs one source per pose and an H*W >= 2x2 ray grid")
+    if labels_u8.dtype != torch.uint8 or labels_u8.shape != volume.shape:
+        raise ValueError("labels must be a uint8 tensor of the volume's shape")
+    out = torch.empty(B, n_channels, N, dtype=torch.float32, device=volume.device)
+    if _empty(B, N):
+        return out
+    labels_u8, volume = labels_u8.contiguous(), volume.contiguous()
+    source, target = source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    _launch(
+        "ddrr_trilinear_forward_channels_bricks", volume.device, volume.data_ptr(),
+        labels_u8.data_ptr(), *volume.shape, source.data_ptr(), target.data_ptr(), _ptr(img), B,
+        H, W, int(n_channels), float(voxel_shift), float(eps), int(n_points), alphamin.data_ptr(),
+        alphamax.data_ptr(), out.data_ptr())
+    return out
+
+
 TRI_AUX_PLANES = 7  # sum T, sum dT_xyz, sum alpha dT_xyz (include/diffdrr_hip.h)
 
 

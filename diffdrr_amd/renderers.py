@@ -741,10 +741,20 @@ class _TrilinearChannelsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, volume, source, target, img, alphamin, alphamax, labels, C, cfg):
         source, target, img = source.contiguous(), target.contiguous(), img.contiguous()
-        out = ops.trilinear_forward_channels(
-            volume, labels, C, source, target, img, alphamin.reshape(1), alphamax.reshape(1),
-            n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
-            align_corners=cfg["align_corners"], det=cfg["det"], tile=cfg["tile"])
+        B, N = target.shape[:2]
+        det = cfg["det"]
+        grid = (det is not None and det[0] * det[1] == N and source.shape[1] == 1
+                and min(det) >= 2 and not cfg["align_corners"])
+        if grid and cfg.get("bricks", True) and ops.channels_fit_bricks(B, C, N):
+            # detector grid: the volume-stationary kernel (label in the staged voxel word)
+            out = ops.trilinear_forward_channels_bricks(
+                volume, labels, C, source, target, img, alphamin.reshape(1), alphamax.reshape(1),
+                det, n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"])
+        else:
+            out = ops.trilinear_forward_channels(
+                volume, labels, C, source, target, img, alphamin.reshape(1), alphamax.reshape(1),
+                n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
+                align_corners=cfg["align_corners"], det=cfg["det"], tile=cfg["tile"])
         ctx.cfg = cfg
         ctx.save_for_backward(volume, source, target, img, alphamin, alphamax, labels)
         return out
@@ -874,6 +884,9 @@ class Trilinear(torch.nn.Module):
         self.trust_detector_shape = False  # see _grid_or_none
         self.tile = None
         self.use_bricks = True  # detector-grid calls: volume-stationary kernels (tri_brick.h)
+        # mask_to_channels of a detector-grid call on the brick kernel (the label rides in the low
+        # byte of the staged voxel word, the value keeps a 16-bit mantissa: as Siddon's)
+        self.channels_on_bricks = True
 
     def dims(self, volume):
         return torch.tensor(volume.shape).to(volume)
@@ -936,7 +949,7 @@ class Trilinear(torch.nn.Module):
             if not f64 and self.mode == "bilinear":
                 ccfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift,
                         "eps": self.eps, "align_corners": bool(align_corners), "det": det,
-                        "tile": self.tile}
+                        "tile": self.tile, "bricks": self.use_bricks and self.channels_on_bricks}
                 return torch.cat([_TrilinearChannelsFn.apply(
                     volume, source, target, img.reshape(B, N), alphamin, alphamax, labels, C,
                     ccfg)[:, k0:] for labels, C, k0 in _labels_u8(mask)], dim=1)

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 23
+#define DDRR_ABI_VERSION 24
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -255,6 +255,20 @@ int ddrr_trilinear_forward_bricks(const float *volume, int dx, int dy, int dz,
                                   int B, int det_h, int det_w, float voxel_shift, float eps,
                                   int n_points, const float *alphamin, const float *alphamax,
                                   float *out, float *aux, void *stream);
+
+/* mask_to_channels of the marcher (Trilinear.forward mask branch, renderers.py:242-252) for the
+ * DRR case on the volume-stationary bricks (mode "bilinear", align_corners = 0): the packed words
+ * of ddrr_siddon_forward_channels_bricks (value with a 16-bit mantissa, label in the low byte)
+ * in the marcher's halo bricks; every sample goes to the channel of the label of its nearest
+ * voxel, found by the reference's own fp32 coordinate chain as in
+ * ddrr_trilinear_forward_channels.  out (B, C, N) is fully written; B * C * N < 2^30, N < 2^22.
+ * The backward is ddrr_trilinear_backward_channels. */
+int ddrr_trilinear_forward_channels_bricks(const float *volume, const unsigned char *labels,
+                                           int dx, int dy, int dz, const float *source,
+                                           const float *target, const float *img, int B,
+                                           int det_h, int det_w, int C, float voxel_shift,
+                                           float eps, int n_points, const float *alphamin,
+                                           const float *alphamax, float *out, void *stream);
 /* Ray / range gradients of the march from the record of ddrr_trilinear_forward_bricks
  * (what ddrr_trilinear_backward computes by marching again); one source per pose.
  * Any output may be NULL; shapes as in ddrr_trilinear_backward. */

@@ -248,6 +248,69 @@ def check_general_case(name, tag, device):
         assert rel_err(mine.cpu().numpy(), want) < tol_grad, (key, rel_err(mine.cpu().numpy(), want))
 
 
+def check_trilinear_channels_on_bricks(device, dims, det, n_points):
+    """The marcher's mask_to_channels on the volume-stationary bricks
+    (ddrr_trilinear_forward_channels_bricks) against the per-ray channel kernel (pinned to the
+    reference by the trilinear_mask fixture), the plain march, and through the module with
+    gradients (the backward is the per-ray channel kernel's)."""
+    import torch
+
+    from diffdrr_amd import DRR, Trilinear, convert, ops
+    from diffdrr_amd.data import synthetic_subject
+
+    H, W = det
+    sub = synthetic_subject(dims, kind="phantom", seed=5, n_labels=7)
+    drr = DRR(sub, sdd=700.0, height=H, width=W, delx=3.0, renderer="trilinear").to(device)
+    rng = np.random.default_rng(11)
+    blocks = rng.integers(0, 256, size=tuple((d + 4) // 5 for d in dims)).astype(np.uint8)
+    labels = torch.from_numpy(np.kron(blocks, np.ones((5, 5, 5), np.uint8))
+                              [:dims[0], :dims[1], :dims[2]].copy()).to(device)
+    rot = torch.tensor([[0.3, 0.2, -0.1], [1.5, 0.1, 0.0], [0.0, 0.0, 0.0]], device=device)
+    xyz = torch.tensor([[5.0, 480.0, -3.0], [0.0, 460.0, 0.0], [0.0, 450.0, 0.0]], device=device)
+    with torch.no_grad():
+        pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+        source, target = drr.detector(pose, None)
+        L = (target - source).norm(dim=-1).contiguous()
+        s = drr.affine_inverse(source).contiguous()
+        t = drr.affine_inverse(target).contiguous()
+    V = drr.density
+    a0, a1 = (x.reshape(1) for x in ops.trilinear_alpha_range(s, t, V.shape)) \
+        if device != "cpu" else (torch.tensor([0.3]), torch.tensor([0.8]))
+    C = 256
+    ch = ops.trilinear_forward_channels_bricks(V, labels, C, s, t, L, a0, a1, (H, W),
+                                               n_points=n_points).cpu().numpy()
+    per_ray = ops.trilinear_forward_channels(V, labels, C, s, t, L, a0, a1,
+                                             n_points=n_points).cpu().numpy()
+    # (the staged values keep a 16-bit mantissa: 2^-17 relative per voxel)
+    assert rel_err(ch, per_ray) < 3e-5
+    assert np.all(ch[per_ray == 0] == 0)  # every sample in its own channel
+    plain = ops.trilinear_forward(V, s, t, L, a0, a1, n_points=n_points)
+    plain = (plain[0] if isinstance(plain, tuple) else plain).cpu().numpy()
+    assert rel_err(ch.sum(1), plain) < 3e-5
+    ch8 = ops.trilinear_forward_channels_bricks(V, labels, 8, s, t, L, a0, a1, (H, W),
+                                                n_points=n_points).cpu().numpy()
+    assert np.array_equal(ch8, ch[:, :8]) or rel_err(ch8, ch[:, :8]) < 1e-6
+    # the module route takes this kernel for a detector grid and stays differentiable
+    taken = []
+    orig = ops.trilinear_forward_channels_bricks
+    ops.trilinear_forward_channels_bricks = lambda *a, **k: (taken.append(1), orig(*a, **k))[1]
+    try:
+        r = rot[:2].clone().requires_grad_()
+        x = xyz[:2].clone().requires_grad_()
+        kw = dict(parameterization="euler_angles", convention="ZXY", n_points=n_points)
+        chm = drr(r, x, mask_to_channels=True, **kw)
+    finally:
+        ops.trilinear_forward_channels_bricks = orig
+    assert taken and chm.shape[1] == 7
+    one = drr(r, x, **kw)
+    assert rel_err(chm.sum(1, keepdim=True).detach().cpu().numpy(), one.detach().cpu().numpy()) < 3e-5
+    w = torch.rand(one.shape, generator=torch.Generator().manual_seed(2)).to(device)
+    ga = torch.autograd.grad((chm.sum(1, keepdim=True) * w).sum(), [r, x])
+    gb = torch.autograd.grad((one * w).sum(), [r, x])
+    for a, b in zip(ga, gb):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-3
+
+
 def has_gpu():
     try:
         import torch

@@ -82,7 +82,8 @@ namespace {
 int tri_bricks_host(const float *volume, int dx, int dy, int dz, const float *source,
                     const float *target, const float *img, int B, int det_h, int det_w,
                     float voxel_shift, float eps, int n_points, float amin, float amax,
-                    float *out, float *aux) {
+                    float *out, float *aux, const unsigned char *labels = nullptr, int C = 0) {
+    // labels: mask_to_channels (out is (B, C, N)): packed words, tri_brick_march_channels
     const Dims D{dx, dy, dz};
     const int N = det_h * det_w;
     const long R = (long)B * N;
@@ -110,7 +111,9 @@ int tri_bricks_host(const float *volume, int dx, int dy, int dz, const float *so
                 for (int lz = 0; lz < BRICK; ++lz) {
                     const int x = lo[0] + lx, y = lo[1] + ly, z = lo[2] + lz;
                     if (x < 0 || y < 0 || z < 0 || x >= dx || y >= dy || z >= dz) continue;
-                    brick[lx * lay.sx + ly * lay.sy + lz] = volume[((long)x * dy + y) * dz + z];
+                    const long at = ((long)x * dy + y) * dz + z;
+                    brick[lx * lay.sx + ly * lay.sy + lz] =
+                        labels ? pack_voxel_label(volume[at], labels[at]) : volume[at];
                 }
         for (int b = 0; b < B; ++b) {
             const PoseGrid pg = pose_grid(source + (long)b * 3, target + (long)b * N * 3, det_h,
@@ -135,6 +138,14 @@ int tri_bricks_host(const float *volume, int dx, int dy, int dz, const float *so
                 float s[3], t[3], sumT, rec[6];
                 const long r = ray(pix, s, t);
                 const float L = img ? img[r] : 1.f;
+                if (labels) {
+                    float *col = out + (long)b * C * N + pix;
+                    tri_brick_march_channels(HostFetch{brick.data()}, 0.f, G, D, s, t, voxel_shift, eps,
+                                             n_points, amin, amax, [&](unsigned lab, float run) {
+                                                 if (lab < (unsigned)C) col[(long)lab * N] += L * step * run;
+                                             });
+                    continue;
+                }
                 if (aux) {
                     if (tri_brick_march<true>(HostFetch{brick.data()}, 0.f, G, s, t, voxel_shift,
                                               eps, n_points, amin, amax, sumT, rec)) {
@@ -148,7 +159,7 @@ int tri_bricks_host(const float *volume, int dx, int dy, int dz, const float *so
                 }
             }
             // phase A must not lose a pixel with samples in this brick
-            for (int pix = 0; pix < N; ++pix) {
+            for (int pix = 0; pix < N && !labels; ++pix) {
                 if (cand[pix]) continue;
                 float s[3], t[3], sumT, rec[6];
                 ray(pix, s, t);
@@ -515,6 +526,17 @@ int ddrr_trilinear_forward_bricks(const float *volume, int dx, int dy, int dz,
     if (aux) memset(aux, 0, sizeof(float) * R * DDRR_TRI_AUX_PLANES);
     return tri_bricks_host(volume, dx, dy, dz, source, target, img, B, det_h, det_w, voxel_shift,
                            eps, n_points, *alphamin, *alphamax, out, aux);
+}
+
+int ddrr_trilinear_forward_channels_bricks(const float *volume, const unsigned char *labels,
+                                           int dx, int dy, int dz, const float *source,
+                                           const float *target, const float *img, int B,
+                                           int det_h, int det_w, int C, float voxel_shift,
+                                           float eps, int n_points, const float *alphamin,
+                                           const float *alphamax, float *out, void *) {
+    memset(out, 0, sizeof(float) * (size_t)B * C * det_h * det_w);
+    return tri_bricks_host(volume, dx, dy, dz, source, target, img, B, det_h, det_w, voxel_shift,
+                           eps, n_points, *alphamin, *alphamax, out, nullptr, labels, C);
 }
 
 int ddrr_trilinear_backward_rays(const float *aux, const float *grad_out, const float *source,

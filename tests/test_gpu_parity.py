@@ -1102,3 +1102,11 @@ def test_general_path_matches_the_reference(gpu, name, tag):
     every keyword combination outside the fused kernels against fixtures of the unmodified
     reference, outputs and autograd gradients."""
     conftest.check_general_case(name, tag, gpu)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,det,P", [((96, 70, 133), (50, 37), 300), ((64, 64, 61), (40, 40), 150)])
+def test_trilinear_channels_on_bricks(gpu, dims, det, P):
+    """The marcher's mask_to_channels on the volume-stationary bricks against the per-ray channel
+    kernel (itself pinned to the reference's fixture), the plain march, and through the module."""
+    conftest.check_trilinear_channels_on_bricks(gpu, dims, det, P)

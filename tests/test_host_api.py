@@ -946,3 +946,9 @@ def test_brick_workspace_follows_the_volume(emulated_ops):
         ops.brick_workspace(vol, "q16p")
     assert _brick_storage(vol, cfg) == "f32"
     assert _brick_storage(torch.rand(64, 64, 128, requires_grad=True), cfg) == "f32"
+
+
+def test_trilinear_channels_on_bricks_on_the_host(emulated_ops):
+    """ddrr_trilinear_forward_channels_bricks (host emulation of the same march) against the
+    per-ray channel kernel, the plain march and through the module."""
+    conftest.check_trilinear_channels_on_bricks("cpu", (40, 36, 45), (14, 11), 60)

@@ -84,3 +84,29 @@ for B in (1, 8):
                                                               det=(H, H)))
     print(f"B {B} entry points only: plain bricks {k_plain:7.3f} ms | channels on bricks {k_chb:7.3f} ms "
           f"= {k_chb / k_plain:5.2f} x | per-ray channel kernel {k_chr:7.3f} ms", flush=True)
+
+# the marcher (Trilinear.forward renderers.py:205-254): plain render (volume-stationary bricks)
+# against its mask branch (per-ray kernel ddrr_trilinear_forward_channels), 500 samples per ray
+tri = DRR(subject, sdd=1020.0, height=H, delx=2.0, renderer="trilinear").to(dev)
+for B in (1, 8):
+    rot = torch.zeros(B, 3, device=dev) + torch.linspace(0, 0.3, B, device=dev)[:, None]
+    xyz = torch.tensor([[0.0, 850.0, 0.0]], device=dev).expand(B, 3).contiguous()
+    with torch.no_grad():
+        kw = dict(parameterization="euler_angles", convention="ZXY", n_points=500)
+        t_plain, _ = timeit(lambda: tri(rot, xyz, **kw))
+        tri.renderer.use_bricks = False
+        t_plain_r, _ = timeit(lambda: tri(rot, xyz, **kw))
+        tri.renderer.use_bricks = True
+        t_chan, _ = timeit(lambda: tri(rot, xyz, mask_to_channels=True, **kw))
+        tri.renderer.channels_on_bricks = False
+        t_chan_r, _ = timeit(lambda: tri(rot, xyz, mask_to_channels=True, **kw))
+        cr = tri(rot, xyz, mask_to_channels=True, **kw)
+        tri.renderer.channels_on_bricks = True
+        a = tri(rot, xyz, **kw)
+        c = tri(rot, xyz, mask_to_channels=True, **kw)
+    err = ((c.sum(1, keepdim=True) - a).abs().max() / a.abs().max()).item()
+    err_r = ((c - cr).abs().max() / cr.abs().max()).item()
+    print(f"trilinear B {B}: plain render bricks {t_plain:7.3f} ms, per-ray {t_plain_r:7.3f} ms | {C}-channel "
+          f"render: bricks {t_chan:7.3f} ms = {t_chan / t_plain:5.2f} x plain bricks, per-ray kernel "
+          f"{t_chan_r:7.3f} ms | channel sum vs plain {err:.1e}, bricks vs per-ray channels {err_r:.1e}",
+          flush=True)
