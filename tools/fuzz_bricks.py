@@ -29,9 +29,11 @@ def ru(lo, hi, *shape):
     return lo + (hi - lo) * torch.rand(*shape, generator=g)
 
 
-worst = {"fwd": 0.0, "aux": 0.0, "volgrad": 0.0, "tri": 0.0, "trivol": 0.0}
+worst = {"fwd": 0.0, "aux": 0.0, "volgrad": 0.0, "tri": 0.0, "trivol": 0.0, "q16": 0.0, "chan": 0.0}
 for case in range(a.cases):
     dims = (ri(20, 150), ri(20, 150), ri(20, 150))
+    if case % 2 == 0:  # z a multiple of 4: the configurable kernels (bricks_fwd.hip) take the volume
+        dims = (dims[0], dims[1], 4 * ri(5, 40))
     H, W = ri(2, 90), ri(2, 90)
     B = ri(1, 5)
     spacing = tuple(float(x) for x in ru(0.5, 2.0, 3))
@@ -86,9 +88,33 @@ for case in range(a.cases):
             e_t = max(e_t, ((rec[k] - rem[k]).abs().max() / (rem[k].abs().max() + 1e-30)).item())
     else:
         e_t = e_tv = 0.0
-    for k, e in zip(worst, (e_f, e_a, e_v, e_t, e_tv)):
+    # 16-bit bricks, from the volume and from the packed copy (first and cached call), with record
+    e_q = 0.0
+    if min(H, W) >= 2:
+        for st in ("q16", "q16p", "q16p"):
+            oq, auxq = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True, storage=st)
+            op, _ = ops.siddon_forward_bricks(V, s, t, L, (H, W), storage=st)
+            e_q = max(e_q, (oq - ref).abs().max().item() / scale, (op - ref).abs().max().item() / scale)
+            giq = ops.siddon_backward_rays(auxq, go, s, t, L)[2]
+            e_q = max(e_q, ((giq - gig).abs().max() / (gig.abs().max() + 1e-30)).item())
+    # mask_to_channels on the bricks against the per-ray channel kernels
+    e_c = 0.0
+    if min(H, W) >= 2:
+        C = ri(2, 40)
+        lab = torch.randint(0, C, tuple((d + 5) // 6 for d in dims), generator=g).to(torch.uint8)
+        lab = lab.repeat_interleave(6, 0).repeat_interleave(6, 1).repeat_interleave(6, 2)
+        lab = lab[:dims[0], :dims[1], :dims[2]].contiguous().to(dev)
+        cb = ops.siddon_forward_channels_bricks(V, lab, C, s, t, L, (H, W))
+        cr = ops.siddon_forward_channels(V, lab, C, s, t, L)
+        e_c = ((cb - cr).abs().max() / (cr.abs().max() + 1e-30)).item()
+        if amax.item() > amin.item():
+            tcb = ops.trilinear_forward_channels_bricks(V, lab, C, s, t, L, amin, amax, (H, W), n_points=P)
+            tcr = ops.trilinear_forward_channels(V, lab, C, s, t, L, amin, amax, n_points=P)
+            e_c = max(e_c, ((tcb - tcr).abs().max() / (tcr.abs().max() + 1e-30)).item())
+    for k, e in zip(worst, (e_f, e_a, e_v, e_t, e_tv, e_q, e_c)):
         worst[k] = max(worst[k], e if e == e else float("inf"))
-    flag = " <<<" if max(e_f, e_v, e_t, e_tv) > 2e-4 or e_a > 5e-3 or e_f != e_f else ""
+    flag = " <<<" if max(e_f, e_v, e_t, e_tv, e_q, e_c) > 2e-4 or e_a > 5e-3 or e_f != e_f else ""
     print(f"case {case:3d} kind {kind} dims {dims} det {H}x{W} B {B} P {P}: fwd {e_f:.1e} "
-          f"pose-grad {e_a:.1e} volgrad {e_v:.1e} tri {e_t:.1e} trivol {e_tv:.1e}{flag}", flush=True)
+          f"pose-grad {e_a:.1e} volgrad {e_v:.1e} tri {e_t:.1e} trivol {e_tv:.1e} q16 {e_q:.1e} "
+          f"channels {e_c:.1e}{flag}", flush=True)
 print("worst", {k: f"{v:.1e}" for k, v in worst.items()})
