@@ -334,3 +334,67 @@ def test_hu_to_density_on_the_gpu(gpu):
     for m in (1.0, 2.5):
         out = transform_hu_to_density(vol, m)
         assert out.is_cuda and np.array_equal(out.cpu().numpy(), g[f"density_{m}"])
+
+
+@pytest.mark.parametrize("storage", ["f32", "q16p"])
+def test_headline_size_properties_that_need_no_oracle(gpu, storage):
+    """Size-independent properties at the headline size (512^3 -> 256^2, 32 poses, where the
+    oracle takes minutes per pose): the render is linear in the volume; a pose's image does not
+    depend on which other poses share its launch (pose chunks, brick order, pooled batches); the
+    workspace of the 16-bit bricks rebuilt from scratch gives the same image as the cached one;
+    the record's d/d img equals the image divided by the ray length."""
+    drr, rot, xyz = scene(512, 256, 2.4, 32, gpu, seed=2)
+    s, t, L = voxel_rays(drr, rot, xyz)
+    V = drr.density
+    det = (256, 256)
+    render = lambda vol, a=slice(None): ops.siddon_forward_bricks(  # noqa: E731
+        vol, s[a], t[a], L[a], det, storage=storage)[0]
+    full = render(V)
+    scale = float(full.abs().max())
+    # linearity: R(a V1 + b V2) = a R(V1) + b R(V2)  (16-bit bricks: each volume has its own
+    # block quantisation, |error| <= brick range / 131070 per voxel: well inside 2e-5 of the scale)
+    g = torch.Generator().manual_seed(9)
+    W = torch.rand(V.shape, generator=g).to(gpu)
+    mix = render(0.75 * V + 0.5 * W)
+    assert float((mix - (0.75 * full + 0.5 * render(W))).abs().max()) < 2e-5 * 1.25 * scale
+    # a pose alone, in a launch of 5, and among all 32: the same image (fp32 atomics: order only)
+    for b in (0, 13, 31):
+        alone = render(V, slice(b, b + 1))[0]
+        assert float((alone - full[b]).abs().max()) < 3e-6 * scale, b
+    some = render(V, slice(11, 16))
+    assert float((some - full[11:16]).abs().max()) < 3e-6 * scale
+    # a rebuilt workspace (a clone is a new tensor: nothing cached) = the cached one
+    again = ops.siddon_forward_bricks(V.clone(), s, t, L, det, storage=storage)[0]
+    assert float((again - full).abs().max()) < 3e-6 * scale
+    # the record: plane I times the ray length is the image, d/d img = I
+    out, aux = ops.siddon_forward_bricks(V, s[:4], t[:4], L[:4], det, want_aux=True, storage=storage)
+    gi = ops.siddon_backward_rays(aux, torch.ones_like(L[:4]), s[:4], t[:4], L[:4])[2]
+    assert float((gi * L[:4] - out).abs().max()) < 3e-6 * scale
+    assert float((out - full[:4]).abs().max()) < 3e-6 * scale
+
+
+def test_channel_renders_sum_to_the_plain_render_at_the_published_size(gpu):
+    """introduction.ipynb:230-286 at its published size (512 x 512 x 133, 119 labels, 200 x 200):
+    the channels of mask_to_channels add up to the plain DRR, for both renderers on the bricks."""
+    from diffdrr_amd.data import make_subject
+
+    dims, C, H = (512, 512, 133), 119, 200
+    g = torch.Generator().manual_seed(0)
+    vol = torch.rand(*dims, generator=g)
+    coarse = torch.randint(0, C, (16, 16, 8), generator=g)
+    mask = coarse
+    for ax, d in enumerate(dims):
+        idx = (torch.arange(d) * coarse.shape[ax] // d).clamp_max(coarse.shape[ax] - 1)
+        mask = mask.index_select(ax, idx)
+    mask[0, 0, 0] = C - 1
+    sub = make_subject(vol, spacing=(0.703, 0.703, 2.5), mask=mask)
+    rot = torch.tensor([[0.0, 0.0, 0.0], [0.3, 0.1, -0.2]], device=gpu)
+    xyz = torch.tensor([[0.0, 850.0, 0.0], [10.0, 800.0, -5.0]], device=gpu)
+    for renderer, kw in (("siddon", {}), ("trilinear", {"n_points": 400})):
+        drr = DRR(sub, sdd=1020.0, height=H, delx=2.0, renderer=renderer).to(gpu)
+        with torch.no_grad():
+            a = drr(rot, xyz, parameterization="euler_angles", convention="ZXY", **kw)
+            c = drr(rot, xyz, parameterization="euler_angles", convention="ZXY",
+                    mask_to_channels=True, **kw)
+        assert c.shape == (2, C, H, H)
+        assert rel_err(c.sum(1, keepdim=True).cpu().numpy(), a.cpu().numpy()) < 3e-5, renderer
