@@ -309,6 +309,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--storage", default=None, choices=["q16p", "q16", "f32"],
                     help="Siddon.brick_storage (default: the module's default, q16p)")
+    ap.add_argument("--packed-record", action="store_true",
+                    help="Siddon.packed_record = True (the opt-in fixed-point backward record)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                     help="cpu: harness test only (gloo ranks; the kernels are whatever "
                          "DDRR_BENCH_HOOK routes diffdrr_amd.ops to, see tests/test_dist_gloo.py)")
@@ -383,6 +385,8 @@ def main():
     def set_storage(d):
         if args.storage is not None and hasattr(d.renderer, "brick_storage"):
             d.renderer.brick_storage = args.storage
+        if args.packed_record and hasattr(d.renderer, "packed_record"):
+            d.renderer.packed_record = True
         return d
 
     if cfg in ("headline", "2"):

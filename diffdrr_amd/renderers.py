@@ -516,7 +516,8 @@ class Siddon(torch.nn.Module):
         # "bricks" (volume-stationary, brick_core.h / brick_step.h) or "generic" (per-ray walk)
         self.grid_path = "bricks"
         # Opt-in: the brick kernel's backward record in 32-bit fixed point (csrc/record_pack.h):
-        # 3 atomics per ray and brick instead of 5 (forward + record 7 % faster) and exact,
+        # 3 atomics per ray and brick instead of 5 (it was 7 % faster than the float record of round 2;
+        # since the blocked float record of round 3 it is 11 % slower: 1.57 vs 1.41 ms) and exact,
         # order-independent sums, i.e. bit-reproducible pose gradients; per brick piece it
         # resolves 2 max|V| (Dx+Dy+Dz+3) / 2^30, ~10x coarser than fp32 accumulation, hence off
         # by default: the default record is fp32 like the reference's arithmetic.
