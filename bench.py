@@ -509,8 +509,9 @@ def main():
     if on_gpu:
         # set-up, not measurement: the first launches on a fresh box allocate (caching allocator,
         # the brick counters, the 16-bit brick ranges) and run at boot clocks; the driver's own
-        # --warmup may be as short as 3 steps
-        for _ in range({"headline": 10, "2": 10, "3": 10, "4": 0, "5": 1}[cfg]):
+        # --warmup may be as short as 3 steps (60 steps = 0.1 s: the clocks of an idle board need
+        # about that long under load; measured 1.576 vs 1.540 ms per step with 10)
+        for _ in range({"headline": 60, "2": 60, "3": 60, "4": 0, "5": 1}[cfg]):
             step()
         fence(pending)
         pending.clear()
