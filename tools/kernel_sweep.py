@@ -39,18 +39,31 @@ def rays(drr, rot, xyz):
         return drr.affine_inverse(s).contiguous(), drr.affine_inverse(t).contiguous(), L
 
 
-def timeit(fn, reps=7, warm=2):
-    for _ in range(warm):
-        fn()
+def timeit(fn, reps=7, warm=2, group=None):
+    """-> (median, best) milliseconds per call.  Calls are timed in back-to-back groups between
+    two events, after a warm-up long enough for the clocks of an idle board (a launch timed alone
+    after a synchronise runs up to 8 % slower: the first tool timings of a process were)."""
+    fn()
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    torch.cuda.synchronize()
+    one = max(e0.elapsed_time(e1), 1e-3)
+    if group is None:
+        group = int(min(20, max(1, 5.0 / one)))          # ~5 ms per group
+    for _ in range(max(warm, int(min(200, 60.0 / one)))):  # ~60 ms of warm-up
+        fn()
     ts = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        fn()
+        for _ in range(group):
+            fn()
         e1.record()
         torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
+        ts.append(e0.elapsed_time(e1) / group)
     ts.sort()
     return ts[len(ts) // 2], ts[0]
 

@@ -9,13 +9,14 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tools.explib  # noqa: E402
 
-tools.explib.use("exp")  # (the development build: its debug switches, argv[1])
+if "product" not in sys.argv:
+    tools.explib.use("exp")  # (the development build: its debug switches, argv[1])
 from diffdrr_amd import DRR, _lib, ops  # noqa: E402
 from diffdrr_amd.data import make_subject, noise_volume  # noqa: E402
 from tools.kernel_sweep import poses, rays, timeit  # noqa: E402
 
 dev = torch.device("cuda:0")
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1] != "product":
     _lib.get_lib().cdll.ddrr_set_brick_debug(int(sys.argv[1]))
     print(f"## debug flags {sys.argv[1]}")
 D, H = 512, 256
