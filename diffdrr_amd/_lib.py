@@ -15,7 +15,7 @@ from ctypes import c_double, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffdrr_hip.so")
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 REDUCE_SUM, REDUCE_MAX = 0, 1
 LOOKUP_STEP, LOOKUP_MID_NEAREST, LOOKUP_MID_TRILINEAR = 0, 1, 2
@@ -32,14 +32,14 @@ _SIGNATURES = {
     "ddrr_siddon_forward": [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _F, _F, _I, _I, _I, _I, _I,
                             _I, _I, _P, _P, _P, _P],
     "ddrr_siddon_forward_bricks": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _F, _I,
-                                   _P, _I, _P],
+                                   _P, _I, _P, _P],
     "ddrr_siddon_backward_rays": [_P, _I, _P, _P, _I, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P],
     "ddrr_siddon_backward_volume": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _I, _I,
                                     _I, _I, _I, _P, _P],
     "ddrr_siddon_forward_channels": [_P, _P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _F, _F, _I,
                                      _I, _I, _I, _P, _P],
     "ddrr_siddon_forward_channels_bricks": [_P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _F,
-                                            _P, _P],
+                                            _P, _P, _P],
     "ddrr_trilinear_alpha_range": [_P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P],
     "ddrr_trilinear_backward_max": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _I, _P, _P,
                                     _I, _I, _P, _P, _P, _P, _P, _P],
@@ -61,15 +61,16 @@ _SIGNATURES = {
                                _I, _I, _I, _I, _I, _I, _P, _P],
     "ddrr_trilinear_backward": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _I, _P, _P,
                                 _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
-    "ddrr_siddon_backward_volume_bricks": [_I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P],
+    "ddrr_siddon_backward_volume_bricks": [_I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P,
+                                           _P],
     "ddrr_trilinear_forward_channels": [_P, _P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _F, _F, _I,
                                         _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "ddrr_trilinear_forward_bricks": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _P,
-                                      _P, _P, _P],
+                                      _P, _P, _P, _P],
     "ddrr_trilinear_backward_rays": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P,
                                      _P],
     "ddrr_trilinear_backward_volume_bricks": [_I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I,
-                                              _P, _P, _P, _P],
+                                              _P, _P, _P, _P, _P],
     "ddrr_pose_euler_forward": [_P, _P, _I, _I, _I, _P, _I, _P, _P],
     "ddrr_pose_euler_backward": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P],
     "ddrr_ncc_forward": [_P, _L, _P, _I, _I, _F, _P, _P, _P],
@@ -94,11 +95,12 @@ _SIGNATURES = {
     "ddrr_trilinear_samples_general_backward": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _D,
                                                 _D, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "ddrr_brick_workspace_bytes": [_I, _I, _I, _I],
+    "ddrr_brick_launch_workspace_bytes": [_I, _I, _I],
     "ddrr_trilinear_forward_channels_bricks": [_P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _F,
-                                               _I, _P, _P, _P, _P],
+                                               _I, _P, _P, _P, _P, _P],
 }
 # (entries that return a size, not a status)
-_RESTYPES = {"ddrr_brick_workspace_bytes": c_long}
+_RESTYPES = {"ddrr_brick_workspace_bytes": c_long, "ddrr_brick_launch_workspace_bytes": c_long}
 EXPORTS = ["ddrr_abi_version", "ddrr_last_error", *_SIGNATURES]
 
 

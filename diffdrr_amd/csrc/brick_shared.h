@@ -39,6 +39,8 @@ struct BrickArgs {
     const unsigned char *labels;  // BRICK_CHANNELS: label of every voxel
     int n_channels;               // BRICK_CHANNELS: out is (B, n_channels, N)
     const float *ranges;          // 16-bit bricks: (vmin, vmax) per brick (bricks_fwd.hip)
+    const int *fallback;          // ... 1: the brick is rendered from its fp32 values (q16_usable)
+    int *ws_header;               // ... the workspace's header words
     int ranges_valid;             // ... already computed for this volume
     const unsigned char *packed;  // 16-bit bricks: their LDS images, brick after brick (or null)
     const int *order;             // bricks_fwd.hip: k-th brick handed out (NULL: k itself)
@@ -156,11 +158,12 @@ __device__ __forceinline__ void wave_fence() {
 
 #endif  // __HIPCC__
 
-// Per-device launch resources of the brick kernels (bricks.hip): the CU count and this launch's
-// brick counter {brick id, wmax bits, n_sum, -}, zeroed on `st`.  Returns 0 or an error code.
-// order_ws / order_cap: this launch's workspace for the hand-out order of the bricks (bricks_fwd.hip).
-int brick_launch_resources(hipStream_t st, int &n_cu, int *&work, int **order_ws = nullptr,
-                           int *order_cap = nullptr);
+// This launch's device-side state, carved out of the caller's launch workspace (bricks.hip): the
+// CU count and the brick counter {brick id, wmax bits, n_sum, -}, zeroed on `st`;
+// order_ws / order_cap: the room for the hand-out order of the bricks (bricks_fwd.hip).
+long brick_launch_workspace_bytes(int dx, int dy, int dz);
+int brick_launch_resources(hipStream_t st, void *launch_ws, int dx, int dy, int dz, int &n_cu,
+                           int *&work, int **order_ws = nullptr, int *order_cap = nullptr);
 
 // The 32^3 fp32 launch path of bricks.hip (every mode); bricks_fwd.hip falls back to it.
 void order_bricks(BrickArgs &q, int BX, int BY, int BZ, int nby, int nbz, int n_bricks, int slots,
@@ -168,20 +171,21 @@ void order_bricks(BrickArgs &q, int BX, int BY, int BZ, int nby, int nbz, int n_
 int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const float *source,
                   const float *target, const float *img, const float *grad_out, int B, int det_h,
                   int det_w, float voxel_shift, float eps, float *out, float *aux,
-                  float *g_volume, hipStream_t st, const char *who, int n_points = 0,
+                  float *g_volume, hipStream_t st, void *launch_ws, const char *who, int n_points = 0,
                   const float *amin = nullptr, const float *amax = nullptr, float rec_q = 0.f,
                   const unsigned char *labels = nullptr, int n_channels = 0);
 
 // The configurable Siddon forward / forward + record kernel (bricks_fwd.hip).  variant:
 // DDRR_BRICKS_F32 / DDRR_BRICKS_Q16; volumes it cannot stage with 16-byte loads take launch_bricks.
-// brick_ranges: DDRR_BRICKS_Q16 workspace (2 floats per 32^3 brick), ranges_valid: it already
-// holds this volume's ranges.
+// brick_ranges: the DDRR_BRICKS_Q16 workspace (header, (min, max) and fallback flag per brick),
+// ranges_valid: it already holds this volume's.
 // packed: the workspace also holds the bricks' LDS images (DDRR_BRICKS_Q16_PACKED) behind the ranges.
 long brick_workspace_bytes(int dx, int dy, int dz, int brick_storage);
 int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_valid, const float *volume,
                       int dx, int dy, int dz, const float *source, const float *target,
                       const float *img, int B, int det_h, int det_w, float voxel_shift, float eps,
-                      float *out, float *aux, float rec_q, hipStream_t st, const char *who);
+                      float *out, float *aux, float rec_q, hipStream_t st, void *launch_ws,
+                      const char *who);
 
 // experiment switches (tools builds: mutable; product: constants)
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)

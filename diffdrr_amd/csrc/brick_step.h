@@ -325,6 +325,24 @@ DDRR_HD Q16Range q16_range(float vmin, float vmax) {
     return r;
 }
 
+// Which bricks may be quantised.  The error of a stored voxel is at most range / 131070 in
+// ABSOLUTE terms, whatever the voxel's own size: one bright voxel (a metal marker, contrast,
+// un-normalised HU) sets the step for the 65 535 others of its brick, and rays that see only
+// the others carry that error against a small integral.  So a brick is quantised only if its
+// range is at most kQ16RangeOverLevel times its LEVEL -- the smallest mean |V| of any of its
+// 4 x 4 x 4 blocks (brick_range_kernel; over the non-zero voxels when the minimum is 0, which
+// q = 0 stores exactly): every voxel's error is then <= 8 / 131070 = 6.1e-5 of the mean of the
+// dimmest block a ray can cross, even if all rounding errors along a ray had one sign.  Any
+// other brick -- and any brick holding inf / NaN or a range outside what the 2^64 pre-scaling
+// of the walk carries -- is rendered from the volume's own fp32 values (bricks_fwd.hip MIXED).
+constexpr float kQ16RangeOverLevel = 8.0f;
+DDRR_HD bool q16_usable(float vmin, float vmax, float level) {
+    const float range = vmax - vmin;
+    if (range == 0.f) return fabsf(vmin) < 0x1p40f;  // a brick of one value: exact
+    return range >= 0x1p-60f && range < 0x1p40f && fabsf(vmin) < 0x1p40f &&
+           range <= kQ16RangeOverLevel * level;     // (false for NaN)
+}
+
 // q of a voxel: round to nearest by adding 2^23 (the sum's low 16 bits are the integer)
 DDRR_HD unsigned q16_encode(float v, const Q16Range &r) {
     const float f = fmaf(v - r.vmin, r.inv_step, 8388608.0f);

@@ -741,44 +741,40 @@ int g_brick_split_t = 0, g_brick_split_s = 1;
 unsigned long long *g_brick_prof = nullptr;  // 16 device counters, see BrickProf
 #endif
 
-// Per-device state, created on first use under a lock (the entry points may be called from
-// several host threads): the CU count and a small ring of brick counters -- one per launch, so
-// that launches in flight on different streams never share one; zeroed on the launch's stream.
-int brick_launch_resources(hipStream_t st, int &n_cu_out, int *&work, int **order_ws, int *order_cap) {
-    constexpr int kRing = 64, kMaxDev = 64;
-    constexpr int kOrderCap = 32768;  // bricks per launch the hand-out order is built for
+// This launch's device-side state lives in the CALLER's launch workspace
+// (ddrr_brick_launch_workspace_bytes): [header: 64 words -- {brick counter, wmax bits, n_sum, -},
+// zeroed here on the launch's stream] [weights: one float per 32^3 brick] [hand-out order: one
+// int per 32^3 brick].  Nothing on the device is shared between launches: two streams, or a
+// captured graph and eager launches, can never meet on one brick counter.  (Per process only the
+// CU count of each device is remembered.)
+long brick_launch_workspace_bytes(int dx, int dy, int dz) {
+    const long n32 = (long)((dx + 31) / 32) * ((dy + 31) / 32) * ((dz + 31) / 32);
+    return 256 + (n32 * 2 * (long)sizeof(int) + 255) / 256 * 256;
+}
+
+int brick_launch_resources(hipStream_t st, void *launch_ws, int dx, int dy, int dz, int &n_cu_out,
+                           int *&work, int **order_ws, int *order_cap) {
+    constexpr int kMaxDev = 64;
     static std::mutex mu;
-    static int *ring[kMaxDev] = {nullptr};
-    static int *order_ring[kMaxDev] = {nullptr};
     static int n_cu[kMaxDev] = {0};
-    static unsigned slot[kMaxDev] = {0};
     hipError_t e;
     int dev = 0;
+    if (!launch_ws) return fail(-1, "null launch workspace (ddrr_brick_launch_workspace_bytes)");
+    if (reinterpret_cast<uintptr_t>(launch_ws) & 15) return fail(-1, "launch workspace not 16-byte aligned");
     if ((e = hipGetDevice(&dev)) != hipSuccess) return fail_hip(e, "hipGetDevice");
     if (dev < 0 || dev >= kMaxDev) return fail(-1, "device index out of range");
     {
         std::lock_guard<std::mutex> lock(mu);
-        if (!ring[dev]) {
-            if ((e = hipMalloc(reinterpret_cast<void **>(&ring[dev]),
-                               kRing * 4 * sizeof(int))) != hipSuccess)
-                return fail_hip(e, "hipMalloc(brick counters)");
-            if ((e = hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount,
-                                           dev)) != hipSuccess)
-                return fail_hip(e, "hipDeviceGetAttribute");
-        }
-        if (order_ws && !order_ring[dev] &&
-            hipMalloc(reinterpret_cast<void **>(&order_ring[dev]),
-                      (size_t)kRing * 2 * kOrderCap * sizeof(int)) != hipSuccess) {
-            order_ring[dev] = nullptr;  // (no workspace: the bricks go out in id order)
-            (void)hipGetLastError();
-        }
-        const unsigned k = slot[dev]++ % kRing;
-        work = ring[dev] + 4 * k;  // {brick counter, wmax bits, n_sum, -}
-        if (order_ws) {
-            *order_ws = order_ring[dev] ? order_ring[dev] + (size_t)k * 2 * kOrderCap : nullptr;
-            *order_cap = kOrderCap;
-        }
+        if (!n_cu[dev] &&
+            (e = hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev)) !=
+                hipSuccess)
+            return fail_hip(e, "hipDeviceGetAttribute");
         n_cu_out = n_cu[dev];
+    }
+    work = reinterpret_cast<int *>(launch_ws);
+    if (order_ws) {
+        *order_ws = work + 64;
+        *order_cap = (int)(((long)((dx + 31) / 32) * ((dy + 31) / 32)) * ((dz + 31) / 32));
     }
     if ((e = hipMemsetAsync(work, 0, 4 * sizeof(int), st)) != hipSuccess)
         return fail_hip(e, "hipMemsetAsync");
@@ -788,7 +784,7 @@ int brick_launch_resources(hipStream_t st, int &n_cu_out, int *&work, int **orde
 int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const float *source,
                   const float *target, const float *img, const float *grad_out, int B, int det_h,
                   int det_w, float voxel_shift, float eps, float *out, float *aux,
-                  float *g_volume, hipStream_t st, const char *who, int n_points,
+                  float *g_volume, hipStream_t st, void *launch_ws, const char *who, int n_points,
                   const float *amin, const float *amax, float rec_q,
                   const unsigned char *labels, int n_channels) {
     const int N = det_h * det_w;
@@ -825,6 +821,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     p.labels = labels;
     p.n_channels = n_channels;
     p.ranges = nullptr;
+    p.fallback = nullptr;
+    p.ws_header = nullptr;
     p.ranges_valid = 0;
     p.brick_times = nullptr;
     p.order = nullptr;
@@ -869,7 +867,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
         }
     }
     int n_cu_dev = 0;
-    if (int rc = brick_launch_resources(st, n_cu_dev, p.work, &p.order_ws, &p.order_cap)) return rc;
+    if (int rc = brick_launch_resources(st, launch_ws, dx, dy, dz, n_cu_dev, p.work, &p.order_ws, &p.order_cap))
+        return rc;
     if (g_brick_dbg & 512) p.order_ws = nullptr;  // (bricks in id order)
     if (mode == BRICK_VOLGRAD || mode == BRICK_TRI_VOLGRAD) {
         const int tri = mode == BRICK_TRI_VOLGRAD;
@@ -961,7 +960,7 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                                const float *target, const float *img, int B, int det_h,
                                int det_w, float voxel_shift, float eps, float *out, float *aux,
                                float record_vmax, int brick_storage, float *brick_ranges,
-                               int ranges_valid, void *stream) {
+                               int ranges_valid, void *launch_ws, void *stream) {
     const int N = det_h * det_w;
     if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
     if (!out) return fail(-1, "null out pointer");
@@ -991,7 +990,7 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     if (int rc = launch_fwd_bricks(packed_bricks ? DDRR_BRICKS_Q16 : brick_storage, packed_bricks,
                                    brick_ranges, ranges_valid, volume, dx, dy, dz,
                                    source, target, img, B, det_h, det_w, voxel_shift, eps, out, aux,
-                                   rec_q, st, "ddrr_siddon_forward_bricks"))
+                                   rec_q, st, launch_ws, "ddrr_siddon_forward_bricks"))
         return rc;
     if (!aux) return 0;
     hipLaunchKernelGGL(siddon_out_from_record_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
@@ -1004,10 +1003,16 @@ long ddrr_brick_workspace_bytes(int dx, int dy, int dz, int brick_storage) {
     return brick_workspace_bytes(dx, dy, dz, brick_storage);
 }
 
+long ddrr_brick_launch_workspace_bytes(int dx, int dy, int dz) {
+    if (dx < 1 || dy < 1 || dz < 1) return 0;
+    return brick_launch_workspace_bytes(dx, dy, dz);
+}
+
 int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char *labels, int dx,
                                         int dy, int dz, const float *source, const float *target,
                                         const float *img, int B, int det_h, int det_w, int C,
-                                        float voxel_shift, float eps, float *out, void *stream) {
+                                        float voxel_shift, float eps, float *out, void *launch_ws,
+                                        void *stream) {
     const int N = det_h * det_w;
     if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
     if (!labels || !out || C < 1) return fail(-1, "null labels/out or C < 1");
@@ -1020,7 +1025,7 @@ int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char
     hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C * N, st);
     if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
     return launch_bricks(BRICK_CHANNELS, volume, dx, dy, dz, source, target, img, nullptr, B, det_h,
-                         det_w, voxel_shift, eps, out, nullptr, nullptr, st,
+                         det_w, voxel_shift, eps, out, nullptr, nullptr, st, launch_ws,
                          "ddrr_siddon_forward_channels_bricks", 0, nullptr, nullptr, 0.f, labels, C);
 }
 
@@ -1029,7 +1034,8 @@ int ddrr_trilinear_forward_channels_bricks(const float *volume, const unsigned c
                                            const float *target, const float *img, int B,
                                            int det_h, int det_w, int C, float voxel_shift,
                                            float eps, int n_points, const float *alphamin,
-                                           const float *alphamax, float *out, void *stream) {
+                                           const float *alphamax, float *out, void *launch_ws,
+                                           void *stream) {
     const int N = det_h * det_w;
     if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
     if (!labels || !out || C < 1) return fail(-1, "null labels/out or C < 1");
@@ -1044,7 +1050,7 @@ int ddrr_trilinear_forward_channels_bricks(const float *volume, const unsigned c
     hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C * N, st);
     if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
     return launch_bricks(BRICK_TRI_CHANNELS, volume, dx, dy, dz, source, target, img, nullptr, B,
-                         det_h, det_w, voxel_shift, eps, out, nullptr, nullptr, st,
+                         det_h, det_w, voxel_shift, eps, out, nullptr, nullptr, st, launch_ws,
                          "ddrr_trilinear_forward_channels_bricks", n_points, alphamin, alphamax, 0.f,
                          labels, C);
 }
@@ -1053,7 +1059,7 @@ int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *sour
                                        const float *target, const float *img,
                                        const float *grad_out, int B, int det_h, int det_w,
                                        float voxel_shift, float eps, float *g_volume,
-                                       void *stream) {
+                                       void *launch_ws, void *stream) {
     const int N = det_h * det_w;
     if (!g_volume || !grad_out) return fail(-1, "null grad_out / g_volume");
     if (int rc = check_common(g_volume, dx, dy, dz, source, 1, target, B, N)) return rc;
@@ -1064,7 +1070,7 @@ int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *sour
         return e == hipSuccess ? 0 : fail_hip(e, "hipMemsetAsync");
     }
     return launch_bricks(BRICK_VOLGRAD, nullptr, dx, dy, dz, source, target, img, grad_out, B,
-                         det_h, det_w, voxel_shift, eps, nullptr, nullptr, g_volume, st,
+                         det_h, det_w, voxel_shift, eps, nullptr, nullptr, g_volume, st, launch_ws,
                          "ddrr_siddon_backward_volume_bricks");
 }
 
@@ -1072,7 +1078,7 @@ int ddrr_trilinear_forward_bricks(const float *volume, int dx, int dy, int dz,
                                   const float *source, const float *target, const float *img,
                                   int B, int det_h, int det_w, float voxel_shift, float eps,
                                   int n_points, const float *alphamin, const float *alphamax,
-                                  float *out, float *aux, void *stream) {
+                                  float *out, float *aux, void *launch_ws, void *stream) {
     const int N = det_h * det_w;
     if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
     if (!out || !alphamin || !alphamax) return fail(-1, "null out / alphamin / alphamax");
@@ -1086,10 +1092,10 @@ int ddrr_trilinear_forward_bricks(const float *volume, int dx, int dy, int dz,
     if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
     if (!aux)
         return launch_bricks(BRICK_TRI_FWD, volume, dx, dy, dz, source, target, img, nullptr, B,
-                             det_h, det_w, voxel_shift, eps, out, nullptr, nullptr, st,
+                             det_h, det_w, voxel_shift, eps, out, nullptr, nullptr, st, launch_ws,
                              "ddrr_trilinear_forward_bricks", n_points, alphamin, alphamax);
     if (int rc = launch_bricks(BRICK_TRI_FWD_AUX, volume, dx, dy, dz, source, target, img, nullptr,
-                               B, det_h, det_w, voxel_shift, eps, out, aux, nullptr, st,
+                               B, det_h, det_w, voxel_shift, eps, out, aux, nullptr, st, launch_ws,
                                "ddrr_trilinear_forward_bricks", n_points, alphamin, alphamax))
         return rc;
     hipLaunchKernelGGL(tri_out_from_record_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
@@ -1119,7 +1125,7 @@ int ddrr_trilinear_backward_volume_bricks(int dx, int dy, int dz, const float *s
                                           const float *grad_out, int B, int det_h, int det_w,
                                           float voxel_shift, float eps, int n_points,
                                           const float *alphamin, const float *alphamax,
-                                          float *g_volume, void *stream) {
+                                          float *g_volume, void *launch_ws, void *stream) {
     const int N = det_h * det_w;
     if (!g_volume || !grad_out || !alphamin || !alphamax)
         return fail(-1, "null grad_out / g_volume / alphamin / alphamax");
@@ -1132,7 +1138,7 @@ int ddrr_trilinear_backward_volume_bricks(int dx, int dy, int dz, const float *s
         return e == hipSuccess ? 0 : fail_hip(e, "hipMemsetAsync");
     }
     return launch_bricks(BRICK_TRI_VOLGRAD, nullptr, dx, dy, dz, source, target, img, grad_out, B,
-                         det_h, det_w, voxel_shift, eps, nullptr, nullptr, g_volume, st,
+                         det_h, det_w, voxel_shift, eps, nullptr, nullptr, g_volume, st, launch_ws,
                          "ddrr_trilinear_backward_volume_bricks", n_points, alphamin, alphamax);
 }
 

@@ -48,12 +48,26 @@ struct FwdCfg {
     static constexpr int SX = BY * SY + ES;
     static constexpr int BRICK_BYTES = (BX * SX + 15) / 16 * 16;
     static constexpr int WGS_PER_CU = 1024 / THREADS;
-    // poses per row-table chunk: what the LDS left by the brick and the queues holds
     static constexpr int LDS_BUDGET = 160 * 1024 / WGS_PER_CU;
-    static constexpr int ROW_ROOM =
-        (LDS_BUDGET - BRICK_BYTES - WAVES * kBuckets * kQueueCap * 4 - 16) / (20 * 4);
+    static constexpr int QUEUE_BYTES = WAVES * kBuckets * kQueueCap * 4;
+    // A 16-bit brick whose values the block quantisation would not keep (brick_step.h
+    // q16_usable: range large against the smallest 4^3-block level, non-finite values) is
+    // rendered from the volume's own fp32 values instead: its two halves along z, one after
+    // the other, as fp32 bricks BX x BY x BZ/2 (rows and planes padded by one float) in the
+    // same LDS.  MIXED: the budget has the room (every product configuration; not two
+    // workgroups per CU).
+    static constexpr int HZ = BZ / 2;
+    static constexpr int FSY = HZ * 4 + 4, FSX = BY * FSY + 4;  // byte strides of a fallback half
+    static constexpr int FALLBACK_BYTES = (BX * FSX + 15) / 16 * 16;
+    static constexpr bool MIXED =
+        Q16 && HZ % 4 == 0 && (BX * BY * (HZ / 4)) % THREADS == 0 &&
+        FALLBACK_BYTES + QUEUE_BYTES + 16 + 8 * 20 * 4 <= LDS_BUDGET;
+    using Half = FwdCfg<BX_, BY_, BZ_ / 2, THREADS_, false>;  // (used where MIXED only)
+    static constexpr int LDS_BRICK = MIXED && FALLBACK_BYTES > BRICK_BYTES ? FALLBACK_BYTES : BRICK_BYTES;
+    // poses per row-table chunk: what the LDS left by the brick and the queues holds
+    static constexpr int ROW_ROOM = (LDS_BUDGET - LDS_BRICK - QUEUE_BYTES - 16) / (20 * 4);
     static constexpr int CHUNK = ROW_ROOM >= 32 ? 32 : ROW_ROOM;
-    static constexpr int LDS_MIN = BRICK_BYTES + WAVES * kBuckets * kQueueCap * 4 + CHUNK * 20 * 4 + 16;
+    static constexpr int LDS_MIN = LDS_BRICK + QUEUE_BYTES + CHUNK * 20 * 4 + 16;
     // what the waves have left in their queues at the end of a brick is pooled (one count per
     // wave and class) where the budget has the room for the counts
     static constexpr int POOL_BYTES = WAVES * kBuckets * 4;
@@ -145,7 +159,10 @@ __device__ __forceinline__ void fwd_item(const BrickArgs &p, unsigned lds_base,
                                          const StepGeom &SG, const Q16Range &range, bool active,
                                          unsigned b, unsigned pix, float *__restrict__ out,
                                          float *__restrict__ aux, BrickProf &prof,
-                                         const FwdRow *rows = nullptr, int b0 = 0) {
+                                         const FwdRow *rows = nullptr, int b0 = 0,
+                                         bool f32_brick = !C::Q16) {
+    // (f32_brick: wave-uniform -- the staged brick holds the volume's own fp32 values)
+    const bool q16 = C::Q16 && !f32_brick;
     const unsigned r = b * (unsigned)(p.det_h * p.det_w) + pix;
     float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     bool ok = false;
@@ -180,12 +197,12 @@ __device__ __forceinline__ void fwd_item(const BrickArgs &p, unsigned lds_base,
         DDRR_PROF_WAIT_VMEM();
         DDRR_PROF(PROF_LOADS);
         StepEntry E = step_enter(SG, s, t, p.shift, p.eps, lds_base);
-        if (C::Q16) q16_scale_entry(E);
+        if (q16) q16_scale_entry(E);
         DDRR_PROF(PROF_SETUP);
         int steps = 0;
         float ex[2] = {0.f, 0.f};
         if (E.hit) {
-            if (C::Q16) {
+            if (q16) {
                 steps = step_walk<AUX, C::MAXSTEPS>(LdsAbsFetch16{}, SG, E, v[0], v + 1, ex);
                 q16_finish<AUX>(range, E, ex, v[0], v + 1);
             } else {
@@ -313,6 +330,7 @@ __global__ __launch_bounds__(C::THREADS) void brick_pack_kernel(BrickArgs p, int
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ int counter[4];
     const int tid = threadIdx.x, brick_id = blockIdx.x;
+    if (p.fallback && p.fallback[brick_id]) return;  // rendered from the volume itself
     constexpr int NV = C::BRICK_BYTES / 16;
     uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
     for (int k = tid; k < NV; k += C::THREADS) lds[k] = make_uint4(0u, 0u, 0u, 0u);  // (the padding)
@@ -331,7 +349,7 @@ __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict__ aux) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned char *brick = smem_raw;
-    unsigned *queue = reinterpret_cast<unsigned *>(smem_raw + C::BRICK_BYTES);
+    unsigned *queue = reinterpret_cast<unsigned *>(smem_raw + C::LDS_BRICK);
     FwdRow *rows = reinterpret_cast<FwdRow *>(queue + C::WAVES * kBuckets * kQueueCap);
     // [0] unit, [1] brick, [2] non-zero, [3] pooled batch; then the pool's counts
     int *counter = reinterpret_cast<int *>(rows + C::CHUNK);
@@ -352,39 +370,60 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
 #if defined(DDRR_BRICK_PROFILE)
     prof.start();
 #endif
+    // the work item in hand (workgroup-uniform): a brick, or -- a 16-bit brick rendered from fp32
+    // values -- one of its `n_sub` halves along z, taken one after the other
+    int brick_id = 0, sub = 0, n_sub = 1, pose_lo = 0, pose_hi = p.B;
+    bool f32_brick = !C::Q16;
     for (;;) {
         __syncthreads();  // every wave is done with the previous brick's LDS
         DDRR_PROF(PROF_BARRIER);
+        const bool next_half = sub + 1 < n_sub;
         if (tid == 0) {
-            counter[1] = atomicAdd(p.work, 1);
+            if (!next_half) counter[1] = atomicAdd(p.work, 1);
             counter[2] = 0;
             counter[3] = 0;
         }
         __syncthreads();
-        // Work items: bricks in the order p.order hands them out (heaviest first, see
-        // brick_weight_kernel), every pose
-        const int item = counter[1];
+        if (next_half) {
+            ++sub;
+        } else {
+            // Work items: bricks in the order p.order hands them out (heaviest first, see
+            // brick_weight_kernel), every pose
+            const int item = counter[1];
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
-        // (tools builds: the last split_t bricks go out in split_s parts of the pose batch each --
-        // measured, not adopted: the smaller batches cost more than the shorter tail gains)
-        const int n_full = n_bricks - p.split_t;
-        if (item >= n_full + p.split_t * p.split_s) break;
-        const int kth = item < n_full ? item : n_full + (item - n_full) / p.split_s;
-        const int part = item < n_full ? 0 : (item - n_full) % p.split_s;
-        const int parts = item < n_full ? 1 : p.split_s;
-        const int pose_lo = (int)((long)p.B * part / parts), pose_hi = (int)((long)p.B * (part + 1) / parts);
+            // (tools builds: the last split_t bricks go out in split_s parts of the pose batch each --
+            // measured, not adopted: the smaller batches cost more than the shorter tail gains)
+            const int n_full = n_bricks - p.split_t;
+            if (item >= n_full + p.split_t * p.split_s) break;
+            const int kth = item < n_full ? item : n_full + (item - n_full) / p.split_s;
+            const int part = item < n_full ? 0 : (item - n_full) % p.split_s;
+            const int parts = item < n_full ? 1 : p.split_s;
+            pose_lo = (int)((long)p.B * part / parts);
+            pose_hi = (int)((long)p.B * (part + 1) / parts);
 #else
-        if (item >= n_bricks) break;
-        const int kth = item, pose_lo = 0, pose_hi = p.B;
+            if (item >= n_bricks) break;
+            const int kth = item;
 #endif
-        const int brick_id = p.order ? p.order[kth] : kth;
+            brick_id = p.order ? p.order[kth] : kth;
+            sub = 0;
+            n_sub = 1;
+            if (C::MIXED) {
+                f32_brick = p.fallback && p.fallback[brick_id] != 0;
+                const int z0 = (brick_id % nbz) * C::BZ;
+                n_sub = f32_brick && p.D.z - z0 > C::HZ ? 2 : 1;
+            }
+        }
 #if defined(DDRR_BRICK_PROFILE)
         const unsigned long long brick_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
         const int n_chunks = (pose_hi - pose_lo + C::CHUNK - 1) / C::CHUNK;
         const int chunk = n_chunks ? (pose_hi - pose_lo + n_chunks - 1) / n_chunks : 0;
         DDRR_PROF(PROF_CLAIM);
-        const Box box = cfg_brick_box<C>(p.D, nby, nbz, brick_id);
+        Box box = cfg_brick_box<C>(p.D, nby, nbz, brick_id);
+        if (C::MIXED && f32_brick) {
+            box.lo[2] += sub * C::HZ;
+            box.hi[2] = box.lo[2] + C::HZ < box.hi[2] ? box.lo[2] + C::HZ : box.hi[2];
+        }
         const BoxF cells = boxf(box);
         StepGeom SG;
 #pragma unroll
@@ -392,9 +431,10 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
             SG.lof[a] = (float)box.lo[a];
             SG.hif[a] = (float)box.hi[a];
         }
-        SG.strideb[0] = bits_as_float((unsigned)C::SX);
-        SG.strideb[1] = bits_as_float((unsigned)C::SY);
-        SG.strideb[2] = bits_as_float((unsigned)C::ES);
+        const bool half = C::MIXED && f32_brick;
+        SG.strideb[0] = bits_as_float((unsigned)(half ? C::FSX : C::SX));
+        SG.strideb[1] = bits_as_float((unsigned)(half ? C::FSY : C::SY));
+        SG.strideb[2] = bits_as_float((unsigned)(half ? 4 : C::ES));
         int qn0 = 0, qn1 = 0, qn2 = 0;  // hits waiting per length class (wave-uniform)
         bool brick_empty = false, pool_open = false;
         Q16Range range = {0.f, 0.f, 0.f};
@@ -419,14 +459,23 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
             if (tid == 0) counter[0] = 0;
             DDRR_PROF(PROF_ROWS);
             if (ch == 0) {
-                if (C::Q16 && p.packed)
+                if constexpr (C::MIXED) {
+                    if (f32_brick)
+                        fwd_stage_brick<typename C::Half>(p, brick, box, brick_id, tid_here, range,
+                                                          brick_empty, counter);
+                    else if (p.packed)
+                        fwd_stage_packed<C>(p, brick, brick_id, tid_here, range, brick_empty);
+                    else
+                        fwd_stage_brick<C>(p, brick, box, brick_id, tid_here, range, brick_empty, counter);
+                } else if (C::Q16 && p.packed) {
                     fwd_stage_packed<C>(p, brick, brick_id, tid_here, range, brick_empty);
-                else
+                } else {
                     fwd_stage_brick<C>(p, brick, box, brick_id, tid_here, range, brick_empty, counter);
+                }
             }
             DDRR_PROF(PROF_STORE);
             __syncthreads();
-            if (!C::Q16 && ch == 0) brick_empty = counter[2] == 0;
+            if ((!C::Q16 || f32_brick) && ch == 0) brick_empty = counter[2] == 0;
             // units per pose -> inclusive prefix, held by every wave in registers (lane k: pose k)
             int incl = lane < nb ? (rows[lane].count + 63) >> 6 : 0;
 #pragma unroll
@@ -562,7 +611,7 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
                     DDRR_PROF(PROF_POP);
                     DDRR_PROF_COUNT(PROF_N_BATCH, 1);
                     fwd_item<AUX, C>(p, lds_base, SG, range, lane < n, e >> p.pix_bits,
-                                     e & pix_mask, out, aux, prof, rows, b0);
+                                     e & pix_mask, out, aux, prof, rows, b0, f32_brick);
                     wave_fence();
                 }
                 if (drain) break;
@@ -871,18 +920,31 @@ siddon_fwd_brick_sq_kernel(BrickArgs p, float *__restrict__ out, float *__restri
 }
 
 // (vmin, vmax) of every brick of a BX x BY x BZ grid, the input of the 16-bit staging
-// (q16_range).  One workgroup per brick; a brick holding a NaN reports vmax = NaN.
+// (q16_range), and whether the brick can be quantised at all (brick_step.h q16_usable): its
+// LEVEL is the smallest mean |V| of any of its 4 x 4 x 4 blocks -- over the non-zero voxels when
+// the brick's minimum is 0 (zeros are then stored exactly: air after the HU -> density
+// transform) -- and fallback[id] = 1 sends the brick to the fp32 path.  One workgroup per brick.
+constexpr int kSubBlocks = 1024;  // 4^3 blocks of a brick, at most
 __global__ __launch_bounds__(256) void brick_range_kernel(const float *__restrict__ vol, Dims D,
                                                           int BX, int BY, int BZ, int nby, int nbz,
-                                                          float *__restrict__ ranges) {
-    __shared__ float red[2][4];
+                                                          float *__restrict__ ranges,
+                                                          int *__restrict__ fallback) {
+    __shared__ float red[3][4];
+    __shared__ float sub_sum[kSubBlocks];
+    __shared__ int sub_nnz[kSubBlocks];
     const int id = blockIdx.x;
     const int bz = id % nbz, by = (id / nbz) % nby, bx = id / (nbz * nby);
     const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
     const int nx = min(BX, D.x - x0), ny = min(BY, D.y - y0), nz = min(BZ, D.z - z0);
+    const int QZ = BZ / 4, quads = nx * ny * QZ;
+    const int SBY = (BY + 3) / 4, n_sub = ((BX + 3) / 4) * SBY * QZ;
+    for (int k = threadIdx.x; k < kSubBlocks; k += 256) {
+        sub_sum[k] = 0.f;
+        sub_nnz[k] = 0;
+    }
+    __syncthreads();
     float tmin = INFINITY, tmax = -INFINITY;
     bool bad = false;
-    const int QZ = BZ / 4, quads = nx * ny * QZ;
     for (int k = threadIdx.x; k < quads; k += 256) {
         const int qz = k % QZ, row = k / QZ, ly = row % ny, lx = row / ny;
         if (qz * 4 >= nz) continue;  // (nz is a multiple of 4)
@@ -890,8 +952,13 @@ __global__ __launch_bounds__(256) void brick_range_kernel(const float *__restric
             vol + ((long)(x0 + lx) * D.y + (y0 + ly)) * D.z + z0 + qz * 4);
         tmin = fminf(fminf(fminf(tmin, v.x), fminf(v.y, v.z)), v.w);
         tmax = fmaxf(fmaxf(fmaxf(tmax, v.x), fmaxf(v.y, v.z)), v.w);
-        const float sum = (v.x + v.y) + (v.z + v.w);
-        bad = bad || sum != sum;  // (min / max drop NaNs)
+        const float sum = (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+        bad = bad || !(sum < INFINITY);  // (min / max drop NaNs)
+        const int sb = ((lx >> 2) * SBY + (ly >> 2)) * QZ + qz;
+        if (n_sub <= kSubBlocks) {
+            atomicAdd(&sub_sum[sb], sum);
+            atomicAdd(&sub_nnz[sb], (v.x != 0.f) + (v.y != 0.f) + (v.z != 0.f) + (v.w != 0.f));
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -905,17 +972,51 @@ __global__ __launch_bounds__(256) void brick_range_kernel(const float *__restric
         red[1][wave] = bad ? NAN : tmax;
     }
     __syncthreads();
+    float lo = INFINITY, hi = -INFINITY;
+    bool nan = false;
+    for (int w = 0; w < 4; ++w) {
+        lo = fminf(lo, red[0][w]);
+        hi = fmaxf(hi, red[1][w]);
+        nan = nan || red[1][w] != red[1][w];
+    }
+    if (!(lo <= hi)) lo = hi = 0.f;  // (no voxel)
+    // level: the smallest block mean; a block's mean is over the voxels the quantisation can be
+    // wrong about -- all of them, or the non-zero ones when 0 is the brick's minimum (q = 0)
+    float level = INFINITY;
+    for (int k = threadIdx.x; k < n_sub && n_sub <= kSubBlocks; k += 256) {
+        const int qz = k % QZ, sy = (k / QZ) % SBY, sx = k / (QZ * SBY);
+        const int cx = min(4, nx - 4 * sx), cy = min(4, ny - 4 * sy), cz = min(4, nz - 4 * qz);
+        if (cx <= 0 || cy <= 0 || cz <= 0) continue;
+        const int n_eff = lo == 0.f ? sub_nnz[k] : cx * cy * cz;
+        if (n_eff > 0) level = fminf(level, sub_sum[k] / (float)n_eff);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) level = fminf(level, __shfl_xor(level, o, 64));
+    if ((threadIdx.x & 63) == 0) red[2][wave] = level;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        float lo = INFINITY, hi = -INFINITY;
-        bool nan = false;
-        for (int w = 0; w < 4; ++w) {
-            lo = fminf(lo, red[0][w]);
-            hi = fmaxf(hi, red[1][w]);
-            nan = nan || red[1][w] != red[1][w];
-        }
-        if (!(lo <= hi)) lo = hi = 0.f;  // (no voxel)
+        level = fminf(fminf(red[2][0], red[2][1]), fminf(red[2][2], red[2][3]));
+        if (n_sub > kSubBlocks) level = 0.f;  // (a brick shape this kernel has no blocks for)
+        const float vmax = nan ? NAN : hi;
         ranges[2 * id] = lo;
-        ranges[2 * id + 1] = nan ? NAN : hi;
+        ranges[2 * id + 1] = vmax;
+        fallback[id] = q16_usable(lo, vmax, level) ? 0 : 1;
+    }
+}
+
+// header word 0 of the brick workspace: how many bricks take the fp32 path
+__global__ __launch_bounds__(256) void brick_fallback_count_kernel(const int *__restrict__ fallback,
+                                                                   int n_bricks, int *__restrict__ header) {
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    int n = 0;
+    for (int k = threadIdx.x; k < n_bricks; k += 256) n += fallback[k] != 0;
+    atomicAdd(&total, n);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        header[0] = total;
+        header[1] = n_bricks;
     }
 }
 
@@ -945,7 +1046,8 @@ __global__ __launch_bounds__(256) void brick_weight_kernel(BrickArgs p, int BX, 
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
-    if (lane == 0) weight[brick] = w;
+    // (a brick on the fp32 path is walked as two halves, one after the other)
+    if (lane == 0) weight[brick] = p.fallback && p.fallback[brick] ? 2.f * w : w;
 }
 
 constexpr int kOrderClasses = 1024;
@@ -1012,7 +1114,10 @@ int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t
         if (!p.ranges) return fail(-1, "DDRR_BRICKS_Q16 needs the brick_ranges workspace");
         if (!p.ranges_valid) {
             hipLaunchKernelGGL(brick_range_kernel, dim3(n_bricks), dim3(256), 0, st, p.vol, p.D, C::BX,
-                               C::BY, C::BZ, nby, nbz, const_cast<float *>(p.ranges));
+                               C::BY, C::BZ, nby, nbz, const_cast<float *>(p.ranges),
+                               const_cast<int *>(p.fallback));
+            hipLaunchKernelGGL(brick_fallback_count_kernel, dim3(1), dim3(256), 0, st, p.fallback,
+                               n_bricks, p.ws_header);
             if (p.packed) {
                 static bool pack_attr[kMaxDev] = {false};
                 {
@@ -1069,7 +1174,9 @@ int launch_sq(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t 
         if (!p.ranges) return fail(-1, "DDRR_BRICKS_Q16 needs the brick_ranges workspace");
         if (!p.ranges_valid)
             hipLaunchKernelGGL(brick_range_kernel, dim3(n_bricks), dim3(256), 0, st, p.vol, p.D, C::BX,
-                               C::BY, C::BZ, nby, nbz, const_cast<float *>(p.ranges));
+                               C::BY, C::BZ, nby, nbz, const_cast<float *>(p.ranges),
+                               const_cast<int *>(p.fallback));
+        // (the shared-ring variants have no fp32 path: tools builds only)
     }
     const dim3 grid(n_bricks < slots ? n_bricks : slots), block(C::THREADS);
     hipLaunchKernelGGL((siddon_fwd_brick_sq_kernel<AUX, C, NCLS>), grid, block, S::LDS, st, p, out, aux);
@@ -1111,9 +1218,15 @@ void order_bricks(BrickArgs &q, int BX, int BY, int BZ, int nby, int nbz, int n_
 // variant: DDRR_BRICKS_F32 (0) or DDRR_BRICKS_Q16 (1); tools builds know more (g_brick_variant)
 // bytes of the caller's brick workspace: the (min, max) pairs, 2 floats per 32^3 brick (any brick
 // grid fits), then, for the packed storage, the LDS images of the 32 x 32 x 64 bricks
+// layout: [header: 64 words, word 0 = bricks on the fp32 path, word 1 = bricks]
+//         [(min, max) per brick: room for every 32^3 brick] [fallback flag per brick: int]
+//         [packed storage: the 16-bit bricks' LDS images]
+constexpr long kWsHeaderBytes = 256;
+static long n32_bricks(int dx, int dy, int dz) {
+    return (long)((dx + 31) / 32) * ((dy + 31) / 32) * ((dz + 31) / 32);
+}
 static long ranges_bytes(int dx, int dy, int dz) {
-    const long n32 = (long)((dx + 31) / 32) * ((dy + 31) / 32) * ((dz + 31) / 32);
-    return (n32 * 2 * (long)sizeof(float) + 255) / 256 * 256;
+    return kWsHeaderBytes + (n32_bricks(dx, dy, dz) * 3 * (long)sizeof(float) + 255) / 256 * 256;
 }
 
 long brick_workspace_bytes(int dx, int dy, int dz, int brick_storage) {
@@ -1128,7 +1241,8 @@ long brick_workspace_bytes(int dx, int dy, int dz, int brick_storage) {
 int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_valid,
                       const float *volume, int dx, int dy, int dz, const float *source, const float *target,
                       const float *img, int B, int det_h, int det_w, float voxel_shift, float eps,
-                      float *out, float *aux, float rec_q, hipStream_t st, const char *who) {
+                      float *out, float *aux, float rec_q, hipStream_t st, void *launch_ws,
+                      const char *who) {
     const int N = det_h * det_w;
     // the configurable kernel stages with 16-byte loads; anything else takes the general kernel
     const bool vec_ok = (dz & 3) == 0 && (reinterpret_cast<uintptr_t>(volume) & 15) == 0;
@@ -1142,8 +1256,8 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
 #endif
     if (!vec_ok || variant < 0)
         return launch_bricks(aux ? BRICK_FWD_AUX : BRICK_FWD, volume, dx, dy, dz, source, target, img,
-                             nullptr, B, det_h, det_w, voxel_shift, eps, out, aux, nullptr, st, who,
-                             0, nullptr, nullptr, rec_q);
+                             nullptr, B, det_h, det_w, voxel_shift, eps, out, aux, nullptr, st,
+                             launch_ws, who, 0, nullptr, nullptr, rec_q);
     BrickArgs p = {};
     p.vol = volume;
     p.D = Dims{dx, dy, dz};
@@ -1160,7 +1274,9 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
                         "split the pose batch");
     p.aux_plane = (unsigned)((long)B * N);
     p.rec_q = rec_q;
-    p.ranges = brick_ranges;
+    p.ws_header = reinterpret_cast<int *>(brick_ranges);
+    p.ranges = brick_ranges ? brick_ranges + kWsHeaderBytes / sizeof(float) : nullptr;
+    p.fallback = brick_ranges ? reinterpret_cast<const int *>(p.ranges + 2 * n32_bricks(dx, dy, dz)) : nullptr;
     p.ranges_valid = ranges_valid;
     p.packed = packed && brick_ranges
                    ? reinterpret_cast<const unsigned char *>(brick_ranges) + ranges_bytes(dx, dy, dz)
@@ -1188,7 +1304,8 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
     if (variant >= 16) p.t1 = g_brick_sq_width;  // shared rings: t1 = class width
 #endif
     int n_cu = 0;
-    if (int rc = brick_launch_resources(st, n_cu, p.work, &p.order_ws, &p.order_cap)) return rc;
+    if (int rc = brick_launch_resources(st, launch_ws, dx, dy, dz, n_cu, p.work, &p.order_ws, &p.order_cap))
+        return rc;
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
     if (g_brick_dbg & 512) p.order_ws = nullptr;  // (bricks in id order)
 #endif

@@ -72,6 +72,15 @@ def _query(name, *args):
     return _lib.get_lib().query(name, *args)
 
 
+def launch_workspace(shape, device):
+    """This launch's own device scratch for a ``*_bricks`` entry point (include/diffdrr_hip.h
+    ``launch_ws``: the brick counter and the hand-out order of the bricks).  From torch's caching
+    allocator, so it is recycled in stream order, a captured graph gets a block of its private
+    pool for as long as the graph lives, and launches on different streams never share one."""
+    n = int(_query("ddrr_brick_launch_workspace_bytes", *(int(d) for d in shape)))
+    return torch.empty((n + 3) // 4, dtype=torch.int32, device=device)
+
+
 def _check_rays(volume, source, target, img, dtype=torch.float32):
     _require_gpu(volume)
     for name, t in (("volume", volume), ("source", source), ("target", target), ("img", img)):
@@ -199,37 +208,98 @@ def record_planes(aux, B, N):
 
 
 _BRICK_STORAGE = {"f32": _lib.BRICKS_F32, "q16": _lib.BRICKS_Q16, "q16p": _lib.BRICKS_Q16_PACKED}
-_range_cache = {}  # id(volume) -> (weakref to the volume, its version, (min, max) per brick)
+_range_cache = {}  # (id(volume), storage) -> _Workspace
+
+
+class _Workspace:
+    """Cache entry of :func:`brick_workspace`: the buffer and what it was built from."""
+    __slots__ = ("ref", "buf", "built_version", "churn", "event", "stream")
+
+    def __init__(self, ref, buf):
+        self.ref, self.buf = ref, buf
+        self.built_version = None  # volume._version the buffer holds the bricks of (None: nothing)
+        self.churn = 0             # rebuilds because the volume had changed
+        self.event = self.stream = None  # end of the building launch, and the stream it ran on
+
+
+def _workspace_entry(volume, storage):
+    ent = _range_cache.get((id(volume), storage))
+    if ent is not None and ent.ref() is volume and ent.buf.device == volume.device:
+        return ent
+    return None
 
 
 def brick_workspace(volume, storage="q16"):
     """Workspace of the 16-bit brick staging (include/diffdrr_hip.h DDRR_BRICKS_Q16 /
-    _PACKED): the bricks' (min, max) and, for "q16p", the bricks themselves as they lie in LDS
-    (+52 % of the volume's bytes).  Cached per volume TENSOR, version and storage -- the kernel
-    fills it on the first launch after the volume changed (one pass over the volume) and reuses
-    it afterwards.  (In-place edits that bypass the version counter, ``volume.data[...] = x``,
-    are not seen.)  -> (tensor, valid)"""
+    _PACKED): a header, the bricks' (min, max) and fp32-fallback flags and, for "q16p", the
+    bricks themselves as they lie in LDS (+52 % of the volume's bytes, held as long as the volume
+    tensor lives).  Cached per volume TENSOR and storage.  The kernel fills it on the first
+    launch after the volume changed (one pass over the volume); the launch that filled it
+    reports so with :func:`brick_workspace_commit`, and only then do later calls get
+    ``valid`` = 1 -- a call that returns early (empty batch) or fails leaves it unbuilt.
+    (In-place edits that bypass the version counter, ``volume.data[...] = x``, are not seen.)
+    -> (tensor, valid)"""
     key = (id(volume), storage)
-    ent = _range_cache.get(key)
-    same = ent is not None and ent[0]() is volume and ent[2].device == volume.device
-    if same and ent[1] == volume._version:
-        return ent[2], 1
+    ent = _workspace_entry(volume, storage)
     n = (int(_query("ddrr_brick_workspace_bytes", *(int(d) for d in volume.shape),
                     _BRICK_STORAGE[storage])) + 3) // 4
-    # a volume edited in place keeps its buffer (a captured graph may hold the address) and
-    # counts the rebuild: workspace_churn() lets the renderer stop paying for it
-    buf = ent[2] if same and ent[2].numel() == n else \
-        torch.empty(n, dtype=torch.float32, device=volume.device)
-    _range_cache[key] = (weakref.ref(volume, lambda _, k=key: _range_cache.pop(k, None)),
-                         volume._version, buf, (ent[3] + 1) if same else 0)
-    return buf, 0
+    if ent is None or ent.buf.numel() != n:
+        # (a volume edited in place keeps its buffer: a captured graph may hold the address)
+        ent = _Workspace(weakref.ref(volume, lambda _, k=key: _range_cache.pop(k, None)),
+                         torch.empty(n, dtype=torch.float32, device=volume.device))
+        _range_cache[key] = ent
+    valid = int(ent.built_version is not None and ent.built_version == volume._version)
+    if valid and ent.event is not None and not torch.cuda.is_current_stream_capturing():
+        # built on another stream: this stream's launches must not overtake the build
+        if ent.event.query():
+            ent.event = ent.stream = None
+        elif torch.cuda.current_stream(volume.device) != ent.stream:
+            torch.cuda.current_stream(volume.device).wait_event(ent.event)
+    return ent.buf, valid
+
+
+def brick_workspace_commit(volume, storage):
+    """The launch that was handed ``valid`` = 0 has been enqueued: the workspace now holds (in
+    stream order) the bricks of the volume's current version."""
+    ent = _workspace_entry(volume, storage)
+    if ent is None or ent.built_version == volume._version:
+        return
+    if ent.built_version is not None:
+        ent.churn += 1  # workspace_churn() lets the renderer stop paying for rebuilds
+    ent.built_version = volume._version
+    ent.event = ent.stream = None
+    if volume.device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+        ent.stream = torch.cuda.current_stream(volume.device)
+        ent.event = torch.cuda.Event()
+        ent.event.record(ent.stream)
 
 
 def workspace_churn(volume, storage):
     """How many times the workspace of this volume was rebuilt because the volume had changed
     (0: built once): a volume that changes between renders gains nothing from a packed copy."""
-    ent = _range_cache.get((id(volume), storage))
-    return ent[3] if ent is not None and ent[0]() is volume else 0
+    ent = _workspace_entry(volume, storage)
+    return ent.churn if ent is not None else 0
+
+
+def brick_fallbacks(volume, storage):
+    """(bricks rendered from their own fp32 values, bricks) of the built workspace of this
+    volume -- the 16-bit block quantisation is only used for bricks whose range is small against
+    their level (csrc/brick_step.h q16_usable) -- or None if no launch has built it yet.
+    Reads two words from the device (a host sync)."""
+    ent = _workspace_entry(volume, storage)
+    if ent is None or ent.built_version is None:
+        return None
+    head = ent.buf[:2].view(torch.int32).tolist()
+    return head[0], head[1]
+
+
+def brick_storage_applies(volume) -> bool:
+    """Whether the 16-bit brick storages can serve this volume tensor at all: the configurable
+    kernel stages with 16-byte loads (else the general fp32 kernel runs and a workspace would
+    never be read), and a non-contiguous volume is a new temporary on every call (its workspace
+    would be rebuilt -- and its memory churned -- per render)."""
+    return (volume.dim() == 3 and volume.is_contiguous() and volume.shape[2] % 4 == 0
+            and volume.data_ptr() % 16 == 0)
 
 
 def brick_ranges(volume):
@@ -253,6 +323,8 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
     H, W = int(det[0]), int(det[1])
     if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
         raise ValueError("the brick path needs one source per pose and an H*W >= 2x2 ray grid")
+    if storage != "f32" and not brick_storage_applies(volume):
+        storage = "f32"
     volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
     img = None if img is None else img.contiguous()
     out = torch.empty(B, N, dtype=torch.float32, device=volume.device)
@@ -269,7 +341,10 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
         "ddrr_siddon_forward_bricks", volume.device, volume.data_ptr(), *volume.shape,
         source.data_ptr(), target.data_ptr(), _ptr(img), B, H, W, float(voxel_shift), float(eps),
         out.data_ptr(), _ptr(aux), float(record_vmax) if packed else 0.0,
-        _BRICK_STORAGE[storage], _ptr(ranges), int(valid))
+        _BRICK_STORAGE[storage], _ptr(ranges), int(valid),
+        launch_workspace(volume.shape, volume.device).data_ptr())
+    if storage != "f32" and not valid:
+        brick_workspace_commit(volume, storage)
     return out, aux
 
 
@@ -438,7 +513,8 @@ def siddon_backward_volume_bricks(volume_shape, source, target, img, grad_out, d
     g_volume = torch.empty(Dx, Dy, Dz, dtype=torch.float32, device=target.device)
     _launch("ddrr_siddon_backward_volume_bricks", target.device, Dx, Dy, Dz, source.data_ptr(),
             target.data_ptr(), _ptr(img), grad_out.data_ptr(), B, H, W, float(voxel_shift),
-            float(eps), g_volume.data_ptr())
+            float(eps), g_volume.data_ptr(),
+            launch_workspace((Dx, Dy, Dz), target.device).data_ptr())
     return g_volume
 
 
@@ -478,7 +554,8 @@ def siddon_forward_channels_bricks(volume, labels_u8, n_channels, source, target
     img = None if img is None else img.contiguous()
     _launch("ddrr_siddon_forward_channels_bricks", volume.device, volume.data_ptr(),
             labels_u8.data_ptr(), *volume.shape, source.data_ptr(), target.data_ptr(), _ptr(img),
-            B, H, W, int(n_channels), float(voxel_shift), float(eps), out.data_ptr())
+            B, H, W, int(n_channels), float(voxel_shift), float(eps), out.data_ptr(),
+            launch_workspace(volume.shape, volume.device).data_ptr())
     return out
 
 
@@ -659,7 +736,8 @@ def trilinear_forward_channels_bricks(volume, labels_u8, n_channels, source, tar
         "ddrr_trilinear_forward_channels_bricks", volume.device, volume.data_ptr(),
         labels_u8.data_ptr(), *volume.shape, source.data_ptr(), target.data_ptr(), _ptr(img), B,
         H, W, int(n_channels), float(voxel_shift), float(eps), int(n_points), alphamin.data_ptr(),
-        alphamax.data_ptr(), out.data_ptr())
+        alphamax.data_ptr(), out.data_ptr(),
+        launch_workspace(volume.shape, volume.device).data_ptr())
     return out
 
 
@@ -684,7 +762,8 @@ def trilinear_forward_bricks(volume, source, target, img, alphamin, alphamax, de
         _launch("ddrr_trilinear_forward_bricks", volume.device, volume.data_ptr(), *volume.shape,
                 source.data_ptr(), target.data_ptr(), _ptr(img), B, H, W, float(voxel_shift),
                 float(eps), int(n_points), alphamin.data_ptr(), alphamax.data_ptr(),
-                out.data_ptr(), _ptr(aux))
+                out.data_ptr(), _ptr(aux),
+                launch_workspace(volume.shape, volume.device).data_ptr())
     return (out, aux) if want_aux else out
 
 
@@ -730,7 +809,8 @@ def trilinear_backward_volume_bricks(volume_shape, source, target, img, grad_out
     _launch("ddrr_trilinear_backward_volume_bricks", target.device, Dx, Dy, Dz,
             source.data_ptr(), target.data_ptr(), _ptr(img), grad_out.data_ptr(), B, H, W,
             float(voxel_shift), float(eps), int(n_points), alphamin.data_ptr(),
-            alphamax.data_ptr(), g_volume.data_ptr())
+            alphamax.data_ptr(), g_volume.data_ptr(),
+            launch_workspace((Dx, Dy, Dz), target.device).data_ptr())
     return g_volume
 
 

@@ -59,13 +59,31 @@ class GraphedIteration:
     Construction has no side effects on the optimisation: the ``warmup`` eager iterations and
     the capture itself (which runs the iteration once more) are undone -- parameters and
     optimizer state are restored to what they were -- so that ``step()`` number k is iteration
-    k of the loop, as in the reference's.  ``iterations_done`` counts the replays."""
+    k of the loop, as in the reference's.  ``iterations_done`` counts the replays.
+    Limits of that undo: optimizer state created by the warm-up is ZEROED, which equals a fresh
+    start for Adam and for SGD with momentum and ``dampening == 0``; with ``dampening != 0`` a
+    fresh first step sets ``buf = grad`` while a zeroed buffer yields ``(1 - dampening) grad``
+    (rejected below), and state that is not a tensor (Python-int step counts of non-capturable
+    optimizers) is not restored.
+
+    ``static_volume`` (default True): the CT volume is not edited in place between replays --
+    the graph then renders from the volume's cached 16-bit bricks (``Siddon.brick_storage``),
+    whose address and "already built" state are baked into the graph.  Pass False if the volume
+    changes under the graph: the captured render then reads the live fp32 volume."""
 
     def __init__(self, reg: Registration, criterion, optimizer, target: torch.Tensor,
-                 warmup: int = 3, **render_kwargs):
+                 warmup: int = 3, static_volume: bool = True, **render_kwargs):
         self.reg, self.criterion, self.optimizer, self.target = reg, criterion, optimizer, target
         self.render_kwargs = render_kwargs
         self.iterations_done = 0
+        for g in optimizer.param_groups:
+            if g.get("momentum", 0) and g.get("dampening", 0):
+                raise ValueError("GraphedIteration: SGD with momentum and dampening != 0 cannot "
+                                 "be restored to a fresh first step after warm-up and capture")
+        renderer = getattr(reg.drr, "renderer", None)
+        had_static = getattr(renderer, "static_volume", None)
+        if had_static is not None:
+            renderer.static_volume = bool(static_volume)
         params = [p for g in optimizer.param_groups for p in g["params"]]
         saved_params = [p.detach().clone() for p in params]
         saved_state = {p: {k: v.detach().clone() for k, v in optimizer.state.get(p, {}).items()
@@ -86,8 +104,12 @@ class GraphedIteration:
                 iteration()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = iteration()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss = iteration()
+        finally:
+            if had_static is not None:
+                renderer.static_volume = had_static
         # undo warm-up and capture: same parameter values, same optimizer state, IN PLACE (the
         # graph holds the addresses of both).  State the warm-up created is zeroed, which is what
         # a first step starts from (Adam's moments and step count, SGD's momentum buffer).

@@ -119,7 +119,16 @@ def _brick_storage(volume, cfg):
     storage = cfg.get("storage", "f32")
     if storage not in ("q16", "q16p") or volume.requires_grad:
         return "f32"
+    if not ops.brick_storage_applies(volume):
+        return "f32"
     dev = volume.device
+    if (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
+            and not cfg.get("static_volume", False)):
+        # A captured graph would bake in the workspace's address and "already built": replays
+        # after an in-place update of the volume would render the OLD bricks.  fp32 bricks read
+        # the live volume.  (Siddon.static_volume = True promises that the volume is not edited
+        # between replays -- registration.GraphedIteration sets it.)
+        return "f32"
     if dev.type == "cuda":
         if dev not in _cu_count:
             _cu_count[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -533,6 +542,10 @@ class Siddon(torch.nn.Module):
         # bytes, built on the first render after the volume changed, +0.35 ms at 512^3): same
         # results; one pose per launch -23 %, 32 poses -3 %.
         self.brick_storage = "q16p"
+        # Under HIP-graph capture the 16-bit storages are only used if the caller promises that
+        # the volume is not edited in place between replays (the graph bakes in the cached
+        # workspace): otherwise captured renders use fp32 bricks, which read the live volume.
+        self.static_volume = False
         # mask_to_channels of a detector-grid call on the brick kernel: the label rides in the low
         # byte of the staged voxel word, the value keeps a 16-bit mantissa (2^-17 relative per
         # voxel; channel sums agree with the plain render to 1e-5 of the image scale,
@@ -557,6 +570,7 @@ class Siddon(torch.nn.Module):
                 "det": self.detector_shape if det == "unchecked" else det, "tile": self.tile,
                 "path": self.grid_path,
                 "packed_record": self.packed_record, "storage": self.brick_storage,
+                "static_volume": self.static_volume,
                 "channels_on_bricks": self.channels_on_bricks}
 
     def supports_pose_entry(self):

@@ -27,8 +27,15 @@
  *  - img (B, N): ray length in world units (drr.py:201), NULL == all ones;
  *  - out (B, N) (the reference's (B, 1, N) without the singleton);
  *  - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous
- *    and never synchronise the device; the library keeps no global state
- *    besides a thread-local error string;
+ *    and never synchronise the device; the library keeps no state on the device
+ *    and, on the host, only a thread-local error string, each device's CU count
+ *    and "kernel attribute set" flags;
+ *  - `launch_ws` of the *_bricks entry points: a caller-owned device buffer of
+ *    ddrr_brick_launch_workspace_bytes(dx, dy, dz) bytes, 16-byte aligned, that
+ *    belongs to THIS call until the call's work on `stream` is done (its brick
+ *    counter and the hand-out order of the bricks live there; contents need not
+ *    be initialised).  Calls that may run concurrently -- other streams, a
+ *    captured graph next to eager launches -- must be given different buffers;
  *  - return value: 0 on success, otherwise a hipError_t (or -1 for an
  *    argument error); ddrr_last_error() describes the last failure.
  *
@@ -44,7 +51,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 24
+#define DDRR_ABI_VERSION 25
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -96,31 +103,46 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
  * brick piece) for aux_layout = DDRR_AUX_PACKED.
  * brick_storage: how a brick is held in LDS.  DDRR_BRICKS_F32: the volume's own fp32 values,
  * 32^3 voxels per brick.  DDRR_BRICKS_Q16: 16-bit block quantisation, one (min, step) pair per
- * brick (V ~ min + q step, q = 0 .. 65535: |error| <= (max - min of the brick) / 131070 per
- * voxel; all arithmetic stays fp32), which lets a brick of twice the volume (32 x 32 x 64) fit a
- * CU's LDS: fewer (ray, brick) pairs, 6-7 % faster.  DDRR_BRICKS_Q16_PACKED: the same bricks,
- * additionally kept in the workspace as they lie in LDS (padding included, brick after brick;
- * + 52 % of the volume's bytes): a later call stages a brick with a straight 16-byte copy of half
- * the bytes instead of converting the fp32 volume again -- what a volume that is rendered many
- * times wants, most of all with few poses per launch, where staging is most of the launch.
+ * brick (V ~ min + q step, q = 0 .. 65535; all arithmetic stays fp32), which lets a brick of
+ * twice the volume (32 x 32 x 64) fit a CU's LDS: fewer (ray, brick) pairs, 6-7 % faster.
+ * ONLY bricks that keep their values are quantised: the error of a stored voxel is at most
+ * (max - min of the brick) / 131070 in absolute terms, so a brick qualifies if that range is at
+ * most 8x its LEVEL, the smallest mean |V| of any of its 4 x 4 x 4 blocks (over the non-zero
+ * voxels when the brick's minimum is 0, which is stored exactly) -- every voxel is then within
+ * 6.1e-5 of the mean of the dimmest block a ray can cross.  Every other brick (one bright voxel
+ * among dim ones: a metal marker, contrast agent, un-normalised HU; inf / NaN; |values| or a
+ * range outside 2^-60 .. 2^40) is rendered from the volume's own fp32 values, as two
+ * 32 x 32 x 32 halves, in the same launch: results of DDRR_BRICKS_Q16 are within the 1e-4 of
+ * DDRR_BRICKS_F32's whatever the volume holds (tests/test_brick_storage_guard.py).
+ * DDRR_BRICKS_Q16_PACKED: the same bricks, additionally kept in the workspace as they lie in
+ * LDS (padding included, brick after brick; + 52 % of the volume's bytes): a later call stages
+ * a brick with a straight 16-byte copy of half the bytes instead of converting the fp32 volume
+ * again -- what a volume that is rendered many times wants, most of all with few poses per
+ * launch, where staging is most of the launch.
+ * (The 16-bit walk carries alpha pre-scaled by 2^64: rays with |alpha| >= 2^63 inside the volume
+ * -- |t - s + eps| < ~1e-16 on an axis, which eps = 1e-8 excludes -- overflow to inf / NaN there,
+ * where fp32 bricks would return a finite value.)
  * brick_ranges: NULL for DDRR_BRICKS_F32; otherwise a caller-owned workspace of
- * ddrr_brick_workspace_bytes(dx, dy, dz, brick_storage) bytes, 16-byte aligned, holding the
- * bricks' (min, max) (and the packed bricks): with ranges_valid = 0 the call fills it first
- * (one pass over the volume, ~0.1 ms at 512^3; ~0.3 ms with the packed bricks), with
- * ranges_valid = 1 it trusts what an earlier call for the SAME volume contents and the same
- * brick_storage left there (a registration or a pose sweep renders one volume thousands of
- * times).  A brick holding a NaN or an infinity yields NaN for every ray
- * through it.  (A volume with only a few double bricks per CU balances badly: 256^3 is 6 %
- * faster on fp32 bricks; the Python layer chooses, diffdrr_amd/renderers.py.) */
+ * ddrr_brick_workspace_bytes(dx, dy, dz, brick_storage) bytes, 16-byte aligned: a 256-byte
+ * header (int32 word 0: bricks on the fp32 path, word 1: bricks), the bricks' (min, max) and
+ * fp32 flags (and the packed bricks).  With ranges_valid = 0 the call fills it first (one pass
+ * over the volume, ~0.1 ms at 512^3; ~0.35 ms with the packed bricks), with ranges_valid = 1 it
+ * trusts what an earlier call for the SAME volume contents and the same brick_storage left
+ * there (a registration or a pose sweep renders one volume thousands of times) -- a caller
+ * must only pass 1 after a call with 0 and B > 0 has returned 0 for these contents.
+ * (A volume with only a few double bricks per CU balances badly: 256^3 is 6 % faster on fp32
+ * bricks; the Python layer chooses, diffdrr_amd/renderers.py.)
+ * launch_ws: see the conventions at the top of this file. */
 #define DDRR_BRICKS_F32 0
 #define DDRR_BRICKS_Q16 1
 #define DDRR_BRICKS_Q16_PACKED 2
 long ddrr_brick_workspace_bytes(int dx, int dy, int dz, int brick_storage);
+long ddrr_brick_launch_workspace_bytes(int dx, int dy, int dz);
 int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
                                const float *target, const float *img, int B, int det_h,
                                int det_w, float voxel_shift, float eps, float *out, float *aux,
                                float record_vmax, int brick_storage, float *brick_ranges,
-                               int ranges_valid, void *stream);
+                               int ranges_valid, void *launch_ws, void *stream);
 
 /* Volume gradient for the DRR case of ddrr_siddon_forward_bricks (reduce sum), also
  * volume-stationary: each 32^3 brick of g_volume is accumulated in LDS (ds_add_f32) from
@@ -132,7 +154,7 @@ int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *sour
                                        const float *target, const float *img,
                                        const float *grad_out, int B, int det_h, int det_w,
                                        float voxel_shift, float eps, float *g_volume,
-                                       void *stream);
+                                       void *launch_ws, void *stream);
 
 /* Pose/ray gradients of ddrr_siddon_forward from its aux record (aux_layout says which
  * forward wrote it): what autograd of renderers.py:94-113 + :70-71 returns.  g_source is per ray (B, N, 3) (sum
@@ -179,7 +201,8 @@ int ddrr_siddon_forward_channels(const float *volume, const unsigned char *label
 int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char *labels, int dx,
                                         int dy, int dz, const float *source, const float *target,
                                         const float *img, int B, int det_h, int det_w, int C,
-                                        float voxel_shift, float eps, float *out, void *stream);
+                                        float voxel_shift, float eps, float *out, void *launch_ws,
+                                        void *stream);
 
 /* Backward of ddrr_siddon_forward_channels: what autograd of renderers.py:77-89 (scatter_add
  * of the weighted segments into channels) returns for grad_out (B, C, N).  Outputs as in
@@ -254,7 +277,7 @@ int ddrr_trilinear_forward_bricks(const float *volume, int dx, int dy, int dz,
                                   const float *source, const float *target, const float *img,
                                   int B, int det_h, int det_w, float voxel_shift, float eps,
                                   int n_points, const float *alphamin, const float *alphamax,
-                                  float *out, float *aux, void *stream);
+                                  float *out, float *aux, void *launch_ws, void *stream);
 
 /* mask_to_channels of the marcher (Trilinear.forward mask branch, renderers.py:242-252) for the
  * DRR case on the volume-stationary bricks (mode "bilinear", align_corners = 0): the packed words
@@ -268,7 +291,8 @@ int ddrr_trilinear_forward_channels_bricks(const float *volume, const unsigned c
                                            const float *target, const float *img, int B,
                                            int det_h, int det_w, int C, float voxel_shift,
                                            float eps, int n_points, const float *alphamin,
-                                           const float *alphamax, float *out, void *stream);
+                                           const float *alphamax, float *out, void *launch_ws,
+                                           void *stream);
 /* Ray / range gradients of the march from the record of ddrr_trilinear_forward_bricks
  * (what ddrr_trilinear_backward computes by marching again); one source per pose.
  * Any output may be NULL; shapes as in ddrr_trilinear_backward. */
@@ -282,7 +306,7 @@ int ddrr_trilinear_backward_volume_bricks(int dx, int dy, int dz, const float *s
                                           const float *grad_out, int B, int det_h, int det_w,
                                           float voxel_shift, float eps, int n_points,
                                           const float *alphamin, const float *alphamax,
-                                          float *g_volume, void *stream);
+                                          float *g_volume, void *launch_ws, void *stream);
 
 /* Backward of ddrr_trilinear_forward (reduce sum).  Any output may be NULL.
  * g_source/g_target: per ray (B, N, 3), through the sample positions;

@@ -330,3 +330,152 @@ def gpu():
 
     _lib.get_lib()  # fail loudly if the HIP library was not built
     return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------ 16-bit brick storage guard
+Q16_RANGE_OVER_LEVEL = 8.0  # csrc/brick_step.h kQ16RangeOverLevel
+
+
+def brick_levels(vol, bdims):
+    """numpy restatement of brick_range_kernel + q16_usable (csrc/bricks_fwd.hip,
+    csrc/brick_step.h): per brick of the ``bdims`` grid its level -- the smallest mean |V| of any
+    4^3 block, over the non-zero voxels when the brick's minimum is 0 -- and whether the brick
+    takes the fp32 path.  -> (level volume: the brick's level at every voxel of a QUANTISED brick,
+    0 elsewhere; fallback flags (nbx, nby, nbz))"""
+    v = np.asarray(vol, dtype=np.float32)
+    D = v.shape
+    nb = [-(-D[a] // bdims[a]) for a in range(3)]
+    level_vol = np.zeros(D, np.float64)
+    flags = np.zeros(nb, bool)
+    for bx in range(nb[0]):
+        for by in range(nb[1]):
+            for bz in range(nb[2]):
+                sl = tuple(slice(i * b, min((i + 1) * b, d)) for i, b, d in zip((bx, by, bz), bdims, D))
+                blk = v[sl]
+                with np.errstate(invalid="ignore", over="ignore"):
+                    lo, hi = np.float32(blk.min()), np.float32(blk.max())
+                    rng = hi - lo
+                    level = np.inf
+                    for x in range(0, blk.shape[0], 4):
+                        for y in range(0, blk.shape[1], 4):
+                            for z in range(0, blk.shape[2], 4):
+                                s = blk[x:x + 4, y:y + 4, z:z + 4].astype(np.float64)
+                                n = int((s != 0).sum()) if lo == 0 else s.size
+                                if n:
+                                    level = min(level, float(np.abs(s).sum()) / n)
+                    if not np.isfinite(blk).all():
+                        ok = False
+                    elif rng == 0:
+                        ok = abs(lo) < 2.0 ** 40
+                    else:
+                        ok = bool(2.0 ** -60 <= rng < 2.0 ** 40 and abs(lo) < 2.0 ** 40
+                                  and rng <= Q16_RANGE_OVER_LEVEL * level)
+                flags[bx, by, bz] = not ok
+                if ok:
+                    level_vol[sl] = level if np.isfinite(level) else 0.0
+    return level_vol, flags
+
+
+def guard_scene(device, det=(40, 40), delx=2.0, dims=(64, 64, 128)):
+    """Rays of a few poses through a (64, 64, 128) volume (2 x 2 x 2 double bricks, 2 x 2 x 4 of
+    32^3) as ``DRR`` builds them: (s, t, L) voxel-space tensors on ``device`` and the module."""
+    import torch
+
+    from diffdrr_amd import DRR, convert
+    from diffdrr_amd.data import make_subject
+
+    drr = DRR(make_subject(torch.zeros(*dims)), sdd=600.0, height=det[0], width=det[1], delx=delx)
+    rot = torch.tensor([[0.0, 0.0, 0.0], [0.5, -0.3, 0.2], [-0.7, 0.4, 1.1]])
+    xyz = torch.tensor([[0.0, 400.0, 0.0], [5.0, 380.0, -8.0], [-12.0, 420.0, 6.0]])
+    with torch.no_grad():
+        pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+        source, target = drr.detector(pose, None)
+        L = (target - source).norm(dim=-1).contiguous()
+        s = drr.affine_inverse(source).contiguous()
+        t = drr.affine_inverse(target).contiguous()
+    return s.to(device), t.to(device), L.to(device)
+
+
+def guard_volumes():
+    """name -> (volume (64, 64, 128) float32, comment).  Everything the 16-bit block quantisation
+    must NOT be trusted with, next to what it is meant for."""
+    rng = np.random.default_rng(7)
+    D = (64, 64, 128)
+    body = (0.5 + 0.01 * (rng.random(D) - 0.5)).astype(np.float32)  # 0.5 +- 0.005
+    vols = {"noise": rng.random(D).astype(np.float32)}
+    for f in (2.0, 20.0, 200.0, 2000.0, 1e4, 1e6):
+        v = body.copy()
+        v[40, 37, 70] = 0.5 * f  # in view of the detector's centre
+        vols[f"outlier_x{f:g}_in_view"] = v
+        v = body.copy()
+        v[1, 62, 2] = 0.5 * f    # a corner no ray of the small detector passes
+        vols[f"outlier_x{f:g}_out_of_view"] = v
+    # un-normalised HU: air -1000, soft tissue ~40 +- 30, a bone shell, a metal sphere at 30000
+    x, y, z = np.meshgrid(*(np.linspace(-1, 1, d) for d in D), indexing="ij")
+    r = np.sqrt((x / 0.8) ** 2 + (y / 0.7) ** 2 + (z / 0.9) ** 2)
+    hu = np.full(D, -1000.0, np.float32)
+    hu[r < 1.0] = (40.0 + 30.0 * rng.standard_normal(D)).astype(np.float32)[r < 1.0]
+    hu[(r > 0.55) & (r < 0.62)] = (1100.0 + 400.0 * rng.random(D)).astype(np.float32)[(r > 0.55) & (r < 0.62)]
+    hu[np.sqrt((x - 0.2) ** 2 + (y + 0.1) ** 2 + (z - 0.3) ** 2) < 0.06] = 30000.0
+    vols["hu_with_metal"] = hu
+    vols["negative"] = (-rng.random(D)).astype(np.float32)
+    vols["mixed_sign"] = rng.standard_normal(D).astype(np.float32)
+    const = np.full(D, 0.37, np.float32)
+    const[:32] = 0.0  # bricks of zeros (skipped as empty space) next to bricks of one value
+    vols["constant_bricks"] = const
+    half = body.copy()
+    half[:, :, ::2] *= 1e-3  # every brick half bright, half 1000x dimmer, finely interleaved
+    vols["dim_and_bright_layers"] = half
+    step = body.copy()
+    step[:, 32:, :] *= 1e-3  # ... and in two slabs that rays can see separately
+    vols["dim_and_bright_slabs"] = step
+    return vols
+
+
+def check_brick_storage_guard(ops, device, name, storage, bdims):
+    """A 16-bit storage of ddrr_siddon_forward_bricks against the fp64 oracle on one of
+    guard_volumes(): the plain image-normalised 1e-4, the stated per-pixel bound
+    (|error| <= 6.1e-5 of the line integral of the brick levels + fp32 rounding), the number of
+    bricks sent to the fp32 path, and the record."""
+    import torch
+
+    import oracle
+
+    vol = guard_volumes()[name]
+    s, t, L = guard_scene(device)
+    B, N = L.shape
+    V = torch.from_numpy(vol).to(device)
+    a64 = (vol.astype(np.float64), s.cpu().numpy().astype(np.float64),
+           t.cpu().numpy().astype(np.float64), L.cpu().numpy().astype(np.float64))
+    ref = oracle.siddon(*a64)["out"].reshape(B, N)
+    if "out_of_view" in name:
+        delta = np.zeros_like(a64[0])
+        delta[1, 62, 2] = 1.0
+        assert not oracle.siddon(delta, *a64[1:])["out"].any()  # really out of view
+    level_vol, flags = brick_levels(vol, bdims)
+    # the quantisation's share of a pixel's error: what it adds to the fp32 bricks' own result
+    # (same clip, same alphas, same walk: fp32 geometry error is common to both), allowance for
+    # the different grouping of the sums: 3e-6 of the line integral of |V|
+    finite = np.where(np.isfinite(a64[0]), np.abs(a64[0]), 0.0)
+    bound = (Q16_RANGE_OVER_LEVEL / 131070.0) * oracle.siddon(level_vol, *a64[1:])["out"].reshape(B, N) \
+        + 3e-6 * oracle.siddon(finite, *a64[1:])["out"].reshape(B, N)
+    out, aux = ops.siddon_forward_bricks(V, s, t, L, (40, 40), storage=storage, want_aux=True)
+    out0, _ = ops.siddon_forward_bricks(V, s, t, L, (40, 40), storage=storage)
+    assert ops.brick_fallbacks(V, storage) == (int(flags.sum()), flags.size)
+    ref32, aux32 = ops.siddon_forward_bricks(V, s, t, L, (40, 40), storage="f32", want_aux=True)
+    f32 = ref32.cpu().numpy().astype(np.float64)
+    for img in (out, out0):
+        img = img.cpu().numpy().astype(np.float64)
+        err = np.abs(img - ref)
+        assert err.max() <= 1e-4 * np.abs(ref).max(), (name, err.max() / np.abs(ref).max())
+        errq = np.abs(img - f32)
+        assert (errq <= bound + 1e-30).all(), (name, float((errq / (bound + 1e-30)).max()))
+    # the record: the same crossings over voxel values within the bound -> the ray gradients of
+    # the fp32 bricks, per pose sum (single rays flip where crossings tie)
+    go = torch.rand(B, N, generator=torch.Generator().manual_seed(5)).to(device)
+    gq = ops.siddon_backward_rays(aux, go, s, t, L)
+    gf = ops.siddon_backward_rays(aux32, go, s, t, L)
+    assert rel_err(gq[2].cpu().numpy(), gf[2].cpu().numpy()) < 1e-4  # d/d img = g * I
+    same = (gq[1] - gf[1]).abs().amax(-1) <= 2e-3 * gf[1].abs().max()
+    assert same.float().mean().item() > 0.99, name
+    return int(flags.sum()), flags.size

@@ -326,18 +326,33 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
 long ddrr_brick_workspace_bytes(int dx, int dy, int dz, int brick_storage) {
     if (brick_storage == DDRR_BRICKS_F32 || dx < 1 || dy < 1 || dz < 1) return 0;
     const long n32 = (long)((dx + 31) / 32) * ((dy + 31) / 32) * ((dz + 31) / 32);
-    long n = (n32 * 8 + 255) / 256 * 256;
+    long n = 256 + (n32 * 12 + 255) / 256 * 256;  // header, (min, max) and fallback flag per brick
     if (brick_storage == DDRR_BRICKS_Q16_PACKED)
         n += (long)((dx + 31) / 32) * ((dy + 31) / 32) * ((dz + 63) / 64) * 133184;
     return n;
 }
 
+// (the emulation keeps no per-launch device state; the size is the product's)
+long ddrr_brick_launch_workspace_bytes(int dx, int dy, int dz) {
+    if (dx < 1 || dy < 1 || dz < 1) return 0;
+    const long n32 = (long)((dx + 31) / 32) * ((dy + 31) / 32) * ((dz + 31) / 32);
+    return 256 + (n32 * 8 + 255) / 256 * 256;
+}
+
 int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
                                const float *target, const float *img, int B, int det_h,
                                int det_w, float voxel_shift, float eps, float *out, float *aux,
-                               float record_vmax, int brick_storage, float *brick_ranges,
-                               int /*ranges_valid*/, void *) {
+                               float record_vmax, int brick_storage, float *brick_ws,
+                               int ranges_valid, void * /*launch_ws*/, void *) {
     const Dims D{dx, dy, dz};
+    // workspace layout of the product (bricks_fwd.hip): header, (min, max) per brick, fallback
+    // flags.  The emulation walks 32^3 bricks; like the product it TRUSTS a workspace handed
+    // over as valid (ranges_valid) instead of looking at the volume again.
+    const long n32 = (long)((dx + 31) / 32) * ((dy + 31) / 32) * ((dz + 31) / 32);
+    int *ws_header = reinterpret_cast<int *>(brick_ws);
+    float *brick_ranges = brick_ws ? brick_ws + 64 : nullptr;
+    int *brick_fallback = brick_ws ? reinterpret_cast<int *>(brick_ranges + 2 * n32) : nullptr;
+    int n_fallback = 0;
     const bool q16 = brick_storage == DDRR_BRICKS_Q16 || brick_storage == DDRR_BRICKS_Q16_PACKED;
     // 16-bit bricks (bricks_fwd.hip CfgQ16x2): rows and planes padded by one element
     const int qsy = 32 * 2 + 2, qsx = 32 * qsy + 2;
@@ -366,21 +381,52 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
         const StepGeom SG = step_geom(box, lay);
         std::fill(brick.begin(), brick.end(), 0.f);
         float vmin = INFINITY, vmax = -INFINITY;
+        bool bad = false;  // (min / max drop NaNs)
         for (int x = box.lo[0]; x < box.hi[0]; ++x)
             for (int y = box.lo[1]; y < box.hi[1]; ++y)
                 for (int z = box.lo[2]; z < box.hi[2]; ++z) {
                     const float v = volume[((long)x * dy + y) * dz + z];
                     brick[(x - box.lo[0]) * lay.sx + (y - box.lo[1]) * lay.sy + (z - box.lo[2])] = v;
                     vmin = fminf(vmin, v);
-                    vmax = v != v ? v : fmaxf(vmax, v);
+                    vmax = fmaxf(vmax, v);
+                    bad = bad || !(fabsf(v) < INFINITY);
                 }
-        Q16Range range = q16_range(vmin, vmax);
-        StepGeom SGq = SG;
-        if (q16) {
-            if (brick_ranges) {
+        if (bad) vmax = NAN;
+        // the brick's level: smallest mean |V| of its 4^3 blocks (brick_range_kernel)
+        float level = INFINITY;
+        for (int x4 = box.lo[0]; x4 < box.hi[0]; x4 += 4)
+            for (int y4 = box.lo[1]; y4 < box.hi[1]; y4 += 4)
+                for (int z4 = box.lo[2]; z4 < box.hi[2]; z4 += 4) {
+                    float sum = 0.f;
+                    int nnz = 0, cnt = 0;
+                    for (int x = x4; x < x4 + 4 && x < box.hi[0]; ++x)
+                        for (int y = y4; y < y4 + 4 && y < box.hi[1]; ++y)
+                            for (int z = z4; z < z4 + 4 && z < box.hi[2]; ++z) {
+                                const float v = volume[((long)x * dy + y) * dz + z];
+                                sum += fabsf(v);
+                                nnz += v != 0.f;
+                                ++cnt;
+                            }
+                    const int n_eff = vmin == 0.f ? nnz : cnt;
+                    if (n_eff > 0) level = fminf(level, sum / (float)n_eff);
+                }
+        bool fallback = !q16_usable(vmin, vmax, level);
+        if (q16 && brick_ranges) {
+            if (ranges_valid) {
+                vmin = brick_ranges[2 * id];
+                vmax = brick_ranges[2 * id + 1];
+                fallback = brick_fallback[id] != 0;
+            } else {
                 brick_ranges[2 * id] = vmin;
                 brick_ranges[2 * id + 1] = vmax;
+                brick_fallback[id] = fallback;
             }
+        }
+        n_fallback += fallback;
+        const bool q16_here = q16 && !fallback;
+        Q16Range range = q16_range(vmin, vmax);
+        StepGeom SGq = SG;
+        if (q16_here) {
             SGq.strideb[0] = bits_as_float((unsigned)qsx);
             SGq.strideb[1] = bits_as_float((unsigned)qsy);
             SGq.strideb[2] = bits_as_float(2u);
@@ -400,7 +446,7 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
             }
             float I, rec[4];
             bool hit;
-            if (q16)
+            if (q16_here)
                 hit = aux ? step_trace_q16<true, 100>(LdsFetch16{qbrick.data()}, 0u, SGq, range, s, t,
                                                       voxel_shift, eps, I, rec)
                           : step_trace_q16<false, 100>(LdsFetch16{qbrick.data()}, 0u, SGq, range, s,
@@ -464,6 +510,10 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
         for (int k = 2; k >= 0; --k)
             for (auto &it : queues[k]) item(it.first, it.second);
     }
+    if (q16 && ws_header && !ranges_valid) {
+        ws_header[0] = n_fallback;
+        ws_header[1] = bg.nx * bg.ny * bg.nz;
+    }
     return 0;
 }
 
@@ -472,7 +522,8 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
 int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *source,
                                        const float *target, const float *img,
                                        const float *grad_out, int B, int det_h, int det_w,
-                                       float voxel_shift, float eps, float *g_volume, void *) {
+                                       float voxel_shift, float eps, float *g_volume, void *,
+                                       void *) {
     const Dims D{dx, dy, dz};
     const int N = det_h * det_w;
     const BrickGrid bg = brick_grid(D);
@@ -520,7 +571,7 @@ int ddrr_trilinear_forward_bricks(const float *volume, int dx, int dy, int dz,
                                   const float *source, const float *target, const float *img,
                                   int B, int det_h, int det_w, float voxel_shift, float eps,
                                   int n_points, const float *alphamin, const float *alphamax,
-                                  float *out, float *aux, void *) {
+                                  float *out, float *aux, void *, void *) {
     const size_t R = (size_t)B * det_h * det_w;
     memset(out, 0, sizeof(float) * R);
     if (aux) memset(aux, 0, sizeof(float) * R * DDRR_TRI_AUX_PLANES);
@@ -533,7 +584,7 @@ int ddrr_trilinear_forward_channels_bricks(const float *volume, const unsigned c
                                            const float *target, const float *img, int B,
                                            int det_h, int det_w, int C, float voxel_shift,
                                            float eps, int n_points, const float *alphamin,
-                                           const float *alphamax, float *out, void *) {
+                                           const float *alphamax, float *out, void *, void *) {
     memset(out, 0, sizeof(float) * (size_t)B * C * det_h * det_w);
     return tri_bricks_host(volume, dx, dy, dz, source, target, img, B, det_h, det_w, voxel_shift,
                            eps, n_points, *alphamin, *alphamax, out, nullptr, labels, C);
@@ -571,7 +622,7 @@ int ddrr_trilinear_backward_volume_bricks(int dx, int dy, int dz, const float *s
                                           const float *grad_out, int B, int det_h, int det_w,
                                           float voxel_shift, float eps, int n_points,
                                           const float *alphamin, const float *alphamax,
-                                          float *g_volume, void *) {
+                                          float *g_volume, void *, void *) {
     // poison: every voxel must be stored by exactly one owner brick
     for (size_t i = 0; i < (size_t)dx * dy * dz; ++i) g_volume[i] = NAN;
     return tri_owner_host(dx, dy, dz, source, target, img, grad_out, B, det_h, det_w, voxel_shift,
@@ -649,7 +700,8 @@ int ddrr_siddon_forward_channels(const float *volume, const unsigned char *label
 int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char *labels, int dx,
                                         int dy, int dz, const float *source, const float *target,
                                         const float *img, int B, int det_h, int det_w, int C,
-                                        float voxel_shift, float eps, float *out, void *) {
+                                        float voxel_shift, float eps, float *out, void *,
+                                        void *) {
     const Dims D{dx, dy, dz};
     const int N = det_h * det_w;
     memset(out, 0, sizeof(float) * (size_t)B * C * N);

@@ -131,12 +131,15 @@ def test_argument_checks_return_errors_without_touching_a_device():
                                     0, 0, 1, 64, P, None) != 0
     assert b"n_points" in c.ddrr_last_error()
     assert c.ddrr_siddon_forward_bricks(P, 4, 4, 4, P, P, P, 1, 1, 5, f(0.5), f(1e-8), P, None,
-                                        f(0.0), 0, None, 0, None) != 0
+                                        f(0.0), 0, None, 0, P, None) != 0
     assert b"2x2" in c.ddrr_last_error()
     # 16-bit bricks need their range workspace
     assert c.ddrr_siddon_forward_bricks(P, 4, 4, 4, P, P, P, 1, 4, 5, f(0.5), f(1e-8), P, None,
-                                        f(0.0), 1, None, 0, None) != 0
+                                        f(0.0), 1, None, 0, P, None) != 0
     assert b"brick_ranges" in c.ddrr_last_error()
+    # every *_bricks entry takes its per-launch state from the caller (no device-side globals)
+    assert c.ddrr_brick_launch_workspace_bytes(512, 512, 512) == 256 + 4096 * 8
+    assert c.ddrr_brick_launch_workspace_bytes(0, 4, 4) == 0
     # an empty batch is a valid no-op
     assert c.ddrr_siddon_forward(P, 4, 4, 4, P, 1, P, P, 0, 5, f(0.5), f(1e-8), 0, 0, 0, 0, 0, 1, 64,
                                  P, None, None, None) == 0

@@ -144,12 +144,12 @@ def test_siddon_channels_on_bricks(emu_lib):
     C = int(labels.max()) + 1
     out = np.full((B, C, N), np.nan, np.float32)
     emu_lib.call("ddrr_siddon_forward_channels_bricks", P(vol), P(labels), *vol.shape, P(src),
-                 P(tgt), P(img), B, 4, N // 4, C, 0.5, 1e-8, P(out), None)
+                 P(tgt), P(img), B, 4, N // 4, C, 0.5, 1e-8, P(out), None, None)
     assert rel_err(out, g["out_f32"]) < FWD_TOL
     # fewer channels than labels: the others are dropped (the per-ray kernel does the same)
     out3 = np.full((B, 3, N), np.nan, np.float32)
     emu_lib.call("ddrr_siddon_forward_channels_bricks", P(vol), P(labels), *vol.shape, P(src),
-                 P(tgt), P(img), B, 4, N // 4, 3, 0.5, 1e-8, P(out3), None)
+                 P(tgt), P(img), B, 4, N // 4, 3, 0.5, 1e-8, P(out3), None, None)
     assert np.array_equal(out3, out[:, :3])
 
 

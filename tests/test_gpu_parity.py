@@ -673,7 +673,8 @@ def test_q16_bricks_small_ragged_sparse_and_many_poses(gpu, q16):
     of the brick grid: partial bricks on every axis, a volume smaller than one brick, empty (all
     zero) bricks next to full ones, a z extent that is not a multiple of 4 (the general fp32
     kernel takes over), more poses than a pose-table chunk; against the oracle, forward and the
-    record's ray gradients; and a NaN voxel poisons the rays through its brick only."""
+    record's ray gradients; and a NaN voxel sends its brick to the fp32 path: only rays through
+    the voxel itself are NaN, as with the volume's own values."""
     cases = (((40, 72, 36), (24, 31), 4), ((32, 32, 64), (16, 16), 4), ((5, 9, 64), (8, 8), 4),
              ((40, 70, 33), (24, 31), 4), ((70, 40, 132), (20, 28), 75))
     for dims, (H, W), B in cases:
@@ -702,7 +703,7 @@ def test_q16_bricks_small_ragged_sparse_and_many_poses(gpu, q16):
         assert rel_err(gq[2].cpu().numpy(), gf[2].cpu().numpy()) < 2e-5, dims      # d / d img
         for a, b in zip(gq[:2], gf[:2]):                                             # per-pose sums
             assert rel_err(a.double().sum(1).cpu().numpy(), b.double().sum(1).cpu().numpy()) < 5e-3, dims
-    # a NaN voxel: every ray through its brick is NaN (documented), the others are untouched
+    # a NaN voxel: the rays through it are NaN, the others are untouched
     vol = torch.rand(64, 64, 128, generator=torch.Generator().manual_seed(2))
     drr = DRR(make_subject(vol, spacing=(1.0, 1.0, 1.0)), sdd=400.0, height=32, delx=3.0).to(gpu)
     rot = torch.tensor([[0.1, 0.2, -0.1]], device=gpu)

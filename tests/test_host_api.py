@@ -934,17 +934,26 @@ def test_brick_workspace_follows_the_volume(emulated_ops):
 
     vol = torch.rand(64, 64, 128)
     buf, valid = ops.brick_workspace(vol, "q16p")
-    assert valid == 0 and ops.brick_workspace(vol, "q16p")[1] == 1
+    # handing the buffer out does not make it valid: only the launch that filled it does
+    assert valid == 0 and ops.brick_workspace(vol, "q16p")[1] == 0
+    ops.brick_workspace_commit(vol, "q16p")
+    assert ops.brick_workspace(vol, "q16p")[1] == 1
     vol[0, 0, 0] = 2.0
     buf2, valid2 = ops.brick_workspace(vol, "q16p")
     assert valid2 == 0 and buf2.data_ptr() == buf.data_ptr()
+    ops.brick_workspace_commit(vol, "q16p")
     assert ops.workspace_churn(vol, "q16p") == 1 and ops.workspace_churn(vol, "q16") == 0
     cfg = {"storage": "q16p"}
     assert _brick_storage(vol, cfg) == "q16p"
     for _ in range(2):
         vol[0, 0, 0] += 1.0
         ops.brick_workspace(vol, "q16p")
+        ops.brick_workspace_commit(vol, "q16p")
     assert _brick_storage(vol, cfg) == "f32"
+    # a volume the configurable kernel cannot stage (or a temporary made contiguous per call)
+    # never gets a workspace
+    assert _brick_storage(torch.rand(64, 64, 130)[:, :, :128], cfg) == "f32"
+    assert _brick_storage(torch.rand(64, 64, 126), cfg) == "f32"
     assert _brick_storage(torch.rand(64, 64, 128, requires_grad=True), cfg) == "f32"
 
 
