@@ -202,7 +202,16 @@ __device__ __forceinline__ void fwd_item(const BrickArgs &p, unsigned lds_base,
         int steps = 0;
         float ex[2] = {0.f, 0.f};
         if (E.hit) {
-            if (q16) {
+            if (!AUX) {
+                // forward only: the accumulating walk (brick_step.h step_walk_fwd)
+                float a_end;
+                if (q16) {
+                    steps = step_walk_fwd<C::MAXSTEPS>(LdsAbsFetch16{}, SG, E, v[0], a_end);
+                    v[0] = q16_finish_fwd(range, E, v[0], a_end);
+                } else {
+                    steps = step_walk_fwd<C::MAXSTEPS>(LdsAbsFetch{}, SG, E, v[0], a_end);
+                }
+            } else if (q16) {
                 steps = step_walk<AUX, C::MAXSTEPS>(LdsAbsFetch16{}, SG, E, v[0], v + 1, ex);
                 q16_finish<AUX>(range, E, ex, v[0], v + 1);
             } else {

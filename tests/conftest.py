@@ -463,9 +463,11 @@ def check_brick_storage_guard(ops, device, name, storage, bdims):
     out0, _ = ops.siddon_forward_bricks(V, s, t, L, (40, 40), storage=storage)
     assert ops.brick_fallbacks(V, storage) == (int(flags.sum()), flags.size)
     ref32, aux32 = ops.siddon_forward_bricks(V, s, t, L, (40, 40), storage="f32", want_aux=True)
-    f32 = ref32.cpu().numpy().astype(np.float64)
-    for img in (out, out0):
-        img = img.cpu().numpy().astype(np.float64)
+    ref32_0, _ = ops.siddon_forward_bricks(V, s, t, L, (40, 40), storage="f32")
+    # (like against like: the forward-only launches walk with accumulated alphas, the launches
+    # with a record with the plane counters -- the same for both storages)
+    for img, f32 in ((out, ref32), (out0, ref32_0)):
+        img, f32 = (x.cpu().numpy().astype(np.float64) for x in (img, f32))
         err = np.abs(img - ref)
         assert err.max() <= 1e-4 * np.abs(ref).max(), (name, err.max() / np.abs(ref).max())
         errq = np.abs(img - f32)

@@ -284,7 +284,11 @@ def test_generic_and_brick_walks_vs_oracle(emulated_ops, D, H, W, delx):
     # volume-stationary brick kernel: per-brick pieces of every ray, added up
     outb, auxb = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True)
     outb0, none = ops.siddon_forward_bricks(V, s, t, L, (H, W))
-    assert none is None and rel_err(outb0.numpy(), outb.numpy()) < 1e-6
+    # (forward only walks with accumulated chord-relative alphas, brick_step.h step_walk_fwd; with
+    # the record every alpha is the reference's quotient: two fp32 evaluations of one integral)
+    assert none is None and rel_err(outb0.numpy(), outb.numpy()) < 1e-5
+    for b, (name, _, _) in enumerate(SLAB_POSES):
+        assert rel_err(outb0[b].numpy(), ref[b]) < 5e-5, name
     for b, (name, _, _) in enumerate(SLAB_POSES):
         assert rel_err(gen[b].numpy(), ref[b]) < 5e-5, name
         assert rel_err(outb[b].numpy(), ref[b]) < 5e-5, name
@@ -303,7 +307,9 @@ def test_generic_and_brick_walks_vs_oracle(emulated_ops, D, H, W, delx):
     # as denormal floats, alphas scaled by 2^64; |V - (vmin + q step)| <= range / 131070 per voxel
     outq, auxq = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True, storage="q16")
     outq0, _ = ops.siddon_forward_bricks(V, s, t, L, (H, W), storage="q16")
-    assert rel_err(outq0.numpy(), outq.numpy()) < 1e-6
+    assert rel_err(outq0.numpy(), outq.numpy()) < 1e-5
+    for b, (name, _, _) in enumerate(SLAB_POSES):
+        assert rel_err(outq0[b].numpy(), ref[b]) < 5e-5, name
     gsq, gtq, giq = ops.siddon_backward_rays(auxq, go, s, t, L)
     for b, (name, _, _) in enumerate(SLAB_POSES):
         assert rel_err(outq[b].numpy(), ref[b]) < 5e-5, name

@@ -106,6 +106,7 @@ def test_launches_on_two_streams_and_in_a_graph_share_no_state(gpu):
     torch.cuda.synchronize()
     for kind, r in results:
         want = serial[kind]
-        # (atomics: sums in a different order; the volume gradient is bit-reproducible)
-        tol = 0.0 if kind == 2 else 2e-6 * float(want.abs().max())
+        # (atomics: sums in a different order; the volume gradient's fixed-point scale comes from a
+        # float sum that is itself order-dependent)
+        tol = 2e-6 * float(want.abs().max())
         assert float((r - want).abs().max()) <= tol, kind
