@@ -488,41 +488,53 @@ DDRR_HD float pack_voxel_label(float v, unsigned lab) {
     return bits_as_float((r & 0xffffff00u) | (lab & 0xffu));
 }
 
-// The walk of step_walk<false> over packed words: the integral of a run of voxels with one
-// label is summed in a register and handed to `flush(label, sum)` when the label changes and
-// at the end.  (A lane that is done idles on its last voxel: same label, zero length.)
+// Siddon channels: a label the caller has no channel for (>= n_channels) is staged as the value
+// 0 under label 0 -- its segments add nothing, and the flush needs no range check.  (Not for the
+// marcher: there a voxel's value also feeds its neighbours' interpolation.)
+DDRR_HD float pack_voxel_label_below(float v, unsigned lab, unsigned n_channels) {
+    lab &= 0xffu;
+    return lab < n_channels ? pack_voxel_label(v, lab) : 0.f;
+}
+
+// The walk of step_walk_fwd over packed words: the integral of a run of voxels with one label is
+// summed in a register and handed to `flush(label, sum)` when the label changes and at the end.
+// (A lane that is done idles on its last voxel: same label, zero length.)  `scale` multiplies
+// every segment length -- the ray's length L, folded into the chord-relative alphas at the entry
+// (the selects only compare alphas; the lengths are their differences), so that a flush is the
+// address and the atomic alone.  16 + 3 vector instructions per step; the flush -- a divergent
+// block whenever ANY lane of the wave changes label -- adds 4.
 template <class Fetch, class Flush>
 DDRR_HD void step_walk_channels(const Fetch &fetch, const StepGeom &G, const StepEntry &E,
-                                const Flush &flush) {
-    float kr0 = 0.f, kr1 = 0.f, kr2 = 0.f;
-    float an0 = E.an[0], an1 = E.an[1], an2 = E.an[2];
-    const float inv0 = E.inv[0], inv1 = E.inv[1], inv2 = E.inv[2];
-    const float af0 = E.a0[0], af1 = E.a0[1], af2 = E.a0[2];
-    const float dir0 = E.dirf[0], dir1 = E.dirf[1], dir2 = E.dirf[2];
-    const float sb0 = in_vgpr(G.strideb[0]), sb1 = in_vgpr(G.strideb[1]);
-    const float sb2 = in_vgpr(G.strideb[2]);
+                                const Flush &flush, float scale = 1.f) {
+    const float st0 = E.inv[0] * E.dirf[0] * scale, st1 = E.inv[1] * E.dirf[1] * scale;
+    const float st2 = E.inv[2] * E.dirf[2] * scale;
+    float an0 = (E.an[0] - E.entry) * scale, an1 = (E.an[1] - E.entry) * scale;
+    float an2 = (E.an[2] - E.entry) * scale;
+    const float exit = fminf(fminf(fmaf(E.nx[0], st0, an0), fmaf(E.nx[1], st1, an1)),
+                             fmaf(E.nx[2], st2, an2));
+    const float sb0 = in_vgpr(G.strideb[0]) * E.dirf[0], sb1 = in_vgpr(G.strideb[1]) * E.dirf[1];
+    const float sb2 = in_vgpr(G.strideb[2]) * E.dirf[2];
     const float nbig = in_vgpr(-kSelBig);
-    const float offc = E.offc;
-    const float nlbig = in_vgpr(-E.lbig), exit_big = E.exit * E.lbig;
-    float a_cur = E.entry, run = 0.f, live = 1.f;
-    float Vc = fetch(float_bits(fmaf(kr0, sb0, fmaf(kr1, sb1, fmaf(kr2, sb2, offc)))));
+    const unsigned field = 379u - ((float_bits(exit) >> 23) & 0xffu);
+    const float lbig = bits_as_float((field < 254u ? field : 254u) << 23);
+    const float thr = fmaf(-exit, 0x1p-17f, exit);
+    const float nlbig = in_vgpr(-lbig), thr_big = thr * lbig;
+    float addr = E.offc, a_cur = 0.f, run = 0.f, live = 1.f;
+    float Vc = fetch(float_bits(addr));
     unsigned cur = float_bits(Vc) & 0xffu;
 #define DDRR_STEP()                                                                       \
     {                                                                                     \
         const float a_next = fminf(fminf(an0, an1), an2);                                 \
         const float len = a_next - a_cur;                                                 \
-        live = sel_zero(a_next, nlbig, exit_big);                                         \
+        live = sel_zero(a_next, nlbig, thr_big);                                          \
         const float t0 = sel_zero(an0 - a_next, nbig, live);                              \
         const float t1 = sel_zero(an1 - a_next, nbig, live);                              \
         const float t2 = sel_zero(an2 - a_next, nbig, live);                              \
-        kr0 = fmaf(t0, dir0, kr0);                                                        \
-        kr1 = fmaf(t1, dir1, kr1);                                                        \
-        kr2 = fmaf(t2, dir2, kr2);                                                        \
-        const float Vn =                                                                  \
-            fetch(float_bits(fmaf(kr0, sb0, fmaf(kr1, sb1, fmaf(kr2, sb2, offc)))));      \
-        an0 = fmaf(kr0, inv0, af0);                                                       \
-        an1 = fmaf(kr1, inv1, af1);                                                       \
-        an2 = fmaf(kr2, inv2, af2);                                                       \
+        addr = fmaf(t0, sb0, fmaf(t1, sb1, fmaf(t2, sb2, addr)));                         \
+        const float Vn = fetch(float_bits(addr));                                         \
+        an0 = fmaf(t0, st0, an0);                                                         \
+        an1 = fmaf(t1, st1, an1);                                                         \
+        an2 = fmaf(t2, st2, an2);                                                         \
         const unsigned w = float_bits(Vc), lab = w & 0xffu;                               \
         if (lab != cur) {                                                                 \
             flush(cur, run);                                                              \

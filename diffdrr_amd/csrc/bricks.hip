@@ -76,18 +76,28 @@ struct LdsAbsAdd {
 
 // A finished label run of a ray's walk through a brick goes to the ray's output column
 // (B, C, N): one fire-and-forget atomic per run.  32-bit offsets: the host checks B C N < 2^30.
+// SCALED: L multiplies every run (else the walk carries it); CHECKED: labels >= C are dropped here
+// (else the staging has already removed them: pack_voxel_label_below).
+template <bool SCALED = true, bool CHECKED = true>
 struct BrickColumnFlush {
     float *out;
     unsigned colb;  // byte offset of (b, 0, pixel): 4 (b C N + pixel)
     unsigned N4, C;  // byte stride between channels
-    float L;
+    float L;         // SCALED: factor of every run (else the walk carries it, step_walk_channels)
     __device__ __forceinline__ void operator()(unsigned lab, float run) const {
-        // (a 32-bit byte offset from the wave-uniform base: one multiply-add and the atomic's
-        // scalar-base addressing instead of 64-bit index arithmetic per flush)
-        if (lab < C)
-            unsafeAtomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(out) +
-                                                      (colb + __umul24(lab, N4))),
-                            L * run);
+        // (a 32-bit byte offset from the wave-uniform base: ONE 24-bit multiply-add -- left to the
+        // compiler this becomes a 64-bit v_mad_u64_u32 with a scalar operand -- and the atomic's
+        // scalar-base addressing)
+        if (!CHECKED || lab < C) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            unsigned off, n4 = N4;
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(off) : "v"(lab), "v"(n4), "v"(colb));
+#else
+            const unsigned off = colb + lab * N4;
+#endif
+            unsafeAtomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(out) + off),
+                            SCALED ? L * run : run);
+        }
     }
 };
 #endif
@@ -183,7 +193,7 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
         const unsigned N = (unsigned)(p.det_h * p.det_w), C = (unsigned)p.n_channels;
         const float step = (a1 - a0) / (float)(p.n_points - 1);  // renderers.py:235
         tri_brick_march_channels(LdsAbsFetch{}, base, T, p.D, s, t, p.shift, p.eps, p.n_points, a0, a1,
-                                 BrickColumnFlush{out, (b * C * N + pix) * 4u, N * 4u, C, L * step});
+                                 BrickColumnFlush<true>{out, (b * C * N + pix) * 4u, N * 4u, C, L * step});
         return;
     }
     if (MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_FWD_AUX) {
@@ -215,15 +225,17 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
     DDRR_PROF(PROF_SETUP);
     if (MODE == BRICK_CHANNELS) {
         const unsigned N = (unsigned)(p.det_h * p.det_w), C = (unsigned)p.n_channels;
+        unsigned n4 = N * 4u;
+        asm volatile("" : "+v"(n4));  // (in a vector register before the loop, not moved there per flush)
         if (E.hit)
             step_walk_channels(LdsAbsFetch{}, SG, E,
-                               BrickColumnFlush{out, (b * C * N + pix) * 4u, N * 4u, C, L});
+                               BrickColumnFlush<false, false>{out, (b * C * N + pix) * 4u, n4, C, 1.f}, L);
         DDRR_PROF(PROF_WALK);
         return;
     }
-    float I = 0.f, rec[4] = {0.f, 0.f, 0.f, 0.f};
+    float I = 0.f, a_end;
     int steps = 0;
-    if (E.hit) steps = step_walk<false>(LdsAbsFetch{}, SG, E, I, rec);
+    if (E.hit) steps = step_walk_fwd(LdsAbsFetch{}, SG, E, I, a_end);  // forward only
     DDRR_PROF(PROF_WALK);
     DDRR_PROF_COUNT(PROF_N_STEPS, (unsigned long long)__builtin_amdgcn_readfirstlane(steps));
     (void)steps;
@@ -259,6 +271,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     const bool vec_ok = (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.vol) & 15) == 0 &&
                         (MODE != BRICK_CHANNELS || (reinterpret_cast<uintptr_t>(p.labels) & 3) == 0);
     const bool vec_out = GRAD && (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.g_volume) & 15) == 0;
+    const bool labels_dword_ok = (MODE == BRICK_CHANNELS || MODE == BRICK_TRI_CHANNELS) &&
+                                 (reinterpret_cast<uintptr_t>(p.labels) & 3) == 0;
     // fixed-point scale of the LDS accumulator (volume-gradient modes): the largest sum a
     // voxel can receive is n_sum (contributions) * wmax (each) -- volgrad_prepare_kernel
     float fixq = 0.f;
@@ -322,6 +336,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     int qn0 = 0, qn1 = 0, qn2 = 0;  // hits waiting per length class (wave-uniform)
     bool brick_empty = false;        // every staged voxel is zero (set with the first chunk)
     // the float backward records: length classes per group of 8 lanes = 8 adjacent pixels (below)
+    // (the channel render gains nothing from it: runs of 8 adjacent pixels, whose label changes
+    // coincide, measured 0.314 vs 0.302 ms at 8 poses -- profiles/r04/channels.txt)
     const bool GROUPED = ((AUX && p.rec_q == 0.f) || MODE == BRICK_TRI_FWD_AUX) && !(p.dbg & 8);
 
     for (int ch = 0; ch < n_chunks; ++ch) {
@@ -341,6 +357,11 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         const int q4 = (tid_here & 7) * 4, z = box.lo[2] + q4;
         float *const d0 = brick + q4;
         constexpr bool LABELS = MODE == BRICK_CHANNELS || MODE == BRICK_TRI_CHANNELS;
+        // (Siddon channels: labels without a channel are staged as value 0 | label 0)
+        auto pack_word = [&](float v, unsigned lab) {
+            return MODE == BRICK_CHANNELS ? pack_voxel_label_below(v, lab, (unsigned)p.n_channels)
+                                          : pack_voxel_label(v, lab);
+        };
         const bool stage_vec = ch == 0 && !GRAD && !TRI && vec_ok;
         // z and D.z are multiples of 4: a quad is wholly inside or wholly outside
         const bool in_z = z + 4 <= box.hi[2];
@@ -382,10 +403,10 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                     const bool in = in_z && box.lo[0] + lx < box.hi[0] && box.lo[1] + ly < box.hi[1];
                     float *d = d0 + lx * p.lay.sx + ly * p.lay.sy;
                     if (LABELS) {
-                        q[i].x = pack_voxel_label(q[i].x, ql[i]);
-                        q[i].y = pack_voxel_label(q[i].y, ql[i] >> 8);
-                        q[i].z = pack_voxel_label(q[i].z, ql[i] >> 16);
-                        q[i].w = pack_voxel_label(q[i].w, ql[i] >> 24);
+                        q[i].x = pack_word(q[i].x, ql[i]);
+                        q[i].y = pack_word(q[i].y, ql[i] >> 8);
+                        q[i].z = pack_word(q[i].z, ql[i] >> 16);
+                        q[i].w = pack_word(q[i].w, ql[i] >> 24);
                     }
                     d[0] = in ? q[i].x : 0.f;
                     d[1] = in ? q[i].y : 0.f;
@@ -398,35 +419,80 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
             }
         } else if (ch == 0) {
             // general path (halo bricks of the trilinear marcher, unaligned volumes, and the
-            // zero fill of the gradient accumulator), two quads in flight
+            // zero fill of the gradient accumulator), kFly quads in flight.  Every load is issued
+            // unconditionally from a clamped (always readable) address and what lies outside is
+            // zeroed afterwards: loads under per-lane conditions end up in separate round trips
+            // (measured with the labels: staging 4x the plain brick's).  The quad's four labels
+            // come as two aligned dwords + a byte alignment -- a z extent like the example CT's
+            // 133 leaves the rows at every alignment -- or, at the array's last bytes and for an
+            // unaligned label pointer, as four byte loads.
+            constexpr int kFly = LABELS ? 2 : 4;  // quads in flight per thread
+            const long total4 = ((long)p.D.x * p.D.y * p.D.z) & ~3L;
 #pragma unroll 1
-            for (int h = 0; h < kQuads; h += 2) {
-                float v[2][4];
+            for (int h = 0; h < kQuads; h += kFly) {
+                float v[kFly][4];
+                unsigned lw[LABELS ? kFly : 1][2], lb[LABELS ? kFly : 1][4];
+                bool in_xy[kFly], wide[kFly];
+                int sh[kFly];
 #pragma unroll
-                for (int it = 0; it < 2; ++it) {
+                for (int it = 0; it < kFly; ++it) {
                     const int row = (tid >> 3) + (h + it) * (kBrickThreads >> 3);
                     const int lx = row / BRICK, ly = row - lx * BRICK;
                     const int x = box.lo[0] + lx, y = box.lo[1] + ly;
-                    const bool in_xy = !GRAD && x >= 0 && y >= 0 && x < box.hi[0] && y < box.hi[1];
+                    in_xy[it] = !GRAD && x >= 0 && y >= 0 && x < box.hi[0] && y < box.hi[1];
                     const int xc = clampi(x, 0, p.D.x - 1), yc = clampi(y, 0, p.D.y - 1);
-                    const float *g = p.vol + ((long)xc * p.D.y + yc) * p.D.z;
+                    const long rowbase = ((long)xc * p.D.y + yc) * p.D.z;
+                    const float *g = p.vol + rowbase;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const bool in = in_xy && z + k >= 0 && z + k < box.hi[2];
-                        v[it][k] = in ? g[z + k] : 0.f;
-                        if (LABELS && in)
-                            v[it][k] = pack_voxel_label(v[it][k], (p.labels + (g - p.vol))[z + k]);
+                    for (int k = 0; k < 4; ++k) v[it][k] = GRAD ? 0.f : g[clampi(z + k, 0, p.D.z - 1)];
+                    if (LABELS) {
+                        const long a = rowbase + (z > 0 ? z : 0), a4 = a & ~3L;
+                        wide[it] = labels_dword_ok && z >= 0 && a4 + 8 <= total4;
+                        sh[it] = (int)(a - a4);
+                        const unsigned *w2 = reinterpret_cast<const unsigned *>(
+                            p.labels + (wide[it] ? a4 : 0L));
+                        if (labels_dword_ok && total4 >= 8) {
+                            lw[it][0] = w2[0];
+                            lw[it][1] = w2[1];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) lb[it][k] = 0u;
+                    }
+                }
+                if (LABELS) {
+                    // (rare: the last bytes of the array, the marcher's halo at z = -1)
+                    bool bytes = false;
+#pragma unroll
+                    for (int it = 0; it < kFly; ++it) bytes = bytes || (in_xy[it] && !wide[it]);
+                    if (__ballot(bytes)) {
+#pragma unroll
+                        for (int it = 0; it < kFly; ++it) {
+                            const int row = (tid >> 3) + (h + it) * (kBrickThreads >> 3);
+                            const int lx = row / BRICK, ly = row - lx * BRICK;
+                            const int xc = clampi(box.lo[0] + lx, 0, p.D.x - 1);
+                            const int yc = clampi(box.lo[1] + ly, 0, p.D.y - 1);
+                            const unsigned char *lr = p.labels + ((long)xc * p.D.y + yc) * p.D.z;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) lb[it][k] = lr[clampi(z + k, 0, p.D.z - 1)];
+                        }
                     }
                 }
 #pragma unroll
-                for (int it = 0; it < 2; ++it) {
+                for (int it = 0; it < kFly; ++it) {
                     const int row = (tid >> 3) + (h + it) * (kBrickThreads >> 3);
                     const int lx = row / BRICK, ly = row - lx * BRICK;
                     float *d = d0 + lx * p.lay.sx + ly * p.lay.sy;
+                    unsigned lab4 = 0u;
+                    if (LABELS)
+                        lab4 = wide[it] ? __builtin_amdgcn_alignbyte(lw[it][1], lw[it][0], (unsigned)sh[it])
+                                        : (lb[it][0] | (lb[it][1] << 8) | (lb[it][2] << 16) | (lb[it][3] << 24));
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        d[k] = v[it][k];
-                        nz |= __float_as_uint(v[it][k]);
+                        const bool in = in_xy[it] && z + k >= 0 && z + k < box.hi[2];
+                        float val = in ? v[it][k] : 0.f;
+                        if (LABELS && in) val = pack_word(val, lab4 >> (8 * k));
+                        d[k] = val;
+                        nz |= __float_as_uint(val);
                     }
                 }
             }

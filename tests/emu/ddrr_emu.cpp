@@ -717,7 +717,7 @@ int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char
                 for (int z = box.lo[2]; z < box.hi[2]; ++z) {
                     const long at = ((long)x * dy + y) * dz + z;
                     brick[(x - box.lo[0]) * lay.sx + (y - box.lo[1]) * lay.sy + (z - box.lo[2])] =
-                        pack_voxel_label(volume[at], labels[at]);
+                        pack_voxel_label_below(volume[at], labels[at], (unsigned)C);
                 }
         for (int b = 0; b < B; ++b)
             for (int pix = 0; pix < N; ++pix) {
@@ -732,8 +732,8 @@ int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char
                 const float L = img ? img[r] : 1.f;
                 float *col = out + (long)b * C * N + pix;
                 step_walk_channels(LdsFetch{brick.data()}, SG, E, [&](unsigned lab, float run) {
-                    if (lab < (unsigned)C) col[(long)lab * N] += L * run;
-                });
+                    col[(long)lab * N] += run;  // (labels >= C were staged as value 0 | label 0)
+                }, L);
             }
     }
     return 0;

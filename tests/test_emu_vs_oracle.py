@@ -150,7 +150,9 @@ def test_siddon_channels_on_bricks(emu_lib):
     out3 = np.full((B, 3, N), np.nan, np.float32)
     emu_lib.call("ddrr_siddon_forward_channels_bricks", P(vol), P(labels), *vol.shape, P(src),
                  P(tgt), P(img), B, 4, N // 4, 3, 0.5, 1e-8, P(out3), None, None)
-    assert np.array_equal(out3, out[:, :3])
+    # (labels without a channel are staged as value 0 under label 0: channel 0's runs are cut
+    # differently, i.e. summed in a different order)
+    assert rel_err(out3, out[:, :3]) < 1e-6
 
 
 @pytest.mark.parametrize("kind", ["noise", "phantom"])

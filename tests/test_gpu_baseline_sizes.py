@@ -370,7 +370,9 @@ def test_headline_size_properties_that_need_no_oracle(gpu, storage):
     out, aux = ops.siddon_forward_bricks(V, s[:4], t[:4], L[:4], det, want_aux=True, storage=storage)
     gi = ops.siddon_backward_rays(aux, torch.ones_like(L[:4]), s[:4], t[:4], L[:4])[2]
     assert float((gi * L[:4] - out).abs().max()) < 3e-6 * scale
-    assert float((out - full[:4]).abs().max()) < 3e-6 * scale
+    # (with the record every alpha is the reference's quotient, forward only they are accumulated
+    # chord-relative: two fp32 evaluations of the same integrals)
+    assert float((out - full[:4]).abs().max()) < 1e-5 * scale
 
 
 def test_channel_renders_sum_to_the_plain_render_at_the_published_size(gpu):

@@ -619,7 +619,9 @@ def test_brick_kernel_equals_generic_walk(gpu, big):
     # Accuracy proper is checked against the fp64 oracle in test_gpu_baseline_sizes.py.)
     assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 2e-5
     again, aux = ops.siddon_forward_bricks(V, s, t, L, (256, 256), want_aux=True)
-    assert rel_err(again.cpu().numpy(), out.cpu().numpy()) < 2e-6  # atomics: not bit-stable
+    # (the forward-only launch accumulates chord-relative alphas, the launch with the record
+    # keeps the plane counters: two fp32 evaluations, brick_step.h step_walk_fwd)
+    assert rel_err(again.cpu().numpy(), out.cpu().numpy()) < 1e-5
     # blocked backward record (csrc/record_layout.h): same I, and the same ray gradients as the
     # generic record except on the ~1 % of rays holding a crossing pair that ties in fp32
     assert aux.shape == (4 * 256 * 256 // 16, 80)
@@ -693,7 +695,9 @@ def test_q16_bricks_small_ragged_sparse_and_many_poses(gpu, q16):
                           grad_out=go.cpu().numpy())
         out, aux = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True, storage=q16)
         plain, _ = ops.siddon_forward_bricks(V, s, t, L, (H, W), storage=q16)
-        assert ops.brick_workspace(V, q16)[1] == 1  # (cached: the second call reused the workspace)
+        # (cached: the second call reused the workspace the first one built -- where the 16-bit
+        # storages apply at all: a z extent that is not a multiple of 4 renders on fp32 bricks)
+        assert ops.brick_workspace(V, q16)[1] == int(ops.brick_storage_applies(V))
         exact, aux_f = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True, storage="f32")
         for img in (out, plain):
             assert rel_err(img.cpu().numpy(), o["out"].reshape(B, -1)) < FWD_TOL, dims
@@ -711,14 +715,21 @@ def test_q16_bricks_small_ragged_sparse_and_many_poses(gpu, q16):
     s, t, L = voxel_rays(drr, rot, xyz)
     clean, _ = ops.siddon_forward_bricks(drr.density, s, t, L, (32, 32), storage=q16)
     bad = drr.density.clone()
-    bad[40, 40, 100] = float("nan")
+    # (a voxel the central pixel's ray crosses: the middle of its samples inside the volume)
+    n_c = 16 * 32 + 16
+    al = torch.linspace(0, 1, 4001, device=gpu)[:, None]
+    pts = s[0, 0] + al * (t[0, n_c] - s[0, 0])
+    ins = ((pts > -0.5) & (pts < torch.tensor(bad.shape, device=gpu) - 0.5)).all(-1)
+    vx = (pts[ins][int(ins.sum()) // 2] + 0.5).floor().long().tolist()
+    bad[vx[0], vx[1], vx[2]] = float("nan")
     dirty, _ = ops.siddon_forward_bricks(bad, s, t, L, (32, 32), storage=q16)
+    same, _ = ops.siddon_forward_bricks(bad, s, t, L, (32, 32), storage="f32")
     # an in-place edit of a rendered volume is seen (the version counter invalidates the workspace)
-    bad[40, 40, 100] = 0.5
+    bad[vx[0], vx[1], vx[2]] = 0.5
     fixed, _ = ops.siddon_forward_bricks(bad, s, t, L, (32, 32), storage=q16)
     assert not torch.isnan(fixed).any()
     nan = torch.isnan(dirty)
-    assert nan.any() and not nan.all()
+    assert nan[0, n_c] and not nan.all() and torch.equal(nan, torch.isnan(same))
     assert torch.allclose(dirty[~nan], clean[~nan], rtol=1e-5, atol=1e-5)  # (atomics: not bit-stable)
 
 
