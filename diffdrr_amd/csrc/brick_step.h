@@ -558,6 +558,92 @@ DDRR_HD void step_walk_channels(const Fetch &fetch, const StepGeom &G, const Ste
     flush(cur, run);
 }
 
+// Backward of the channel render w.r.t. the ray (reference: autograd of renderers.py:77-89): the
+// brick-local record of step_walk<true> for the volume W(x) = V(x) g[label(x)], g = the incoming
+// gradient of the ray's own output column -- d/d source, d/d target and d/d img of sum_c g_c I_c
+// follow from it by the single-channel formulas (ddrr_siddon_backward_rays with grad_out = 1).
+// Packed words as in step_walk_channels (labels without a channel staged as value 0); the weight
+// of the current label is kept in a register and fetched by `weight(label)` -- a global gather --
+// when the label of the voxel entering the walk changes: a divergent block, and the one place
+// where the walk waits for memory (runs of 8 adjacent pixels change label together and read one
+// 32-byte run of g).  Plane counters and quotient alphas as in step_walk: the record's attribution
+// of crossings to axes rests on them.  rec = {S0x, S0z, S1x, S1z}.
+template <int MAXSTEPS = 3 * BRICK + 4, class Fetch, class Weight>
+DDRR_HD int step_walk_weighted(const Fetch &fetch, const StepGeom &G, const StepEntry &E,
+                               const Weight &weight, float &I, float rec[4]) {
+    float kr0 = 0.f, kr1 = 0.f, kr2 = 0.f;
+    float an0 = E.an[0], an1 = E.an[1], an2 = E.an[2];
+    const float inv0 = E.inv[0], inv1 = E.inv[1], inv2 = E.inv[2];
+    const float af0 = E.a0[0], af1 = E.a0[1], af2 = E.a0[2];
+    const float dir0 = E.dirf[0], dir1 = E.dirf[1], dir2 = E.dirf[2];
+    const float sb0 = in_vgpr(G.strideb[0]), sb1 = in_vgpr(G.strideb[1]);
+    const float sb2 = in_vgpr(G.strideb[2]);
+    const float nbig = in_vgpr(-kSelBig);
+    const float exit = E.exit, offc = E.offc;
+    const float nlbig = in_vgpr(-E.lbig), exit_big = exit * E.lbig;
+    float a_cur = E.entry, acc = 0.f;
+    unsigned Wn = float_bits(fetch(float_bits(fmaf(kr0, sb0, fmaf(kr1, sb1, fmaf(kr2, sb2, offc))))));
+    unsigned cur = 0xffffffffu;  // (no label yet: the first voxel fetches its weight)
+    float gcur = 0.f, Vc = 0.f, Vp = 0.f;
+    float tpx = E.ent[0], tpy = E.ent[1];
+    float S0x = 0.f, S0y = 0.f, S1x = 0.f, S1y = 0.f;
+    float live = 1.f;
+    int it = 0;
+    for (; it < MAXSTEPS; ++it) {
+        // the voxel whose segment this step closes: its weighted value
+        const unsigned lab = Wn & 0xffu;
+        if (lab != cur) {
+            gcur = weight(lab);
+            cur = lab;
+        }
+        Vc = bits_as_float(Wn & 0xffffff00u) * gcur;
+        const float a_next = fminf(fminf(an0, an1), an2);
+        const float len = a_next - a_cur;
+        live = sel_zero(a_next, nlbig, exit_big);
+        const float t0 = sel_zero(an0 - a_next, nbig, live);
+        const float t1 = sel_zero(an1 - a_next, nbig, live);
+        const float t2 = sel_zero(an2 - a_next, nbig, live);
+        kr0 = fmaf(t0, dir0, kr0);
+        kr1 = fmaf(t1, dir1, kr1);
+        kr2 = fmaf(t2, dir2, kr2);
+        Wn = float_bits(fetch(float_bits(fmaf(kr0, sb0, fmaf(kr1, sb1, fmaf(kr2, sb2, offc))))));
+        an0 = fmaf(kr0, inv0, af0);
+        an1 = fmaf(kr1, inv1, af1);
+        an2 = fmaf(kr2, inv2, af2);
+        acc = fmaf(Vc, len, acc);
+        const float dv = Vp - Vc, dva = dv * a_cur;
+        S0x = fmaf(dv, tpx, S0x);
+        S0y = fmaf(dv, tpy, S0y);
+        S1x = fmaf(dva, tpx, S1x);
+        S1y = fmaf(dva, tpy, S1y);
+        tpx = t0;
+        tpy = fmaf(-t0, t1, t1);  // exclusive: x before y
+        a_cur = a_next;
+        Vp = Vc;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if ((it & 1) && !__builtin_amdgcn_ballot_w64(live != 0.f)) break;
+#else
+        if (live == 0.f) break;
+#endif
+    }
+    I = acc;
+    // (a lane that is done idles on its last voxel with zero-length steps: Vp == Vc, nothing added)
+    // the exit crossing: last voxel | 0 at alpha = exit, on the axis whose face it is
+    const float ex = sel_zero(an0 - exit, nbig, 1.f);
+    const float ey0 = sel_zero(an1 - exit, nbig, 1.f);
+    const float ey = fmaf(-ex, ey0, ey0);
+    const float va = Vp * exit;
+    S0x = fmaf(Vp, ex, S0x);
+    S0y = fmaf(Vp, ey, S0y);
+    S1x = fmaf(va, ex, S1x);
+    S1y = fmaf(va, ey, S1y);
+    rec[0] = S0x;
+    rec[1] = -(S0x + S0y);       // sum_a S0_a = 0
+    rec[2] = S1x;
+    rec[3] = acc - (S1x + S1y);  // sum_a S1_a = I
+    return it + 1;
+}
+
 // Volume gradient of one ray through one brick: adds w * dalpha_k to the LDS cell of every
 // voxel the ray crosses (d out / d V[k] = L dalpha_k; reference: grid_sampler_3d_backward
 // behind renderers.py:159-164).  `add(bits, value)` is the scatter at byte address `bits`.

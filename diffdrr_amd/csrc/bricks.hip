@@ -100,6 +100,16 @@ struct BrickColumnFlush {
         }
     }
 };
+
+// The incoming gradient of the ray's own output column, by label (BRICK_CHANNELS_AUX): a gather
+// at a 32-bit byte offset from the wave-uniform base.
+struct BrickColumnWeight {
+    const float *g;
+    unsigned colb, N4;
+    __device__ __forceinline__ float operator()(unsigned lab) const {
+        return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(g) + (colb + __umul24(lab, N4)));
+    }
+};
 #endif
 
 // Phase B for one queue entry: load the real ray, clip, walk; add to the image (forward)
@@ -112,7 +122,7 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
                                            unsigned b, unsigned pix, float fixq,
                                            float *__restrict__ out, float *__restrict__ aux,
                                            BrickProf &prof) {
-    constexpr bool AUX = MODE == BRICK_FWD_AUX;
+    constexpr bool AUX = MODE == BRICK_FWD_AUX || MODE == BRICK_CHANNELS_AUX;
     const unsigned r = b * (unsigned)(p.det_h * p.det_w) + pix;
     if (AUX) {
         // the walk under the lanes that hold an entry, the record's delivery by all of them
@@ -126,7 +136,15 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
             const StepEntry E = step_enter(SG, s, t, p.shift, p.eps, LdsAbsFetch::base_of(brick));
             DDRR_PROF(PROF_SETUP);
             int steps = 0;
-            if (E.hit) steps = step_walk<true>(LdsAbsFetch{}, SG, E, v[0], v + 1);
+            if (MODE == BRICK_CHANNELS_AUX) {
+                const unsigned N = (unsigned)(p.det_h * p.det_w), C = (unsigned)p.n_channels;
+                if (E.hit)
+                    steps = step_walk_weighted(LdsAbsFetch{}, SG, E,
+                                               BrickColumnWeight{p.grad_out, (b * C * N + pix) * 4u, N * 4u},
+                                               v[0], v + 1);
+            } else if (E.hit) {
+                steps = step_walk<true>(LdsAbsFetch{}, SG, E, v[0], v + 1);
+            }
             DDRR_PROF(PROF_WALK);
             DDRR_PROF_COUNT(PROF_N_STEPS, (unsigned long long)__builtin_amdgcn_readfirstlane(steps));
             (void)steps;
@@ -247,7 +265,7 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
 template <int MODE>
 __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     BrickArgs p, float *__restrict__ out, float *__restrict__ aux) {
-    constexpr bool AUX = MODE == BRICK_FWD_AUX;
+    constexpr bool AUX = MODE == BRICK_FWD_AUX || MODE == BRICK_CHANNELS_AUX;
     // TRI: bricks of 31^3 base cells + halo (the marcher's forward); the marcher's volume
     // gradient (TRI_OWNER) runs on the plain 32^3 voxel bricks, see tri_brick.h
     constexpr bool TRI = MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_FWD_AUX || MODE == BRICK_TRI_CHANNELS;
@@ -269,9 +287,11 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     const unsigned pix_mask = (1u << p.pix_bits) - 1u;
     const int n_chunks = (p.B + kPoseChunk - 1) / kPoseChunk;
     const bool vec_ok = (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.vol) & 15) == 0 &&
-                        (MODE != BRICK_CHANNELS || (reinterpret_cast<uintptr_t>(p.labels) & 3) == 0);
+                        ((MODE != BRICK_CHANNELS && MODE != BRICK_CHANNELS_AUX) ||
+                         (reinterpret_cast<uintptr_t>(p.labels) & 3) == 0);
     const bool vec_out = GRAD && (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.g_volume) & 15) == 0;
-    const bool labels_dword_ok = (MODE == BRICK_CHANNELS || MODE == BRICK_TRI_CHANNELS) &&
+    const bool labels_dword_ok = (MODE == BRICK_CHANNELS || MODE == BRICK_TRI_CHANNELS ||
+                                  MODE == BRICK_CHANNELS_AUX) &&
                                  (reinterpret_cast<uintptr_t>(p.labels) & 3) == 0;
     // fixed-point scale of the LDS accumulator (volume-gradient modes): the largest sum a
     // voxel can receive is n_sum (contributions) * wmax (each) -- volgrad_prepare_kernel
@@ -356,10 +376,11 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         asm volatile("" : "+v"(tid_here));
         const int q4 = (tid_here & 7) * 4, z = box.lo[2] + q4;
         float *const d0 = brick + q4;
-        constexpr bool LABELS = MODE == BRICK_CHANNELS || MODE == BRICK_TRI_CHANNELS;
+        constexpr bool LABELS = MODE == BRICK_CHANNELS || MODE == BRICK_TRI_CHANNELS ||
+                                MODE == BRICK_CHANNELS_AUX;
         // (Siddon channels: labels without a channel are staged as value 0 | label 0)
         auto pack_word = [&](float v, unsigned lab) {
-            return MODE == BRICK_CHANNELS ? pack_voxel_label_below(v, lab, (unsigned)p.n_channels)
+            return MODE != BRICK_TRI_CHANNELS ? pack_voxel_label_below(v, lab, (unsigned)p.n_channels)
                                           : pack_voxel_label(v, lab);
         };
         const bool stage_vec = ch == 0 && !GRAD && !TRI && vec_ok;
@@ -916,7 +937,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     {
         std::lock_guard<std::mutex> lock(mu);
         if (!attr_set[dev]) {
-            const void *fns[8] = {
+            const void *fns[9] = {
+                reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_CHANNELS_AUX>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_CHANNELS>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_CHANNELS>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_FWD_AUX>),
@@ -950,7 +972,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     const int n_bricks = bg.nx * bg.ny * bg.nz;
     // the Siddon modes hand their bricks out heaviest first like the forward kernels (the marcher's
     // bricks are cells + halo with their own boxes: id order)
-    if (mode == BRICK_FWD || mode == BRICK_FWD_AUX || mode == BRICK_VOLGRAD || mode == BRICK_CHANNELS)
+    if (mode == BRICK_FWD || mode == BRICK_FWD_AUX || mode == BRICK_VOLGRAD || mode == BRICK_CHANNELS ||
+        mode == BRICK_CHANNELS_AUX)
         order_bricks(p, BRICK, BRICK, BRICK, bg.ny, bg.nz, n_bricks, n_cu_dev, st);
     const dim3 grid(n_bricks < n_cu_dev ? n_bricks : n_cu_dev), block(kBrickThreads);
     if (mode == BRICK_TRI_FWD)
@@ -967,6 +990,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_FWD_AUX>, grid, block, lds, st, p, out, aux);
     else if (mode == BRICK_CHANNELS)
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_CHANNELS>, grid, block, lds, st, p, out, aux);
+    else if (mode == BRICK_CHANNELS_AUX)
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_CHANNELS_AUX>, grid, block, lds, st, p, out, aux);
     else if (mode == BRICK_TRI_CHANNELS)
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_CHANNELS>, grid, block, lds, st, p, out, aux);
     else
@@ -1093,6 +1118,27 @@ int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char
     return launch_bricks(BRICK_CHANNELS, volume, dx, dy, dz, source, target, img, nullptr, B, det_h,
                          det_w, voxel_shift, eps, out, nullptr, nullptr, st, launch_ws,
                          "ddrr_siddon_forward_channels_bricks", 0, nullptr, nullptr, 0.f, labels, C);
+}
+
+int ddrr_siddon_backward_channels_bricks(const float *volume, const unsigned char *labels, int dx,
+                                         int dy, int dz, const float *source, const float *target,
+                                         const float *grad_out, int B, int det_h, int det_w, int C,
+                                         float voxel_shift, float eps, float *aux, void *launch_ws,
+                                         void *stream) {
+    const int N = det_h * det_w;
+    if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
+    if (!labels || !grad_out || !aux || C < 1) return fail(-1, "null labels/grad_out/aux or C < 1");
+    if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
+    if ((long)B * C * N >= (1L << 30) || N >= (1 << 22))
+        return fail(-1, "B * C * N must stay below 2^30 (and N below 2^22) for one channel launch "
+                        "on the bricks: split the pose batch or use ddrr_siddon_backward_channels");
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(aux, 0, sizeof(float) * (size_t)rec_blocked_floats((long)B * N), st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    return launch_bricks(BRICK_CHANNELS_AUX, volume, dx, dy, dz, source, target, nullptr, grad_out, B,
+                         det_h, det_w, voxel_shift, eps, nullptr, aux, nullptr, st, launch_ws,
+                         "ddrr_siddon_backward_channels_bricks", 0, nullptr, nullptr, 0.f, labels, C);
 }
 
 int ddrr_trilinear_forward_channels_bricks(const float *volume, const unsigned char *labels,

@@ -559,6 +559,32 @@ def siddon_forward_channels_bricks(volume, labels_u8, n_channels, source, target
     return out
 
 
+def siddon_backward_channels_bricks(volume, labels_u8, source, target, img, grad_out, det, *,
+                                    voxel_shift=0.5, eps=1e-8, want_img=True):
+    """Ray / img gradients of :func:`siddon_forward_channels_bricks` for grad_out (B, C, N) on the
+    volume-stationary bricks: the brick kernel writes the backward record of the volume weighted by
+    every voxel's own incoming gradient, ``ddrr_siddon_backward_rays`` turns it into gradients.
+    -> (g_source per ray (B,N,3), g_target (B,N,3), g_img (B,N) | None)"""
+    B, N = _check_rays(volume, source, target, img)
+    H, W = int(det[0]), int(det[1])
+    C = grad_out.shape[1]
+    if grad_out.shape != (B, C, N):
+        raise ValueError(f"grad_out must be (B, C, N) = ({B}, C, {N}), got {tuple(grad_out.shape)}")
+    if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
+        raise ValueError("the brick path needs one source per pose and an H*W >= 2x2 ray grid")
+    dev = volume.device
+    aux = torch.empty(record_blocks(B, N), _lib.REC_BLOCK_FLOATS, dtype=torch.float32, device=dev)
+    ones = torch.ones(B, N, dtype=torch.float32, device=dev)
+    if not _empty(B, N):
+        labels_u8, volume, grad_out = labels_u8.contiguous(), volume.contiguous(), grad_out.contiguous()
+        source, target = source.contiguous(), target.contiguous()
+        _launch("ddrr_siddon_backward_channels_bricks", dev, volume.data_ptr(), labels_u8.data_ptr(),
+                *volume.shape, source.data_ptr(), target.data_ptr(), grad_out.data_ptr(), B, H, W,
+                int(C), float(voxel_shift), float(eps), aux.data_ptr(),
+                launch_workspace(volume.shape, dev).data_ptr())
+    return siddon_backward_rays(aux, ones, source, target, img, eps=eps, want_img_grad=want_img)
+
+
 def channels_fit_bricks(B, C, N):
     """One brick launch addresses the (B, C, N) result with 32-bit byte offsets."""
     return B * C * N < 2 ** 30 and N < 2 ** 22

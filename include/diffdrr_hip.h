@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 25
+#define DDRR_ABI_VERSION 26
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -203,6 +203,21 @@ int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char
                                         const float *img, int B, int det_h, int det_w, int C,
                                         float voxel_shift, float eps, float *out, void *launch_ws,
                                         void *stream);
+
+/* Backward of the channel render w.r.t. the RAYS for the DRR case, on the volume-stationary
+ * bricks (replaces ScatterAddBackward . SortBackward of renderers.py:77-89 for source / target /
+ * img): for grad_out (B, C, N) it writes the blocked backward record (DDRR_AUX_BLOCKED,
+ * DDRR_REC_BLOCK_FLOATS * ceil(B N / DDRR_REC_BLOCK_RAYS) floats, zero-filled by the call) of
+ * the volume weighted by each voxel's own incoming gradient, W(x) = V(x) grad_out[b, label(x), n]
+ * -- labels >= C weigh 0 -- so that ddrr_siddon_backward_rays(aux, DDRR_AUX_BLOCKED, ones (B, N),
+ * ...) returns d/d source, d/d target and d/d img of sum_c grad_out_c out_c.  The weight of a
+ * label run is gathered from grad_out when a ray's label changes inside a brick.
+ * B * C * N < 2^30, N < 2^22.  (The volume gradient stays with ddrr_siddon_backward_channels.) */
+int ddrr_siddon_backward_channels_bricks(const float *volume, const unsigned char *labels, int dx,
+                                         int dy, int dz, const float *source, const float *target,
+                                         const float *grad_out, int B, int det_h, int det_w, int C,
+                                         float voxel_shift, float eps, float *aux, void *launch_ws,
+                                         void *stream);
 
 /* Backward of ddrr_siddon_forward_channels: what autograd of renderers.py:77-89 (scatter_add
  * of the weighted segments into channels) returns for grad_out (B, C, N).  Outputs as in

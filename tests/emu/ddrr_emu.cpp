@@ -739,6 +739,51 @@ int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char
     return 0;
 }
 
+// Host emulation of the channel render's ray backward on the bricks: the blocked record of the
+// volume weighted by grad_out[b, label, n], with the kernel's own step_walk_weighted.
+int ddrr_siddon_backward_channels_bricks(const float *volume, const unsigned char *labels, int dx,
+                                         int dy, int dz, const float *source, const float *target,
+                                         const float *grad_out, int B, int det_h, int det_w, int C,
+                                         float voxel_shift, float eps, float *aux, void *, void *) {
+    const Dims D{dx, dy, dz};
+    const int N = det_h * det_w;
+    const long R = (long)B * N;
+    memset(aux, 0, sizeof(float) * (size_t)rec_blocked_floats(R));
+    const BrickGrid bg = brick_grid(D);
+    const BrickLayout lay{33, 32 * 33 + 1};
+    std::vector<float> brick((size_t)brick_floats(lay));
+    for (int id = 0; id < bg.nx * bg.ny * bg.nz; ++id) {
+        const Box box = brick_box(D, bg, id);
+        const StepGeom SG = step_geom(box, lay);
+        std::fill(brick.begin(), brick.end(), 0.f);
+        for (int x = box.lo[0]; x < box.hi[0]; ++x)
+            for (int y = box.lo[1]; y < box.hi[1]; ++y)
+                for (int z = box.lo[2]; z < box.hi[2]; ++z) {
+                    const long at = ((long)x * dy + y) * dz + z;
+                    brick[(x - box.lo[0]) * lay.sx + (y - box.lo[1]) * lay.sy + (z - box.lo[2])] =
+                        pack_voxel_label_below(volume[at], labels[at], (unsigned)C);
+                }
+        for (int b = 0; b < B; ++b)
+            for (int pix = 0; pix < N; ++pix) {
+                const long r = (long)b * N + pix;
+                float s[3], t[3];
+                for (int a = 0; a < 3; ++a) {
+                    s[a] = source[(long)b * 3 + a];
+                    t[a] = target[r * 3 + a];
+                }
+                const StepEntry E = step_enter(SG, s, t, voxel_shift, eps, 0u);
+                if (!E.hit) continue;
+                const float *col = grad_out + (long)b * C * N + pix;
+                float I, rec[4];
+                step_walk_weighted(LdsFetch{brick.data()}, SG, E,
+                                   [&](unsigned lab) { return col[(long)lab * N]; }, I, rec);
+                aux[rec_index(r, 0)] += I;
+                for (int k = 0; k < 4; ++k) aux[rec_index(r, k + 1)] += rec[k];
+            }
+    }
+    return 0;
+}
+
 int ddrr_siddon_backward_channels(const float *volume, const unsigned char *labels, int dx,
                                   int dy, int dz, const float *source, int src_n,
                                   const float *target, const float *img, const float *grad_out,

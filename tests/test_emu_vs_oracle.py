@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import oracle
+import conftest
 from conftest import golden, rel_err
 from diffdrr_amd._lib import SIDDON_AUX
 
@@ -501,3 +502,9 @@ def test_siddon_segments_equal_oracle_terms(emu_lib):
     ref, _ = oracle.siddon_segments(vol, src, tgt, img)
     assert ref.shape == (B, N, M1)
     assert rel_err(terms.transpose(0, 2, 1), ref) < 1e-5
+
+
+def test_channel_backward_on_bricks_vs_oracle(emulated_ops):
+    """The ray / img backward of the channel render on the volume-stationary bricks (host
+    emulation of step_walk_weighted) against the fp64 oracle and the per-ray channel backward."""
+    conftest.check_channel_backward_on_bricks(emulated_ops, "cpu")

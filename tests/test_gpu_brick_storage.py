@@ -110,3 +110,36 @@ def test_launches_on_two_streams_and_in_a_graph_share_no_state(gpu):
         # float sum that is itself order-dependent)
         tol = 2e-6 * float(want.abs().max())
         assert float((r - want).abs().max()) <= tol, kind
+
+
+def test_channel_backward_on_bricks_vs_oracle(gpu):
+    """ddrr_siddon_backward_channels_bricks on the device (step_walk_weighted: the gather of
+    grad_out[b, label, n] at every label change) against the fp64 oracle and the per-ray kernel."""
+    conftest.check_channel_backward_on_bricks(ops, gpu)
+
+
+def test_channel_backward_through_the_module_takes_the_bricks(gpu, monkeypatch):
+    """Siddon(mask=...) with a detector grid and no volume gradient: the backward runs on the
+    bricks and gives the per-ray kernel's gradients (what the same call gives with
+    channels_on_bricks = False)."""
+    from diffdrr_amd import DRR
+    from diffdrr_amd.data import synthetic_subject
+
+    drr = DRR(synthetic_subject((64, 64, 72), kind="noise", seed=1, n_labels=9), sdd=500.0, height=28,
+              width=36, delx=2.5).to(gpu)
+    rot = torch.tensor([[0.2, -0.1, 0.3], [0.9, 0.2, -0.4]], device=gpu)
+    xyz = torch.tensor([[3.0, 300.0, -2.0], [-4.0, 320.0, 5.0]], device=gpu)
+    go = torch.rand(2, 9, 28, 36, device=gpu)
+    calls = []
+    real = ops.siddon_backward_channels_bricks
+    monkeypatch.setattr(ops, "siddon_backward_channels_bricks", lambda *a, **k: calls.append(1) or real(*a, **k))
+    grads = {}
+    for on_bricks in (True, False):
+        drr.renderer.channels_on_bricks = on_bricks
+        r, x = rot.clone().requires_grad_(), xyz.clone().requires_grad_()
+        img = drr(r, x, parameterization="euler_angles", convention="ZXY", mask_to_channels=True)
+        (img * go).sum().backward()
+        grads[on_bricks] = (r.grad.clone(), x.grad.clone())
+    assert calls == [1]
+    for a, b in zip(grads[True], grads[False]):
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max())  # (tie flips: see conftest)
