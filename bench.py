@@ -351,7 +351,7 @@ FULL = {"headline": (400, 10, 60), "2": (800, 10, 60), "3": (400, 10, 60), "4": 
 SHORT = {"2": (300, 5, 40), "3": (150, 5, 30), "5": (2, 0, 1)}
 
 
-def issue_bound_record(kernel_key, kernel_ms):
+def issue_bound_record(kernel_key, kernel_ms, visits=None):
     """What binds a brick kernel, from the committed counter passes of this round (they cannot be
     collected from inside the process): newest profiles/rNN/issue_bound.json (tools/issue_bound.py
     wrote it from rocprofv3 --pmc SQ_INSTS_VALU ... and the walk counters of the profile build).
@@ -378,13 +378,19 @@ def issue_bound_record(kernel_key, kernel_ms):
            "profiled_kernel_ms": k.get("kernel_ms"),
            "source": src + " (separate rocprofv3 --pmc passes + the profile build's walk counters, "
                            "committed; not measured in this run)"}
-    if "walk_wave_steps" in k:
-        useful = k["walk_wave_steps"] * k["walk_useful_lane_frac"] * k["insts_per_step"]
-        out.update(walk_wave_steps=k["walk_wave_steps"], walk_useful_lane_frac=k["walk_useful_lane_frac"],
-                   insts_per_step=k["insts_per_step"], useful_frac=useful / k["valu_wave_insts"],
+    if "walk_wave_steps" in k and visits:
+        # lanes of the walk that hold a live ray = voxel visits of this launch (counted by the
+        # bench) / (64 x wave-steps of the profiled launch of the same workload)
+        lanes = visits / (64.0 * k["walk_wave_steps"])
+        useful = k["walk_wave_steps"] * lanes * k["insts_per_step"]
+        out.update(walk_wave_steps=k["walk_wave_steps"], walk_useful_lane_frac=lanes,
+                   insts_per_step=k["insts_per_step"], hits=k.get("hits"), batches=k.get("batches"),
+                   useful_frac=useful / k["valu_wave_insts"],
                    useful_frac_of_kernel=useful / k["valu_wave_insts"] * (issue_ms / kernel_ms) if kernel_ms else None)
-    if "lds_atomic_wave_insts" in k:
-        out.update(lds_atomic_wave_insts=k["lds_atomic_wave_insts"], lds_atomic_ms=k.get("lds_atomic_ms"))
+    if "lds_busy_ms" in k:
+        # SQ_LDS_IDX_ACTIVE summed over the CUs / 256 CUs / 2.4 GHz: how long the LDS pipe of a CU is busy
+        out.update(lds_wave_insts_per_launch=k.get("lds_wave_insts"), lds_busy_ms=k["lds_busy_ms"],
+                   lds_busy_frac=k["lds_busy_ms"] / kernel_ms if kernel_ms else None)
     return out
 
 
@@ -683,8 +689,8 @@ def run_config(cfg, args, rt, short=False):
         ent = {"kernel": name, "kernel_ms": tot / cnt, "launches_per_step": cnt / steps_k}
         if name == k_name:
             ent.update(algorithmic_bytes_per_launch=alg_bytes, frac=achieved / HBM_PEAK_GBS)
-            if cfg in ("headline", "4") and at_headline_size and B == FULL_BATCH.get(cfg):
-                ib = issue_bound_record("forward_record", tot / cnt)
+            if cfg == "headline" and at_headline_size and B == 32:  # (the workload the counters were taken on)
+                ib = issue_bound_record("forward_record", tot / cnt, nv_total)
                 if ib:
                     ent["issue_bound"] = ib
         elif cfg == "3" and name == "ddrr_trilinear_backward_volume_bricks":
@@ -711,7 +717,7 @@ def run_config(cfg, args, rt, short=False):
                    "frac": alg_bytes / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "target_frac": 0.70}
         if at_headline_size and cfg in ("headline", "5") and f_poses in (32, 512):
-            ib = issue_bound_record("forward" if f_poses == 32 else "forward_sweep", f_ms)
+            ib = issue_bound_record("forward" if f_poses == 32 else "forward_sweep", f_ms, nv_total)
             if ib:
                 forward["issue_bound"] = ib
         log(f"[bench] config {cfg} forward only: {f_ms:.3f} ms per launch of {f_poses} poses = "
@@ -845,9 +851,6 @@ def run_config(cfg, args, rt, short=False):
             "source": "profiles/r02/ref_cpu_baseline.txt (tools/ref_cpu_baseline.py)"}
     result.update(extra)
     return result
-
-
-FULL_BATCH = {"headline": 32, "4": 1}
 
 
 def trilinear_parity(drr, rot, xyz, image, go, P, H, rows=4):

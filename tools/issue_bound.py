@@ -23,10 +23,10 @@ os.makedirs(os.path.join(ROOT, out_dir), exist_ok=True)
 NS_PER_INST, SIMDS, CUS, CLOCK_GHZ = 1.05, 1024, 256, 2.4
 
 CASES = {  # key -> (prof_cases args, substring of the kernel name, profile-build case or None, insts per step)
-    "forward": (["--kernel", "brick", "--case", "pert32", "--reps", "12"], "siddon_fwd_brick_kernel<false", "pert32", 20),
+    "forward": (["--kernel", "brick", "--case", "pert32", "--reps", "12"], "siddon_fwd_brick_kernel<false", "pert32", 16),
     "forward_record": (["--kernel", "brick", "--case", "pert32", "--aux", "1", "--reps", "12"],
                        "siddon_fwd_brick_kernel<true", "pert32aux", 27),
-    "forward_sweep": (["--kernel", "brick", "--case", "pert512", "--reps", "4"], "siddon_fwd_brick_kernel<false", "pert512", 20),
+    "forward_sweep": (["--kernel", "brick", "--case", "pert512", "--reps", "4"], "siddon_fwd_brick_kernel<false", "pert512", 16),
     "trilinear_volume_gradient": (["--kernel", "trivol", "--case", "pert1", "--det", "512", "--reps", "12"],
                                   "siddon_brick_kernel<4>", None, None),
     "trilinear_forward": (["--kernel", "trifwd", "--case", "pert1", "--det", "512", "--reps", "12"],
