@@ -22,11 +22,17 @@ launcher (RANK / WORLD_SIZE set) it uses the ranks it is given.  `n_gpus` in the
 world size RCCL actually has.
 
 Rank 0 prints ONE JSON line on stdout: the driver's contract plus
-  "roofline":     the dominant kernel's algorithmic byte rate (SURVEY.md section 8d formulas),
-                  timed with HIP events around every launch inside the timed region;
-                  "roofline.forward": the forward-only kernel (the north star's target) on the
-                  step's own poses, 30 launches after the timed region; "roofline.kernels": every
-                  renderer kernel of the step with its own algorithmic bytes,
+  "roofline":     the dominant kernel's algorithmic byte rate (SURVEY.md section 8d formulas), timed
+                  with HIP events around every launch inside the timed region; "roofline.forward":
+                  the forward-only kernel (the north star's target) on the step's own poses, primed
+                  with 60 launches directly after the timed region, then 30 timed;
+                  "roofline.forward_sweep": the same kernel at 512 of config 5's poses per launch,
+                  with its parity; "roofline.kernels": every renderer kernel of the step with its
+                  own algorithmic bytes and, where the counters were taken, "issue_bound": VALU issue
+                  time, its share of the kernel and the useful fraction (profiles/rNN/issue_bound.json),
+  "configs":      (default run, one GPU) short runs of BASELINE configs 2, 3 and 5: ms per step,
+                  dominant-kernel rate, parity; "sweep": config 5's figure -- with --gpus N the
+                  strong-scaling point (4096 poses over the ranks) next to the weak-scaling headline,
   "cpu_baseline": the CPU oracle (a port of the reference's algorithm, OpenMP) on a bounded
                   sample of the same workload, rank 0, N = 1 only; "reference_cpu": the
                   UNMODIFIED reference on CPU torch, measured in the build container (it does
