@@ -412,9 +412,12 @@ def run_config(cfg, args, rt, short=False):
     from diffdrr_amd.data import make_subject, noise_volume, synthetic_subject
 
     top = not short  # the run the command line asked for
-    D = (args.size if top else None) or (256 if cfg == "2" else 512)
-    H = (args.det if top else None) or (512 if cfg == "3" else 256)
+    sized = top or (cfg == "5" and args.sweep_poses is not None)  # (the harness test's small sweep)
+    D = (args.size if sized else None) or (256 if cfg == "2" else 512)
+    H = (args.det if sized else None) or (512 if cfg == "3" else 256)
     B = (args.batch if top else None) or {"headline": 32, "2": 32, "3": 1, "4": 1, "5": 4096}[cfg]
+    if short and cfg == "5" and args.sweep_poses is not None:
+        B = args.sweep_poses
     steps, warmup, prime = SHORT[cfg] if short else FULL[cfg]
     if top and args.steps is not None:
         steps = args.steps
@@ -921,6 +924,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true",
                     help="headline only: skip the short runs of configs 2, 3, 5 (`configs`, `sweep`)")
+    ap.add_argument("--sweep-poses", type=int, default=None,
+                    help="candidate poses of the `sweep` sub-run (default 4096; given explicitly, the "
+                         "sub-run also happens at non-default sizes / on the cpu harness)")
     ap.add_argument("--storage", default=None, choices=["q16p", "q16", "f32"],
                     help="Siddon.brick_storage (default: the module's default, q16p)")
     ap.add_argument("--packed-record", action="store_true",
@@ -945,12 +951,14 @@ def main():
     result = run_config(args.config, args, rt)
     plain_headline = (args.config == "headline" and rt.on_gpu and not args.no_configs
                       and args.size is None and args.det is None and args.batch is None)
-    if plain_headline:
+    sweep_only = (args.config == "headline" and not plain_headline and not args.no_configs
+                  and args.sweep_poses is not None)
+    if plain_headline or sweep_only:
         # The other BASELINE configs, short, in the driver's own record.  N = 1: configs 2, 3 and 5
         # with their parity; N > 1: the sweep only (config 5 -- 4096 poses over the N ranks, the
         # informative strong-scaling curve; the headline above is N independent 32-pose steps).
         configs = {}
-        for cfg in (("2", "3", "5") if rt.world == 1 else ("5",)):
+        for cfg in (("2", "3", "5") if rt.world == 1 and plain_headline else ("5",)):
             t0 = time.perf_counter()
             res = run_config(cfg, args, rt, short=True)
             if rt.rank == 0:
@@ -960,10 +968,10 @@ def main():
             c5 = configs["5"]
             result["sweep"] = {"metric": c5["metric"], "value": c5["value"], "unit": c5["unit"],
                                "n_gpus": rt.world, "scaling": "strong", "ms_per_step": c5["ms_per_step"],
-                               "steps": c5["steps"], "poses": 4096, "poses_per_launch": 512,
+                               "steps": c5["steps"], "poses": args.sweep_poses or 4096, "poses_per_launch": 512,
                                "what": "bench.py --config 5, short: the candidate sweep of BASELINE "
                                        "configs[4], pose-sharded over the ranks"}
-            if rt.world == 1:
+            if rt.world == 1 and plain_headline:
                 result["configs"] = configs
                 # the north star's figure at the batch size it is met at: 512 poses per launch
                 fs = dict(c5["forward"])

@@ -142,7 +142,8 @@ def test_trilinear_sweep_does_not_depend_on_world_size_or_chunking(emulated_ops)
     assert r0 == min(p[0] for p in parts) and r1 == max(p[1] for p in parts)
 
 
-@pytest.mark.parametrize("config,extra", [("headline", ["--batch", "3"]), ("5", ["--batch", "7"])])
+@pytest.mark.parametrize("config,extra", [("headline", ["--batch", "3", "--sweep-poses", "5"]),
+                                          ("5", ["--batch", "7"])])
 def test_bench_harness_spawns_its_ranks(config, extra):
     """`python bench.py --gpus 2` with no launcher starts two ranks itself (torch.distributed.run,
     127.0.0.1), runs its step on both and rank 0 prints the contract's JSON line with the world
@@ -169,6 +170,9 @@ def test_bench_harness_spawns_its_ranks(config, extra):
     if config == "headline":
         assert out["scaling"] == "weak" and out["config"]["global_batch"] == 6
         assert abs(out["value"] - 6 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+        # ... and the strong-scaling figure next to it: config 5's sweep over the same two ranks
+        sw = out["sweep"]
+        assert sw["n_gpus"] == 2 and sw["scaling"] == "strong" and sw["poses"] == 5 and sw["value"] > 0
     else:
         assert out["scaling"] == "strong" and out["config"]["global_batch"] == 7
     assert out["roofline"]["kernel"] == "ddrr_siddon_forward_bricks" and out["roofline"]["frac"] > 0
