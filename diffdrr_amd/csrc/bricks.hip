@@ -103,10 +103,14 @@ struct BrickColumnFlush {
 
 // The incoming gradient of the ray's own output column, by label (BRICK_CHANNELS_AUX): a gather
 // at a 32-bit byte offset from the wave-uniform base.
+// CHECKED: labels without a channel (>= C) weigh nothing (the Siddon staging has already turned
+// them into value 0 | label 0).
+template <bool CHECKED = false>
 struct BrickColumnWeight {
     const float *g;
-    unsigned colb, N4;
+    unsigned colb, N4, C;
     __device__ __forceinline__ float operator()(unsigned lab) const {
+        if (CHECKED && lab >= C) return 0.f;
         return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(g) + (colb + __umul24(lab, N4)));
     }
 };
@@ -140,7 +144,7 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
                 const unsigned N = (unsigned)(p.det_h * p.det_w), C = (unsigned)p.n_channels;
                 if (E.hit)
                     steps = step_walk_weighted(LdsAbsFetch{}, SG, E,
-                                               BrickColumnWeight{p.grad_out, (b * C * N + pix) * 4u, N * 4u},
+                                               BrickColumnWeight<false>{p.grad_out, (b * C * N + pix) * 4u, N * 4u, C},
                                                v[0], v + 1);
             } else if (E.hit) {
                 steps = step_walk<true>(LdsAbsFetch{}, SG, E, v[0], v + 1);
@@ -214,6 +218,25 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
                                  BrickColumnFlush<true>{out, (b * C * N + pix) * 4u, N * 4u, C, L * step});
         return;
     }
+    if (MODE == BRICK_TRI_CHANNELS_AUX) {
+        TriGeom T;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            T.lo[a] = G.lof[a];
+            T.stridef[a] = G.stridef[a];
+        }
+        const unsigned N = (unsigned)(p.det_h * p.det_w), C = (unsigned)p.n_channels;
+        float sumT, rec[6];
+        if (!tri_brick_march_weighted(LdsAbsFetch{}, base, T, p.D, s, t, p.shift, p.eps, p.n_points,
+                                      p.amin[0], p.amax[0],
+                                      BrickColumnWeight<true>{p.grad_out, (b * C * N + pix) * 4u, N * 4u, C},
+                                      sumT, rec))
+            return;
+        unsafeAtomicAdd(aux + r, sumT);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) unsafeAtomicAdd(aux + (unsigned)(k + 1) * p.aux_plane + r, rec[k]);
+        return;
+    }
     if (MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_FWD_AUX) {
         TriGeom T;  // G.lof holds the first base cell here (set by the kernel)
 #pragma unroll
@@ -268,7 +291,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     constexpr bool AUX = MODE == BRICK_FWD_AUX || MODE == BRICK_CHANNELS_AUX;
     // TRI: bricks of 31^3 base cells + halo (the marcher's forward); the marcher's volume
     // gradient (TRI_OWNER) runs on the plain 32^3 voxel bricks, see tri_brick.h
-    constexpr bool TRI = MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_FWD_AUX || MODE == BRICK_TRI_CHANNELS;
+    constexpr bool TRI = MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_FWD_AUX || MODE == BRICK_TRI_CHANNELS ||
+                         MODE == BRICK_TRI_CHANNELS_AUX;
     constexpr bool TRI_OWNER = MODE == BRICK_TRI_VOLGRAD;
     constexpr bool GRAD = MODE == BRICK_VOLGRAD || MODE == BRICK_TRI_VOLGRAD;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -291,7 +315,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                          (reinterpret_cast<uintptr_t>(p.labels) & 3) == 0);
     const bool vec_out = GRAD && (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.g_volume) & 15) == 0;
     const bool labels_dword_ok = (MODE == BRICK_CHANNELS || MODE == BRICK_TRI_CHANNELS ||
-                                  MODE == BRICK_CHANNELS_AUX) &&
+                                  MODE == BRICK_CHANNELS_AUX || MODE == BRICK_TRI_CHANNELS_AUX) &&
                                  (reinterpret_cast<uintptr_t>(p.labels) & 3) == 0;
     // fixed-point scale of the LDS accumulator (volume-gradient modes): the largest sum a
     // voxel can receive is n_sum (contributions) * wmax (each) -- volgrad_prepare_kernel
@@ -358,7 +382,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     // the float backward records: length classes per group of 8 lanes = 8 adjacent pixels (below)
     // (the channel render gains nothing from it: runs of 8 adjacent pixels, whose label changes
     // coincide, measured 0.314 vs 0.302 ms at 8 poses -- profiles/r04/channels.txt)
-    const bool GROUPED = ((AUX && p.rec_q == 0.f) || MODE == BRICK_TRI_FWD_AUX) && !(p.dbg & 8);
+    const bool GROUPED = ((AUX && p.rec_q == 0.f) || MODE == BRICK_TRI_FWD_AUX ||
+                          MODE == BRICK_TRI_CHANNELS_AUX) && !(p.dbg & 8);
 
     for (int ch = 0; ch < n_chunks; ++ch) {
         const int b0 = ch * kPoseChunk;
@@ -377,10 +402,11 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         const int q4 = (tid_here & 7) * 4, z = box.lo[2] + q4;
         float *const d0 = brick + q4;
         constexpr bool LABELS = MODE == BRICK_CHANNELS || MODE == BRICK_TRI_CHANNELS ||
-                                MODE == BRICK_CHANNELS_AUX;
+                                MODE == BRICK_CHANNELS_AUX || MODE == BRICK_TRI_CHANNELS_AUX;
         // (Siddon channels: labels without a channel are staged as value 0 | label 0)
         auto pack_word = [&](float v, unsigned lab) {
-            return MODE != BRICK_TRI_CHANNELS ? pack_voxel_label_below(v, lab, (unsigned)p.n_channels)
+            return MODE != BRICK_TRI_CHANNELS && MODE != BRICK_TRI_CHANNELS_AUX
+                       ? pack_voxel_label_below(v, lab, (unsigned)p.n_channels)
                                           : pack_voxel_label(v, lab);
         };
         const bool stage_vec = ch == 0 && !GRAD && !TRI && vec_ok;
@@ -921,7 +947,7 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     p.prof = g_brick_prof;
 #endif
     if (mode == BRICK_TRI_FWD || mode == BRICK_TRI_VOLGRAD || mode == BRICK_TRI_FWD_AUX ||
-        mode == BRICK_TRI_CHANNELS) {
+        mode == BRICK_TRI_CHANNELS || mode == BRICK_TRI_CHANNELS_AUX) {
         p.t1 = g_tri_t1;
         p.t2 = g_tri_t2;
     }
@@ -937,7 +963,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     {
         std::lock_guard<std::mutex> lock(mu);
         if (!attr_set[dev]) {
-            const void *fns[9] = {
+            const void *fns[10] = {
+                reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_CHANNELS_AUX>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_CHANNELS_AUX>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_CHANNELS>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_CHANNELS>),
@@ -967,7 +994,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
                            amax, p.work);
     }
     const BrickGrid bg = (mode == BRICK_TRI_FWD || mode == BRICK_TRI_FWD_AUX ||
-                          mode == BRICK_TRI_CHANNELS) ? tri_brick_grid(p.D)
+                          mode == BRICK_TRI_CHANNELS || mode == BRICK_TRI_CHANNELS_AUX)
+                             ? tri_brick_grid(p.D)
                                                                               : brick_grid(p.D);
     const int n_bricks = bg.nx * bg.ny * bg.nz;
     // the Siddon modes hand their bricks out heaviest first like the forward kernels (the marcher's
@@ -994,6 +1022,9 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_CHANNELS_AUX>, grid, block, lds, st, p, out, aux);
     else if (mode == BRICK_TRI_CHANNELS)
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_CHANNELS>, grid, block, lds, st, p, out, aux);
+    else if (mode == BRICK_TRI_CHANNELS_AUX)
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_CHANNELS_AUX>, grid, block, lds, st, p, out,
+                           aux);
     else
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_VOLGRAD>, grid, block, lds, st, p, out, aux);
     return finish(who);
@@ -1165,6 +1196,32 @@ int ddrr_trilinear_forward_channels_bricks(const float *volume, const unsigned c
                          det_h, det_w, voxel_shift, eps, out, nullptr, nullptr, st, launch_ws,
                          "ddrr_trilinear_forward_channels_bricks", n_points, alphamin, alphamax, 0.f,
                          labels, C);
+}
+
+int ddrr_trilinear_backward_channels_bricks(const float *volume, const unsigned char *labels,
+                                            int dx, int dy, int dz, const float *source,
+                                            const float *target, const float *grad_out, int B,
+                                            int det_h, int det_w, int C, float voxel_shift,
+                                            float eps, int n_points, const float *alphamin,
+                                            const float *alphamax, float *aux, void *launch_ws,
+                                            void *stream) {
+    const int N = det_h * det_w;
+    if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
+    if (!labels || !grad_out || !aux || C < 1) return fail(-1, "null labels/grad_out/aux or C < 1");
+    if (!alphamin || !alphamax) return fail(-1, "null alphamin / alphamax");
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
+    if ((long)B * C * N >= (1L << 30) || N >= (1 << 22))
+        return fail(-1, "B * C * N must stay below 2^30 (and N below 2^22) for one channel launch "
+                        "on the bricks: split the pose batch or use ddrr_trilinear_backward_channels");
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(aux, 0, sizeof(float) * (size_t)B * N * DDRR_TRI_AUX_PLANES, st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    return launch_bricks(BRICK_TRI_CHANNELS_AUX, volume, dx, dy, dz, source, target, nullptr,
+                         grad_out, B, det_h, det_w, voxel_shift, eps, nullptr, aux, nullptr, st,
+                         launch_ws, "ddrr_trilinear_backward_channels_bricks", n_points, alphamin,
+                         alphamax, 0.f, labels, C);
 }
 
 int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *source,

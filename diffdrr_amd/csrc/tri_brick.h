@@ -241,6 +241,109 @@ DDRR_HD bool tri_brick_march_channels(const Acc &acc, float base, const TriGeom 
     return true;
 }
 
+// Backward of tri_brick_march_channels w.r.t. the rays: the record of tri_brick_march<true> with
+// every sample (its T and dT) multiplied by `weight(label)` -- the incoming gradient of the
+// channel the sample's nearest voxel selects, fetched when the label changes along the ray.
+// The values are the packed words' (16-bit mantissa), as the forward rendered them.
+template <class Acc, class Weight>
+DDRR_HD bool tri_brick_march_weighted(const Acc &acc, float base, const TriGeom &G, const Dims D,
+                                      const float s[3], const float t[3], float shift, float eps,
+                                      int P, float amin, float amax, const Weight &weight,
+                                      float &sumT, float rec[6]) {
+    sumT = 0.f;
+    rec[0] = rec[1] = rec[2] = rec[3] = rec[4] = rec[5] = 0.f;
+    const float go = shift - 0.5f;
+    MarchSetup q;
+    float entry = -INFINITY, exit = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        q.d[a] = (t[a] - s[a]) + eps;
+        const float g0 = s[a] + go;
+        const float a1 = (G.lo[a] - g0) / q.d[a], a2 = (G.lo[a] + (float)TRI_CELLS - g0) / q.d[a];
+        entry = fmaxf(entry, fminf(a1, a2));
+        exit = fminf(exit, fmaxf(a1, a2));
+    }
+    q.span = amax - amin;
+    if (!(entry < exit) || !(q.span > 0.f)) return false;
+    const float lstep = 1.0f / (float)(P - 1), sc = (float)(P - 1) / q.span;
+    const float f0 = fminf(fmaxf(floorf((entry - amin) * sc) - 1.f, 0.f), (float)P);
+    const float f1 = fminf(fmaxf(ceilf((exit - amin) * sc) + 1.f, -1.f), (float)(P - 1));
+    if (!(f0 <= f1)) return false;
+    const int m0 = (int)f0, m1 = (int)f1;
+    const float offc = fmaf(-G.lo[0], G.stridef[0],
+                            fmaf(-G.lo[1], G.stridef[1], fmaf(-G.lo[2], G.stridef[2], base)));
+    const float sx = G.stridef[0], sy = G.stridef[1];
+    auto val = [](float w) { return bits_as_float(float_bits(w) & 0xffffff00u); };
+    int cur = -1;
+    float g = 0.f;
+    float sum = 0.f, Ax = 0.f, Ay = 0.f, Az = 0.f, Bx = 0.f, By = 0.f, Bz = 0.f;
+    for (int m = m0; m <= m1; ++m) {
+        const float lin = lin01(m, P, lstep);
+        const float al = fmaf(lin, q.span, amin);  // renderers.py:224-225
+        const float gx = fmaf(al, q.d[0], s[0]) + go;
+        const float gy = fmaf(al, q.d[1], s[1]) + go;
+        const float gz = fmaf(al, q.d[2], s[2]) + go;
+        const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+        const bool in = fx >= G.lo[0] && fx < G.lo[0] + (float)TRI_CELLS && fy >= G.lo[1] &&
+                        fy < G.lo[1] + (float)TRI_CELLS && fz >= G.lo[2] &&
+                        fz < G.lo[2] + (float)TRI_CELLS;
+        if (!in) continue;
+        const float ax = gx - fx, ay = gy - fy, az = gz - fz;
+        const float o00 = fmaf(fx, sx, fmaf(fy, sy, fmaf(fz, 4.f, offc)));  // exact, < 2^24
+        const unsigned a00 = (unsigned)(int)o00;
+        const unsigned a10 = (unsigned)(int)(o00 + sx), a01 = (unsigned)(int)(o00 + sy);
+        const unsigned a11 = (unsigned)(int)(o00 + sx + sy);
+        const float v000 = val(acc(a00)), v001 = val(acc(a00 + 4u));
+        const float v100 = val(acc(a10)), v101 = val(acc(a10 + 4u));
+        const float v010 = val(acc(a01)), v011 = val(acc(a01 + 4u));
+        const float v110 = val(acc(a11)), v111 = val(acc(a11 + 4u));
+        // the label as tri_brick_march_channels finds it
+        float un[3];
+        march_exact_coord(D, lin, q, amin, s, shift, false, un);
+        const float rx = fminf(fmaxf(rintf(un[0]), fx), fx + 1.f);
+        const float ry = fminf(fmaxf(rintf(un[1]), fy), fy + 1.f);
+        const float rz = fminf(fmaxf(rintf(un[2]), fz), fz + 1.f);
+        const unsigned an = (unsigned)(int)fmaf(rx, sx, fmaf(ry, sy, fmaf(rz, 4.f, offc)));
+        const int lab = (int)(float_bits(acc(an)) & 0xffu);
+        if (lab != cur) {
+            cur = lab;
+            g = weight((unsigned)lab);
+        }
+        const float wx0 = 1.f - ax, wy0 = 1.f - ay;
+        const float dz00 = v001 - v000, dz10 = v101 - v100, dz01 = v011 - v010, dz11 = v111 - v110;
+        const float l00 = fmaf(az, dz00, v000), l10 = fmaf(az, dz10, v100);
+        const float l01 = fmaf(az, dz01, v010), l11 = fmaf(az, dz11, v110);
+        float T = (wx0 * wy0) * l00;
+        T = fmaf(ax * wy0, l10, T);
+        T = fmaf(wx0 * ay, l01, T);
+        T = fmaf(ax * ay, l11, T);
+        sum = fmaf(g, T, sum);
+        float gX = -wy0 * l00;
+        gX = fmaf(wy0, l10, gX);
+        gX = fmaf(-ay, l01, gX);
+        gX = fmaf(ay, l11, gX);
+        float gY = -wx0 * l00;
+        gY = fmaf(-ax, l10, gY);
+        gY = fmaf(wx0, l01, gY);
+        gY = fmaf(ax, l11, gY);
+        float gZ = (wx0 * wy0) * dz00;
+        gZ = fmaf(ax * wy0, dz10, gZ);
+        gZ = fmaf(wx0 * ay, dz01, gZ);
+        gZ = fmaf(ax * ay, dz11, gZ);
+        gX *= g, gY *= g, gZ *= g;
+        Ax += gX;
+        Ay += gY;
+        Az += gZ;
+        Bx = fmaf(al, gX, Bx);
+        By = fmaf(al, gY, By);
+        Bz = fmaf(al, gZ, Bz);
+    }
+    sumT = sum;
+    rec[0] = Ax, rec[1] = Ay, rec[2] = Az;
+    rec[3] = Bx, rec[4] = By, rec[5] = Bz;
+    return true;
+}
+
 // Backward of the sum-reduced march from the record of tri_brick_march<AUX> (the sums over
 // ALL bricks): what trilinear_backward_ray computes by marching (align_corners = False, so
 // d(index coordinate)/dx = 1).  gl = grad_out * ray length.

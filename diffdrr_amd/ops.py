@@ -770,6 +770,37 @@ def trilinear_forward_channels_bricks(volume, labels_u8, n_channels, source, tar
 TRI_AUX_PLANES = 7  # sum T, sum dT_xyz, sum alpha dT_xyz (include/diffdrr_hip.h)
 
 
+def trilinear_backward_channels_bricks(volume, labels_u8, source, target, img, grad_out, alphamin,
+                                       alphamax, det, *, n_points=500, voxel_shift=0.5, eps=1e-8,
+                                       want_rays=True, want_img=True, want_alpha=True):
+    """Ray / img / range gradients of :func:`trilinear_forward_channels_bricks` for grad_out
+    (B, C, N) on the volume-stationary bricks: the brick kernel writes the marcher's record with
+    every sample weighted by the incoming gradient of its channel,
+    ``ddrr_trilinear_backward_rays`` turns it into gradients.  Results as
+    :func:`trilinear_backward` (without g_volume)."""
+    B, N = _check_rays(volume, source, target, img)
+    H, W = int(det[0]), int(det[1])
+    C = grad_out.shape[1]
+    if grad_out.shape != (B, C, N):
+        raise ValueError(f"grad_out must be (B, C, N) = ({B}, C, {N}), got {tuple(grad_out.shape)}")
+    if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
+        raise ValueError("the brick path needs one source per pose and an H*W >= 2x2 ray grid")
+    dev = volume.device
+    aux = torch.empty(TRI_AUX_PLANES, B, N, dtype=torch.float32, device=dev)
+    ones = torch.ones(B, N, dtype=torch.float32, device=dev)
+    if not _empty(B, N):
+        labels_u8, volume, grad_out = labels_u8.contiguous(), volume.contiguous(), grad_out.contiguous()
+        source, target = source.contiguous(), target.contiguous()
+        _launch("ddrr_trilinear_backward_channels_bricks", dev, volume.data_ptr(),
+                labels_u8.data_ptr(), *volume.shape, source.data_ptr(), target.data_ptr(),
+                grad_out.data_ptr(), B, H, W, int(C), float(voxel_shift), float(eps), int(n_points),
+                alphamin.data_ptr(), alphamax.data_ptr(), aux.data_ptr(),
+                launch_workspace(volume.shape, dev).data_ptr())
+    return trilinear_backward_rays(aux, ones, source, target, img, alphamin, alphamax,
+                                   n_points=n_points, eps=eps, want_rays=want_rays,
+                                   want_img=want_img, want_alpha=want_alpha)
+
+
 def trilinear_forward_bricks(volume, source, target, img, alphamin, alphamax, det, *,
                              n_points=500, voxel_shift=0.5, eps=1e-8, want_aux=False):
     """Detector-grid trilinear march (bilinear, sum, align_corners=False) through the

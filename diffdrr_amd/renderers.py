@@ -764,9 +764,10 @@ class _TrilinearFn(torch.autograd.Function):
 
 
 class _TrilinearChannelsFn(torch.autograd.Function):
-    """The marcher's mask_to_channels (renderers.py:242-252): out (B,C,N); backward = one
-    ddrr_trilinear_backward_channels launch (every sample weighted by the incoming gradient
-    of the channel its nearest label selects)."""
+    """The marcher's mask_to_channels (renderers.py:242-252): out (B,C,N); backward = every sample
+    weighted by the incoming gradient of the channel its nearest label selects -- the weighted
+    record on the bricks for a detector grid without a volume gradient, one
+    ddrr_trilinear_backward_channels launch otherwise."""
 
     @staticmethod
     def forward(ctx, volume, source, target, img, alphamin, alphamax, labels, C, cfg):
@@ -794,13 +795,26 @@ class _TrilinearChannelsFn(torch.autograd.Function):
         volume, source, target, img, alphamin, alphamax, labels = ctx.saved_tensors
         cfg = ctx.cfg
         need_vol, need_s, need_t, need_i, need_a0, need_a1 = ctx.needs_input_grad[:6]
-        r = ops.trilinear_backward_channels(
-            volume, labels, source, target, img, grad_out, alphamin.reshape(1),
-            alphamax.reshape(1), n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"],
-            eps=cfg["eps"], align_corners=cfg["align_corners"],
-            want_rays=bool(need_s or need_t), want_img=bool(need_i),
-            want_alpha=bool(need_a0 or need_a1), want_volume=bool(need_vol), det=cfg["det"],
-            tile=cfg["tile"])
+        B, C, N = grad_out.shape
+        det = cfg["det"]
+        grid = (det is not None and det[0] * det[1] == N and source.shape[1] == 1
+                and min(det) >= 2 and not cfg["align_corners"])
+        if not need_vol and grid and cfg.get("bricks", True) and ops.channels_fit_bricks(B, C, N):
+            # no volume gradient asked: the weighted record on the bricks
+            # (ddrr_trilinear_backward_channels_bricks) instead of the per-ray re-march
+            r = ops.trilinear_backward_channels_bricks(
+                volume, labels, source, target, img, grad_out, alphamin.reshape(1),
+                alphamax.reshape(1), det, n_points=cfg["n_points"],
+                voxel_shift=cfg["voxel_shift"], eps=cfg["eps"], want_rays=bool(need_s or need_t),
+                want_img=bool(need_i), want_alpha=bool(need_a0 or need_a1))
+        else:
+            r = ops.trilinear_backward_channels(
+                volume, labels, source, target, img, grad_out, alphamin.reshape(1),
+                alphamax.reshape(1), n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"],
+                eps=cfg["eps"], align_corners=cfg["align_corners"],
+                want_rays=bool(need_s or need_t), want_img=bool(need_i),
+                want_alpha=bool(need_a0 or need_a1), want_volume=bool(need_vol), det=cfg["det"],
+                tile=cfg["tile"])
         g_s = g_t = g_a0 = g_a1 = g_i = None
         if need_s:
             g_s = r["g_source"].sum(dim=1, keepdim=True) if source.shape[1] == 1 \

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 26
+#define DDRR_ABI_VERSION 27
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -218,6 +218,21 @@ int ddrr_siddon_backward_channels_bricks(const float *volume, const unsigned cha
                                          const float *grad_out, int B, int det_h, int det_w, int C,
                                          float voxel_shift, float eps, float *aux, void *launch_ws,
                                          void *stream);
+
+/* The same for the marcher's channel render (ddrr_trilinear_forward_channels_bricks): the planar
+ * record of ddrr_trilinear_forward_bricks (DDRR_TRI_AUX_PLANES planes of B N floats, zero-filled
+ * by the call) with every sample's T and dT multiplied by grad_out[b, label of its nearest
+ * voxel, n] (labels >= C weigh 0), so that ddrr_trilinear_backward_rays(aux, ones (B, N), ...)
+ * returns d/d source, d/d target, d/d img and d/d alphamin, alphamax of sum_c grad_out_c out_c.
+ * The values are the staged words' (16-bit mantissas), as the forward rendered them.
+ * B * C * N < 2^30, N < 2^22.  (The volume gradient stays with ddrr_trilinear_backward_channels.) */
+int ddrr_trilinear_backward_channels_bricks(const float *volume, const unsigned char *labels,
+                                            int dx, int dy, int dz, const float *source,
+                                            const float *target, const float *grad_out, int B,
+                                            int det_h, int det_w, int C, float voxel_shift,
+                                            float eps, int n_points, const float *alphamin,
+                                            const float *alphamax, float *aux, void *launch_ws,
+                                            void *stream);
 
 /* Backward of ddrr_siddon_forward_channels: what autograd of renderers.py:77-89 (scatter_add
  * of the weighted segments into channels) returns for grad_out (B, C, N).  Outputs as in

@@ -251,8 +251,9 @@ def check_general_case(name, tag, device):
 def check_trilinear_channels_on_bricks(device, dims, det, n_points):
     """The marcher's mask_to_channels on the volume-stationary bricks
     (ddrr_trilinear_forward_channels_bricks) against the per-ray channel kernel (pinned to the
-    reference by the trilinear_mask fixture), the plain march, and through the module with
-    gradients (the backward is the per-ray channel kernel's)."""
+    reference by the trilinear_mask fixture), the plain march, its ray backward
+    (ddrr_trilinear_backward_channels_bricks) against the per-ray channel backward, and through
+    the module with gradients."""
     import torch
 
     from diffdrr_amd import DRR, Trilinear, convert, ops
@@ -290,7 +291,18 @@ def check_trilinear_channels_on_bricks(device, dims, det, n_points):
     ch8 = ops.trilinear_forward_channels_bricks(V, labels, 8, s, t, L, a0, a1, (H, W),
                                                 n_points=n_points).cpu().numpy()
     assert np.array_equal(ch8, ch[:, :8]) or rel_err(ch8, ch[:, :8]) < 1e-6
-    # the module route takes this kernel for a detector grid and stays differentiable
+    # the ray backward on the bricks (the weighted record) against the per-ray channel backward
+    # (pinned to the reference's autograd by the trilinear_mask fixture); labels >= 200 dropped
+    Cb = 200
+    B, N = L.shape
+    go = torch.rand(B, Cb, N, generator=torch.Generator().manual_seed(4)).to(device)
+    rb = ops.trilinear_backward_channels_bricks(V, labels, s, t, L, go, a0, a1, (H, W),
+                                                n_points=n_points)
+    rp = ops.trilinear_backward_channels(V, labels, s, t, L, go, a0, a1, n_points=n_points)
+    for key, tol in (("g_img", 3e-5), ("g_target", 2e-4), ("g_source", 2e-4), ("g_alpha", 2e-4)):
+        mine, want = rb[key].cpu().numpy(), rp[key].cpu().numpy()
+        assert rel_err(mine, want) < tol, (key, rel_err(mine, want))
+    # the module route takes these kernels for a detector grid and stays differentiable
     taken = []
     orig = ops.trilinear_forward_channels_bricks
     ops.trilinear_forward_channels_bricks = lambda *a, **k: (taken.append(1), orig(*a, **k))[1]

@@ -82,8 +82,10 @@ namespace {
 int tri_bricks_host(const float *volume, int dx, int dy, int dz, const float *source,
                     const float *target, const float *img, int B, int det_h, int det_w,
                     float voxel_shift, float eps, int n_points, float amin, float amax,
-                    float *out, float *aux, const unsigned char *labels = nullptr, int C = 0) {
-    // labels: mask_to_channels (out is (B, C, N)): packed words, tri_brick_march_channels
+                    float *out, float *aux, const unsigned char *labels = nullptr, int C = 0,
+                    const float *grad_cols = nullptr) {
+    // labels: mask_to_channels (out is (B, C, N)): packed words, tri_brick_march_channels;
+    // grad_cols (B, C, N): its ray backward instead -- the weighted record (tri_brick_march_weighted)
     const Dims D{dx, dy, dz};
     const int N = det_h * det_w;
     const long R = (long)B * N;
@@ -138,6 +140,17 @@ int tri_bricks_host(const float *volume, int dx, int dy, int dz, const float *so
                 float s[3], t[3], sumT, rec[6];
                 const long r = ray(pix, s, t);
                 const float L = img ? img[r] : 1.f;
+                if (labels && grad_cols) {
+                    const float *col = grad_cols + (long)b * C * N + pix;
+                    if (tri_brick_march_weighted(
+                            HostFetch{brick.data()}, 0.f, G, D, s, t, voxel_shift, eps, n_points, amin,
+                            amax, [&](unsigned lab) { return lab < (unsigned)C ? col[(long)lab * N] : 0.f; },
+                            sumT, rec)) {
+                        aux[r] += sumT;
+                        for (int k = 0; k < 6; ++k) aux[(k + 1) * R + r] += rec[k];
+                    }
+                    continue;
+                }
                 if (labels) {
                     float *col = out + (long)b * C * N + pix;
                     tri_brick_march_channels(HostFetch{brick.data()}, 0.f, G, D, s, t, voxel_shift, eps,
@@ -170,7 +183,7 @@ int tri_bricks_host(const float *volume, int dx, int dy, int dz, const float *so
             }
         }
     }
-    if (aux)
+    if (aux && out)
         for (long r = 0; r < R; ++r) out[r] = (img ? img[r] : 1.f) * step * aux[r];
     return 0;
 }
@@ -588,6 +601,18 @@ int ddrr_trilinear_forward_channels_bricks(const float *volume, const unsigned c
     memset(out, 0, sizeof(float) * (size_t)B * C * det_h * det_w);
     return tri_bricks_host(volume, dx, dy, dz, source, target, img, B, det_h, det_w, voxel_shift,
                            eps, n_points, *alphamin, *alphamax, out, nullptr, labels, C);
+}
+
+int ddrr_trilinear_backward_channels_bricks(const float *volume, const unsigned char *labels,
+                                            int dx, int dy, int dz, const float *source,
+                                            const float *target, const float *grad_out, int B,
+                                            int det_h, int det_w, int C, float voxel_shift,
+                                            float eps, int n_points, const float *alphamin,
+                                            const float *alphamax, float *aux, void *, void *) {
+    memset(aux, 0, sizeof(float) * (size_t)B * det_h * det_w * DDRR_TRI_AUX_PLANES);
+    return tri_bricks_host(volume, dx, dy, dz, source, target, nullptr, B, det_h, det_w,
+                           voxel_shift, eps, n_points, *alphamin, *alphamax, nullptr, aux, labels, C,
+                           grad_out);
 }
 
 int ddrr_trilinear_backward_rays(const float *aux, const float *grad_out, const float *source,

@@ -127,3 +127,24 @@ for B in (1, 8):
           f"render: bricks {t_chan:7.3f} ms = {t_chan / t_plain:5.2f} x plain bricks, per-ray kernel "
           f"{t_chan_r:7.3f} ms | channel sum vs plain {err:.1e}, bricks vs per-ray channels {err_r:.1e}",
           flush=True)
+    # the marcher's channel backward for rays / img / range: per-ray re-march against the weighted
+    # record on the bricks (ddrr_trilinear_backward_channels_bricks + ddrr_trilinear_backward_rays)
+    with torch.no_grad():
+        pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+        source, target = tri.detector(pose, None)
+        L = (target - source).norm(dim=-1).contiguous()
+        s_, t_ = tri.affine_inverse(source).contiguous(), tri.affine_inverse(target).contiguous()
+        a0, a1 = (x.reshape(1) for x in ops.trilinear_alpha_range(s_, t_, tri.density.shape))
+        go = torch.rand(B, C, H * H, device=dev)
+        tb_r, _ = timeit(lambda: ops.trilinear_backward_channels(tri.density, labels, s_, t_, L, go, a0, a1,
+                                                                 n_points=500, det=(H, H)))
+        tb_b, _ = timeit(lambda: ops.trilinear_backward_channels_bricks(tri.density, labels, s_, t_, L, go,
+                                                                        a0, a1, (H, H), n_points=500))
+        rb = ops.trilinear_backward_channels_bricks(tri.density, labels, s_, t_, L, go, a0, a1, (H, H),
+                                                    n_points=500)
+        rp = ops.trilinear_backward_channels(tri.density, labels, s_, t_, L, go, a0, a1, n_points=500,
+                                             det=(H, H))
+    errs = {k: float((rb[k] - rp[k]).abs().max() / rp[k].abs().max()) for k in ("g_img", "g_target", "g_alpha")}
+    print(f"trilinear B {B} channel backward, rays + img + range: per-ray kernel {tb_r:7.3f} ms | ON THE "
+          f"BRICKS {tb_b:7.3f} ms = {tb_r / tb_b:4.1f} x faster | bricks vs per-ray: "
+          + ", ".join(f"{k} {v:.1e}" for k, v in errs.items()), flush=True)
