@@ -450,6 +450,18 @@ class _SiddonPoseFn(torch.autograd.Function):
         return g_vol, g_M, None, None, None
 
 
+def _cat_channels(blocks):
+    """Channel blocks of the label chunks side by side (one chunk -- up to 256 labels -- is the
+    result itself: no copy of the (B, C, N) tensor)."""
+    blocks = list(blocks)
+    return blocks[0] if len(blocks) == 1 else torch.cat(blocks, dim=1)
+
+
+def _chunk(block, k0):
+    """A later label chunk's block without its placeholder channels below k0."""
+    return block if k0 == 0 else block[:, k0:]
+
+
 def _channels_use_bricks(cfg, source, N):
     """Whether a channel render / its ray backward may take the volume-stationary kernels: a
     detector grid, one source per pose, the brick path switched on."""
@@ -600,8 +612,8 @@ class Siddon(torch.nn.Module):
         cfg = self._cfg(False)
         if mask is not None:
             source, target, img = _RaygenFn.apply(Mw, P, Ainv)
-            return torch.cat([_SiddonChannelsFn.apply(volume, source, target, img, labels, C, cfg)[:, k0:]
-                              for labels, C, k0 in _labels_u8(mask)], dim=1)
+            return _cat_channels(_chunk(_SiddonChannelsFn.apply(volume, source, target, img, labels, C, cfg), k0)
+                                 for labels, C, k0 in _labels_u8(mask))
         return _SiddonPoseFn.apply(volume, Mw, P, Ainv, cfg).unsqueeze(1)
 
     def _general(self, volume, source, target, img, lookup, align_corners, mask):
@@ -635,9 +647,9 @@ class Siddon(torch.nn.Module):
             if f64 or lookup != "step":
                 return self._general(volume, source, target, img, lookup, align_corners, mask)
             cfg = self._cfg(align_corners, _grid_or_none(self, source, target), reducefn="sum")
-            return torch.cat([_SiddonChannelsFn.apply(volume, source, target, img.reshape(B, N),
-                                                      labels, C, cfg)[:, k0:]
-                              for labels, C, k0 in _labels_u8(mask)], dim=1)
+            return _cat_channels(_chunk(_SiddonChannelsFn.apply(volume, source, target, img.reshape(B, N),
+                                                                labels, C, cfg), k0)
+                                 for labels, C, k0 in _labels_u8(mask))
         if user_reduce:
             # a user reduction over the per-segment tensor (renderers.py:175-183,
             # introduction.ipynb:506-529): the tensor is materialised for it
@@ -994,9 +1006,9 @@ class Trilinear(torch.nn.Module):
                 ccfg = {"n_points": int(n_points), "voxel_shift": self.voxel_shift,
                         "eps": self.eps, "align_corners": bool(align_corners), "det": det,
                         "tile": self.tile, "bricks": self.use_bricks and self.channels_on_bricks}
-                return torch.cat([_TrilinearChannelsFn.apply(
+                return _cat_channels(_chunk(_TrilinearChannelsFn.apply(
                     volume, source, target, img.reshape(B, N), alphamin, alphamax, labels, C,
-                    ccfg)[:, k0:] for labels, C, k0 in _labels_u8(mask)], dim=1)
+                    ccfg), k0) for labels, C, k0 in _labels_u8(mask))
             labels = ops.trilinear_samples_general(
                 mask.to(volume), source.detach().to(volume), target.detach().to(volume), None,
                 alphamin.detach(), alphamax.detach(), n_points=int(n_points),
