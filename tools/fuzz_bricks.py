@@ -29,7 +29,7 @@ def ru(lo, hi, *shape):
     return lo + (hi - lo) * torch.rand(*shape, generator=g)
 
 
-worst = {"fwd": 0.0, "aux": 0.0, "volgrad": 0.0, "tri": 0.0, "trivol": 0.0, "q16": 0.0, "chan": 0.0}
+worst = {"fwd": 0.0, "aux": 0.0, "volgrad": 0.0, "tri": 0.0, "trivol": 0.0, "q16": 0.0, "chan": 0.0, "chan_bwd": 0.0, "chan_bwd_sum": 0.0}
 for case in range(a.cases):
     dims = (ri(20, 150), ri(20, 150), ri(20, 150))
     if case % 2 == 0:  # z a multiple of 4: the configurable kernels (bricks_fwd.hip) take the volume
@@ -38,6 +38,14 @@ for case in range(a.cases):
     B = ri(1, 5)
     spacing = tuple(float(x) for x in ru(0.5, 2.0, 3))
     vol = torch.rand(*dims, generator=g)
+    dist = (case // 4) % 4
+    if dist == 1:    # CT-like: air = 0, soft tissue ~1, a few bright voxels (metal) -> guarded bricks
+        vol = torch.where(vol < 0.3, torch.zeros(()), 0.9 + 0.2 * vol)
+        vol[torch.rand(*dims, generator=g) < 1e-3] = 40.0
+    elif dist == 2:  # mixed sign, wide range
+        vol = (vol - 0.5) * torch.exp(4.0 * torch.rand(*dims, generator=g))
+    elif dist == 3:  # sparse: mostly zeros (air bricks are skipped)
+        vol = vol * (torch.rand(*dims, generator=g) < 0.05)
     if a.smooth:  # a smooth field: neighbouring voxels differ by ~1 %
         ax = [torch.linspace(0, float(ru(2, 6, 1)), d) for d in dims]
         vol = 0.5 + 0.5 * torch.sin(ax[0])[:, None, None] * torch.cos(ax[1])[None, :, None] * torch.sin(ax[2] + 1.0)[None, None, :]
@@ -98,23 +106,36 @@ for case in range(a.cases):
             giq = ops.siddon_backward_rays(auxq, go, s, t, L)[2]
             e_q = max(e_q, ((giq - gig).abs().max() / (gig.abs().max() + 1e-30)).item())
     # mask_to_channels on the bricks against the per-ray channel kernels
-    e_c = 0.0
+    e_c = e_cb = e_cg = 0.0
     if min(H, W) >= 2:
         C = ri(2, 40)
         lab = torch.randint(0, C, tuple((d + 5) // 6 for d in dims), generator=g).to(torch.uint8)
         lab = lab.repeat_interleave(6, 0).repeat_interleave(6, 1).repeat_interleave(6, 2)
         lab = lab[:dims[0], :dims[1], :dims[2]].contiguous().to(dev)
+        if case % 3 == 0:
+            C = max(1, C - ri(1, 5))  # the highest labels have no channel
         cb = ops.siddon_forward_channels_bricks(V, lab, C, s, t, L, (H, W))
         cr = ops.siddon_forward_channels(V, lab, C, s, t, L)
         e_c = ((cb - cr).abs().max() / (cr.abs().max() + 1e-30)).item()
+        # the channel backward on the bricks (weighted record) against the per-ray kernel: d/d img
+        # to rounding, per-pose sums of d/d target (single rays may book a tie on the other axis)
+        goc = torch.rand(B, C, H * W, generator=g).to(dev)
+        bs, bt, bi = ops.siddon_backward_channels_bricks(V, lab, s, t, L, goc, (H, W))
+        ps, pt, pi, _ = ops.siddon_backward_channels(V, lab, s, t, L, goc, det=(H, W))
+        e_cb = ((bi - pi).abs().max() / (pi.abs().max() + 1e-30)).item()
+        e_cg = ((bt.sum(1) - pt.sum(1)).abs().max() / (pt.sum(1).abs().max() + 1e-30)).item()
         if amax.item() > amin.item():
             tcb = ops.trilinear_forward_channels_bricks(V, lab, C, s, t, L, amin, amax, (H, W), n_points=P)
             tcr = ops.trilinear_forward_channels(V, lab, C, s, t, L, amin, amax, n_points=P)
             e_c = max(e_c, ((tcb - tcr).abs().max() / (tcr.abs().max() + 1e-30)).item())
-    for k, e in zip(worst, (e_f, e_a, e_v, e_t, e_tv, e_q, e_c)):
+            rb = ops.trilinear_backward_channels_bricks(V, lab, s, t, L, goc, amin, amax, (H, W), n_points=P)
+            rp = ops.trilinear_backward_channels(V, lab, s, t, L, goc, amin, amax, n_points=P)
+            for k in ("g_img", "g_target", "g_source", "g_alpha"):
+                e_cb = max(e_cb, ((rb[k] - rp[k]).abs().max() / (rp[k].abs().max() + 1e-30)).item())
+    for k, e in zip(worst, (e_f, e_a, e_v, e_t, e_tv, e_q, e_c, e_cb, e_cg)):
         worst[k] = max(worst[k], e if e == e else float("inf"))
-    flag = " <<<" if max(e_f, e_v, e_t, e_tv, e_q, e_c) > 2e-4 or e_a > 5e-3 or e_f != e_f else ""
+    flag = " <<<" if max(e_f, e_v, e_t, e_tv, e_q, e_c, e_cb) > 2e-4 or max(e_a, e_cg) > 5e-3 or e_f != e_f else ""
     print(f"case {case:3d} kind {kind} dims {dims} det {H}x{W} B {B} P {P}: fwd {e_f:.1e} "
           f"pose-grad {e_a:.1e} volgrad {e_v:.1e} tri {e_t:.1e} trivol {e_tv:.1e} q16 {e_q:.1e} "
-          f"channels {e_c:.1e}{flag}", flush=True)
+          f"channels {e_c:.1e} chan-bwd {e_cb:.1e} / sums {e_cg:.1e} dist {dist}{flag}", flush=True)
 print("worst", {k: f"{v:.1e}" for k, v in worst.items()})
