@@ -65,9 +65,9 @@ struct FwdCfg {
     using Half = FwdCfg<BX_, BY_, BZ_ / 2, THREADS_, false>;  // (used where MIXED only)
     static constexpr int LDS_BRICK = MIXED && FALLBACK_BYTES > BRICK_BYTES ? FALLBACK_BYTES : BRICK_BYTES;
     // poses per row-table chunk: what the LDS left by the brick and the queues holds
-    static constexpr int ROW_ROOM = (LDS_BUDGET - LDS_BRICK - QUEUE_BYTES - 16) / (20 * 4);
+    static constexpr int ROW_ROOM = (LDS_BUDGET - LDS_BRICK - QUEUE_BYTES - 48) / (20 * 4);
     static constexpr int CHUNK = ROW_ROOM >= 32 ? 32 : ROW_ROOM;
-    static constexpr int LDS_MIN = LDS_BRICK + QUEUE_BYTES + CHUNK * 20 * 4 + 16;
+    static constexpr int LDS_MIN = LDS_BRICK + QUEUE_BYTES + CHUNK * 20 * 4 + 16 + 32;  // (+ counters, look-ahead slots)
     // what the waves have left in their queues at the end of a brick is pooled (one count per
     // wave and class) where the budget has the room for the counts
     static constexpr int POOL_BYTES = WAVES * kBuckets * 4;
@@ -332,6 +332,49 @@ __device__ __forceinline__ void fwd_stage_packed(const BrickArgs &p, unsigned ch
     for (int k = FULL * G * C::THREADS + tid; k < NV; k += C::THREADS) dst[k] = src[k];
 }
 
+// The packed image of brick `brick_id` into registers (issued by a wave that has nothing left to
+// walk in the brick in hand: the loads fly while the others finish) and from there into LDS.
+// (Native vector registers by name: HIP's uint4 is copied with memcpy, which keeps an object that
+// lives across the brick loop in scratch.)
+typedef unsigned int pf_u32x4 __attribute__((ext_vector_type(4)));  // (a native vector: plain loads / stores)
+template <class C>
+struct PackedPrefetch {
+    static constexpr int NV = C::BRICK_BYTES / 16, N = (NV + C::THREADS - 1) / C::THREADS;
+    static constexpr bool FITS = N <= 9;
+    pf_u32x4 v0, v1, v2, v3, v4, v5, v6, v7, v8;
+    template <int I>
+    __device__ __forceinline__ void load1(pf_u32x4 &v, const pf_u32x4 *src, int tid) {
+        if constexpr (I < N) {
+            const int k = I * C::THREADS + tid;
+            v = src[(I + 1) * C::THREADS <= NV || k < NV ? k : NV - 1];  // (clamped: unconditional)
+        }
+    }
+    template <int I>
+    __device__ __forceinline__ void store1(const pf_u32x4 &v, pf_u32x4 *dst, int tid) const {
+        if constexpr (I < N) {
+            const int k = I * C::THREADS + tid;
+            if ((I + 1) * C::THREADS <= NV || k < NV) dst[k] = v;
+        }
+    }
+    __device__ __forceinline__ void load(const BrickArgs &p, int brick_id, int tid) {
+        const pf_u32x4 *src = reinterpret_cast<const pf_u32x4 *>(p.packed + (size_t)brick_id * C::BRICK_BYTES);
+        load1<0>(v0, src, tid), load1<1>(v1, src, tid), load1<2>(v2, src, tid);
+        load1<3>(v3, src, tid), load1<4>(v4, src, tid), load1<5>(v5, src, tid);
+        load1<6>(v6, src, tid), load1<7>(v7, src, tid), load1<8>(v8, src, tid);
+    }
+    // (nothing held: without this on the paths that do not load, the old contents would stay live
+    // through the whole next iteration -- 36 registers the walk does not have)
+    __device__ __forceinline__ void clear() {
+        v0 = v1 = v2 = v3 = v4 = v5 = v6 = v7 = v8 = pf_u32x4{0u, 0u, 0u, 0u};
+    }
+    __device__ __forceinline__ void store(unsigned char *brick, int tid) const {
+        pf_u32x4 *dst = reinterpret_cast<pf_u32x4 *>(brick);
+        store1<0>(v0, dst, tid), store1<1>(v1, dst, tid), store1<2>(v2, dst, tid);
+        store1<3>(v3, dst, tid), store1<4>(v4, dst, tid), store1<5>(v5, dst, tid);
+        store1<6>(v6, dst, tid), store1<7>(v7, dst, tid), store1<8>(v8, dst, tid);
+    }
+};
+
 // One workgroup per brick: stage it exactly as the render kernel would and store the LDS image.
 template <class C>
 __global__ __launch_bounds__(C::THREADS) void brick_pack_kernel(BrickArgs p, int nby, int nbz,
@@ -353,6 +396,21 @@ __global__ __launch_bounds__(C::THREADS) void brick_pack_kernel(BrickArgs p, int
     for (int k = tid; k < NV; k += C::THREADS) dst[k] = lds[k];
 }
 
+// (profiling builds: stamps of a brick's stages behind the per-brick durations, 10 ns ticks from
+// the brick's start: [n_bricks + 8 brick + k]; k = 0 staged, 1 at the pool's barrier, 2 behind
+// it, 3 wave 0 out of work, 5 last wave out of work, 6 last walk done)
+#if defined(DDRR_BRICK_PROFILE)
+#define DDRR_TRACE(k, how)                                                                      \
+    if (p.brick_times && lane == 0) {                                                           \
+        const unsigned dt_ = (unsigned)__builtin_amdgcn_s_memrealtime() - (unsigned)ahead[6];   \
+        unsigned *slot_ = p.brick_times + n_bricks + 8 * brick_id + (k);                        \
+        if (how) atomicMax(slot_, dt_);                                                         \
+        else if (wave == 0) *slot_ = dt_;                                                       \
+    }
+#else
+#define DDRR_TRACE(k, how)
+#endif
+
 template <bool AUX, class C>
 __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict__ aux) {
@@ -362,7 +420,10 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
     FwdRow *rows = reinterpret_cast<FwdRow *>(queue + C::WAVES * kBuckets * kQueueCap);
     // [0] unit, [1] brick, [2] non-zero, [3] pooled batch; then the pool's counts
     int *counter = reinterpret_cast<int *>(rows + C::CHUNK);
-    int *pool = counter + 4;
+    // the look-ahead: [0] the item after the one in hand (-1: none), [1] its brick | kLaStage,
+    // [2], [3] the brick's (min, max); [4] the item after that (held until it is looked at)
+    volatile int *ahead = counter + 4;
+    int *pool = counter + 12;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nbx = (p.D.x + C::BX - 1) / C::BX, nby = (p.D.y + C::BY - 1) / C::BY;
@@ -383,22 +444,51 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
     // values -- one of its `n_sub` halves along z, taken one after the other
     int brick_id = 0, sub = 0, n_sub = 1, pose_lo = 0, pose_hi = p.B;
     bool f32_brick = !C::Q16;
+    // Looking ahead (packed 16-bit bricks).  A brick's fixed latencies -- the claim's atomic, the
+    // table lookups behind it, the brick's own bytes -- are what a launch of a few poses spends
+    // its time on (a registration step: one pose).  So while a brick is in hand, lane 0 of wave 1
+    // claims the item after the next one and looks up the next one's brick (order, fallback flag,
+    // range) -- nothing in one iteration depends on another request of the same iteration -- and a
+    // wave that has nothing left to walk requests its share of the next brick's image into
+    // registers: the loads fly while the other waves finish, and the next iteration starts with
+    // LDS stores.  Not in the last two rounds of the launch (an item held ahead there could wait
+    // behind its workgroup while others idle), not for bricks on the fp32 path (staged as before).
+    constexpr int kLaStage = 1 << 30;  // the next brick is known but staged the ordinary way
+    const bool LOOK = C::Q16 && PackedPrefetch<C>::FITS && p.packed != nullptr && !(p.dbg & 4096)
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+                      && p.split_t == 0
+#endif
+        ;
+    const int n_wg = (int)gridDim.x;
+    PackedPrefetch<C> pf;
+    pf.clear();
+    // (workgroup-uniform) la_item / la_brick / la_lo / la_hi: the next item as published by the
+    // iteration in hand, -1: none; la_loaded: its image is in `pf` (or it is empty)
+    int la_item = -1, la_brick = 0, la_after = -1;
+    float la_lo = 0.f, la_hi = 0.f;
+    bool la_loaded = false;
+    int item = 0;
     for (;;) {
         __syncthreads();  // every wave is done with the previous brick's LDS
         DDRR_PROF(PROF_BARRIER);
         const bool next_half = sub + 1 < n_sub;
+        const bool known = !next_half && la_item >= 0;  // no claim needed
+        const bool loaded = known && la_loaded;
         if (tid == 0) {
-            if (!next_half) counter[1] = atomicAdd(p.work, 1);
+            if (!next_half && !known) counter[1] = atomicAdd(p.work, 1);
             counter[2] = 0;
             counter[3] = 0;
         }
-        __syncthreads();
+        // (a brick that arrives in registers uses neither counter[1] nor [2]; [3] is read behind
+        // later barriers)
+        if (!loaded) __syncthreads();
+        float cur_lo = 0.f, cur_hi = 0.f;  // (the range of a brick that arrives in registers)
         if (next_half) {
             ++sub;
         } else {
             // Work items: bricks in the order p.order hands them out (heaviest first, see
             // brick_weight_kernel), every pose
-            const int item = counter[1];
+            item = known ? la_item : counter[1];
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
             // (tools builds: the last split_t bricks go out in split_s parts of the pose batch each --
             // measured, not adopted: the smaller batches cost more than the shorter tail gains)
@@ -413,17 +503,42 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
             if (item >= n_bricks) break;
             const int kth = item;
 #endif
-            brick_id = p.order ? p.order[kth] : kth;
+            brick_id = known ? la_brick : (p.order ? p.order[kth] : kth);
+            cur_lo = la_lo;
+            cur_hi = la_hi;
+            la_item = -1;  // (taken; la_after stays with the workgroup)
             sub = 0;
             n_sub = 1;
             if (C::MIXED) {
-                f32_brick = p.fallback && p.fallback[brick_id] != 0;
+                // (a brick that arrives in registers is a quantised one)
+                f32_brick = !loaded && p.fallback && p.fallback[brick_id] != 0;
                 const int z0 = (brick_id % nbz) * C::BZ;
                 n_sub = f32_brick && p.D.z - z0 > C::HZ ? 2 : 1;
             }
         }
+        // the requests of this iteration's look-ahead (lane 0 of wave 1; published before the
+        // staging barrier below): the item after the next -- unless this item's last part is not
+        // in hand yet, or the launch is in its last two rounds -- and the next item's brick
+        const bool last_part = sub + 1 >= n_sub;
+        const bool look = LOOK && last_part;
+        const bool claim = look && item + 2 * n_wg < n_bricks;
+        int nx_item = la_after;  // (claimed by an earlier iteration)
+        int req_item = -1, req_brick = 0, req_fb = 0;
+        float req_lo = 0.f, req_hi = 0.f;
+        if (tid == 64 && look) {
+            // (the workgroup's first look-ahead claims both, one after the other: once per launch)
+            if (nx_item < 0 && claim) nx_item = atomicAdd(p.work, 1);
+            if (claim) req_item = atomicAdd(p.work, 1);
+            if (nx_item >= 0 && nx_item < n_bricks) {
+                req_brick = p.order ? p.order[nx_item] : nx_item;
+                req_fb = C::MIXED && p.fallback ? p.fallback[req_brick] : 0;
+                req_lo = p.ranges[2 * req_brick];
+                req_hi = p.ranges[2 * req_brick + 1];
+            }
+        }
 #if defined(DDRR_BRICK_PROFILE)
         const unsigned long long brick_t0 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) ahead[6] = (int)(unsigned)brick_t0;  // (read behind the staging / pool barrier)
 #endif
         const int n_chunks = (pose_hi - pose_lo + C::CHUNK - 1) / C::CHUNK;
         const int chunk = n_chunks ? (pose_hi - pose_lo + n_chunks - 1) / n_chunks : 0;
@@ -447,6 +562,13 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
         int qn0 = 0, qn1 = 0, qn2 = 0;  // hits waiting per length class (wave-uniform)
         bool brick_empty = false, pool_open = false;
         Q16Range range = {0.f, 0.f, 0.f};
+        if (loaded) {
+            // the image was requested by the previous iteration: registers -> LDS (first, so that
+            // the registers are free again before the row table is worked out)
+            range = q16_range(cur_lo, cur_hi);
+            brick_empty = cur_lo == 0.f && cur_hi == 0.f;
+            if (!brick_empty) pf.store(brick, tid);
+        }
 
         for (int ch = 0; ch < n_chunks; ++ch) {  // chunks of at most C::CHUNK poses, of equal size
             const int b0 = pose_lo + ch * chunk;
@@ -467,7 +589,7 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
             }
             if (tid == 0) counter[0] = 0;
             DDRR_PROF(PROF_ROWS);
-            if (ch == 0) {
+            if (ch == 0 && !loaded) {
                 if constexpr (C::MIXED) {
                     if (f32_brick)
                         fwd_stage_brick<typename C::Half>(p, brick, box, brick_id, tid_here, range,
@@ -482,8 +604,16 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
                     fwd_stage_brick<C>(p, brick, box, brick_id, tid_here, range, brick_empty, counter);
                 }
             }
+            if (ch == 0 && look && tid == 64) {
+                ahead[0] = nx_item;
+                ahead[1] = req_brick | (req_fb ? kLaStage : 0);
+                ahead[2] = __float_as_int(req_lo);
+                ahead[3] = __float_as_int(req_hi);
+                ahead[4] = req_item;
+            }
             DDRR_PROF(PROF_STORE);
             __syncthreads();
+            if (ch == 0) DDRR_TRACE(0, 0)
             if ((!C::Q16 || f32_brick) && ch == 0) brick_empty = counter[2] == 0;
             // units per pose -> inclusive prefix, held by every wave in registers (lane k: pose k)
             int incl = lane < nb ? (rows[lane].count + 63) >> 6 : 0;
@@ -568,7 +698,9 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
                             // in the last chunk)
                             if (lane < kBuckets)
                                 pool[wave * kBuckets + lane] = lane == 0 ? qn0 : (lane == 1 ? qn1 : qn2);
+                            DDRR_TRACE(1, 0)
                             __syncthreads();
+                            DDRR_TRACE(2, 0)
                             DDRR_PROF(PROF_BARRIER);
                             pool_open = true;
                             continue;
@@ -626,6 +758,25 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
                 if (drain) break;
             }
         }
+        DDRR_TRACE(3, 0)
+        DDRR_TRACE(6, 1)
+        if (look) {
+            // what lane 0 of wave 1 published before this part's staging barrier; this wave has
+            // nothing left to walk: its share of the next brick's image, into registers
+            la_item = uni(ahead[0]);
+            la_after = uni(ahead[4]);
+            const int b = uni(ahead[1]);
+            la_brick = b & ~kLaStage;
+            la_lo = __int_as_float(uni(ahead[2]));
+            la_hi = __int_as_float(uni(ahead[3]));
+            la_loaded = la_item >= 0 && la_item < n_bricks && !(b & kLaStage);
+            const bool fetch = la_loaded && !(la_lo == 0.f && la_hi == 0.f);
+            if (fetch) pf.load(p, la_brick, tid);
+            else pf.clear();
+        } else {
+            pf.clear();
+        }
+        DDRR_TRACE(5, 1)
 #if defined(DDRR_BRICK_PROFILE)
         __syncthreads();
         if (tid == 0 && p.brick_times)

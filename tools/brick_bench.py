@@ -30,6 +30,7 @@ ap.add_argument("--variants", default="-2",
                      "2 32^3 16-bit, 10 32^3 16-bit x 2 workgroups per CU, 3 32x32x16 fp32 x 2, 4 / 6 double "
                      "16-bit bricks long in x / y, 7-9 anisotropic fp32 bricks 16x64x32, 64x16x32, 16x32x64; "
                      "16 + v / 32 + v: workgroup-shared rings of 12 / 8 length classes")
+ap.add_argument("--storage", default="auto", help="auto (by variant) | f32 | q16 | q16p")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 D, H = a.size, a.det
@@ -97,13 +98,15 @@ for lay, dbg, cl, var, sqw, order, split in itertools.product(
     lib.cdll.ddrr_set_brick_variant(var)
     lib.cdll.ddrr_set_brick_sq_width(ctypes.c_float(float(sqw)))
     storage = "q16" if var >= 0 and var % 16 in (1, 2, 4, 5, 6, 10) else "f32"
+    if a.storage != "auto":
+        storage = a.storage
     lib.cdll.ddrr_set_brick_debug(int(dbg))
     t1, t2 = (float(v) for v in cl.split(":"))
     import ctypes
     lib.cdll.ddrr_set_brick_classes(ctypes.c_float(t1), ctypes.c_float(t2))
     T_, S_ = (int(v) for v in split.split(":"))
     lib.cdll.ddrr_set_brick_split(T_, S_)
-    lay = f"dbg{dbg} cls{cl if var < 16 else sqw} var{var:2d} ord {order} split {split}"
+    lay = f"dbg{dbg} cls{cl if var < 16 else sqw} var{var:2d} {storage} ord {order} split {split}"
     rc = lib.cdll.ddrr_set_brick_layout(sy, sx)
     if rc != 0:
         print(f"layout {lay}: rejected")

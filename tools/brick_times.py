@@ -21,6 +21,7 @@ from tools.kernel_sweep import poses, rays, timeit  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", default="pert32,pert32aux")
 ap.add_argument("--variant", type=int, default=5)
+ap.add_argument("--storage", default=None, help="f32 | q16 | q16p (default: by variant)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 D, H = 512, 256
@@ -28,7 +29,7 @@ drr = DRR(make_subject(noise_volume(D, 0)), sdd=1020.0, height=H, delx=2.4).to(d
 V = drr.density
 lib = _lib.get_lib()
 lib.cdll.ddrr_set_brick_variant(a.variant)
-storage = "q16" if a.variant in (1, 2, 4, 5, 6, 10) else "f32"
+storage = a.storage or ("q16" if a.variant in (1, 2, 4, 5, 6, 10) else "f32")
 times = torch.zeros(32768, dtype=torch.int32, device=dev)
 
 
@@ -51,13 +52,19 @@ for case in a.cases.split(","):
         med, _ = timeit(fn)
         times.zero_()
         lib.cdll.ddrr_set_brick_times(ctypes.c_void_p(times.data_ptr()))
-        for _ in range(3):
-            fn()
+        fn()
         torch.cuda.synchronize()
-        d = times.cpu().float().numpy() * 0.01  # us
-        d = d[d > 0]
+        raw = times.cpu().float().numpy() * 0.01  # us
+        d = raw[:2048]
+        live = d > 0
+        tr = raw[2048:2048 + 8 * 2048].reshape(2048, 8)[live]
+        d = d[live]
         import numpy as np
         print(f"## {case}, {label}: launch {med * 1e3:.0f} us (median, profiling build), {len(d)} bricks: sum / 256 = "
               f"{d.sum() / 256:.0f} us, longest {d.max():.0f} us, mean {d.mean():.0f} us, p99 {np.percentile(d, 99):.0f} us | "
               f"list schedule in id order {schedule(d):.0f} us, by decreasing duration {schedule(sorted(d, reverse=True)):.0f} us",
               flush=True)
+        names = ("staged", "at pool barrier", "behind pool barrier", "wave 0 out of work", "next rows worked out",
+                 "last wave out of work", "last walk done")
+        print("   stages (us from the brick's start, mean over the bricks): "
+              + ", ".join(f"{n} {tr[:, k].mean():.1f}" for k, n in enumerate(names)), flush=True)

@@ -1,0 +1,4 @@
+#!/bin/bash
+# round 4: stage trace of single-pose launches with the look-ahead (lazy staging on / off)
+OUT=gpurun_out/r04t; mkdir -p $OUT
+(timeout 600 python tools/brick_times.py --cases pert1,pert1aux --variant=-2 --storage q16p) 2>&1 | grep -v amdgpu.ids > $OUT/brick_times_few_poses.txt; cat $OUT/brick_times_few_poses.txt
