@@ -452,9 +452,12 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
     // wave that has nothing left to walk requests its share of the next brick's image into
     // registers: the loads fly while the other waves finish, and the next iteration starts with
     // LDS stores.  Not in the last two rounds of the launch (an item held ahead there could wait
-    // behind its workgroup while others idle), not for bricks on the fp32 path (staged as before).
+    // behind its workgroup while others idle), not for bricks on the fp32 path (staged as before),
+    // and not for more poses than one chunk: bricks that take long have nothing to hide, and the
+    // items held ahead cost the launch's end its balance (64 poses: +1.5 %, 512: +5 %;
+    // profiles/r04/look_ahead.txt).
     constexpr int kLaStage = 1 << 30;  // the next brick is known but staged the ordinary way
-    const bool LOOK = C::Q16 && PackedPrefetch<C>::FITS && p.packed != nullptr && !(p.dbg & 4096)
+    const bool LOOK = C::Q16 && PackedPrefetch<C>::FITS && p.packed != nullptr && p.B <= C::CHUNK && !(p.dbg & 4096)
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
                       && p.split_t == 0
 #endif
