@@ -143,3 +143,51 @@ def test_channel_backward_through_the_module_takes_the_bricks(gpu, monkeypatch):
     assert calls == [1]
     for a, b in zip(grads[True], grads[False]):
         assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max())  # (tie flips: see conftest)
+
+
+@pytest.mark.parametrize("B", [1, 5, 32])
+def test_look_ahead_over_quantised_empty_and_fp32_bricks(gpu, B):
+    """The brick kernel's look-ahead (bricks_fwd.hip: the item after the next claimed ahead, its
+    brick looked up by a spare lane, its packed image requested into registers by waves that have
+    run out of work) only engages with more than two bricks per workgroup to go: a 256 x 384 x 768
+    volume (1152 bricks of 32 x 32 x 64) made of slabs of air (empty bricks: nothing to load), smooth
+    tissue (quantised bricks: prefetched) and tissue with bright voxels (bricks on the fp32 path:
+    staged the ordinary way, as two halves), so that every kind follows every other.  One pose, a
+    few, a full chunk: image and record against the per-ray kernel and against the fp32 bricks."""
+    from diffdrr_amd import DRR, convert
+    from diffdrr_amd.data import make_subject
+
+    g = torch.Generator().manual_seed(3)
+    D = (256, 384, 768)
+    vol = 0.8 + 0.4 * torch.rand(*D, generator=g)
+    kind = torch.randint(0, 3, (8, 12, 12), generator=g)  # per 32 x 32 x 64 brick: air / tissue / metal
+    kind = kind.repeat_interleave(32, 0).repeat_interleave(32, 1).repeat_interleave(64, 2)
+    vol[kind == 0] = 0.0
+    metal = (kind == 2) & (torch.rand(*D, generator=g) < 2e-4)
+    vol[metal] = 60.0
+    H, W = 48, 64
+    drr = DRR(make_subject(vol, spacing=(1.0, 1.0, 1.0)), sdd=1200.0, height=H, width=W, delx=8.0).to(gpu)
+    rot = ((torch.rand(B, 3, generator=g) - 0.5) * 1.2).to(gpu)
+    xyz = (torch.tensor([0.0, 900.0, 0.0]) + (torch.rand(B, 3, generator=g) - 0.5) * 60).to(gpu)
+    with torch.no_grad():
+        pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+        source, target = drr.detector(pose, None)
+        L = (target - source).norm(dim=-1).contiguous()
+        s, t = drr.affine_inverse(source).contiguous(), drr.affine_inverse(target).contiguous()
+    V = drr.density
+    ref, aux_ref, _ = ops.siddon_forward(V, s, t, L, want_aux=True)
+    scale = float(ref.abs().max())
+    assert scale > 0
+    for storage in ("q16p", "q16p"):  # (the first call builds the packed copy, the second reuses it)
+        out, aux = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True, storage=storage)
+        fwd, _ = ops.siddon_forward_bricks(V, s, t, L, (H, W), storage=storage)
+        n_f32, n = ops.brick_fallbacks(V, storage)
+        assert n == 1152 and 200 < n_f32 < 600
+        assert float((out - ref).abs().max()) < 1e-4 * scale
+        assert float((fwd - ref).abs().max()) < 1e-4 * scale
+        go = torch.ones_like(ref)
+        gi = ops.siddon_backward_rays(aux, go, s, t, L)[2]
+        gi_ref = ops.siddon_backward_rays(aux_ref, go, s, t, L)[2]
+        assert float((gi - gi_ref).abs().max()) < 1e-4 * float(gi_ref.abs().max())
+    f32, _ = ops.siddon_forward_bricks(V, s, t, L, (H, W), storage="f32")
+    assert float((fwd - f32).abs().max()) < 1e-4 * scale
