@@ -362,6 +362,53 @@ struct PackedPrefetch {
         load1<3>(v3, src, tid), load1<4>(v4, src, tid), load1<5>(v5, src, tid);
         load1<6>(v6, src, tid), load1<7>(v7, src, tid), load1<8>(v8, src, tid);
     }
+    template <int I>
+    __device__ __forceinline__ pf_u32x4 &reg() {
+        if constexpr (I == 0) return v0;
+        else if constexpr (I == 1) return v1;
+        else if constexpr (I == 2) return v2;
+        else if constexpr (I == 3) return v3;
+        else if constexpr (I == 4) return v4;
+        else if constexpr (I == 5) return v5;
+        else if constexpr (I == 6) return v6;
+        else if constexpr (I == 7) return v7;
+        else return v8;
+    }
+    // A brick on the fp32 path: the half `box` (H: its configuration, C::Half) from the volume's own
+    // values, one round of fwd_stage_brick<H>'s loads held in the same registers, and its stores.
+    template <class H, int I>
+    __device__ __forceinline__ void half1(const BrickArgs &p, unsigned char *brick, const Box &box,
+                                          int tid, bool load) {
+        constexpr int QZ = H::BZ / 4, NQ = H::BX * H::BY * QZ / H::THREADS;
+        constexpr int ROWS_PER_PASS = H::THREADS / QZ;
+        static_assert(NQ <= 9, "a half's quads per thread must fit the prefetch registers");
+        if constexpr (I < NQ) {
+            const int qz4 = (tid % QZ) * 4, row = tid / QZ + I * ROWS_PER_PASS;
+            const int lx = row / H::BY, ly = row - lx * H::BY;
+            const int x = box.lo[0] + lx, y = box.lo[1] + ly, z = box.lo[2] + qz4;
+            const bool in_z = z + 4 <= box.hi[2];  // (z and D.z are multiples of 4)
+            if (load) {
+                // clamped (always readable) address; what lies outside is zeroed by the store
+                const int xc = x < p.D.x ? x : p.D.x - 1, yc = y < p.D.y ? y : p.D.y - 1;
+                const long at = ((long)xc * p.D.y + yc) * p.D.z + (in_z ? z : 0);
+                reg<I>() = *reinterpret_cast<const pf_u32x4 *>(p.vol + at);
+            } else {
+                pf_u32x4 q = reg<I>();
+                if (!(in_z && x < box.hi[0] && y < box.hi[1])) q = pf_u32x4{0u, 0u, 0u, 0u};
+                unsigned *d = reinterpret_cast<unsigned *>(brick + lx * H::SX + ly * H::SY + qz4 * 4);
+                d[0] = q.x, d[1] = q.y, d[2] = q.z, d[3] = q.w;
+            }
+        }
+    }
+    template <class H>
+    __device__ __forceinline__ void half(const BrickArgs &p, unsigned char *brick, const Box &box, int tid,
+                                         bool load) {
+        half1<H, 0>(p, brick, box, tid, load), half1<H, 1>(p, brick, box, tid, load);
+        half1<H, 2>(p, brick, box, tid, load), half1<H, 3>(p, brick, box, tid, load);
+        half1<H, 4>(p, brick, box, tid, load), half1<H, 5>(p, brick, box, tid, load);
+        half1<H, 6>(p, brick, box, tid, load), half1<H, 7>(p, brick, box, tid, load);
+        half1<H, 8>(p, brick, box, tid, load);
+    }
     // (nothing held: without this on the paths that do not load, the old contents would stay live
     // through the whole next iteration -- 36 registers the walk does not have)
     __device__ __forceinline__ void clear() {
@@ -451,12 +498,12 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
     // range) -- nothing in one iteration depends on another request of the same iteration -- and a
     // wave that has nothing left to walk requests its share of the next brick's image into
     // registers: the loads fly while the other waves finish, and the next iteration starts with
-    // LDS stores.  Not in the last two rounds of the launch (an item held ahead there could wait
-    // behind its workgroup while others idle), not for bricks on the fp32 path (staged as before),
+    // LDS stores (a brick on the fp32 path: one half's values at a time).  Not in the last two rounds
+    // of the launch (an item held ahead there could wait behind its workgroup while others idle),
     // and not for more poses than one chunk: bricks that take long have nothing to hide, and the
     // items held ahead cost the launch's end its balance (64 poses: +1.5 %, 512: +5 %;
     // profiles/r04/look_ahead.txt).
-    constexpr int kLaStage = 1 << 30;  // the next brick is known but staged the ordinary way
+    constexpr int kLaStage = 1 << 30;  // the next brick is on the fp32 path (its halves are requested one by one)
     const bool LOOK = C::Q16 && PackedPrefetch<C>::FITS && p.packed != nullptr && p.B <= C::CHUNK && !(p.dbg & 4096)
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
                       && p.split_t == 0
@@ -469,14 +516,18 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
     // iteration in hand, -1: none; la_loaded: its image is in `pf` (or it is empty)
     int la_item = -1, la_brick = 0, la_after = -1;
     float la_lo = 0.f, la_hi = 0.f;
-    bool la_loaded = false;
+    bool la_f32 = false;  // the next item's brick is on the fp32 path
+    // what `pf` holds for the unit (brick, or half of a brick on the fp32 path) after the one in
+    // hand: 0 nothing, 1 the packed image of a quantised brick (or nothing to load: air), 2 a half's
+    // fp32 values
+    int pf_kind = 0;
     int item = 0;
     for (;;) {
         __syncthreads();  // every wave is done with the previous brick's LDS
         DDRR_PROF(PROF_BARRIER);
         const bool next_half = sub + 1 < n_sub;
         const bool known = !next_half && la_item >= 0;  // no claim needed
-        const bool loaded = known && la_loaded;
+        const bool loaded = pf_kind != 0;
         if (tid == 0) {
             if (!next_half && !known) counter[1] = atomicAdd(p.work, 1);
             counter[2] = 0;
@@ -513,8 +564,7 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
             sub = 0;
             n_sub = 1;
             if (C::MIXED) {
-                // (a brick that arrives in registers is a quantised one)
-                f32_brick = !loaded && p.fallback && p.fallback[brick_id] != 0;
+                f32_brick = known ? la_f32 : (p.fallback && p.fallback[brick_id] != 0);
                 const int z0 = (brick_id % nbz) * C::BZ;
                 n_sub = f32_brick && p.D.z - z0 > C::HZ ? 2 : 1;
             }
@@ -565,12 +615,16 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
         int qn0 = 0, qn1 = 0, qn2 = 0;  // hits waiting per length class (wave-uniform)
         bool brick_empty = false, pool_open = false;
         Q16Range range = {0.f, 0.f, 0.f};
-        if (loaded) {
+        if (pf_kind == 1) {
             // the image was requested by the previous iteration: registers -> LDS (first, so that
             // the registers are free again before the row table is worked out)
             range = q16_range(cur_lo, cur_hi);
             brick_empty = cur_lo == 0.f && cur_hi == 0.f;
             if (!brick_empty) pf.store(brick, tid);
+        }
+        if constexpr (C::MIXED) {
+            // (a half that arrives in registers is walked whatever it holds: no count of non-zeros)
+            if (pf_kind == 2) pf.template half<typename C::Half>(p, brick, box, tid, false);
         }
 
         for (int ch = 0; ch < n_chunks; ++ch) {  // chunks of at most C::CHUNK poses, of equal size
@@ -617,7 +671,7 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
             DDRR_PROF(PROF_STORE);
             __syncthreads();
             if (ch == 0) DDRR_TRACE(0, 0)
-            if ((!C::Q16 || f32_brick) && ch == 0) brick_empty = counter[2] == 0;
+            if ((!C::Q16 || f32_brick) && ch == 0 && !loaded) brick_empty = counter[2] == 0;
             // units per pose -> inclusive prefix, held by every wave in registers (lane k: pose k)
             int incl = lane < nb ? (rows[lane].count + 63) >> 6 : 0;
 #pragma unroll
@@ -763,19 +817,37 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
         }
         DDRR_TRACE(3, 0)
         DDRR_TRACE(6, 1)
-        if (look) {
-            // what lane 0 of wave 1 published before this part's staging barrier; this wave has
-            // nothing left to walk: its share of the next brick's image, into registers
+        // this wave has nothing left to walk: its share of the next unit, into registers
+        pf_kind = 0;
+        int half_of = -1, half_sub = 0;  // (a brick on the fp32 path whose half comes next)
+        if (C::MIXED && LOOK && !last_part) {
+            half_of = brick_id;  // the other half of the brick in hand
+            half_sub = sub + 1;
+        } else if (look) {
+            // what lane 0 of wave 1 published before this part's staging barrier
             la_item = uni(ahead[0]);
             la_after = uni(ahead[4]);
             const int b = uni(ahead[1]);
             la_brick = b & ~kLaStage;
             la_lo = __int_as_float(uni(ahead[2]));
             la_hi = __int_as_float(uni(ahead[3]));
-            la_loaded = la_item >= 0 && la_item < n_bricks && !(b & kLaStage);
-            const bool fetch = la_loaded && !(la_lo == 0.f && la_hi == 0.f);
-            if (fetch) pf.load(p, la_brick, tid);
-            else pf.clear();
+            la_f32 = (b & kLaStage) != 0;
+            if (la_item >= 0 && la_item < n_bricks) {
+                if (la_f32) half_of = la_brick;
+                else pf_kind = 1;
+            }
+        }
+        if (pf_kind == 1 && !(la_lo == 0.f && la_hi == 0.f)) {
+            pf.load(p, la_brick, tid);
+        } else if (C::MIXED && half_of >= 0) {
+            if constexpr (C::MIXED) {
+                Box nbox = cfg_brick_box<C>(p.D, nby, nbz, half_of);
+                nbox.lo[2] += half_sub * C::HZ;
+                nbox.hi[2] = nbox.lo[2] + C::HZ < nbox.hi[2] ? nbox.lo[2] + C::HZ : nbox.hi[2];
+                pf.clear();
+                pf.template half<typename C::Half>(p, brick, nbox, tid, true);
+                pf_kind = 2;
+            }
         } else {
             pf.clear();
         }
