@@ -615,16 +615,20 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
         int qn0 = 0, qn1 = 0, qn2 = 0;  // hits waiting per length class (wave-uniform)
         bool brick_empty = false, pool_open = false;
         Q16Range range = {0.f, 0.f, 0.f};
+        // (the thread's offsets into the image are worked out where they are used: hoisted out of
+        // the brick loop they cost the walk two registers it does not have)
+        int tid_pf = tid;
+        asm volatile("" : "+v"(tid_pf));
         if (pf_kind == 1) {
             // the image was requested by the previous iteration: registers -> LDS (first, so that
             // the registers are free again before the row table is worked out)
             range = q16_range(cur_lo, cur_hi);
             brick_empty = cur_lo == 0.f && cur_hi == 0.f;
-            if (!brick_empty) pf.store(brick, tid);
+            if (!brick_empty) pf.store(brick, tid_pf);
         }
         if constexpr (C::MIXED) {
             // (a half that arrives in registers is walked whatever it holds: no count of non-zeros)
-            if (pf_kind == 2) pf.template half<typename C::Half>(p, brick, box, tid, false);
+            if (pf_kind == 2) pf.template half<typename C::Half>(p, brick, box, tid_pf, false);
         }
 
         for (int ch = 0; ch < n_chunks; ++ch) {  // chunks of at most C::CHUNK poses, of equal size
@@ -837,15 +841,17 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
                 else pf_kind = 1;
             }
         }
+        int tid_ld = tid;
+        asm volatile("" : "+v"(tid_ld));
         if (pf_kind == 1 && !(la_lo == 0.f && la_hi == 0.f)) {
-            pf.load(p, la_brick, tid);
+            pf.load(p, la_brick, tid_ld);
         } else if (C::MIXED && half_of >= 0) {
             if constexpr (C::MIXED) {
                 Box nbox = cfg_brick_box<C>(p.D, nby, nbz, half_of);
                 nbox.lo[2] += half_sub * C::HZ;
                 nbox.hi[2] = nbox.lo[2] + C::HZ < nbox.hi[2] ? nbox.lo[2] + C::HZ : nbox.hi[2];
                 pf.clear();
-                pf.template half<typename C::Half>(p, brick, nbox, tid, true);
+                pf.template half<typename C::Half>(p, brick, nbox, tid_ld, true);
                 pf_kind = 2;
             }
         } else {
