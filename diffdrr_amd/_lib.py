@@ -15,7 +15,7 @@ from ctypes import c_double, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffdrr_hip.so")
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 REDUCE_SUM, REDUCE_MAX = 0, 1
 LOOKUP_STEP, LOOKUP_MID_NEAREST, LOOKUP_MID_TRILINEAR = 0, 1, 2
@@ -42,6 +42,8 @@ _SIGNATURES = {
                                             _P, _P, _P],
     "ddrr_siddon_backward_channels_bricks": [_P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _F,
                                              _P, _P, _P],
+    "ddrr_siddon_backward_channels_volume_bricks": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _F,
+                                                    _F, _P, _P, _P],
     "ddrr_trilinear_backward_channels_bricks": [_P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F,
                                                 _F, _I, _P, _P, _P, _P, _P],
     "ddrr_trilinear_alpha_range": [_P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P],

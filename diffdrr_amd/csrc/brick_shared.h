@@ -31,7 +31,7 @@ struct BrickArgs {
     float t1, t2;        // length-class thresholds on the estimated crossing count
     int dbg;             // experiment switches (tools builds with -DDDRR_EXPERIMENTS; else 0)
     int *work;           // global brick counter of this launch (zero at launch)
-    const float *grad_out;  // *_VOLGRAD: dLoss/dout (B, N); BRICK_[TRI_]CHANNELS_AUX: (B, n_channels, N)
+    const float *grad_out;  // *_VOLGRAD: dLoss/dout (B, N); BRICK_[TRI_]CHANNELS_AUX, BRICK_CHANNELS_VOLGRAD: (B, n_channels, N)
     float *g_volume;        // *_VOLGRAD: dLoss/dvolume
     int n_points;           // BRICK_TRI_*: samples per ray
     const float *amin, *amax;  // BRICK_TRI_*: device scalars (renderers.py:220-223)
@@ -105,6 +105,7 @@ constexpr int BRICK_CHANNELS = 6;     // out (B, C, N): one line integral per la
 constexpr int BRICK_TRI_CHANNELS = 7; // trilinear marcher, out (B, C, N): samples by the label of their nearest voxel
 constexpr int BRICK_CHANNELS_AUX = 8; // backward of BRICK_CHANNELS w.r.t. the rays: the record of the volume weighted by grad_out[b, label, n]
 constexpr int BRICK_TRI_CHANNELS_AUX = 9;  // backward of BRICK_TRI_CHANNELS w.r.t. the rays: the marcher's record weighted by grad_out[b, label, n]
+constexpr int BRICK_CHANNELS_VOLGRAD = 10;  // backward of BRICK_CHANNELS w.r.t. the volume: the LDS accumulator's words carry the voxel's label in their low byte
 
 
 #if defined(__HIPCC__)

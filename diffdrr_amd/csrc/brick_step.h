@@ -678,6 +678,46 @@ DDRR_HD bool step_scatter(const Add &add, unsigned base_bits, const StepGeom &G,
     return true;
 }
 
+// The volume gradient of the channel render inside one brick (reference renderers.py:77-89,
+// autograd w.r.t. the volume): every voxel the ray crosses receives len L grad_out[b, label, n].
+// step_scatter with the weight of the voxel's own label: `label(addr)` looks the label of the
+// voxel at LDS byte address `addr` up, `weight(label)` gathers the incoming gradient of the ray's
+// column -- only when the label changes along the ray.
+template <class Add, class Label, class Weight>
+DDRR_HD bool step_scatter_weighted(const Add &add, const Label &label, const Weight &weight,
+                                   unsigned base_bits, const StepGeom &G, const float s[3],
+                                   const float t[3], float shift, float eps, float L) {
+    const StepEntry E = step_enter(G, s, t, shift, eps, base_bits);
+    if (!E.hit) return false;
+    float kr0 = 0.f, kr1 = 0.f, kr2 = 0.f;
+    float an0 = E.an[0], an1 = E.an[1], an2 = E.an[2];
+    const float sb0 = in_vgpr(G.strideb[0]), sb1 = in_vgpr(G.strideb[1]);
+    const float sb2 = in_vgpr(G.strideb[2]);
+    const float nbig = in_vgpr(-kSelBig), one = in_vgpr(1.f);
+    float a_cur = E.entry, w = 0.f;
+    int cur = -1;
+    for (int it = 0; it < 3 * BRICK + 4; ++it) {
+        const unsigned addr =
+            float_bits(fmaf(kr0, sb0, fmaf(kr1, sb1, fmaf(kr2, sb2, E.offc))));
+        const float a_next = fminf(fminf(an0, an1), an2);
+        const int lab = (int)label(addr);
+        if (lab != cur) {
+            cur = lab;
+            w = weight((unsigned)lab) * L;
+        }
+        add(addr, w * (a_next - a_cur));
+        if (!(a_next < E.exit)) break;
+        kr0 = fmaf(sel_zero(an0 - a_next, nbig, one), E.dirf[0], kr0);
+        kr1 = fmaf(sel_zero(an1 - a_next, nbig, one), E.dirf[1], kr1);
+        kr2 = fmaf(sel_zero(an2 - a_next, nbig, one), E.dirf[2], kr2);
+        an0 = fmaf(kr0, E.inv[0], E.a0[0]);
+        an1 = fmaf(kr1, E.inv[1], E.a0[1]);
+        an2 = fmaf(kr2, E.inv[2], E.a0[2]);
+        a_cur = a_next;
+    }
+    return true;
+}
+
 // Exact clip + walk of a 16-bit brick (G: its byte strides as bit-pattern floats).
 template <bool AUX, int MAXSTEPS, class Fetch>
 DDRR_HD bool step_trace_q16(const Fetch &fetch, unsigned base_bits, const StepGeom &G,

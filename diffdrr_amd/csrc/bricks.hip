@@ -74,6 +74,43 @@ struct LdsAbsAdd {
     }
 };
 
+// The same into the upper 24 bits of the word (BRICK_CHANNELS_VOLGRAD): the low byte holds the
+// voxel's label, which sums of multiples of 256 never touch.  q: counts per unit, for 23 bits.
+// (Fewer label bits for fewer channels -- variable shifts -- cost 20 % and bought no accuracy: a
+// voxel's gradient is one or two segment lengths, and those carry the 1e-4 of a difference of two
+// fp32 alphas whatever the accumulator.)
+struct LdsAbsAddHigh {
+    float q;
+    __device__ __forceinline__ void operator()(unsigned addr, float v) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __hip_atomic_fetch_add((int *)(__attribute__((address_space(3))) int *)(unsigned long long)addr,
+                               __float2int_rn(v * q) << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        (void)addr;
+        (void)v;
+#endif
+    }
+};
+// ... and the label of the voxel at an LDS address: that low byte,
+struct LdsLabelLow {
+    __device__ __forceinline__ unsigned operator()(unsigned addr) const {
+        return float_bits(LdsAbsFetch{}(addr)) & 0xffu;
+    }
+};
+// or -- no bound on a voxel's sum, float accumulators (see LdsAbsAdd) -- the label map itself,
+// at the voxel the address belongs to (byte strides of the LDS copy: 4 sx, 4 sy, 4).
+struct GlobalLabelOf {
+    const unsigned char *labels;
+    Dims D;
+    int lo[3];
+    unsigned base, sx4, sy4;
+    __device__ __forceinline__ unsigned operator()(unsigned addr) const {
+        const unsigned off = addr - base, lx = off / sx4, r = off - lx * sx4, ly = r / sy4;
+        const unsigned lz = (r - ly * sy4) >> 2;
+        return labels[((long)(lo[0] + (int)lx) * D.y + (lo[1] + (int)ly)) * D.z + (lo[2] + (int)lz)];
+    }
+};
+
 // A finished label run of a ray's walk through a brick goes to the ray's output column
 // (B, C, N): one fire-and-forget atomic per run.  32-bit offsets: the host checks B C N < 2^30.
 // SCALED: L multiplies every run (else the walk carries it); CHECKED: labels >= C are dropped here
@@ -196,6 +233,20 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
             step_scatter(LdsAbsAdd{fixq}, LdsAbsFetch::base_of(brick), SG, s, t, p.shift, p.eps, w);
         return;
     }
+    if (MODE == BRICK_CHANNELS_VOLGRAD) {
+        const unsigned N = (unsigned)(p.det_h * p.det_w), C = (unsigned)p.n_channels;
+        const BrickColumnWeight<true> weight{p.grad_out, (b * C * N + pix) * 4u, N * 4u, C};
+        const unsigned lbase = LdsAbsFetch::base_of(brick);
+        if (fixq != 0.f) {
+            step_scatter_weighted(LdsAbsAddHigh{fixq}, LdsLabelLow{}, weight, lbase, SG, s, t, p.shift,
+                                  p.eps, L);
+        } else {
+            const GlobalLabelOf label{p.labels, p.D, {(int)G.lof[0], (int)G.lof[1], (int)G.lof[2]}, lbase,
+                                      (unsigned)p.lay.sx * 4u, (unsigned)p.lay.sy * 4u};
+            step_scatter_weighted(LdsAbsAdd{0.f}, label, weight, lbase, SG, s, t, p.shift, p.eps, L);
+        }
+        return;
+    }
     if (MODE == BRICK_TRI_VOLGRAD) {
         const float a0 = p.amin[0], a1 = p.amax[0];
         const float w = p.grad_out[r] * L * ((a1 - a0) / (float)(p.n_points - 1));
@@ -294,7 +345,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     constexpr bool TRI = MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_FWD_AUX || MODE == BRICK_TRI_CHANNELS ||
                          MODE == BRICK_TRI_CHANNELS_AUX;
     constexpr bool TRI_OWNER = MODE == BRICK_TRI_VOLGRAD;
-    constexpr bool GRAD = MODE == BRICK_VOLGRAD || MODE == BRICK_TRI_VOLGRAD;
+    constexpr bool GRAD = MODE == BRICK_VOLGRAD || MODE == BRICK_TRI_VOLGRAD || MODE == BRICK_CHANNELS_VOLGRAD;
+    constexpr bool GRADL = MODE == BRICK_CHANNELS_VOLGRAD;  // ... with the labels in the accumulator's words
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *brick = reinterpret_cast<float *>(smem_raw);
     unsigned *queue = reinterpret_cast<unsigned *>(brick + brick_floats(p.lay));
@@ -315,7 +367,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                          (reinterpret_cast<uintptr_t>(p.labels) & 3) == 0);
     const bool vec_out = GRAD && (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.g_volume) & 15) == 0;
     const bool labels_dword_ok = (MODE == BRICK_CHANNELS || MODE == BRICK_TRI_CHANNELS ||
-                                  MODE == BRICK_CHANNELS_AUX || MODE == BRICK_TRI_CHANNELS_AUX) &&
+                                  MODE == BRICK_CHANNELS_AUX || MODE == BRICK_TRI_CHANNELS_AUX || GRADL) &&
                                  (reinterpret_cast<uintptr_t>(p.labels) & 3) == 0;
     // fixed-point scale of the LDS accumulator (volume-gradient modes): the largest sum a
     // voxel can receive is n_sum (contributions) * wmax (each) -- volgrad_prepare_kernel
@@ -323,8 +375,9 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     if (GRAD && !(p.dbg & 32)) {
         const float wmax = __uint_as_float((unsigned)p.work[1]);
         const float n_sum = reinterpret_cast<const float *>(p.work)[2];
+        // (the channel gradient keeps the voxel's label in the word's low byte: 24 bits)
         if (wmax > 0.f && wmax < 1e30f && n_sum > 0.f && n_sum <= 16384.f)
-            fixq = 2.0e9f / (n_sum * wmax);
+            fixq = (GRADL ? 7.8e6f : 2.0e9f) / (n_sum * wmax);
     }
 
   // Persistent workgroups: bricks are handed out by a global counter, so a CU that drew
@@ -402,9 +455,11 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         const int q4 = (tid_here & 7) * 4, z = box.lo[2] + q4;
         float *const d0 = brick + q4;
         constexpr bool LABELS = MODE == BRICK_CHANNELS || MODE == BRICK_TRI_CHANNELS ||
-                                MODE == BRICK_CHANNELS_AUX || MODE == BRICK_TRI_CHANNELS_AUX;
-        // (Siddon channels: labels without a channel are staged as value 0 | label 0)
+                                MODE == BRICK_CHANNELS_AUX || MODE == BRICK_TRI_CHANNELS_AUX || GRADL;
+        // (Siddon channels: labels without a channel are staged as value 0 | label 0; the channel
+        // gradient's accumulator: an integer 0 over the label, or a float 0 where there is no bound)
         auto pack_word = [&](float v, unsigned lab) {
+            if (GRADL) return fixq != 0.f ? bits_as_float(lab & 0xffu) : 0.f;
             return MODE != BRICK_TRI_CHANNELS && MODE != BRICK_TRI_CHANNELS_AUX
                        ? pack_voxel_label_below(v, lab, (unsigned)p.n_channels)
                                           : pack_voxel_label(v, lab);
@@ -486,7 +541,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                     const int row = (tid >> 3) + (h + it) * (kBrickThreads >> 3);
                     const int lx = row / BRICK, ly = row - lx * BRICK;
                     const int x = box.lo[0] + lx, y = box.lo[1] + ly;
-                    in_xy[it] = !GRAD && x >= 0 && y >= 0 && x < box.hi[0] && y < box.hi[1];
+                    in_xy[it] = (!GRAD || GRADL) && x >= 0 && y >= 0 && x < box.hi[0] && y < box.hi[1];
                     const int xc = clampi(x, 0, p.D.x - 1), yc = clampi(y, 0, p.D.y - 1);
                     const long rowbase = ((long)xc * p.D.y + yc) * p.D.z;
                     const float *g = p.vol + rowbase;
@@ -676,7 +731,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                 float val[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    val[k] = fixq != 0.f ? (float)__float_as_int(src[k]) / fixq : src[k];
+                    val[k] = fixq != 0.f ? (float)(GRADL ? __float_as_int(src[k]) >> 8 : __float_as_int(src[k])) / fixq
+                                         : src[k];
                 if (vec_out && z + 4 <= box.hi[2]) {
                     *reinterpret_cast<float4 *>(g) = make_float4(val[0], val[1], val[2], val[3]);
                 } else {
@@ -709,7 +765,7 @@ __global__ __launch_bounds__(kBlock) void volgrad_prepare_kernel(
     int tri, const float *__restrict__ source, const float *__restrict__ target,
     const float *__restrict__ img, const float *__restrict__ grad_out, int N, int det_w, Dims D,
     float shift, float eps, int n_points, const float *__restrict__ amin,
-    const float *__restrict__ amax, int *__restrict__ work) {
+    const float *__restrict__ amax, int *__restrict__ work, int n_channels) {
     const int b = blockIdx.y;
     const float s[3] = {source[b * 3], source[b * 3 + 1], source[b * 3 + 2]};
     const float step = tri ? (amax[0] - amin[0]) / (float)(n_points - 1) : 0.f;
@@ -721,7 +777,14 @@ __global__ __launch_bounds__(kBlock) void volgrad_prepare_kernel(
         const float dn = sqrtf(dx * dx + dy * dy + dz * dz);
         const float L = img ? img[r] : 1.f;
         const float c = tri ? (3.4642f / dn + step) : 1.7321f / dn;
-        wmax = fmaxf(wmax, fabsf(grad_out[r]) * L * c);
+        float g = 0.f;
+        if (n_channels > 0) {  // (B, C, N): the largest weight any label of the ray's column carries
+            for (int ch = 0; ch < n_channels; ++ch)
+                g = fmaxf(g, fabsf(grad_out[((long)b * n_channels + ch) * N + n]));
+        } else {
+            g = fabsf(grad_out[r]);
+        }
+        wmax = fmaxf(wmax, g * L * c);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
@@ -963,7 +1026,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     {
         std::lock_guard<std::mutex> lock(mu);
         if (!attr_set[dev]) {
-            const void *fns[10] = {
+            const void *fns[11] = {
+                reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_CHANNELS_VOLGRAD>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_CHANNELS_AUX>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_CHANNELS_AUX>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_CHANNELS>),
@@ -985,13 +1049,13 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     if (int rc = brick_launch_resources(st, launch_ws, dx, dy, dz, n_cu_dev, p.work, &p.order_ws, &p.order_cap))
         return rc;
     if (g_brick_dbg & 512) p.order_ws = nullptr;  // (bricks in id order)
-    if (mode == BRICK_VOLGRAD || mode == BRICK_TRI_VOLGRAD) {
+    if (mode == BRICK_VOLGRAD || mode == BRICK_TRI_VOLGRAD || mode == BRICK_CHANNELS_VOLGRAD) {
         const int tri = mode == BRICK_TRI_VOLGRAD;
         int bx = (N + kBlock - 1) / kBlock;
         bx = bx > 64 ? 64 : bx;
         hipLaunchKernelGGL(volgrad_prepare_kernel, dim3(bx, B), dim3(kBlock), 0, st, tri, source,
                            target, img, grad_out, N, det_w, p.D, voxel_shift, eps, n_points, amin,
-                           amax, p.work);
+                           amax, p.work, mode == BRICK_CHANNELS_VOLGRAD ? n_channels : 0);
     }
     const BrickGrid bg = (mode == BRICK_TRI_FWD || mode == BRICK_TRI_FWD_AUX ||
                           mode == BRICK_TRI_CHANNELS || mode == BRICK_TRI_CHANNELS_AUX)
@@ -1001,7 +1065,7 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     // the Siddon modes hand their bricks out heaviest first like the forward kernels (the marcher's
     // bricks are cells + halo with their own boxes: id order)
     if (mode == BRICK_FWD || mode == BRICK_FWD_AUX || mode == BRICK_VOLGRAD || mode == BRICK_CHANNELS ||
-        mode == BRICK_CHANNELS_AUX)
+        mode == BRICK_CHANNELS_AUX || mode == BRICK_CHANNELS_VOLGRAD)
         order_bricks(p, BRICK, BRICK, BRICK, bg.ny, bg.nz, n_bricks, n_cu_dev, st);
     const dim3 grid(n_bricks < n_cu_dev ? n_bricks : n_cu_dev), block(kBrickThreads);
     if (mode == BRICK_TRI_FWD)
@@ -1024,6 +1088,9 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_CHANNELS>, grid, block, lds, st, p, out, aux);
     else if (mode == BRICK_TRI_CHANNELS_AUX)
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_CHANNELS_AUX>, grid, block, lds, st, p, out,
+                           aux);
+    else if (mode == BRICK_CHANNELS_VOLGRAD)
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_CHANNELS_VOLGRAD>, grid, block, lds, st, p, out,
                            aux);
     else
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_VOLGRAD>, grid, block, lds, st, p, out, aux);
@@ -1222,6 +1289,31 @@ int ddrr_trilinear_backward_channels_bricks(const float *volume, const unsigned 
                          grad_out, B, det_h, det_w, voxel_shift, eps, nullptr, aux, nullptr, st,
                          launch_ws, "ddrr_trilinear_backward_channels_bricks", n_points, alphamin,
                          alphamax, 0.f, labels, C);
+}
+
+int ddrr_siddon_backward_channels_volume_bricks(const unsigned char *labels, int dx, int dy, int dz,
+                                                const float *source, const float *target,
+                                                const float *img, const float *grad_out, int B,
+                                                int det_h, int det_w, int C, float voxel_shift,
+                                                float eps, float *g_volume, void *launch_ws,
+                                                void *stream) {
+    const int N = det_h * det_w;
+    if (!g_volume || !grad_out || !labels || C < 1)
+        return fail(-1, "null labels / grad_out / g_volume or C < 1");
+    if (int rc = check_common(g_volume, dx, dy, dz, source, 1, target, B, N)) return rc;
+    if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
+    if ((long)B * C * N >= (1L << 30) || N >= (1 << 22))
+        return fail(-1, "B * C * N must stay below 2^30 (and N below 2^22) for one channel launch "
+                        "on the bricks: split the pose batch or use ddrr_siddon_backward_channels");
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {  // nothing contributes: the gradient is zero
+        hipError_t e = hipMemsetAsync(g_volume, 0, sizeof(float) * (size_t)dx * dy * dz, st);
+        return e == hipSuccess ? 0 : fail_hip(e, "hipMemsetAsync");
+    }
+    return launch_bricks(BRICK_CHANNELS_VOLGRAD, nullptr, dx, dy, dz, source, target, img, grad_out,
+                         B, det_h, det_w, voxel_shift, eps, nullptr, nullptr, g_volume, st, launch_ws,
+                         "ddrr_siddon_backward_channels_volume_bricks", 0, nullptr, nullptr, 0.f,
+                         labels, C);
 }
 
 int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *source,

@@ -585,6 +585,33 @@ def siddon_backward_channels_bricks(volume, labels_u8, source, target, img, grad
     return siddon_backward_rays(aux, ones, source, target, img, eps=eps, want_img_grad=want_img)
 
 
+def siddon_backward_channels_volume_bricks(labels_u8, source, target, img, grad_out, det, *,
+                                           voxel_shift=0.5, eps=1e-8):
+    """Volume gradient of :func:`siddon_forward_channels_bricks` for grad_out (B, C, N) on the
+    volume-stationary bricks (the LDS brick is the accumulator, the voxel's label rides in the
+    word's low byte).  -> g_volume, the label map's shape"""
+    B, N, _ = target.shape
+    H, W = int(det[0]), int(det[1])
+    C = grad_out.shape[1]
+    if grad_out.shape != (B, C, N):
+        raise ValueError(f"grad_out must be (B, C, N) = ({B}, C, {N}), got {tuple(grad_out.shape)}")
+    if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
+        raise ValueError("the brick path needs one source per pose and an H*W >= 2x2 ray grid")
+    if labels_u8.dtype != torch.uint8 or labels_u8.dim() != 3:
+        raise ValueError("labels must be a 3-D uint8 tensor")
+    _require_gpu(target)
+    dev = target.device
+    labels_u8, grad_out = labels_u8.contiguous(), grad_out.contiguous()
+    source, target = source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    g_volume = torch.empty(labels_u8.shape, dtype=torch.float32, device=dev)
+    _launch("ddrr_siddon_backward_channels_volume_bricks", dev, labels_u8.data_ptr(),
+            *labels_u8.shape, source.data_ptr(), target.data_ptr(), _ptr(img), grad_out.data_ptr(), B,
+            H, W, int(C), float(voxel_shift), float(eps), g_volume.data_ptr(),
+            launch_workspace(labels_u8.shape, dev).data_ptr())
+    return g_volume
+
+
 def channels_fit_bricks(B, C, N):
     """One brick launch addresses the (B, C, N) result with 32-bit byte offsets."""
     return B * C * N < 2 ** 30 and N < 2 ** 22

@@ -304,13 +304,19 @@ class _SiddonChannelsFn(torch.autograd.Function):
         stop = cfg["stop_gradients"]
         want_vol = bool(need_vol and not stop)
         B, C, N = grad_out.shape
-        if (not want_vol and _channels_use_bricks(cfg, source, N) and ops.channels_fit_bricks(B, C, N)):
-            # the DRR case without a volume gradient: the record of the gradient-weighted volume on
-            # the bricks (ddrr_siddon_backward_channels_bricks), 4-6x faster than the per-ray re-walk
-            gs, gt, gi = ops.siddon_backward_channels_bricks(
-                volume, labels, source, target, img, grad_out, cfg["det"],
-                voxel_shift=cfg["voxel_shift"], eps=cfg["eps"], want_img=bool(need_i and not stop))
-            gv = None
+        if _channels_use_bricks(cfg, source, N) and ops.channels_fit_bricks(B, C, N):
+            # the DRR case: the record of the gradient-weighted volume on the bricks
+            # (ddrr_siddon_backward_channels_bricks), 4-6x faster than the per-ray re-walk, and the
+            # volume gradient with the brick in LDS as its accumulator
+            gs = gt = gi = gv = None
+            if need_s or need_t or (need_i and not stop):
+                gs, gt, gi = ops.siddon_backward_channels_bricks(
+                    volume, labels, source, target, img, grad_out, cfg["det"],
+                    voxel_shift=cfg["voxel_shift"], eps=cfg["eps"], want_img=bool(need_i and not stop))
+            if want_vol:
+                gv = ops.siddon_backward_channels_volume_bricks(
+                    labels, source, target, img, grad_out, cfg["det"],
+                    voxel_shift=cfg["voxel_shift"], eps=cfg["eps"]).to(volume.dtype)
         else:
             gs, gt, gi, gv = ops.siddon_backward_channels(
                 volume, labels, source, target, img, grad_out, voxel_shift=cfg["voxel_shift"],

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 27
+#define DDRR_ABI_VERSION 28
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -212,7 +212,7 @@ int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char
  * -- labels >= C weigh 0 -- so that ddrr_siddon_backward_rays(aux, DDRR_AUX_BLOCKED, ones (B, N),
  * ...) returns d/d source, d/d target and d/d img of sum_c grad_out_c out_c.  The weight of a
  * label run is gathered from grad_out when a ray's label changes inside a brick.
- * B * C * N < 2^30, N < 2^22.  (The volume gradient stays with ddrr_siddon_backward_channels.) */
+ * B * C * N < 2^30, N < 2^22.  (The volume gradient: ddrr_siddon_backward_channels_volume_bricks.) */
 int ddrr_siddon_backward_channels_bricks(const float *volume, const unsigned char *labels, int dx,
                                          int dy, int dz, const float *source, const float *target,
                                          const float *grad_out, int B, int det_h, int det_w, int C,
@@ -233,6 +233,21 @@ int ddrr_trilinear_backward_channels_bricks(const float *volume, const unsigned 
                                             float eps, int n_points, const float *alphamin,
                                             const float *alphamax, float *aux, void *launch_ws,
                                             void *stream);
+
+/* Backward of the channel render w.r.t. the VOLUME for the DRR case, on the volume-stationary
+ * bricks (the grid_sampler_3d_backward of renderers.py:77-89's gather, weighted per channel):
+ * g_volume[x] = sum over poses and rays of len(ray in voxel x) img grad_out[b, label(x), n], labels
+ * >= C weigh 0.  STORED, every voxel exactly once (no zero fill by the caller, unlike
+ * ddrr_siddon_backward_channels).  The brick in LDS is the accumulator, 24-bit fixed point over the
+ * voxel's label in the word's low byte (the label plane has no room of its own next to it); poses
+ * whose source lies in or next to the volume -- no bound on a voxel's sum -- accumulate in fp32
+ * and look the labels up in the label map.  B * C * N < 2^30, N < 2^22. */
+int ddrr_siddon_backward_channels_volume_bricks(const unsigned char *labels, int dx, int dy, int dz,
+                                                const float *source, const float *target,
+                                                const float *img, const float *grad_out, int B,
+                                                int det_h, int det_w, int C, float voxel_shift,
+                                                float eps, float *g_volume, void *launch_ws,
+                                                void *stream);
 
 /* Backward of ddrr_siddon_forward_channels: what autograd of renderers.py:77-89 (scatter_add
  * of the weighted segments into channels) returns for grad_out (B, C, N).  Outputs as in

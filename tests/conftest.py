@@ -497,7 +497,8 @@ def check_brick_storage_guard(ops, device, name, storage, bdims):
 
 def check_channel_backward_on_bricks(ops, device):
     """ddrr_siddon_backward_channels_bricks (the record of the volume weighted by every voxel's own
-    incoming gradient, then ddrr_siddon_backward_rays) against the fp64 oracle's autograd of the
+    incoming gradient, then ddrr_siddon_backward_rays) and ddrr_siddon_backward_channels_volume_bricks
+    (the volume gradient) against the fp64 oracle's autograd of the
     mask branch (reference renderers.py:77-89) and against the per-ray channel backward: several
     bricks, up to 200 labels of which the last 56 have no channel, forward image for scale."""
     import torch
@@ -550,3 +551,13 @@ def check_channel_backward_on_bricks(ops, device):
     assert rel_err(gs.sum(1).cpu().numpy(), o["g_source"].reshape(B, -1, 3).sum(1)) < 5e-2
     same = (gt - pt).abs().amax(-1) <= 1e-3 * pt.abs().max()
     assert same.float().mean().item() > 0.99
+    # the volume gradient with the brick in LDS as the accumulator (24-bit fixed point over the
+    # label byte; ddrr_siddon_backward_channels_volume_bricks) against the fp64 oracle and the
+    # per-ray kernel's global atomics: every voxel stored (no NaN left), labels >= C get nothing
+    gv = ops.siddon_backward_channels_volume_bricks(lab, sd, td, Ld, god, (H, W)).cpu().numpy()
+    pv = ops.siddon_backward_channels(V, lab, sd, td, Ld, god, det=(H, W), want_rays=False,
+                                      want_img=False, want_volume=True)[3].cpu().numpy()
+    assert np.isfinite(gv).all()
+    assert rel_err(gv, o["g_volume"]) < 1e-4, rel_err(gv, o["g_volume"])  # (fp32 sums of ~50 terms)
+    assert rel_err(gv, pv) < 5e-5
+    assert np.all(gv[labels >= C] == 0)

@@ -580,6 +580,63 @@ int ddrr_siddon_backward_volume_bricks(int dx, int dy, int dz, const float *sour
     return 0;
 }
 
+// The channel render's volume gradient on the bricks: as above with the weight of the voxel's
+// own label (step_scatter_weighted); the emulation keeps the labels in a plane of its own (the
+// device packs them into the accumulator's words) and poisons the result first: every voxel must
+// be stored exactly once.
+int ddrr_siddon_backward_channels_volume_bricks(const unsigned char *labels, int dx, int dy, int dz,
+                                                const float *source, const float *target,
+                                                const float *img, const float *grad_out, int B,
+                                                int det_h, int det_w, int C, float voxel_shift,
+                                                float eps, float *g_volume, void *, void *) {
+    const Dims D{dx, dy, dz};
+    const int N = det_h * det_w;
+    const BrickGrid bg = brick_grid(D);
+    const BrickLayout lay{33, 32 * 33 + 1};
+    std::vector<float> brick((size_t)brick_floats(lay));
+    std::vector<unsigned char> lab((size_t)brick_floats(lay));
+    for (size_t i = 0; i < (size_t)dx * dy * dz; ++i) g_volume[i] = NAN;
+    for (int id = 0; id < bg.nx * bg.ny * bg.nz; ++id) {
+        const Box box = brick_box(D, bg, id);
+        std::fill(brick.begin(), brick.end(), 0.f);
+        std::fill(lab.begin(), lab.end(), (unsigned char)0);
+        for (int x = box.lo[0]; x < box.hi[0]; ++x)
+            for (int y = box.lo[1]; y < box.hi[1]; ++y)
+                for (int z = box.lo[2]; z < box.hi[2]; ++z)
+                    lab[(x - box.lo[0]) * lay.sx + (y - box.lo[1]) * lay.sy + (z - box.lo[2])] =
+                        labels[((long)x * dy + y) * dz + z];
+        for (int b = 0; b < B; ++b) {
+            const PoseGrid pg = pose_grid(source + (long)b * 3, target + (long)b * N * 3, det_h,
+                                          det_w);
+            const PixBox pb = project_brick_grid(pg, det_h, det_w, boxf(box), voxel_shift);
+            const BrickRow row = brick_row(pg, pb, boxf(box), voxel_shift, eps, 0.f);
+            for (int local = 0; local < row.count; ++local) {
+                int pix;
+                float n_est;
+                if (!brick_candidate(row, local, det_w, pix, n_est)) continue;
+                const long r = (long)b * N + pix;
+                float s[3], t[3];
+                for (int a = 0; a < 3; ++a) {
+                    s[a] = source[(long)b * 3 + a];
+                    t[a] = target[r * 3 + a];
+                }
+                const float *col = grad_out + (long)b * C * N + pix;
+                step_scatter_weighted(
+                    [&](unsigned off, float v) { brick[off >> 2] += v; },
+                    [&](unsigned off) { return (unsigned)lab[off >> 2]; },
+                    [&](unsigned l) { return l < (unsigned)C ? col[(long)l * N] : 0.f; }, 0u,
+                    step_geom(box, lay), s, t, voxel_shift, eps, img ? img[r] : 1.f);
+            }
+        }
+        for (int x = box.lo[0]; x < box.hi[0]; ++x)
+            for (int y = box.lo[1]; y < box.hi[1]; ++y)
+                for (int z = box.lo[2]; z < box.hi[2]; ++z)
+                    g_volume[((long)x * dy + y) * dz + z] =
+                        brick[(x - box.lo[0]) * lay.sx + (y - box.lo[1]) * lay.sy + (z - box.lo[2])];
+    }
+    return 0;
+}
+
 int ddrr_trilinear_forward_bricks(const float *volume, int dx, int dy, int dz,
                                   const float *source, const float *target, const float *img,
                                   int B, int det_h, int det_w, float voxel_shift, float eps,

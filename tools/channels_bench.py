@@ -96,6 +96,17 @@ for B in (1, 8):
         k_bwdb, _ = timeit(lambda: ops.siddon_backward_channels_bricks(drr.density, labels, s_, t_, L, go, (H, H)))
         gb = ops.siddon_backward_channels_bricks(drr.density, labels, s_, t_, L, go, (H, H))
         gr = ops.siddon_backward_channels(drr.density, labels, s_, t_, L, go, want_volume=False, det=(H, H))
+        k_vb, _ = timeit(lambda: ops.siddon_backward_channels_volume_bricks(labels, s_, t_, L, go, (H, H)))
+        k_pv, _ = timeit(lambda: ops.siddon_backward_volume_bricks(drr.density.shape, s_, t_, L, go[:, 0].contiguous(), (H, H)))
+        gvb = ops.siddon_backward_channels_volume_bricks(labels, s_, t_, L, go, (H, H))
+        gvr = ops.siddon_backward_channels(drr.density, labels, s_, t_, L, go, want_rays=False, want_img=False,
+                                           want_volume=True, det=(H, H))[3]
+    print(f"B {B} channel backward, VOLUME gradient: per-ray kernel (global atomics, with the ray gradients) "
+          f"{k_bwdv:7.3f} ms | ON THE BRICKS {k_vb:7.3f} ms = {k_bwdv / k_vb:4.1f} x faster (plain volume gradient "
+          f"on the bricks {k_pv:7.3f} ms) | bricks vs per-ray {float((gvb - gvr).abs().max() / gvr.abs().max()):.1e}",
+          flush=True)
+    with torch.no_grad():
+        pass
     same = float(((gb[1] - gr[1]).abs().amax(-1) <= 1e-3 * gr[1].abs().max()).float().mean())
     print(f"B {B} channel backward, rays + img: per-ray kernel {k_bwd:7.3f} ms | ON THE BRICKS {k_bwdb:7.3f} ms "
           f"= {k_bwd / k_bwdb:4.1f} x faster (rays agreeing to 1e-3: {100 * same:.2f} %, d/d img "

@@ -124,6 +124,11 @@ for case in range(a.cases):
         ps, pt, pi, _ = ops.siddon_backward_channels(V, lab, s, t, L, goc, det=(H, W))
         e_cb = ((bi - pi).abs().max() / (pi.abs().max() + 1e-30)).item()
         e_cg = ((bt.sum(1) - pt.sum(1)).abs().max() / (pt.sum(1).abs().max() + 1e-30)).item()
+        # ... and its volume gradient (the LDS brick as accumulator, labels in the words' low byte)
+        vb = ops.siddon_backward_channels_volume_bricks(lab, s, t, L, goc, (H, W))
+        vr = ops.siddon_backward_channels(V, lab, s, t, L, goc, det=(H, W), want_rays=False, want_img=False,
+                                          want_volume=True)[3]
+        e_cb = max(e_cb, ((vb - vr).abs().max() / (vr.abs().max() + 1e-30)).item())
         if amax.item() > amin.item():
             tcb = ops.trilinear_forward_channels_bricks(V, lab, C, s, t, L, amin, amax, (H, W), n_points=P)
             tcr = ops.trilinear_forward_channels(V, lab, C, s, t, L, amin, amax, n_points=P)
