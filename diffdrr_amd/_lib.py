@@ -44,6 +44,8 @@ _SIGNATURES = {
                                              _P, _P, _P],
     "ddrr_siddon_backward_channels_volume_bricks": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _F,
                                                     _F, _P, _P, _P],
+    "ddrr_trilinear_backward_channels_volume_bricks": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I,
+                                                       _F, _F, _I, _P, _P, _P, _P, _P],
     "ddrr_trilinear_backward_channels_bricks": [_P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F,
                                                 _F, _I, _P, _P, _P, _P, _P],
     "ddrr_trilinear_alpha_range": [_P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P],

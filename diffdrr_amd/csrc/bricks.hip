@@ -111,6 +111,21 @@ struct GlobalLabelOf {
     }
 };
 
+// The marcher's sample label (BRICK_TRI_CHANNELS_VOLGRAD): from the label map, 0 outside the
+// volume.  (Labels in the accumulator words' low byte, as for Siddon, were built and measured:
+// the marcher adds ~100 corner weights per voxel under a bound of thousands, and 24 bits leave
+// 1e-4 .. 4e-4 of the largest gradient as rounding -- the 31-bit accumulator 4e-6.  The byte loads
+// hit L1 / L2: neighbouring samples share their nearest voxel.)
+struct TriLabelOf {
+    const unsigned char *labels;
+    Dims D;
+    __device__ __forceinline__ unsigned operator()(float rx, float ry, float rz, bool, unsigned) const {
+        const bool in = rx >= 0.f && ry >= 0.f && rz >= 0.f && rx < (float)D.x && ry < (float)D.y &&
+                        rz < (float)D.z;
+        return in ? labels[((long)(int)rx * D.y + (int)ry) * D.z + (int)rz] : 0u;
+    }
+};
+
 // A finished label run of a ray's walk through a brick goes to the ray's output column
 // (B, C, N): one fire-and-forget atomic per run.  32-bit offsets: the host checks B C N < 2^30.
 // SCALED: L multiplies every run (else the walk carries it); CHECKED: labels >= C are dropped here
@@ -247,6 +262,15 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
         }
         return;
     }
+    if (MODE == BRICK_TRI_CHANNELS_VOLGRAD) {
+        const unsigned N = (unsigned)(p.det_h * p.det_w), C = (unsigned)p.n_channels;
+        const BrickColumnWeight<true> weight{p.grad_out, (b * C * N + pix) * 4u, N * 4u, C};
+        const float a0 = p.amin[0], a1 = p.amax[0];
+        const float k = L * ((a1 - a0) / (float)(p.n_points - 1));
+        tri_owner_scatter_weighted(LdsAbsAdd{fixq}, TriLabelOf{p.labels, p.D}, weight, base, G.lof, G.hif,
+                                   G.stridef, p.D, s, t, p.shift, p.eps, p.n_points, a0, a1, k);
+        return;
+    }
     if (MODE == BRICK_TRI_VOLGRAD) {
         const float a0 = p.amin[0], a1 = p.amax[0];
         const float w = p.grad_out[r] * L * ((a1 - a0) / (float)(p.n_points - 1));
@@ -344,9 +368,11 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     // gradient (TRI_OWNER) runs on the plain 32^3 voxel bricks, see tri_brick.h
     constexpr bool TRI = MODE == BRICK_TRI_FWD || MODE == BRICK_TRI_FWD_AUX || MODE == BRICK_TRI_CHANNELS ||
                          MODE == BRICK_TRI_CHANNELS_AUX;
-    constexpr bool TRI_OWNER = MODE == BRICK_TRI_VOLGRAD;
-    constexpr bool GRAD = MODE == BRICK_VOLGRAD || MODE == BRICK_TRI_VOLGRAD || MODE == BRICK_CHANNELS_VOLGRAD;
-    constexpr bool GRADL = MODE == BRICK_CHANNELS_VOLGRAD;  // ... with the labels in the accumulator's words
+    constexpr bool TRI_OWNER = MODE == BRICK_TRI_VOLGRAD || MODE == BRICK_TRI_CHANNELS_VOLGRAD;
+    constexpr bool GRAD = MODE == BRICK_VOLGRAD || MODE == BRICK_TRI_VOLGRAD || MODE == BRICK_CHANNELS_VOLGRAD ||
+                          MODE == BRICK_TRI_CHANNELS_VOLGRAD;
+    // ... with the labels in the accumulator's words
+    constexpr bool GRADL = MODE == BRICK_CHANNELS_VOLGRAD;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *brick = reinterpret_cast<float *>(smem_raw);
     unsigned *queue = reinterpret_cast<unsigned *>(brick + brick_floats(p.lay));
@@ -1010,7 +1036,7 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     p.prof = g_brick_prof;
 #endif
     if (mode == BRICK_TRI_FWD || mode == BRICK_TRI_VOLGRAD || mode == BRICK_TRI_FWD_AUX ||
-        mode == BRICK_TRI_CHANNELS || mode == BRICK_TRI_CHANNELS_AUX) {
+        mode == BRICK_TRI_CHANNELS || mode == BRICK_TRI_CHANNELS_AUX || mode == BRICK_TRI_CHANNELS_VOLGRAD) {
         p.t1 = g_tri_t1;
         p.t2 = g_tri_t2;
     }
@@ -1026,7 +1052,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     {
         std::lock_guard<std::mutex> lock(mu);
         if (!attr_set[dev]) {
-            const void *fns[11] = {
+            const void *fns[12] = {
+                reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_CHANNELS_VOLGRAD>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_CHANNELS_VOLGRAD>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_CHANNELS_AUX>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_CHANNELS_AUX>),
@@ -1049,13 +1076,15 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     if (int rc = brick_launch_resources(st, launch_ws, dx, dy, dz, n_cu_dev, p.work, &p.order_ws, &p.order_cap))
         return rc;
     if (g_brick_dbg & 512) p.order_ws = nullptr;  // (bricks in id order)
-    if (mode == BRICK_VOLGRAD || mode == BRICK_TRI_VOLGRAD || mode == BRICK_CHANNELS_VOLGRAD) {
-        const int tri = mode == BRICK_TRI_VOLGRAD;
+    if (mode == BRICK_VOLGRAD || mode == BRICK_TRI_VOLGRAD || mode == BRICK_CHANNELS_VOLGRAD ||
+        mode == BRICK_TRI_CHANNELS_VOLGRAD) {
+        const int tri = mode == BRICK_TRI_VOLGRAD || mode == BRICK_TRI_CHANNELS_VOLGRAD;
         int bx = (N + kBlock - 1) / kBlock;
         bx = bx > 64 ? 64 : bx;
         hipLaunchKernelGGL(volgrad_prepare_kernel, dim3(bx, B), dim3(kBlock), 0, st, tri, source,
                            target, img, grad_out, N, det_w, p.D, voxel_shift, eps, n_points, amin,
-                           amax, p.work, mode == BRICK_CHANNELS_VOLGRAD ? n_channels : 0);
+                           amax, p.work,
+                           mode == BRICK_CHANNELS_VOLGRAD || mode == BRICK_TRI_CHANNELS_VOLGRAD ? n_channels : 0);
     }
     const BrickGrid bg = (mode == BRICK_TRI_FWD || mode == BRICK_TRI_FWD_AUX ||
                           mode == BRICK_TRI_CHANNELS || mode == BRICK_TRI_CHANNELS_AUX)
@@ -1092,6 +1121,9 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     else if (mode == BRICK_CHANNELS_VOLGRAD)
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_CHANNELS_VOLGRAD>, grid, block, lds, st, p, out,
                            aux);
+    else if (mode == BRICK_TRI_CHANNELS_VOLGRAD)
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_CHANNELS_VOLGRAD>, grid, block, lds, st, p,
+                           out, aux);
     else
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_VOLGRAD>, grid, block, lds, st, p, out, aux);
     return finish(who);
@@ -1379,6 +1411,33 @@ int ddrr_trilinear_backward_rays(const float *aux, const float *grad_out, const 
                        dim3(kBlock), 0, (hipStream_t)stream, aux, grad_out, source, target, img, R,
                        N, eps, n_points, alphamin, alphamax, g_source, g_target, g_img, g_alpha);
     return finish("ddrr_trilinear_backward_rays");
+}
+
+int ddrr_trilinear_backward_channels_volume_bricks(const unsigned char *labels, int dx, int dy,
+                                                   int dz, const float *source, const float *target,
+                                                   const float *img, const float *grad_out, int B,
+                                                   int det_h, int det_w, int C, float voxel_shift,
+                                                   float eps, int n_points, const float *alphamin,
+                                                   const float *alphamax, float *g_volume,
+                                                   void *launch_ws, void *stream) {
+    const int N = det_h * det_w;
+    if (!g_volume || !grad_out || !labels || !alphamin || !alphamax || C < 1)
+        return fail(-1, "null labels / grad_out / g_volume / alphamin / alphamax or C < 1");
+    if (int rc = check_common(g_volume, dx, dy, dz, source, 1, target, B, N)) return rc;
+    if (n_points < 2) return fail(-1, "n_points must be >= 2");
+    if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
+    if ((long)B * C * N >= (1L << 30) || N >= (1 << 22))
+        return fail(-1, "B * C * N must stay below 2^30 (and N below 2^22) for one channel launch "
+                        "on the bricks: split the pose batch or use ddrr_trilinear_backward_channels");
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        hipError_t e = hipMemsetAsync(g_volume, 0, sizeof(float) * (size_t)dx * dy * dz, st);
+        return e == hipSuccess ? 0 : fail_hip(e, "hipMemsetAsync");
+    }
+    return launch_bricks(BRICK_TRI_CHANNELS_VOLGRAD, nullptr, dx, dy, dz, source, target, img,
+                         grad_out, B, det_h, det_w, voxel_shift, eps, nullptr, nullptr, g_volume, st,
+                         launch_ws, "ddrr_trilinear_backward_channels_volume_bricks", n_points, alphamin,
+                         alphamax, 0.f, labels, C);
 }
 
 int ddrr_trilinear_backward_volume_bricks(int dx, int dy, int dz, const float *source,

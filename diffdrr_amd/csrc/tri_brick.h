@@ -435,4 +435,91 @@ DDRR_HD void tri_owner_scatter(const Acc &acc, float base, const float lo[3], co
     }
 }
 
+// The marcher's mask_to_channels volume gradient inside one OWNER brick (reference
+// renderers.py:242-252, autograd w.r.t. the volume): tri_owner_scatter with every sample weighted
+// by the incoming gradient of the channel its NEAREST voxel's label selects -- the voxel
+// tri_brick_march_channels picks (the reference's own coordinate chain, held to the sample's 8
+// corners).  That voxel may lie one layer outside the owned box: `label(rx, ry, rz, owned, addr)`
+// gets its index coordinates and, for an owned voxel, its LDS address; voxels outside the volume
+// carry label 0 (the zero padding).
+// `weight(label)` is gathered when the label changes along the ray; k = L step.
+template <class Acc, class Label, class Weight>
+DDRR_HD void tri_owner_scatter_weighted(const Acc &acc, const Label &label, const Weight &weight,
+                                        float base, const float lo[3], const float hi[3],
+                                        const float stridef[3], const Dims D, const float s[3],
+                                        const float t[3], float shift, float eps, int P, float amin,
+                                        float amax, float k) {
+    const float go = shift - 0.5f;  // align_corners = False: g = x + shift - 1/2
+    MarchSetup q;
+    float entry = -INFINITY, exit = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        q.d[a] = (t[a] - s[a]) + eps;
+        const float g0 = s[a] + go;
+        const float a1 = (lo[a] - 1.f - g0) / q.d[a], a2 = (hi[a] - g0) / q.d[a];
+        entry = fmaxf(entry, fminf(a1, a2));
+        exit = fminf(exit, fmaxf(a1, a2));
+    }
+    q.span = amax - amin;
+    if (!(entry < exit) || !(q.span > 0.f)) return;
+    const float lstep = 1.0f / (float)(P - 1), sc = (float)(P - 1) / q.span;
+    const float f0 = fminf(fmaxf(floorf((entry - amin) * sc) - 1.f, 0.f), (float)P);
+    const float f1 = fminf(fmaxf(ceilf((exit - amin) * sc) + 1.f, -1.f), (float)(P - 1));
+    if (!(f0 <= f1)) return;
+    const int m0 = (int)f0, m1 = (int)f1;
+    const float offc = fmaf(-lo[0], stridef[0], fmaf(-lo[1], stridef[1], fmaf(-lo[2], stridef[2], base)));
+    const float sx = stridef[0], sy = stridef[1];
+    int cur = -1;
+    float w = 0.f;
+    for (int m = m0; m <= m1; ++m) {
+        const float lin = lin01(m, P, lstep);
+        const float al = fmaf(lin, q.span, amin);  // renderers.py:224-225
+        const float gx = fmaf(al, q.d[0], s[0]) + go;
+        const float gy = fmaf(al, q.d[1], s[1]) + go;
+        const float gz = fmaf(al, q.d[2], s[2]) + go;
+        const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+        const bool x0 = fx >= lo[0] && fx < hi[0], x1 = fx + 1.f >= lo[0] && fx + 1.f < hi[0];
+        const bool y0 = fy >= lo[1] && fy < hi[1], y1 = fy + 1.f >= lo[1] && fy + 1.f < hi[1];
+        const bool z0 = fz >= lo[2] && fz < hi[2], z1 = fz + 1.f >= lo[2] && fz + 1.f < hi[2];
+        if (!((x0 || x1) && (y0 || y1) && (z0 || z1))) continue;
+        // the sample's label: its nearest voxel by the reference's arithmetic, among the 8 corners
+        float un[3];
+        march_exact_coord(D, lin, q, amin, s, shift, false, un);
+        const float rx = fminf(fmaxf(rintf(un[0]), fx), fx + 1.f);
+        const float ry = fminf(fmaxf(rintf(un[1]), fy), fy + 1.f);
+        const float rz = fminf(fmaxf(rintf(un[2]), fz), fz + 1.f);
+        const bool owned = rx >= lo[0] && rx < hi[0] && ry >= lo[1] && ry < hi[1] && rz >= lo[2] &&
+                           rz < hi[2];
+        const float an = fmaf(rx, sx, fmaf(ry, sy, fmaf(rz, 4.f, offc)));
+        const int lab = (int)label(rx, ry, rz, owned, owned ? (unsigned)(int)an : 0u);
+        if (lab != cur) {
+            cur = lab;
+            w = weight((unsigned)lab) * k;
+        }
+        const float ax = gx - fx, ay = gy - fy, az = gz - fz;
+        const float o00 = fmaf(fx, sx, fmaf(fy, sy, fmaf(fz, 4.f, offc)));
+        const float wx0 = 1.f - ax, wy0 = 1.f - ay, wz0 = 1.f - az;
+        if (x0 && y0) {
+            const unsigned a00 = (unsigned)(int)(o00 + (z0 ? 0.f : 4.f));
+            if (z0) acc(a00, w * (wx0 * wy0 * wz0));
+            if (z1) acc(z0 ? a00 + 4u : a00, w * (wx0 * wy0 * az));
+        }
+        if (x1 && y0) {
+            const unsigned a10 = (unsigned)(int)(o00 + sx + (z0 ? 0.f : 4.f));
+            if (z0) acc(a10, w * (ax * wy0 * wz0));
+            if (z1) acc(z0 ? a10 + 4u : a10, w * (ax * wy0 * az));
+        }
+        if (x0 && y1) {
+            const unsigned a01 = (unsigned)(int)(o00 + sy + (z0 ? 0.f : 4.f));
+            if (z0) acc(a01, w * (wx0 * ay * wz0));
+            if (z1) acc(z0 ? a01 + 4u : a01, w * (wx0 * ay * az));
+        }
+        if (x1 && y1) {
+            const unsigned a11 = (unsigned)(int)(o00 + sx + sy + (z0 ? 0.f : 4.f));
+            if (z0) acc(a11, w * (ax * ay * wz0));
+            if (z1) acc(z0 ? a11 + 4u : a11, w * (ax * ay * az));
+        }
+    }
+}
+
 }  // namespace ddrr

@@ -797,6 +797,34 @@ def trilinear_forward_channels_bricks(volume, labels_u8, n_channels, source, tar
 TRI_AUX_PLANES = 7  # sum T, sum dT_xyz, sum alpha dT_xyz (include/diffdrr_hip.h)
 
 
+def trilinear_backward_channels_volume_bricks(labels_u8, source, target, img, grad_out, alphamin,
+                                              alphamax, det, *, n_points=500, voxel_shift=0.5,
+                                              eps=1e-8):
+    """Volume gradient of :func:`trilinear_forward_channels_bricks` for grad_out (B, C, N) on the
+    owner bricks (LDS accumulator, labels in the words' low byte).  -> g_volume, the label map's
+    shape"""
+    B, N, _ = target.shape
+    H, W = int(det[0]), int(det[1])
+    C = grad_out.shape[1]
+    if grad_out.shape != (B, C, N):
+        raise ValueError(f"grad_out must be (B, C, N) = ({B}, C, {N}), got {tuple(grad_out.shape)}")
+    if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
+        raise ValueError("the brick path needs one source per pose and an H*W >= 2x2 ray grid")
+    if labels_u8.dtype != torch.uint8 or labels_u8.dim() != 3:
+        raise ValueError("labels must be a 3-D uint8 tensor")
+    _require_gpu(target)
+    dev = target.device
+    labels_u8, grad_out = labels_u8.contiguous(), grad_out.contiguous()
+    source, target = source.contiguous(), target.contiguous()
+    img = None if img is None else img.contiguous()
+    g_volume = torch.empty(labels_u8.shape, dtype=torch.float32, device=dev)
+    _launch("ddrr_trilinear_backward_channels_volume_bricks", dev, labels_u8.data_ptr(),
+            *labels_u8.shape, source.data_ptr(), target.data_ptr(), _ptr(img), grad_out.data_ptr(), B,
+            H, W, int(C), float(voxel_shift), float(eps), int(n_points), alphamin.data_ptr(),
+            alphamax.data_ptr(), g_volume.data_ptr(), launch_workspace(labels_u8.shape, dev).data_ptr())
+    return g_volume
+
+
 def trilinear_backward_channels_bricks(volume, labels_u8, source, target, img, grad_out, alphamin,
                                        alphamax, det, *, n_points=500, voxel_shift=0.5, eps=1e-8,
                                        want_rays=True, want_img=True, want_alpha=True):

@@ -817,14 +817,21 @@ class _TrilinearChannelsFn(torch.autograd.Function):
         det = cfg["det"]
         grid = (det is not None and det[0] * det[1] == N and source.shape[1] == 1
                 and min(det) >= 2 and not cfg["align_corners"])
-        if not need_vol and grid and cfg.get("bricks", True) and ops.channels_fit_bricks(B, C, N):
-            # no volume gradient asked: the weighted record on the bricks
-            # (ddrr_trilinear_backward_channels_bricks) instead of the per-ray re-march
-            r = ops.trilinear_backward_channels_bricks(
-                volume, labels, source, target, img, grad_out, alphamin.reshape(1),
-                alphamax.reshape(1), det, n_points=cfg["n_points"],
-                voxel_shift=cfg["voxel_shift"], eps=cfg["eps"], want_rays=bool(need_s or need_t),
-                want_img=bool(need_i), want_alpha=bool(need_a0 or need_a1))
+        if grid and cfg.get("bricks", True) and ops.channels_fit_bricks(B, C, N):
+            # the DRR case: the weighted record on the bricks (ddrr_trilinear_backward_channels_bricks)
+            # instead of the per-ray re-march, the volume gradient on the owner bricks
+            r = {"g_source": None, "g_target": None, "g_img": None, "g_alpha": None, "g_volume": None}
+            if need_s or need_t or need_i or need_a0 or need_a1:
+                r = ops.trilinear_backward_channels_bricks(
+                    volume, labels, source, target, img, grad_out, alphamin.reshape(1),
+                    alphamax.reshape(1), det, n_points=cfg["n_points"],
+                    voxel_shift=cfg["voxel_shift"], eps=cfg["eps"], want_rays=bool(need_s or need_t),
+                    want_img=bool(need_i), want_alpha=bool(need_a0 or need_a1))
+            if need_vol:
+                r["g_volume"] = ops.trilinear_backward_channels_volume_bricks(
+                    labels, source, target, img, grad_out, alphamin.reshape(1), alphamax.reshape(1),
+                    det, n_points=cfg["n_points"], voxel_shift=cfg["voxel_shift"],
+                    eps=cfg["eps"]).to(volume.dtype)
         else:
             r = ops.trilinear_backward_channels(
                 volume, labels, source, target, img, grad_out, alphamin.reshape(1),

@@ -225,7 +225,7 @@ int ddrr_siddon_backward_channels_bricks(const float *volume, const unsigned cha
  * voxel, n] (labels >= C weigh 0), so that ddrr_trilinear_backward_rays(aux, ones (B, N), ...)
  * returns d/d source, d/d target, d/d img and d/d alphamin, alphamax of sum_c grad_out_c out_c.
  * The values are the staged words' (16-bit mantissas), as the forward rendered them.
- * B * C * N < 2^30, N < 2^22.  (The volume gradient stays with ddrr_trilinear_backward_channels.) */
+ * B * C * N < 2^30, N < 2^22.  (The volume gradient: ddrr_trilinear_backward_channels_volume_bricks.) */
 int ddrr_trilinear_backward_channels_bricks(const float *volume, const unsigned char *labels,
                                             int dx, int dy, int dz, const float *source,
                                             const float *target, const float *grad_out, int B,
@@ -248,6 +248,18 @@ int ddrr_siddon_backward_channels_volume_bricks(const unsigned char *labels, int
                                                 int det_h, int det_w, int C, float voxel_shift,
                                                 float eps, float *g_volume, void *launch_ws,
                                                 void *stream);
+
+/* The same for the marcher's channel render (renderers.py:242-252): g_volume[x] = sum over poses,
+ * rays and samples of (trilinear weight of corner x) img step grad_out[b, label of the sample's
+ * nearest voxel, n], on the owner bricks of ddrr_trilinear_backward_volume_bricks (31-bit fixed-point
+ * accumulators; the labels are read from the label map).  STORED. */
+int ddrr_trilinear_backward_channels_volume_bricks(const unsigned char *labels, int dx, int dy,
+                                                   int dz, const float *source, const float *target,
+                                                   const float *img, const float *grad_out, int B,
+                                                   int det_h, int det_w, int C, float voxel_shift,
+                                                   float eps, int n_points, const float *alphamin,
+                                                   const float *alphamax, float *g_volume,
+                                                   void *launch_ws, void *stream);
 
 /* Backward of ddrr_siddon_forward_channels: what autograd of renderers.py:77-89 (scatter_add
  * of the weighted segments into channels) returns for grad_out (B, C, N).  Outputs as in

@@ -302,6 +302,15 @@ def check_trilinear_channels_on_bricks(device, dims, det, n_points):
     for key, tol in (("g_img", 3e-5), ("g_target", 2e-4), ("g_source", 2e-4), ("g_alpha", 2e-4)):
         mine, want = rb[key].cpu().numpy(), rp[key].cpu().numpy()
         assert rel_err(mine, want) < tol, (key, rel_err(mine, want))
+    # the volume gradient on the owner bricks (ddrr_trilinear_backward_channels_volume_bricks)
+    # against the per-ray kernel's global atomics; labels >= Cb get no weight
+    gvb = ops.trilinear_backward_channels_volume_bricks(labels, s, t, L, go, a0, a1, (H, W),
+                                                        n_points=n_points).cpu().numpy()
+    gvr = ops.trilinear_backward_channels(V, labels, s, t, L, go, a0, a1, n_points=n_points,
+                                          want_rays=False, want_img=False, want_alpha=False,
+                                          want_volume=True)["g_volume"].cpu().numpy()
+    assert np.isfinite(gvb).all()
+    assert rel_err(gvb, gvr) < 5e-5, rel_err(gvb, gvr)
     # the module route takes these kernels for a detector grid and stays differentiable
     taken = []
     orig = ops.trilinear_forward_channels_bricks

@@ -194,7 +194,9 @@ int tri_bricks_host(const float *volume, int dx, int dy, int dz, const float *so
 int tri_owner_host(int dx, int dy, int dz, const float *source, const float *target,
                    const float *img, const float *grad_out, int B, int det_h, int det_w,
                    float voxel_shift, float eps, int n_points, float amin, float amax,
-                   float *g_volume) {
+                   float *g_volume, const unsigned char *labels = nullptr, int C = 0) {
+    // labels: the channel render's volume gradient, grad_out is (B, C, N) (tri_owner_scatter_weighted;
+    // the emulation looks every label up in the label map)
     const Dims D{dx, dy, dz};
     const int N = det_h * det_w;
     const BrickGrid bg = brick_grid(D);
@@ -229,6 +231,19 @@ int tri_owner_host(int dx, int dy, int dz, const float *source, const float *tar
                     t[a] = target[r * 3 + a];
                 }
                 const float L = img ? img[r] : 1.f;
+                if (labels) {
+                    const float *col = grad_out + (long)b * C * N + pix;
+                    tri_owner_scatter_weighted(
+                        HostAddB{acc},
+                        [&](float rx, float ry, float rz, bool, unsigned) -> unsigned {
+                            const bool in = rx >= 0.f && ry >= 0.f && rz >= 0.f && rx < (float)dx &&
+                                            ry < (float)dy && rz < (float)dz;
+                            return in ? labels[((long)(int)rx * dy + (int)ry) * dz + (int)rz] : 0u;
+                        },
+                        [&](unsigned l) { return l < (unsigned)C ? col[(long)l * N] : 0.f; }, 0.f, G.lof,
+                        G.hif, G.stridef, D, s, t, voxel_shift, eps, n_points, amin, amax, L * step);
+                    return;
+                }
                 tri_owner_scatter(HostAddB{acc}, 0.f, G.lof, G.hif, G.stridef, s, t, voxel_shift,
                                   eps, n_points, amin, amax, grad_out[r] * L * step);
             };
@@ -242,7 +257,7 @@ int tri_owner_host(int dx, int dy, int dz, const float *source, const float *tar
             // phase A must not lose a pixel with samples that touch this brick
             std::vector<float> probe(brick.size());
             for (int pix = 0; pix < N; ++pix) {
-                if (cand[pix] || grad_out[(long)b * N + pix] == 0.f) continue;
+                if (cand[pix] || labels || grad_out[(long)b * N + pix] == 0.f) continue;
                 std::fill(probe.begin(), probe.end(), 0.f);
                 scatter(pix, probe.data());
                 for (float v : probe)
@@ -709,6 +724,18 @@ int ddrr_trilinear_backward_volume_bricks(int dx, int dy, int dz, const float *s
     for (size_t i = 0; i < (size_t)dx * dy * dz; ++i) g_volume[i] = NAN;
     return tri_owner_host(dx, dy, dz, source, target, img, grad_out, B, det_h, det_w, voxel_shift,
                           eps, n_points, *alphamin, *alphamax, g_volume);
+}
+
+int ddrr_trilinear_backward_channels_volume_bricks(const unsigned char *labels, int dx, int dy,
+                                                   int dz, const float *source, const float *target,
+                                                   const float *img, const float *grad_out, int B,
+                                                   int det_h, int det_w, int C, float voxel_shift,
+                                                   float eps, int n_points, const float *alphamin,
+                                                   const float *alphamax, float *g_volume, void *,
+                                                   void *) {
+    for (size_t i = 0; i < (size_t)dx * dy * dz; ++i) g_volume[i] = NAN;
+    return tri_owner_host(dx, dy, dz, source, target, img, grad_out, B, det_h, det_w, voxel_shift,
+                          eps, n_points, *alphamin, *alphamax, g_volume, labels, C);
 }
 
 int ddrr_siddon_backward_rays(const float *aux, int aux_layout, const float *grad_out,

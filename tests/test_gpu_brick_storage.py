@@ -230,3 +230,36 @@ def test_channel_volume_gradient_on_bricks(gpu, inside, monkeypatch):
     assert float((gb - gr).abs().max()) <= 5e-5 * float(gr.abs().max())
     # (the ray gradients of the two routes: tie flips on a noise volume, see conftest)
     assert float((grads[True][1] - grads[False][1]).abs().max()) <= 5e-2 * float(grads[False][1].abs().max())
+
+
+def test_marcher_channel_volume_gradient_on_bricks(gpu, monkeypatch):
+    """ddrr_trilinear_backward_channels_volume_bricks through the module (Trilinear(mask=...), the
+    volume requires a gradient): owner bricks with the LDS brick as accumulator, the sample's label
+    from the accumulator word or -- nearest voxel outside the owned box -- the label map, against the
+    per-ray kernel's global atomics."""
+    from diffdrr_amd import DRR
+    from diffdrr_amd.data import synthetic_subject
+
+    drr = DRR(synthetic_subject((70, 64, 72), kind="noise", seed=1, n_labels=9), sdd=500.0, height=28,
+              width=36, delx=2.5, renderer="trilinear").to(gpu)
+    rot = torch.tensor([[0.2, -0.1, 0.3], [0.9, 0.2, -0.4]], device=gpu)
+    xyz = torch.tensor([[3.0, 300.0, -2.0], [-4.0, 320.0, 5.0]], device=gpu)
+    go = torch.rand(2, 9, 28, 36, device=gpu)
+    calls = []
+    real = ops.trilinear_backward_channels_volume_bricks
+    monkeypatch.setattr(ops, "trilinear_backward_channels_volume_bricks",
+                        lambda *a, **k: calls.append(1) or real(*a, **k))
+    grads = {}
+    vol = drr.density
+    for on_bricks in (True, False):
+        drr.renderer.channels_on_bricks = on_bricks
+        v = vol.detach().clone().requires_grad_()
+        drr.density = v
+        img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY", mask_to_channels=True,
+                  n_points=120)
+        (img * go).sum().backward()
+        grads[on_bricks] = v.grad.clone()
+    drr.density = vol
+    assert calls == [1]
+    assert torch.isfinite(grads[True]).all()
+    assert float((grads[True] - grads[False]).abs().max()) <= 5e-5 * float(grads[False].abs().max())

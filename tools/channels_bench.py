@@ -155,6 +155,21 @@ for B in (1, 8):
                                                     n_points=500)
         rp = ops.trilinear_backward_channels(tri.density, labels, s_, t_, L, go, a0, a1, n_points=500,
                                              det=(H, H))
+        tv_b, _ = timeit(lambda: ops.trilinear_backward_channels_volume_bricks(labels, s_, t_, L, go, a0, a1,
+                                                                               (H, H), n_points=500))
+        tv_r, _ = timeit(lambda: ops.trilinear_backward_channels(tri.density, labels, s_, t_, L, go, a0, a1,
+                                                                 n_points=500, det=(H, H), want_rays=False,
+                                                                 want_img=False, want_alpha=False,
+                                                                 want_volume=True))
+        gvb = ops.trilinear_backward_channels_volume_bricks(labels, s_, t_, L, go, a0, a1, (H, H), n_points=500)
+        gvr = ops.trilinear_backward_channels(tri.density, labels, s_, t_, L, go, a0, a1, n_points=500,
+                                              det=(H, H), want_rays=False, want_img=False, want_alpha=False,
+                                              want_volume=True)["g_volume"]
+    print(f"trilinear B {B} channel backward, VOLUME gradient: per-ray kernel (global atomics) {tv_r:7.3f} ms | ON THE "
+          f"BRICKS {tv_b:7.3f} ms = {tv_r / tv_b:4.1f} x faster | bricks vs per-ray "
+          f"{float((gvb - gvr).abs().max() / gvr.abs().max()):.1e}", flush=True)
+    with torch.no_grad():
+        pass
     errs = {k: float((rb[k] - rp[k]).abs().max() / rp[k].abs().max()) for k in ("g_img", "g_target", "g_alpha")}
     print(f"trilinear B {B} channel backward, rays + img + range: per-ray kernel {tb_r:7.3f} ms | ON THE "
           f"BRICKS {tb_b:7.3f} ms = {tb_r / tb_b:4.1f} x faster | bricks vs per-ray: "

@@ -137,6 +137,10 @@ for case in range(a.cases):
             rp = ops.trilinear_backward_channels(V, lab, s, t, L, goc, amin, amax, n_points=P)
             for k in ("g_img", "g_target", "g_source", "g_alpha"):
                 e_cb = max(e_cb, ((rb[k] - rp[k]).abs().max() / (rp[k].abs().max() + 1e-30)).item())
+            tvb = ops.trilinear_backward_channels_volume_bricks(lab, s, t, L, goc, amin, amax, (H, W), n_points=P)
+            tvr = ops.trilinear_backward_channels(V, lab, s, t, L, goc, amin, amax, n_points=P, want_rays=False,
+                                                  want_img=False, want_alpha=False, want_volume=True)["g_volume"]
+            e_cb = max(e_cb, ((tvb - tvr).abs().max() / (tvr.abs().max() + 1e-30)).item())
     for k, e in zip(worst, (e_f, e_a, e_v, e_t, e_tv, e_q, e_c, e_cb, e_cg)):
         worst[k] = max(worst[k], e if e == e else float("inf"))
     flag = " <<<" if max(e_f, e_v, e_t, e_tv, e_q, e_c, e_cb) > 2e-4 or max(e_a, e_cg) > 5e-3 or e_f != e_f else ""
