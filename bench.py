@@ -73,11 +73,16 @@ def perturbed_poses(B, seed, device):
 
 
 class KernelTimer:
-    """HIP-event timing of every C-ABI launch inside the timed region, on the stream
-    the kernels run on (ops._launch launches on torch's current stream)."""
+    """HIP-event timing of C-ABI launches, on the stream the kernels run on (ops._launch launches
+    on torch's current stream).  Inside the timed region only the dominant kernel carries events
+    (`only`): a pair of events per launch costs the step 5-10 us of pipeline, and a step has seven
+    launches; the other kernels are timed in a few steps of their own after it (`skip`: all but
+    the dominant one)."""
 
     def __init__(self, ops, on_gpu=True):
         self.enabled = False
+        self.only = None
+        self.skip = None
         self.events = {}
         self.ops = ops
         self.on_gpu = on_gpu
@@ -85,7 +90,9 @@ class KernelTimer:
 
     def install(self):
         def timed(name, device, *args):
-            if self.enabled and self.on_gpu:
+            if self.enabled and ((self.only is not None and name != self.only) or name == self.skip):
+                self._orig(name, device, *args)
+            elif self.enabled and self.on_gpu:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -565,14 +572,24 @@ def run_config(cfg, args, rt, short=False):
         step()
     fence(pending)
     pending.clear()
-    timer.enabled = True
+    timer.enabled, timer.only = True, (dominant if cfg != "4" else None)
     t0 = time.perf_counter()
     for _ in range(steps):
         last = step()
     fence(pending)
     dt = time.perf_counter() - t0
-    timer.enabled = False
+    timer.enabled, timer.only = False, None
     assert torch.isfinite(last).all()
+    # the step's other kernels: a few steps of their own, every launch but the dominant one timed
+    census_steps = 0
+    if cfg != "4":
+        census_steps = min(steps, 30)
+        timer.enabled, timer.skip = True, dominant
+        for _ in range(census_steps):
+            step()
+        fence(pending)
+        pending.clear()
+        timer.enabled, timer.skip = False, None
     if cfg in ("headline", "2"):
         assert torch.isfinite(rot.grad).all() and torch.isfinite(xyz.grad).all()
         images = keep["img"].detach()
@@ -595,11 +612,11 @@ def run_config(cfg, args, rt, short=False):
             for _ in range(n_prime):
                 drr(fr, fx, parameterization="euler_angles", convention="ZXY")
             before = len(timer.events.get(dominant, []))
-            timer.enabled = True
+            timer.enabled, timer.only = True, dominant
             for _ in range(n_timed):
                 drr(fr, fx, parameterization="euler_angles", convention="ZXY")
             torch.cuda.synchronize()
-            timer.enabled = False
+            timer.enabled, timer.only = False, None
             ev = timer.events[dominant][before:]
             f_ms, f_n, f_poses = sum(a.elapsed_time(b) for a, b in ev) / len(ev), len(ev), int(fr.shape[0])
             del timer.events[dominant][before:]
@@ -628,7 +645,8 @@ def run_config(cfg, args, rt, short=False):
         return None
 
     ms_per_step = dt / steps * 1e3
-    kernel_timing = "HIP events around every launch inside the timed region"
+    kernel_timing = ("HIP events around every launch of the dominant kernel inside the timed region (the "
+                     f"step's other kernels: around every launch in {census_steps} further steps)")
     if cfg == "4" and not timer.events:
         # the timed region replayed a HIP graph: no launches went through the timer.  Time the
         # same forward (+ record) launches eagerly, after the fact
@@ -641,6 +659,7 @@ def run_config(cfg, args, rt, short=False):
         torch.cuda.synchronize()
         timer.enabled = False
     steps_k = steps if kernel_timing.startswith("HIP events around every") else 50
+    steps_other = census_steps if kernel_timing.startswith("HIP events around every") else 50
     # the dominant kernel: every launch of it in the timed region, HIP events on its stream
     names = [n for n in timer.events if n == dominant] or \
         [max(timer.events, key=lambda n: timer.total_ms(n)[0])]
@@ -648,7 +667,7 @@ def run_config(cfg, args, rt, short=False):
     k_total, k_n = timer.total_ms(k_name)
     k_ms = k_total / max(1, k_n)   # per launch
     per_step = k_n / steps_k
-    bwd_ms = sum(timer.total_ms(n)[0] for n in timer.events if "backward" in n) / steps_k
+    bwd_ms = sum(timer.total_ms(n)[0] for n in timer.events if "backward" in n and n != k_name) / max(1, steps_other)
     # algorithmic bytes of ONE launch
     with torch.no_grad():
         if cfg == "3":
@@ -695,7 +714,8 @@ def run_config(cfg, args, rt, short=False):
         tot, cnt = timer.total_ms(name)
         if not cnt:
             continue
-        ent = {"kernel": name, "kernel_ms": tot / cnt, "launches_per_step": cnt / steps_k}
+        ent = {"kernel": name, "kernel_ms": tot / cnt,
+               "launches_per_step": cnt / (steps_k if name == k_name else max(1, steps_other))}
         if name == k_name:
             ent.update(algorithmic_bytes_per_launch=alg_bytes, frac=achieved / HBM_PEAK_GBS)
             if cfg == "headline" and at_headline_size and B == 32:  # (the workload the counters were taken on)
