@@ -467,7 +467,7 @@ def siddon_backward_pose(aux, grad_out, source, target, img, Mw, Ainv, P, *, eps
     and reduced per pose in one kernel (reduce sum)."""
     B, N, _ = target.shape
     layout = _aux_layout(aux, B, N)
-    gMw = torch.zeros(B, 3, 4, dtype=torch.float32, device=target.device)
+    gMw = torch.empty(B, 3, 4, dtype=torch.float32, device=target.device)  # (zero-filled by the call)
     if B == 0:
         return gMw
     # (named, so that a contiguous copy outlives the launch)

@@ -427,7 +427,7 @@ int ddrr_raygen_forward(const float *Mw, const float *Ainv, const float *P, int 
                         float *source_v, float *target_v, float *img, void *stream);
 
 /* Adjoint of ddrr_raygen_forward chained behind ddrr_siddon_backward_rays, reduced per
- * pose in the kernel: gMw (B, 3, 4) = dLoss/dMw from the forward record `aux`, grad_out
+ * pose in the kernel: gMw (B, 3, 4) = dLoss/dMw (zero-filled by the call) from the forward record `aux`, grad_out
  * (B, N) and the rays the forward used.  Replaces torch autograd of renderers.py:94-113,
  * drr.py:201-205 and detector.py:151-153 (no (B, N, 3) gradient tensor is materialised).
  * with_img_path = 0 drops the gradient through `img`
