@@ -167,11 +167,12 @@ __device__ __forceinline__ void wave_fence() {
 // order_ws / order_cap: the room for the hand-out order of the bricks (bricks_fwd.hip).
 long brick_launch_workspace_bytes(int dx, int dy, int dz);
 int brick_launch_resources(hipStream_t st, void *launch_ws, int dx, int dy, int dz, int &n_cu,
-                           int *&work, int **order_ws = nullptr, int *order_cap = nullptr);
+                           int *&work, int **order_ws = nullptr, int *order_cap = nullptr,
+                           bool zero_work = true);
 
 // The 32^3 fp32 launch path of bricks.hip (every mode); bricks_fwd.hip falls back to it.
-void order_bricks(BrickArgs &q, int BX, int BY, int BZ, int nby, int nbz, int n_bricks, int slots,
-                  hipStream_t st);
+bool order_bricks(BrickArgs &q, int BX, int BY, int BZ, int nby, int nbz, int n_bricks, int slots,
+                  hipStream_t st, bool zero_counter = false);
 int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const float *source,
                   const float *target, const float *img, const float *grad_out, int B, int det_h,
                   int det_w, float voxel_shift, float eps, float *out, float *aux,

@@ -955,7 +955,7 @@ long brick_launch_workspace_bytes(int dx, int dy, int dz) {
 }
 
 int brick_launch_resources(hipStream_t st, void *launch_ws, int dx, int dy, int dz, int &n_cu_out,
-                           int *&work, int **order_ws, int *order_cap) {
+                           int *&work, int **order_ws, int *order_cap, bool zero_work) {
     constexpr int kMaxDev = 64;
     static std::mutex mu;
     static int n_cu[kMaxDev] = {0};
@@ -978,7 +978,8 @@ int brick_launch_resources(hipStream_t st, void *launch_ws, int dx, int dy, int 
         *order_ws = work + 64;
         *order_cap = (int)(((long)((dx + 31) / 32) * ((dy + 31) / 32)) * ((dz + 31) / 32));
     }
-    if ((e = hipMemsetAsync(work, 0, 4 * sizeof(int), st)) != hipSuccess)
+    // (zero_work = false: the caller clears the counter itself, bricks_fwd.hip launch_cfg)
+    if (zero_work && (e = hipMemsetAsync(work, 0, 4 * sizeof(int), st)) != hipSuccess)
         return fail_hip(e, "hipMemsetAsync");
     return 0;
 }

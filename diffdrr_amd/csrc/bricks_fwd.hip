@@ -1293,7 +1293,10 @@ __global__ __launch_bounds__(256) void brick_weight_kernel(BrickArgs p, int BX, 
 
 constexpr int kOrderClasses = 1024;
 __global__ __launch_bounds__(1024) void brick_order_kernel(const float *__restrict__ weight,
-                                                           int n_bricks, int *__restrict__ order) {
+                                                           int n_bricks, int *__restrict__ order,
+                                                           int *__restrict__ zero4) {
+    // (zero4: the launch's brick counter, cleared here instead of by a memset of its own)
+    if (zero4 && threadIdx.x < 4) zero4[threadIdx.x] = 0;
     __shared__ int hist[kOrderClasses];
     __shared__ float wmax_s[16];
     const int tid = threadIdx.x;
@@ -1381,7 +1384,11 @@ int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t
         return fail(-1, "packed bricks are 16-bit bricks");
     }
     BrickArgs q = p;
-    order_bricks(q, C::BX, C::BY, C::BZ, nby, nbz, n_bricks, slots, st);
+    // (the launch's counter is cleared by the order kernel, or -- no order -- by a memset)
+    if (!order_bricks(q, C::BX, C::BY, C::BZ, nby, nbz, n_bricks, slots, st, true)) {
+        const hipError_t e = hipMemsetAsync(q.work, 0, 4 * sizeof(int), st);
+        if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    }
     const dim3 grid(n_bricks < slots ? n_bricks : slots), block(C::THREADS);
     hipLaunchKernelGGL((siddon_fwd_brick_kernel<AUX, C>), grid, block, C::LDS, st, q, out, aux);
     return 0;
@@ -1420,6 +1427,7 @@ int launch_sq(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t 
         // (the shared-ring variants have no fp32 path: tools builds only)
     }
     const dim3 grid(n_bricks < slots ? n_bricks : slots), block(C::THREADS);
+    if (hipMemsetAsync(p.work, 0, 4 * sizeof(int), st) != hipSuccess) return fail(-1, "hipMemsetAsync");
     hipLaunchKernelGGL((siddon_fwd_brick_sq_kernel<AUX, C, NCLS>), grid, block, S::LDS, st, p, out, aux);
     return 0;
 }
@@ -1445,15 +1453,17 @@ namespace ddrr_brick {
 // Heaviest bricks first (brick_weight_kernel, brick_order_kernel): fills q.order from the launch's
 // order workspace.  Not with fewer bricks than workgroups (nothing to order) or a handful of
 // poses (the launch is latency-bound and the two small kernels cost more than the order gains).
-void order_bricks(BrickArgs &q, int BX, int BY, int BZ, int nby, int nbz, int n_bricks, int slots,
-                  hipStream_t st) {
-    if (!(q.order_ws && n_bricks <= q.order_cap && n_bricks > slots && !q.order && q.B >= 8)) return;
+bool order_bricks(BrickArgs &q, int BX, int BY, int BZ, int nby, int nbz, int n_bricks, int slots,
+                  hipStream_t st, bool zero_counter) {
+    if (!(q.order_ws && n_bricks <= q.order_cap && n_bricks > slots && !q.order && q.B >= 8)) return false;
     float *weight = reinterpret_cast<float *>(q.order_ws);
     int *order = q.order_ws + q.order_cap;
     hipLaunchKernelGGL(brick_weight_kernel, dim3((n_bricks + 3) / 4), dim3(256), 0, st, q, BX, BY,
                        BZ, nby, nbz, n_bricks, weight);
-    hipLaunchKernelGGL(brick_order_kernel, dim3(1), dim3(1024), 0, st, weight, n_bricks, order);
+    hipLaunchKernelGGL(brick_order_kernel, dim3(1), dim3(1024), 0, st, weight, n_bricks, order,
+                       zero_counter ? q.work : nullptr);
     q.order = order;
+    return true;
 }
 
 // variant: DDRR_BRICKS_F32 (0) or DDRR_BRICKS_Q16 (1); tools builds know more (g_brick_variant)
@@ -1545,7 +1555,8 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
     if (variant >= 16) p.t1 = g_brick_sq_width;  // shared rings: t1 = class width
 #endif
     int n_cu = 0;
-    if (int rc = brick_launch_resources(st, launch_ws, dx, dy, dz, n_cu, p.work, &p.order_ws, &p.order_cap))
+    if (int rc = brick_launch_resources(st, launch_ws, dx, dy, dz, n_cu, p.work, &p.order_ws, &p.order_cap,
+                                        /*zero_work=*/false))
         return rc;
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
     if (g_brick_dbg & 512) p.order_ws = nullptr;  // (bricks in id order)

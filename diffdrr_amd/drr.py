@@ -55,7 +55,10 @@ class DRR(nn.Module):
         self.subject = subject
         affine = torch.as_tensor(subject.volume.affine, dtype=torch.float32).unsqueeze(0)
         self.register_buffer("_affine", affine, persistent=persistent)
-        self.register_buffer("_affine_inverse", torch.linalg.inv(affine), persistent=persistent)
+        # (row-major: torch.linalg.inv hands back column-major strides, and every render would
+        # copy the 3 x 4 block it passes to the kernels)
+        self.register_buffer("_affine_inverse", torch.linalg.inv(affine).contiguous(),
+                             persistent=persistent)
         density = subject.density.data.squeeze().to(torch.float32).contiguous()
         self.register_buffer("density", density, persistent=persistent)
         if subject.mask is not None:
