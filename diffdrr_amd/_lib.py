@@ -82,7 +82,7 @@ _SIGNATURES = {
     "ddrr_pose_euler_forward": [_P, _P, _I, _I, _I, _P, _I, _P, _P],
     "ddrr_pose_euler_backward": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P],
     "ddrr_ncc_forward": [_P, _L, _P, _I, _I, _F, _P, _P, _P],
-    "ddrr_ncc_backward": [_P, _L, _P, _P, _P, _I, _I, _P, _P, _P],
+    "ddrr_ncc_backward": [_P, _L, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "ddrr_sobel_forward": [_P, _I, _I, _I, _P, _P],
     "ddrr_sobel_backward": [_P, _I, _I, _I, _P, _P],
     "ddrr_raygen_forward": [_P, _P, _P, _I, _I, _P, _P, _P, _P],

@@ -215,14 +215,14 @@ __global__ __launch_bounds__(kNccThreads) void ncc_fwd_kernel(
 // shared x1 gets no gradient from this kernel).
 __global__ __launch_bounds__(kBlock) void ncc_bwd_kernel(
     const float *__restrict__ x1, long x1_stride, const float *__restrict__ x2,
-    const float *__restrict__ stats, const float *__restrict__ g_out, int N,
+    const float *__restrict__ stats, const float *__restrict__ g_out, int g_stride, int N,
     float *__restrict__ g_x1, float *__restrict__ g_x2) {
     const int b = blockIdx.y, n = blockIdx.x * kBlock + threadIdx.x;
     if (n >= N) return;
     const float mu1 = stats[b * 5], s1 = stats[b * 5 + 1], mu2 = stats[b * 5 + 2];
     const float s2 = stats[b * 5 + 3], ncc = stats[b * 5 + 4];
     const float z1 = (x1[b * x1_stride + n] - mu1) / s1, z2 = (x2[(long)b * N + n] - mu2) / s2;
-    const float g = g_out[b] / (float)N;
+    const float g = g_out[b * g_stride] / (float)N;
     if (g_x2) g_x2[(long)b * N + n] = g * (z1 - z2 * ncc) / s2;
     if (g_x1) g_x1[(long)b * N + n] = g * (z2 - z1 * ncc) / s1;
 }
@@ -318,13 +318,15 @@ int ddrr_ncc_forward(const float *x1, long x1_stride, const float *x2, int B, in
 }
 
 int ddrr_ncc_backward(const float *x1, long x1_stride, const float *x2, const float *stats,
-                      const float *g_out, int B, int N, float *g_x1, float *g_x2, void *stream) {
+                      const float *g_out, int g_stride, int B, int N, float *g_x1, float *g_x2,
+                      void *stream) {
     if (!x1 || !x2 || !stats || !g_out) return fail(-1, "null pointer");
+    if (g_stride != 0 && g_stride != 1) return fail(-1, "g_stride must be 1, or 0 for one value shared by the batch");
     if (g_x1 && x1_stride == 0) return fail(-1, "a shared x1 gets no gradient here");
     if (B < 0 || N < 1) return fail(-1, "bad batch / image size");
     if (B == 0 || B > 65535) return B == 0 ? 0 : fail(-1, "at most 65535 pairs per call");
     hipLaunchKernelGGL(ncc_bwd_kernel, dim3((N + kBlock - 1) / kBlock, B), dim3(kBlock), 0,
-                       (hipStream_t)stream, x1, x1_stride, x2, stats, g_out, N, g_x1, g_x2);
+                       (hipStream_t)stream, x1, x1_stride, x2, stats, g_out, g_stride, N, g_x1, g_x2);
     return finish("ddrr_ncc_backward");
 }
 

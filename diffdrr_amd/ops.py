@@ -407,12 +407,16 @@ def ncc_forward(x1, x2, eps):
 def ncc_backward(x1, x2, stats, g_out, want_x1, want_x2):
     B, N = x2.shape
     shared = x1.shape[0] == 1 and B != 1
-    x1, x2, g_out = x1.contiguous(), x2.contiguous(), g_out.contiguous()
+    x1, x2 = x1.contiguous(), x2.contiguous()
+    # (the gradient of `.sum()` / `.mean()` arrives as an expanded scalar: read in place, stride 0)
+    g_stride = 0 if (g_out.dim() == 1 and B > 1 and g_out.stride(0) == 0) else 1
+    if g_stride:
+        g_out = g_out.contiguous()
     g_x2 = torch.empty_like(x2) if want_x2 else None
     g_x1 = torch.empty_like(x2) if (want_x1 and not shared) else None
     if B:
         _launch("ddrr_ncc_backward", x2.device, x1.data_ptr(), 0 if shared else N, x2.data_ptr(),
-                stats.data_ptr(), g_out.data_ptr(), B, N, _ptr(g_x1), _ptr(g_x2))
+                stats.data_ptr(), g_out.data_ptr(), g_stride, B, N, _ptr(g_x1), _ptr(g_x2))
     return g_x1, g_x2
 
 

@@ -457,9 +457,12 @@ int ddrr_pose_euler_backward(const float *rot, const float *xyz, int a0, int a1,
 int ddrr_ncc_forward(const float *x1, long x1_stride, const float *x2, int B, int N, float eps,
                      float *out, float *stats, void *stream);
 
-/* Gradient of ddrr_ncc_forward w.r.t. x2 (and x1 unless shared); either may be NULL. */
+/* Gradient of ddrr_ncc_forward w.r.t. x2 (and x1 unless shared); either may be NULL.  g_out: (B)
+ * with g_stride = 1, or ONE value for every pair with g_stride = 0 (what autograd hands the
+ * backward of `.sum()` / `.mean()`: an expanded scalar, read in place). */
 int ddrr_ncc_backward(const float *x1, long x1_stride, const float *x2, const float *stats,
-                      const float *g_out, int B, int N, float *g_x1, float *g_x2, void *stream);
+                      const float *g_out, int g_stride, int B, int N, float *g_x1, float *g_x2,
+                      void *stream);
 
 /* The Sobel pair in front of GradientNormalizedCrossCorrelation2d (reference metrics.py:69-94:
  * Conv2d(1, 2, 3, padding=1) with Gx = [[1,0,-1],[2,0,-2],[1,0,-1]], Gy = [[1,2,1],[0,0,0],

@@ -1363,10 +1363,11 @@ int ddrr_ncc_forward(const float *x1, long x1_stride, const float *x2, int B, in
 }
 
 int ddrr_ncc_backward(const float *x1, long x1_stride, const float *x2, const float *stats,
-                      const float *g_out, int B, int N, float *g_x1, float *g_x2, void *) {
+                      const float *g_out, int g_stride, int B, int N, float *g_x1, float *g_x2,
+                      void *) {
     for (int b = 0; b < B; ++b) {
         const float *st = stats + b * 5;
-        const float g = g_out[b] / (float)N;
+        const float g = g_out[b * g_stride] / (float)N;
         for (int n = 0; n < N; ++n) {
             const float z1 = (x1[b * x1_stride + n] - st[0]) / st[1];
             const float z2 = (x2[(long)b * N + n] - st[2]) / st[3];

@@ -210,6 +210,23 @@ def test_ncc_matches_reference():
                    g["ncc_ab_patch5"]) < 1e-5
 
 
+def test_ncc_backward_reads_an_expanded_gradient_in_place(emulated_ops):
+    """`.sum().backward()` hands the fused NCC an expanded scalar (stride 0): ddrr_ncc_backward
+    reads it in place (g_stride = 0) and gives what a materialised vector of ones gives."""
+    g = torch.Generator().manual_seed(5)
+    fixed = torch.rand(1, 1, 12, 9, generator=g) + 2
+    grads = []
+    for weights in (None, torch.ones(4)):
+        x = (torch.rand(4, 1, 12, 9, generator=torch.Generator().manual_seed(6)) + 1).requires_grad_()
+        ncc = NormalizedCrossCorrelation2d()(fixed.expand(4, -1, -1, -1), x)
+        (ncc.sum() if weights is None else (ncc * weights).sum()).backward()
+        grads.append(x.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    x = (torch.rand(4, 1, 12, 9, generator=torch.Generator().manual_seed(6)) + 1).requires_grad_()
+    NormalizedCrossCorrelation2d()(fixed.expand(4, -1, -1, -1), x).mean().backward()
+    assert torch.allclose(x.grad * 4, grads[0], rtol=1e-6, atol=0)
+
+
 def test_metrics_match_reference_values_and_gradients(emulated_ops):
     """NCC (whole image, patch-wise, multiscale) and gradient-NCC against the fixture made from the
     unmodified reference's metrics.py (host emulation of the Sobel / NCC kernels; GPU twin:
