@@ -302,8 +302,9 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
         }
         const unsigned N = (unsigned)(p.det_h * p.det_w), C = (unsigned)p.n_channels;
         float sumT, rec[6];
-        if (!tri_brick_march_weighted(LdsAbsFetch{}, base, T, p.D, s, t, p.shift, p.eps, p.n_points,
-                                      p.amin[0], p.amax[0],
+        const TriLabelOf tl{p.labels, p.D};
+        if (!tri_brick_march_weighted(LdsAbsFetch{}, [&](float rx, float ry, float rz) { return tl(rx, ry, rz, false, 0u); },
+                                      base, T, p.D, s, t, p.shift, p.eps, p.n_points, p.amin[0], p.amax[0],
                                       BrickColumnWeight<true>{p.grad_out, (b * C * N + pix) * 4u, N * 4u, C},
                                       sumT, rec))
             return;
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                          (reinterpret_cast<uintptr_t>(p.labels) & 3) == 0);
     const bool vec_out = GRAD && (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.g_volume) & 15) == 0;
     const bool labels_dword_ok = (MODE == BRICK_CHANNELS || MODE == BRICK_TRI_CHANNELS ||
-                                  MODE == BRICK_CHANNELS_AUX || MODE == BRICK_TRI_CHANNELS_AUX || GRADL) &&
+                                  MODE == BRICK_CHANNELS_AUX || GRADL) &&
                                  (reinterpret_cast<uintptr_t>(p.labels) & 3) == 0;
     // fixed-point scale of the LDS accumulator (volume-gradient modes): the largest sum a
     // voxel can receive is n_sum (contributions) * wmax (each) -- volgrad_prepare_kernel
@@ -480,13 +481,14 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         asm volatile("" : "+v"(tid_here));
         const int q4 = (tid_here & 7) * 4, z = box.lo[2] + q4;
         float *const d0 = brick + q4;
+        // (the marcher's channel backward stages the volume's own values and reads the label map)
         constexpr bool LABELS = MODE == BRICK_CHANNELS || MODE == BRICK_TRI_CHANNELS ||
-                                MODE == BRICK_CHANNELS_AUX || MODE == BRICK_TRI_CHANNELS_AUX || GRADL;
+                                MODE == BRICK_CHANNELS_AUX || GRADL;
         // (Siddon channels: labels without a channel are staged as value 0 | label 0; the channel
         // gradient's accumulator: an integer 0 over the label, or a float 0 where there is no bound)
         auto pack_word = [&](float v, unsigned lab) {
             if (GRADL) return fixq != 0.f ? bits_as_float(lab & 0xffu) : 0.f;
-            return MODE != BRICK_TRI_CHANNELS && MODE != BRICK_TRI_CHANNELS_AUX
+            return MODE != BRICK_TRI_CHANNELS
                        ? pack_voxel_label_below(v, lab, (unsigned)p.n_channels)
                                           : pack_voxel_label(v, lab);
         };

@@ -244,12 +244,15 @@ DDRR_HD bool tri_brick_march_channels(const Acc &acc, float base, const TriGeom 
 // Backward of tri_brick_march_channels w.r.t. the rays: the record of tri_brick_march<true> with
 // every sample (its T and dT) multiplied by `weight(label)` -- the incoming gradient of the
 // channel the sample's nearest voxel selects, fetched when the label changes along the ray.
-// The values are the packed words' (16-bit mantissa), as the forward rendered them.
-template <class Acc, class Weight>
-DDRR_HD bool tri_brick_march_weighted(const Acc &acc, float base, const TriGeom &G, const Dims D,
-                                      const float s[3], const float t[3], float shift, float eps,
-                                      int P, float amin, float amax, const Weight &weight,
-                                      float &sumT, float rec[6]) {
+// The brick holds the volume's own fp32 values (dT is made of DIFFERENCES of neighbouring voxels:
+// on a smooth volume the packed words' 16-bit mantissas would cost it three digits); the label of
+// the nearest voxel comes from `label(rx, ry, rz)` (the label map; 0 outside the volume).
+template <class Acc, class Label, class Weight>
+DDRR_HD bool tri_brick_march_weighted(const Acc &acc, const Label &label, float base,
+                                      const TriGeom &G, const Dims D, const float s[3],
+                                      const float t[3], float shift, float eps, int P, float amin,
+                                      float amax, const Weight &weight, float &sumT,
+                                      float rec[6]) {
     sumT = 0.f;
     rec[0] = rec[1] = rec[2] = rec[3] = rec[4] = rec[5] = 0.f;
     const float go = shift - 0.5f;
@@ -273,7 +276,6 @@ DDRR_HD bool tri_brick_march_weighted(const Acc &acc, float base, const TriGeom 
     const float offc = fmaf(-G.lo[0], G.stridef[0],
                             fmaf(-G.lo[1], G.stridef[1], fmaf(-G.lo[2], G.stridef[2], base)));
     const float sx = G.stridef[0], sy = G.stridef[1];
-    auto val = [](float w) { return bits_as_float(float_bits(w) & 0xffffff00u); };
     int cur = -1;
     float g = 0.f;
     float sum = 0.f, Ax = 0.f, Ay = 0.f, Az = 0.f, Bx = 0.f, By = 0.f, Bz = 0.f;
@@ -293,18 +295,15 @@ DDRR_HD bool tri_brick_march_weighted(const Acc &acc, float base, const TriGeom 
         const unsigned a00 = (unsigned)(int)o00;
         const unsigned a10 = (unsigned)(int)(o00 + sx), a01 = (unsigned)(int)(o00 + sy);
         const unsigned a11 = (unsigned)(int)(o00 + sx + sy);
-        const float v000 = val(acc(a00)), v001 = val(acc(a00 + 4u));
-        const float v100 = val(acc(a10)), v101 = val(acc(a10 + 4u));
-        const float v010 = val(acc(a01)), v011 = val(acc(a01 + 4u));
-        const float v110 = val(acc(a11)), v111 = val(acc(a11 + 4u));
+        const float v000 = acc(a00), v001 = acc(a00 + 4u), v100 = acc(a10), v101 = acc(a10 + 4u);
+        const float v010 = acc(a01), v011 = acc(a01 + 4u), v110 = acc(a11), v111 = acc(a11 + 4u);
         // the label as tri_brick_march_channels finds it
         float un[3];
         march_exact_coord(D, lin, q, amin, s, shift, false, un);
         const float rx = fminf(fmaxf(rintf(un[0]), fx), fx + 1.f);
         const float ry = fminf(fmaxf(rintf(un[1]), fy), fy + 1.f);
         const float rz = fminf(fmaxf(rintf(un[2]), fz), fz + 1.f);
-        const unsigned an = (unsigned)(int)fmaf(rx, sx, fmaf(ry, sy, fmaf(rz, 4.f, offc)));
-        const int lab = (int)(float_bits(acc(an)) & 0xffu);
+        const int lab = (int)label(rx, ry, rz);
         if (lab != cur) {
             cur = lab;
             g = weight((unsigned)lab);

@@ -224,7 +224,7 @@ int ddrr_siddon_backward_channels_bricks(const float *volume, const unsigned cha
  * by the call) with every sample's T and dT multiplied by grad_out[b, label of its nearest
  * voxel, n] (labels >= C weigh 0), so that ddrr_trilinear_backward_rays(aux, ones (B, N), ...)
  * returns d/d source, d/d target, d/d img and d/d alphamin, alphamax of sum_c grad_out_c out_c.
- * The values are the staged words' (16-bit mantissas), as the forward rendered them.
+ * The brick holds the volume's own fp32 values; the labels are read from the label map.
  * B * C * N < 2^30, N < 2^22.  (The volume gradient: ddrr_trilinear_backward_channels_volume_bricks.) */
 int ddrr_trilinear_backward_channels_bricks(const float *volume, const unsigned char *labels,
                                             int dx, int dy, int dz, const float *source,

@@ -115,7 +115,7 @@ int tri_bricks_host(const float *volume, int dx, int dy, int dz, const float *so
                     if (x < 0 || y < 0 || z < 0 || x >= dx || y >= dy || z >= dz) continue;
                     const long at = ((long)x * dy + y) * dz + z;
                     brick[lx * lay.sx + ly * lay.sy + lz] =
-                        labels ? pack_voxel_label(volume[at], labels[at]) : volume[at];
+                        labels && !grad_cols ? pack_voxel_label(volume[at], labels[at]) : volume[at];
                 }
         for (int b = 0; b < B; ++b) {
             const PoseGrid pg = pose_grid(source + (long)b * 3, target + (long)b * N * 3, det_h,
@@ -143,7 +143,13 @@ int tri_bricks_host(const float *volume, int dx, int dy, int dz, const float *so
                 if (labels && grad_cols) {
                     const float *col = grad_cols + (long)b * C * N + pix;
                     if (tri_brick_march_weighted(
-                            HostFetch{brick.data()}, 0.f, G, D, s, t, voxel_shift, eps, n_points, amin,
+                            HostFetch{brick.data()},
+                            [&](float rx, float ry, float rz) -> unsigned {
+                                const bool in = rx >= 0.f && ry >= 0.f && rz >= 0.f && rx < (float)dx &&
+                                                ry < (float)dy && rz < (float)dz;
+                                return in ? labels[((long)(int)rx * dy + (int)ry) * dz + (int)rz] : 0u;
+                            },
+                            0.f, G, D, s, t, voxel_shift, eps, n_points, amin,
                             amax, [&](unsigned lab) { return lab < (unsigned)C ? col[(long)lab * N] : 0.f; },
                             sumT, rec)) {
                         aux[r] += sumT;
