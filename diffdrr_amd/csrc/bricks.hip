@@ -389,9 +389,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     unsigned *myq = queue + wave * kBuckets * kQueueCap;
     const unsigned pix_mask = (1u << p.pix_bits) - 1u;
     const int n_chunks = (p.B + kPoseChunk - 1) / kPoseChunk;
-    const bool vec_ok = (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.vol) & 15) == 0 &&
-                        ((MODE != BRICK_CHANNELS && MODE != BRICK_CHANNELS_AUX) ||
-                         (reinterpret_cast<uintptr_t>(p.labels) & 3) == 0);
+    // (quads of four voxels from dword-aligned addresses, brick_shared.h quad_load: any D.z)
+    const bool vec_ok = (long)p.D.x * p.D.y * p.D.z >= 4 && (reinterpret_cast<uintptr_t>(p.vol) & 3) == 0;
     const bool vec_out = GRAD && (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.g_volume) & 15) == 0;
     const bool labels_dword_ok = (MODE == BRICK_CHANNELS || MODE == BRICK_TRI_CHANNELS ||
                                   MODE == BRICK_CHANNELS_AUX || GRADL) &&
@@ -493,8 +492,6 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                                           : pack_voxel_label(v, lab);
         };
         const bool stage_vec = ch == 0 && !GRAD && !TRI && vec_ok;
-        // z and D.z are multiples of 4: a quad is wholly inside or wholly outside
-        const bool in_z = z + 4 <= box.hi[2];
         if (tid < nb) {
             const PoseGrid pg = pose_grid(p.source + (long)(b0 + tid) * 3,
                                           p.target + (long)(b0 + tid) * N * 3, p.det_h, p.det_w);
@@ -513,8 +510,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         if (stage_vec) {
 #pragma unroll
             for (int h0 = 0; h0 < kQuads; h0 += kPer) {
-                float4 q[kPer];
-                unsigned ql[LABELS ? kPer : 1];  // BRICK_CHANNELS: the quads' four labels
+                quad_u32x4 qv[kPer];
+                unsigned ql[LABELS ? kPer : 1] = {};  // BRICK_CHANNELS: the quads' four labels
 #pragma unroll
                 for (int i = 0; i < kPer; ++i) {
                     const int row = (tid >> 3) + (h0 + i) * (kBrickThreads >> 3);
@@ -522,34 +519,39 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                     const int x = box.lo[0] + lx, y = box.lo[1] + ly;
                     // clamped (always readable) address; what lies outside is zeroed below
                     const int xc = x < p.D.x ? x : p.D.x - 1, yc = y < p.D.y ? y : p.D.y - 1;
-                    const long at = ((long)xc * p.D.y + yc) * p.D.z + (in_z ? z : 0);
-                    q[i] = *reinterpret_cast<const float4 *>(p.vol + at);
-                    if (LABELS) ql[i] = *reinterpret_cast<const unsigned *>(p.labels + at);
+                    quad_load<LABELS>(p.vol, p.labels, p.D, ((long)xc * p.D.y + yc) * p.D.z + z, qv[i],
+                                      ql[LABELS ? i : 0]);
                 }
 #pragma unroll
                 for (int i = 0; i < kPer; ++i) {
                     const int row = (tid >> 3) + (h0 + i) * (kBrickThreads >> 3);
                     const int lx = row / BRICK, ly = row - lx * BRICK;
-                    const bool in = in_z && box.lo[0] + lx < box.hi[0] && box.lo[1] + ly < box.hi[1];
+                    const int x = box.lo[0] + lx, y = box.lo[1] + ly;
+                    const bool in = x < box.hi[0] && y < box.hi[1];
                     float *d = d0 + lx * p.lay.sx + ly * p.lay.sy;
+                    quad_u32x4 w = qv[i];
+                    unsigned lab4 = ql[LABELS ? i : 0];
+                    quad_fix(p.D, x, y, z, w, lab4);
+                    float4 q = make_float4(bits_as_float(w.x), bits_as_float(w.y), bits_as_float(w.z),
+                                           bits_as_float(w.w));
                     if (LABELS) {
-                        q[i].x = pack_word(q[i].x, ql[i]);
-                        q[i].y = pack_word(q[i].y, ql[i] >> 8);
-                        q[i].z = pack_word(q[i].z, ql[i] >> 16);
-                        q[i].w = pack_word(q[i].w, ql[i] >> 24);
+                        q.x = pack_word(q.x, lab4);
+                        q.y = pack_word(q.y, lab4 >> 8);
+                        q.z = pack_word(q.z, lab4 >> 16);
+                        q.w = pack_word(q.w, lab4 >> 24);
                     }
-                    d[0] = in ? q[i].x : 0.f;
-                    d[1] = in ? q[i].y : 0.f;
-                    d[2] = in ? q[i].z : 0.f;
-                    d[3] = in ? q[i].w : 0.f;
+                    d[0] = in && z < box.hi[2] ? q.x : 0.f;
+                    d[1] = in && z + 1 < box.hi[2] ? q.y : 0.f;
+                    d[2] = in && z + 2 < box.hi[2] ? q.z : 0.f;
+                    d[3] = in && z + 3 < box.hi[2] ? q.w : 0.f;
                     nz |= __float_as_uint(d[0]) | __float_as_uint(d[1]) | __float_as_uint(d[2]) |
                           __float_as_uint(d[3]);
                 }
                 if (LABELS) __builtin_amdgcn_sched_barrier(0);  // keep the rounds apart
             }
         } else if (ch == 0) {
-            // general path (halo bricks of the trilinear marcher, unaligned volumes, and the
-            // zero fill of the gradient accumulator), kFly quads in flight.  Every load is issued
+            // general path (halo bricks of the trilinear marcher, volumes of fewer than four voxels,
+            // and the zero fill of the gradient accumulator), kFly quads in flight.  Every load is issued
             // unconditionally from a clamped (always readable) address and what lies outside is
             // zeroed afterwards: loads under per-lane conditions end up in separate round trips
             // (measured with the labels: staging 4x the plain brick's).  The quad's four labels

@@ -247,6 +247,9 @@ __device__ __forceinline__ void fwd_item(const BrickArgs &p, unsigned lds_base,
 // of them in flight at a time (all of a round's loads are issued before its first LDS store).
 // 16-bit bricks: `range` / `brick_empty` from the ranges brick_range_kernel left; fp32 bricks:
 // counter[2] is raised if any staged voxel is non-zero (read after the next barrier).
+// Any D.z (the reference's example CT has 133 slices): a quad is ONE 16-byte load from a
+// dword-aligned address (brick_shared.h quad_load); what it reads beyond its row is masked per
+// voxel.
 template <class C>
 __device__ __forceinline__ void fwd_stage_brick(const BrickArgs &p, unsigned char *brick,
                                                 const Box &box, int brick_id, int tid,
@@ -257,7 +260,6 @@ __device__ __forceinline__ void fwd_stage_brick(const BrickArgs &p, unsigned cha
     constexpr int ROWS_PER_PASS = C::THREADS / QZ;
     const int qz4 = (tid % QZ) * 4, row0 = tid / QZ;
     const int z = box.lo[2] + qz4;
-    const bool in_z = z + 4 <= box.hi[2];  // (z and D.z are multiples of 4)
     if (C::Q16) {
         const float lo = p.ranges[2 * brick_id], hi = p.ranges[2 * brick_id + 1];
         range = q16_range(lo, hi);
@@ -266,38 +268,44 @@ __device__ __forceinline__ void fwd_stage_brick(const BrickArgs &p, unsigned cha
     unsigned nz = 0u;
 #pragma unroll
     for (int h0 = 0; h0 < NQ; h0 += PER) {
-        float4 q[PER];
+        quad_u32x4 q[PER];
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int row = row0 + (h0 + i) * ROWS_PER_PASS;
             const int lx = row / C::BY, ly = row - lx * C::BY;
             const int x = box.lo[0] + lx, y = box.lo[1] + ly;
-            // clamped (always readable) address; what lies outside is zeroed below
+            // clamped (always readable) addresses; what lies outside is zeroed below
             const int xc = x < p.D.x ? x : p.D.x - 1, yc = y < p.D.y ? y : p.D.y - 1;
-            const long at = ((long)xc * p.D.y + yc) * p.D.z + (in_z ? z : 0);
-            q[i] = *reinterpret_cast<const float4 *>(p.vol + at);
+            unsigned none = 0u;
+            quad_load<false>(p.vol, nullptr, p.D, ((long)xc * p.D.y + yc) * p.D.z + z, q[i], none);
         }
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int row = row0 + (h0 + i) * ROWS_PER_PASS;
             const int lx = row / C::BY, ly = row - lx * C::BY;
-            const bool in = in_z && box.lo[0] + lx < box.hi[0] && box.lo[1] + ly < box.hi[1];
-            if (!in) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int x = box.lo[0] + lx, y = box.lo[1] + ly;
+            const bool in = x < box.hi[0] && y < box.hi[1];
+            quad_u32x4 w = q[i];
+            unsigned none = 0u;
+            quad_fix(p.D, x, y, z, w, none);
+            if (!(in && z < box.hi[2])) w.x = 0u;
+            if (!(in && z + 1 < box.hi[2])) w.y = 0u;
+            if (!(in && z + 2 < box.hi[2])) w.z = 0u;
+            if (!(in && z + 3 < box.hi[2])) w.w = 0u;
             if (C::Q16) {
                 unsigned short *d =
                     reinterpret_cast<unsigned short *>(brick + lx * C::SX + ly * C::SY + qz4 * 2);
-                d[0] = (unsigned short)q16_encode(q[i].x, range);
-                d[1] = (unsigned short)q16_encode(q[i].y, range);
-                d[2] = (unsigned short)q16_encode(q[i].z, range);
-                d[3] = (unsigned short)q16_encode(q[i].w, range);
+                d[0] = (unsigned short)q16_encode(bits_as_float(w.x), range);
+                d[1] = (unsigned short)q16_encode(bits_as_float(w.y), range);
+                d[2] = (unsigned short)q16_encode(bits_as_float(w.z), range);
+                d[3] = (unsigned short)q16_encode(bits_as_float(w.w), range);
             } else {
-                float *df = reinterpret_cast<float *>(brick + lx * C::SX + ly * C::SY + qz4 * 4);
-                df[0] = q[i].x;
-                df[1] = q[i].y;
-                df[2] = q[i].z;
-                df[3] = q[i].w;
-                nz |= __float_as_uint(q[i].x) | __float_as_uint(q[i].y) |
-                      __float_as_uint(q[i].z) | __float_as_uint(q[i].w);
+                unsigned *df = reinterpret_cast<unsigned *>(brick + lx * C::SX + ly * C::SY + qz4 * 4);
+                df[0] = w.x;
+                df[1] = w.y;
+                df[2] = w.z;
+                df[3] = w.w;
+                nz |= (w.x | w.y) | (w.z | w.w);
             }
         }
     }
@@ -336,7 +344,7 @@ __device__ __forceinline__ void fwd_stage_packed(const BrickArgs &p, unsigned ch
 // walk in the brick in hand: the loads fly while the others finish) and from there into LDS.
 // (Native vector registers by name: HIP's uint4 is copied with memcpy, which keeps an object that
 // lives across the brick loop in scratch.)
-typedef unsigned int pf_u32x4 __attribute__((ext_vector_type(4)));  // (a native vector: plain loads / stores)
+typedef quad_u32x4 pf_u32x4;
 template <class C>
 struct PackedPrefetch {
     static constexpr int NV = C::BRICK_BYTES / 16, N = (NV + C::THREADS - 1) / C::THREADS;
@@ -386,15 +394,19 @@ struct PackedPrefetch {
             const int qz4 = (tid % QZ) * 4, row = tid / QZ + I * ROWS_PER_PASS;
             const int lx = row / H::BY, ly = row - lx * H::BY;
             const int x = box.lo[0] + lx, y = box.lo[1] + ly, z = box.lo[2] + qz4;
-            const bool in_z = z + 4 <= box.hi[2];  // (z and D.z are multiples of 4)
+            unsigned none = 0u;
             if (load) {
-                // clamped (always readable) address; what lies outside is zeroed by the store
+                // clamped (always readable) addresses; what lies outside is zeroed by the store
                 const int xc = x < p.D.x ? x : p.D.x - 1, yc = y < p.D.y ? y : p.D.y - 1;
-                const long at = ((long)xc * p.D.y + yc) * p.D.z + (in_z ? z : 0);
-                reg<I>() = *reinterpret_cast<const pf_u32x4 *>(p.vol + at);
+                quad_load<false>(p.vol, nullptr, p.D, ((long)xc * p.D.y + yc) * p.D.z + z, reg<I>(), none);
             } else {
                 pf_u32x4 q = reg<I>();
-                if (!(in_z && x < box.hi[0] && y < box.hi[1])) q = pf_u32x4{0u, 0u, 0u, 0u};
+                quad_fix(p.D, x, y, z, q, none);
+                const bool in = x < box.hi[0] && y < box.hi[1];
+                if (!(in && z < box.hi[2])) q.x = 0u;
+                if (!(in && z + 1 < box.hi[2])) q.y = 0u;
+                if (!(in && z + 2 < box.hi[2])) q.z = 0u;
+                if (!(in && z + 3 < box.hi[2])) q.w = 0u;
                 unsigned *d = reinterpret_cast<unsigned *>(brick + lx * H::SX + ly * H::SY + qz4 * 4);
                 d[0] = q.x, d[1] = q.y, d[2] = q.z, d[3] = q.w;
             }
@@ -503,6 +515,7 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
     // and not for more poses than one chunk: bricks that take long have nothing to hide, and the
     // items held ahead cost the launch's end its balance (64 poses: +1.5 %, 512: +5 %;
     // profiles/r04/look_ahead.txt).
+    constexpr int kLookRounds = 3;
     constexpr int kLaStage = 1 << 30;  // the next brick is on the fp32 path (its halves are requested one by one)
     const bool LOOK = C::Q16 && PackedPrefetch<C>::FITS && p.packed != nullptr && p.B <= C::CHUNK && !(p.dbg & 4096)
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
@@ -574,7 +587,12 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
         // in hand yet, or the launch is in its last two rounds -- and the next item's brick
         const bool last_part = sub + 1 >= n_sub;
         const bool look = LOOK && last_part;
-        const bool claim = look && item + 2 * n_wg < n_bricks;
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+        const int look_rounds = (p.dbg >> 13) & 3 ? 1 + ((p.dbg >> 13) & 3) : kLookRounds;  // (tools: 2 .. 4)
+#else
+        constexpr int look_rounds = kLookRounds;
+#endif
+        const bool claim = look && item + look_rounds * n_wg < n_bricks;
         int nx_item = la_after;  // (claimed by an earlier iteration)
         int req_item = -1, req_brick = 0, req_fb = 0;
         float req_lo = 0.f, req_hi = 0.f;
@@ -1169,7 +1187,7 @@ constexpr int kSubBlocks = 1024;  // 4^3 blocks of a brick, at most
 __global__ __launch_bounds__(256) void brick_range_kernel(const float *__restrict__ vol, Dims D,
                                                           int BX, int BY, int BZ, int nby, int nbz,
                                                           float *__restrict__ ranges,
-                                                          int *__restrict__ fallback) {
+                                                          int *__restrict__ fallback, int vec) {
     __shared__ float red[3][4];
     __shared__ float sub_sum[kSubBlocks];
     __shared__ int sub_nnz[kSubBlocks];
@@ -1188,17 +1206,29 @@ __global__ __launch_bounds__(256) void brick_range_kernel(const float *__restric
     bool bad = false;
     for (int k = threadIdx.x; k < quads; k += 256) {
         const int qz = k % QZ, row = k / QZ, ly = row % ny, lx = row / ny;
-        if (qz * 4 >= nz) continue;  // (nz is a multiple of 4)
-        const float4 v = *reinterpret_cast<const float4 *>(
-            vol + ((long)(x0 + lx) * D.y + (y0 + ly)) * D.z + z0 + qz * 4);
+        if (qz * 4 >= nz) continue;
+        const float *g = vol + ((long)(x0 + lx) * D.y + (y0 + ly)) * D.z + z0 + qz * 4;
+        const int nv = nz - qz * 4;  // voxels of the quad inside the volume (vec: always >= 4)
+        float4 v;
+        if (vec) {
+            v = *reinterpret_cast<const float4 *>(g);
+        } else {
+            // (what lies outside repeats the quad's first voxel for min / max and counts 0 below)
+            v.x = g[0];
+            v.y = nv > 1 ? g[1] : v.x;
+            v.z = nv > 2 ? g[2] : v.x;
+            v.w = nv > 3 ? g[3] : v.x;
+        }
         tmin = fminf(fminf(fminf(tmin, v.x), fminf(v.y, v.z)), v.w);
         tmax = fmaxf(fmaxf(fmaxf(tmax, v.x), fmaxf(v.y, v.z)), v.w);
-        const float sum = (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+        const float sum = (fabsf(v.x) + (nv > 1 ? fabsf(v.y) : 0.f)) +
+                          ((nv > 2 ? fabsf(v.z) : 0.f) + (nv > 3 ? fabsf(v.w) : 0.f));
         bad = bad || !(sum < INFINITY);  // (min / max drop NaNs)
         const int sb = ((lx >> 2) * SBY + (ly >> 2)) * QZ + qz;
         if (n_sub <= kSubBlocks) {
             atomicAdd(&sub_sum[sb], sum);
-            atomicAdd(&sub_nnz[sb], (v.x != 0.f) + (v.y != 0.f) + (v.z != 0.f) + (v.w != 0.f));
+            atomicAdd(&sub_nnz[sb], (v.x != 0.f) + (nv > 1 && v.y != 0.f) + (nv > 2 && v.z != 0.f) +
+                                        (nv > 3 && v.w != 0.f));
         }
     }
 #pragma unroll
@@ -1359,7 +1389,7 @@ int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t
         if (!p.ranges_valid) {
             hipLaunchKernelGGL(brick_range_kernel, dim3(n_bricks), dim3(256), 0, st, p.vol, p.D, C::BX,
                                C::BY, C::BZ, nby, nbz, const_cast<float *>(p.ranges),
-                               const_cast<int *>(p.fallback));
+                               const_cast<int *>(p.fallback), p.vec);
             hipLaunchKernelGGL(brick_fallback_count_kernel, dim3(1), dim3(256), 0, st, p.fallback,
                                n_bricks, p.ws_header);
             if (p.packed) {
@@ -1423,7 +1453,7 @@ int launch_sq(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t 
         if (!p.ranges_valid)
             hipLaunchKernelGGL(brick_range_kernel, dim3(n_bricks), dim3(256), 0, st, p.vol, p.D, C::BX,
                                C::BY, C::BZ, nby, nbz, const_cast<float *>(p.ranges),
-                               const_cast<int *>(p.fallback));
+                               const_cast<int *>(p.fallback), p.vec);
         // (the shared-ring variants have no fp32 path: tools builds only)
     }
     const dim3 grid(n_bricks < slots ? n_bricks : slots), block(C::THREADS);
@@ -1495,17 +1525,24 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
                       float *out, float *aux, float rec_q, hipStream_t st, void *launch_ws,
                       const char *who) {
     const int N = det_h * det_w;
-    // the configurable kernel stages with 16-byte loads; anything else takes the general kernel
+    // (brick_range_kernel: 16-byte loads where the volume's rows are aligned, else dwords)
     const bool vec_ok = (dz & 3) == 0 && (reinterpret_cast<uintptr_t>(volume) & 15) == 0;
+    // the staging reads quads of four voxels from dword-aligned addresses (quad_load)
+    const bool quads_ok = (long)dx * dy * dz >= 4 && (reinterpret_cast<uintptr_t>(volume) & 3) == 0;
+    // fp32 bricks at a handful of poses: the general kernel (no pooled end, no hand-out order --
+    // neither pays there): 7-12 % ahead at one pose, within 2 % from 8 on (profiles/r04/
+    // fp32_bricks_general_vs_configurable.txt)
+    bool few_f32 = variant == DDRR_BRICKS_F32 && B < 8;
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
     if (g_brick_variant != -2) {  // (-2: no override, -1: bricks.hip)
         static int last_variant = -100;
         variant = g_brick_variant;
         if (variant != last_variant) ranges_valid = 0;  // (the variants differ in their brick grids)
         last_variant = variant;
+        few_f32 = false;  // (the variant asked for)
     }
 #endif
-    if (!vec_ok || variant < 0)
+    if (!quads_ok || variant < 0 || few_f32)
         return launch_bricks(aux ? BRICK_FWD_AUX : BRICK_FWD, volume, dx, dy, dz, source, target, img,
                              nullptr, B, det_h, det_w, voxel_shift, eps, out, aux, nullptr, st,
                              launch_ws, who, 0, nullptr, nullptr, rec_q);
@@ -1520,6 +1557,7 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
     p.det_w = det_w;
     p.shift = voxel_shift;
     p.eps = eps;
+    p.vec = vec_ok ? 1 : 0;
     if ((long)B * N * 12 >= (1L << 32))
         return fail(-1, "B * N too large for one brick launch (12 B N must stay below 2^32): "
                         "split the pose batch");

@@ -294,12 +294,11 @@ def brick_fallbacks(volume, storage):
 
 
 def brick_storage_applies(volume) -> bool:
-    """Whether the 16-bit brick storages can serve this volume tensor at all: the configurable
-    kernel stages with 16-byte loads (else the general fp32 kernel runs and a workspace would
-    never be read), and a non-contiguous volume is a new temporary on every call (its workspace
-    would be rebuilt -- and its memory churned -- per render)."""
-    return (volume.dim() == 3 and volume.is_contiguous() and volume.shape[2] % 4 == 0
-            and volume.data_ptr() % 16 == 0)
+    """Whether the 16-bit brick storages can serve this volume tensor at all: a non-contiguous
+    volume is a new temporary on every call (its workspace would be rebuilt -- and its memory
+    churned -- per render).  Any shape does (the reference's example CT has 133 slices: the
+    staging reads quads of four voxels from dword-aligned addresses)."""
+    return volume.dim() == 3 and volume.is_contiguous() and volume.numel() >= 4
 
 
 def brick_ranges(volume):

@@ -263,3 +263,95 @@ def test_marcher_channel_volume_gradient_on_bricks(gpu, monkeypatch):
     assert calls == [1]
     assert torch.isfinite(grads[True]).all()
     assert float((grads[True] - grads[False]).abs().max()) <= 5e-5 * float(grads[False].abs().max())
+
+
+def _scene(gpu, vol, H, W, B, seed, delx=4.0, dist=700.0):
+    from diffdrr_amd import DRR, convert
+    from diffdrr_amd.data import make_subject
+
+    g = torch.Generator().manual_seed(seed)
+    drr = DRR(make_subject(vol, spacing=(1.0, 1.0, 1.0)), sdd=2 * dist, height=H, width=W, delx=delx).to(gpu)
+    rot = ((torch.rand(B, 3, generator=g) - 0.5) * 1.6).to(gpu)
+    xyz = (torch.tensor([0.0, dist, 0.0]) + (torch.rand(B, 3, generator=g) - 0.5) * 40).to(gpu)
+    with torch.no_grad():
+        pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+        source, target = drr.detector(pose, None)
+        L = (target - source).norm(dim=-1).contiguous()
+        s, t = drr.affine_inverse(source).contiguous(), drr.affine_inverse(target).contiguous()
+    return drr, s, t, L
+
+
+@pytest.mark.parametrize("dims", [(70, 50, 133), (33, 34, 5), (64, 40, 66), (20, 24, 3), (40, 40, 131)])
+def test_any_depth_on_the_configurable_kernel(gpu, dims):
+    """The reference's example CT has 133 slices: the brick kernel's staging (bricks_fwd.hip
+    quad_load: 16-byte loads from dword-aligned addresses, per-voxel masks, the volume's last quad
+    read from its last 16 bytes and shifted) serves any D.z, for every storage -- fp32 bricks, 16-bit
+    bricks from the volume, from the packed copy, with bright voxels that put bricks on the fp32
+    path -- image and record against the per-ray kernel, at one pose (look-ahead) and a few."""
+    g = torch.Generator().manual_seed(dims[2])
+    vol = 0.6 + 0.4 * torch.rand(*dims, generator=g)
+    vol[torch.rand(*dims, generator=g) < 1e-3] = 80.0  # (bricks on the fp32 path)
+    vol[-1, -1, -1] = 3.0  # the volume's last voxel: the shifted quad
+    vol[-1, -1, -2 if dims[2] > 1 else -1] = 2.0
+    H, W = 36, 44
+    for B in (1, 4):
+        drr, s, t, L = _scene(gpu, vol, H, W, B, seed=B, delx=3.0, dist=400.0)
+        V = drr.density
+        ref, aux_ref, _ = ops.siddon_forward(V, s, t, L, want_aux=True)
+        scale = float(ref.abs().max())
+        assert scale > 0
+        go = torch.ones_like(ref)
+        gi_ref = ops.siddon_backward_rays(aux_ref, go, s, t, L)[2]
+        for storage in ("f32", "q16", "q16p", "q16p"):
+            out, aux = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True, storage=storage)
+            fwd, _ = ops.siddon_forward_bricks(V, s, t, L, (H, W), storage=storage)
+            assert float((out - ref).abs().max()) < 1e-4 * scale, (storage, B)
+            assert float((fwd - ref).abs().max()) < 1e-4 * scale, (storage, B)
+            gi = ops.siddon_backward_rays(aux, go, s, t, L)[2]
+            assert float((gi - gi_ref).abs().max()) < 1e-4 * float(gi_ref.abs().max()), (storage, B)
+    # a 2 x 2 grid of rays along z inside the volume's last row: exactly the voxels set above
+    x0, y0, n = dims[0] - 0.9, dims[1] - 0.9, dims[2]
+    s = torch.tensor([[[x0 + 0.05, y0 + 0.05, -60.0]]], device=gpu)
+    t = torch.tensor([[x0 + 0.1 * i, y0 + 0.1 * j, n + 60.0] for i in range(2) for j in range(2)],
+                     device=gpu)[None].contiguous()
+    Lz = (t - s).norm(dim=-1).contiguous()
+    ref = ops.siddon_forward(V, s, t, Lz)[0]
+    assert float(ref.min()) > 4.9  # (3 + 2 + what else lies in the row)
+    for storage in ("f32", "q16", "q16p"):
+        out, _ = ops.siddon_forward_bricks(V, s, t, Lz, (2, 2), storage=storage)
+        assert float((out - ref).abs().max()) < 1e-4 * float(ref.abs().max()), storage
+
+
+@pytest.mark.parametrize("dims,B", [((96, 96, 133), 1), ((96, 96, 133), 8), ((64, 64, 128), 3), ((40, 36, 45), 40)])
+def test_channel_render_stages_any_depth_and_label_alignment(gpu, dims, B):
+    """mask_to_channels on the bricks with quads of four voxels and their label dword read from any
+    address (brick_shared.h quad_load: the reference's example CT has 133 slices, so neither the
+    volume's rows nor the label map's are aligned): labels in blocks with air between them (empty
+    bricks), labels the caller has no channel for, a label map at an odd address; against the
+    per-ray channel kernel and the plain render."""
+    g = torch.Generator().manual_seed(dims[0] + B)
+    vol = 0.5 + torch.rand(*dims, generator=g)
+    lab = torch.randint(0, 9, (dims[0] // 8 + 1, dims[1] // 8 + 1, dims[2] // 16 + 1), generator=g)
+    lab = lab.repeat_interleave(8, 0).repeat_interleave(8, 1).repeat_interleave(16, 2)
+    lab = lab[: dims[0], : dims[1], : dims[2]].contiguous().to(torch.uint8)
+    vol[lab == 0] = 0.0  # air
+    vol[:, :, 32:64] = 0.0  # a whole layer of empty halves
+    lab[-1, -1, -1] = 5
+    vol[-1, -1, -1] = 7.0
+    H, W = 40, 48
+    drr, s, t, L = _scene(gpu, vol, H, W, B, seed=7, delx=3.0, dist=500.0)
+    V = drr.density
+    buf = torch.empty(lab.numel() + 1, dtype=torch.uint8, device=gpu)
+    M = buf[1:].view(*dims)  # (an odd address)
+    M.copy_(lab)
+    assert M.data_ptr() % 2 == 1 and M.is_contiguous()
+    for C in (9, 6):  # (6: labels 6 .. 8 have no channel)
+        ref = ops.siddon_forward_channels(V, M, C, s, t, L)
+        out = ops.siddon_forward_channels_bricks(V, M, C, s, t, L, (H, W))
+        scale = float(ref.abs().max())
+        assert scale > 0 and out.shape == ref.shape == (B, C, H * W)
+        assert float((out - ref).abs().max()) < 1e-4 * scale, C
+        assert float(out[:, 0].abs().max()) == 0.0  # air
+    plain = ops.siddon_forward(V, s, t, L)[0]
+    out = ops.siddon_forward_channels_bricks(V, M, 9, s, t, L, (H, W))
+    assert float((out.sum(1) - plain).abs().max()) < 1e-4 * float(plain.abs().max())

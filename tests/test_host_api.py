@@ -967,10 +967,11 @@ def test_brick_workspace_follows_the_volume(emulated_ops):
         ops.brick_workspace(vol, "q16p")
         ops.brick_workspace_commit(vol, "q16p")
     assert _brick_storage(vol, cfg) == "f32"
-    # a volume the configurable kernel cannot stage (or a temporary made contiguous per call)
-    # never gets a workspace
+    # a temporary made contiguous per call never gets a workspace; any shape does (the
+    # reference's example CT has 133 slices)
     assert _brick_storage(torch.rand(64, 64, 130)[:, :, :128], cfg) == "f32"
-    assert _brick_storage(torch.rand(64, 64, 126), cfg) == "f32"
+    assert _brick_storage(torch.rand(64, 64, 126), cfg) == "q16p"
+    assert _brick_storage(torch.rand(64, 64, 133), cfg) == "q16p"
     assert _brick_storage(torch.rand(64, 64, 128, requires_grad=True), cfg) == "f32"
 
 
