@@ -32,7 +32,7 @@ def ru(lo, hi, *shape):
 worst = {"fwd": 0.0, "aux": 0.0, "volgrad": 0.0, "tri": 0.0, "trivol": 0.0, "q16": 0.0, "chan": 0.0, "chan_bwd": 0.0, "chan_bwd_sum": 0.0, "chan_volgrad": 0.0, "chan_trivolgrad": 0.0}
 for case in range(a.cases):
     dims = (ri(20, 150), ri(20, 150), ri(20, 150))
-    if case % 2 == 0:  # z a multiple of 4: the configurable kernels (bricks_fwd.hip) take the volume
+    if case % 2 == 0:  # z a multiple of 4 (aligned rows; any other D.z is staged from dword-aligned quads)
         dims = (dims[0], dims[1], 4 * ri(5, 40))
     H, W = ri(2, 90), ri(2, 90)
     B = ri(1, 5)
