@@ -212,7 +212,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
                   const unsigned char *labels = nullptr, int n_channels = 0);
 
 // The configurable Siddon forward / forward + record kernel (bricks_fwd.hip).  variant:
-// DDRR_BRICKS_F32 / DDRR_BRICKS_Q16; volumes it cannot stage with 16-byte loads take launch_bricks.
+// DDRR_BRICKS_F32 / DDRR_BRICKS_Q16 (fp32 bricks at fewer than 8 poses, and volumes of fewer than four
+// voxels, take launch_bricks).
 // brick_ranges: the DDRR_BRICKS_Q16 workspace (header, (min, max) and fallback flag per brick),
 // ranges_valid: it already holds this volume's.
 // packed: the workspace also holds the bricks' LDS images (DDRR_BRICKS_Q16_PACKED) behind the ranges.

@@ -555,9 +555,9 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
             // unconditionally from a clamped (always readable) address and what lies outside is
             // zeroed afterwards: loads under per-lane conditions end up in separate round trips
             // (measured with the labels: staging 4x the plain brick's).  The quad's four labels
-            // come as two aligned dwords + a byte alignment -- a z extent like the example CT's
-            // 133 leaves the rows at every alignment -- or, at the array's last bytes and for an
-            // unaligned label pointer, as four byte loads.
+            // come as two aligned dwords + a byte alignment -- the halo shifts the rows to every
+            // alignment -- or, at the array's last bytes and for an unaligned label pointer, as
+            // four byte loads.
             constexpr int kFly = LABELS ? 2 : 4;  // quads in flight per thread
             const long total4 = ((long)p.D.x * p.D.y * p.D.z) & ~3L;
 #pragma unroll 1

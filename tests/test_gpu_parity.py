@@ -673,8 +673,8 @@ def test_q16_bricks_small_ragged_sparse_and_many_poses(gpu, q16):
     DDRR_BRICKS_Q16, and DDRR_BRICKS_Q16_PACKED: the same bricks staged from the packed copy in
     the workspace, first call and cached call) where the module would not choose them -- small volumes -- for the edge cases
     of the brick grid: partial bricks on every axis, a volume smaller than one brick, empty (all
-    zero) bricks next to full ones, a z extent that is not a multiple of 4 (the general fp32
-    kernel takes over), more poses than a pose-table chunk; against the oracle, forward and the
+    zero) bricks next to full ones, a z extent that is not a multiple of 4 (quads staged from
+    dword-aligned addresses), more poses than a pose-table chunk; against the oracle, forward and the
     record's ray gradients; and a NaN voxel sends its brick to the fp32 path: only rays through
     the voxel itself are NaN, as with the volume's own values."""
     cases = (((40, 72, 36), (24, 31), 4), ((32, 32, 64), (16, 16), 4), ((5, 9, 64), (8, 8), 4),
@@ -695,8 +695,7 @@ def test_q16_bricks_small_ragged_sparse_and_many_poses(gpu, q16):
                           grad_out=go.cpu().numpy())
         out, aux = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True, storage=q16)
         plain, _ = ops.siddon_forward_bricks(V, s, t, L, (H, W), storage=q16)
-        # (cached: the second call reused the workspace the first one built -- where the 16-bit
-        # storages apply at all: a z extent that is not a multiple of 4 renders on fp32 bricks)
+        # (cached: the second call reused the workspace the first one built)
         assert ops.brick_workspace(V, q16)[1] == int(ops.brick_storage_applies(V))
         exact, aux_f = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=True, storage="f32")
         for img in (out, plain):
