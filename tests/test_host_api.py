@@ -979,3 +979,19 @@ def test_trilinear_channels_on_bricks_on_the_host(emulated_ops):
     """ddrr_trilinear_forward_channels_bricks (host emulation of the same march) against the
     per-ray channel kernel, the plain march and through the module."""
     conftest.check_trilinear_channels_on_bricks("cpu", (40, 36, 45), (14, 11), 60)
+
+
+@pytest.mark.parametrize("dims", [(70, 50, 133), (33, 34, 5), (20, 24, 3)])
+def test_any_depth_on_every_brick_storage_on_the_host(emulated_ops, dims):
+    """The host twin of tests/test_gpu_brick_storage.py::test_any_depth_on_the_configurable_kernel:
+    the Python layer hands volumes of any D.z to the 16-bit storages (ops.brick_storage_applies)
+    and the emulation of the same entry points agrees with the per-ray walk."""
+    import test_gpu_brick_storage as G
+
+    G.test_any_depth_on_the_configurable_kernel("cpu", dims)
+
+
+def test_channel_render_with_an_odd_label_address_on_the_host(emulated_ops):
+    import test_gpu_brick_storage as G
+
+    G.test_channel_render_stages_any_depth_and_label_alignment("cpu", (40, 36, 45), 5)
