@@ -309,6 +309,14 @@ def test_any_depth_on_the_configurable_kernel(gpu, dims):
             assert float((fwd - ref).abs().max()) < 1e-4 * scale, (storage, B)
             gi = ops.siddon_backward_rays(aux, go, s, t, L)[2]
             assert float((gi - gi_ref).abs().max()) < 1e-4 * float(gi_ref.abs().max()), (storage, B)
+    # the same volume at an address that is dword- but not 16-byte aligned (a view into a flat buffer)
+    buf = torch.empty(V.numel() + 1, device=gpu)
+    V4 = buf[1:].view(*dims)
+    V4.copy_(V)
+    assert V4.data_ptr() % 16 == 4 and V4.is_contiguous()
+    for storage in ("f32", "q16", "q16p"):
+        out, _ = ops.siddon_forward_bricks(V4, s, t, L, (H, W), storage=storage)
+        assert float((out - ref).abs().max()) < 1e-4 * scale, storage
     # a 2 x 2 grid of rays along z inside the volume's last row: exactly the voxels set above
     x0, y0, n = dims[0] - 0.9, dims[1] - 0.9, dims[2]
     s = torch.tensor([[[x0 + 0.05, y0 + 0.05, -60.0]]], device=gpu)
