@@ -132,6 +132,9 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
  * must only pass 1 after a call with 0 and B > 0 has returned 0 for these contents.
  * (A volume with only a few double bricks per CU balances badly: 256^3 is 6 % faster on fp32
  * bricks; the Python layer chooses, diffdrr_amd/renderers.py.)
+ * Any volume shape and any float-aligned volume pointer take every brick_storage: the kernels
+ * stage quads of four voxels along z with one 16-byte load from a dword-aligned address (the
+ * reference's example CT has 133 slices).
  * launch_ws: see the conventions at the top of this file. */
 #define DDRR_BRICKS_F32 0
 #define DDRR_BRICKS_Q16 1
