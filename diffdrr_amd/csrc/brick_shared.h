@@ -152,10 +152,10 @@ __device__ __forceinline__ void deliver_record_blocked(float *__restrict__ aux, 
 // Four voxels along z from element `at` of the volume (LABELS: and their labels): one 16-byte
 // load from a dword-aligned address -- global memory takes any dword alignment, and the label
 // dword any alignment -- so that any D.z is staged like a multiple of 4 (the reference's example
-// CT has 133 slices).  The address is clamped to the volume's last four voxels; the one quad this
-// happens to (it reaches beyond the last row: none does when D.z is a multiple of 4) has its words
-// shifted into place by quad_fix -- where the words are USED, so that a round's loads stay in
-// flight together.  What a load picks up behind the quad's row is for the caller to mask.
+// CT has 133 slices).  The address is clamped to the volume's last four voxels; the quads this
+// happens to (they reach beyond the volume's end: none does when D.z is a multiple of 4, one with
+// any other D.z >= 4, up to three with a single slice or two) have their words shifted into place
+// by quad_fix -- where the words are USED, so that a round's loads stay in flight together.  What a load picks up behind the quad's row is for the caller to mask.
 // (The volume holds at least four voxels: the host checks.)
 typedef unsigned int quad_u32x4 __attribute__((ext_vector_type(4)));  // (a native vector: plain loads / stores)
 typedef unsigned int quad_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -163,15 +163,15 @@ template <bool LABELS>
 __device__ __forceinline__ void quad_load(const float *__restrict__ vol,
                                           const unsigned char *__restrict__ label_map, const Dims &D,
                                           long at, quad_u32x4 &v, unsigned &labels) {
-    const long last = (long)D.x * D.y * D.z - 4, a = at < last ? at : last;
+    const long a = quad_clamped_at(D, at);
     v = *reinterpret_cast<const quad_u32x4_a4 *>(vol + a);
     if (LABELS) __builtin_memcpy(&labels, label_map + a, 4);
 }
-// (x, y, z: the quad's first voxel.  Only a quad of the volume's last row can reach beyond the
-// volume; one that starts behind a row's end is masked by the caller whatever it holds.)
+// (x, y, z: the quad's first voxel; brick_core.h quad_shift says which quads were clamped.  One
+// that starts behind a row's end is masked by the caller whatever it holds.)
 __device__ __forceinline__ void quad_fix(const Dims &D, int x, int y, int z, quad_u32x4 &v,
                                          unsigned &labels) {
-    const int shift = x >= D.x - 1 && y >= D.y - 1 ? z + 4 - D.z : 0;
+    const int shift = quad_shift(D, x, y, z);
     if (shift > 0) {
         if (shift >= 2) v = quad_u32x4{v.z, v.w, 0u, 0u};
         if (shift & 1) v = quad_u32x4{v.y, v.z, v.w, 0u};

@@ -197,28 +197,46 @@ __global__ __launch_bounds__(kBlock) void trilinear_bwd_max_kernel(
     }
 }
 
-}  // namespace
-
 // Batch-global marching range (renderers.py:220-223): min over all rays of alphamin, max of
-// alphamax, one integer atomic per wave on the floats' bit patterns.  alphamin >= +0: unsigned
-// order is float order, range[0] starts at +inf.  alphamax <= 1 may be negative (every ray
-// leaves the volume behind the source): non-negative values compete as signed ints (max),
-// negative ones as unsigned ints (min: the least negative wins, any non-negative beats them);
-// range[1] starts at -inf.
-__global__ __launch_bounds__(kBlock) void alpha_range_kernel(const float *__restrict__ source,
-                                                             int src_n,
-                                                             const float *__restrict__ target,
-                                                             long R, int N, Dims D, float shift,
-                                                             float eps, unsigned *range) {
+// alphamax.  At most 64 workgroups of 1024 threads stride over the rays; a workgroup reduces its
+// rays through shuffles and LDS and issues ONE atomic pair on the floats' bit patterns (round 4:
+// one pair per wave, 8 k same-address atomics at 512^2 rays = 0.105 ms; now at most 128).
+// alphamin >= +0: unsigned order is float order.  alphamax <= 1 may be negative (every ray leaves
+// the volume behind the source): non-negative values compete as signed ints (max), negative ones
+// as unsigned ints (min: the least negative wins, any non-negative beats them).  Both words start
+// at 0xffffffff -- above every float as an unsigned int, -1 (below every non-negative float) as a
+// signed one -- so that ONE 8-byte memset initialises both.
+constexpr int kRangeBlock = 1024, kRangeBlocks = 64;
+__global__ __launch_bounds__(kRangeBlock) void alpha_range_kernel(const float *__restrict__ source,
+                                                                  int src_n,
+                                                                  const float *__restrict__ target,
+                                                                  long R, int N, Dims D, float shift,
+                                                                  float eps, unsigned *range) {
+    __shared__ float red[2][kRangeBlock / 64];
     float lo = INFINITY, hi = -INFINITY;
-    for (long r = (long)blockIdx.x * kBlock + threadIdx.x; r < R; r += (long)gridDim.x * kBlock) {
-        const long b = r / N, n = r - b * N;
-        const float *sp = source + (b * src_n + (src_n == 1 ? 0 : n)) * 3, *tp = target + r * 3;
-        const float s[3] = {sp[0], sp[1], sp[2]}, t[3] = {tp[0], tp[1], tp[2]};
-        float a0, a1;
-        ddrr::ray_alpha_range(D, s, t, shift, eps, a0, a1);
-        lo = fminf(lo, a0);
-        hi = fmaxf(hi, a1);
+    // four rays per thread and round: the round's loads are in flight together (rays beyond the
+    // batch re-read the last ray: it is a member of the min / max anyway)
+    const long stride = (long)gridDim.x * kRangeBlock;
+    for (long r0 = (long)blockIdx.x * kRangeBlock + threadIdx.x; r0 < R; r0 += 4 * stride) {
+        float s[4][3], t[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long rk = r0 + k * stride, r = rk < R ? rk : R - 1;
+            const long b = r / N, n = r - b * N;
+            const float *sp = source + (b * src_n + (src_n == 1 ? 0 : n)) * 3, *tp = target + r * 3;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                s[k][a] = sp[a];
+                t[k][a] = tp[a];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float a0, a1;
+            ddrr::ray_alpha_range(D, s[k], t[k], shift, eps, a0, a1);
+            lo = fminf(lo, a0);
+            hi = fmaxf(hi, a1);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -226,13 +244,30 @@ __global__ __launch_bounds__(kBlock) void alpha_range_kernel(const float *__rest
         hi = fmaxf(hi, __shfl_xor(hi, o, 64));
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicMin(range, __float_as_uint(lo + 0.f));  // (-0 + 0 = +0)
-        if (hi >= 0.f)
-            atomicMax(reinterpret_cast<int *>(range + 1), __float_as_int(hi));
-        else
-            atomicMin(range + 1, __float_as_uint(hi));
+        red[0][threadIdx.x >> 6] = lo;
+        red[1][threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        lo = threadIdx.x < kRangeBlock / 64 ? red[0][threadIdx.x] : INFINITY;
+        hi = threadIdx.x < kRangeBlock / 64 ? red[1][threadIdx.x] : -INFINITY;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+        }
+        // (a workgroup without a ray -- none is launched -- would hold +inf / -inf: harmless)
+        if (threadIdx.x == 0) {
+            atomicMin(range, __float_as_uint(lo + 0.f));  // (-0 + 0 = +0)
+            if (hi >= 0.f)
+                atomicMax(reinterpret_cast<int *>(range + 1), __float_as_int(hi));
+            else
+                atomicMin(range + 1, __float_as_uint(hi));
+        }
     }
 }
+
+}  // namespace
 
 extern "C" {
 
@@ -244,15 +279,13 @@ int ddrr_trilinear_alpha_range(const float *source, int src_n, const float *targ
     if (B < 1 || N < 1) return fail(-1, "the marching range of an empty ray batch is undefined");
     if (src_n != 1 && src_n != N) return fail(-1, "src_n must be 1 or N");
     hipStream_t st = (hipStream_t)stream;
-    const unsigned init[2] = {0x7f800000u, 0xff800000u};  // +inf, -inf
-    hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(range2), (int)init[0], 1, st);
-    if (e == hipSuccess)
-        e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(range2 + 1), (int)init[1], 1, st);
-    if (e != hipSuccess) return fail_hip(e, "hipMemsetD32Async");
+    // both words 0xffffffff (see alpha_range_kernel)
+    const hipError_t e = hipMemsetAsync(range2, 0xff, 2 * sizeof(float), st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
     const long R = (long)B * N;
-    const long blocks = (R + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(alpha_range_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)),
-                       dim3(kBlock), 0, st, source, src_n, target, R, N, Dims{dx, dy, dz},
+    const long blocks = (R + kRangeBlock - 1) / kRangeBlock;
+    hipLaunchKernelGGL(alpha_range_kernel, dim3((unsigned)(blocks < kRangeBlocks ? blocks : kRangeBlocks)),
+                       dim3(kRangeBlock), 0, st, source, src_n, target, R, N, Dims{dx, dy, dz},
                        voxel_shift, eps, reinterpret_cast<unsigned *>(range2));
     return finish("ddrr_trilinear_alpha_range");
 }

@@ -264,11 +264,15 @@ def brick_workspace_commit(volume, storage):
     ent = _workspace_entry(volume, storage)
     if ent is None or ent.built_version == volume._version:
         return
+    if volume.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        # a captured launch has not run: the workspace stays unbuilt for eager launches (which
+        # rebuild into the same buffer); the captured graph rebuilds it on every replay
+        return
     if ent.built_version is not None:
         ent.churn += 1  # workspace_churn() lets the renderer stop paying for rebuilds
     ent.built_version = volume._version
     ent.event = ent.stream = None
-    if volume.device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+    if volume.device.type == "cuda":
         ent.stream = torch.cuda.current_stream(volume.device)
         ent.event = torch.cuda.Event()
         ent.event.record(ent.stream)

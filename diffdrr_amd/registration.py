@@ -96,18 +96,21 @@ class GraphedIteration:
             optimizer.step()
             return loss.detach()
 
-        # warm up on a side stream (first-call costs and lazy initialisations must not be captured)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                iteration()
-        torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
         try:
+            # warm up on a side stream (first-call costs and lazy initialisations must not be
+            # captured)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    iteration()
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.loss = iteration()
         finally:
+            # (whatever the warm-up or the capture raised: the caller's module gets its own
+            # promise back)
             if had_static is not None:
                 renderer.static_volume = had_static
         # undo warm-up and capture: same parameter values, same optimizer state, IN PLACE (the

@@ -541,10 +541,16 @@ class Siddon(torch.nn.Module):
             raise ValueError(f"mode must be 'nearest' or 'bilinear', not {mode}")
         self.mode = mode
         self.stop_gradients_through_grid_sample = stop_gradients_through_grid_sample
-        # Accepted for signature compatibility.  In the reference the flag only
-        # drops crossings outside the volume (zero-valued segments), and its
-        # implementation raises a TypeError (renderers.py:118 vs :124); the fused
-        # walk never visits those crossings, so the result is the same either way.
+        # The reference's branch (renderers.py:116-121) cannot run: it calls _get_alpha_minmax
+        # without `voxel_shift` (:118 vs :124), a TypeError on every call.  Its INTENDED semantics
+        # -- drop the sorted-crossing columns that lie outside [alphamin, alphamax] for every ray --
+        # remove only segments outside the volume, which add nothing (zero padding): image and
+        # every gradient equal the default render's.  Pinned by tests/golden/
+        # siddon_filter_outside.npz (the reference with that one call completed, made by
+        # tests/golden/make_golden_filter.py).  The fused walks never visit crossings outside
+        # the volume, so the flag changes nothing here; with a ray endpoint INSIDE the volume the
+        # intended filter would also clamp to alpha in [0, 1] where every ray agrees -- the
+        # product integrates the whole line, as without the flag.
         self.filter_intersections_outside_volume = filter_intersections_outside_volume
         self.reducefn = reducefn
         self.voxel_shift = voxel_shift

@@ -1690,3 +1690,19 @@ int ddrr_trilinear_samples_general_backward(const void *volume, int f64, int dx,
 }
 
 }  // extern "C"
+
+// Test hook (tests/test_host_api.py): the arithmetic of the brick kernels' staging by quads --
+// brick_core.h quad_clamped_at / quad_shift, which brick_shared.h quad_load / quad_fix are made of
+// -- on a host volume: the four words a lane ends up with for the quad whose first voxel is
+// (x, y, z), before the caller's masks.
+extern "C" int ddrr_emu_quad_stage(const float *volume, int dx, int dy, int dz, int x, int y, int z,
+                                   float *out4) {
+    const Dims D{dx, dy, dz};
+    if ((long)dx * dy * dz < 4) return -1;
+    const int xc = x < dx ? x : dx - 1, yc = y < dy ? y : dy - 1;
+    const long a = quad_clamped_at(D, ((long)xc * dy + yc) * dz + z);
+    float w[8] = {volume[a], volume[a + 1], volume[a + 2], volume[a + 3], 0.f, 0.f, 0.f, 0.f};
+    const int shift = quad_shift(D, x, y, z);
+    for (int i = 0; i < 4; ++i) out4[i] = shift + i < 8 ? w[shift + i] : 0.f;
+    return 0;
+}

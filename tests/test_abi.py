@@ -58,6 +58,11 @@ def test_library_builds_loads_and_exports_every_symbol():
     # the development builds of tools/explib.py, never in the product library
     exported = set(re.findall(r"\bT (ddrr_\w+)", syms))
     assert exported == set(_declared()), exported ^ set(_declared())
+    # ... of ANY kind: no kernel stub, no C++ helper shared by the translation units, no data
+    # (csrc/exports.map; round 4 leaked `__device_stub__alpha_range_kernel` and the ddrr_rt:: /
+    # ddrr_brick:: functions)
+    every = {line.split()[-1] for line in syms.splitlines() if line.strip()}
+    assert every == set(_declared()), every ^ set(_declared())
 
 
 def test_library_contains_gfx950_code_object():

@@ -1121,3 +1121,9 @@ def test_trilinear_channels_on_bricks(gpu, dims, det, P):
     """The marcher's mask_to_channels on the volume-stationary bricks against the per-ray channel
     kernel (itself pinned to the reference's fixture), the plain march, and through the module."""
     conftest.check_trilinear_channels_on_bricks(gpu, dims, det, P)
+
+
+def test_filter_intersections_outside_volume(gpu):
+    """the flag the reference itself cannot run (TypeError,
+    renderers.py:118 vs :124), against the fixture of its intended semantics."""
+    conftest.check_filter_intersections_outside_volume(gpu)

@@ -981,7 +981,7 @@ def test_trilinear_channels_on_bricks_on_the_host(emulated_ops):
     conftest.check_trilinear_channels_on_bricks("cpu", (40, 36, 45), (14, 11), 60)
 
 
-@pytest.mark.parametrize("dims", [(70, 50, 133), (33, 34, 5), (20, 24, 3)])
+@pytest.mark.parametrize("dims", [(70, 50, 133), (33, 34, 5), (20, 24, 3), (40, 36, 1), (3, 50, 1), (2, 3, 37)])
 def test_any_depth_on_every_brick_storage_on_the_host(emulated_ops, dims):
     """The host twin of tests/test_gpu_brick_storage.py::test_any_depth_on_the_configurable_kernel:
     the Python layer hands volumes of any D.z to the 16-bit storages (ops.brick_storage_applies)
@@ -995,3 +995,45 @@ def test_channel_render_with_an_odd_label_address_on_the_host(emulated_ops):
     import test_gpu_brick_storage as G
 
     G.test_channel_render_stages_any_depth_and_label_alignment("cpu", (40, 36, 45), 5)
+
+
+@pytest.mark.parametrize("dims", [(4, 4, 1), (2, 2, 1), (1, 4, 1), (5, 1, 1), (1, 1, 7), (3, 3, 2), (2, 3, 3),
+                                  (1, 2, 5), (2, 2, 4), (3, 2, 6)])
+def test_quads_are_staged_from_the_right_voxels_on_any_shape(emu_lib, dims):
+    """The arithmetic of brick_shared.h quad_load / quad_fix (brick_core.h quad_clamped_at /
+    quad_shift, compiled here for the host): a quad is one 16-byte load clamped to the volume's last
+    four voxels and shifted where it is used.  With a single slice (D.z == 1) or two, quads of rows
+    BEFORE the volume's last row are clamped too (round 4 shifted only the last row's: (4, 4, 1)
+    staged two voxels from the wrong address).  Every voxel of every row must arrive in its word."""
+    import ctypes
+
+    fn = emu_lib.cdll.ddrr_emu_quad_stage
+    fn.restype = ctypes.c_int
+    dx, dy, dz = dims
+    vol = np.arange(1, dx * dy * dz + 1, dtype=np.float32).reshape(dims)
+    out = np.zeros(4, dtype=np.float32)
+    for x in range(dx):
+        for y in range(dy):
+            for z in range(0, dz + 3, 4) if dz % 4 else range(0, dz, 4):
+                rc = fn(vol.ctypes.data_as(ctypes.c_void_p), dx, dy, dz, x, y, z,
+                        out.ctypes.data_as(ctypes.c_void_p))
+                assert rc == 0
+                for i in range(4):
+                    if z + i < dz:  # (what lies behind the row's end is the caller's to mask)
+                        assert out[i] == vol[x, y, z + i], (dims, x, y, z, i)
+    # quads at any z offset (a brick's box starts at multiples of 4 only; the arithmetic holds anyway)
+    for z in range(dz):
+        fn(vol.ctypes.data_as(ctypes.c_void_p), dx, dy, dz, dx - 1, dy - 1, z,
+           out.ctypes.data_as(ctypes.c_void_p))
+        for i in range(4):
+            if z + i < dz:
+                assert out[i] == vol[dx - 1, dy - 1, z + i]
+
+
+def test_filter_intersections_outside_volume_on_the_host(emulated_ops):
+    """Row a5 on the host emulation (the GPU twin: tests/test_gpu_parity.py)."""
+    conftest.check_filter_intersections_outside_volume("cpu")
+
+
+def test_channel_backward_on_bricks_smooth_volume_on_the_host(emulated_ops):
+    conftest.check_channel_backward_on_bricks_smooth(emulated_ops, "cpu")
