@@ -30,9 +30,16 @@ Rank 0 prints ONE JSON line on stdout: the driver's contract plus
                   with its parity; "roofline.kernels": every renderer kernel of the step with its
                   own algorithmic bytes and, where the counters were taken, "issue_bound": VALU issue
                   time, its share of the kernel and the useful fraction (profiles/rNN/issue_bound.json),
-  "configs":      (default run, one GPU) short runs of BASELINE configs 2, 3 and 5: ms per step,
-                  dominant-kernel rate, parity; "sweep": config 5's figure -- with --gpus N the
-                  strong-scaling point (4096 poses over the ranks) next to the weak-scaling headline,
+                  "roofline.forward_f32": the forward-only kernel on the same 32 poses with
+                  brick_storage = "f32" (the volume's own values, as the reference gathers them),
+  "configs":      (default run, one GPU) short runs of BASELINE configs 2, 3 (and its B = 4 timing,
+                  "b4"), 4 (the registration loop as one HIP graph per iteration: iterations/s) and 5:
+                  ms per step, dominant-kernel rate, parity; "ct": the reference's example geometry
+                  on a CT-like 512 x 512 x 133 volume after transform_hu_to_density -- forward and
+                  forward + record at 1 / 8 / 32 poses on the guarded 16-bit bricks and on fp32
+                  bricks, the bricks the guard sent to the fp32 path, parity against the oracle;
+                  "sweep": config 5's figure -- with --gpus N the strong-scaling point (4096 poses
+                  over the ranks) next to the weak-scaling headline,
   "cpu_baseline": the CPU oracle (a port of the reference's algorithm, OpenMP) on a bounded
                   sample of the same workload, rank 0, N = 1 only; "reference_cpu": the
                   UNMODIFIED reference on CPU torch, measured in the build container (it does
@@ -361,7 +368,7 @@ class Runtime:
 # (steps, warmup, priming steps) of a config: the full run, and the short run whose summary the
 # default line carries as "configs" (each short timed region >= ~0.3 s on one MI355X)
 FULL = {"headline": (400, 10, 60), "2": (800, 10, 60), "3": (400, 10, 60), "4": (1500, 20, 0), "5": (5, 1, 1)}
-SHORT = {"2": (300, 5, 40), "3": (150, 5, 30), "5": (2, 0, 1)}
+SHORT = {"2": (300, 5, 40), "3": (150, 5, 30), "4": (1000, 20, 0), "5": (2, 0, 1)}
 
 
 def issue_bound_record(kernel_key, kernel_ms, visits=None):
@@ -407,9 +414,10 @@ def issue_bound_record(kernel_key, kernel_ms, visits=None):
     return out
 
 
-def run_config(cfg, args, rt, short=False):
+def run_config(cfg, args, rt, short=False, batch=None, parity=True):
     """One timed run of a BASELINE config on the ranks of `rt`; -> the result dict (rank 0) or
-    None.  short: few steps, no CPU baseline -- the summaries of the default line."""
+    None.  short: few steps, no CPU baseline -- the summaries of the default line (batch: poses per
+    step of such a run, e.g. config 3 at B = 4; parity = False: timing only)."""
     on_gpu, world, rank, device, dist = rt.on_gpu, rt.world, rt.rank, rt.device, rt.dist
     fence, fence_wait, timer = rt.fence, rt.fence_wait, rt.timer
     timer.events = {}
@@ -422,10 +430,12 @@ def run_config(cfg, args, rt, short=False):
     sized = top or (cfg == "5" and args.sweep_poses is not None)  # (the harness test's small sweep)
     D = (args.size if sized else None) or (256 if cfg == "2" else 512)
     H = (args.det if sized else None) or (512 if cfg == "3" else 256)
-    B = (args.batch if top else None) or {"headline": 32, "2": 32, "3": 1, "4": 1, "5": 4096}[cfg]
+    B = (args.batch if top else batch) or {"headline": 32, "2": 32, "3": 1, "4": 1, "5": 4096}[cfg]
     if short and cfg == "5" and args.sweep_poses is not None:
         B = args.sweep_poses
     steps, warmup, prime = SHORT[cfg] if short else FULL[cfg]
+    if short and batch:
+        steps = max(20, steps // batch)
     if top and args.steps is not None:
         steps = args.steps
     if top and args.warmup is not None:
@@ -621,6 +631,28 @@ def run_config(cfg, args, rt, short=False):
             f_ms, f_n, f_poses = sum(a.elapsed_time(b) for a, b in ev) / len(ev), len(ev), int(fr.shape[0])
             del timer.events[dominant][before:]
 
+    # The same launches from the volume's OWN fp32 values (brick_storage = "f32": what the reference
+    # gathers, renderers.py:159-164): the value-faithful figure next to the 16-bit default's.
+    f32_ms, f32_n = None, 0
+    if on_gpu and cfg == "headline" and hasattr(drr.renderer, "brick_storage") and args.storage is None:
+        had = drr.renderer.brick_storage
+        drr.renderer.brick_storage = "f32"
+        try:
+            with torch.no_grad():
+                for _ in range(40):
+                    drr(rot0, xyz0, parameterization="euler_angles", convention="ZXY")
+                before = len(timer.events.get(dominant, []))
+                timer.enabled, timer.only = True, dominant
+                for _ in range(20):
+                    drr(rot0, xyz0, parameterization="euler_angles", convention="ZXY")
+                torch.cuda.synchronize()
+                timer.enabled, timer.only = False, None
+                ev = timer.events[dominant][before:]
+                f32_ms, f32_n = sum(a.elapsed_time(b) for a, b in ev) / len(ev), len(ev)
+                del timer.events[dominant][before:]
+        finally:
+            drr.renderer.brick_storage = had
+
     t_max = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -751,6 +783,18 @@ def run_config(cfg, args, rt, short=False):
                 forward["issue_bound"] = ib
         log(f"[bench] config {cfg} forward only: {f_ms:.3f} ms per launch of {f_poses} poses = "
             f"{forward['frac'] * 100:.1f} % of the 8 TB/s roofline")
+    forward_f32 = None
+    if f32_ms is not None:
+        forward_f32 = {"kernel": dominant + " (aux = NULL: forward only), brick_storage = \"f32\"",
+                       "what": "the same 32-pose launches on 32^3 bricks of the volume's own fp32 values "
+                               "(what the reference gathers, renderers.py:159-164): no quantisation anywhere",
+                       "kernel_ms": f32_ms, "launches_timed": f32_n, "poses_per_launch": int(rot0.shape[0]),
+                       "primed_with": "40 launches, directly after the 16-bit forward leg",
+                       "algorithmic_bytes_per_launch": alg_bytes,
+                       "achieved": alg_bytes / (f32_ms * 1e-3) / 1e9,
+                       "frac": alg_bytes / (f32_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "target_frac": 0.70}
+        log(f"[bench] config {cfg} forward only, fp32 bricks: {f32_ms:.3f} ms = "
+            f"{forward_f32['frac'] * 100:.1f} % of the 8 TB/s roofline")
     log(f"[bench] config {cfg}: step {ms_per_step:.3f} ms | {k_name} {k_ms:.3f} ms per launch, "
         f"{per_step:.1f} launch(es) per step | backward kernels {bwd_ms:.3f} ms per step | "
         f"{per_unit} | {alg_bytes / launch_units / 1e6:.1f} MB algorithmic per DRR")
@@ -798,6 +842,7 @@ def run_config(cfg, args, rt, short=False):
             "launches_per_step": per_step,
             "launches_timed": k_n,
             "forward": forward,
+            "forward_f32": forward_f32,
             "kernels": kernels,
         },
     }
@@ -859,7 +904,7 @@ def run_config(cfg, args, rt, short=False):
             pp["brick_storage_fallbacks"], pp["bricks"] = fb
         result["parity"]["phantom"] = pp
         del ph
-    if world == 1 and cfg == "3" and on_gpu and not (top and args.no_cpu_baseline):
+    if world == 1 and cfg == "3" and on_gpu and parity and not (top and args.no_cpu_baseline):
         result["parity"] = trilinear_parity(drr, rot0, xyz0, keep["img"].detach(), go, P, H)
     if world == 1 and cfg == "5" and on_gpu and not (top and args.no_cpu_baseline):
         with torch.no_grad():
@@ -915,6 +960,90 @@ def trilinear_parity(drr, rot, xyz, image, go, P, H, rows=4):
             "tolerance": "fwd_rel_err <= 1e-4, volume_grad_rel_err <= 1e-3"}
 
 
+def ct_config(rt, poses=(1, 8, 32), det=200):
+    """`configs.ct`: the reference's example geometry (README.md:67-87: 512 x 512 x 133 CT at
+    0.703 x 0.703 x 2.5 mm, sdd 1020, 200 x 200 detector at delx 2.0, source 850 mm away) on a
+    CT-LIKE volume -- the CT itself is not shipped -- that went through the package's own
+    `transform_hu_to_density` (reference data.py:214-227): exact-zero air, dim lung texture among
+    zeros, a partial-volume skin, bone near 0.5, a metal marker at 1.0.  Kernel-only timings of the
+    forward and forward + record launches at 1 / 8 / 32 perturbed poses on the default storage
+    (guarded 16-bit bricks, with how many bricks the guard sent to the fp32 path) and on fp32
+    bricks, the algorithmic rate of each, and parity of a rendered pose against the oracle."""
+    import numpy as np
+
+    import oracle
+    from diffdrr_amd import DRR, ops
+    from diffdrr_amd.data import ct_like_hu_volume, make_subject, transform_hu_to_density
+
+    device, timer = rt.device, rt.timer
+    dims, spacing = (512, 512, 133), (0.703, 0.703, 2.5)
+    density = transform_hu_to_density(ct_like_hu_volume(dims, seed=0))
+    drr = DRR(make_subject(density, spacing=spacing, orientation="AP"), sdd=1020.0, height=det, delx=2.0,
+              renderer="siddon").to(device)
+    V = drr.density
+    name = "ddrr_siddon_forward_bricks"
+    out = {"workload": "512x512x133 CT-like volume (HU phantom -> transform_hu_to_density) at 0.703 x 0.703 x "
+                       f"2.5 mm -> {det}x{det} detector (sdd 1020, delx 2.0), Siddon, perturbed poses: the "
+                       "reference's example geometry (README.md:67-87)",
+           "volume": {"shape": list(dims), "zero_fraction": float((density == 0).float().mean()),
+                      "max": float(density.max()), "soft_tissue": float(density[256, 256, 66])},
+           "kernel": name, "poses": {}}
+
+    def timed(fn, n_prime, n_timed):
+        for _ in range(n_prime):
+            fn()
+        before = len(timer.events.get(name, []))
+        timer.enabled, timer.only = True, name
+        for _ in range(n_timed):
+            fn()
+        torch.cuda.synchronize()
+        timer.enabled, timer.only = False, None
+        ev = timer.events[name][before:]
+        ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        del timer.events[name][before:]
+        return ms
+
+    with torch.no_grad():
+        for B in poses:
+            rot, xyz = perturbed_poses(B, seed=2, device=device)
+            s, t, L = voxel_rays(drr, rot, xyz)
+            _, _, nvox = ops.siddon_forward(V, s, t, L, count_voxels=True, det=(det, det))
+            visits = int(nvox.sum().item())
+            alg = 4 * visits + B * det * det * 20 + 12 * B
+            ent = {"voxels_per_ray": visits / (B * det * det), "algorithmic_bytes_per_launch": alg}
+            n_prime, n_timed = (60, 40) if B <= 8 else (30, 20)
+            for key, storage, aux in (("forward", "q16p", False), ("forward_record", "q16p", True),
+                                      ("forward_f32", "f32", False), ("forward_record_f32", "f32", True)):
+                ms = timed(lambda: ops.siddon_forward_bricks(V, s, t, L, (det, det), want_aux=aux,
+                                                             storage=storage), n_prime, n_timed)
+                ent[key] = {"kernel_ms": ms, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "drrs_per_s": B / (ms * 1e-3)}
+            out["poses"][str(B)] = ent
+            log(f"[bench] config ct, {B} pose(s): forward {ent['forward']['kernel_ms']:.3f} ms (fp32 bricks "
+                f"{ent['forward_f32']['kernel_ms']:.3f}), + record {ent['forward_record']['kernel_ms']:.3f} ms "
+                f"(fp32 bricks {ent['forward_record_f32']['kernel_ms']:.3f})")
+        fb = ops.brick_fallbacks(V, "q16p")
+        if fb is not None:
+            out["brick_storage_fallbacks"], out["bricks"] = fb
+        # parity: pose 0 of the 8-pose batch on both storages against the oracle's fp32 / fp64 renders
+        rot, xyz = perturbed_poses(8, seed=2, device=device)
+        s, t, L = voxel_rays(drr, rot[:1], xyz[:1])
+        a32 = (V.cpu().numpy(), s.cpu().numpy(), t.cpu().numpy(), L.cpu().numpy())
+        r32 = oracle.siddon(*a32)["out"].reshape(-1)
+        r64 = oracle.siddon(*(a.astype(np.float64) for a in a32))["out"].reshape(-1)
+        rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - b).max() / np.abs(b).max())  # noqa: E731
+        par = {"pose": 0, "ref_fp32_fwd_rel_err_vs_fp64": rel(r32, r64),
+               "tolerance": "fwd_rel_err <= 1e-4 (image-normalised), every storage"}
+        for storage in ("q16p", "f32"):
+            mine = ops.siddon_forward_bricks(V, s, t, L, (det, det), storage=storage)[0].reshape(-1).cpu().numpy()
+            par[storage] = {"fwd_rel_err": rel(mine, r32), "fwd_rel_err_vs_fp64": rel(mine, r64),
+                            # per pixel, relative to the pixel's own value (where it is not in air)
+                            "max_pixel_rel_err_vs_fp64": float(
+                                (np.abs(mine - r64) / np.maximum(np.abs(r64), 1e-3 * np.abs(r64).max())).max())}
+        out["parity"] = par
+    return out
+
+
 def summary_of(res):
     """What the default line keeps of a short config run."""
     rf = res["roofline"]
@@ -926,9 +1055,11 @@ def summary_of(res):
            "kernels": rf["kernels"], "parity": res.get("parity")}
     if rf.get("forward"):
         out["forward"] = rf["forward"]
-    for k in ("brick_storage", "brick_storage_fallbacks"):
+    for k in ("brick_storage", "brick_storage_fallbacks", "bricks"):
         if k in res["config"]:
             out[k] = res["config"][k]
+    if "registration" in res:
+        out["registration"] = res["registration"]
     return out
 
 
@@ -978,12 +1109,20 @@ def main():
         # with their parity; N > 1: the sweep only (config 5 -- 4096 poses over the N ranks, the
         # informative strong-scaling curve; the headline above is N independent 32-pose steps).
         configs = {}
-        for cfg in (("2", "3", "5") if rt.world == 1 and plain_headline else ("5",)):
+        for cfg in (("2", "3", "4", "5") if rt.world == 1 and plain_headline else ("5",)):
             t0 = time.perf_counter()
             res = run_config(cfg, args, rt, short=True)
             if rt.rank == 0:
                 configs[cfg] = summary_of(res)
                 configs[cfg]["wall_s"] = time.perf_counter() - t0
+        if rt.world == 1 and plain_headline:
+            # config 3 also at B = 4 (timing only; the parity block above is B = 1's)
+            res = run_config("3", args, rt, short=True, batch=4, parity=False)
+            configs["3"]["b4"] = {k: res[k] for k in ("value", "unit", "ms_per_step", "steps")}
+            configs["3"]["b4"]["kernels"] = res["roofline"]["kernels"]
+            t0 = time.perf_counter()
+            configs["ct"] = ct_config(rt)
+            configs["ct"]["wall_s"] = time.perf_counter() - t0
         if rt.rank == 0:
             c5 = configs["5"]
             result["sweep"] = {"metric": c5["metric"], "value": c5["value"], "unit": c5["unit"],
