@@ -51,24 +51,24 @@ DDRR_HD Box brick_box(const Dims D, const BrickGrid &g, int id) {
     return b;
 }
 
-// Staging by quads of four voxels along z (brick_shared.h quad_load / quad_fix).  A quad is one
-// 16-byte load from element `at` of the volume, clamped to the volume's last four voxels; the
-// quads that are clamped -- fewer than four voxels are left from their first one to the volume's
-// end: with D.z >= 4 a quad of the volume's last row only, with fewer slices also quads of the rows
-// (and, rows of fewer than four voxels in all, slabs) before it -- have their words shifted into place where they are used.  (x, y, z): the quad's first
-// voxel (x, y beyond the volume: the caller loads from a clamped row and masks the result).
+// Staging by quads of four voxels along z (brick_shared.h quad_load / quad_fix), for volumes of
+// at least four slices (D.z >= 4; thinner ones take the scalar staging of the general kernel,
+// bricks.hip).  A quad is one 16-byte load from element `at` of the volume, clamped to the
+// volume's last four voxels; with D.z >= 4 the only quad this can happen to is the one of the
+// volume's LAST ROW that reaches beyond it (none when D.z is a multiple of 4): its words are
+// shifted into place where they are used.  (x, y, z): the quad's first voxel (x, y beyond the
+// volume: the caller loads from a clamped row and masks the result).
+// (Round 5 tried the form that also serves D.z < 4 -- quads of earlier rows and slabs are clamped
+// there too -- inside the kernels: 17 more VGPRs in the staging, 4-5 spilled registers in the
+// headline kernel.  Hence the split.)
 DDRR_HD long quad_clamped_at(const Dims &D, long at) {
     const long last = (long)D.x * D.y * D.z - 4;
     return at < last ? at : last;
 }
 DDRR_HD int quad_shift(const Dims &D, int x, int y, int z) {
-    const int slabs_left = D.x - 1 - (x < D.x ? x : D.x - 1);  // whole x-slabs behind this one
-    const int rows_left = D.y - 1 - (y < D.y ? y : D.y - 1);   // whole rows behind this one in its slab
-    if (slabs_left >= 4 || rows_left >= 4) return 0;            // (at least four voxels follow)
-    // voxels from the quad's first to the volume's end
-    const long left = ((long)slabs_left * D.y + rows_left) * D.z + (D.z - z);
-    return left < 4 ? (int)(4 - left) : 0;
+    return x >= D.x - 1 && y >= D.y - 1 ? z + 4 - D.z : 0;  // (> 0: shift; D.z >= 4)
 }
+DDRR_HD bool quads_serve(const Dims &D) { return D.z >= 4; }
 
 // How a brick is laid out in LDS: z contiguous, rows and planes padded so that the
 // voxels a wave reads in one step (neighbouring rays: a small patch perpendicular to the

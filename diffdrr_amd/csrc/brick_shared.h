@@ -151,12 +151,13 @@ __device__ __forceinline__ void deliver_record_blocked(float *__restrict__ aux, 
 
 // Four voxels along z from element `at` of the volume (LABELS: and their labels): one 16-byte
 // load from a dword-aligned address -- global memory takes any dword alignment, and the label
-// dword any alignment -- so that any D.z is staged like a multiple of 4 (the reference's example
-// CT has 133 slices).  The address is clamped to the volume's last four voxels; the quads this
-// happens to (they reach beyond the volume's end: none does when D.z is a multiple of 4, one with
-// any other D.z >= 4, up to three with a single slice or two) have their words shifted into place
-// by quad_fix -- where the words are USED, so that a round's loads stay in flight together.  What a load picks up behind the quad's row is for the caller to mask.
-// (The volume holds at least four voxels: the host checks.)
+// dword any alignment -- so that any D.z >= 4 is staged like a multiple of 4 (the reference's
+// example CT has 133 slices).  The address is clamped to the volume's last four voxels; the one
+// quad this happens to (it reaches beyond the volume's last row: none does when D.z is a multiple
+// of 4) has its words shifted into place by quad_fix -- where the words are USED, so that a
+// round's loads stay in flight together.  What a load picks up behind the quad's row is for the
+// caller to mask.  (Volumes of fewer than four slices: brick_core.h quads_serve -- the host sends
+// them to the general kernel's scalar staging.)
 typedef unsigned int quad_u32x4 __attribute__((ext_vector_type(4)));  // (a native vector: plain loads / stores)
 typedef unsigned int quad_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 template <bool LABELS>

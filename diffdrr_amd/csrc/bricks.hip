@@ -390,7 +390,9 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     const unsigned pix_mask = (1u << p.pix_bits) - 1u;
     const int n_chunks = (p.B + kPoseChunk - 1) / kPoseChunk;
     // (quads of four voxels from dword-aligned addresses, brick_shared.h quad_load: any D.z)
-    const bool vec_ok = (long)p.D.x * p.D.y * p.D.z >= 4 && (reinterpret_cast<uintptr_t>(p.vol) & 3) == 0;
+    // (fewer than four slices: quads of rows before the last one would be clamped too -- scalar staging)
+    const bool vec_ok = quads_serve(p.D) && (long)p.D.x * p.D.y * p.D.z >= 4 &&
+                        (reinterpret_cast<uintptr_t>(p.vol) & 3) == 0;
     const bool vec_out = GRAD && (p.D.z & 3) == 0 && (reinterpret_cast<uintptr_t>(p.g_volume) & 15) == 0;
     const bool labels_dword_ok = (MODE == BRICK_CHANNELS || MODE == BRICK_TRI_CHANNELS ||
                                   MODE == BRICK_CHANNELS_AUX || GRADL) &&
@@ -1193,10 +1195,11 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
     if (!(record_vmax >= 0.f)) return fail(-1, "record_vmax must be >= 0");
     if (brick_storage != DDRR_BRICKS_F32 && brick_storage != DDRR_BRICKS_Q16 &&
-        brick_storage != DDRR_BRICKS_Q16_PACKED)
-        return fail(-1, "brick_storage must be DDRR_BRICKS_F32, DDRR_BRICKS_Q16 or DDRR_BRICKS_Q16_PACKED");
+        brick_storage != DDRR_BRICKS_Q16_PACKED && brick_storage != DDRR_BRICKS_F32_PACKED)
+        return fail(-1, "brick_storage must be DDRR_BRICKS_F32, DDRR_BRICKS_Q16, DDRR_BRICKS_Q16_PACKED "
+                        "or DDRR_BRICKS_F32_PACKED");
     if (brick_storage != DDRR_BRICKS_F32 && !brick_ranges)
-        return fail(-1, "DDRR_BRICKS_Q16 needs the brick_ranges workspace");
+        return fail(-1, "every brick_storage but DDRR_BRICKS_F32 needs the brick_ranges workspace");
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const long R = (long)B * N;
@@ -1212,8 +1215,10 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                            dim3(kBlock), 0, st, source, target, R, N, Dims{dx, dy, dz}, voxel_shift,
                            eps, rec_q, aux);
     }
-    const int packed_bricks = brick_storage == DDRR_BRICKS_Q16_PACKED;
-    if (int rc = launch_fwd_bricks(packed_bricks ? DDRR_BRICKS_Q16 : brick_storage, packed_bricks,
+    const int packed_bricks = brick_storage == DDRR_BRICKS_Q16_PACKED || brick_storage == DDRR_BRICKS_F32_PACKED;
+    const int variant = brick_storage == DDRR_BRICKS_Q16_PACKED ? DDRR_BRICKS_Q16
+                        : (brick_storage == DDRR_BRICKS_F32_PACKED ? DDRR_BRICKS_F32 : brick_storage);
+    if (int rc = launch_fwd_bricks(variant, packed_bricks,
                                    brick_ranges, ranges_valid, volume, dx, dy, dz,
                                    source, target, img, B, det_h, det_w, voxel_shift, eps, out, aux,
                                    rec_q, st, launch_ws, "ddrr_siddon_forward_bricks"))

@@ -363,6 +363,7 @@ long ddrr_brick_workspace_bytes(int dx, int dy, int dz, int brick_storage) {
     long n = 256 + (n32 * 12 + 255) / 256 * 256;  // header, (min, max) and fallback flag per brick
     if (brick_storage == DDRR_BRICKS_Q16_PACKED)
         n += (long)((dx + 31) / 32) * ((dy + 31) / 32) * ((dz + 63) / 64) * 133184;
+    if (brick_storage == DDRR_BRICKS_F32_PACKED) n += n32 * 135296;
     return n;
 }
 
@@ -1698,11 +1699,11 @@ int ddrr_trilinear_samples_general_backward(const void *volume, int f64, int dx,
 extern "C" int ddrr_emu_quad_stage(const float *volume, int dx, int dy, int dz, int x, int y, int z,
                                    float *out4) {
     const Dims D{dx, dy, dz};
-    if ((long)dx * dy * dz < 4) return -1;
+    if ((long)dx * dy * dz < 4 || !quads_serve(D)) return -1;  // (the host sends these elsewhere)
     const int xc = x < dx ? x : dx - 1, yc = y < dy ? y : dy - 1;
     const long a = quad_clamped_at(D, ((long)xc * dy + yc) * dz + z);
     float w[8] = {volume[a], volume[a + 1], volume[a + 2], volume[a + 3], 0.f, 0.f, 0.f, 0.f};
-    const int shift = quad_shift(D, x, y, z);
+    const int sh = quad_shift(D, x, y, z), shift = sh > 0 ? sh : 0;  // (quad_fix: only if > 0)
     for (int i = 0; i < 4; ++i) out4[i] = shift + i < 8 ? w[shift + i] : 0.f;
     return 0;
 }

@@ -236,7 +236,7 @@ def test_metrics_match_reference_values_and_gradients(emulated_ops):
     check_metrics_against_reference(torch.device("cpu"))
 
 
-@pytest.mark.parametrize("storage", ["f32", "q16", "q16p"])
+@pytest.mark.parametrize("storage", ["f32", "q16", "q16p", "f32p"])
 @pytest.mark.parametrize("stop", [False, True])
 def test_registration_trajectory_matches_reference(emulated_ops, stop, storage):
     """First SGD steps of the tutorial's registration loop: same losses and the
@@ -262,7 +262,7 @@ def test_registration_trajectory_matches_reference(emulated_ops, stop, storage):
     opt = torch.optim.SGD([{"params": [reg._rotation], "lr": 5e-2},
                            {"params": [reg._translation], "lr": 1e2}], maximize=True)
     tag = "stop" if stop else "full"
-    for k in range(len(g[f"losses_{tag}"]) if storage == "f32" else 5):
+    for k in range(len(g[f"losses_{tag}"]) if storage in ("f32", "f32p") else 5):
         opt.zero_grad()
         loss = crit(gt, reg()).mean()
         loss.backward()
@@ -997,14 +997,15 @@ def test_channel_render_with_an_odd_label_address_on_the_host(emulated_ops):
     G.test_channel_render_stages_any_depth_and_label_alignment("cpu", (40, 36, 45), 5)
 
 
-@pytest.mark.parametrize("dims", [(4, 4, 1), (2, 2, 1), (1, 4, 1), (5, 1, 1), (1, 1, 7), (3, 3, 2), (2, 3, 3),
-                                  (1, 2, 5), (2, 2, 4), (3, 2, 6)])
+@pytest.mark.parametrize("dims", [(1, 1, 7), (1, 2, 5), (2, 2, 4), (3, 2, 6), (2, 3, 9), (1, 1, 4),
+                                  (4, 4, 1), (2, 2, 1), (1, 4, 1), (5, 1, 1), (3, 3, 2), (2, 3, 3)])
 def test_quads_are_staged_from_the_right_voxels_on_any_shape(emu_lib, dims):
     """The arithmetic of brick_shared.h quad_load / quad_fix (brick_core.h quad_clamped_at /
     quad_shift, compiled here for the host): a quad is one 16-byte load clamped to the volume's last
-    four voxels and shifted where it is used.  With a single slice (D.z == 1) or two, quads of rows
-    BEFORE the volume's last row are clamped too (round 4 shifted only the last row's: (4, 4, 1)
-    staged two voxels from the wrong address).  Every voxel of every row must arrive in its word."""
+    four voxels and shifted where it is used -- right for every D.z >= 4.  With fewer slices quads of
+    rows BEFORE the volume's last row are clamped too ((4, 4, 1) staged two voxels from
+    the wrong address): `quads_serve` says so, and the launchers send such volumes to the general
+    kernel's scalar staging (tests/test_gpu_brick_storage.py::test_any_depth_...: (40, 36, 1) ...)."""
     import ctypes
 
     fn = emu_lib.cdll.ddrr_emu_quad_stage
@@ -1012,22 +1013,18 @@ def test_quads_are_staged_from_the_right_voxels_on_any_shape(emu_lib, dims):
     dx, dy, dz = dims
     vol = np.arange(1, dx * dy * dz + 1, dtype=np.float32).reshape(dims)
     out = np.zeros(4, dtype=np.float32)
+    args = lambda x, y, z: (vol.ctypes.data_as(ctypes.c_void_p), dx, dy, dz, x, y, z,  # noqa: E731
+                            out.ctypes.data_as(ctypes.c_void_p))
+    if dz < 4:
+        assert fn(*args(0, 0, 0)) == -1  # refused: not this path's volume
+        return
     for x in range(dx):
         for y in range(dy):
-            for z in range(0, dz + 3, 4) if dz % 4 else range(0, dz, 4):
-                rc = fn(vol.ctypes.data_as(ctypes.c_void_p), dx, dy, dz, x, y, z,
-                        out.ctypes.data_as(ctypes.c_void_p))
-                assert rc == 0
+            for z in range(0, dz, 4):
+                assert fn(*args(x, y, z)) == 0
                 for i in range(4):
                     if z + i < dz:  # (what lies behind the row's end is the caller's to mask)
                         assert out[i] == vol[x, y, z + i], (dims, x, y, z, i)
-    # quads at any z offset (a brick's box starts at multiples of 4 only; the arithmetic holds anyway)
-    for z in range(dz):
-        fn(vol.ctypes.data_as(ctypes.c_void_p), dx, dy, dz, dx - 1, dy - 1, z,
-           out.ctypes.data_as(ctypes.c_void_p))
-        for i in range(4):
-            if z + i < dz:
-                assert out[i] == vol[dx - 1, dy - 1, z + i]
 
 
 def test_filter_intersections_outside_volume_on_the_host(emulated_ops):
