@@ -1078,7 +1078,7 @@ def main():
     ap.add_argument("--sweep-poses", type=int, default=None,
                     help="candidate poses of the `sweep` sub-run (default 4096; given explicitly, the "
                          "sub-run also happens at non-default sizes / on the cpu harness)")
-    ap.add_argument("--storage", default=None, choices=["q16p", "q16", "f32", "f32p"],
+    ap.add_argument("--storage", default=None, choices=["q16p", "q16", "f32"],
                     help="Siddon.brick_storage (default: the module's default, q16p)")
     ap.add_argument("--packed-record", action="store_true",
                     help="Siddon.packed_record = True (the opt-in fixed-point backward record)")

@@ -15,14 +15,14 @@ from ctypes import c_double, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffdrr_hip.so")
-ABI_VERSION = 29
+ABI_VERSION = 28
 
 REDUCE_SUM, REDUCE_MAX = 0, 1
 LOOKUP_STEP, LOOKUP_MID_NEAREST, LOOKUP_MID_TRILINEAR = 0, 1, 2
 SIDDON_AUX = 8
 AUX_INTERLEAVED, AUX_BLOCKED, AUX_PACKED = 0, 1, 2
 REC_BLOCK_RAYS, REC_BLOCK_FLOATS = 16, 80  # blocked float record (csrc/record_layout.h)
-BRICKS_F32, BRICKS_Q16, BRICKS_Q16_PACKED, BRICKS_F32_PACKED = 0, 1, 2, 3  # how a brick is held in LDS (ddrr_siddon_forward_bricks)
+BRICKS_F32, BRICKS_Q16, BRICKS_Q16_PACKED = 0, 1, 2  # how a brick is held in LDS (ddrr_siddon_forward_bricks)
 PACKED_AUX_PLANES = 7  # fixed-point record (csrc/record_pack.h)
 
 _P, _I, _F, _L, _D = c_void_p, c_int, c_float, c_long, c_double

@@ -1195,11 +1195,10 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
     if (!(record_vmax >= 0.f)) return fail(-1, "record_vmax must be >= 0");
     if (brick_storage != DDRR_BRICKS_F32 && brick_storage != DDRR_BRICKS_Q16 &&
-        brick_storage != DDRR_BRICKS_Q16_PACKED && brick_storage != DDRR_BRICKS_F32_PACKED)
-        return fail(-1, "brick_storage must be DDRR_BRICKS_F32, DDRR_BRICKS_Q16, DDRR_BRICKS_Q16_PACKED "
-                        "or DDRR_BRICKS_F32_PACKED");
+        brick_storage != DDRR_BRICKS_Q16_PACKED)
+        return fail(-1, "brick_storage must be DDRR_BRICKS_F32, DDRR_BRICKS_Q16 or DDRR_BRICKS_Q16_PACKED");
     if (brick_storage != DDRR_BRICKS_F32 && !brick_ranges)
-        return fail(-1, "every brick_storage but DDRR_BRICKS_F32 needs the brick_ranges workspace");
+        return fail(-1, "DDRR_BRICKS_Q16 needs the brick_ranges workspace");
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const long R = (long)B * N;
@@ -1215,10 +1214,8 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                            dim3(kBlock), 0, st, source, target, R, N, Dims{dx, dy, dz}, voxel_shift,
                            eps, rec_q, aux);
     }
-    const int packed_bricks = brick_storage == DDRR_BRICKS_Q16_PACKED || brick_storage == DDRR_BRICKS_F32_PACKED;
-    const int variant = brick_storage == DDRR_BRICKS_Q16_PACKED ? DDRR_BRICKS_Q16
-                        : (brick_storage == DDRR_BRICKS_F32_PACKED ? DDRR_BRICKS_F32 : brick_storage);
-    if (int rc = launch_fwd_bricks(variant, packed_bricks,
+    const int packed_bricks = brick_storage == DDRR_BRICKS_Q16_PACKED;
+    if (int rc = launch_fwd_bricks(packed_bricks ? DDRR_BRICKS_Q16 : brick_storage, packed_bricks,
                                    brick_ranges, ranges_valid, volume, dx, dy, dz,
                                    source, target, img, B, det_h, det_w, voxel_shift, eps, out, aux,
                                    rec_q, st, launch_ws, "ddrr_siddon_forward_bricks"))

@@ -36,14 +36,10 @@ using namespace ddrr_brick;
 
 namespace {
 
-template <int BX_, int BY_, int BZ_, int THREADS_, bool Q16_, int ROWPAD_ = -1, bool LA_ = Q16_>
+template <int BX_, int BY_, int BZ_, int THREADS_, bool Q16_, int ROWPAD_ = -1>
 struct FwdCfg {
     static constexpr int BX = BX_, BY = BY_, BZ = BZ_, THREADS = THREADS_, WAVES = THREADS_ / 64;
     static constexpr bool Q16 = Q16_;
-    // the look-ahead (the next brick's packed image requested into registers) is compiled in: every
-    // 16-bit configuration, and fp32 bricks with a packed copy (the plain fp32 configuration stays
-    // without it: the live prefetch registers cost its walk two spills)
-    static constexpr bool LA = LA_;
     static constexpr int ES = Q16 ? 2 : 4;  // bytes per staged voxel
     // rows and planes padded by one element so that x-, y- and z-neighbours fall in different
     // banks (ROWPAD_ = 0: no row padding, where the LDS budget of a half CU has no room for it)
@@ -521,7 +517,7 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
     // profiles/r04/look_ahead.txt).
     constexpr int kLookRounds = 3;
     constexpr int kLaStage = 1 << 30;  // the next brick is on the fp32 path (its halves are requested one by one)
-    const bool LOOK = C::LA && PackedPrefetch<C>::FITS && p.packed != nullptr && p.B <= C::CHUNK && !(p.dbg & 4096)
+    const bool LOOK = C::Q16 && PackedPrefetch<C>::FITS && p.packed != nullptr && p.B <= C::CHUNK && !(p.dbg & 4096)
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
                       && p.split_t == 0
 #endif
@@ -681,7 +677,7 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
                         fwd_stage_packed<C>(p, brick, brick_id, tid_here, range, brick_empty);
                     else
                         fwd_stage_brick<C>(p, brick, box, brick_id, tid_here, range, brick_empty, counter);
-                } else if (p.packed) {  // (16-bit or fp32 bricks: the image is the image)
+                } else if (C::Q16 && p.packed) {
                     fwd_stage_packed<C>(p, brick, brick_id, tid_here, range, brick_empty);
                 } else {
                     fwd_stage_brick<C>(p, brick, box, brick_id, tid_here, range, brick_empty, counter);
@@ -697,9 +693,7 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
             DDRR_PROF(PROF_STORE);
             __syncthreads();
             if (ch == 0) DDRR_TRACE(0, 0)
-            // (fp32 values staged from the volume were counted; a packed image's range says it)
-            if (((!C::Q16 && !p.packed) || (C::Q16 && f32_brick)) && ch == 0 && !loaded)
-                brick_empty = counter[2] == 0;
+            if ((!C::Q16 || f32_brick) && ch == 0 && !loaded) brick_empty = counter[2] == 0;
             // units per pose -> inclusive prefix, held by every wave in registers (lane k: pose k)
             int incl = lane < nb ? (rows[lane].count + 63) >> 6 : 0;
 #pragma unroll
@@ -1288,7 +1282,7 @@ __global__ __launch_bounds__(256) void brick_fallback_count_kernel(const int *__
     if (threadIdx.x == 0) total = 0;
     __syncthreads();
     int n = 0;
-    for (int k = threadIdx.x; fallback && k < n_bricks; k += 256) n += fallback[k] != 0;
+    for (int k = threadIdx.x; k < n_bricks; k += 256) n += fallback[k] != 0;
     atomicAdd(&total, n);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1390,16 +1384,14 @@ int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t
     const int nbx = (p.D.x + C::BX - 1) / C::BX, nby = (p.D.y + C::BY - 1) / C::BY;
     const int nbz = (p.D.z + C::BZ - 1) / C::BZ;
     const int n_bricks = nbx * nby * nbz, slots = n_cu * C::WGS_PER_CU;
-    if (C::Q16 && !p.ranges) return fail(-1, "DDRR_BRICKS_Q16 needs the brick_ranges workspace");
-    if (!C::Q16 && p.packed && !p.ranges) return fail(-1, "DDRR_BRICKS_F32_PACKED needs the workspace");
-    if (p.ranges) {
+    if constexpr (C::Q16) {
+        if (!p.ranges) return fail(-1, "DDRR_BRICKS_Q16 needs the brick_ranges workspace");
         if (!p.ranges_valid) {
             hipLaunchKernelGGL(brick_range_kernel, dim3(n_bricks), dim3(256), 0, st, p.vol, p.D, C::BX,
                                C::BY, C::BZ, nby, nbz, const_cast<float *>(p.ranges),
                                const_cast<int *>(p.fallback), p.vec);
-            // (fp32 bricks: no brick is "on the fp32 path" of a quantised storage -- header word 0 = 0)
-            hipLaunchKernelGGL(brick_fallback_count_kernel, dim3(1), dim3(256), 0, st,
-                               C::Q16 ? p.fallback : nullptr, n_bricks, p.ws_header);
+            hipLaunchKernelGGL(brick_fallback_count_kernel, dim3(1), dim3(256), 0, st, p.fallback,
+                               n_bricks, p.ws_header);
             if (p.packed) {
                 static bool pack_attr[kMaxDev] = {false};
                 {
@@ -1413,16 +1405,15 @@ int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t
                         pack_attr[dev] = true;
                     }
                 }
-                BrickArgs pk = p;
-                if (!C::Q16) pk.fallback = nullptr;  // (every fp32 brick is packed)
                 hipLaunchKernelGGL(brick_pack_kernel<C>, dim3(n_bricks), dim3(C::THREADS),
-                                   C::BRICK_BYTES, st, pk, nby, nbz,
+                                   C::BRICK_BYTES, st, p, nby, nbz,
                                    const_cast<unsigned char *>(p.packed));
             }
         }
+    } else if (p.packed) {
+        return fail(-1, "packed bricks are 16-bit bricks");
     }
     BrickArgs q = p;
-    if (!C::Q16) q.fallback = nullptr;  // (the flags in the workspace are the 16-bit storages')
     // (the launch's counter is cleared by the order kernel, or -- no order -- by a memset)
     if (!order_bricks(q, C::BX, C::BY, C::BZ, nby, nbz, n_bricks, slots, st, true)) {
         const hipError_t e = hipMemsetAsync(q.work, 0, 4 * sizeof(int), st);
@@ -1473,7 +1464,6 @@ int launch_sq(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t 
 
 // brick variants (DDRR_BRICKS_* of include/diffdrr_hip.h; the others exist in tools builds)
 using CfgF32 = FwdCfg<32, 32, 32, 1024, false>;        // DDRR_BRICKS_F32: 32^3 fp32
-using CfgF32P = FwdCfg<32, 32, 32, 1024, false, -1, true>;  // DDRR_BRICKS_F32_PACKED: the same bricks from their packed copy, with the look-ahead
 using CfgQ16Z64 = FwdCfg<32, 32, 64, 1024, true>;      // DDRR_BRICKS_Q16: 32x32x64 16-bit
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
 using CfgQ16x2 = FwdCfg<32, 32, 32, 512, true>;        // 32^3 16-bit, two workgroups per CU
@@ -1526,7 +1516,6 @@ long brick_workspace_bytes(int dx, int dy, int dz, int brick_storage) {
     if (brick_storage == DDRR_BRICKS_Q16_PACKED)
         n += (long)((dx + CfgQ16Z64::BX - 1) / CfgQ16Z64::BX) * ((dy + CfgQ16Z64::BY - 1) / CfgQ16Z64::BY) *
              ((dz + CfgQ16Z64::BZ - 1) / CfgQ16Z64::BZ) * CfgQ16Z64::BRICK_BYTES;
-    if (brick_storage == DDRR_BRICKS_F32_PACKED) n += n32_bricks(dx, dy, dz) * CfgF32P::BRICK_BYTES;
     return n;
 }
 
@@ -1544,8 +1533,7 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
     // fp32 bricks at a handful of poses: the general kernel (no pooled end, no hand-out order --
     // neither pays there): 7-12 % ahead at one pose, within 2 % from 8 on (profiles/r04/
     // fp32_bricks_general_vs_configurable.txt)
-    // (fp32 bricks with a packed copy always come here: straight copies and the look-ahead)
-    bool few_f32 = variant == DDRR_BRICKS_F32 && B < 8 && !(packed && brick_ranges);
+    bool few_f32 = variant == DDRR_BRICKS_F32 && B < 8;
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
     if (g_brick_variant != -2) {  // (-2: no override, -1: bricks.hip)
         static int last_variant = -100;
@@ -1621,7 +1609,7 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
         p.t2 = g_brick_t2 * (48.f / 40.f);
     }
     switch (variant) {
-        case DDRR_BRICKS_F32: rc = p.packed ? DDRR_LAUNCH(CfgF32P) : DDRR_LAUNCH(CfgF32); break;
+        case DDRR_BRICKS_F32: rc = DDRR_LAUNCH(CfgF32); break;
         case DDRR_BRICKS_Q16: rc = DDRR_LAUNCH(CfgQ16Z64); break;
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
         case 2: rc = DDRR_LAUNCH(CfgQ16x1); break;

@@ -207,8 +207,7 @@ def record_planes(aux, B, N):
     return torch.cat([p03, blk[:, 4].reshape(1, -1)])[:, :R].reshape(5, B, N)
 
 
-_BRICK_STORAGE = {"f32": _lib.BRICKS_F32, "q16": _lib.BRICKS_Q16, "q16p": _lib.BRICKS_Q16_PACKED,
-                  "f32p": _lib.BRICKS_F32_PACKED}
+_BRICK_STORAGE = {"f32": _lib.BRICKS_F32, "q16": _lib.BRICKS_Q16, "q16p": _lib.BRICKS_Q16_PACKED}
 _range_cache = {}  # (id(volume), storage) -> _Workspace
 
 

@@ -117,7 +117,7 @@ def _brick_storage(volume, cfg):
     over the persistent workgroups (256^3 = 256 bricks of 32 x 32 x 64, one per CU: 0.83 ms
     against 0.74 ms with 512 fp32 bricks handed out dynamically)."""
     storage = cfg.get("storage", "f32")
-    if storage not in ("q16", "q16p", "f32p") or volume.requires_grad:
+    if storage not in ("q16", "q16p") or volume.requires_grad:
         return "f32"
     if not ops.brick_storage_applies(volume):
         return "f32"
@@ -133,12 +133,8 @@ def _brick_storage(volume, cfg):
         if dev not in _cu_count:
             _cu_count[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
         dx, dy, dz = volume.shape
-        if storage != "f32p" and (-(-dx // 32)) * (-(-dy // 32)) * (-(-dz // 64)) < 4 * _cu_count[dev]:
-            # too few double bricks to balance: 32^3 fp32 bricks -- from their own packed copy when
-            # the module's storage already keeps one per volume ("q16p"), else from the volume
-            storage = "f32p" if storage == "q16p" else "f32"
-            if storage == "f32":
-                return "f32"
+        if (-(-dx // 32)) * (-(-dy // 32)) * (-(-dz // 64)) < 4 * _cu_count[dev]:
+            return "f32"
     if ops.workspace_churn(volume, storage) >= 3:
         # edited in place between renders again and again (a reconstruction loop on a plain
         # tensor): every render would pay the pass over the volume that builds the workspace
@@ -583,11 +579,10 @@ class Siddon(torch.nn.Module):
         # for a volume that requires grad).  "q16p": the same bricks, staged from a packed copy that
         # is kept with the cached per-volume workspace (ops.brick_workspace: +52 % of the volume's
         # bytes, built on the first render after the volume changed, +0.35 ms at 512^3): same
-        # results; one pose per launch -23 %, 32 poses -3 %.  "f32p": the volume's own fp32 values
-        # in 32^3 bricks staged from a packed copy (+103 % of the volume's bytes): no quantisation
-        # anywhere, straight 16-byte copies and the look-ahead of "q16p" -- what "q16p" itself
-        # falls back to for a volume with few double bricks per CU (256^3, the reference's
-        # 512 x 512 x 133 example CT).
+        # results; one pose per launch -23 %, 32 poses -3 %.  (fp32 bricks from a packed copy with
+        # the same look-ahead were built and measured in round 5: within 1-3 % of "f32" at 512^3
+        # and 256^3, 45 % SLOWER on the 133-slice example shape -- not kept,
+        # profiles/r05/f32_packed_lookahead_experiment.txt.)
         self.brick_storage = "q16p"
         # Under HIP-graph capture the 16-bit storages are only used if the caller promises that
         # the volume is not edited in place between replays (the graph bakes in the cached

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 29
+#define DDRR_ABI_VERSION 28
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -119,13 +119,6 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
  * a brick with a straight 16-byte copy of half the bytes instead of converting the fp32 volume
  * again -- what a volume that is rendered many times wants, most of all with few poses per
  * launch, where staging is most of the launch.
- * DDRR_BRICKS_F32_PACKED: the 32^3 fp32 bricks of DDRR_BRICKS_F32 -- the volume's own values, no
- * quantisation anywhere -- kept in the workspace as they lie in LDS (+ 103 % of the volume's bytes),
- * with the bricks' (min, max): staging is a straight 16-byte copy of one contiguous 132 KiB run
- * instead of 1024 rows of 128 bytes, air bricks are known before they are read, and launches of at
- * most 32 poses request the next brick ahead like the packed 16-bit storage's.  What a volume
- * with few double bricks per CU (256^3, the reference's 512 x 512 x 133 example) or a caller who
- * wants the reference's fp32 values wants when the volume is rendered many times.
  * (The 16-bit walk carries alpha pre-scaled by 2^64: rays with |alpha| >= 2^63 inside the volume
  * -- |t - s + eps| < ~1e-16 on an axis, which eps = 1e-8 excludes -- overflow to inf / NaN there,
  * where fp32 bricks would return a finite value.)
@@ -146,7 +139,6 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
 #define DDRR_BRICKS_F32 0
 #define DDRR_BRICKS_Q16 1
 #define DDRR_BRICKS_Q16_PACKED 2
-#define DDRR_BRICKS_F32_PACKED 3
 long ddrr_brick_workspace_bytes(int dx, int dy, int dz, int brick_storage);
 long ddrr_brick_launch_workspace_bytes(int dx, int dy, int dz);
 int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,

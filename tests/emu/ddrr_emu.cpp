@@ -363,7 +363,6 @@ long ddrr_brick_workspace_bytes(int dx, int dy, int dz, int brick_storage) {
     long n = 256 + (n32 * 12 + 255) / 256 * 256;  // header, (min, max) and fallback flag per brick
     if (brick_storage == DDRR_BRICKS_Q16_PACKED)
         n += (long)((dx + 31) / 32) * ((dy + 31) / 32) * ((dz + 63) / 64) * 133184;
-    if (brick_storage == DDRR_BRICKS_F32_PACKED) n += n32 * 135296;
     return n;
 }
 

@@ -1,6 +1,6 @@
 """Kernel-only timing of ddrr_siddon_forward_bricks by brick storage (product library): fp32 bricks
-from the volume ("f32"), from their packed copy ("f32p"), guarded 16-bit bricks from their packed
-copy ("q16p"); forward and forward + record; 1 / 8 / 32 poses; on the bench's 512^3 and 256^3 noise
+from the volume ("f32"), guarded 16-bit bricks from their packed copy ("q16p") (round 5 also had
+"f32p", fp32 bricks from a packed copy: profiles/r05/f32_packed_lookahead_experiment.*); forward and forward + record; 1 / 8 / 32 poses; on the bench's 512^3 and 256^3 noise
 volumes, the 512^3 phantom and the CT-like 512 x 512 x 133 volume (diffdrr_amd.data.ct_like_hu_volume
 through transform_hu_to_density).
 Usage: python tools/storage_bench.py [--scenes noise512,noise256,phantom512,ct] [--poses 1,8,32]"""
@@ -19,7 +19,7 @@ from tools.kernel_sweep import poses, rays, timeit  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--scenes", default="noise512,noise256,phantom512,ct")
 ap.add_argument("--poses", default="1,8,32")
-ap.add_argument("--storages", default="f32,f32p,q16p")
+ap.add_argument("--storages", default="f32,q16p")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 print(f"# {torch.cuda.get_device_name(0)}")
