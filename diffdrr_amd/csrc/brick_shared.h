@@ -70,9 +70,17 @@ struct BrickProf {
     }
     __device__ __forceinline__ void count(int i, unsigned long long n) { t[i] += n; }
 };
+#if defined(DDRR_TRACE_ONLY)
+// (-DDDRR_TRACE_ONLY: the per-brick stage stamps of DDRR_TRACE alone -- the phase marks cost a
+// scalar-memory round trip each and stretch a one-pose brick by a quarter)
+#define DDRR_PROF(i)
+#define DDRR_PROF_COUNT(i, n)
+#define DDRR_PROF_WAIT_VMEM()
+#else
 #define DDRR_PROF(i) prof.mark(i)
 #define DDRR_PROF_COUNT(i, n) prof.count(i, n)
 #define DDRR_PROF_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
 #else
 struct BrickProf {};
 #define DDRR_PROF(i)

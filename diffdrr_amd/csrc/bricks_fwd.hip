@@ -456,18 +456,23 @@ __global__ __launch_bounds__(C::THREADS) void brick_pack_kernel(BrickArgs p, int
 }
 
 // (profiling builds: stamps of a brick's stages behind the per-brick durations, 10 ns ticks from
-// the brick's start: [n_bricks + 8 brick + k]; k = 0 staged, 1 at the pool's barrier, 2 behind
-// it, 3 wave 0 out of work, 5 last wave out of work, 6 last walk done)
+// the brick's start: [n_bricks + 16 brick + k]; k = 0 staged, 1 at the pool's barrier, 2 behind
+// it, 3 wave 0 out of work, 4 / 7 wave 0 / the last wave at the staging barrier, 5 last wave out
+// of work, 6 last walk done, 8 / 10 wave 0's / the last wave's share of the image stored, 9 wave 0:
+// row table written.  A stamp is a scalar-memory round trip and a global store: with
+// -DDDRR_TRACE_ONLY (no phase marks) a one-pose launch takes 117 instead of 108 us.)
 #if defined(DDRR_BRICK_PROFILE)
 #define DDRR_TRACE(k, how)                                                                      \
     if (p.brick_times && lane == 0) {                                                           \
         const unsigned dt_ = (unsigned)__builtin_amdgcn_s_memrealtime() - (unsigned)ahead[6];   \
-        unsigned *slot_ = p.brick_times + n_bricks + 8 * brick_id + (k);                        \
+        unsigned *slot_ = p.brick_times + n_bricks + 16 * brick_id + (k);                        \
         if (how) atomicMax(slot_, dt_);                                                         \
         else if (wave == 0) *slot_ = dt_;                                                       \
     }
 #else
-#define DDRR_TRACE(k, how)
+// (a statement of its own: `if (c) DDRR_TRACE(..)` in front of a barrier must not swallow it --
+// round 5 lost the staging barrier of every pose chunk but the first that way for an hour)
+#define DDRR_TRACE(k, how) {}
 #endif
 
 template <bool AUX, class C>
@@ -648,6 +653,8 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
             // (a half that arrives in registers is walked whatever it holds: no count of non-zeros)
             if (pf_kind == 2) pf.template half<typename C::Half>(p, brick, box, tid_pf, false);
         }
+        DDRR_TRACE(8, 0)
+        DDRR_TRACE(10, 1)
 
         for (int ch = 0; ch < n_chunks; ++ch) {  // chunks of at most C::CHUNK poses, of equal size
             const int b0 = pose_lo + ch * chunk;
@@ -668,6 +675,7 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
             }
             if (tid == 0) counter[0] = 0;
             DDRR_PROF(PROF_ROWS);
+            if (ch == 0) DDRR_TRACE(9, 0)
             if (ch == 0 && !loaded) {
                 if constexpr (C::MIXED) {
                     if (f32_brick)
@@ -691,6 +699,8 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
                 ahead[4] = req_item;
             }
             DDRR_PROF(PROF_STORE);
+            if (ch == 0) DDRR_TRACE(4, 0)
+            if (ch == 0) DDRR_TRACE(7, 1)
             __syncthreads();
             if (ch == 0) DDRR_TRACE(0, 0)
             if ((!C::Q16 || f32_brick) && ch == 0 && !loaded) brick_empty = counter[2] == 0;

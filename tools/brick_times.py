@@ -30,7 +30,7 @@ V = drr.density
 lib = _lib.get_lib()
 lib.cdll.ddrr_set_brick_variant(a.variant)
 storage = a.storage or ("q16" if a.variant in (1, 2, 4, 5, 6, 10) else "f32")
-times = torch.zeros(32768, dtype=torch.int32, device=dev)
+times = torch.zeros(2048 * 17, dtype=torch.int32, device=dev)
 
 
 def schedule(durs, n_wg=256):
@@ -57,14 +57,19 @@ for case in a.cases.split(","):
         raw = times.cpu().float().numpy() * 0.01  # us
         d = raw[:2048]
         live = d > 0
-        tr = raw[2048:2048 + 8 * 2048].reshape(2048, 8)[live]
+        tr = raw[2048:2048 + 16 * 2048].reshape(2048, 16)[live]
         d = d[live]
         import numpy as np
         print(f"## {case}, {label}: launch {med * 1e3:.0f} us (median, profiling build), {len(d)} bricks: sum / 256 = "
               f"{d.sum() / 256:.0f} us, longest {d.max():.0f} us, mean {d.mean():.0f} us, p99 {np.percentile(d, 99):.0f} us | "
               f"list schedule in id order {schedule(d):.0f} us, by decreasing duration {schedule(sorted(d, reverse=True)):.0f} us",
               flush=True)
-        names = ("staged", "at pool barrier", "behind pool barrier", "wave 0 out of work", "next rows worked out",
-                 "last wave out of work", "last walk done")
+        names = ("staged", "at pool barrier", "behind pool barrier", "wave 0 out of work",
+                 "wave 0 at the staging barrier", "last wave out of work", "last walk done",
+                 "last wave at the staging barrier", "wave 0 image stored", "wave 0 rows written",
+                 "last wave image stored")
+        q = np.percentile(d, [5, 25, 50, 75, 95])
+        print("   durations: p5 %.1f p25 %.1f p50 %.1f p75 %.1f p95 %.1f us; the quarter of shortest bricks: "
+              % tuple(q) + ", ".join(f"{n} {tr[d <= q[1]][:, k].mean():.1f}" for k, n in enumerate(names)), flush=True)
         print("   stages (us from the brick's start, mean over the bricks): "
               + ", ".join(f"{n} {tr[:, k].mean():.1f}" for k, n in enumerate(names)), flush=True)
