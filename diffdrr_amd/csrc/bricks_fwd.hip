@@ -237,6 +237,11 @@ __device__ __forceinline__ void fwd_item(const BrickArgs &p, unsigned lds_base,
                 unsafeAtomicAdd(aux + 4u * p.aux_plane + r, v[0]);
             }
         } else {
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+            // (timing experiment: the record computed but NOT delivered -- the bound on what any other
+            // delivery, e.g. through LDS, could gain: profiles/r05/record_structural_candidates.txt)
+            if (p.dbg & 131072) ok = ok && v[0] == 12345.678f;
+#endif
             deliver_record_blocked(aux, ok, r, v);
         }
     }

@@ -29,3 +29,9 @@ mkdir -p gpurun_out/r05h; timeout 600 python -m pytest tests/test_gpu_baseline_s
 
 # ---------------------------------------------------------------- 2026-09-27T00:49:28Z  few poses: rows-ready flag instead of the staging barrier, lane-parallel rows, wave 0 free
 mkdir -p gpurun_out/r05i; timeout 900 python -m pytest tests/test_gpu_brick_storage.py tests/test_gpu_baseline_sizes.py -x -q 2>&1 | tail -5 > gpurun_out/r05i/gpu_tests_subset.txt; tail -3 gpurun_out/r05i/gpu_tests_subset.txt; timeout 600 python tools/storage_bench.py --storages q16p --poses 1,2,4,8,32 --scenes noise512,phantom512,ct 2>&1 | grep -v amdgpu.ids > gpurun_out/r05i/storage_bench.txt; cat gpurun_out/r05i/storage_bench.txt; DDRR_EXP_FLAGS=-DDDRR_TRACE_ONLY timeout 600 python tools/brick_times.py --cases pert1,pert1aux --variant 5 --storage q16p 2>&1 | grep -v amdgpu.ids | grep -A2 "product" > gpurun_out/r05i/brick_times_trace_only.txt; cat gpurun_out/r05i/brick_times_trace_only.txt
+
+# ---------------------------------------------------------------- 2026-09-27T00:54:36Z  256^3: bricks handed out in pose parts (split) on fp32 bricks, order weight
+mkdir -p gpurun_out/r05j; timeout 600 python tools/brick_bench.py --size 256 --variants 0 --storage f32 --order weight --cases pert32,pert32aux --split 0:1,512:2,512:4,256:2,128:2 2>&1 | grep -v amdgpu.ids | cut -c1-230 > gpurun_out/r05j/split_256.txt; cat gpurun_out/r05j/split_256.txt
+
+# ---------------------------------------------------------------- 2026-09-27T00:55:57Z  forward + record with the record computed but not delivered (bound for delivery through LDS)
+mkdir -p gpurun_out/r05k; timeout 600 python tools/brick_bench.py --variants=-2 --storage q16p --order weight --cases pert32aux,pert8aux,pert1aux --dbg 0,131072 2>&1 | grep -v amdgpu.ids | cut -c1-230 > gpurun_out/r05k/no_delivery.txt; cat gpurun_out/r05k/no_delivery.txt
