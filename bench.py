@@ -468,10 +468,14 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
         def step():
             rot.grad = None
             xyz.grad = None
-            img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
-            loss = ncc(base.expand(B, -1, -1, -1), img)  # (B,) one similarity per pose
+            if args.unfused:
+                img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+                loss = ncc(base.expand(B, -1, -1, -1), img)  # (B,) one similarity per pose
+            else:
+                # the same objective through DRR.ncc: pose -> rays, image-from-record + NCC and NCC
+                # backward -> pose parameters as three fused launches around the brick kernel
+                loss = drr.ncc(base, rot, xyz, convention="ZXY", eps=ncc.eps)
             loss.sum().backward()
-            keep["img"] = img
             if world > 1:
                 # the 4 B/pose of losses travel on RCCL's own stream while the next step renders:
                 # nothing on the compute stream waits for them before fence()
@@ -602,7 +606,11 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
         timer.enabled, timer.skip = False, None
     if cfg in ("headline", "2"):
         assert torch.isfinite(rot.grad).all() and torch.isfinite(xyz.grad).all()
-        images = keep["img"].detach()
+        with torch.no_grad():  # (the fused step writes no image: the same poses, rendered once more)
+            images = drr(rot0, xyz0, parameterization="euler_angles", convention="ZXY")
+        extra["step"] = ("unfused: DRR.forward + NormalizedCrossCorrelation2d through autograd" if args.unfused
+                         else "DRR.ncc: ddrr_pose_raygen_forward, the brick kernel with its record, "
+                              "ddrr_siddon_ncc_forward; backward: ddrr_siddon_ncc_backward_pose")
     if cfg == "4":
         extra["registration"].update(
             ncc_after=float(last.item()), iterations=warmup + steps,
@@ -1080,6 +1088,9 @@ def main():
                          "sub-run also happens at non-default sizes / on the cpu harness)")
     ap.add_argument("--storage", default=None, choices=["q16p", "q16", "f32"],
                     help="Siddon.brick_storage (default: the module's default, q16p)")
+    ap.add_argument("--unfused", action="store_true",
+                    help="headline / config 2: the step as DRR.forward + the NCC module through autograd "
+                         "(nine small launches around the brick kernel) instead of DRR.ncc (three)")
     ap.add_argument("--packed-record", action="store_true",
                     help="Siddon.packed_record = True (the opt-in fixed-point backward record)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],

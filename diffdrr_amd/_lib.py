@@ -15,7 +15,7 @@ from ctypes import c_double, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffdrr_hip.so")
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 REDUCE_SUM, REDUCE_MAX = 0, 1
 LOOKUP_STEP, LOOKUP_MID_NEAREST, LOOKUP_MID_TRILINEAR = 0, 1, 2
@@ -81,6 +81,11 @@ _SIGNATURES = {
                                               _P, _P, _P, _P, _P],
     "ddrr_pose_euler_forward": [_P, _P, _I, _I, _I, _P, _I, _P, _P],
     "ddrr_pose_euler_backward": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P],
+    "ddrr_siddon_ncc_workspace_bytes": [_I],
+    "ddrr_pose_raygen_forward": [_P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
+    "ddrr_siddon_ncc_forward": [_P, _P, _P, _L, _I, _I, _F, _P, _P, _P, _P, _P],
+    "ddrr_siddon_ncc_backward_pose": [_P, _P, _P, _L, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I,
+                                      _P, _I, _I, _F, _I, _P, _P, _P, _P],
     "ddrr_ncc_forward": [_P, _L, _P, _I, _I, _F, _P, _P, _P],
     "ddrr_ncc_backward": [_P, _L, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "ddrr_sobel_forward": [_P, _I, _I, _I, _P, _P],
@@ -108,7 +113,8 @@ _SIGNATURES = {
                                                _I, _P, _P, _P, _P, _P],
 }
 # (entries that return a size, not a status)
-_RESTYPES = {"ddrr_brick_workspace_bytes": c_long, "ddrr_brick_launch_workspace_bytes": c_long}
+_RESTYPES = {"ddrr_brick_workspace_bytes": c_long, "ddrr_brick_launch_workspace_bytes": c_long,
+             "ddrr_siddon_ncc_workspace_bytes": c_long}
 EXPORTS = ["ddrr_abi_version", "ddrr_last_error", *_SIGNATURES]
 
 

@@ -1191,7 +1191,7 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                                int ranges_valid, void *launch_ws, void *stream) {
     const int N = det_h * det_w;
     if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
-    if (!out) return fail(-1, "null out pointer");
+    if (!out && !aux) return fail(-1, "null out pointer");  // (the record alone: ddrr_siddon_ncc_forward forms the image)
     if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
     if (!(record_vmax >= 0.f)) return fail(-1, "record_vmax must be >= 0");
     if (brick_storage != DDRR_BRICKS_F32 && brick_storage != DDRR_BRICKS_Q16 &&
@@ -1221,8 +1221,9 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                                    rec_q, st, launch_ws, "ddrr_siddon_forward_bricks"))
         return rc;
     if (!aux) return 0;
-    hipLaunchKernelGGL(siddon_out_from_record_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, st, aux + (packed ? 4 * R : 0), packed ? 0 : 1, img, R, out);
+    if (out)
+        hipLaunchKernelGGL(siddon_out_from_record_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, st, aux + (packed ? 4 * R : 0), packed ? 0 : 1, img, R, out);
     return finish("ddrr_siddon_forward_bricks");
 }
 

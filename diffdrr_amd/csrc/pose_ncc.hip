@@ -141,6 +141,211 @@ __global__ __launch_bounds__(kBlock) void pose_euler_bwd_kernel(
     }
 }
 
+
+// ----------------------------------- the registration / sweep step around the renderer, fused
+// A registration iteration at one pose is ~0.19 ms of brick kernel and -- as separate launches:
+// pose -> matrix, matrix -> rays, record -> image, NCC, its backward, rays -> dL/dMw, dL/dMw ->
+// dL/d(rot, xyz), plus two zero-fills -- 0.06 ms of small kernels at ~4.4 us each
+// (profiles/r04/bench_config_4.json).  Three kernels do the same arithmetic, in the same order
+// per element:
+//   pose_raygen_fwd_kernel      = pose_euler_fwd_kernel + raygen_fwd_kernel (every workgroup works
+//                                 its pose's matrix out again: three sincos, 30 fma);
+//   siddon_ncc_fwd_kernel       = siddon_out_from_record_kernel + ncc_fwd_kernel, many workgroups per
+//                                 pair: moments by double atomics into the caller's workspace, the
+//                                 LAST workgroup of a pair (a ticket) finishes its statistics;
+//   siddon_ncc_bwd_pose_kernel  = ncc_bwd_kernel + siddon_bwd_pose_kernel + pose_euler_bwd_kernel: the
+//                                 image gradient is formed per ray from the statistics, chained
+//                                 through the record and the ray generation, reduced per pose; the
+//                                 last workgroup of a pose takes dL/dMw on to the pose parameters.
+// The workspace (moments, dL/dMw accumulators, tickets) is caller-owned, zero when it is first
+// handed over, and left zero by every call: no fills.  Reference: diffdrr/pose.py:140-190,
+// detector.py:144-154, drr.py:201-205, metrics.py:21-44 and their autograd.
+constexpr int kNccRaysPerBlock = 4096;
+
+struct NccWs {
+    double *mom;   // [B][5]  sum x1, x2, x1^2, x2^2, x1 x2
+    float *gacc;   // [B][12] dLoss/dMw
+    int *tick1, *tick2;  // [B] each
+};
+__host__ __device__ inline NccWs ncc_ws(void *ws, int B) {
+    NccWs w;
+    w.mom = reinterpret_cast<double *>(ws);
+    w.gacc = reinterpret_cast<float *>(w.mom + 5 * (long)B);
+    w.tick1 = reinterpret_cast<int *>(w.gacc + 12 * (long)B);
+    w.tick2 = w.tick1 + B;
+    return w;
+}
+
+__global__ __launch_bounds__(kBlock) void pose_raygen_fwd_kernel(
+    const float *__restrict__ rot, const float *__restrict__ xyz, int a0, int a1, int a2,
+    const float *__restrict__ Ro, const float *__restrict__ Ainv, const float *__restrict__ P, int N,
+    float *__restrict__ Mw, float *__restrict__ source_v, float *__restrict__ target_v,
+    float *__restrict__ img) {
+    const int b = blockIdx.y, n = blockIdx.x * kBlock + threadIdx.x;
+    const float th[3] = {rot[b * 3], rot[b * 3 + 1], rot[b * 3 + 2]};
+    const float t[3] = {xyz[b * 3], xyz[b * 3 + 1], xyz[b * 3 + 2]};
+    const int axes[3] = {a0, a1, a2};
+    float M[12];
+    pose_euler_forward(th, t, axes, Ro, M);
+    if (n == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Mw[b * 12 + k] = M[k];
+        const float sw[3] = {M[3], M[7], M[11]};
+        float sv[3];
+        apply34(Ainv, sw, sv);
+        source_v[b * 3 + 0] = sv[0];
+        source_v[b * 3 + 1] = sv[1];
+        source_v[b * 3 + 2] = sv[2];
+    }
+    if (n >= N) return;
+    const float Pn[3] = {P[n * 3], P[n * 3 + 1], P[n * 3 + 2]};
+    const RayGenOut o = raygen_ray(M, Ainv, Pn);
+    const long r = (long)b * N + n;
+    target_v[r * 3 + 0] = o.tv[0];
+    target_v[r * 3 + 1] = o.tv[1];
+    target_v[r * 3 + 2] = o.tv[2];
+    img[r] = o.L;
+}
+
+__global__ __launch_bounds__(kBlock) void siddon_ncc_fwd_kernel(
+    const float *__restrict__ aux, const float *__restrict__ img, const float *__restrict__ x1,
+    long x1_stride, int B, int N, float eps, void *ws_raw, float *__restrict__ ncc_out,
+    float *__restrict__ stats, float *__restrict__ out) {
+    __shared__ double red[5][kWavesPerBlock];
+    __shared__ int last;
+    const NccWs ws = ncc_ws(ws_raw, B);
+    const int b = blockIdx.y;
+    double m[5] = {0., 0., 0., 0., 0.};
+    const int n_end = min(N, (int)(blockIdx.x + 1) * kNccRaysPerBlock);
+    for (int n = blockIdx.x * kNccRaysPerBlock + threadIdx.x; n < n_end; n += kBlock) {
+        const long r = (long)b * N + n;
+        const float x2 = img[r] * aux[rec_index(r, 0)];  // (= siddon_out_from_record_kernel)
+        if (out) out[r] = x2;
+        const double da = (double)x1[b * x1_stride + n], dc = (double)x2;
+        m[0] += da;
+        m[1] += dc;
+        m[2] = fma(da, da, m[2]);
+        m[3] = fma(dc, dc, m[3]);
+        m[4] = fma(da, dc, m[4]);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        double v = m[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[k][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double v = 0.;
+        for (int w = 0; w < kWavesPerBlock; ++w) v += red[threadIdx.x][w];
+        atomicAdd(ws.mom + b * 5 + threadIdx.x, v);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(ws.tick1 + b, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!last || threadIdx.x != 0) return;
+    __threadfence();
+    double t[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        t[k] = atomicAdd(ws.mom + b * 5 + k, 0.0);  // (a coherent read)
+        ws.mom[b * 5 + k] = 0.0;                    // left zero for the next call
+    }
+    ws.tick1[b] = 0;
+    const double inv_n = 1.0 / (double)N;
+    const double mu1 = t[0] * inv_n, mu2 = t[1] * inv_n;
+    const double v1 = t[2] * inv_n - mu1 * mu1, v2 = t[3] * inv_n - mu2 * mu2;
+    const double c12 = t[4] * inv_n - mu1 * mu2;
+    const float s1 = sqrtf((float)v1 + eps), s2 = sqrtf((float)v2 + eps);
+    const float ncc = (float)c12 / (s1 * s2);
+    ncc_out[b] = ncc;
+    stats[b * 5 + 0] = (float)mu1;
+    stats[b * 5 + 1] = s1;
+    stats[b * 5 + 2] = (float)mu2;
+    stats[b * 5 + 3] = s2;
+    stats[b * 5 + 4] = ncc;
+}
+
+__global__ __launch_bounds__(kBlock) void siddon_ncc_bwd_pose_kernel(
+    const float *__restrict__ aux, const float *__restrict__ img, const float *__restrict__ x1,
+    long x1_stride, const float *__restrict__ stats, const float *__restrict__ g_out, int g_stride,
+    const float *__restrict__ source_v, const float *__restrict__ target_v,
+    const float *__restrict__ Mw, const float *__restrict__ Ainv, const float *__restrict__ P,
+    const float *__restrict__ rot, const float *__restrict__ xyz, int a0, int a1, int a2,
+    const float *__restrict__ Ro, int B, int N, float eps, int with_img_path, void *ws_raw,
+    float *__restrict__ g_rot, float *__restrict__ g_xyz) {
+    __shared__ float red[kWavesPerBlock][12];
+    __shared__ int last;
+    const NccWs ws = ncc_ws(ws_raw, B);
+    const int b = blockIdx.y;
+    const float *M = Mw + (long)b * 12;
+    const float s[3] = {source_v[b * 3], source_v[b * 3 + 1], source_v[b * 3 + 2]};
+    const float mu1 = stats[b * 5], s1 = stats[b * 5 + 1], mu2 = stats[b * 5 + 2];
+    const float s2 = stats[b * 5 + 3], ncc = stats[b * 5 + 4];
+    const float gn = g_out[b * g_stride] / (float)N;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    const int n_end = min(N, (int)(blockIdx.x + 1) * kPoseRaysPerBlock);
+    for (int n = blockIdx.x * kPoseRaysPerBlock + threadIdx.x; n < n_end; n += kBlock) {
+        const long r = (long)b * N + n;
+        float rec[SIDDON_AUX];
+        rec_blocked_load(aux, r, rec);
+        const float L = img[r];
+        // d ncc / d x2[n] (= ncc_bwd_kernel on x2 = L I)
+        const float z1 = (x1[b * x1_stride + n] - mu1) / s1, z2 = (L * rec[0] - mu2) / s2;
+        const float g = gn * (z1 - z2 * ncc) / s2;
+        const float t[3] = {target_v[r * 3], target_v[r * 3 + 1], target_v[r * 3 + 2]};
+        const float Pn[3] = {P[n * 3], P[n * 3 + 1], P[n * 3 + 2]};
+        float gs[3], gt[3];
+        siddon_backward_ray<REDUCE_SUM>(rec, s, t, eps, g * L, gs, gt);
+        raygen_ray_adjoint(M, Ainv, Pn, gt, gs, with_img_path ? g * rec[0] : 0.f, L, acc);
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o, 64);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) red[wave][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) v += red[w][threadIdx.x];
+        unsafeAtomicAdd(ws.gacc + (long)b * 12 + threadIdx.x, v);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(ws.tick2 + b, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!last || threadIdx.x != 0) return;
+    __threadfence();
+    // the last workgroup of the pose: dLoss/dMw -> dLoss/d(rot, xyz) (= pose_euler_bwd_kernel)
+    float g[12], gth[3], gx[3];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        g[k] = atomicAdd(ws.gacc + (long)b * 12 + k, 0.f);  // (a coherent read)
+        ws.gacc[(long)b * 12 + k] = 0.f;                     // left zero for the next call
+    }
+    ws.tick2[b] = 0;
+    const float th[3] = {rot[b * 3], rot[b * 3 + 1], rot[b * 3 + 2]};
+    const float tr[3] = {xyz[b * 3], xyz[b * 3 + 1], xyz[b * 3 + 2]};
+    const int axes[3] = {a0, a1, a2};
+    pose_euler_backward(th, tr, axes, Ro, g, gth, gx);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        g_rot[b * 3 + k] = gth[k];
+        g_xyz[b * 3 + k] = gx[k];
+    }
+}
+
 // ------------------------------------------------- fused NCC (sweep / registration)
 // NormalizedCrossCorrelation2d with patch_size = None (reference metrics.py:21-44):
 // ncc_b = mean(z1 * z2), z = (x - mean) / sqrt(var + eps), one value per image pair.
@@ -328,6 +533,68 @@ int ddrr_ncc_backward(const float *x1, long x1_stride, const float *x2, const fl
     hipLaunchKernelGGL(ncc_bwd_kernel, dim3((N + kBlock - 1) / kBlock, B), dim3(kBlock), 0,
                        (hipStream_t)stream, x1, x1_stride, x2, stats, g_out, g_stride, N, g_x1, g_x2);
     return finish("ddrr_ncc_backward");
+}
+
+long ddrr_siddon_ncc_workspace_bytes(int B) {
+    return B < 1 ? 0 : (long)B * (5 * sizeof(double) + 12 * sizeof(float) + 2 * sizeof(int));
+}
+
+static int check_axes(int a0, int a1, int a2) {
+    if (a0 < 0 || a0 > 2 || a1 < 0 || a1 > 2 || a2 < 0 || a2 > 2 || a1 == a0 || a1 == a2)
+        return fail(-1, "invalid Euler convention");
+    return 0;
+}
+
+int ddrr_pose_raygen_forward(const float *rot, const float *xyz, int a0, int a1, int a2,
+                             const float *reorient34, const float *Ainv, const float *P, int B, int N,
+                             float *Mw, float *source_v, float *target_v, float *img, void *stream) {
+    if (!rot || !xyz || !reorient34 || !Ainv || !P || !Mw || !source_v || !target_v || !img)
+        return fail(-1, "null pointer");
+    if (int rc = check_axes(a0, a1, a2)) return rc;
+    if (B < 0 || N < 0) return fail(-1, "negative batch or ray count");
+    if (B == 0 || N == 0) return 0;
+    if (B > 65535) return fail(-1, "at most 65535 poses per call");
+    const dim3 grid((N + kBlock - 1) / kBlock, B), block(kBlock);
+    hipLaunchKernelGGL(pose_raygen_fwd_kernel, grid, block, 0, (hipStream_t)stream, rot, xyz, a0, a1,
+                       a2, reorient34, Ainv, P, N, Mw, source_v, target_v, img);
+    return finish("ddrr_pose_raygen_forward");
+}
+
+int ddrr_siddon_ncc_forward(const float *aux, const float *img, const float *x1, long x1_stride, int B,
+                            int N, float eps, void *ws, float *ncc, float *stats, float *out,
+                            void *stream) {
+    if (!aux || !img || !x1 || !ws || !ncc || !stats) return fail(-1, "null pointer");
+    if (x1_stride != 0 && x1_stride != N) return fail(-1, "x1_stride must be N, or 0 for a shared image");
+    if (B < 0 || N < 1) return fail(-1, "bad batch / image size");
+    if (B == 0) return 0;
+    if (B > 65535) return fail(-1, "at most 65535 pairs per call");
+    const dim3 grid((N + kNccRaysPerBlock - 1) / kNccRaysPerBlock, B), block(kBlock);
+    hipLaunchKernelGGL(siddon_ncc_fwd_kernel, grid, block, 0, (hipStream_t)stream, aux, img, x1,
+                       x1_stride, B, N, eps, ws, ncc, stats, out);
+    return finish("ddrr_siddon_ncc_forward");
+}
+
+int ddrr_siddon_ncc_backward_pose(const float *aux, const float *img, const float *x1, long x1_stride,
+                                  const float *stats, const float *g_out, int g_stride,
+                                  const float *source_v, const float *target_v, const float *Mw,
+                                  const float *Ainv, const float *P, const float *rot, const float *xyz,
+                                  int a0, int a1, int a2, const float *reorient34, int B, int N,
+                                  float eps, int with_img_path, void *ws, float *g_rot, float *g_xyz,
+                                  void *stream) {
+    if (!aux || !img || !x1 || !stats || !g_out || !source_v || !target_v || !Mw || !Ainv || !P ||
+        !rot || !xyz || !reorient34 || !ws || !g_rot || !g_xyz)
+        return fail(-1, "null pointer");
+    if (int rc = check_axes(a0, a1, a2)) return rc;
+    if (x1_stride != 0 && x1_stride != N) return fail(-1, "x1_stride must be N, or 0 for a shared image");
+    if (g_stride != 0 && g_stride != 1) return fail(-1, "g_stride must be 1, or 0 for one value shared by the batch");
+    if (B < 0 || N < 1) return fail(-1, "bad batch / image size");
+    if (B == 0) return 0;
+    if (B > 65535) return fail(-1, "at most 65535 poses per call");
+    const dim3 grid((N + kPoseRaysPerBlock - 1) / kPoseRaysPerBlock, B), block(kBlock);
+    hipLaunchKernelGGL(siddon_ncc_bwd_pose_kernel, grid, block, 0, (hipStream_t)stream, aux, img, x1,
+                       x1_stride, stats, g_out, g_stride, source_v, target_v, Mw, Ainv, P, rot, xyz,
+                       a0, a1, a2, reorient34, B, N, eps, with_img_path, ws, g_rot, g_xyz);
+    return finish("ddrr_siddon_ncc_backward_pose");
 }
 
 int ddrr_pose_euler_forward(const float *rot, const float *xyz, int a0, int a1, int a2,

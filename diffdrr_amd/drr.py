@@ -11,6 +11,8 @@ program, which makes ``patch_size`` and ``checkpoint_gradients`` unnecessary
 """
 from __future__ import annotations
 
+import math
+
 import torch
 import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
@@ -197,6 +199,54 @@ class DRR(nn.Module):
                                               **kwargs)
         finally:
             self.renderer.trust_detector_shape = False
+
+    def ncc(self, fixed: torch.Tensor, rot: torch.Tensor, xyz: torch.Tensor, *,
+            convention: str = "ZXY", degrees: bool = False, eps: float = 1e-5) -> torch.Tensor:
+        """Per-pose normalised cross-correlation of ``fixed`` ((1 | B), 1, H, W) with the DRRs at the
+        Euler poses (rot, xyz) (B, 3): ``NormalizedCrossCorrelation2d(eps=eps)(fixed.expand(B, ...),
+        self(rot, xyz, parameterization="euler_angles", convention=convention))`` -- the objective of
+        the reference's registration loop (registration.py:32-42 + metrics.py:21-44) -- -> (B,).
+
+        When the pose parameters require a gradient and the render takes the brick kernel, the
+        whole step runs as three fused launches around it instead of nine (pose -> matrix -> rays;
+        image from the backward record + NCC; NCC backward -> ray gradients -> matrix -> pose
+        parameters: ``renderers._EulerSiddonNccFn``): 9-14 % of a one-pose registration iteration.
+        Anything else (no gradient wanted: the forward-only kernel is the faster one; other
+        renderers, subsampling, patches, a volume that requires a gradient) composes the same
+        result from ``forward`` and the NCC module."""
+        from .metrics import NormalizedCrossCorrelation2d
+        from .pose import _AXIS, _check_convention
+        from .renderers import _EulerSiddonNccFn
+
+        B = rot.shape[0]
+        r, det = self.renderer, self.detector
+        ok = (torch.is_grad_enabled() and (rot.requires_grad or xyz.requires_grad)
+              and self._fused_ok(False, {}, None) and isinstance(r, Siddon)
+              and r.grid_path == "bricks" and not r.packed_record and not self.density.requires_grad
+              and all(torch.is_tensor(a) and a.dim() == 2 and a.shape == (B, 3)
+                      and a.dtype == torch.float32 and ops.on_device(a) for a in (rot, xyz))
+              and torch.is_tensor(fixed) and fixed.dim() == 4 and fixed.shape[0] in (1, B)
+              and fixed.shape[1:] == (1, det.height, det.width) and fixed.dtype == torch.float32
+              and fixed.device == rot.device and not fixed.requires_grad and B > 0)
+        if not ok:
+            img = self(rot, xyz, parameterization="euler_angles", convention=convention, degrees=degrees)
+            return NormalizedCrossCorrelation2d(eps=eps)(fixed.expand(B, -1, -1, -1), img)
+        _check_convention(convention)
+        if degrees:
+            rot = rot / 180 * math.pi
+        axes = tuple(_AXIS[c] for c in convention)
+        # (as _render_fused_Mw: the calibrated detector points, cached per intrinsics)
+        key = getattr(self, "_P_key", None)
+        if key is None or key[0] is not det._calibration or key[1] != det._calibration._version \
+                or key[2] is not det.target or key[3] != det.target._version:
+            self._P_cache = det.calibration(det.target)[0].detach()
+            self._P_key = (det._calibration, det._calibration._version, det.target, det.target._version)
+        Ainv = self._affine_inverse[0, :3, :] if self._affine_inverse.dim() == 3 \
+            else self._affine_inverse[:3, :]
+        cfg = r._cfg(False, det=(det.height, det.width))
+        x1 = fixed.reshape(fixed.shape[0], det.height * det.width)
+        return _EulerSiddonNccFn.apply(rot, xyz, self.density, det._reorient[:3, :].contiguous(),
+                                       self._P_cache, Ainv, x1, axes, cfg, float(eps))
 
     @torch.no_grad()
     def marching_range(self, *args, parameterization: str = None, convention: str = None,

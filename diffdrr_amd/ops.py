@@ -311,7 +311,7 @@ def brick_ranges(volume):
 
 
 def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, eps=1e-8,
-                          want_aux=False, record_vmax=0.0, storage="f32"):
+                          want_aux=False, record_vmax=0.0, storage="f32", want_image=True):
     """Detector-grid Siddon (sum) through the volume-stationary brick kernel: every 32^3
     brick is staged in LDS once and all rays of all poses are traced through it.
     Requires the targets to be the affine detector grid DRR builds.
@@ -330,7 +330,8 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
         storage = "f32"
     volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
     img = None if img is None else img.contiguous()
-    out = torch.empty(B, N, dtype=torch.float32, device=volume.device)
+    # (want_image = False with want_aux: the record alone -- siddon_ncc_forward forms the image)
+    out = torch.empty(B, N, dtype=torch.float32, device=volume.device) if (want_image or not want_aux) else None
     ranges, valid = brick_workspace(volume, storage) if storage != "f32" else (None, 0)
     packed = bool(want_aux and record_vmax and record_vmax > 0.0)
     aux = None
@@ -343,7 +344,7 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
     _launch(
         "ddrr_siddon_forward_bricks", volume.device, volume.data_ptr(), *volume.shape,
         source.data_ptr(), target.data_ptr(), _ptr(img), B, H, W, float(voxel_shift), float(eps),
-        out.data_ptr(), _ptr(aux), float(record_vmax) if packed else 0.0,
+        _ptr(out), _ptr(aux), float(record_vmax) if packed else 0.0,
         _BRICK_STORAGE[storage], _ptr(ranges), int(valid),
         launch_workspace(volume.shape, volume.device).data_ptr())
     if storage != "f32" and not valid:
@@ -485,6 +486,87 @@ def siddon_backward_pose(aux, grad_out, source, target, img, Mw, Ainv, P, *, eps
             Mw.data_ptr(), Ainv.data_ptr(), P.data_ptr(), B, N, float(eps),
             int(bool(with_img_path)), gMw.data_ptr())
     return gMw
+
+
+# ---------------------------------------------------------------- the fused registration step
+_ncc_ws = {}  # (device, stream, B) -> workspace of ddrr_siddon_ncc_* (zero between calls)
+
+
+def siddon_ncc_workspace(B, device):
+    """The caller-owned accumulators / tickets of :func:`siddon_ncc_forward` and
+    :func:`siddon_ncc_backward_pose`: zero when first handed over, left zero by every call, so one
+    buffer per (device, stream, batch size) serves every call on that stream without a fill.
+    (First use inside a stream capture: the zero-fill becomes a node of the graph -- harmless, one
+    small launch per replay; ``GraphedIteration`` creates the buffer for its capture stream before
+    it captures.)"""
+    dev = torch.device(device)
+    sid = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+    key = (dev, sid, int(B))
+    ws = _ncc_ws.get(key)
+    if ws is None:
+        n = int(_query("ddrr_siddon_ncc_workspace_bytes", int(B)))
+        ws = _ncc_ws[key] = torch.zeros((n + 7) // 8, dtype=torch.float64, device=dev)
+    return ws
+
+
+def pose_raygen_forward(rot, xyz, axes, reorient34, Ainv, P):
+    """pose_euler_forward + raygen_forward in one launch -> (Mw (B,3,4), source_v (B,1,3),
+    target_v (B,N,3), img (B,N))."""
+    _require_gpu(rot)
+    B, N = rot.shape[0], P.shape[0]
+    rot, xyz, reorient34, Ainv, P = (t.contiguous() for t in (rot, xyz, reorient34, Ainv, P))
+    dev = rot.device
+    Mw = torch.empty(B, 3, 4, dtype=torch.float32, device=dev)
+    source = torch.empty(B, 1, 3, dtype=torch.float32, device=dev)
+    target = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+    img = torch.empty(B, N, dtype=torch.float32, device=dev)
+    if not _empty(B, N):
+        _launch("ddrr_pose_raygen_forward", dev, rot.data_ptr(), xyz.data_ptr(), *axes,
+                reorient34.data_ptr(), Ainv.data_ptr(), P.data_ptr(), B, N, Mw.data_ptr(),
+                source.data_ptr(), target.data_ptr(), img.data_ptr())
+    return Mw, source, target, img
+
+
+def siddon_ncc_forward(aux, img, x1, eps, *, want_image=False):
+    """Per-pose NCC of the fixed image(s) ``x1`` ((B | 1), N) with the DRRs whose blocked record
+    is ``aux`` (``img`` (B,N): the rays' lengths): the image is formed from the record on the fly.
+    -> (ncc (B), stats (B,5), image (B,N) | None)"""
+    B, N = img.shape
+    shared = x1.shape[0] == 1 and B != 1
+    x1, img = x1.contiguous(), img.contiguous()
+    dev = img.device
+    ncc = torch.empty(B, dtype=torch.float32, device=dev)
+    stats = torch.empty(B, 5, dtype=torch.float32, device=dev)
+    out = torch.empty(B, N, dtype=torch.float32, device=dev) if want_image else None
+    if B:
+        _launch("ddrr_siddon_ncc_forward", dev, aux.data_ptr(), img.data_ptr(), x1.data_ptr(),
+                0 if shared else N, B, N, float(eps), siddon_ncc_workspace(B, dev).data_ptr(),
+                ncc.data_ptr(), stats.data_ptr(), _ptr(out))
+    return ncc, stats, out
+
+
+def siddon_ncc_backward_pose(aux, img, x1, stats, g_out, source, target, Mw, Ainv, P, rot, xyz, axes,
+                             reorient34, *, eps=1e-8, with_img_path=True):
+    """(g_rot (B,3), g_xyz (B,3)) of sum_b g_out[b] ncc[b]: ncc_backward, siddon_backward_pose and
+    pose_euler_backward in one launch."""
+    B, N = img.shape
+    shared = x1.shape[0] == 1 and B != 1
+    g_stride = 0 if (g_out.dim() == 1 and B > 1 and g_out.stride(0) == 0) else 1
+    if g_stride:
+        g_out = g_out.contiguous()
+    x1, img, source, target = (t.contiguous() for t in (x1, img, source, target))
+    Mw, Ainv, P, rot, xyz, reorient34 = (t.contiguous() for t in (Mw, Ainv, P, rot, xyz, reorient34))
+    dev = img.device
+    g_rot = torch.empty(B, 3, dtype=torch.float32, device=dev)
+    g_xyz = torch.empty(B, 3, dtype=torch.float32, device=dev)
+    if B:
+        _launch("ddrr_siddon_ncc_backward_pose", dev, aux.data_ptr(), img.data_ptr(), x1.data_ptr(),
+                0 if shared else N, stats.data_ptr(), g_out.data_ptr(), g_stride, source.data_ptr(),
+                target.data_ptr(), Mw.data_ptr(), Ainv.data_ptr(), P.data_ptr(), rot.data_ptr(),
+                xyz.data_ptr(), *axes, reorient34.data_ptr(), B, N, float(eps),
+                int(bool(with_img_path)), siddon_ncc_workspace(B, dev).data_ptr(), g_rot.data_ptr(),
+                g_xyz.data_ptr())
+    return g_rot, g_xyz
 
 
 def siddon_backward_volume(volume, source, target, img, grad_out, *, voxel_shift=0.5, eps=1e-8,

@@ -69,10 +69,17 @@ class GraphedIteration:
     ``static_volume`` (default True): the CT volume is not edited in place between replays --
     the graph then renders from the volume's cached 16-bit bricks (``Siddon.brick_storage``),
     whose address and "already built" state are baked into the graph.  Pass False if the volume
-    changes under the graph: the captured render then reads the live fp32 volume."""
+    changes under the graph: the captured render then reads the live fp32 volume.
+
+    ``fused_similarity`` (default True): with ``NormalizedCrossCorrelation2d()`` as the criterion
+    and Euler pose parameters the iteration goes through ``DRR.ncc`` -- three fused launches around
+    the brick kernel instead of nine -- where that applies (``self.fused_similarity`` says whether
+    it was asked for; the value and the gradients are those of the criterion on the rendered
+    image, up to the order of the sums)."""
 
     def __init__(self, reg: Registration, criterion, optimizer, target: torch.Tensor,
-                 warmup: int = 3, static_volume: bool = True, **render_kwargs):
+                 warmup: int = 3, static_volume: bool = True, fused_similarity: bool = True,
+                 **render_kwargs):
         self.reg, self.criterion, self.optimizer, self.target = reg, criterion, optimizer, target
         self.render_kwargs = render_kwargs
         self.iterations_done = 0
@@ -89,9 +96,21 @@ class GraphedIteration:
         saved_state = {p: {k: v.detach().clone() for k, v in optimizer.state.get(p, {}).items()
                            if torch.is_tensor(v)} for p in params}
 
+        # NCC of Euler poses: the step around the renderer as three fused launches (DRR.ncc; it
+        # composes the same value from `reg()` and the criterion itself where they do not apply)
+        from .metrics import NormalizedCrossCorrelation2d
+        fused = (type(criterion) is NormalizedCrossCorrelation2d and criterion.patch_size is None
+                 and reg.parameterization == "euler_angles" and not render_kwargs
+                 and hasattr(reg.drr, "ncc") and fused_similarity)
+        self.fused_similarity = bool(fused)
+
         def iteration():
             optimizer.zero_grad(set_to_none=True)
-            loss = criterion(target, reg(**render_kwargs)).sum()
+            if fused:
+                loss = reg.drr.ncc(target, reg._rotation, reg._translation, convention=reg.convention,
+                                   eps=criterion.eps).sum()
+            else:
+                loss = criterion(target, reg(**render_kwargs)).sum()
             loss.backward()
             optimizer.step()
             return loss.detach()
@@ -106,7 +125,16 @@ class GraphedIteration:
                     iteration()
             torch.cuda.current_stream().wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # (the capture stream is ours, so that the fused step's zeroed workspace -- one per
+            # stream -- exists before the capture: inside it, its zero-fill would become a node)
+            cap = torch.cuda.Stream()
+            cap.wait_stream(torch.cuda.current_stream())
+            if fused:
+                from . import ops
+                with torch.cuda.stream(cap):
+                    ops.siddon_ncc_workspace(reg._rotation.shape[0], reg._rotation.device)
+                cap.synchronize()
+            with torch.cuda.graph(self.graph, stream=cap):
                 self.loss = iteration()
         finally:
             # (whatever the warm-up or the capture raised: the caller's module gets its own

@@ -456,6 +456,36 @@ class _SiddonPoseFn(torch.autograd.Function):
         return g_vol, g_M, None, None, None
 
 
+class _EulerSiddonNccFn(torch.autograd.Function):
+    """A registration step's forward and backward around the brick kernel in three launches
+    instead of nine: (rot, xyz) Euler pose parameters -> per-pose NCC of the DRR with a fixed
+    image.  Forward: ddrr_pose_raygen_forward (pose -> matrix -> rays), the brick kernel with its
+    record (no image is written), ddrr_siddon_ncc_forward (image from the record + NCC).
+    Backward: ddrr_siddon_ncc_backward_pose (NCC backward, the record's ray gradients chained
+    through the ray generation, matrix -> pose parameters).  The arithmetic per element is that
+    of ``NormalizedCrossCorrelation2d()(fixed, drr(rot, xyz, parameterization="euler_angles"))``
+    (reference registration.py:32-42, metrics.py:21-44); only the order of the sums differs."""
+
+    @staticmethod
+    def forward(ctx, rot, xyz, volume, reorient34, P, Ainv, fixed, axes, cfg, ncc_eps):
+        Mw, source, target, img = ops.pose_raygen_forward(rot, xyz, axes, reorient34, Ainv, P)
+        _, aux = ops.siddon_forward_bricks(
+            volume, source, target, img, cfg["det"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
+            want_aux=True, storage=_brick_storage(volume, cfg), want_image=False)
+        ncc, stats, _ = ops.siddon_ncc_forward(aux, img, fixed, ncc_eps)
+        ctx.axes, ctx.cfg = axes, cfg
+        ctx.save_for_backward(rot, xyz, reorient34, P, Ainv, fixed, Mw, source, target, img, aux, stats)
+        return ncc
+
+    @staticmethod
+    def backward(ctx, g):
+        rot, xyz, reorient34, P, Ainv, fixed, Mw, source, target, img, aux, stats = ctx.saved_tensors
+        g_rot, g_xyz = ops.siddon_ncc_backward_pose(
+            aux, img, fixed, stats, g, source, target, Mw, Ainv, P, rot, xyz, ctx.axes, reorient34,
+            eps=ctx.cfg["eps"], with_img_path=not ctx.cfg["stop_gradients"])
+        return g_rot, g_xyz, None, None, None, None, None, None, None, None
+
+
 def _cat_channels(blocks):
     """Channel blocks of the label chunks side by side (one chunk -- up to 256 labels -- is the
     result itself: no copy of the (B, C, N) tensor)."""

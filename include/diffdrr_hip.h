@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 28
+#define DDRR_ABI_VERSION 29
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -93,6 +93,7 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
  * adds the partial integrals to `out` (zero-filled by the call) with fp32 atomics.  The
  * volume is read from HBM once per call, whatever B.  The image equals
  * ddrr_siddon_forward's up to fp32 summation order (which is not deterministic here).
+ * out: (B, N); may be NULL when aux is given (the record alone: ddrr_siddon_ncc_forward forms the image).
  * aux: NULL, or the blocked backward record, DDRR_REC_BLOCK_FLOATS * ceil(B N / DDRR_REC_BLOCK_RAYS)
  * floats (zero-filled and accumulated by the call) for ddrr_siddon_backward_rays /
  * ddrr_siddon_backward_pose (aux_layout = DDRR_AUX_BLOCKED): a run of 8 adjacent pixels adds whole
@@ -451,6 +452,39 @@ int ddrr_pose_euler_forward(const float *rot, const float *xyz, int a0, int a1, 
 int ddrr_pose_euler_backward(const float *rot, const float *xyz, int a0, int a1, int a2,
                              const float *reorient34, const float *gMw, int B, float *g_rot,
                              float *g_xyz, void *stream);
+
+/* The registration / sweep step AROUND the renderer in three launches instead of nine (ABI 29).
+ * A registration iteration (reference registration.py:32-42 + metrics.py:21-44 per iteration of
+ * notebooks/tutorials/registration.ipynb:240-316) is, at one pose, ~0.19 ms of brick kernel and
+ * ~0.06 ms of small launches at ~4.4 us each.  Same arithmetic per element as the entries they fuse:
+ *   ddrr_pose_raygen_forward      = ddrr_pose_euler_forward + ddrr_raygen_forward (Mw is still
+ *                                   written: the backward reads it);
+ *   ddrr_siddon_ncc_forward       = the image from the record (out = img * plane I; `out` may be
+ *                                   NULL) + ddrr_ncc_forward, many workgroups per pair (moments
+ *                                   by double atomics; the pair's last workgroup finishes `stats`);
+ *   ddrr_siddon_ncc_backward_pose = ddrr_ncc_backward + ddrr_siddon_backward_pose +
+ *                                   ddrr_pose_euler_backward: g_rot, g_xyz (B, 3) of
+ *                                   sum_b g_out[b] ncc[b], nothing per ray or per pixel is written.
+ * aux: the BLOCKED float record of ddrr_siddon_forward_bricks (which may be called with
+ * out = NULL when only the record is wanted).  x1: the fixed image(s), (B, N) with
+ * x1_stride = N or one image with x1_stride = 0.  ws: ddrr_siddon_ncc_workspace_bytes(B) bytes,
+ * 8-byte aligned, caller-owned, ZERO when first handed over and left zero by every call (the
+ * accumulators and tickets clean up after themselves: no fills between calls); one workspace
+ * per stream.  Reduce sum, float record only. */
+long ddrr_siddon_ncc_workspace_bytes(int B);
+int ddrr_pose_raygen_forward(const float *rot, const float *xyz, int a0, int a1, int a2,
+                             const float *reorient34, const float *Ainv, const float *P, int B, int N,
+                             float *Mw, float *source_v, float *target_v, float *img, void *stream);
+int ddrr_siddon_ncc_forward(const float *aux, const float *img, const float *x1, long x1_stride, int B,
+                            int N, float eps, void *ws, float *ncc, float *stats, float *out,
+                            void *stream);
+int ddrr_siddon_ncc_backward_pose(const float *aux, const float *img, const float *x1, long x1_stride,
+                                  const float *stats, const float *g_out, int g_stride,
+                                  const float *source_v, const float *target_v, const float *Mw,
+                                  const float *Ainv, const float *P, const float *rot, const float *xyz,
+                                  int a0, int a1, int a2, const float *reorient34, int B, int N,
+                                  float eps, int with_img_path, void *ws, float *g_rot, float *g_xyz,
+                                  void *stream);
 
 /* NormalizedCrossCorrelation2d, patch_size = None (reference metrics.py:21-44) for image
  * pairs of N pixels: out (B) = mean(z1 z2), z = (x - mean) / sqrt(var + eps).  x2 (B, N);

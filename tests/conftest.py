@@ -661,3 +661,54 @@ def check_filter_intersections_outside_volume(device):
     # ... and the intended semantics are the default's (fp64: to the rounding of the shorter sums)
     for k in names:
         assert rel_err(g[f"filtered_{k}_f64"], g[f"default_{k}_f64"]) < 1e-12
+
+
+def check_fused_ncc_step(device):
+    """``DRR.ncc`` -- the registration step around the brick kernel as three fused launches
+    (ddrr_pose_raygen_forward, ddrr_siddon_ncc_forward, ddrr_siddon_ncc_backward_pose; reference
+    registration.py:32-42 + metrics.py:21-44) -- against the composition it replaces,
+    ``NormalizedCrossCorrelation2d()(fixed, drr(rot, xyz, ...))``: values and the gradients of a
+    weighted sum w.r.t. the pose parameters; a fixed image shared by the batch and one per pose;
+    with and without the gradient path through the ray length; the workspace is left zero."""
+    import torch
+
+    from diffdrr_amd import DRR, NormalizedCrossCorrelation2d, ops
+    from diffdrr_amd.data import synthetic_subject
+
+    H, W = 28, 36
+    for stop in (False, True):
+        drr = DRR(synthetic_subject((40, 48, 36), kind="phantom", seed=3), sdd=500.0, height=H, width=W,
+                  delx=2.5, stop_gradients_through_grid_sample=stop).to(device)
+        rot0 = torch.tensor([[0.2, -0.1, 0.3], [0.0, 0.0, 0.0], [-0.4, 0.25, 0.1]], device=device)
+        xyz0 = torch.tensor([[3.0, 300.0, -2.0], [0.0, 310.0, 0.0], [-4.0, 320.0, 5.0]], device=device)
+        B = 3
+        with torch.no_grad():
+            base = drr(torch.zeros(1, 3, device=device), torch.tensor([[0.0, 305.0, 0.0]], device=device),
+                       parameterization="euler_angles", convention="ZXY")
+            per_pose = drr(rot0 + 0.05, xyz0 + 2.0, parameterization="euler_angles", convention="ZXY")
+        w = torch.tensor([0.7, -1.3, 2.1], device=device)
+        crit = NormalizedCrossCorrelation2d()
+        v_base = None
+        for fixed in (base, per_pose):
+            res = []
+            for fused in (True, False):
+                r, x = rot0.clone().requires_grad_(), xyz0.clone().requires_grad_()
+                if fused:
+                    val = drr.ncc(fixed, r, x, convention="ZXY")
+                    assert type(val.grad_fn).__name__.startswith("_EulerSiddonNccFn")  # the fused route
+                else:
+                    val = crit(fixed.expand(B, -1, -1, -1),
+                               drr(r, x, parameterization="euler_angles", convention="ZXY"))
+                (val * w).sum().backward()
+                res.append((val.detach().cpu().numpy(), r.grad.cpu().numpy(), x.grad.cpu().numpy()))
+            (v1, gr1, gx1), (v0, gr0, gx0) = res
+            assert v1.shape == (B,) and np.abs(v1 - v0).max() < 2e-6, (v1, v0)
+            assert rel_err(gr1, gr0) < 2e-4 and rel_err(gx1, gx0) < 2e-4, (rel_err(gr1, gr0), rel_err(gx1, gx0))
+            v_base = v0 if v_base is None else v_base
+        if device != "cpu":  # (the host emulation does not touch the workspace)
+            torch.cuda.synchronize()
+            assert float(ops.siddon_ncc_workspace(B, device).abs().max()) == 0.0
+        # nothing to differentiate: the composition (forward-only kernel), same values
+        with torch.no_grad():
+            v = drr.ncc(base, rot0, xyz0)
+        assert v.shape == (B,) and np.abs(v.cpu().numpy() - v_base).max() < 2e-6

@@ -393,6 +393,13 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     std::vector<unsigned short> qbrick((size_t)qsx * 32 / 2);
     const int N = det_h * det_w;
     const long plane = (long)B * N;
+    // (out may be NULL with aux: the record alone)
+    std::vector<float> out_scratch;
+    if (!out) {
+        if (!aux) return -1;
+        out_scratch.resize((size_t)B * N);
+        out = out_scratch.data();
+    }
     memset(out, 0, sizeof(float) * (size_t)B * N);
     // packed fixed-point record (record_pack.h): planes 5 (A per ray) and 6 (q) first
     const bool packed = aux && record_vmax > 0.f;
@@ -1400,6 +1407,43 @@ int ddrr_pose_euler_backward(const float *rot, const float *xyz, int a0, int a1,
         pose_euler_backward(rot + b * 3, xyz + b * 3, axes, reorient34, gMw + b * 12, g_rot + b * 3,
                             g_xyz + b * 3);
     return 0;
+}
+
+// ---- the fused registration step (csrc/pose_ncc.hip): on the host simply the entries it fuses,
+// one after the other (the workspace stays untouched: zero in, zero out)
+long ddrr_siddon_ncc_workspace_bytes(int B) { return B < 1 ? 0 : (long)B * (5 * 8 + 12 * 4 + 2 * 4); }
+
+int ddrr_pose_raygen_forward(const float *rot, const float *xyz, int a0, int a1, int a2,
+                             const float *reorient34, const float *Ainv, const float *P, int B, int N,
+                             float *Mw, float *source_v, float *target_v, float *img, void *st) {
+    if (int rc = ddrr_pose_euler_forward(rot, xyz, a0, a1, a2, reorient34, B, Mw, st)) return rc;
+    return ddrr_raygen_forward(Mw, Ainv, P, B, N, source_v, target_v, img, st);
+}
+
+int ddrr_siddon_ncc_forward(const float *aux, const float *img, const float *x1, long x1_stride, int B,
+                            int N, float eps, void *, float *ncc, float *stats, float *out, void *st) {
+    std::vector<float> x2((size_t)B * N);
+    for (long r = 0; r < (long)B * N; ++r) x2[r] = img[r] * aux[rec_index(r, 0)];
+    if (out) memcpy(out, x2.data(), sizeof(float) * x2.size());
+    return ddrr_ncc_forward(x1, x1_stride, x2.data(), B, N, eps, ncc, stats, st);
+}
+
+int ddrr_siddon_ncc_backward_pose(const float *aux, const float *img, const float *x1, long x1_stride,
+                                  const float *stats, const float *g_out, int g_stride,
+                                  const float *source_v, const float *target_v, const float *Mw,
+                                  const float *Ainv, const float *P, const float *rot, const float *xyz,
+                                  int a0, int a1, int a2, const float *reorient34, int B, int N,
+                                  float eps, int with_img_path, void *, float *g_rot, float *g_xyz,
+                                  void *st) {
+    std::vector<float> x2((size_t)B * N), g_x2((size_t)B * N), gMw((size_t)B * 12);
+    for (long r = 0; r < (long)B * N; ++r) x2[r] = img[r] * aux[rec_index(r, 0)];
+    if (int rc = ddrr_ncc_backward(x1, x1_stride, x2.data(), stats, g_out, g_stride, B, N, nullptr,
+                                   g_x2.data(), st))
+        return rc;
+    if (int rc = ddrr_siddon_backward_pose(aux, DDRR_AUX_BLOCKED, g_x2.data(), source_v, target_v, img, Mw,
+                                           Ainv, P, B, N, eps, with_img_path, gMw.data(), st))
+        return rc;
+    return ddrr_pose_euler_backward(rot, xyz, a0, a1, a2, reorient34, gMw.data(), B, g_rot, g_xyz, st);
 }
 
 // ---- double precision (csrc/f64_rays.hip): the same per-ray cores, host loops

@@ -237,8 +237,9 @@ def test_config3_trilinear_bricks_vs_oracle_512(gpu):
     assert rel_err(img.detach().cpu().numpy().reshape(1, 1, N), ref32["out"]) < FWD_TOL
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("stop", [False, True])
-def test_config4_registration_trajectory_on_gpu(gpu, stop):
+def test_config4_registration_trajectory_on_gpu(gpu, stop, fused):
     """The first SGD steps of the tutorial's registration loop (reference
     registration.py:14-50, registration.ipynb:240-316) replayed on the HIP kernels: same
     losses and parameter trajectory as the unmodified reference (tests/golden)."""
@@ -262,7 +263,8 @@ def test_config4_registration_trajectory_on_gpu(gpu, stop):
     losses = []
     for k in range(len(g[f"losses_{tag}"])):
         opt.zero_grad()
-        loss = crit(gt, reg()).mean()
+        # (fused: the step around the renderer as three launches, DRR.ncc)
+        loss = (drr.ncc(gt, reg._rotation, reg._translation) if fused else crit(gt, reg())).mean()
         loss.backward()
         losses.append(loss.item())
         if k <= 4:
@@ -314,6 +316,7 @@ def test_graphed_registration_iteration_equals_eager_loop(gpu):
         eager.append(loss.item())
     reg_g, opt_g = make()
     step = GraphedIteration(reg_g, crit, opt_g, gt, warmup=3)
+    assert step.fused_similarity  # (NCC of Euler poses: the iteration goes through DRR.ncc)
     # construction (3 eager warm-up iterations + the capture) leaves parameters and optimizer state
     # as they were: replay k is iteration k of the loop
     assert torch.equal(reg_g._rotation.detach(), r0) and torch.equal(reg_g._translation.detach(), x0)

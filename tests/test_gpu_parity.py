@@ -1127,3 +1127,9 @@ def test_filter_intersections_outside_volume(gpu):
     """the flag the reference itself cannot run (TypeError,
     renderers.py:118 vs :124), against the fixture of its intended semantics."""
     conftest.check_filter_intersections_outside_volume(gpu)
+
+
+def test_fused_ncc_step(gpu):
+    """ddrr_pose_raygen_forward / ddrr_siddon_ncc_forward / ddrr_siddon_ncc_backward_pose through
+    DRR.ncc against the launches they fuse."""
+    conftest.check_fused_ncc_step(gpu)

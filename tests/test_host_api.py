@@ -1034,3 +1034,9 @@ def test_filter_intersections_outside_volume_on_the_host(emulated_ops):
 
 def test_channel_backward_on_bricks_smooth_volume_on_the_host(emulated_ops):
     conftest.check_channel_backward_on_bricks_smooth(emulated_ops, "cpu")
+
+
+def test_fused_ncc_step_on_the_host(emulated_ops):
+    """DRR.ncc through the host build of the entries it fuses (tests/emu): the Python / autograd
+    wiring; the GPU twin checks the kernels (tests/test_gpu_parity.py)."""
+    conftest.check_fused_ncc_step("cpu")
