@@ -455,6 +455,8 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
     if cfg in ("headline", "2"):
         subject = make_subject(noise_volume(D, seed=0), spacing=(1.0, 1.0, 1.0), orientation="AP")
         drr = set_storage(DRR(subject, sdd=1020.0, height=H, delx=delx, renderer="siddon").to(device))
+        if args.fused_max_poses is not None:
+            drr.FUSED_NCC_MAX_POSES = args.fused_max_poses
         rot0, xyz0 = perturbed_poses(B, seed=2 + rank, device=device)
         with torch.no_grad():
             base = drr(torch.zeros(1, 3, device=device), torch.tensor([[0.0, 850.0, 0.0]], device=device),
@@ -608,9 +610,12 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
         assert torch.isfinite(rot.grad).all() and torch.isfinite(xyz.grad).all()
         with torch.no_grad():  # (the fused step writes no image: the same poses, rendered once more)
             images = drr(rot0, xyz0, parameterization="euler_angles", convention="ZXY")
-        extra["step"] = ("unfused: DRR.forward + NormalizedCrossCorrelation2d through autograd" if args.unfused
-                         else "DRR.ncc: ddrr_pose_raygen_forward, the brick kernel with its record, "
-                              "ddrr_siddon_ncc_forward; backward: ddrr_siddon_ncc_backward_pose")
+        fused_used = not args.unfused and B <= drr.FUSED_NCC_MAX_POSES
+        extra["step"] = ("DRR.ncc, fused (at most %d poses per call): ddrr_pose_raygen_forward, the brick kernel "
+                         "with its record, ddrr_siddon_ncc_forward; backward: ddrr_siddon_ncc_backward_pose"
+                         % drr.FUSED_NCC_MAX_POSES if fused_used else
+                         "DRR.forward + NormalizedCrossCorrelation2d through autograd (what DRR.ncc composes "
+                         "for more than %d poses per call)" % drr.FUSED_NCC_MAX_POSES)
     if cfg == "4":
         extra["registration"].update(
             ncc_after=float(last.item()), iterations=warmup + steps,
@@ -995,7 +1000,16 @@ def ct_config(rt, poses=(1, 8, 32), det=200):
                        "reference's example geometry (README.md:67-87)",
            "volume": {"shape": list(dims), "zero_fraction": float((density == 0).float().mean()),
                       "max": float(density.max()), "soft_tissue": float(density[256, 256, 66])},
-           "kernel": name, "poses": {}}
+           "kernel": name, "poses": {},
+           "frac_is": "algorithmic bytes (4 B per voxel a ray crosses, air included, + 20 B per ray) per launch / "
+                      "kernel time / 8 TB/s: a WORK RATE, not a distance to the HBM wall -- two thirds of this "
+                      "volume is exact-zero air, whose bricks are skipped, so the figure can exceed 1"}
+    from diffdrr_amd.renderers import _brick_storage
+    out["module_default_storage"] = {
+        "storage": _brick_storage(V, {"storage": drr.renderer.brick_storage}),
+        "why": "Siddon.brick_storage = \"q16p\" applies to volumes with >= 4 double bricks per CU; this shape has "
+               "768 (3 per CU), so the module renders it from 32^3 fp32 bricks (`forward_f32` / "
+               "`forward_record_f32` below are what a DRR of this volume runs)"}
 
     def timed(fn, n_prime, n_timed):
         for _ in range(n_prime):
@@ -1091,6 +1105,8 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="headline / config 2: the step as DRR.forward + the NCC module through autograd "
                          "(nine small launches around the brick kernel) instead of DRR.ncc (three)")
+    ap.add_argument("--fused-max-poses", type=int, default=None,
+                    help="DRR.FUSED_NCC_MAX_POSES for this run (measurement: where the fused step stops paying)")
     ap.add_argument("--packed-record", action="store_true",
                     help="Siddon.packed_record = True (the opt-in fixed-point backward record)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void pose_euler_bwd_kernel(
 // The workspace (moments, dL/dMw accumulators, tickets) is caller-owned, zero when it is first
 // handed over, and left zero by every call: no fills.  Reference: diffdrr/pose.py:140-190,
 // detector.py:144-154, drr.py:201-205, metrics.py:21-44 and their autograd.
-constexpr int kNccRaysPerBlock = 4096;
+constexpr int kStepRaysPerBlock = 1024;  // rays of one pose per workgroup of the two epilogues
 
 struct NccWs {
     double *mom;   // [B][5]  sum x1, x2, x1^2, x2^2, x1 x2
@@ -176,28 +176,53 @@ __host__ __device__ inline NccWs ncc_ws(void *ws, int B) {
     return w;
 }
 
+// The last workgroup of a pose (a ticket).  No agent-scope fence: on this part it writes the
+// XCD's whole L2 back, per wave that executes it -- tens of microseconds with the record just
+// written (measured: the first form of these kernels, with __threadfence(), ran 2x the launches it
+// fuses).  What has to be ordered are atomics only: every accumulator update is a device-scope
+// atomic, performed at the coherence point; the wave that issued them waits for their completion
+// (a workgroup-scope release = s_waitcnt) before the workgroup takes its ticket, and the last
+// workgroup reads the accumulators with atomics again.
+__device__ __forceinline__ bool last_workgroup_of_pose(int *ticket, int *shared_flag) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's atomics have completed
+    __syncthreads();
+    if (threadIdx.x == 0) *shared_flag = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    return *shared_flag != 0;
+}
+
 __global__ __launch_bounds__(kBlock) void pose_raygen_fwd_kernel(
     const float *__restrict__ rot, const float *__restrict__ xyz, int a0, int a1, int a2,
     const float *__restrict__ Ro, const float *__restrict__ Ainv, const float *__restrict__ P, int N,
     float *__restrict__ Mw, float *__restrict__ source_v, float *__restrict__ target_v,
     float *__restrict__ img) {
+    __shared__ float Ms[12];
     const int b = blockIdx.y, n = blockIdx.x * kBlock + threadIdx.x;
-    const float th[3] = {rot[b * 3], rot[b * 3 + 1], rot[b * 3 + 2]};
-    const float t[3] = {xyz[b * 3], xyz[b * 3 + 1], xyz[b * 3 + 2]};
-    const int axes[3] = {a0, a1, a2};
-    float M[12];
-    pose_euler_forward(th, t, axes, Ro, M);
-    if (n == 0) {
+    if (threadIdx.x == 0) {
+        // (once per workgroup: three sincos and a few dozen fma)
+        const float th[3] = {rot[b * 3], rot[b * 3 + 1], rot[b * 3 + 2]};
+        const float t[3] = {xyz[b * 3], xyz[b * 3 + 1], xyz[b * 3 + 2]};
+        const int axes[3] = {a0, a1, a2};
+        float M[12];
+        pose_euler_forward(th, t, axes, Ro, M);
 #pragma unroll
-        for (int k = 0; k < 12; ++k) Mw[b * 12 + k] = M[k];
-        const float sw[3] = {M[3], M[7], M[11]};
-        float sv[3];
-        apply34(Ainv, sw, sv);
-        source_v[b * 3 + 0] = sv[0];
-        source_v[b * 3 + 1] = sv[1];
-        source_v[b * 3 + 2] = sv[2];
+        for (int k = 0; k < 12; ++k) Ms[k] = M[k];
+        if (blockIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) Mw[b * 12 + k] = M[k];
+            const float sw[3] = {M[3], M[7], M[11]};
+            float sv[3];
+            apply34(Ainv, sw, sv);
+            source_v[b * 3 + 0] = sv[0];
+            source_v[b * 3 + 1] = sv[1];
+            source_v[b * 3 + 2] = sv[2];
+        }
     }
+    __syncthreads();
     if (n >= N) return;
+    float M[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) M[k] = Ms[k];
     const float Pn[3] = {P[n * 3], P[n * 3 + 1], P[n * 3 + 2]};
     const RayGenOut o = raygen_ray(M, Ainv, Pn);
     const long r = (long)b * N + n;
@@ -216,17 +241,40 @@ __global__ __launch_bounds__(kBlock) void siddon_ncc_fwd_kernel(
     const NccWs ws = ncc_ws(ws_raw, B);
     const int b = blockIdx.y;
     double m[5] = {0., 0., 0., 0., 0.};
-    const int n_end = min(N, (int)(blockIdx.x + 1) * kNccRaysPerBlock);
-    for (int n = blockIdx.x * kNccRaysPerBlock + threadIdx.x; n < n_end; n += kBlock) {
-        const long r = (long)b * N + n;
-        const float x2 = img[r] * aux[rec_index(r, 0)];  // (= siddon_out_from_record_kernel)
-        if (out) out[r] = x2;
-        const double da = (double)x1[b * x1_stride + n], dc = (double)x2;
+    auto take = [&](float a, float c) {
+        const double da = (double)a, dc = (double)c;
         m[0] += da;
         m[1] += dc;
         m[2] = fma(da, da, m[2]);
         m[3] = fma(dc, dc, m[3]);
         m[4] = fma(da, dc, m[4]);
+    };
+    const float *p1 = x1 + b * x1_stride, *pl = img + (long)b * N;
+    const long r0 = (long)b * N;
+    const int n0 = blockIdx.x * kStepRaysPerBlock, n_end = min(N, n0 + kStepRaysPerBlock);
+    // four consecutive rays per thread: plane I of rays 4 k .. 4 k + 3 is one aligned 16-byte run of
+    // the blocked record (record_layout.h), like the rays' lengths and the fixed image's pixels
+    const bool vec = (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(pl) |
+                                       reinterpret_cast<uintptr_t>(aux)) & 15) == 0 &&
+                     (!out || (reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    if (vec) {
+        for (int n = n0 + 4 * threadIdx.x; n < n_end; n += 4 * kBlock) {
+            const float4 I4 = *reinterpret_cast<const float4 *>(aux + rec_index(r0 + n, 0));
+            const float4 L4 = *reinterpret_cast<const float4 *>(pl + n);
+            const float4 a4 = *reinterpret_cast<const float4 *>(p1 + n);
+            const float4 x4 = make_float4(L4.x * I4.x, L4.y * I4.y, L4.z * I4.z, L4.w * I4.w);
+            if (out) *reinterpret_cast<float4 *>(out + r0 + n) = x4;
+            take(a4.x, x4.x);
+            take(a4.y, x4.y);
+            take(a4.z, x4.z);
+            take(a4.w, x4.w);
+        }
+    } else {
+        for (int n = n0 + threadIdx.x; n < n_end; n += kBlock) {
+            const float x2 = pl[n] * aux[rec_index(r0 + n, 0)];  // (= siddon_out_from_record_kernel)
+            if (out) out[r0 + n] = x2;
+            take(p1[n], x2);
+        }
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -242,12 +290,7 @@ __global__ __launch_bounds__(kBlock) void siddon_ncc_fwd_kernel(
         for (int w = 0; w < kWavesPerBlock; ++w) v += red[threadIdx.x][w];
         atomicAdd(ws.mom + b * 5 + threadIdx.x, v);
     }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(ws.tick1 + b, 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (!last || threadIdx.x != 0) return;
-    __threadfence();
+    if (!last_workgroup_of_pose(ws.tick1 + b, &last) || threadIdx.x != 0) return;
     double t[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -289,8 +332,8 @@ __global__ __launch_bounds__(kBlock) void siddon_ncc_bwd_pose_kernel(
     float acc[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.f;
-    const int n_end = min(N, (int)(blockIdx.x + 1) * kPoseRaysPerBlock);
-    for (int n = blockIdx.x * kPoseRaysPerBlock + threadIdx.x; n < n_end; n += kBlock) {
+    const int n_end = min(N, (int)(blockIdx.x + 1) * kStepRaysPerBlock);
+    for (int n = blockIdx.x * kStepRaysPerBlock + threadIdx.x; n < n_end; n += kBlock) {
         const long r = (long)b * N + n;
         float rec[SIDDON_AUX];
         rec_blocked_load(aux, r, rec);
@@ -321,12 +364,7 @@ __global__ __launch_bounds__(kBlock) void siddon_ncc_bwd_pose_kernel(
         for (int w = 0; w < kWavesPerBlock; ++w) v += red[w][threadIdx.x];
         unsafeAtomicAdd(ws.gacc + (long)b * 12 + threadIdx.x, v);
     }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(ws.tick2 + b, 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (!last || threadIdx.x != 0) return;
-    __threadfence();
+    if (!last_workgroup_of_pose(ws.tick2 + b, &last) || threadIdx.x != 0) return;
     // the last workgroup of the pose: dLoss/dMw -> dLoss/d(rot, xyz) (= pose_euler_bwd_kernel)
     float g[12], gth[3], gx[3];
 #pragma unroll
@@ -568,7 +606,7 @@ int ddrr_siddon_ncc_forward(const float *aux, const float *img, const float *x1,
     if (B < 0 || N < 1) return fail(-1, "bad batch / image size");
     if (B == 0) return 0;
     if (B > 65535) return fail(-1, "at most 65535 pairs per call");
-    const dim3 grid((N + kNccRaysPerBlock - 1) / kNccRaysPerBlock, B), block(kBlock);
+    const dim3 grid((N + kStepRaysPerBlock - 1) / kStepRaysPerBlock, B), block(kBlock);
     hipLaunchKernelGGL(siddon_ncc_fwd_kernel, grid, block, 0, (hipStream_t)stream, aux, img, x1,
                        x1_stride, B, N, eps, ws, ncc, stats, out);
     return finish("ddrr_siddon_ncc_forward");
@@ -590,7 +628,7 @@ int ddrr_siddon_ncc_backward_pose(const float *aux, const float *img, const floa
     if (B < 0 || N < 1) return fail(-1, "bad batch / image size");
     if (B == 0) return 0;
     if (B > 65535) return fail(-1, "at most 65535 poses per call");
-    const dim3 grid((N + kPoseRaysPerBlock - 1) / kPoseRaysPerBlock, B), block(kBlock);
+    const dim3 grid((N + kStepRaysPerBlock - 1) / kStepRaysPerBlock, B), block(kBlock);
     hipLaunchKernelGGL(siddon_ncc_bwd_pose_kernel, grid, block, 0, (hipStream_t)stream, aux, img, x1,
                        x1_stride, stats, g_out, g_stride, source_v, target_v, Mw, Ainv, P, rot, xyz,
                        a0, a1, a2, reorient34, B, N, eps, with_img_path, ws, g_rot, g_xyz);

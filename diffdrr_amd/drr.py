@@ -200,6 +200,8 @@ class DRR(nn.Module):
         finally:
             self.renderer.trust_detector_shape = False
 
+    FUSED_NCC_MAX_POSES = 16
+
     def ncc(self, fixed: torch.Tensor, rot: torch.Tensor, xyz: torch.Tensor, *,
             convention: str = "ZXY", degrees: bool = False, eps: float = 1e-5) -> torch.Tensor:
         """Per-pose normalised cross-correlation of ``fixed`` ((1 | B), 1, H, W) with the DRRs at the
@@ -210,7 +212,8 @@ class DRR(nn.Module):
         When the pose parameters require a gradient and the render takes the brick kernel, the
         whole step runs as three fused launches around it instead of nine (pose -> matrix -> rays;
         image from the backward record + NCC; NCC backward -> ray gradients -> matrix -> pose
-        parameters: ``renderers._EulerSiddonNccFn``): 9-14 % of a one-pose registration iteration.
+        parameters: ``renderers._EulerSiddonNccFn``): 13 % of a one-pose registration iteration
+        (0.246 -> 0.213 ms; up to ``FUSED_NCC_MAX_POSES`` poses).
         Anything else (no gradient wanted: the forward-only kernel is the faster one; other
         renderers, subsampling, patches, a volume that requires a gradient) composes the same
         result from ``forward`` and the NCC module."""
@@ -220,7 +223,12 @@ class DRR(nn.Module):
 
         B = rot.shape[0]
         r, det = self.renderer, self.detector
+        # (at most FUSED_NCC_MAX_POSES poses: beyond, the launches around the brick kernel are bound
+        # by their bytes, not by their count, and the fused ones -- a reduction tail per 1024 rays --
+        # are no faster: 16 poses 0.821 against 0.875 ms per eager step, 32 poses 1.480 against
+        # 1.463, profiles/r05/fused_step.txt)
         ok = (torch.is_grad_enabled() and (rot.requires_grad or xyz.requires_grad)
+              and B <= self.FUSED_NCC_MAX_POSES
               and self._fused_ok(False, {}, None) and isinstance(r, Siddon)
               and r.grid_path == "bricks" and not r.packed_record and not self.density.requires_grad
               and all(torch.is_tensor(a) and a.dim() == 2 and a.shape == (B, 3)

@@ -104,14 +104,19 @@ class GraphedIteration:
                  and hasattr(reg.drr, "ncc") and fused_similarity)
         self.fused_similarity = bool(fused)
 
+        # (two launches an iteration does not need: the sum of ONE value, and the ones autograd
+        # fills in as the gradient of a scalar loss -- handed over ready-made)
+        one = torch.ones((), dtype=reg._rotation.dtype, device=reg._rotation.device)
+
         def iteration():
             optimizer.zero_grad(set_to_none=True)
             if fused:
-                loss = reg.drr.ncc(target, reg._rotation, reg._translation, convention=reg.convention,
-                                   eps=criterion.eps).sum()
+                values = reg.drr.ncc(target, reg._rotation, reg._translation, convention=reg.convention,
+                                     eps=criterion.eps)
             else:
-                loss = criterion(target, reg(**render_kwargs)).sum()
-            loss.backward()
+                values = criterion(target, reg(**render_kwargs))
+            loss = values.reshape(()) if values.numel() == 1 else values.sum()
+            loss.backward(gradient=one)
             optimizer.step()
             return loss.detach()
 

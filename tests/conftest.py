@@ -653,7 +653,9 @@ def check_filter_intersections_outside_volume(device):
         res[flag] = [out.detach().cpu().numpy()] + [x.cpu().numpy() for x in grads]
     names = ("out", "g_source", "g_target", "g_img", "g_volume")
     for k, a, b in zip(names, res[True], res[False]):
-        assert np.array_equal(a, b), k  # the flag changes nothing in the product
+        # the flag changes nothing in the product (bit for bit, but for the volume gradient's fp32
+        # atomics on the device, whose order differs from launch to launch)
+        assert np.array_equal(a, b) or (k == "g_volume" and rel_err(a, b) < 1e-6), k
         assert a.shape == g[f"filtered_{k}_f32"].shape
         tol = 1e-4 if k == "out" else 1e-3
         assert rel_err(a, g[f"filtered_{k}_f64"]) < tol, k

@@ -35,3 +35,22 @@ mkdir -p gpurun_out/r05j; timeout 600 python tools/brick_bench.py --size 256 --v
 
 # ---------------------------------------------------------------- 2026-09-27T00:55:57Z  forward + record with the record computed but not delivered (bound for delivery through LDS)
 mkdir -p gpurun_out/r05k; timeout 600 python tools/brick_bench.py --variants=-2 --storage q16p --order weight --cases pert32aux,pert8aux,pert1aux --dbg 0,131072 2>&1 | grep -v amdgpu.ids | cut -c1-230 > gpurun_out/r05k/no_delivery.txt; cat gpurun_out/r05k/no_delivery.txt
+
+# ---------------------------------------------------------------- 2026-09-27T01:04:57Z  fused registration step: GPU tests (all), bench headline fused vs unfused, config 4, config 2
+mkdir -p gpurun_out/r05l; timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/r05l/gpu_tests.txt; tail -4 gpurun_out/r05l/gpu_tests.txt; for f in "" "--unfused"; do timeout 300 python bench.py --no-configs --no-cpu-baseline $f > gpurun_out/r05l/bench_headline$f.json 2> gpurun_out/r05l/h$f.err; grep "config headline:" gpurun_out/r05l/h$f.err | cut -c1-150; done; timeout 300 python bench.py --config 4 --no-cpu-baseline > gpurun_out/r05l/bench_config_4.json 2> gpurun_out/r05l/c4.err; grep "config 4:" gpurun_out/r05l/c4.err | cut -c1-150; for f in "" "--unfused"; do timeout 300 python bench.py --config 2 --no-cpu-baseline $f > gpurun_out/r05l/bench_config_2$f.json 2> gpurun_out/r05l/c2$f.err; grep "config 2:" gpurun_out/r05l/c2$f.err | cut -c1-150; done; python -c "
+import json
+for n in (\"bench_headline\",\"bench_headline--unfused\",\"bench_config_4\",\"bench_config_2\",\"bench_config_2--unfused\"):
+    d=json.load(open(\"gpurun_out/r05l/\"+n+\".json\")); print(n, round(d[\"value\"],1), round(d[\"ms_per_step\"],4), round(d[\"roofline\"][\"kernel_ms\"],4), [(k[\"kernel\"][5:], round(k[\"kernel_ms\"]*1e3,1)) for k in d[\"roofline\"][\"kernels\"][1:]])"
+
+# ---------------------------------------------------------------- 2026-09-27T01:07:04Z  a5 GPU test failure details
+timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -k filter_intersections 2>&1 | grep -E "assert|Error|rel_err" | head -20
+
+# ---------------------------------------------------------------- 2026-09-27T01:09:34Z  fused step v2 (no agent fences, 1024 rays per workgroup, matrix via LDS): tests + bench fused vs unfused
+mkdir -p gpurun_out/r05m; timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r05m/gpu_tests.txt; tail -3 gpurun_out/r05m/gpu_tests.txt; for f in "" "--unfused"; do timeout 300 python bench.py --no-configs --no-cpu-baseline $f > gpurun_out/r05m/bench_headline$f.json 2> gpurun_out/r05m/h$f.err; done; timeout 300 python bench.py --config 4 --no-cpu-baseline > gpurun_out/r05m/bench_config_4.json 2> gpurun_out/r05m/c4.err; for f in "" "--unfused"; do timeout 300 python bench.py --config 2 --no-cpu-baseline $f > gpurun_out/r05m/bench_config_2$f.json 2> gpurun_out/r05m/c2$f.err; done; python -c "
+import json
+for n in (\"bench_headline\",\"bench_headline--unfused\",\"bench_config_4\",\"bench_config_2\",\"bench_config_2--unfused\"):
+    d=json.load(open(\"gpurun_out/r05m/\"+n+\".json\")); print(n, round(d[\"value\"],1), round(d[\"ms_per_step\"],4), round(d[\"roofline\"][\"kernel_ms\"],4), [(k[\"kernel\"][5:], round(k[\"kernel_ms\"]*1e3,1)) for k in d[\"roofline\"][\"kernels\"][1:]])"
+
+# ---------------------------------------------------------------- 2026-09-27T01:12:59Z  fused vs unfused step by poses per call (bench --batch B)
+mkdir -p gpurun_out/r05n; for B in 1 2 4 8 16; do for f in "--fused-max-poses 64" "--unfused"; do timeout 200 python bench.py --no-configs --no-cpu-baseline --batch $B --steps 300 $f 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(\"B\", d[\"config\"][\"batch_per_gpu\"], \"\", \"ms_per_step %.4f\" % d[\"ms_per_step\"], \"kernel %.4f\" % d[\"roofline\"][\"kernel_ms\"], [(k[\"kernel\"][5:], round(k[\"kernel_ms\"]*1e3,1)) for k in d[\"roofline\"][\"kernels\"][1:]])"; done; done 2>&1 | tee gpurun_out/r05n/fused_by_batch.txt
