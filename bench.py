@@ -790,6 +790,9 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
                    "achieved": alg_bytes / (f_ms * 1e-3) / 1e9,
                    "frac": alg_bytes / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "target_frac": 0.70}
+        tr = traffic_record("forward") if at_headline_size and cfg == "headline" and f_poses == 32 else None
+        if tr:
+            forward["traffic"], forward["traffic_source"] = tr
         if at_headline_size and cfg in ("headline", "5") and f_poses in (32, 512):
             ib = issue_bound_record("forward" if f_poses == 32 else "forward_sweep", f_ms, nv_total)
             if ib:
@@ -806,6 +809,9 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
                        "algorithmic_bytes_per_launch": alg_bytes,
                        "achieved": alg_bytes / (f32_ms * 1e-3) / 1e9,
                        "frac": alg_bytes / (f32_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "target_frac": 0.70}
+        tr = traffic_record("forward_f32") if at_headline_size else None
+        if tr:
+            forward_f32["traffic"], forward_f32["traffic_source"] = tr
         log(f"[bench] config {cfg} forward only, fp32 bricks: {f32_ms:.3f} ms = "
             f"{forward_f32['frac'] * 100:.1f} % of the 8 TB/s roofline")
     log(f"[bench] config {cfg}: step {ms_per_step:.3f} ms | {k_name} {k_ms:.3f} ms per launch, "

@@ -28,7 +28,10 @@ traffic = {"_comment": "HBM traffic per launch of the brick kernels on bench.py'
            "from separate rocprofv3 --pmc passes of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline "
            "--no-configs` (tools/prof_bench.sh).  bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE counts "
            "half of wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM section)."}
-for key, pat in (("forward_record", "siddon_fwd_brick_kernel<true"), ("forward", "siddon_fwd_brick_kernel<false")):
+# (the bench line's forward_f32 leg runs the 32^3 fp32 configuration of the same kernel template)
+for key, pat in (("forward_record", "siddon_fwd_brick_kernel<true, (anonymous namespace)::FwdCfg<32, 32, 64"),
+                 ("forward", "siddon_fwd_brick_kernel<false, (anonymous namespace)::FwdCfg<32, 32, 64"),
+                 ("forward_f32", "siddon_fwd_brick_kernel<false, (anonymous namespace)::FwdCfg<32, 32, 32")):
     for k, d in cnt.items():
         if pat in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             f, w = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]), sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
