@@ -38,6 +38,8 @@ Rank 0 prints ONE JSON line on stdout: the driver's contract plus
                   on a CT-like 512 x 512 x 133 volume after transform_hu_to_density -- forward and
                   forward + record at 1 / 8 / 32 poses on the guarded 16-bit bricks and on fp32
                   bricks, the bricks the guard sent to the fp32 path, parity against the oracle;
+                  "few_poses": the brick kernel at the headline size with 1 / 2 / 8 poses per launch on
+                  the noise volume and on the phantom;
                   "sweep": config 5's figure -- with --gpus N the strong-scaling point (4096 poses
                   over the ranks) next to the weak-scaling headline,
   "cpu_baseline": the CPU oracle (a port of the reference's algorithm, OpenMP) on a bounded
@@ -185,7 +187,7 @@ class OracleChain:
         return r64.grad.numpy().ravel(), x64.grad.numpy().ravel(), o["out"].reshape(-1)
 
 
-def cpu_baseline_and_parity(drr, rot, xyz, images, g_rot, g_xyz, base, det, budget_s=12.0, n_parity=2):
+def cpu_baseline_and_parity(drr, rot, xyz, images, g_rot, g_xyz, base, det, budget_s=12.0, n_parity=4):
     """Oracle (C port of the reference algorithm, OpenMP over rays) forward + analytic backward
     on a bounded sample of the step's poses: the timing is `cpu_baseline`.  `parity`: the images
     the timed step produced and the pose gradients its backward left in rot.grad / xyz.grad,
@@ -1072,6 +1074,63 @@ def ct_config(rt, poses=(1, 8, 32), det=200):
     return out
 
 
+def few_poses_config(rt, poses=(1, 2, 8), det=256, D=512):
+    """`configs.few_poses`: kernel-only timings of ddrr_siddon_forward_bricks at the headline size with
+    1 / 2 / 8 poses per launch -- what a registration step or a small sweep launches -- on the bench's
+    noise volume (every brick quantised) and on the phantom (a third of its bricks on the fp32 path),
+    default storage; forward and forward + record.  A launch of one pose is ~71 % per-brick fixed
+    cost (profiles/r05/one_pose_stage_stamps.txt)."""
+    from diffdrr_amd import DRR, ops
+    from diffdrr_amd.data import make_subject, noise_volume, phantom_volume
+
+    device, timer = rt.device, rt.timer
+    name = "ddrr_siddon_forward_bricks"
+    out = {"kernel": name, "detector": f"{det}x{det}", "storage": "q16p",
+           "frac_is": "algorithmic bytes per launch / kernel time / 8 TB/s: a work rate (see roofline.frac_is)"}
+
+    def timed(fn, n_prime, n_timed):
+        for _ in range(n_prime):
+            fn()
+        before = len(timer.events.get(name, []))
+        timer.enabled, timer.only = True, name
+        for _ in range(n_timed):
+            fn()
+        torch.cuda.synchronize()
+        timer.enabled, timer.only = False, None
+        ev = timer.events[name][before:]
+        ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        del timer.events[name][before:]
+        return ms
+
+    with torch.no_grad():
+        for kind, vol in (("noise", noise_volume(D, seed=0)), ("phantom", phantom_volume(D, seed=0))):
+            drr = DRR(make_subject(vol, spacing=(1.0, 1.0, 1.0), orientation="AP"), sdd=1020.0, height=det,
+                      delx=2.4 * (256 / det) * (D / 512), renderer="siddon").to(device)
+            V = drr.density
+            ent = {}
+            for B in poses:
+                rot, xyz = perturbed_poses(B, seed=2, device=device)
+                s, t, L = voxel_rays(drr, rot, xyz)
+                _, _, nvox = ops.siddon_forward(V, s, t, L, count_voxels=True, det=(det, det))
+                alg = 4 * int(nvox.sum().item()) + B * det * det * 20 + 12 * B
+                e = {"algorithmic_bytes_per_launch": alg}
+                for key, aux in (("forward", False), ("forward_record", True)):
+                    ms = timed(lambda: ops.siddon_forward_bricks(V, s, t, L, (det, det), want_aux=aux,
+                                                                 storage="q16p"), 60, 40)
+                    e[key] = {"kernel_ms": ms, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "drrs_per_s": B / (ms * 1e-3)}
+                ent[str(B)] = e
+            fb = ops.brick_fallbacks(V, "q16p")
+            if fb is not None:
+                ent["brick_storage_fallbacks"], ent["bricks"] = fb
+            out[kind] = ent
+            log(f"[bench] few poses, {kind}: " + ", ".join(
+                f"{B}: {ent[str(B)]['forward']['kernel_ms']:.3f} / {ent[str(B)]['forward_record']['kernel_ms']:.3f} ms"
+                for B in poses) + " (forward / forward + record)")
+            del drr, V
+    return out
+
+
 def summary_of(res):
     """What the default line keeps of a short config run."""
     rf = res["roofline"]
@@ -1156,6 +1215,9 @@ def main():
             t0 = time.perf_counter()
             configs["ct"] = ct_config(rt)
             configs["ct"]["wall_s"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            configs["few_poses"] = few_poses_config(rt)
+            configs["few_poses"]["wall_s"] = time.perf_counter() - t0
         if rt.rank == 0:
             c5 = configs["5"]
             result["sweep"] = {"metric": c5["metric"], "value": c5["value"], "unit": c5["unit"],
