@@ -149,6 +149,23 @@ def test_argument_checks_return_errors_without_touching_a_device():
     assert c.ddrr_siddon_forward(P, 4, 4, 4, P, 1, P, P, 0, 5, f(0.5), f(1e-8), 0, 0, 0, 0, 0, 1, 64,
                                  P, None, None, None) == 0
     assert c.ddrr_pose_euler_forward(P, P, 0, 0, 1, P, 1, P, None) != 0  # repeated axis
+    # the fused registration step (ABI 29): the same checks as the entries it fuses
+    L = ctypes.c_long
+    assert c.ddrr_siddon_ncc_workspace_bytes(3) == 3 * 96 and c.ddrr_siddon_ncc_workspace_bytes(0) == 0
+    assert c.ddrr_pose_raygen_forward(P, P, 2, 2, 1, P, P, P, 1, 4, P, P, P, P, None) != 0
+    assert b"Euler" in c.ddrr_last_error()
+    assert c.ddrr_siddon_ncc_forward(P, P, P, L(3), 1, 4, f(1e-5), P, P, P, None, None) != 0
+    assert b"x1_stride" in c.ddrr_last_error()
+    assert c.ddrr_siddon_ncc_forward(P, P, P, L(0), 1, 4, f(1e-5), None, P, P, None, None) != 0
+    assert b"null" in c.ddrr_last_error()
+    assert c.ddrr_siddon_ncc_backward_pose(P, P, P, L(0), P, P, 2, P, P, P, P, P, P, P, 2, 0, 1, P, 1, 4,
+                                           f(1e-8), 1, P, P, P, None) != 0
+    assert b"g_stride" in c.ddrr_last_error()
+    assert c.ddrr_siddon_ncc_forward(P, P, P, L(0), 0, 4, f(1e-5), P, P, P, None, None) == 0  # empty batch
+    # the record alone: out may be NULL only together with aux
+    assert c.ddrr_siddon_forward_bricks(P, 4, 4, 4, P, P, P, 1, 4, 5, f(0.5), f(1e-8), None, None,
+                                        f(0.0), 0, None, 0, P, None) != 0
+    assert b"out" in c.ddrr_last_error()
 
 
 def test_brick_kernels_fit_their_register_budget():
