@@ -61,3 +61,17 @@ OUT=gpurun_out/r05z; mkdir -p $OUT; (timeout 1200 python -m pytest tests -m gpu 
 # ---------------------------------------------------------------- 2026-09-27T01:27:58Z  default bench line with configs.few_poses and 4-pose parity
 mkdir -p gpurun_out/r05y; (time timeout 900 python bench.py > gpurun_out/r05y/bench_config_headline.json 2> gpurun_out/r05y/bench_headline.err) 2>&1 | tail -3; grep "few poses\|config 4:\|config headline:" gpurun_out/r05y/bench_headline.err | cut -c1-200; python -c "
 import json; d=json.load(open(\"gpurun_out/r05y/bench_config_headline.json\")); print(d[\"value\"], d[\"ms_per_step\"], d[\"parity\"][\"poses\"], d[\"parity\"][\"fwd_rel_err_vs_fp64\"], d[\"parity\"][\"pose_grad_rel_err_vs_fp64\"], d[\"configs\"][\"4\"][\"value\"], d[\"configs\"][\"3\"][\"value\"], d[\"roofline\"][\"forward\"].get(\"traffic\"), d[\"roofline\"][\"forward_f32\"].get(\"traffic\"))"
+
+# ---------------------------------------------------------------- 2026-09-27T01:30:19Z  driver-like bench invocations (N = 1: plain and under torch.distributed.run)
+mkdir -p gpurun_out/r05x; timeout 500 python bench.py --gpus 1 --steps 20 --warmup 3 > gpurun_out/r05x/driver_like.json 2> gpurun_out/r05x/driver_like.err; python -c "
+import json; d=json.load(open(\"gpurun_out/r05x/driver_like.json\")); print(d[\"value\"], d[\"ms_per_step\"], d[\"steps\"], d[\"warmup\"], sorted(d.keys())); print(sorted(d[\"configs\"].keys()), d[\"roofline\"][\"frac\"], d[\"cpu_baseline\"][\"value\"])"; timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 3 --no-configs > gpurun_out/r05x/driver_like_tdr.json 2> gpurun_out/r05x/driver_like_tdr.err; python -c "
+import json; d=json.load(open(\"gpurun_out/r05x/driver_like_tdr.json\")); print(d[\"value\"], d[\"ms_per_step\"], d[\"n_gpus\"])"
+
+# ---------------------------------------------------------------- 2026-09-27T01:32:52Z  new test: the 32-pose headline launch vs the oracle for every pose
+mkdir -p gpurun_out/r05w; (time timeout 1200 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -s -k "32_poses_vs_oracle" 2>&1 | grep -v amdgpu.ids | tail -8) 2>&1 | tee gpurun_out/r05w/headline_32_poses_vs_oracle.txt
+
+# ---------------------------------------------------------------- 2026-09-27T01:35:08Z  32-pose oracle test: per-pose error listing
+timeout 1200 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -s -k "32_poses_vs_oracle" 2>&1 | grep "^pose\|passed\|failed\|headline launch" | cut -c1-330 | tee gpurun_out/r05w/per_pose.txt
+
+# ---------------------------------------------------------------- 2026-09-27T01:36:40Z  32-pose oracle test, restated gates
+(timeout 1200 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -s -k "32_poses_vs_oracle" 2>&1 | grep "passed\|failed\|headline launch\|Error" | cut -c1-400) | tee gpurun_out/r05w/headline_32_poses_vs_oracle.txt
