@@ -151,6 +151,51 @@ def test_headline_launch_of_32_poses_vs_oracle(gpu):
           f"itself > 1e-4 from fp64: {exempt}; pixels > 1e-4 from the fp32 reference (both kernels): {off_ref}")
 
 
+def test_ct_like_volume_vs_oracle(gpu):
+    """A volume that looks like what the reference is used on: the CT-like 512 x 512 x 133 HU phantom
+    (diffdrr_amd.data.ct_like_hu_volume) through the package's transform_hu_to_density (reference
+    data.py:214-227) -- exact-zero air, partial-volume skin, dim lung texture among zeros, bone, a metal
+    marker at 1.0 -- in the reference's example geometry (README.md:67-87), three poses per launch:
+    both brick storages and both kernels against the oracle; the guard sends the skin / lung boundary
+    bricks to the fp32 path and nothing else."""
+    from diffdrr_amd.data import ct_like_hu_volume, make_subject, transform_hu_to_density
+
+    density = transform_hu_to_density(ct_like_hu_volume((512, 512, 133), seed=0))
+    assert float(density.min()) == 0.0 and float(density.max()) == 1.0
+    assert 0.5 < float((density == 0).float().mean()) < 0.8  # air, exactly
+    drr = DRR(make_subject(density, spacing=(0.703, 0.703, 2.5)), sdd=1020.0, height=200, delx=2.0).to(gpu)
+    g = torch.Generator().manual_seed(3)
+    B, N = 3, 200 * 200
+    rot = ((torch.rand(B, 3, generator=g) - 0.5) * (np.pi / 2)).to(gpu)
+    xyz = (torch.tensor([0.0, 850.0, 0.0]) + (torch.rand(B, 3, generator=g) - 0.5) * 60).to(gpu)
+    s, t, L = voxel_rays(drr, rot, xyz)
+    V = drr.density
+    go = torch.randn(B, N, generator=torch.Generator().manual_seed(5)).to(gpu)
+    ref32, ref64 = _oracle_pair(V.cpu().numpy(), s, t, L, go)
+    r32, r64 = ref32["out"].reshape(B, N).astype(np.float64), ref64["out"].reshape(B, N)
+    for storage in ("q16p", "f32"):
+        out, aux = ops.siddon_forward_bricks(V, s, t, L, (200, 200), want_aux=True, storage=storage)
+        plain, _ = ops.siddon_forward_bricks(V, s, t, L, (200, 200), storage=storage)
+        for img in (out, plain):
+            mine = img.cpu().numpy().astype(np.float64)
+            for b in range(B):
+                scale = np.abs(r32[b]).max()
+                assert scale > 10 and np.abs(mine[b] - r64[b]).max() <= FWD_TOL * scale, (storage, b)
+                assert rel_err(mine[b], r64[b]) < 2 * rel_err(r32[b], r64[b]) + 5e-6, (storage, b)
+        gs, gt, gi = ops.siddon_backward_rays(aux, go, s, t, L)
+        for mine, key in ((gt.cpu().numpy(), "g_target"), (gi.cpu().numpy().reshape(B, 1, N), "g_img")):
+            err, err_ref = rel_err(mine, ref64[key]), rel_err(ref32[key], ref64[key])
+            assert err < 2 * err_ref + GRAD_TOL, (storage, key, err, err_ref)
+    n_f32, n = ops.brick_fallbacks(V, "q16p")
+    assert n == 768 and 100 < n_f32 < 400, (n_f32, n)
+    # ... and through the module: this shape (3 double bricks per CU) renders from fp32 bricks
+    from diffdrr_amd.renderers import _brick_storage
+    assert _brick_storage(V, {"storage": drr.renderer.brick_storage}) == "f32"
+    with torch.no_grad():
+        img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY").reshape(B, N).cpu().numpy()
+    assert all(np.abs(img[b] - r64[b]).max() <= FWD_TOL * np.abs(r32[b]).max() for b in range(B))
+
+
 def sweep_parity(drr, fixed, rot, xyz, images, vals, picks, eps=1e-5):
     """Sampled poses of a sweep launch against the oracle: image-normalised error of the launch's
     images vs the oracle's fp32 / fp64 renders of the same rays, and the launch's per-pose NCC

@@ -75,3 +75,6 @@ timeout 1200 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -s -k "32_p
 
 # ---------------------------------------------------------------- 2026-09-27T01:36:40Z  32-pose oracle test, restated gates
 (timeout 1200 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -s -k "32_poses_vs_oracle" 2>&1 | grep "passed\|failed\|headline launch\|Error" | cut -c1-400) | tee gpurun_out/r05w/headline_32_poses_vs_oracle.txt
+
+# ---------------------------------------------------------------- 2026-09-27T01:39:15Z  new test: CT-like volume vs oracle
+timeout 900 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -k "ct_like" 2>&1 | tail -12
