@@ -78,3 +78,6 @@ timeout 1200 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -s -k "32_p
 
 # ---------------------------------------------------------------- 2026-09-27T01:39:15Z  new test: CT-like volume vs oracle
 timeout 900 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -k "ct_like" 2>&1 | tail -12
+
+# ---------------------------------------------------------------- 2026-09-27T01:41:14Z  randomised sweep of the brick kernels on the final tree
+mkdir -p gpurun_out/r05v; (timeout 600 python tools/fuzz_bricks.py --cases 96 --seed 5; timeout 400 python tools/fuzz_bricks.py --cases 32 --seed 6 --smooth) 2>&1 | grep -v amdgpu.ids > gpurun_out/r05v/fuzz_bricks.txt; tail -12 gpurun_out/r05v/fuzz_bricks.txt | cut -c1-220
