@@ -81,3 +81,9 @@ timeout 900 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -k "ct_like"
 
 # ---------------------------------------------------------------- 2026-09-27T01:41:14Z  randomised sweep of the brick kernels on the final tree
 mkdir -p gpurun_out/r05v; (timeout 600 python tools/fuzz_bricks.py --cases 96 --seed 5; timeout 400 python tools/fuzz_bricks.py --cases 32 --seed 6 --smooth) 2>&1 | grep -v amdgpu.ids > gpurun_out/r05v/fuzz_bricks.txt; tail -12 gpurun_out/r05v/fuzz_bricks.txt | cut -c1-220
+
+# ---------------------------------------------------------------- 2026-09-27T01:44:24Z  final tree: full GPU suite + smoke
+mkdir -p gpurun_out/r05final; (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4) > gpurun_out/r05final/gpu_tests.txt; cat gpurun_out/r05final/gpu_tests.txt; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -3
+
+# ---------------------------------------------------------------- 2026-09-27T01:51:44Z  empty launches: the staging loop alone
+mkdir -p gpurun_out/r05u; timeout 600 python tools/empty_launch_probe.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05u/empty_launch_probe.txt
