@@ -87,3 +87,12 @@ mkdir -p gpurun_out/r05final; (timeout 1500 python -m pytest tests -m gpu -q 2>&
 
 # ---------------------------------------------------------------- 2026-09-27T01:51:44Z  empty launches: the staging loop alone
 mkdir -p gpurun_out/r05u; timeout 600 python tools/empty_launch_probe.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05u/empty_launch_probe.txt
+
+# ---------------------------------------------------------------- 2026-09-27T02:05:51Z  few-pose kernel: first run (storage tests + timing)
+timeout 500 python -m pytest tests/test_gpu_brick_storage.py -x -q -k "look_ahead or any_depth or q16_storage or non_finite" 2>&1 | tail -25 > gpurun_out/few_tests.txt; timeout 300 python tools/storage_bench.py --scenes noise512,phantom512 --poses 1,2,4 --storages q16p > gpurun_out/few_bench.txt 2>&1; tail -5 gpurun_out/few_tests.txt; cat gpurun_out/few_bench.txt
+
+# ---------------------------------------------------------------- 2026-09-27T02:07:16Z  few-pose kernel: static parts
+timeout 300 python tools/storage_bench.py --scenes noise512,phantom512 --poses 1,2,4 --storages q16p > gpurun_out/few_bench.txt 2>&1; cat gpurun_out/few_bench.txt; timeout 200 python tools/empty_launch_probe.py 2>&1 | grep -v "^B   8\|^B  32" | tee gpurun_out/few_probe.txt
+
+# ---------------------------------------------------------------- 2026-09-27T02:08:29Z  product kernel at 1/2/4 poses for the parts experiment's table
+timeout 300 python tools/storage_bench.py --scenes noise512,phantom512 --poses 1,2,4 --storages q16p 2>&1 | tee gpurun_out/few_bench_product.txt
