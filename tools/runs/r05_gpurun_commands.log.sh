@@ -96,3 +96,14 @@ timeout 300 python tools/storage_bench.py --scenes noise512,phantom512 --poses 1
 
 # ---------------------------------------------------------------- 2026-09-27T02:08:29Z  product kernel at 1/2/4 poses for the parts experiment's table
 timeout 300 python tools/storage_bench.py --scenes noise512,phantom512 --poses 1,2,4 --storages q16p 2>&1 | tee gpurun_out/few_bench_product.txt
+
+# ---------------------------------------------------------------- 2026-09-27T02:11:05Z  claim-ahead in the general brick kernel: config 3 + full gpu suite
+python bench.py --config 3 --no-cpu-baseline > gpurun_out/c3_ahead.json 2> gpurun_out/c3_ahead.err; python - <<EOF
+import json
+d=json.load(open("gpurun_out/c3_ahead.json"))
+print(d["value"], d["ms_per_step"], [(k["kernel"], round(k["kernel_ms"],4)) for k in d.get("kernels",[])], d.get("b4",{}).get("value"))
+EOF
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee gpurun_out/gpu_tests_ahead.txt
+
+# ---------------------------------------------------------------- 2026-09-27T02:15:13Z  phase profile of the marcher's brick kernels at config 3
+timeout 600 python tools/tri_profile.py 2>&1 | tee gpurun_out/tri_profile.txt
