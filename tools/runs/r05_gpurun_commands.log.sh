@@ -107,3 +107,14 @@ timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee gpurun_out
 
 # ---------------------------------------------------------------- 2026-09-27T02:15:13Z  phase profile of the marcher's brick kernels at config 3
 timeout 600 python tools/tri_profile.py 2>&1 | tee gpurun_out/tri_profile.txt
+
+# ---------------------------------------------------------------- 2026-09-27T02:18:56Z  phase profile of the marcher's brick kernels at config 3
+timeout 600 python tools/tri_profile.py 2>&1 | tee gpurun_out/tri_profile.txt
+
+# ---------------------------------------------------------------- 2026-09-27T02:22:09Z  marcher: ray parts at <= 2 poses: trilinear tests + config 3
+timeout 600 python -m pytest tests -m gpu -x -q -k "tri or march or Tri" 2>&1 | tail -4; python bench.py --config 3 --no-cpu-baseline > gpurun_out/c3_parts.json 2> gpurun_out/c3_parts.err; python - <<EOF
+import json
+d=json.load(open("gpurun_out/c3_parts.json"))
+print(d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"], json.dumps(d.get("parity")))
+EOF
+python tools/trilinear_bench.py 2>&1 | tail -6
