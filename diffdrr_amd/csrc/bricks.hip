@@ -59,6 +59,14 @@ struct LdsAbsAdd {
     float q;
     __device__ __forceinline__ void operator()(unsigned addr, float v) const {
 #if defined(__HIP_DEVICE_COMPILE__)
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+        // (timing experiment, q < 0: a plain LDS store instead of the atomic -- the bound on what the
+        // atomics cost; the result is garbage)
+        if (q < 0.f) {
+            *(__attribute__((address_space(3))) int *)(unsigned long long)addr = __float2int_rn(v * q);
+            return;
+        }
+#endif
         if (q != 0.f) {
             __hip_atomic_fetch_add((int *)(__attribute__((address_space(3))) int *)(unsigned long long)addr,
                                    __float2int_rn(v * q), __ATOMIC_RELAXED,
@@ -361,6 +369,21 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
     DDRR_PROF(PROF_DELIVER);
 }
 
+// (profiling builds: stamps of a brick's stages, 10 ns ticks from its claim: [n_bricks + 16 brick + k];
+// how = 0: wave 0, 1: the latest wave.  k = 0 claimed, 1 / 2 rows + staging issued, 3 behind the staging
+// barrier, 4 / 5 out of units, 6 / 7 walks done, 8 behind the gradient's barrier, 9 / 10 stored)
+#if defined(DDRR_BRICK_PROFILE)
+#define DDRR_STAMP(k, how)                                                                              \
+    if (p.brick_times && lane == 0) {                                                                   \
+        const unsigned dt_ = (unsigned)__builtin_amdgcn_s_memrealtime() - (unsigned)counter[3];         \
+        unsigned *slot_ = p.brick_times + n_bricks + 16 * brick_id + (k);                               \
+        if (how) atomicMax(slot_, dt_);                                                                 \
+        else if (wave == 0) *slot_ = dt_;                                                               \
+    }
+#else
+#define DDRR_STAMP(k, how) {}
+#endif
+
 template <int MODE>
 __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     BrickArgs p, float *__restrict__ out, float *__restrict__ aux) {
@@ -407,6 +430,9 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         if (wmax > 0.f && wmax < 1e30f && n_sum > 0.f && n_sum <= 16384.f)
             fixq = (GRADL ? 7.8e6f : 2.0e9f) / (n_sum * wmax);
     }
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+    if (GRAD && (p.dbg & (1 << 23))) fixq = -fixq;  // (LdsAbsAdd: plain stores)
+#endif
 
   // Persistent workgroups: bricks are handed out by a global counter, so a CU that drew
   // light bricks (far from the sources: fewer rays cross them) simply takes more of them.
@@ -417,6 +443,9 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
   for (;;) {
     __syncthreads();  // every wave is done with the previous brick's LDS
     DDRR_PROF(PROF_BARRIER);
+#if defined(DDRR_BRICK_PROFILE)
+    if (tid == 0) counter[3] = (int)(unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
     if (tid == 0) {
         counter[1] = atomicAdd(p.work, 1);
         counter[2] = 0;  // "a staged voxel is non-zero"
@@ -425,6 +454,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
     if (counter[1] >= n_bricks) break;
     const int brick_id = p.order ? p.order[counter[1]] : counter[1];  // (heaviest first)
     DDRR_PROF(PROF_CLAIM);
+    DDRR_STAMP(0, 0)
     // `box`: the voxels staged in LDS; `cells`: the planes the candidates are clipped against
     Box box;
     BoxF cells;
@@ -638,7 +668,10 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         // not make a voxel non-zero; the volume-gradient modes have no such shortcut.)
         constexpr unsigned kValueBits = LABELS ? 0x7fffff00u : 0x7fffffffu;
         if (!GRAD && ch == 0 && (nz & kValueBits) != 0u) counter[2] = 1;  // (cleared with the claim)
+        if (ch == 0) DDRR_STAMP(1, 0)
+        if (ch == 0) DDRR_STAMP(2, 1)
         __syncthreads();
+        if (ch == 0) DDRR_STAMP(3, 0)
         if (!GRAD && ch == 0) brick_empty = counter[2] == 0;
         // units per pose -> inclusive prefix, held by every wave in registers (lane k: pose k)
         int incl = lane < nb ? (reinterpret_cast<const BrickRow *>(rows + lane * kRowWords)->count +
@@ -658,6 +691,10 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
             u = uni(u);
             const bool drain = u >= units;  // no unit left in this chunk
             if (drain && !last_chunk) break;
+            if (drain) {
+                DDRR_STAMP(4, 0)
+                DDRR_STAMP(5, 1)
+            }
             if (!drain) {
                 while (u >= cur_hi) {  // units arrive in increasing order: forward cursor
                     ++cur;
@@ -749,11 +786,14 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
             if (drain) break;
         }
     }
+    DDRR_STAMP(6, 0)
+    DDRR_STAMP(7, 1)
     if (GRAD) {
         // every ray of every pose has been scattered into the LDS accumulator, and the brick
         // owns its voxels (Siddon bricks, and the marcher's owner bricks): the gradient is
         // complete and is stored, 16 bytes per thread
         __syncthreads();
+        DDRR_STAMP(8, 0)
         for (int row = tid >> 3; row < BRICK * BRICK; row += kBrickThreads >> 3) {
             const int lx = row / BRICK, ly = row - lx * BRICK, q4 = (tid & 7) * 4;
             const int x = box.lo[0] + lx, y = box.lo[1] + ly, z = box.lo[2] + q4;
@@ -774,6 +814,8 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                 }
             }
         }
+        DDRR_STAMP(9, 0)
+        DDRR_STAMP(10, 1)
     }
   }
 #if defined(DDRR_BRICK_PROFILE)
@@ -1034,6 +1076,9 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     p.ws_header = nullptr;
     p.ranges_valid = 0;
     p.brick_times = nullptr;
+#if defined(DDRR_BRICK_PROFILE)
+    p.brick_times = g_brick_times;
+#endif
     p.order = nullptr;
     p.order_ws = nullptr;
     p.order_cap = 0;

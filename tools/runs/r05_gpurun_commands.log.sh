@@ -118,3 +118,9 @@ d=json.load(open("gpurun_out/c3_parts.json"))
 print(d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"], json.dumps(d.get("parity")))
 EOF
 python tools/trilinear_bench.py 2>&1 | tail -6
+
+# ---------------------------------------------------------------- 2026-09-27T02:24:21Z  stage stamps of the marcher's brick kernels
+timeout 600 python tools/tri_stamps.py 2>&1 | tee gpurun_out/tri_stamps.txt; timeout 300 python tools/tri_stamps.py 4 2>&1 | tee -a gpurun_out/tri_stamps.txt
+
+# ---------------------------------------------------------------- 2026-09-27T02:25:35Z  volume gradient: what the LDS atomics cost
+timeout 600 python tools/scratch/volgrad_noatomic.py 2>&1 | tee gpurun_out/volgrad_noatomic.txt
