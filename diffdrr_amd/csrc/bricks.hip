@@ -82,6 +82,37 @@ struct LdsAbsAdd {
     }
 };
 
+// The same with the choice between the two made where the accumulator is built (a test per add is a
+// branch per corner of the marcher's samples) and the scale folded into the ray's weight
+// (tri_brick.h acc_scale / acc_add): one conversion per add, round half up.
+template <bool FIXED>
+struct LdsAbsAddT {
+    float q;
+    __device__ __forceinline__ float scale(float w) const { return FIXED ? w * q : w; }
+    __device__ __forceinline__ void add_scaled(unsigned addr, float v) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (FIXED) {
+            int c;
+            asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(c) : "v"(v));  // floor(v + 1/2)
+#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
+            if (q < 0.f) {  // (timing experiment: a plain store, see LdsAbsAdd)
+                *(__attribute__((address_space(3))) int *)(unsigned long long)addr = c;
+                return;
+            }
+#endif
+            __hip_atomic_fetch_add((int *)(__attribute__((address_space(3))) int *)(unsigned long long)addr, c,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            __hip_atomic_fetch_add((float *)(__attribute__((address_space(3))) float *)(unsigned long long)addr,
+                                   v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#else
+        (void)addr;
+        (void)v;
+#endif
+    }
+};
+
 // The same into the upper 24 bits of the word (BRICK_CHANNELS_VOLGRAD): the low byte holds the
 // voxel's label, which sums of multiples of 256 never touch.  q: counts per unit, for 23 bits.
 // (Fewer label bits for fewer channels -- variable shifts -- cost 20 % and bought no accuracy: a
@@ -275,16 +306,25 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
         const BrickColumnWeight<true> weight{p.grad_out, (b * C * N + pix) * 4u, N * 4u, C};
         const float a0 = p.amin[0], a1 = p.amax[0];
         const float k = L * ((a1 - a0) / (float)(p.n_points - 1));
-        tri_owner_scatter_weighted(LdsAbsAdd{fixq}, TriLabelOf{p.labels, p.D}, weight, base, G.lof, G.hif,
-                                   G.stridef, p.D, s, t, p.shift, p.eps, p.n_points, a0, a1, k);
+        if (fixq != 0.f)
+            tri_owner_scatter_weighted(LdsAbsAddT<true>{fixq}, TriLabelOf{p.labels, p.D}, weight, base, G.lof, G.hif,
+                                       G.stridef, p.D, s, t, p.shift, p.eps, p.n_points, a0, a1, k);
+        else
+            tri_owner_scatter_weighted(LdsAbsAddT<false>{0.f}, TriLabelOf{p.labels, p.D}, weight, base, G.lof, G.hif,
+                                       G.stridef, p.D, s, t, p.shift, p.eps, p.n_points, a0, a1, k);
         return;
     }
     if (MODE == BRICK_TRI_VOLGRAD) {
         const float a0 = p.amin[0], a1 = p.amax[0];
         const float w = p.grad_out[r] * L * ((a1 - a0) / (float)(p.n_points - 1));
-        if (w != 0.f)
-            tri_owner_scatter(LdsAbsAdd{fixq}, base, G.lof, G.hif, G.stridef, s, t, p.shift, p.eps,
-                              p.n_points, a0, a1, w);
+        if (w != 0.f) {
+            if (fixq != 0.f)
+                tri_owner_scatter(LdsAbsAddT<true>{fixq}, base, G.lof, G.hif, G.stridef, s, t, p.shift, p.eps,
+                                  p.n_points, a0, a1, w);
+            else
+                tri_owner_scatter(LdsAbsAddT<false>{0.f}, base, G.lof, G.hif, G.stridef, s, t, p.shift, p.eps,
+                                  p.n_points, a0, a1, w);
+        }
         return;
     }
     if (MODE == BRICK_TRI_CHANNELS) {

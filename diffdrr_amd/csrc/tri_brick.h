@@ -369,6 +369,58 @@ DDRR_HD MarchGrad trilinear_backward_from_record(float sumT, const float A[3], c
     return r;
 }
 
+// An accumulator may take its weights pre-scaled (the LDS fixed-point accumulator: one multiply by
+// its scale per ray instead of one per corner): `scale(w)` once, `add_scaled(addr, v)` per corner;
+// any other accumulator is called as acc(addr, v).
+template <class Acc>
+DDRR_HD auto acc_scale(const Acc &a, float w, int) -> decltype(a.scale(w)) {
+    return a.scale(w);
+}
+template <class Acc>
+DDRR_HD float acc_scale(const Acc &, float w, long) {
+    return w;
+}
+template <class Acc>
+DDRR_HD auto acc_add(const Acc &a, unsigned addr, float v, int) -> decltype(a.add_scaled(addr, v)) {
+    a.add_scaled(addr, v);
+}
+template <class Acc>
+DDRR_HD void acc_add(const Acc &a, unsigned addr, float v, long) {
+    a(addr, v);
+}
+
+// One sample's eight corner updates inside an OWNER brick, without a branch per corner: a corner that
+// is not owned adds 0 to the owned corner next to it (per axis: the plane of the owned corner, weight
+// 0) -- eight unconditional adds cost less than the twelve divergent regions that pick the owned
+// ones (round 5: the marcher's volume gradient 0.895 -> 0.777 ms at 512^3 -> 512^2, one pose), and
+// adding 0 changes no sum.  x0 / x1 ...: the brick owns the corner at fx / fx + 1 ... (at least one per
+// axis); (ax, ay, az): the sample's fractions; o = byte offset of (0, 0, 0); w: the sample's weight
+// through acc_scale.
+template <class Acc>
+DDRR_HD void tri_owner_add8(const Acc &acc, bool x0, bool x1, bool y0, bool y1, bool z0, bool z1, float fx,
+                            float fy, float fz, float ax, float ay, float az, float sx, float sy, float offc,
+                            float w) {
+    const float wxa = x0 ? 1.f - ax : 0.f, wxb = x1 ? ax : 0.f;
+    const float wya = y0 ? 1.f - ay : 0.f, wyb = y1 ? ay : 0.f;
+    const float wza = z0 ? 1.f - az : 0.f, wzb = z1 ? az : 0.f;
+    // the first corner's plane per axis: fx if owned, else fx + 1 (then that is the owned one); the
+    // second corner lies one stride further only if BOTH are owned
+    const float o000 =
+        fmaf(x0 ? fx : fx + 1.f, sx, fmaf(y0 ? fy : fy + 1.f, sy, fmaf(z0 ? fz : fz + 1.f, 4.f, offc)));
+    const unsigned a000 = (unsigned)(int)o000;  // exact, < 2^24
+    const unsigned dx = x0 && x1 ? (unsigned)(int)sx : 0u, dy = y0 && y1 ? (unsigned)(int)sy : 0u;
+    const unsigned dz = z0 && z1 ? 4u : 0u;
+    const float waa = w * (wxa * wya), wba = w * (wxb * wya), wab = w * (wxa * wyb), wbb = w * (wxb * wyb);
+    acc_add(acc, a000, waa * wza, 0);
+    acc_add(acc, a000 + dz, waa * wzb, 0);
+    acc_add(acc, a000 + dx, wba * wza, 0);
+    acc_add(acc, a000 + dx + dz, wba * wzb, 0);
+    acc_add(acc, a000 + dy, wab * wza, 0);
+    acc_add(acc, a000 + dy + dz, wab * wzb, 0);
+    acc_add(acc, a000 + dx + dy, wbb * wza, 0);
+    acc_add(acc, a000 + dx + dy + dz, wbb * wzb, 0);
+}
+
 // Volume gradient of one ray inside one OWNER brick: voxels [lo, hi) per axis (hi - lo <= 32),
 // staged at LDS offset (v - lo) . stride.  `acc(addr, value)` adds into the LDS accumulator;
 // corners outside [lo, hi) belong to a neighbour (or lie outside the volume) and are skipped.
@@ -396,6 +448,7 @@ DDRR_HD void tri_owner_scatter(const Acc &acc, float base, const float lo[3], co
     const int m0 = (int)f0, m1 = (int)f1;
     const float offc = fmaf(-lo[0], stridef[0], fmaf(-lo[1], stridef[1], fmaf(-lo[2], stridef[2], base)));
     const float sx = stridef[0], sy = stridef[1];
+    const float ws = acc_scale(acc, w, 0);
     for (int m = m0; m <= m1; ++m) {
         const float al = fmaf(lin01(m, P, lstep), span, amin);  // renderers.py:224-225
         const float gx = fmaf(al, d[0], s[0]) + go;
@@ -408,29 +461,7 @@ DDRR_HD void tri_owner_scatter(const Acc &acc, float base, const float lo[3], co
         const bool z0 = fz >= lo[2] && fz < hi[2], z1 = fz + 1.f >= lo[2] && fz + 1.f < hi[2];
         if (!((x0 || x1) && (y0 || y1) && (z0 || z1))) continue;
         const float ax = gx - fx, ay = gy - fy, az = gz - fz;
-        const float o00 = fmaf(fx, sx, fmaf(fy, sy, fmaf(fz, 4.f, offc)));
-        // (offsets of corners that are not owned may be negative: never converted or used)
-        const float wx0 = 1.f - ax, wy0 = 1.f - ay, wz0 = 1.f - az;
-        if (x0 && y0) {
-            const unsigned a00 = (unsigned)(int)(o00 + (z0 ? 0.f : 4.f));
-            if (z0) acc(a00, w * (wx0 * wy0 * wz0));
-            if (z1) acc(z0 ? a00 + 4u : a00, w * (wx0 * wy0 * az));
-        }
-        if (x1 && y0) {
-            const unsigned a10 = (unsigned)(int)(o00 + sx + (z0 ? 0.f : 4.f));
-            if (z0) acc(a10, w * (ax * wy0 * wz0));
-            if (z1) acc(z0 ? a10 + 4u : a10, w * (ax * wy0 * az));
-        }
-        if (x0 && y1) {
-            const unsigned a01 = (unsigned)(int)(o00 + sy + (z0 ? 0.f : 4.f));
-            if (z0) acc(a01, w * (wx0 * ay * wz0));
-            if (z1) acc(z0 ? a01 + 4u : a01, w * (wx0 * ay * az));
-        }
-        if (x1 && y1) {
-            const unsigned a11 = (unsigned)(int)(o00 + sx + sy + (z0 ? 0.f : 4.f));
-            if (z0) acc(a11, w * (ax * ay * wz0));
-            if (z1) acc(z0 ? a11 + 4u : a11, w * (ax * ay * az));
-        }
+        tri_owner_add8(acc, x0, x1, y0, y1, z0, z1, fx, fy, fz, ax, ay, az, sx, sy, offc, ws);
     }
 }
 
@@ -493,31 +524,10 @@ DDRR_HD void tri_owner_scatter_weighted(const Acc &acc, const Label &label, cons
         const int lab = (int)label(rx, ry, rz, owned, owned ? (unsigned)(int)an : 0u);
         if (lab != cur) {
             cur = lab;
-            w = weight((unsigned)lab) * k;
+            w = acc_scale(acc, weight((unsigned)lab) * k, 0);
         }
         const float ax = gx - fx, ay = gy - fy, az = gz - fz;
-        const float o00 = fmaf(fx, sx, fmaf(fy, sy, fmaf(fz, 4.f, offc)));
-        const float wx0 = 1.f - ax, wy0 = 1.f - ay, wz0 = 1.f - az;
-        if (x0 && y0) {
-            const unsigned a00 = (unsigned)(int)(o00 + (z0 ? 0.f : 4.f));
-            if (z0) acc(a00, w * (wx0 * wy0 * wz0));
-            if (z1) acc(z0 ? a00 + 4u : a00, w * (wx0 * wy0 * az));
-        }
-        if (x1 && y0) {
-            const unsigned a10 = (unsigned)(int)(o00 + sx + (z0 ? 0.f : 4.f));
-            if (z0) acc(a10, w * (ax * wy0 * wz0));
-            if (z1) acc(z0 ? a10 + 4u : a10, w * (ax * wy0 * az));
-        }
-        if (x0 && y1) {
-            const unsigned a01 = (unsigned)(int)(o00 + sy + (z0 ? 0.f : 4.f));
-            if (z0) acc(a01, w * (wx0 * ay * wz0));
-            if (z1) acc(z0 ? a01 + 4u : a01, w * (wx0 * ay * az));
-        }
-        if (x1 && y1) {
-            const unsigned a11 = (unsigned)(int)(o00 + sx + sy + (z0 ? 0.f : 4.f));
-            if (z0) acc(a11, w * (ax * ay * wz0));
-            if (z1) acc(z0 ? a11 + 4u : a11, w * (ax * ay * az));
-        }
+        tri_owner_add8(acc, x0, x1, y0, y1, z0, z1, fx, fy, fz, ax, ay, az, sx, sy, offc, w);
     }
 }
 

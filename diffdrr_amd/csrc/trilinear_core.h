@@ -20,7 +20,9 @@ namespace ddrr {
 
 // torch.linspace(0, 1, P)[m] as aten's scalar (and GPU) kernel evaluates it.
 DDRR_HD float lin01(int m, int P, float lstep) {
-    return m < P / 2 ? (float)m * lstep : 1.0f - (float)(P - 1 - m) * lstep;
+    // (both halves computed and one selected: as a branch it is a divergent region per sample)
+    const float up = (float)m * lstep, down = 1.0f - (float)(P - 1 - m) * lstep;
+    return m < P / 2 ? up : down;
 }
 
 // The marching range of one ray: first / last intersection with the volume enlarged by one

@@ -124,3 +124,9 @@ timeout 600 python tools/tri_stamps.py 2>&1 | tee gpurun_out/tri_stamps.txt; tim
 
 # ---------------------------------------------------------------- 2026-09-27T02:25:35Z  volume gradient: what the LDS atomics cost
 timeout 600 python tools/scratch/volgrad_noatomic.py 2>&1 | tee gpurun_out/volgrad_noatomic.txt
+
+# ---------------------------------------------------------------- 2026-09-27T02:29:52Z  marcher volume gradient: branch-free owner scatter
+timeout 600 python -m pytest tests -m gpu -x -q -k "tri or march or Tri or volume" 2>&1 | tail -3; python tools/trilinear_bench.py 2>&1 | grep "volume-grad"
+
+# ---------------------------------------------------------------- 2026-09-27T02:34:25Z  marcher volume gradient: hoisted accumulator choice, prescale, branch-free lin01
+timeout 700 python -m pytest tests -m gpu -x -q -k "tri or march or Tri or volume or channel" 2>&1 | tail -3; python tools/trilinear_bench.py 2>&1 | grep "volume-grad\|forward+record"

@@ -1,4 +1,5 @@
-"""The marcher's volume gradient at config 3 with integer LDS atomics (product), plain LDS stores (what the atomics cost;\ngarbage result) and float LDS atomics: tools build (development tool).  Usage: python tools/volgrad_noatomic.py"""
+"""The marcher's volume gradient at config 3 with integer LDS atomics (product), plain LDS stores (what the atomics cost;
+garbage result) and float LDS atomics: tools build (development tool).  Usage: python tools/volgrad_noatomic.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tools.explib
