@@ -644,6 +644,26 @@ DDRR_HD int step_walk_weighted(const Fetch &fetch, const StepGeom &G, const Step
     return it + 1;
 }
 
+// An accumulator may take its weights pre-scaled (the LDS fixed-point accumulator: one multiply by
+// its scale per ray instead of one per corner): `scale(w)` once, `add_scaled(addr, v)` per corner;
+// any other accumulator is called as acc(addr, v).
+template <class Acc>
+DDRR_HD auto acc_scale(const Acc &a, float w, int) -> decltype(a.scale(w)) {
+    return a.scale(w);
+}
+template <class Acc>
+DDRR_HD float acc_scale(const Acc &, float w, long) {
+    return w;
+}
+template <class Acc>
+DDRR_HD auto acc_add(const Acc &a, unsigned addr, float v, int) -> decltype(a.add_scaled(addr, v)) {
+    a.add_scaled(addr, v);
+}
+template <class Acc>
+DDRR_HD void acc_add(const Acc &a, unsigned addr, float v, long) {
+    a(addr, v);
+}
+
 // Volume gradient of one ray through one brick: adds w * dalpha_k to the LDS cell of every
 // voxel the ray crosses (d out / d V[k] = L dalpha_k; reference: grid_sampler_3d_backward
 // behind renderers.py:159-164).  `add(bits, value)` is the scatter at byte address `bits`.
@@ -661,11 +681,12 @@ DDRR_HD bool step_scatter(const Add &add, unsigned base_bits, const StepGeom &G,
     const float sb2 = in_vgpr(G.strideb[2]);
     const float nbig = in_vgpr(-kSelBig), one = in_vgpr(1.f);
     float a_cur = E.entry;
+    const float ws = acc_scale(add, w, 0);
     for (int it = 0; it < 3 * BRICK + 4; ++it) {
         const unsigned addr =
             float_bits(fmaf(kr0, sb0, fmaf(kr1, sb1, fmaf(kr2, sb2, E.offc))));
         const float a_next = fminf(fminf(an0, an1), an2);
-        add(addr, w * (a_next - a_cur));
+        acc_add(add, addr, ws * (a_next - a_cur), 0);
         if (!(a_next < E.exit)) break;
         kr0 = fmaf(sel_zero(an0 - a_next, nbig, one), E.dirf[0], kr0);
         kr1 = fmaf(sel_zero(an1 - a_next, nbig, one), E.dirf[1], kr1);
@@ -703,9 +724,9 @@ DDRR_HD bool step_scatter_weighted(const Add &add, const Label &label, const Wei
         const int lab = (int)label(addr);
         if (lab != cur) {
             cur = lab;
-            w = weight((unsigned)lab) * L;
+            w = acc_scale(add, weight((unsigned)lab) * L, 0);
         }
-        add(addr, w * (a_next - a_cur));
+        acc_add(add, addr, w * (a_next - a_cur), 0);
         if (!(a_next < E.exit)) break;
         kr0 = fmaf(sel_zero(an0 - a_next, nbig, one), E.dirf[0], kr0);
         kr1 = fmaf(sel_zero(an1 - a_next, nbig, one), E.dirf[1], kr1);

@@ -55,36 +55,9 @@ inline size_t brick_lds_bytes(const BrickLayout &lay) {
 // a voxel can receive (volgrad_prepare_kernel); q == 0 selects the float path (the bound
 // does not exist, e.g. the source lies inside the volume).  Integer sums are associative:
 // the fixed-point gradient is bit-reproducible.
-struct LdsAbsAdd {
-    float q;
-    __device__ __forceinline__ void operator()(unsigned addr, float v) const {
-#if defined(__HIP_DEVICE_COMPILE__)
-#if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
-        // (timing experiment, q < 0: a plain LDS store instead of the atomic -- the bound on what the
-        // atomics cost; the result is garbage)
-        if (q < 0.f) {
-            *(__attribute__((address_space(3))) int *)(unsigned long long)addr = __float2int_rn(v * q);
-            return;
-        }
-#endif
-        if (q != 0.f) {
-            __hip_atomic_fetch_add((int *)(__attribute__((address_space(3))) int *)(unsigned long long)addr,
-                                   __float2int_rn(v * q), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-            return;
-        }
-        __hip_atomic_fetch_add((float *)(__attribute__((address_space(3))) float *)(unsigned long long)addr,
-                               v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-        (void)addr;
-        (void)v;
-#endif
-    }
-};
-
-// The same with the choice between the two made where the accumulator is built (a test per add is a
-// branch per corner of the marcher's samples) and the scale folded into the ray's weight
-// (tri_brick.h acc_scale / acc_add): one conversion per add, round half up.
+// The choice between the two is made where the accumulator is built, not per add (a test per add is
+// a branch per corner of the marcher's samples, per step of a walk), and the scale is folded into
+// the ray's weight (brick_step.h acc_scale / acc_add): one conversion per add, round half up.
 template <bool FIXED>
 struct LdsAbsAddT {
     float q;
@@ -95,7 +68,7 @@ struct LdsAbsAddT {
             int c;
             asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(c) : "v"(v));  // floor(v + 1/2)
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
-            if (q < 0.f) {  // (timing experiment: a plain store, see LdsAbsAdd)
+            if (q < 0.f) {  // (timing experiment: a plain store instead of the atomic; the result is garbage)
                 *(__attribute__((address_space(3))) int *)(unsigned long long)addr = c;
                 return;
             }
@@ -120,6 +93,18 @@ struct LdsAbsAddT {
 // fp32 alphas whatever the accumulator.)
 struct LdsAbsAddHigh {
     float q;
+    __device__ __forceinline__ float scale(float w) const { return w * q; }
+    __device__ __forceinline__ void add_scaled(unsigned addr, float v) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        int c;
+        asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(c) : "v"(v));  // floor(v + 1/2)
+        __hip_atomic_fetch_add((int *)(__attribute__((address_space(3))) int *)(unsigned long long)addr, c << 8,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        (void)addr;
+        (void)v;
+#endif
+    }
     __device__ __forceinline__ void operator()(unsigned addr, float v) const {
 #if defined(__HIP_DEVICE_COMPILE__)
         __hip_atomic_fetch_add((int *)(__attribute__((address_space(3))) int *)(unsigned long long)addr,
@@ -136,7 +121,7 @@ struct LdsLabelLow {
         return float_bits(LdsAbsFetch{}(addr)) & 0xffu;
     }
 };
-// or -- no bound on a voxel's sum, float accumulators (see LdsAbsAdd) -- the label map itself,
+// or -- no bound on a voxel's sum, float accumulators (see LdsAbsAddT) -- the label map itself,
 // at the voxel the address belongs to (byte strides of the LDS copy: 4 sx, 4 sy, 4).
 struct GlobalLabelOf {
     const unsigned char *labels;
@@ -283,8 +268,12 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
     const float base = (float)LdsAbsFetch::base_of(brick);
     if (MODE == BRICK_VOLGRAD) {
         const float w = p.grad_out[r] * L;
-        if (w != 0.f)
-            step_scatter(LdsAbsAdd{fixq}, LdsAbsFetch::base_of(brick), SG, s, t, p.shift, p.eps, w);
+        if (w != 0.f) {
+            if (fixq != 0.f)
+                step_scatter(LdsAbsAddT<true>{fixq}, LdsAbsFetch::base_of(brick), SG, s, t, p.shift, p.eps, w);
+            else
+                step_scatter(LdsAbsAddT<false>{0.f}, LdsAbsFetch::base_of(brick), SG, s, t, p.shift, p.eps, w);
+        }
         return;
     }
     if (MODE == BRICK_CHANNELS_VOLGRAD) {
@@ -297,7 +286,7 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
         } else {
             const GlobalLabelOf label{p.labels, p.D, {(int)G.lof[0], (int)G.lof[1], (int)G.lof[2]}, lbase,
                                       (unsigned)p.lay.sx * 4u, (unsigned)p.lay.sy * 4u};
-            step_scatter_weighted(LdsAbsAdd{0.f}, label, weight, lbase, SG, s, t, p.shift, p.eps, L);
+            step_scatter_weighted(LdsAbsAddT<false>{0.f}, label, weight, lbase, SG, s, t, p.shift, p.eps, L);
         }
         return;
     }
@@ -471,7 +460,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
             fixq = (GRADL ? 7.8e6f : 2.0e9f) / (n_sum * wmax);
     }
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
-    if (GRAD && (p.dbg & (1 << 23))) fixq = -fixq;  // (LdsAbsAdd: plain stores)
+    if (GRAD && (p.dbg & (1 << 23))) fixq = -fixq;  // (LdsAbsAddT: plain stores)
 #endif
 
   // Persistent workgroups: bricks are handed out by a global counter, so a CU that drew
@@ -868,7 +857,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
 // ------------------------------------------- volume-gradient fixed-point bound
 // work[1] = bits of max over rays of the largest single contribution a ray can make to a
 // voxel; work[2] = float: bound on the number of such contributions a voxel can receive in
-// this launch (sum over poses of the rays that can cross one voxel); see LdsAbsAdd.
+// this launch (sum over poses of the rays that can cross one voxel); see LdsAbsAddT.
 //   Siddon:    |g| L dalpha,  dalpha |d| <= sqrt(3)           ->  sqrt(3) |g| L / |d|
 //   trilinear: |g| L step per sample, at most 2 sqrt(3) / (step |d|) + 1 samples of a ray
 //              touch one voxel                                 ->  |g| L (2 sqrt(3) / |d| + step)

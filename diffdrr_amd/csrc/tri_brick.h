@@ -106,9 +106,10 @@ DDRR_HD bool tri_brick_march(const Acc &acc, float base, const TriGeom &G, const
         const float gy = fmaf(al, d[1], s[1]) + go;
         const float gz = fmaf(al, d[2], s[2]) + go;
         const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
-        const bool in = fx >= G.lo[0] && fx < G.lo[0] + (float)TRI_CELLS && fy >= G.lo[1] &&
-                        fy < G.lo[1] + (float)TRI_CELLS && fz >= G.lo[2] &&
-                        fz < G.lo[2] + (float)TRI_CELLS;
+        // (one test, not a chain of three divergent regions: samples handed to a brick are mostly in it)
+        const bool in = (fx >= G.lo[0]) & (fx < G.lo[0] + (float)TRI_CELLS) & (fy >= G.lo[1]) &
+                        (fy < G.lo[1] + (float)TRI_CELLS) & (fz >= G.lo[2]) &
+                        (fz < G.lo[2] + (float)TRI_CELLS);
         if (!in) continue;
         const float ax = gx - fx, ay = gy - fy, az = gz - fz;
         const float o00 = fmaf(fx, sx, fmaf(fy, sy, fmaf(fz, 4.f, offc)));  // exact, < 2^24
@@ -202,9 +203,10 @@ DDRR_HD bool tri_brick_march_channels(const Acc &acc, float base, const TriGeom 
         const float gy = fmaf(al, q.d[1], s[1]) + go;
         const float gz = fmaf(al, q.d[2], s[2]) + go;
         const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
-        const bool in = fx >= G.lo[0] && fx < G.lo[0] + (float)TRI_CELLS && fy >= G.lo[1] &&
-                        fy < G.lo[1] + (float)TRI_CELLS && fz >= G.lo[2] &&
-                        fz < G.lo[2] + (float)TRI_CELLS;
+        // (one test, not a chain of three divergent regions: samples handed to a brick are mostly in it)
+        const bool in = (fx >= G.lo[0]) & (fx < G.lo[0] + (float)TRI_CELLS) & (fy >= G.lo[1]) &
+                        (fy < G.lo[1] + (float)TRI_CELLS) & (fz >= G.lo[2]) &
+                        (fz < G.lo[2] + (float)TRI_CELLS);
         if (!in) continue;
         const float ax = gx - fx, ay = gy - fy, az = gz - fz;
         const float o00 = fmaf(fx, sx, fmaf(fy, sy, fmaf(fz, 4.f, offc)));  // exact, < 2^24
@@ -286,9 +288,10 @@ DDRR_HD bool tri_brick_march_weighted(const Acc &acc, const Label &label, float 
         const float gy = fmaf(al, q.d[1], s[1]) + go;
         const float gz = fmaf(al, q.d[2], s[2]) + go;
         const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
-        const bool in = fx >= G.lo[0] && fx < G.lo[0] + (float)TRI_CELLS && fy >= G.lo[1] &&
-                        fy < G.lo[1] + (float)TRI_CELLS && fz >= G.lo[2] &&
-                        fz < G.lo[2] + (float)TRI_CELLS;
+        // (one test, not a chain of three divergent regions: samples handed to a brick are mostly in it)
+        const bool in = (fx >= G.lo[0]) & (fx < G.lo[0] + (float)TRI_CELLS) & (fy >= G.lo[1]) &
+                        (fy < G.lo[1] + (float)TRI_CELLS) & (fz >= G.lo[2]) &
+                        (fz < G.lo[2] + (float)TRI_CELLS);
         if (!in) continue;
         const float ax = gx - fx, ay = gy - fy, az = gz - fz;
         const float o00 = fmaf(fx, sx, fmaf(fy, sy, fmaf(fz, 4.f, offc)));  // exact, < 2^24
@@ -367,26 +370,6 @@ DDRR_HD MarchGrad trilinear_backward_from_record(float sumT, const float A[3], c
     r.g_amax = k * Cu + ws;
     r.sumT = sumT;
     return r;
-}
-
-// An accumulator may take its weights pre-scaled (the LDS fixed-point accumulator: one multiply by
-// its scale per ray instead of one per corner): `scale(w)` once, `add_scaled(addr, v)` per corner;
-// any other accumulator is called as acc(addr, v).
-template <class Acc>
-DDRR_HD auto acc_scale(const Acc &a, float w, int) -> decltype(a.scale(w)) {
-    return a.scale(w);
-}
-template <class Acc>
-DDRR_HD float acc_scale(const Acc &, float w, long) {
-    return w;
-}
-template <class Acc>
-DDRR_HD auto acc_add(const Acc &a, unsigned addr, float v, int) -> decltype(a.add_scaled(addr, v)) {
-    a.add_scaled(addr, v);
-}
-template <class Acc>
-DDRR_HD void acc_add(const Acc &a, unsigned addr, float v, long) {
-    a(addr, v);
 }
 
 // One sample's eight corner updates inside an OWNER brick, without a branch per corner: a corner that

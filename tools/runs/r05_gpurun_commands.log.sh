@@ -130,3 +130,10 @@ timeout 600 python -m pytest tests -m gpu -x -q -k "tri or march or Tri or volum
 
 # ---------------------------------------------------------------- 2026-09-27T02:34:25Z  marcher volume gradient: hoisted accumulator choice, prescale, branch-free lin01
 timeout 700 python -m pytest tests -m gpu -x -q -k "tri or march or Tri or volume or channel" 2>&1 | tail -3; python tools/trilinear_bench.py 2>&1 | grep "volume-grad\|forward+record"
+
+# ---------------------------------------------------------------- 2026-09-27T02:40:41Z  volume-gradient walks with the hoisted accumulators: full gpu suite + Siddon volgrad + config 3
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee gpurun_out/gpu_tests_now.txt; python tools/volgrad_bench.py 2>&1 | tail -4; python bench.py --config 3 --no-cpu-baseline > gpurun_out/c3_new.json 2>/dev/null; python - <<EOF
+import json
+d=json.load(open("gpurun_out/c3_new.json"))
+print("config 3:", d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"])
+EOF
