@@ -621,6 +621,14 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
             // four byte loads.
             constexpr int kFly = LABELS ? 2 : 4;  // quads in flight per thread
             const long total4 = ((long)p.D.x * p.D.y * p.D.z) & ~3L;
+            // Plain halo bricks (the marcher's forward, with and without the record): a quad is ONE
+            // 16-byte load from a dword-aligned address, like the Siddon bricks' (brick_shared.h
+            // quad_load) -- the halo puts the rows at every alignment, and as four dword loads a
+            // brick is 512 wave-loads of which every cache line is asked for four times.  The quad
+            // is read from inside its row (z clamped to 0 .. D.z - 4) and shifted where that moved it
+            // (the bricks at the volume's two ends only); what lies outside is masked below as before.
+            const bool quads = !GRAD && !LABELS && p.D.z >= 4 && (reinterpret_cast<uintptr_t>(p.vol) & 3) == 0;
+            const int zq = clampi(z, 0, p.D.z - 4), zsh = z - zq;
 #pragma unroll 1
             for (int h = 0; h < kQuads; h += kFly) {
                 float v[kFly][4];
@@ -636,8 +644,14 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                     const int xc = clampi(x, 0, p.D.x - 1), yc = clampi(y, 0, p.D.y - 1);
                     const long rowbase = ((long)xc * p.D.y + yc) * p.D.z;
                     const float *g = p.vol + rowbase;
+                    if (quads) {
+                        const quad_u32x4 q = *reinterpret_cast<const quad_u32x4_a4 *>(g + zq);
+                        v[it][0] = bits_as_float(q.x), v[it][1] = bits_as_float(q.y);
+                        v[it][2] = bits_as_float(q.z), v[it][3] = bits_as_float(q.w);
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[it][k] = GRAD ? 0.f : g[clampi(z + k, 0, p.D.z - 1)];
+                        for (int k = 0; k < 4; ++k) v[it][k] = GRAD ? 0.f : g[clampi(z + k, 0, p.D.z - 1)];
+                    }
                     if (LABELS) {
                         const long a = rowbase + (z > 0 ? z : 0), a4 = a & ~3L;
                         wide[it] = labels_dword_ok && z >= 0 && a4 + 8 <= total4;
@@ -675,6 +689,14 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                     const int row = (tid >> 3) + (h + it) * (kBrickThreads >> 3);
                     const int lx = row / BRICK, ly = row - lx * BRICK;
                     float *d = d0 + lx * p.lay.sx + ly * p.lay.sy;
+                    if (quads && zsh != 0) {  // voxel z + k is element k + zsh of what was read
+                        const float q0 = v[it][0], q1 = v[it][1], q2 = v[it][2], q3 = v[it][3];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int e = k + zsh;
+                            v[it][k] = e == 0 ? q0 : (e == 1 ? q1 : (e == 2 ? q2 : (e == 3 ? q3 : 0.f)));
+                        }
+                    }
                     unsigned lab4 = 0u;
                     if (LABELS)
                         lab4 = wide[it] ? __builtin_amdgcn_alignbyte(lw[it][1], lw[it][0], (unsigned)sh[it])

@@ -137,3 +137,9 @@ import json
 d=json.load(open("gpurun_out/c3_new.json"))
 print("config 3:", d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"])
 EOF
+
+# ---------------------------------------------------------------- 2026-09-27T02:43:38Z  marcher forward: 8 quads in flight while staging + one membership region
+timeout 500 python -m pytest tests -m gpu -x -q -k "tri or march or Tri" 2>&1 | tail -2; python tools/trilinear_bench.py 2>&1 | grep "volume-grad"
+
+# ---------------------------------------------------------------- 2026-09-27T02:45:35Z  marcher: halo bricks staged with 16-byte loads
+timeout 500 python -m pytest tests -m gpu -x -q -k "tri or march or Tri or depth" 2>&1 | tail -2; python tools/trilinear_bench.py 2>&1 | grep "volume-grad\|forward+record"
