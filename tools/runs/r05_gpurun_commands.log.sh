@@ -143,3 +143,6 @@ timeout 500 python -m pytest tests -m gpu -x -q -k "tri or march or Tri" 2>&1 | 
 
 # ---------------------------------------------------------------- 2026-09-27T02:45:35Z  marcher: halo bricks staged with 16-byte loads
 timeout 500 python -m pytest tests -m gpu -x -q -k "tri or march or Tri or depth" 2>&1 | tail -2; python tools/trilinear_bench.py 2>&1 | grep "volume-grad\|forward+record"
+
+# ---------------------------------------------------------------- 2026-09-27T02:48:19Z  pooled end in the general brick kernel: A/B
+timeout 700 python tools/pool_ab.py 2>&1 | tee gpurun_out/pool_ab.txt
