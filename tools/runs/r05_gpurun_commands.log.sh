@@ -146,3 +146,21 @@ timeout 500 python -m pytest tests -m gpu -x -q -k "tri or march or Tri or depth
 
 # ---------------------------------------------------------------- 2026-09-27T02:48:19Z  pooled end in the general brick kernel: A/B
 timeout 700 python tools/pool_ab.py 2>&1 | tee gpurun_out/pool_ab.txt
+
+# ---------------------------------------------------------------- 2026-09-27T02:49:11Z  stage stamps of the marcher's kernels after the round's changes
+timeout 600 python tools/tri_stamps.py 2>&1 | tee gpurun_out/tri_stamps2.txt
+
+# ---------------------------------------------------------------- 2026-09-27T02:50:32Z  marcher forward: eight 16-byte quads in flight
+python tools/trilinear_bench.py 2>&1 | grep "volume-grad"
+
+# ---------------------------------------------------------------- 2026-09-27T02:51:25Z  stage stamps of the channel render
+timeout 500 python tools/channel_stamps.py 8 2>&1 | tee gpurun_out/channel_stamps.txt; timeout 300 python tools/channel_stamps.py 1 2>&1 | tee -a gpurun_out/channel_stamps.txt
+
+# ---------------------------------------------------------------- 2026-09-27T02:53:18Z  general brick kernel: detector models cached in LDS
+timeout 700 python -m pytest tests -m gpu -x -q 2>&1 | tail -2; python tools/trilinear_bench.py 2>&1 | grep "volume-grad"; python tools/channels_bench.py --real-mask 2>&1 | tail -5
+
+# ---------------------------------------------------------------- 2026-09-27T02:55:05Z  channels bench, real mask (detector models cached)
+python tools/channels_bench.py --real-mask 2>&1 | grep -v "^trilinear" | tee gpurun_out/channels_now.txt
+
+# ---------------------------------------------------------------- 2026-09-27T03:00:28Z  channels bench, real mask (detector models cached)
+python tools/channels_bench.py --real-mask 2>&1 | grep -v "^trilinear" | tee gpurun_out/channels_now.txt
