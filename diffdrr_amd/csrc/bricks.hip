@@ -845,6 +845,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
         // complete and is stored, 16 bytes per thread
         __syncthreads();
         DDRR_STAMP(8, 0)
+        const float unfix = fixq != 0.f ? 1.0f / fixq : 0.f;  // (one division per brick, not one per voxel)
         for (int row = tid >> 3; row < BRICK * BRICK; row += kBrickThreads >> 3) {
             const int lx = row / BRICK, ly = row - lx * BRICK, q4 = (tid & 7) * 4;
             const int x = box.lo[0] + lx, y = box.lo[1] + ly, z = box.lo[2] + q4;
@@ -854,7 +855,7 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                 float val[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    val[k] = fixq != 0.f ? (float)(GRADL ? __float_as_int(src[k]) >> 8 : __float_as_int(src[k])) / fixq
+                    val[k] = fixq != 0.f ? (float)(GRADL ? __float_as_int(src[k]) >> 8 : __float_as_int(src[k])) * unfix
                                          : src[k];
                 if (vec_out && z + 4 <= box.hi[2]) {
                     *reinterpret_cast<float4 *>(g) = make_float4(val[0], val[1], val[2], val[3]);

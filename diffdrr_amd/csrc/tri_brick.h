@@ -83,7 +83,10 @@ DDRR_HD bool tri_brick_march(const Acc &acc, float base, const TriGeom &G, const
     for (int a = 0; a < 3; ++a) {
         d[a] = (t[a] - s[a]) + eps;
         const float g0 = s[a] + go;
-        const float a1 = (G.lo[a] - g0) / d[a], a2 = (G.lo[a] + (float)TRI_CELLS - g0) / d[a];
+        // (v_rcp_f32, 1 ulp: these bounds only pick the run of samples that is looked at -- with one
+        // sample of slack on both sides -- the membership test below decides)
+        const float inv = approx_rcp(d[a]);
+        const float a1 = (G.lo[a] - g0) * inv, a2 = (G.lo[a] + (float)TRI_CELLS - g0) * inv;
         entry = fmaxf(entry, fminf(a1, a2));
         exit = fminf(exit, fmaxf(a1, a2));
     }
@@ -179,7 +182,8 @@ DDRR_HD bool tri_brick_march_channels(const Acc &acc, float base, const TriGeom 
     for (int a = 0; a < 3; ++a) {
         q.d[a] = (t[a] - s[a]) + eps;
         const float g0 = s[a] + go;
-        const float a1 = (G.lo[a] - g0) / q.d[a], a2 = (G.lo[a] + (float)TRI_CELLS - g0) / q.d[a];
+        const float inv = approx_rcp(q.d[a]);  // (bounds of the run of samples looked at, see tri_brick_march)
+        const float a1 = (G.lo[a] - g0) * inv, a2 = (G.lo[a] + (float)TRI_CELLS - g0) * inv;
         entry = fmaxf(entry, fminf(a1, a2));
         exit = fminf(exit, fmaxf(a1, a2));
     }
@@ -264,7 +268,8 @@ DDRR_HD bool tri_brick_march_weighted(const Acc &acc, const Label &label, float 
     for (int a = 0; a < 3; ++a) {
         q.d[a] = (t[a] - s[a]) + eps;
         const float g0 = s[a] + go;
-        const float a1 = (G.lo[a] - g0) / q.d[a], a2 = (G.lo[a] + (float)TRI_CELLS - g0) / q.d[a];
+        const float inv = approx_rcp(q.d[a]);  // (bounds of the run of samples looked at, see tri_brick_march)
+        const float a1 = (G.lo[a] - g0) * inv, a2 = (G.lo[a] + (float)TRI_CELLS - g0) * inv;
         entry = fmaxf(entry, fminf(a1, a2));
         exit = fminf(exit, fmaxf(a1, a2));
     }
@@ -418,7 +423,8 @@ DDRR_HD void tri_owner_scatter(const Acc &acc, float base, const float lo[3], co
         d[a] = (t[a] - s[a]) + eps;
         const float g0 = s[a] + go;
         // base cells lo - 1 .. hi - 1  <=>  g in [lo - 1, hi)
-        const float a1 = (lo[a] - 1.f - g0) / d[a], a2 = (hi[a] - g0) / d[a];
+        const float inv = approx_rcp(d[a]);  // (bounds of the run of samples looked at, see tri_brick_march)
+        const float a1 = (lo[a] - 1.f - g0) * inv, a2 = (hi[a] - g0) * inv;
         entry = fmaxf(entry, fminf(a1, a2));
         exit = fminf(exit, fmaxf(a1, a2));
     }
@@ -469,7 +475,8 @@ DDRR_HD void tri_owner_scatter_weighted(const Acc &acc, const Label &label, cons
     for (int a = 0; a < 3; ++a) {
         q.d[a] = (t[a] - s[a]) + eps;
         const float g0 = s[a] + go;
-        const float a1 = (lo[a] - 1.f - g0) / q.d[a], a2 = (hi[a] - g0) / q.d[a];
+        const float inv = approx_rcp(q.d[a]);  // (bounds of the run of samples looked at, see tri_brick_march)
+        const float a1 = (lo[a] - 1.f - g0) * inv, a2 = (hi[a] - g0) * inv;
         entry = fmaxf(entry, fminf(a1, a2));
         exit = fminf(exit, fmaxf(a1, a2));
     }

@@ -164,3 +164,6 @@ python tools/channels_bench.py --real-mask 2>&1 | grep -v "^trilinear" | tee gpu
 
 # ---------------------------------------------------------------- 2026-09-27T03:00:28Z  channels bench, real mask (detector models cached)
 python tools/channels_bench.py --real-mask 2>&1 | grep -v "^trilinear" | tee gpurun_out/channels_now.txt
+
+# ---------------------------------------------------------------- 2026-09-27T03:06:14Z  marcher: approx reciprocal for the sample-run bounds, flush by multiplication
+timeout 700 python -m pytest tests -m gpu -x -q 2>&1 | tail -2; python tools/trilinear_bench.py 2>&1 | grep "volume-grad\|forward+record"; python tools/volgrad_bench.py | tail -4
