@@ -873,7 +873,7 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
 
         used = _brick_storage(drr.density, {"storage": storage})
         q16 = ("bricks staged as 16-bit block-quantised voxels, one (min, step) per 32x32x64 "
-               "brick, where the brick's range is <= 8x its level (else the brick is rendered from "
+               "brick, where the brick's range is <= 12x its level (else the brick is rendered from "
                "its fp32 values: brick_storage_fallbacks), |error| <= brick range / 131070 per "
                "voxel, fp32 arithmetic (parity block: measured in this run)")
         result["config"]["brick_storage"] = {

@@ -402,11 +402,14 @@ DDRR_HD Q16Range q16_range(float vmin, float vmax) {
 // the others carry that error against a small integral.  So a brick is quantised only if its
 // range is at most kQ16RangeOverLevel times its LEVEL -- the smallest mean |V| of any of its
 // 4 x 4 x 4 blocks (brick_range_kernel; over the non-zero voxels when the minimum is 0, which
-// q = 0 stores exactly): every voxel's error is then <= 8 / 131070 = 6.1e-5 of the mean of the
-// dimmest block a ray can cross, even if all rounding errors along a ray had one sign.  Any
+// q = 0 stores exactly): every voxel's error is then <= 12 / 131070 = 9.2e-5 of the mean of the
+// dimmest block a ray can cross, even if all rounding errors along a ray had one sign -- under the
+// 1e-4 the forward is held to PER PIXEL, with room for the fp32 arithmetic (3e-6).  (Rounds 4 and
+// early 5 had 8 = 6.1e-5, chosen without that arithmetic: it sent 644 instead of 369 of the 512^3
+// phantom's 2048 bricks to the fp32 path.)  Any
 // other brick -- and any brick holding inf / NaN or a range outside what the 2^64 pre-scaling
 // of the walk carries -- is rendered from the volume's own fp32 values (bricks_fwd.hip MIXED).
-constexpr float kQ16RangeOverLevel = 8.0f;
+constexpr float kQ16RangeOverLevel = 12.0f;
 DDRR_HD bool q16_usable(float vmin, float vmax, float level) {
     const float range = vmax - vmin;
     if (range == 0.f) return fabsf(vmin) < 0x1p40f;  // a brick of one value: exact

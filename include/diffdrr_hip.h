@@ -108,9 +108,9 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
  * twice the volume (32 x 32 x 64) fit a CU's LDS: fewer (ray, brick) pairs, 6-7 % faster.
  * ONLY bricks that keep their values are quantised: the error of a stored voxel is at most
  * (max - min of the brick) / 131070 in absolute terms, so a brick qualifies if that range is at
- * most 8x its LEVEL, the smallest mean |V| of any of its 4 x 4 x 4 blocks (over the non-zero
+ * most 12x its LEVEL, the smallest mean |V| of any of its 4 x 4 x 4 blocks (over the non-zero
  * voxels when the brick's minimum is 0, which is stored exactly) -- every voxel is then within
- * 6.1e-5 of the mean of the dimmest block a ray can cross.  Every other brick (one bright voxel
+ * 9.2e-5 of the mean of the dimmest block a ray can cross.  Every other brick (one bright voxel
  * among dim ones: a metal marker, contrast agent, un-normalised HU; inf / NaN; |values| or a
  * range outside 2^-60 .. 2^40) is rendered from the volume's own fp32 values, as two
  * 32 x 32 x 32 halves, in the same launch: results of DDRR_BRICKS_Q16 are within the 1e-4 of

@@ -173,3 +173,9 @@ OUT=gpurun_out/r05z2; mkdir -p $OUT; (timeout 1200 python -m pytest tests -m gpu
 
 # ---------------------------------------------------------------- 2026-09-27T03:14:55Z  randomised sweep of every brick kernel on the tree with the new volume-gradient loops
 mkdir -p gpurun_out/r05w; (timeout 600 python tools/fuzz_bricks.py --cases 96 --seed 7; timeout 400 python tools/fuzz_bricks.py --cases 32 --seed 8 --smooth) 2>&1 | grep -v amdgpu.ids > gpurun_out/r05w/fuzz_bricks.txt; tail -14 gpurun_out/r05w/fuzz_bricks.txt | cut -c1-260
+
+# ---------------------------------------------------------------- 2026-09-27T03:18:39Z  guard constant 12: full gpu suite, few-pose timing on the phantom, config 4
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -6; timeout 300 python tools/storage_bench.py --scenes phantom512,ct --poses 1,8,32 --storages q16p 2>&1 | grep -v amdgpu; timeout 300 python bench.py --config 4 --no-cpu-baseline > gpurun_out/c4_r12.json 2> gpurun_out/c4_r12.err; python - <<EOF
+import json
+d=json.load(open("gpurun_out/c4_r12.json")); print("config 4:", d["value"], d["ms_per_step"], d["config"].get("brick_storage_fallbacks"), d.get("registration"))
+EOF
