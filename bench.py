@@ -527,9 +527,17 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
         from diffdrr_amd import GraphedIteration
 
         reg = Registration(drr, r0.clone(), x0.clone(), parameterization="euler_angles", convention="ZXY")
-        opt = torch.optim.Adam([{"params": [reg._rotation], "lr": 1e-1},
-                                {"params": [reg._translation], "lr": 5e0}], maximize=True,
-                               capturable=on_gpu, fused=on_gpu)  # fused: one kernel per group
+        if args.torch_adam or not on_gpu:
+            opt = torch.optim.Adam([{"params": [reg._rotation], "lr": 1e-1},
+                                    {"params": [reg._translation], "lr": 5e0}], maximize=True,
+                                   capturable=on_gpu, fused=on_gpu)  # fused: two launches per group
+            opt_name = "torch.optim.Adam(1e-1 / 5e0, fused)"
+        else:
+            # the same update rule, both groups in one launch (four with torch's fused Adam)
+            from diffdrr_amd import PoseAdam
+
+            opt = PoseAdam(reg._rotation, reg._translation, 1e-1, 5e0, maximize=True)
+            opt_name = "diffdrr_amd.PoseAdam(1e-1 / 5e0) = torch.optim.Adam's update, both groups in one launch"
         pending, keep = [], {}
         try:
             if not on_gpu:
@@ -554,7 +562,7 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
         units_per_step, unit, scaling = world, "iterations/s", "weak"
         metric = f"registration iterations/sec, {D}^3 vol -> {H}^2 det, SE(3) gradient ascent on NCC"
         workload = (f"{D}^3 fp32 phantom volume -> {H}x{H} detector, Siddon "
-                    f"(stop_gradients_through_grid_sample), Registration + NCC + torch.optim.Adam(1e-1 / 5e0, fused), "
+                    f"(stop_gradients_through_grid_sample), Registration + NCC + {opt_name}, "
                     f"one pose per GPU, one HIP graph per iteration")
         dominant = "ddrr_siddon_forward_bricks"
     else:  # "5": the candidate-pose sweep, sharded (strong scaling)
@@ -1172,6 +1180,8 @@ def main():
                          "(nine small launches around the brick kernel) instead of DRR.ncc (three)")
     ap.add_argument("--fused-max-poses", type=int, default=None,
                     help="DRR.FUSED_NCC_MAX_POSES for this run (measurement: where the fused step stops paying)")
+    ap.add_argument("--torch-adam", action="store_true",
+                    help="config 4: torch.optim.Adam(fused, capturable) instead of diffdrr_amd.PoseAdam")
     ap.add_argument("--packed-record", action="store_true",
                     help="Siddon.packed_record = True (the opt-in fixed-point backward record)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],

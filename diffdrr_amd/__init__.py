@@ -15,5 +15,5 @@ from .metrics import (  # noqa: F401
     NormalizedCrossCorrelation2d,
 )
 from .pose import RigidTransform, convert  # noqa: F401
-from .registration import GraphedIteration, Registration  # noqa: F401
+from .registration import GraphedIteration, PoseAdam, Registration  # noqa: F401
 from .renderers import Siddon, Trilinear  # noqa: F401

@@ -47,6 +47,8 @@ struct BrickArgs {
     const int *order;             // bricks_fwd.hip: k-th brick handed out (NULL: k itself)
     int *order_ws;                // ... this launch's workspace for it: order_cap weights, order_cap ints
     int order_cap;
+    float *clear;                 // host side of bricks_fwd.hip: floats to zero in front of the launch (or NULL) ...
+    long clear_n;                 // ... so many, by the launch that zeroes the brick counter (brick_clear_kernel)
     unsigned *brick_times;        // profiling builds: duration of every brick (10 ns ticks), or NULL
     int split_t, split_s;         // ... the last split_t bricks are handed out in split_s pose parts
 };
@@ -226,12 +228,15 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
 // brick_ranges: the DDRR_BRICKS_Q16 workspace (header, (min, max) and fallback flag per brick),
 // ranges_valid: it already holds this volume's.
 // packed: the workspace also holds the bricks' LDS images (DDRR_BRICKS_Q16_PACKED) behind the ranges.
+// clear, clear_n: floats the launch has to find zeroed (the image or the record its atomics add to):
+// cleared by the launch that clears the brick counter -- one launch instead of two memsets, each
+// of which is a launch of its own (5 us apiece in front of a 140 us one-pose render).
 long brick_workspace_bytes(int dx, int dy, int dz, int brick_storage);
 int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_valid, const float *volume,
                       int dx, int dy, int dz, const float *source, const float *target,
                       const float *img, int B, int det_h, int det_w, float voxel_shift, float eps,
                       float *out, float *aux, float rec_q, hipStream_t st, void *launch_ws,
-                      const char *who);
+                      const char *who, float *clear = nullptr, long clear_n = 0);
 
 // experiment switches (tools builds: mutable; product: constants)
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)

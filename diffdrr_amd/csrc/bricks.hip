@@ -1302,10 +1302,12 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     const bool packed = aux && record_vmax > 0.f;
     // (the packed record's planes 5, 6 are written by record_prepare_kernel)
     const size_t fill = !aux ? (size_t)R : (packed ? (size_t)R * 5 : (size_t)rec_blocked_floats(R));
-    hipError_t e = hipMemsetAsync(aux ? aux : out, 0, sizeof(float) * fill, st);
-    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    // (the packed record's preparation writes behind the zeros: cleared here; else with the brick
+    // counter, by one launch: launch_fwd_bricks)
     float rec_q = 0.f;
     if (packed) {
+        const hipError_t e = hipMemsetAsync(aux, 0, sizeof(float) * fill, st);
+        if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
         rec_q = record_scale(record_vmax, Dims{dx, dy, dz});
         hipLaunchKernelGGL(record_prepare_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
                            dim3(kBlock), 0, st, source, target, R, N, Dims{dx, dy, dz}, voxel_shift,
@@ -1315,7 +1317,8 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     if (int rc = launch_fwd_bricks(packed_bricks ? DDRR_BRICKS_Q16 : brick_storage, packed_bricks,
                                    brick_ranges, ranges_valid, volume, dx, dy, dz,
                                    source, target, img, B, det_h, det_w, voxel_shift, eps, out, aux,
-                                   rec_q, st, launch_ws, "ddrr_siddon_forward_bricks"))
+                                   rec_q, st, launch_ws, "ddrr_siddon_forward_bricks",
+                                   packed ? nullptr : (aux ? aux : out), packed ? 0 : (long)fill))
         return rc;
     if (!aux) return 0;
     if (out)

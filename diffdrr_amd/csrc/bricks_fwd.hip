@@ -1376,6 +1376,16 @@ __global__ __launch_bounds__(1024) void brick_order_kernel(const float *__restri
         order[atomicAdd(&hist[kOrderClasses - 1 - (int)(weight[i] * scale)], 1)] = i;
 }
 
+// What a launch has to find zeroed, in one go: the image or the record its atomics add to, and
+// the brick counter.
+__global__ __launch_bounds__(256) void brick_clear_kernel(float *__restrict__ buf, long n, int *__restrict__ work) {
+    if (work && blockIdx.x == 0 && threadIdx.x < 4) work[threadIdx.x] = 0;
+    const long stride = (long)gridDim.x * 256, n4 = n >> 2;
+    float4 *b4 = reinterpret_cast<float4 *>(buf);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) b4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) buf[(n4 << 2) + threadIdx.x] = 0.f;
+}
+
 template <bool AUX, class C>
 int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t st) {
     static_assert(C::LDS <= C::LDS_BUDGET, "LDS budget");
@@ -1429,10 +1439,20 @@ int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t
         return fail(-1, "packed bricks are 16-bit bricks");
     }
     BrickArgs q = p;
-    // (the launch's counter is cleared by the order kernel, or -- no order -- by a memset)
-    if (!order_bricks(q, C::BX, C::BY, C::BZ, nby, nbz, n_bricks, slots, st, true)) {
-        const hipError_t e = hipMemsetAsync(q.work, 0, 4 * sizeof(int), st);
-        if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    // (the launch's counter is cleared by the order kernel, or -- no order -- together with the image
+    // or the record by brick_clear_kernel, or by a memset)
+    const bool ordered = order_bricks(q, C::BX, C::BY, C::BZ, nby, nbz, n_bricks, slots, st, true);
+    const bool clear_here = p.clear && p.clear_n > 0;
+    if (clear_here && (reinterpret_cast<uintptr_t>(p.clear) & 15) == 0) {
+        const long blocks = (p.clear_n / 4 + 255) / 256;
+        hipLaunchKernelGGL(brick_clear_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks))),
+                           dim3(256), 0, st, p.clear, p.clear_n, ordered ? nullptr : q.work);
+    } else {
+        // (a buffer at an odd address: two memsets as before)
+        if (clear_here && (e = hipMemsetAsync(p.clear, 0, sizeof(float) * (size_t)p.clear_n, st)) != hipSuccess)
+            return fail_hip(e, "hipMemsetAsync");
+        if (!ordered && (e = hipMemsetAsync(q.work, 0, 4 * sizeof(int), st)) != hipSuccess)
+            return fail_hip(e, "hipMemsetAsync");
     }
     const dim3 grid(n_bricks < slots ? n_bricks : slots), block(C::THREADS);
     hipLaunchKernelGGL((siddon_fwd_brick_kernel<AUX, C>), grid, block, C::LDS, st, q, out, aux);
@@ -1473,6 +1493,9 @@ int launch_sq(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t 
     }
     const dim3 grid(n_bricks < slots ? n_bricks : slots), block(C::THREADS);
     if (hipMemsetAsync(p.work, 0, 4 * sizeof(int), st) != hipSuccess) return fail(-1, "hipMemsetAsync");
+    if (p.clear && p.clear_n > 0 &&
+        hipMemsetAsync(p.clear, 0, sizeof(float) * (size_t)p.clear_n, st) != hipSuccess)
+        return fail(-1, "hipMemsetAsync");
     hipLaunchKernelGGL((siddon_fwd_brick_sq_kernel<AUX, C, NCLS>), grid, block, S::LDS, st, p, out, aux);
     return 0;
 }
@@ -1538,7 +1561,7 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
                       const float *volume, int dx, int dy, int dz, const float *source, const float *target,
                       const float *img, int B, int det_h, int det_w, float voxel_shift, float eps,
                       float *out, float *aux, float rec_q, hipStream_t st, void *launch_ws,
-                      const char *who) {
+                      const char *who, float *clear, long clear_n) {
     const int N = det_h * det_w;
     // (brick_range_kernel: 16-byte loads where the volume's rows are aligned, else dwords)
     const bool vec_ok = (dz & 3) == 0 && (reinterpret_cast<uintptr_t>(volume) & 15) == 0;
@@ -1558,10 +1581,13 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
         few_f32 = false;  // (the variant asked for)
     }
 #endif
-    if (!quads_ok || variant < 0 || few_f32)
+    if (!quads_ok || variant < 0 || few_f32) {
+        if (clear && clear_n > 0 && hipMemsetAsync(clear, 0, sizeof(float) * (size_t)clear_n, st) != hipSuccess)
+            return fail(-1, "hipMemsetAsync");
         return launch_bricks(aux ? BRICK_FWD_AUX : BRICK_FWD, volume, dx, dy, dz, source, target, img,
                              nullptr, B, det_h, det_w, voxel_shift, eps, out, aux, nullptr, st,
                              launch_ws, who, 0, nullptr, nullptr, rec_q);
+    }
     BrickArgs p = {};
     p.vol = volume;
     p.D = Dims{dx, dy, dz};
@@ -1587,6 +1613,8 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
                    ? reinterpret_cast<const unsigned char *>(brick_ranges) + ranges_bytes(dx, dy, dz)
                    : nullptr;
     p.order = nullptr;
+    p.clear = clear;
+    p.clear_n = clear_n;
     p.split_t = 0;
     p.split_s = 1;
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)

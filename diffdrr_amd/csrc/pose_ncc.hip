@@ -492,6 +492,47 @@ __global__ __launch_bounds__(kBlock) void sobel_bwd_kernel(const float *__restri
     g_img[(long)b * H * W + n] = sobel_pixel_adjoint(gx, gx + (long)H * W, H, W, i, j);
 }
 
+// One Adam step of the two pose parameter groups of a registration (reference
+// notebooks/tutorials/registration.ipynb:240-316: torch.optim.Adam over {rotation: lr_rot},
+// {translation: lr_xyz}) in ONE launch.  torch's fused Adam is two launches per parameter group
+// (step counters, update): four launches of ~5 us for 6 numbers in a 0.19 ms iteration.  The
+// update is torch/optim/adam.py's (no weight decay, no amsgrad):
+//   step += 1;  m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;
+//   p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)        (maximize: g = -g)
+// One workgroup: the counters are read by every thread before any is written.
+constexpr int kAdamBlock = 256;
+__global__ __launch_bounds__(kAdamBlock) void pose_adam_kernel(
+    float *__restrict__ rot, float *__restrict__ xyz, const float *__restrict__ g_rot,
+    const float *__restrict__ g_xyz, float *__restrict__ m_rot, float *__restrict__ v_rot,
+    float *__restrict__ m_xyz, float *__restrict__ v_xyz, float *__restrict__ step_rot,
+    float *__restrict__ step_xyz, int B, float lr_rot, float lr_xyz, float beta1, float beta2, float eps,
+    int maximize) {
+    const float steps[2] = {step_rot[0] + 1.f, step_xyz[0] + 1.f};
+    __syncthreads();
+    float ss[2], rb2[2];  // lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        ss[k] = (k ? lr_xyz : lr_rot) / (1.f - powf(beta1, steps[k]));
+        rb2[k] = 1.f / sqrtf(1.f - powf(beta2, steps[k]));
+    }
+    const int n = 3 * B;
+    for (int i = threadIdx.x; i < 2 * n; i += kAdamBlock) {
+        const int k = i >= n, j = k ? i - n : i;
+        float *p = k ? xyz : rot, *m = k ? m_xyz : m_rot, *v = k ? v_xyz : v_rot;
+        float g = (k ? g_xyz : g_rot)[j];
+        g = maximize ? -g : g;
+        const float mj = fmaf(g - m[j], 1.f - beta1, m[j]);
+        const float vj = fmaf(beta2, v[j], (1.f - beta2) * g * g);
+        m[j] = mj;
+        v[j] = vj;
+        p[j] -= ss[k] * mj / fmaf(sqrtf(vj), rb2[k], eps);
+    }
+    if (threadIdx.x == 0) {
+        step_rot[0] = steps[0];
+        step_xyz[0] = steps[1];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -633,6 +674,22 @@ int ddrr_siddon_ncc_backward_pose(const float *aux, const float *img, const floa
                        x1_stride, stats, g_out, g_stride, source_v, target_v, Mw, Ainv, P, rot, xyz,
                        a0, a1, a2, reorient34, B, N, eps, with_img_path, ws, g_rot, g_xyz);
     return finish("ddrr_siddon_ncc_backward_pose");
+}
+
+int ddrr_pose_adam_step(float *rot, float *xyz, const float *g_rot, const float *g_xyz, float *m_rot,
+                        float *v_rot, float *m_xyz, float *v_xyz, float *step_rot, float *step_xyz, int B,
+                        float lr_rot, float lr_xyz, float beta1, float beta2, float eps, int maximize,
+                        void *stream) {
+    if (!rot || !xyz || !g_rot || !g_xyz || !m_rot || !v_rot || !m_xyz || !v_xyz || !step_rot || !step_xyz)
+        return fail(-1, "null pointer");
+    if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f) || !(lr_rot >= 0.f) ||
+        !(lr_xyz >= 0.f))
+        return fail(-1, "invalid Adam hyper-parameters");
+    if (B <= 0) return B == 0 ? 0 : fail(-1, "negative batch");
+    hipLaunchKernelGGL(pose_adam_kernel, dim3(1), dim3(kAdamBlock), 0, (hipStream_t)stream, rot, xyz, g_rot,
+                       g_xyz, m_rot, v_rot, m_xyz, v_xyz, step_rot, step_xyz, B, lr_rot, lr_xyz, beta1, beta2,
+                       eps, maximize);
+    return finish("ddrr_pose_adam_step");
 }
 
 int ddrr_pose_euler_forward(const float *rot, const float *xyz, int a0, int a1, int a2,

@@ -545,6 +545,25 @@ def siddon_ncc_forward(aux, img, x1, eps, *, want_image=False):
     return ncc, stats, out
 
 
+def pose_adam_step(rot, xyz, g_rot, g_xyz, m_rot, v_rot, m_xyz, v_xyz, step_rot, step_xyz, *, lr_rot, lr_xyz,
+                   betas=(0.9, 0.999), eps=1e-8, maximize=False):
+    """One Adam step of the two pose parameter groups, in place, in one launch (include/diffdrr_hip.h
+    ddrr_pose_adam_step: torch.optim.Adam's update; `step_*` are 1-element float tensors)."""
+    _require_gpu(rot)
+    B = rot.shape[0]
+    for t in (rot, xyz, g_rot, g_xyz, m_rot, v_rot, m_xyz, v_xyz):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != (B, 3):
+            raise ValueError("pose_adam_step: contiguous float32 (B, 3) tensors")
+    for t in (step_rot, step_xyz):
+        if t.dtype != torch.float32 or t.numel() != 1:
+            raise ValueError("pose_adam_step: 1-element float32 step counters")
+    if B:
+        _launch("ddrr_pose_adam_step", rot.device, rot.data_ptr(), xyz.data_ptr(), g_rot.data_ptr(),
+                g_xyz.data_ptr(), m_rot.data_ptr(), v_rot.data_ptr(), m_xyz.data_ptr(), v_xyz.data_ptr(),
+                step_rot.data_ptr(), step_xyz.data_ptr(), B, float(lr_rot), float(lr_xyz), float(betas[0]),
+                float(betas[1]), float(eps), int(bool(maximize)))
+
+
 def siddon_ncc_backward_pose(aux, img, x1, stats, g_out, source, target, Mw, Ainv, P, rot, xyz, axes,
                              reorient34, *, eps=1e-8, with_img_path=True):
     """(g_rot (B,3), g_xyz (B,3)) of sum_b g_out[b] ncc[b]: ncc_backward, siddon_backward_pose and

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 29
+#define DDRR_ABI_VERSION 30
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -485,6 +485,20 @@ int ddrr_siddon_ncc_backward_pose(const float *aux, const float *img, const floa
                                   int a0, int a1, int a2, const float *reorient34, int B, int N,
                                   float eps, int with_img_path, void *ws, float *g_rot, float *g_xyz,
                                   void *stream);
+
+/* One Adam step of a registration's two pose parameter groups in ONE launch (ABI 30): rot, xyz
+ * (B, 3) updated in place from their gradients, with torch.optim.Adam's update rule (no weight
+ * decay, no amsgrad; reference notebooks/tutorials/registration.ipynb:240-316 steps
+ * torch.optim.Adam([{rotation, lr_rot}, {translation, lr_xyz}], maximize=True)):
+ *   step += 1;  m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;
+ *   p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)      (maximize: g = -g)
+ * m_*, v_* (B, 3) and step_* (1 float each) are the optimizer's state, zero before the first step.
+ * torch's fused Adam takes four launches for the two groups (diffdrr_amd.registration.PoseAdam is
+ * the torch.optim.Optimizer over this entry). */
+int ddrr_pose_adam_step(float *rot, float *xyz, const float *g_rot, const float *g_xyz, float *m_rot,
+                        float *v_rot, float *m_xyz, float *v_xyz, float *step_rot, float *step_xyz, int B,
+                        float lr_rot, float lr_xyz, float beta1, float beta2, float eps, int maximize,
+                        void *stream);
 
 /* NormalizedCrossCorrelation2d, patch_size = None (reference metrics.py:21-44) for image
  * pairs of N pixels: out (B) = mean(z1 z2), z = (x - mean) / sqrt(var + eps).  x2 (B, N);

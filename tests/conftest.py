@@ -665,6 +665,53 @@ def check_filter_intersections_outside_volume(device):
         assert rel_err(g[f"filtered_{k}_f64"], g[f"default_{k}_f64"]) < 1e-12
 
 
+def check_pose_adam(device):
+    """``PoseAdam`` (ddrr_pose_adam_step: both pose parameter groups in one launch) against
+    ``torch.optim.Adam`` with the same two groups -- the optimizer of the reference's registration
+    loop (notebooks/tutorials/registration.ipynb:240-316) -- over a few steps of the same gradients:
+    parameters and state, minimising and maximising, with a learning-rate change in between."""
+    import torch
+
+    from diffdrr_amd.registration import PoseAdam
+
+    g = torch.Generator().manual_seed(11)
+    for B, maximize in ((1, True), (5, False)):
+        p0 = [torch.randn(B, 3, generator=g), torch.randn(B, 3, generator=g) * 50.0]
+        mine = [torch.nn.Parameter(p.clone().to(device)) for p in p0]
+        ref = [torch.nn.Parameter(p.clone()) for p in p0]
+        opt = PoseAdam(mine[0], mine[1], 1e-1, 5e0, betas=(0.9, 0.999), eps=1e-8, maximize=maximize)
+        ropt = torch.optim.Adam([{"params": [ref[0]], "lr": 1e-1}, {"params": [ref[1]], "lr": 5e0}],
+                                maximize=maximize)
+        for it in range(12):
+            grads = [torch.randn(B, 3, generator=g) * (10.0 ** (it % 3 - 1)), torch.randn(B, 3, generator=g) * 1e-3]
+            for p, r, gr in zip(mine, ref, grads):
+                p.grad = gr.clone().to(device)
+                r.grad = gr.clone()
+            if it == 6:  # (a scheduler's doing)
+                for o in (opt, ropt):
+                    o.param_groups[0]["lr"] = 3e-2
+            opt.step()
+            ropt.step()
+            # (a step moves a parameter by up to its learning rate: fp32 rounding of the quotient is
+            # relative to THAT, and adds up over the steps)
+            for p, r, lr in zip(mine, ref, (1e-1, 5e0)):
+                assert torch.allclose(p.detach().cpu(), r.detach(), rtol=2e-5, atol=2e-5 * lr), (B, it)
+        for p, r in zip(mine, ref):
+            st, rst = opt.state[p], ropt.state[r]
+            assert float(st["step"]) == float(rst["step"]) == 12.0
+            assert torch.allclose(st["exp_avg"].cpu(), rst["exp_avg"], rtol=1e-4, atol=1e-9)
+            assert torch.allclose(st["exp_avg_sq"].cpu(), rst["exp_avg_sq"], rtol=1e-4, atol=1e-12)
+    # a parameter without a gradient is an error, not a silent no-op
+    q = [torch.nn.Parameter(torch.zeros(1, 3, device=device)) for _ in range(2)]
+    q[0].grad = torch.ones(1, 3, device=device)
+    try:
+        PoseAdam(q[0], q[1], 0.1, 1.0).step()
+    except RuntimeError as e:
+        assert "gradient" in str(e)
+    else:
+        raise AssertionError("PoseAdam.step() without a gradient did not raise")
+
+
 def check_fused_ncc_step(device):
     """``DRR.ncc`` -- the registration step around the brick kernel as three fused launches
     (ddrr_pose_raygen_forward, ddrr_siddon_ncc_forward, ddrr_siddon_ncc_backward_pose; reference

@@ -1411,6 +1411,32 @@ int ddrr_pose_euler_backward(const float *rot, const float *xyz, int a0, int a1,
 
 // ---- the fused registration step (csrc/pose_ncc.hip): on the host simply the entries it fuses,
 // one after the other (the workspace stays untouched: zero in, zero out)
+int ddrr_pose_adam_step(float *rot, float *xyz, const float *g_rot, const float *g_xyz, float *m_rot,
+                        float *v_rot, float *m_xyz, float *v_xyz, float *step_rot, float *step_xyz, int B,
+                        float lr_rot, float lr_xyz, float beta1, float beta2, float eps, int maximize, void *) {
+    if (!rot || !xyz || !g_rot || !g_xyz || !m_rot || !v_rot || !m_xyz || !v_xyz || !step_rot || !step_xyz)
+        return -1;
+    if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f) || !(lr_rot >= 0.f) ||
+        !(lr_xyz >= 0.f) || B < 0)
+        return -1;
+    for (int k = 0; k < 2; ++k) {
+        float *p = k ? xyz : rot, *m = k ? m_xyz : m_rot, *v = k ? v_xyz : v_rot, *st = k ? step_xyz : step_rot;
+        const float *gp = k ? g_xyz : g_rot;
+        if (B == 0) continue;
+        const float step = st[0] + 1.f;
+        const float ss = (k ? lr_xyz : lr_rot) / (1.f - powf(beta1, step));
+        const float rb2 = 1.f / sqrtf(1.f - powf(beta2, step));
+        for (int j = 0; j < 3 * B; ++j) {
+            const float g = maximize ? -gp[j] : gp[j];
+            m[j] = fmaf(g - m[j], 1.f - beta1, m[j]);
+            v[j] = fmaf(beta2, v[j], (1.f - beta2) * g * g);
+            p[j] -= ss * m[j] / fmaf(sqrtf(v[j]), rb2, eps);
+        }
+        st[0] = step;
+    }
+    return 0;
+}
+
 long ddrr_siddon_ncc_workspace_bytes(int B) { return B < 1 ? 0 : (long)B * (5 * 8 + 12 * 4 + 2 * 4); }
 
 int ddrr_pose_raygen_forward(const float *rot, const float *xyz, int a0, int a1, int a2,

@@ -162,6 +162,15 @@ def test_argument_checks_return_errors_without_touching_a_device():
                                            f(1e-8), 1, P, P, P, None) != 0
     assert b"g_stride" in c.ddrr_last_error()
     assert c.ddrr_siddon_ncc_forward(P, P, P, L(0), 0, 4, f(1e-5), P, P, P, None, None) == 0  # empty batch
+    # the fused pose Adam step (ABI 30)
+    assert c.ddrr_pose_adam_step(P, P, P, P, P, P, P, P, P, None, 1, f(0.1), f(5.0), f(0.9), f(0.999), f(1e-8), 1,
+                                 None) != 0
+    assert b"null" in c.ddrr_last_error()
+    assert c.ddrr_pose_adam_step(P, P, P, P, P, P, P, P, P, P, 1, f(0.1), f(5.0), f(1.0), f(0.999), f(1e-8), 1,
+                                 None) != 0
+    assert b"Adam" in c.ddrr_last_error()
+    assert c.ddrr_pose_adam_step(P, P, P, P, P, P, P, P, P, P, 0, f(0.1), f(5.0), f(0.9), f(0.999), f(1e-8), 1,
+                                 None) == 0  # no poses
     # the record alone: out may be NULL only together with aux
     assert c.ddrr_siddon_forward_bricks(P, 4, 4, 4, P, P, P, 1, 4, 5, f(0.5), f(1e-8), None, None,
                                         f(0.0), 0, None, 0, P, None) != 0

@@ -1133,3 +1133,8 @@ def test_fused_ncc_step(gpu):
     """ddrr_pose_raygen_forward / ddrr_siddon_ncc_forward / ddrr_siddon_ncc_backward_pose through
     DRR.ncc against the launches they fuse."""
     conftest.check_fused_ncc_step(gpu)
+
+
+@pytest.mark.gpu
+def test_pose_adam_matches_torch_adam(gpu):
+    conftest.check_pose_adam(gpu)

@@ -1040,3 +1040,7 @@ def test_fused_ncc_step_on_the_host(emulated_ops):
     """DRR.ncc through the host build of the entries it fuses (tests/emu): the Python / autograd
     wiring; the GPU twin checks the kernels (tests/test_gpu_parity.py)."""
     conftest.check_fused_ncc_step("cpu")
+
+
+def test_pose_adam_matches_torch_adam_on_the_host_twin(emulated_ops):
+    conftest.check_pose_adam("cpu")

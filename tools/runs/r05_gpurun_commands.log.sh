@@ -182,3 +182,6 @@ EOF
 
 # ---------------------------------------------------------------- 2026-09-27T03:21:08Z  round 5 evidence pass 3 (guard at 12x, marcher work): GPU tests, smoke, default bench line, configs 2-5, rocprofv3 stats + PMC traffic, issue-bound counters
 OUT=gpurun_out/r05z3; mkdir -p $OUT; (timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -6) > $OUT/gpu_tests.txt; tail -2 $OUT/gpu_tests.txt; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids > $OUT/smoke.txt; tail -3 $OUT/smoke.txt; timeout 900 python bench.py > $OUT/bench_config_headline.json 2> $OUT/bench_headline.err; grep "\[bench\]" $OUT/bench_headline.err | cut -c1-170; for c in 2 3 4 5; do timeout 600 python bench.py --config $c > $OUT/bench_config_$c.json 2> $OUT/c$c.err; grep "config $c:" $OUT/c$c.err | cut -c1-140; done; timeout 900 bash tools/prof_bench.sh $OUT/prof > $OUT/rocprof_bench.txt 2>&1; head -6 $OUT/rocprof_bench.txt | cut -c1-150; cp $OUT/prof/traffic.json $OUT/traffic.json 2>/dev/null; find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/rocprof_bench_kernel_stats.csv; cp $OUT/prof/bench_line_under_trace.json $OUT/ 2>/dev/null; rm -rf $OUT/prof; ls $OUT | wc -l
+
+# ---------------------------------------------------------------- 2026-09-27T03:27:24Z  timeline of a registration iteration inside its graph
+cd /tmp && TMPDIR=/tmp timeout 300 rocprofv3 --kernel-trace -d /tmp/g4 -o x --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --config 4 --no-cpu-baseline > /dev/null 2>&1; cd $GRAFT_REPO_ROOT; python tools/graph_timeline.py /tmp/g4 | tee gpurun_out/graph_timeline.txt
