@@ -48,7 +48,8 @@ struct BrickArgs {
     int *order_ws;                // ... this launch's workspace for it: order_cap weights, order_cap ints
     int order_cap;
     float *clear;                 // host side of bricks_fwd.hip: floats to zero in front of the launch (or NULL) ...
-    long clear_n;                 // ... so many, by the launch that zeroes the brick counter (brick_clear_kernel)
+    long clear_n;                 // ... so many, by the launch that zeroes the brick counter (brick_clear_kernel);
+                                  // -1: the caller has cleared them and the counter (DDRR_BRICKS_CLEARED)
     unsigned *brick_times;        // profiling builds: duration of every brick (10 ns ticks), or NULL
     int split_t, split_s;         // ... the last split_t bricks are handed out in split_s pose parts
 };

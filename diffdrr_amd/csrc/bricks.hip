@@ -1299,6 +1299,9 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const long R = (long)B * N;
+    // (DDRR_BRICKS_CLEARED: the record / image and the brick counter are zero already)
+    const bool cleared = (ranges_valid & DDRR_BRICKS_CLEARED) != 0;
+    ranges_valid &= 1;
     const bool packed = aux && record_vmax > 0.f;
     // (the packed record's planes 5, 6 are written by record_prepare_kernel)
     const size_t fill = !aux ? (size_t)R : (packed ? (size_t)R * 5 : (size_t)rec_blocked_floats(R));
@@ -1306,7 +1309,7 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     // counter, by one launch: launch_fwd_bricks)
     float rec_q = 0.f;
     if (packed) {
-        const hipError_t e = hipMemsetAsync(aux, 0, sizeof(float) * fill, st);
+        const hipError_t e = cleared ? hipSuccess : hipMemsetAsync(aux, 0, sizeof(float) * fill, st);
         if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
         rec_q = record_scale(record_vmax, Dims{dx, dy, dz});
         hipLaunchKernelGGL(record_prepare_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
@@ -1318,7 +1321,8 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                                    brick_ranges, ranges_valid, volume, dx, dy, dz,
                                    source, target, img, B, det_h, det_w, voxel_shift, eps, out, aux,
                                    rec_q, st, launch_ws, "ddrr_siddon_forward_bricks",
-                                   packed ? nullptr : (aux ? aux : out), packed ? 0 : (long)fill))
+                                   packed || cleared ? nullptr : (aux ? aux : out),
+                                   cleared ? -1 : (packed ? 0 : (long)fill)))
         return rc;
     if (!aux) return 0;
     if (out)

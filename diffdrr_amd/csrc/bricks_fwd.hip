@@ -1443,7 +1443,9 @@ int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t
     // or the record by brick_clear_kernel, or by a memset)
     const bool ordered = order_bricks(q, C::BX, C::BY, C::BZ, nby, nbz, n_bricks, slots, st, true);
     const bool clear_here = p.clear && p.clear_n > 0;
-    if (clear_here && (reinterpret_cast<uintptr_t>(p.clear) & 15) == 0) {
+    if (p.clear_n < 0) {
+        // (the caller has cleared the image / record and the counter: DDRR_BRICKS_CLEARED)
+    } else if (clear_here && (reinterpret_cast<uintptr_t>(p.clear) & 15) == 0) {
         const long blocks = (p.clear_n / 4 + 255) / 256;
         hipLaunchKernelGGL(brick_clear_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks))),
                            dim3(256), 0, st, p.clear, p.clear_n, ordered ? nullptr : q.work);
@@ -1492,7 +1494,8 @@ int launch_sq(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t 
         // (the shared-ring variants have no fp32 path: tools builds only)
     }
     const dim3 grid(n_bricks < slots ? n_bricks : slots), block(C::THREADS);
-    if (hipMemsetAsync(p.work, 0, 4 * sizeof(int), st) != hipSuccess) return fail(-1, "hipMemsetAsync");
+    if (p.clear_n >= 0 && hipMemsetAsync(p.work, 0, 4 * sizeof(int), st) != hipSuccess)
+        return fail(-1, "hipMemsetAsync");
     if (p.clear && p.clear_n > 0 &&
         hipMemsetAsync(p.clear, 0, sizeof(float) * (size_t)p.clear_n, st) != hipSuccess)
         return fail(-1, "hipMemsetAsync");

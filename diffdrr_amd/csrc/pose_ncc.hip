@@ -195,9 +195,19 @@ __global__ __launch_bounds__(kBlock) void pose_raygen_fwd_kernel(
     const float *__restrict__ rot, const float *__restrict__ xyz, int a0, int a1, int a2,
     const float *__restrict__ Ro, const float *__restrict__ Ainv, const float *__restrict__ P, int N,
     float *__restrict__ Mw, float *__restrict__ source_v, float *__restrict__ target_v,
-    float *__restrict__ img) {
+    float *__restrict__ img, float *__restrict__ clear, long clear_n, int *__restrict__ counter) {
     __shared__ float Ms[12];
     const int b = blockIdx.y, n = blockIdx.x * kBlock + threadIdx.x;
+    // what the render behind this launch has to find zeroed (its record or image, its brick
+    // counter): cleared here instead of by a launch of its own
+    if (clear) {
+        const long stride = (long)gridDim.x * gridDim.y * kBlock, n4 = clear_n >> 2;
+        float4 *c4 = reinterpret_cast<float4 *>(clear);
+        const long first = ((long)blockIdx.y * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+        for (long i = first; i < n4; i += stride) c4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (first < (clear_n & 3)) clear[(n4 << 2) + first] = 0.f;
+    }
+    if (counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) counter[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         // (once per workgroup: three sincos and a few dozen fma)
         const float th[3] = {rot[b * 3], rot[b * 3 + 1], rot[b * 3 + 2]};
@@ -290,13 +300,17 @@ __global__ __launch_bounds__(kBlock) void siddon_ncc_fwd_kernel(
         for (int w = 0; w < kWavesPerBlock; ++w) v += red[threadIdx.x][w];
         atomicAdd(ws.mom + b * 5 + threadIdx.x, v);
     }
-    if (!last_workgroup_of_pose(ws.tick1 + b, &last) || threadIdx.x != 0) return;
+    if (!last_workgroup_of_pose(ws.tick1 + b, &last)) return;
+    // (the five sums by five lanes: one round trip to the coherence point, not five in a row)
+    if (threadIdx.x < 5) {
+        red[threadIdx.x][0] = atomicAdd(ws.mom + b * 5 + threadIdx.x, 0.0);  // (a coherent read)
+        ws.mom[b * 5 + threadIdx.x] = 0.0;                                    // left zero for the next call
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     double t[5];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        t[k] = atomicAdd(ws.mom + b * 5 + k, 0.0);  // (a coherent read)
-        ws.mom[b * 5 + k] = 0.0;                    // left zero for the next call
-    }
+    for (int k = 0; k < 5; ++k) t[k] = red[k][0];
     ws.tick1[b] = 0;
     const double inv_n = 1.0 / (double)N;
     const double mu1 = t[0] * inv_n, mu2 = t[1] * inv_n;
@@ -332,20 +346,37 @@ __global__ __launch_bounds__(kBlock) void siddon_ncc_bwd_pose_kernel(
     float acc[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    // a thread's rays of the workgroup's kStepRaysPerBlock: everything they read is requested before
+    // the first is worked on (one round trip to memory, not one per ray); a ray beyond the image
+    // re-reads the last one with weight 0
+    constexpr int kPer = kStepRaysPerBlock / kBlock;
     const int n_end = min(N, (int)(blockIdx.x + 1) * kStepRaysPerBlock);
-    for (int n = blockIdx.x * kStepRaysPerBlock + threadIdx.x; n < n_end; n += kBlock) {
+    float rec[kPer][SIDDON_AUX], Ls[kPer], x1s[kPer], ts[kPer][3], Ps[kPer][3];
+    bool in[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int n0 = blockIdx.x * kStepRaysPerBlock + threadIdx.x + k * kBlock;
+        in[k] = n0 < n_end;
+        const int n = in[k] ? n0 : n_end - 1;
         const long r = (long)b * N + n;
-        float rec[SIDDON_AUX];
-        rec_blocked_load(aux, r, rec);
-        const float L = img[r];
+        rec_blocked_load(aux, r, rec[k]);
+        Ls[k] = img[r];
+        x1s[k] = x1[b * x1_stride + n];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            ts[k][a] = target_v[r * 3 + a];
+            Ps[k][a] = P[n * 3 + a];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const float L = Ls[k];
         // d ncc / d x2[n] (= ncc_bwd_kernel on x2 = L I)
-        const float z1 = (x1[b * x1_stride + n] - mu1) / s1, z2 = (L * rec[0] - mu2) / s2;
-        const float g = gn * (z1 - z2 * ncc) / s2;
-        const float t[3] = {target_v[r * 3], target_v[r * 3 + 1], target_v[r * 3 + 2]};
-        const float Pn[3] = {P[n * 3], P[n * 3 + 1], P[n * 3 + 2]};
+        const float z1 = (x1s[k] - mu1) / s1, z2 = (L * rec[k][0] - mu2) / s2;
+        const float g = in[k] ? gn * (z1 - z2 * ncc) / s2 : 0.f;
         float gs[3], gt[3];
-        siddon_backward_ray<REDUCE_SUM>(rec, s, t, eps, g * L, gs, gt);
-        raygen_ray_adjoint(M, Ainv, Pn, gt, gs, with_img_path ? g * rec[0] : 0.f, L, acc);
+        siddon_backward_ray<REDUCE_SUM>(rec[k], s, ts[k], eps, g * L, gs, gt);
+        raygen_ray_adjoint(M, Ainv, Ps[k], gt, gs, with_img_path ? g * rec[k][0] : 0.f, L, acc);
     }
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
@@ -364,14 +395,18 @@ __global__ __launch_bounds__(kBlock) void siddon_ncc_bwd_pose_kernel(
         for (int w = 0; w < kWavesPerBlock; ++w) v += red[w][threadIdx.x];
         unsafeAtomicAdd(ws.gacc + (long)b * 12 + threadIdx.x, v);
     }
-    if (!last_workgroup_of_pose(ws.tick2 + b, &last) || threadIdx.x != 0) return;
+    if (!last_workgroup_of_pose(ws.tick2 + b, &last)) return;
     // the last workgroup of the pose: dLoss/dMw -> dLoss/d(rot, xyz) (= pose_euler_bwd_kernel)
+    // (the twelve sums by twelve lanes: one round trip to the coherence point, not twelve in a row)
+    if (threadIdx.x < 12) {
+        red[0][threadIdx.x] = atomicAdd(ws.gacc + (long)b * 12 + threadIdx.x, 0.f);  // (a coherent read)
+        ws.gacc[(long)b * 12 + threadIdx.x] = 0.f;                                    // left zero for the next call
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     float g[12], gth[3], gx[3];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        g[k] = atomicAdd(ws.gacc + (long)b * 12 + k, 0.f);  // (a coherent read)
-        ws.gacc[(long)b * 12 + k] = 0.f;                     // left zero for the next call
-    }
+    for (int k = 0; k < 12; ++k) g[k] = red[0][k];
     ws.tick2[b] = 0;
     const float th[3] = {rot[b * 3], rot[b * 3 + 1], rot[b * 3 + 2]};
     const float tr[3] = {xyz[b * 3], xyz[b * 3 + 1], xyz[b * 3 + 2]};
@@ -626,16 +661,23 @@ static int check_axes(int a0, int a1, int a2) {
 
 int ddrr_pose_raygen_forward(const float *rot, const float *xyz, int a0, int a1, int a2,
                              const float *reorient34, const float *Ainv, const float *P, int B, int N,
-                             float *Mw, float *source_v, float *target_v, float *img, void *stream) {
+                             float *Mw, float *source_v, float *target_v, float *img, float *clear,
+                             long clear_floats, void *clear_launch_ws, void *stream) {
     if (!rot || !xyz || !reorient34 || !Ainv || !P || !Mw || !source_v || !target_v || !img)
         return fail(-1, "null pointer");
     if (int rc = check_axes(a0, a1, a2)) return rc;
     if (B < 0 || N < 0) return fail(-1, "negative batch or ray count");
+    if (clear_floats < 0 || (clear_floats > 0 && !clear)) return fail(-1, "clear_floats without a buffer");
+    if ((reinterpret_cast<uintptr_t>(clear) & 15) || (reinterpret_cast<uintptr_t>(clear_launch_ws) & 15))
+        return fail(-1, "the buffers to clear must be 16-byte aligned");
+    if ((clear_floats > 0 || clear_launch_ws) && (B == 0 || N == 0))
+        return fail(-1, "nothing is launched for an empty batch: clear the buffers yourself");
     if (B == 0 || N == 0) return 0;
     if (B > 65535) return fail(-1, "at most 65535 poses per call");
     const dim3 grid((N + kBlock - 1) / kBlock, B), block(kBlock);
     hipLaunchKernelGGL(pose_raygen_fwd_kernel, grid, block, 0, (hipStream_t)stream, rot, xyz, a0, a1,
-                       a2, reorient34, Ainv, P, N, Mw, source_v, target_v, img);
+                       a2, reorient34, Ainv, P, N, Mw, source_v, target_v, img, clear_floats > 0 ? clear : nullptr,
+                       clear_floats, reinterpret_cast<int *>(clear_launch_ws));
     return finish("ddrr_pose_raygen_forward");
 }
 

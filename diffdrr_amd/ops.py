@@ -310,8 +310,14 @@ def brick_ranges(volume):
     return brick_workspace(volume, "q16")
 
 
+def brick_record_buffer(B, N, device):
+    """The (uninitialised) blocked float record of a brick launch of B x N rays."""
+    return torch.empty(record_blocks(B, N), _lib.REC_BLOCK_FLOATS, dtype=torch.float32, device=device)
+
+
 def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, eps=1e-8,
-                          want_aux=False, record_vmax=0.0, storage="f32", want_image=True):
+                          want_aux=False, record_vmax=0.0, storage="f32", want_image=True,
+                          aux=None, launch_ws=None, cleared=False):
     """Detector-grid Siddon (sum) through the volume-stationary brick kernel: every 32^3
     brick is staged in LDS once and all rays of all poses are traced through it.
     Requires the targets to be the affine detector grid DRR builds.
@@ -321,7 +327,10 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
     instead of 5, bit-reproducible; csrc/record_pack.h).
     ``storage``: "f32" stages the volume's own values in 32^3 bricks, "q16" a 16-bit block
     quantisation in 32 x 32 x 64 bricks, "q16p" the same bricks from a packed copy kept in the
-    cached workspace (include/diffdrr_hip.h DDRR_BRICKS_*)."""
+    cached workspace (include/diffdrr_hip.h DDRR_BRICKS_*).
+    ``aux`` / ``launch_ws``: a record (:func:`brick_record_buffer`) and a launch workspace
+    (:func:`launch_workspace`) the caller brings along; ``cleared``: both are zero already
+    (:func:`pose_raygen_forward` did it in its launch) -- the call then clears nothing."""
     B, N = _check_rays(volume, source, target, img)
     H, W = int(det[0]), int(det[1])
     if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
@@ -334,19 +343,24 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
     out = torch.empty(B, N, dtype=torch.float32, device=volume.device) if (want_image or not want_aux) else None
     ranges, valid = brick_workspace(volume, storage) if storage != "f32" else (None, 0)
     packed = bool(want_aux and record_vmax and record_vmax > 0.0)
-    aux = None
-    if want_aux:
+    if cleared and (aux is None or launch_ws is None or packed or want_image or not want_aux):
+        raise ValueError("cleared=True: the float record and the launch workspace the caller cleared, no image")
+    if want_aux and aux is None:
         shape = (_lib.PACKED_AUX_PLANES, B, N) if packed else \
             (record_blocks(B, N), _lib.REC_BLOCK_FLOATS)
         aux = torch.empty(*shape, dtype=torch.float32, device=volume.device)
+    elif not want_aux:
+        aux = None
     if _empty(B, N):
         return out, aux
+    if launch_ws is None:
+        launch_ws = launch_workspace(volume.shape, volume.device)
     _launch(
         "ddrr_siddon_forward_bricks", volume.device, volume.data_ptr(), *volume.shape,
         source.data_ptr(), target.data_ptr(), _ptr(img), B, H, W, float(voxel_shift), float(eps),
         _ptr(out), _ptr(aux), float(record_vmax) if packed else 0.0,
-        _BRICK_STORAGE[storage], _ptr(ranges), int(valid),
-        launch_workspace(volume.shape, volume.device).data_ptr())
+        _BRICK_STORAGE[storage], _ptr(ranges), int(valid) | (_lib.BRICKS_CLEARED if cleared else 0),
+        launch_ws.data_ptr())
     if storage != "f32" and not valid:
         brick_workspace_commit(volume, storage)
     return out, aux
@@ -509,9 +523,11 @@ def siddon_ncc_workspace(B, device):
     return ws
 
 
-def pose_raygen_forward(rot, xyz, axes, reorient34, Ainv, P):
+def pose_raygen_forward(rot, xyz, axes, reorient34, Ainv, P, *, clear=None, clear_launch_ws=None):
     """pose_euler_forward + raygen_forward in one launch -> (Mw (B,3,4), source_v (B,1,3),
-    target_v (B,N,3), img (B,N))."""
+    target_v (B,N,3), img (B,N)).  ``clear`` (a float32 tensor) and ``clear_launch_ws`` (the launch
+    workspace of the render that follows) are zeroed by the same launch: hand them to
+    :func:`siddon_forward_bricks` with ``cleared=True``."""
     _require_gpu(rot)
     B, N = rot.shape[0], P.shape[0]
     rot, xyz, reorient34, Ainv, P = (t.contiguous() for t in (rot, xyz, reorient34, Ainv, P))
@@ -523,7 +539,10 @@ def pose_raygen_forward(rot, xyz, axes, reorient34, Ainv, P):
     if not _empty(B, N):
         _launch("ddrr_pose_raygen_forward", dev, rot.data_ptr(), xyz.data_ptr(), *axes,
                 reorient34.data_ptr(), Ainv.data_ptr(), P.data_ptr(), B, N, Mw.data_ptr(),
-                source.data_ptr(), target.data_ptr(), img.data_ptr())
+                source.data_ptr(), target.data_ptr(), img.data_ptr(), _ptr(clear),
+                0 if clear is None else clear.numel(), _ptr(clear_launch_ws))
+    elif clear is not None or clear_launch_ws is not None:
+        raise ValueError("pose_raygen_forward: nothing is launched for an empty batch, nothing is cleared")
     return Mw, source, target, img
 
 

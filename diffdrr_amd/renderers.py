@@ -468,10 +468,18 @@ class _EulerSiddonNccFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rot, xyz, volume, reorient34, P, Ainv, fixed, axes, cfg, ncc_eps):
-        Mw, source, target, img = ops.pose_raygen_forward(rot, xyz, axes, reorient34, Ainv, P)
-        _, aux = ops.siddon_forward_bricks(
+        # (the record and the brick counter of the render are cleared by the launch in front of it)
+        B, N = rot.shape[0], P.shape[0]
+        aux = ops.brick_record_buffer(B, N, rot.device)
+        launch_ws = ops.launch_workspace(volume.shape, volume.device)
+        some = B > 0 and N > 0  # (an empty batch launches nothing)
+        Mw, source, target, img = ops.pose_raygen_forward(rot, xyz, axes, reorient34, Ainv, P,
+                                                          clear=aux if some else None,
+                                                          clear_launch_ws=launch_ws if some else None)
+        ops.siddon_forward_bricks(
             volume, source, target, img, cfg["det"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
-            want_aux=True, storage=_brick_storage(volume, cfg), want_image=False)
+            want_aux=True, storage=_brick_storage(volume, cfg), want_image=False, aux=aux,
+            launch_ws=launch_ws, cleared=some)
         ncc, stats, _ = ops.siddon_ncc_forward(aux, img, fixed, ncc_eps)
         ctx.axes, ctx.cfg = axes, cfg
         ctx.save_for_backward(rot, xyz, reorient34, P, Ainv, fixed, Mw, source, target, img, aux, stats)

@@ -131,6 +131,10 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
  * trusts what an earlier call for the SAME volume contents and the same brick_storage left
  * there (a registration or a pose sweep renders one volume thousands of times) -- a caller
  * must only pass 1 after a call with 0 and B > 0 has returned 0 for these contents.
+ * ranges_valid | DDRR_BRICKS_CLEARED (ABI 30): the caller has already zeroed what the launch's atomics
+ * add to -- `aux` if given, else `out` -- AND the first 16 bytes of launch_ws (the brick counter),
+ * on this stream (ddrr_pose_raygen_forward can do both in its own launch): the call then clears
+ * nothing, one launch less in front of a render of a pose or two.
  * (A volume with only a few double bricks per CU balances badly: 256^3 is 6 % faster on fp32
  * bricks; the Python layer chooses, diffdrr_amd/renderers.py.)
  * Any volume shape and any float-aligned volume pointer take every brick_storage: the kernels
@@ -140,6 +144,7 @@ int ddrr_siddon_forward(const float *volume, int dx, int dy, int dz, const float
 #define DDRR_BRICKS_F32 0
 #define DDRR_BRICKS_Q16 1
 #define DDRR_BRICKS_Q16_PACKED 2
+#define DDRR_BRICKS_CLEARED 2 /* (a bit of ranges_valid) */
 long ddrr_brick_workspace_bytes(int dx, int dy, int dz, int brick_storage);
 long ddrr_brick_launch_workspace_bytes(int dx, int dy, int dz);
 int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
@@ -458,7 +463,13 @@ int ddrr_pose_euler_backward(const float *rot, const float *xyz, int a0, int a1,
  * notebooks/tutorials/registration.ipynb:240-316) is, at one pose, ~0.19 ms of brick kernel and
  * ~0.06 ms of small launches at ~4.4 us each.  Same arithmetic per element as the entries they fuse:
  *   ddrr_pose_raygen_forward      = ddrr_pose_euler_forward + ddrr_raygen_forward (Mw is still
- *                                   written: the backward reads it);
+ *                                   written: the backward reads it); since ABI 30 it can also clear
+ *                                   what the render behind it needs zeroed -- `clear`: clear_floats
+ *                                   floats (the record or image of ddrr_siddon_forward_bricks),
+ *                                   clear_launch_ws: that call's launch workspace (its brick
+ *                                   counter), either may be NULL; both 16-byte aligned -- which
+ *                                   is then told so (ranges_valid | DDRR_BRICKS_CLEARED): one
+ *                                   launch less in front of a one-pose render;
  *   ddrr_siddon_ncc_forward       = the image from the record (out = img * plane I; `out` may be
  *                                   NULL) + ddrr_ncc_forward, many workgroups per pair (moments
  *                                   by double atomics; the pair's last workgroup finishes `stats`);
@@ -474,7 +485,8 @@ int ddrr_pose_euler_backward(const float *rot, const float *xyz, int a0, int a1,
 long ddrr_siddon_ncc_workspace_bytes(int B);
 int ddrr_pose_raygen_forward(const float *rot, const float *xyz, int a0, int a1, int a2,
                              const float *reorient34, const float *Ainv, const float *P, int B, int N,
-                             float *Mw, float *source_v, float *target_v, float *img, void *stream);
+                             float *Mw, float *source_v, float *target_v, float *img, float *clear,
+                             long clear_floats, void *clear_launch_ws, void *stream);
 int ddrr_siddon_ncc_forward(const float *aux, const float *img, const float *x1, long x1_stride, int B,
                             int N, float eps, void *ws, float *ncc, float *stats, float *out,
                             void *stream);

@@ -378,6 +378,7 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                                int det_w, float voxel_shift, float eps, float *out, float *aux,
                                float record_vmax, int brick_storage, float *brick_ws,
                                int ranges_valid, void * /*launch_ws*/, void *) {
+    ranges_valid &= 1;  // (DDRR_BRICKS_CLEARED: the emulation clears its outputs anyway)
     const Dims D{dx, dy, dz};
     // workspace layout of the product (bricks_fwd.hip): header, (min, max) per brick, fallback
     // flags.  The emulation walks 32^3 bricks; like the product it TRUSTS a workspace handed
@@ -1441,7 +1442,12 @@ long ddrr_siddon_ncc_workspace_bytes(int B) { return B < 1 ? 0 : (long)B * (5 * 
 
 int ddrr_pose_raygen_forward(const float *rot, const float *xyz, int a0, int a1, int a2,
                              const float *reorient34, const float *Ainv, const float *P, int B, int N,
-                             float *Mw, float *source_v, float *target_v, float *img, void *st) {
+                             float *Mw, float *source_v, float *target_v, float *img, float *clear,
+                             long clear_floats, void *clear_launch_ws, void *st) {
+    if (clear_floats < 0 || (clear_floats > 0 && !clear)) return -1;
+    if ((clear_floats > 0 || clear_launch_ws) && (B == 0 || N == 0)) return -1;
+    if (clear_floats > 0) memset(clear, 0, sizeof(float) * (size_t)clear_floats);
+    if (clear_launch_ws) memset(clear_launch_ws, 0, 16);
     if (int rc = ddrr_pose_euler_forward(rot, xyz, a0, a1, a2, reorient34, B, Mw, st)) return rc;
     return ddrr_raygen_forward(Mw, Ainv, P, B, N, source_v, target_v, img, st);
 }

@@ -152,8 +152,12 @@ def test_argument_checks_return_errors_without_touching_a_device():
     # the fused registration step (ABI 29): the same checks as the entries it fuses
     L = ctypes.c_long
     assert c.ddrr_siddon_ncc_workspace_bytes(3) == 3 * 96 and c.ddrr_siddon_ncc_workspace_bytes(0) == 0
-    assert c.ddrr_pose_raygen_forward(P, P, 2, 2, 1, P, P, P, 1, 4, P, P, P, P, None) != 0
+    assert c.ddrr_pose_raygen_forward(P, P, 2, 2, 1, P, P, P, 1, 4, P, P, P, P, None, L(0), None, None) != 0
     assert b"Euler" in c.ddrr_last_error()
+    assert c.ddrr_pose_raygen_forward(P, P, 2, 0, 1, P, P, P, 1, 4, P, P, P, P, None, L(8), None, None) != 0
+    assert b"clear_floats" in c.ddrr_last_error()
+    assert c.ddrr_pose_raygen_forward(P, P, 2, 0, 1, P, P, P, 0, 4, P, P, P, P, P, L(8), None, None) != 0
+    assert b"empty batch" in c.ddrr_last_error()
     assert c.ddrr_siddon_ncc_forward(P, P, P, L(3), 1, 4, f(1e-5), P, P, P, None, None) != 0
     assert b"x1_stride" in c.ddrr_last_error()
     assert c.ddrr_siddon_ncc_forward(P, P, P, L(0), 1, 4, f(1e-5), None, P, P, None, None) != 0

@@ -185,3 +185,10 @@ OUT=gpurun_out/r05z3; mkdir -p $OUT; (timeout 1200 python -m pytest tests -m gpu
 
 # ---------------------------------------------------------------- 2026-09-27T03:27:24Z  timeline of a registration iteration inside its graph
 cd /tmp && TMPDIR=/tmp timeout 300 rocprofv3 --kernel-trace -d /tmp/g4 -o x --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --config 4 --no-cpu-baseline > /dev/null 2>&1; cd $GRAFT_REPO_ROOT; python tools/graph_timeline.py /tmp/g4 | tee gpurun_out/graph_timeline.txt
+
+# ---------------------------------------------------------------- 2026-09-27T03:34:00Z  one clear launch + PoseAdam: tests, config 4, timeline
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3; for f in "" "--torch-adam"; do timeout 300 python bench.py --config 4 --no-cpu-baseline $f > gpurun_out/c4$f.json 2> gpurun_out/c4$f.err; python - <<EOF
+import json
+d=json.load(open("gpurun_out/c4$f.json")); print("config 4 $f:", d["value"], d["ms_per_step"], d.get("registration"))
+EOF
+done; cd /tmp && TMPDIR=/tmp timeout 300 rocprofv3 --kernel-trace -d /tmp/g4 -o x --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --config 4 --no-cpu-baseline > /dev/null 2>&1; cd $GRAFT_REPO_ROOT; python tools/graph_timeline.py /tmp/g4 | tee gpurun_out/graph_timeline2.txt; timeout 200 python tools/storage_bench.py --scenes noise512 --poses 1,2,8,32 --storages q16p 2>&1 | grep -v amdgpu
