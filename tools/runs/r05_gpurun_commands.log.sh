@@ -192,3 +192,10 @@ import json
 d=json.load(open("gpurun_out/c4$f.json")); print("config 4 $f:", d["value"], d["ms_per_step"], d.get("registration"))
 EOF
 done; cd /tmp && TMPDIR=/tmp timeout 300 rocprofv3 --kernel-trace -d /tmp/g4 -o x --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --config 4 --no-cpu-baseline > /dev/null 2>&1; cd $GRAFT_REPO_ROOT; python tools/graph_timeline.py /tmp/g4 | tee gpurun_out/graph_timeline2.txt; timeout 200 python tools/storage_bench.py --scenes noise512 --poses 1,2,8,32 --storages q16p 2>&1 | grep -v amdgpu
+
+# ---------------------------------------------------------------- 2026-09-27T03:39:20Z  registration step without its clear launch: tests, config 4, timeline
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3; timeout 300 python bench.py --config 4 --no-cpu-baseline > gpurun_out/c4.json 2> gpurun_out/c4.err; python - <<EOF
+import json
+d=json.load(open("gpurun_out/c4.json")); print("config 4:", d["value"], d["ms_per_step"], d.get("registration"))
+EOF
+cd /tmp && rm -rf /tmp/g4 && TMPDIR=/tmp timeout 300 rocprofv3 --kernel-trace -d /tmp/g4 -o x --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --config 4 --no-cpu-baseline > /dev/null 2>&1; cd $GRAFT_REPO_ROOT; python tools/graph_timeline.py /tmp/g4 | tee gpurun_out/graph_timeline3.txt
