@@ -200,7 +200,7 @@ class DRR(nn.Module):
         finally:
             self.renderer.trust_detector_shape = False
 
-    FUSED_NCC_MAX_POSES = 16
+    FUSED_NCC_MAX_POSES = 32
 
     def ncc(self, fixed: torch.Tensor, rot: torch.Tensor, xyz: torch.Tensor, *,
             convention: str = "ZXY", degrees: bool = False, eps: float = 1e-5) -> torch.Tensor:
@@ -213,7 +213,7 @@ class DRR(nn.Module):
         whole step runs as three fused launches around it instead of nine (pose -> matrix -> rays;
         image from the backward record + NCC; NCC backward -> ray gradients -> matrix -> pose
         parameters: ``renderers._EulerSiddonNccFn``): 13 % of a one-pose registration iteration
-        (0.246 -> 0.213 ms; up to ``FUSED_NCC_MAX_POSES`` poses).
+        (0.246 -> 0.213 ms; up to ``FUSED_NCC_MAX_POSES`` poses per call).
         Anything else (no gradient wanted: the forward-only kernel is the faster one; other
         renderers, subsampling, patches, a volume that requires a gradient) composes the same
         result from ``forward`` and the NCC module."""
@@ -223,10 +223,11 @@ class DRR(nn.Module):
 
         B = rot.shape[0]
         r, det = self.renderer, self.detector
-        # (at most FUSED_NCC_MAX_POSES poses: beyond, the launches around the brick kernel are bound
-        # by their bytes, not by their count, and the fused ones -- a reduction tail per 1024 rays --
-        # are no faster: 16 poses 0.821 against 0.875 ms per eager step, 32 poses 1.480 against
-        # 1.463, profiles/r05/fused_step.txt)
+        # (at most FUSED_NCC_MAX_POSES poses: the launches around the brick kernel are bound by their
+        # bytes, not by their count, from a few dozen poses on -- 16 poses 0.821 against 0.875 ms per
+        # eager step; 32 poses 1.481 against 1.488 at 512^3, 0.721 against 0.751 at 256^3 since the
+        # epilogues' last workgroups read their sums in one round trip (1.480 against 1.463 before);
+        # not measured beyond: profiles/r05/fused_step.txt)
         ok = (torch.is_grad_enabled() and (rot.requires_grad or xyz.requires_grad)
               and B <= self.FUSED_NCC_MAX_POSES
               and self._fused_ok(False, {}, None) and isinstance(r, Siddon)

@@ -199,3 +199,14 @@ import json
 d=json.load(open("gpurun_out/c4.json")); print("config 4:", d["value"], d["ms_per_step"], d.get("registration"))
 EOF
 cd /tmp && rm -rf /tmp/g4 && TMPDIR=/tmp timeout 300 rocprofv3 --kernel-trace -d /tmp/g4 -o x --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --config 4 --no-cpu-baseline > /dev/null 2>&1; cd $GRAFT_REPO_ROOT; python tools/graph_timeline.py /tmp/g4 | tee gpurun_out/graph_timeline3.txt
+
+# ---------------------------------------------------------------- 2026-09-27T03:42:04Z  headline step: fused step at 32 poses again, after the epilogue work
+for f in "" "--fused-max-poses 64"; do timeout 300 python bench.py --no-configs --no-cpu-baseline --steps 300 $f > gpurun_out/h.json 2> gpurun_out/h.err; python - <<EOF
+import json
+d=json.load(open("gpurun_out/h.json")); print("headline [$f]:", round(d["value"]), d["ms_per_step"], d["roofline"]["kernel_ms"], [(k["kernel"].replace("ddrr_",""), round(k["kernel_ms"]*1e3,1)) for k in d.get("kernels",[])[1:8]])
+EOF
+done; for f in "" "--fused-max-poses 64"; do timeout 300 python bench.py --config 2 --no-cpu-baseline $f > gpurun_out/h.json 2> gpurun_out/h.err; python - <<EOF
+import json
+d=json.load(open("gpurun_out/h.json")); print("config 2 [$f]:", round(d["value"]), d["ms_per_step"], d["roofline"]["kernel_ms"])
+EOF
+done
