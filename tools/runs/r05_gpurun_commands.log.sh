@@ -210,3 +210,6 @@ import json
 d=json.load(open("gpurun_out/h.json")); print("config 2 [$f]:", round(d["value"]), d["ms_per_step"], d["roofline"]["kernel_ms"])
 EOF
 done
+
+# ---------------------------------------------------------------- 2026-09-27T03:43:32Z  round 5 evidence pass 4 (fused step to 32 poses, PoseAdam, clears merged): GPU tests, smoke, default bench line, configs 2-5, rocprofv3 stats + PMC traffic, issue-bound counters
+OUT=gpurun_out/r05z4; mkdir -p $OUT; (timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -6) > $OUT/gpu_tests.txt; tail -2 $OUT/gpu_tests.txt; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids > $OUT/smoke.txt; tail -3 $OUT/smoke.txt; timeout 900 python bench.py > $OUT/bench_config_headline.json 2> $OUT/bench_headline.err; grep "\[bench\]" $OUT/bench_headline.err | cut -c1-170 | head -12; for c in 2 3 4 5; do timeout 600 python bench.py --config $c > $OUT/bench_config_$c.json 2> $OUT/c$c.err; grep "config $c:" $OUT/c$c.err | cut -c1-140; done; timeout 900 bash tools/prof_bench.sh $OUT/prof > $OUT/rocprof_bench.txt 2>&1; head -14 $OUT/rocprof_bench.txt | cut -c1-150; cp $OUT/prof/traffic.json $OUT/traffic.json 2>/dev/null; find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/rocprof_bench_kernel_stats.csv; cp $OUT/prof/bench_line_under_trace.json $OUT/ 2>/dev/null; rm -rf $OUT/prof; ls $OUT | wc -l
