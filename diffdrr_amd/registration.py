@@ -59,6 +59,10 @@ class PoseAdam(torch.optim.Optimizer):
             raise ValueError("PoseAdam: negative learning rate")
         super().__init__([{"params": [rotation], "lr": lr_rotation}, {"params": [translation], "lr": lr_translation}],
                          dict(lr=lr_rotation, betas=betas, eps=eps, maximize=maximize))
+        # (the state exists from the start, not from the first step: a first step inside a graph
+        # capture would otherwise bake the zero-fills of its state into every replay)
+        for p in (rotation, translation):
+            self._state(p)
 
     def _state(self, p):
         st = self.state[p]
