@@ -213,3 +213,27 @@ done
 
 # ---------------------------------------------------------------- 2026-09-27T03:43:32Z  round 5 evidence pass 4 (fused step to 32 poses, PoseAdam, clears merged): GPU tests, smoke, default bench line, configs 2-5, rocprofv3 stats + PMC traffic, issue-bound counters
 OUT=gpurun_out/r05z4; mkdir -p $OUT; (timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -6) > $OUT/gpu_tests.txt; tail -2 $OUT/gpu_tests.txt; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids > $OUT/smoke.txt; tail -3 $OUT/smoke.txt; timeout 900 python bench.py > $OUT/bench_config_headline.json 2> $OUT/bench_headline.err; grep "\[bench\]" $OUT/bench_headline.err | cut -c1-170 | head -12; for c in 2 3 4 5; do timeout 600 python bench.py --config $c > $OUT/bench_config_$c.json 2> $OUT/c$c.err; grep "config $c:" $OUT/c$c.err | cut -c1-140; done; timeout 900 bash tools/prof_bench.sh $OUT/prof > $OUT/rocprof_bench.txt 2>&1; head -14 $OUT/rocprof_bench.txt | cut -c1-150; cp $OUT/prof/traffic.json $OUT/traffic.json 2>/dev/null; find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/rocprof_bench_kernel_stats.csv; cp $OUT/prof/bench_line_under_trace.json $OUT/ 2>/dev/null; rm -rf $OUT/prof; ls $OUT | wc -l
+
+# ---------------------------------------------------------------- 2026-09-27T03:48:50Z  PoseAdam in the graphed loop vs torch Adam eager
+timeout 400 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -k "graphed or adam" 2>&1 | tail -6
+
+# ---------------------------------------------------------------- 2026-09-27T03:49:11Z  PoseAdam graphed test: see the failure
+timeout 400 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -k "pose_adam" 2>&1 | grep -E "^E|assert" | head -12
+
+# ---------------------------------------------------------------- 2026-09-27T03:49:40Z  PoseAdam graphed test again
+timeout 400 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -k "pose_adam or graphed" 2>&1 | tail -4
+
+# ---------------------------------------------------------------- 2026-09-27T03:50:27Z  PoseAdam graphed test: failure details
+timeout 400 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -k "pose_adam" 2>&1 | grep -E "^E  " | head -8 | cut -c1-400
+
+# ---------------------------------------------------------------- 2026-09-27T03:50:48Z  PoseAdam graphed test: failure details
+timeout 400 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -k "pose_adam" 2>&1 | tail -30 | cut -c1-300
+
+# ---------------------------------------------------------------- 2026-09-27T03:51:13Z  PoseAdam graphed test with its neighbour
+for i in 1 2 3; do timeout 400 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -k "pose_adam or graphed" 2>&1 | grep -E "^E   |passed|failed" | head -6 | cut -c1-420; done
+
+# ---------------------------------------------------------------- 2026-09-27T03:51:52Z  PoseAdam graphed test, six iterations, five times
+for i in 1 2 3 4 5; do timeout 400 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -k "pose_adam or graphed" 2>&1 | grep -E "^E   |passed|failed" | head -4 | cut -c1-300; done
+
+# ---------------------------------------------------------------- 2026-09-27T03:52:33Z  PoseAdam graphed test, eight times
+for i in 1 2 3 4 5 6 7 8; do timeout 400 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -k "pose_adam or graphed" 2>&1 | grep -E "^E   |passed|failed" | head -3 | cut -c1-300; done
