@@ -702,6 +702,9 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
     ms_per_step = dt / steps * 1e3
     kernel_timing = ("HIP events around every launch of the dominant kernel inside the timed region (the "
                      f"step's other kernels: around every launch in {census_steps} further steps)")
+    if cfg in ("headline", "2") and "fused (" in str(extra.get("step", "")):
+        kernel_timing += ("; in the fused step the record and the brick counter are cleared by the launch in "
+                          "front of this one (ddrr_pose_raygen_forward), not by this entry")
     if cfg == "4" and not timer.events:
         # the timed region replayed a HIP graph: no launches went through the timer.  Time the
         # same forward (+ record) launches eagerly, after the fact
