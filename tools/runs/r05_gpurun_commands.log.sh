@@ -237,3 +237,6 @@ for i in 1 2 3 4 5; do timeout 400 python -m pytest tests/test_gpu_baseline_size
 
 # ---------------------------------------------------------------- 2026-09-27T03:52:33Z  PoseAdam graphed test, eight times
 for i in 1 2 3 4 5 6 7 8; do timeout 400 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -k "pose_adam or graphed" 2>&1 | grep -E "^E   |passed|failed" | head -3 | cut -c1-300; done
+
+# ---------------------------------------------------------------- 2026-09-27T03:55:29Z  final tree: full GPU suite + smoke
+mkdir -p gpurun_out/r05final; (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4) > gpurun_out/r05final/gpu_tests.txt; cat gpurun_out/r05final/gpu_tests.txt; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05final/smoke.txt | tail -3
