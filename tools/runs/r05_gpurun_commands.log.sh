@@ -240,3 +240,12 @@ for i in 1 2 3 4 5 6 7 8; do timeout 400 python -m pytest tests/test_gpu_baselin
 
 # ---------------------------------------------------------------- 2026-09-27T03:55:29Z  final tree: full GPU suite + smoke
 mkdir -p gpurun_out/r05final; (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4) > gpurun_out/r05final/gpu_tests.txt; cat gpurun_out/r05final/gpu_tests.txt; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05final/smoke.txt | tail -3
+
+# ---------------------------------------------------------------- 2026-09-27T03:57:19Z  module call cost at one pose
+timeout 400 python tools/module_call_bench.py 2>&1 | grep -v amdgpu
+
+# ---------------------------------------------------------------- 2026-09-27T03:57:48Z  module call cost at one pose (order check)
+timeout 400 python tools/module_call_bench.py 2>&1 | grep -v amdgpu
+
+# ---------------------------------------------------------------- 2026-09-27T03:58:17Z  module call cost (for the record)
+timeout 400 python tools/module_call_bench.py 2>&1 | grep -v amdgpu > gpurun_out/module_call.txt; cat gpurun_out/module_call.txt
