@@ -215,7 +215,7 @@ int brick_launch_resources(hipStream_t st, void *launch_ws, int dx, int dy, int 
 
 // The 32^3 fp32 launch path of bricks.hip (every mode); bricks_fwd.hip falls back to it.
 bool order_bricks(BrickArgs &q, int BX, int BY, int BZ, int nby, int nbz, int n_bricks, int slots,
-                  hipStream_t st, bool zero_counter = false);
+                  hipStream_t st, bool zero_counter = false, int min_poses = 8);
 int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const float *source,
                   const float *target, const float *img, const float *grad_out, int B, int det_h,
                   int det_w, float voxel_shift, float eps, float *out, float *aux,

@@ -1200,6 +1200,9 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     if (mode == BRICK_FWD || mode == BRICK_FWD_AUX || mode == BRICK_VOLGRAD || mode == BRICK_CHANNELS ||
         mode == BRICK_CHANNELS_AUX || mode == BRICK_CHANNELS_VOLGRAD)
         order_bricks(p, BRICK, BRICK, BRICK, bg.ny, bg.nz, n_bricks, n_cu_dev, st);
+    // (the marcher's volume gradient: owner bricks = the plain grid; a brick's walks are long
+    // whatever the pose count)
+    if (mode == BRICK_TRI_VOLGRAD) order_bricks(p, BRICK, BRICK, BRICK, bg.ny, bg.nz, n_bricks, n_cu_dev, st, false, 1);
     const dim3 grid(n_bricks < n_cu_dev ? n_bricks : n_cu_dev), block(kBrickThreads);
     if (mode == BRICK_TRI_FWD)
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_TRI_FWD>, grid, block, lds, st, p, out, aux);

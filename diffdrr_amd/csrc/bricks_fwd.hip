@@ -1525,8 +1525,8 @@ namespace ddrr_brick {
 // order workspace.  Not with fewer bricks than workgroups (nothing to order) or a handful of
 // poses (the launch is latency-bound and the two small kernels cost more than the order gains).
 bool order_bricks(BrickArgs &q, int BX, int BY, int BZ, int nby, int nbz, int n_bricks, int slots,
-                  hipStream_t st, bool zero_counter) {
-    if (!(q.order_ws && n_bricks <= q.order_cap && n_bricks > slots && !q.order && q.B >= 8)) return false;
+                  hipStream_t st, bool zero_counter, int min_poses) {
+    if (!(q.order_ws && n_bricks <= q.order_cap && n_bricks > slots && !q.order && q.B >= min_poses)) return false;
     float *weight = reinterpret_cast<float *>(q.order_ws);
     int *order = q.order_ws + q.order_cap;
     hipLaunchKernelGGL(brick_weight_kernel, dim3((n_bricks + 3) / 4), dim3(256), 0, st, q, BX, BY,

@@ -249,3 +249,9 @@ timeout 400 python tools/module_call_bench.py 2>&1 | grep -v amdgpu
 
 # ---------------------------------------------------------------- 2026-09-27T03:58:17Z  module call cost (for the record)
 timeout 400 python tools/module_call_bench.py 2>&1 | grep -v amdgpu > gpurun_out/module_call.txt; cat gpurun_out/module_call.txt
+
+# ---------------------------------------------------------------- 2026-09-27T04:00:21Z  marcher volume gradient: bricks handed out heaviest first
+python tools/trilinear_bench.py 2>&1 | grep "volume-grad"
+
+# ---------------------------------------------------------------- 2026-09-27T04:00:46Z  marcher volume gradient ordered: tests
+timeout 700 python -m pytest tests -m gpu -x -q -k "tri or march or Tri or volume" 2>&1 | tail -2; python bench.py --config 3 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print(d[\"value\"], d[\"ms_per_step\"])"
