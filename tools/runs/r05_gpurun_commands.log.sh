@@ -255,3 +255,6 @@ python tools/trilinear_bench.py 2>&1 | grep "volume-grad"
 
 # ---------------------------------------------------------------- 2026-09-27T04:00:46Z  marcher volume gradient ordered: tests
 timeout 700 python -m pytest tests -m gpu -x -q -k "tri or march or Tri or volume" 2>&1 | tail -2; python bench.py --config 3 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print(d[\"value\"], d[\"ms_per_step\"])"
+
+# ---------------------------------------------------------------- 2026-09-27T04:02:12Z  final tree: default bench line + config 3 + GPU suite + smoke
+OUT=gpurun_out/r05z5; mkdir -p $OUT; (timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4) > $OUT/gpu_tests.txt; tail -1 $OUT/gpu_tests.txt; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids > $OUT/smoke.txt; tail -1 $OUT/smoke.txt; timeout 900 python bench.py > $OUT/bench_config_headline.json 2> $OUT/bench_headline.err; grep "\[bench\] config headline:\|config 4:\|config 3:" $OUT/bench_headline.err | cut -c1-150; timeout 600 python bench.py --config 3 > $OUT/bench_config_3.json 2> $OUT/c3.err; grep "config 3:" $OUT/c3.err | cut -c1-140
