@@ -258,3 +258,6 @@ timeout 700 python -m pytest tests -m gpu -x -q -k "tri or march or Tri or volum
 
 # ---------------------------------------------------------------- 2026-09-27T04:02:12Z  final tree: default bench line + config 3 + GPU suite + smoke
 OUT=gpurun_out/r05z5; mkdir -p $OUT; (timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4) > $OUT/gpu_tests.txt; tail -1 $OUT/gpu_tests.txt; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids > $OUT/smoke.txt; tail -1 $OUT/smoke.txt; timeout 900 python bench.py > $OUT/bench_config_headline.json 2> $OUT/bench_headline.err; grep "\[bench\] config headline:\|config 4:\|config 3:" $OUT/bench_headline.err | cut -c1-150; timeout 600 python bench.py --config 3 > $OUT/bench_config_3.json 2> $OUT/c3.err; grep "config 3:" $OUT/c3.err | cut -c1-140
+
+# ---------------------------------------------------------------- 2026-09-27T04:06:53Z  final tree: extended randomised sweep (256 + 64 smooth cases, new seeds)
+mkdir -p gpurun_out/r05x; (timeout 900 python tools/fuzz_bricks.py --cases 256 --seed 9; timeout 600 python tools/fuzz_bricks.py --cases 64 --seed 10 --smooth) 2>&1 | grep -v amdgpu.ids > gpurun_out/r05x/fuzz_bricks.txt; grep -n "worst" gpurun_out/r05x/fuzz_bricks.txt | cut -c1-400; grep -c "<<<" gpurun_out/r05x/fuzz_bricks.txt
