@@ -118,6 +118,12 @@ class DRR(nn.Module):
         if (fused and parameterization == "euler_angles" and len(args) == 2
                 and all(torch.is_tensor(a) and a.dim() == 2 and a.shape[-1] == 3
                         and a.dtype == torch.float32 and ops.on_device(a) for a in args)):
+            if (not mask_to_channels and calibration is None and not kwargs
+                    and not (torch.is_grad_enabled() and (args[0].requires_grad or args[1].requires_grad
+                                                          or self.density.requires_grad))):
+                img = self._render_euler_inference(args[0], args[1], convention, degrees)
+                if img is not None:
+                    return self.reshape_transform(img, batch_size=len(args[0]))
             # pose parameters -> world matrix in one kernel (pose.py euler_world_pose)
             Mw = euler_world_pose(args[0], args[1], convention, self.detector._reorient,
                                   degrees=degrees)
@@ -199,6 +205,45 @@ class DRR(nn.Module):
                                               **kwargs)
         finally:
             self.renderer.trust_detector_shape = False
+
+    def _render_euler_inference(self, rot, xyz, convention, degrees):
+        """The everyday call -- ``drr(rot, xyz, parameterization="euler_angles")`` with nothing to
+        differentiate -- in TWO launches: pose -> matrix -> rays (which also clears the image and
+        the brick counter of the render behind it), and the brick kernel.  The same kernels'
+        arithmetic as the differentiable path (four launches: pose, rays, clear, render); None
+        where that path does not apply (then the caller takes the usual one)."""
+        from .pose import _AXIS, _check_convention
+        from .renderers import _brick_storage
+
+        r, det = self.renderer, self.detector
+        B = rot.shape[0]
+        if not (isinstance(r, Siddon) and r.grid_path == "bricks" and not r.packed_record and B > 0
+                and rot.shape == xyz.shape and rot.device == self.density.device == xyz.device):
+            return None
+        _check_convention(convention)
+        if degrees:
+            rot = rot / 180 * math.pi
+        axes = tuple(_AXIS[c] for c in convention)
+        key = getattr(self, "_P_key", None)
+        if key is None or key[0] is not det._calibration or key[1] != det._calibration._version \
+                or key[2] is not det.target or key[3] != det.target._version:
+            self._P_cache = det.calibration(det.target)[0].detach()
+            self._P_key = (det._calibration, det._calibration._version, det.target, det.target._version)
+        P = self._P_cache
+        Ainv = self._affine_inverse[0, :3, :] if self._affine_inverse.dim() == 3 \
+            else self._affine_inverse[:3, :]
+        cfg = r._cfg(False, det=(det.height, det.width))
+        with torch.no_grad():
+            out = torch.empty(B, P.shape[0], dtype=torch.float32, device=rot.device)
+            launch_ws = ops.launch_workspace(self.density.shape, self.density.device)
+            _, source, target, img = ops.pose_raygen_forward(
+                rot.detach(), xyz.detach(), axes, det._reorient[:3, :].contiguous(), Ainv, P, clear=out,
+                clear_launch_ws=launch_ws)
+            ops.siddon_forward_bricks(self.density.detach(), source, target, img, cfg["det"],
+                                      voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
+                                      storage=_brick_storage(self.density, cfg), out=out, launch_ws=launch_ws,
+                                      cleared=True)
+        return out.unsqueeze(1)
 
     FUSED_NCC_MAX_POSES = 32
 

@@ -317,7 +317,7 @@ def brick_record_buffer(B, N, device):
 
 def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, eps=1e-8,
                           want_aux=False, record_vmax=0.0, storage="f32", want_image=True,
-                          aux=None, launch_ws=None, cleared=False):
+                          aux=None, out=None, launch_ws=None, cleared=False):
     """Detector-grid Siddon (sum) through the volume-stationary brick kernel: every 32^3
     brick is staged in LDS once and all rays of all poses are traced through it.
     Requires the targets to be the affine detector grid DRR builds.
@@ -328,9 +328,11 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
     ``storage``: "f32" stages the volume's own values in 32^3 bricks, "q16" a 16-bit block
     quantisation in 32 x 32 x 64 bricks, "q16p" the same bricks from a packed copy kept in the
     cached workspace (include/diffdrr_hip.h DDRR_BRICKS_*).
-    ``aux`` / ``launch_ws``: a record (:func:`brick_record_buffer`) and a launch workspace
-    (:func:`launch_workspace`) the caller brings along; ``cleared``: both are zero already
-    (:func:`pose_raygen_forward` did it in its launch) -- the call then clears nothing."""
+    ``aux`` / ``out`` / ``launch_ws``: a record (:func:`brick_record_buffer`) or an image (B, N) and a
+    launch workspace (:func:`launch_workspace`) the caller brings along; ``cleared``: what the
+    launch's atomics add to (the record if one is wanted, else the image) and the workspace's
+    counter are zero already (:func:`pose_raygen_forward` did it in its launch) -- the call then
+    clears nothing."""
     B, N = _check_rays(volume, source, target, img)
     H, W = int(det[0]), int(det[1])
     if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
@@ -340,11 +342,17 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
     volume, source, target = volume.contiguous(), source.contiguous(), target.contiguous()
     img = None if img is None else img.contiguous()
     # (want_image = False with want_aux: the record alone -- siddon_ncc_forward forms the image)
-    out = torch.empty(B, N, dtype=torch.float32, device=volume.device) if (want_image or not want_aux) else None
+    need_out = want_image or not want_aux
+    if out is not None and (not need_out or out.shape != (B, N) or out.dtype != torch.float32
+                            or not out.is_contiguous() or out.device != volume.device):
+        raise ValueError("out: a contiguous float32 (B, N) image on the volume's device, where one is written")
+    if need_out and out is None:
+        out = torch.empty(B, N, dtype=torch.float32, device=volume.device)
     ranges, valid = brick_workspace(volume, storage) if storage != "f32" else (None, 0)
     packed = bool(want_aux and record_vmax and record_vmax > 0.0)
-    if cleared and (aux is None or launch_ws is None or packed or want_image or not want_aux):
-        raise ValueError("cleared=True: the float record and the launch workspace the caller cleared, no image")
+    if cleared and (launch_ws is None or packed or (want_aux and (aux is None or want_image))):
+        raise ValueError("cleared=True: the float record (no image with it) or the image, and the launch "
+                         "workspace, as the caller cleared them")
     if want_aux and aux is None:
         shape = (_lib.PACKED_AUX_PLANES, B, N) if packed else \
             (record_blocks(B, N), _lib.REC_BLOCK_FLOATS)

@@ -665,6 +665,42 @@ def check_filter_intersections_outside_volume(device):
         assert rel_err(g[f"filtered_{k}_f64"], g[f"default_{k}_f64"]) < 1e-12
 
 
+def check_euler_inference_path(device):
+    """``drr(rot, xyz, parameterization="euler_angles")`` with nothing to differentiate takes two
+    launches (DRR._render_euler_inference: pose -> matrix -> rays + the clears, the brick kernel);
+    with a gradient wanted it takes the differentiable path (pose, rays, clear, render): the same
+    kernels' arithmetic, so the images agree to the atomics' order of summation -- in radians and
+    degrees, for every brick storage, and through ``convert`` + ``drr(pose)`` (reference
+    drr.py:155-188)."""
+    import torch
+
+    from diffdrr_amd import DRR, convert
+    from diffdrr_amd.data import synthetic_subject
+
+    drr = DRR(synthetic_subject(40, kind="phantom", seed=3), sdd=600.0, height=30, width=26, delx=3.0).to(device)
+    g = torch.Generator().manual_seed(9)
+    rot = ((torch.rand(3, 3, generator=g) - 0.5) * 0.8).to(device)
+    xyz = (torch.tensor([0.0, 400.0, 0.0]) + (torch.rand(3, 3, generator=g) - 0.5) * 20).to(device)
+    calls = []
+    orig = drr._render_euler_inference
+    drr._render_euler_inference = lambda *a: calls.append(1) or orig(*a)
+    for storage in ("f32", "q16", "q16p"):
+        drr.renderer.brick_storage = storage
+        with torch.no_grad():
+            fast = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+            fast_deg = drr(rot * 180 / torch.pi, xyz, parameterization="euler_angles", convention="ZXY", degrees=True)
+            via_pose = drr(convert(rot, xyz, parameterization="euler_angles", convention="ZXY"))
+        n = len(calls)
+        slow = drr(rot.clone().requires_grad_(), xyz, parameterization="euler_angles", convention="ZXY")
+        assert len(calls) == n and slow.requires_grad and not fast.requires_grad
+        scale = float(slow.detach().abs().max())
+        assert fast.shape == slow.shape == (3, 1, 30, 26) and scale > 0
+        assert float((fast - slow.detach()).abs().max()) <= 2e-6 * scale, storage
+        assert float((fast_deg - fast).abs().max()) <= 2e-5 * scale
+        assert float((via_pose - fast).abs().max()) <= 2e-5 * scale
+    assert len(calls) == 6  # (both no-grad calls of every storage)
+
+
 def check_pose_adam(device):
     """``PoseAdam`` (ddrr_pose_adam_step: both pose parameter groups in one launch) against
     ``torch.optim.Adam`` with the same two groups -- the optimizer of the reference's registration

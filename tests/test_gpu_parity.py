@@ -1136,5 +1136,10 @@ def test_fused_ncc_step(gpu):
 
 
 @pytest.mark.gpu
+def test_euler_inference_path(gpu):
+    conftest.check_euler_inference_path(gpu)
+
+
+@pytest.mark.gpu
 def test_pose_adam_matches_torch_adam(gpu):
     conftest.check_pose_adam(gpu)

@@ -1042,5 +1042,9 @@ def test_fused_ncc_step_on_the_host(emulated_ops):
     conftest.check_fused_ncc_step("cpu")
 
 
+def test_euler_inference_path_on_the_host_twin(emulated_ops):
+    conftest.check_euler_inference_path("cpu")
+
+
 def test_pose_adam_matches_torch_adam_on_the_host_twin(emulated_ops):
     conftest.check_pose_adam("cpu")
