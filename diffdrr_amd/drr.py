@@ -239,7 +239,8 @@ class DRR(nn.Module):
             _, source, target, img = ops.pose_raygen_forward(
                 rot.detach(), xyz.detach(), axes, det._reorient[:3, :].contiguous(), Ainv, P, clear=out,
                 clear_launch_ws=launch_ws)
-            ops.siddon_forward_bricks(self.density.detach(), source, target, img, cfg["det"],
+            # (the density tensor itself: its packed bricks are cached per tensor object and version)
+            ops.siddon_forward_bricks(self.density, source, target, img, cfg["det"],
                                       voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
                                       storage=_brick_storage(self.density, cfg), out=out, launch_ws=launch_ws,
                                       cleared=True)

@@ -21,7 +21,7 @@ for name, vol in (("noise", noise_volume(512, 0)), ("phantom", phantom_volume(51
         s, t, L = rays(drr, rot, xyz)
         with torch.no_grad():
             call = lambda: drr(rot, xyz, parameterization="euler_angles", convention="ZXY")  # noqa: E731
-            for _ in range(20):
+            for _ in range(400):  # (the GPU's clocks drop while the host builds a volume)
                 call()
             torch.cuda.synchronize()
             t0 = time.perf_counter()

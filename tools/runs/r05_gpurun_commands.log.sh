@@ -261,3 +261,12 @@ OUT=gpurun_out/r05z5; mkdir -p $OUT; (timeout 1200 python -m pytest tests -m gpu
 
 # ---------------------------------------------------------------- 2026-09-27T04:06:53Z  final tree: extended randomised sweep (256 + 64 smooth cases, new seeds)
 mkdir -p gpurun_out/r05x; (timeout 900 python tools/fuzz_bricks.py --cases 256 --seed 9; timeout 600 python tools/fuzz_bricks.py --cases 64 --seed 10 --smooth) 2>&1 | grep -v amdgpu.ids > gpurun_out/r05x/fuzz_bricks.txt; grep -n "worst" gpurun_out/r05x/fuzz_bricks.txt | cut -c1-400; grep -c "<<<" gpurun_out/r05x/fuzz_bricks.txt
+
+# ---------------------------------------------------------------- 2026-09-27T04:10:41Z  inference path: GPU test + module call cost
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -2; timeout 300 python tools/module_call_bench.py 2>&1 | grep -v amdgpu
+
+# ---------------------------------------------------------------- 2026-09-27T04:12:32Z  inference path without the cache miss: module call cost
+timeout 300 python tools/module_call_bench.py 2>&1 | grep -v amdgpu; timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -k "inference" 2>&1 | tail -1
+
+# ---------------------------------------------------------------- 2026-09-27T04:13:03Z  module call cost, longer warm-up
+timeout 300 python tools/module_call_bench.py 2>&1 | grep -v amdgpu | tee gpurun_out/module_call2.txt
