@@ -270,3 +270,6 @@ timeout 300 python tools/module_call_bench.py 2>&1 | grep -v amdgpu; timeout 300
 
 # ---------------------------------------------------------------- 2026-09-27T04:13:03Z  module call cost, longer warm-up
 timeout 300 python tools/module_call_bench.py 2>&1 | grep -v amdgpu | tee gpurun_out/module_call2.txt
+
+# ---------------------------------------------------------------- 2026-09-27T04:13:54Z  final tree: GPU suite + smoke
+mkdir -p gpurun_out/r05final2; (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4) > gpurun_out/r05final2/gpu_tests.txt; cat gpurun_out/r05final2/gpu_tests.txt | tail -2; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05final2/smoke.txt | tail -1
