@@ -39,6 +39,7 @@ def test_header_constants_match():
     assert int(const["DDRR_LOOKUP_MID_NEAREST"]) == _lib.LOOKUP_MID_NEAREST
     assert int(const["DDRR_LOOKUP_MID_TRILINEAR"]) == _lib.LOOKUP_MID_TRILINEAR
     assert int(const["DDRR_SIDDON_AUX"]) == _lib.SIDDON_AUX
+    assert int(const["DDRR_BRICKS_CLEARED"]) == _lib.BRICKS_CLEARED == 2  # (a bit of ranges_valid, next to bit 0)
 
 
 def test_library_builds_loads_and_exports_every_symbol():

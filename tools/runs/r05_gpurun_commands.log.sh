@@ -273,3 +273,10 @@ timeout 300 python tools/module_call_bench.py 2>&1 | grep -v amdgpu | tee gpurun
 
 # ---------------------------------------------------------------- 2026-09-27T04:13:54Z  final tree: GPU suite + smoke
 mkdir -p gpurun_out/r05final2; (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4) > gpurun_out/r05final2/gpu_tests.txt; cat gpurun_out/r05final2/gpu_tests.txt | tail -2; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05final2/smoke.txt | tail -1
+
+# ---------------------------------------------------------------- 2026-09-27T04:15:39Z  final tree: default bench + config 5 (inference path in the sweep)
+timeout 900 python bench.py > gpurun_out/bh.json 2> gpurun_out/bh.err; echo rc=$?; grep "\[bench\] config headline:\|config 5:\|config 4:" gpurun_out/bh.err | cut -c1-160; timeout 600 python bench.py --config 5 > gpurun_out/b5.json 2> gpurun_out/b5.err; echo rc=$?; python - <<EOF
+import json
+d=json.load(open("gpurun_out/bh.json")); print(d["value"], d["ms_per_step"], d["sweep"]["value"], d["configs"]["5"]["value"], d["configs"]["4"]["value"], d["parity"]["fwd_rel_err_vs_fp64"])
+x=json.load(open("gpurun_out/b5.json")); print(x["value"], x["ms_per_step"], [(k["kernel"], round(k["kernel_ms"],3), k["launches_per_step"]) for k in x.get("kernels",[])], x.get("parity"))
+EOF
