@@ -337,6 +337,7 @@ class Runtime:
 
             importlib.import_module(os.environ["DDRR_BENCH_HOOK"])
         self.dist = None
+        self.rccl_ranks = 1
         if self.world > 1:
             import torch.distributed as dist
 
@@ -346,6 +347,12 @@ class Runtime:
             else:
                 dist.init_process_group(backend="gloo")
             self.world = dist.get_world_size()
+            # proof that the N ranks of this run each hold a device and reach each other: an
+            # all_reduce of ones ON the device (RCCL over xGMI on the GPU box, gloo on the harness)
+            ones = torch.ones(1, device=self.device)
+            dist.all_reduce(ones)
+            self.rccl_ranks = int(ones.item())
+            assert self.rccl_ranks == self.world, (self.rccl_ranks, self.world)
         from diffdrr_amd import ops
 
         self.timer = KernelTimer(ops, self.on_gpu)
@@ -860,9 +867,12 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "frac_is": "algorithmic (SURVEY 8d) bytes per launch / kernel time / 8 TB/s: a work rate "
-                       "-- the bricks are read from LDS, so HBM is not the wall that binds these "
-                       "kernels; `issue_bound` (where present) is the distance to the one that does",
+            "frac_is": "the contract's A / P: algorithmic (SURVEY 8d) bytes per launch / kernel time / "
+                       "8 TB/s.  `bound` is the wall the contract prices the kernel against; what BINDS "
+                       "it is `limiter` (the bricks are read from LDS: HBM carries `hbm_traffic_frac` "
+                       "of its peak) and `issue_bound` is the distance to that wall",
+            "limiter": "valu_issue",
+            "hbm_traffic_frac": (traffic[0] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and k_ms else None,
             "traffic": traffic[0] if traffic else None,
             "traffic_source": (traffic[1] + " (separate rocprofv3 --pmc passes of this command, "
                                "committed; not measured in this run)") if traffic else None,
@@ -1020,9 +1030,9 @@ def ct_config(rt, poses=(1, 8, 32), det=200):
            "volume": {"shape": list(dims), "zero_fraction": float((density == 0).float().mean()),
                       "max": float(density.max()), "soft_tissue": float(density[256, 256, 66])},
            "kernel": name, "poses": {},
-           "frac_is": "algorithmic bytes (4 B per voxel a ray crosses, air included, + 20 B per ray) per launch / "
-                      "kernel time / 8 TB/s: a WORK RATE, not a distance to the HBM wall -- two thirds of this "
-                      "volume is exact-zero air, whose bricks are skipped, so the figure can exceed 1"}
+           "work_rate_is": "algorithmic bytes (4 B per voxel a ray crosses, air included, + 20 B per ray) per "
+                           "launch / kernel time / 8 TB/s: NOT a roofline fraction -- two thirds of this "
+                           "volume is exact-zero air, whose bricks are skipped, so the figure can exceed 1"}
     from diffdrr_amd.renderers import _brick_storage
     out["module_default_storage"] = {
         "storage": _brick_storage(V, {"storage": drr.renderer.brick_storage}),
@@ -1057,7 +1067,7 @@ def ct_config(rt, poses=(1, 8, 32), det=200):
                                       ("forward_f32", "f32", False), ("forward_record_f32", "f32", True)):
                 ms = timed(lambda: ops.siddon_forward_bricks(V, s, t, L, (det, det), want_aux=aux,
                                                              storage=storage), n_prime, n_timed)
-                ent[key] = {"kernel_ms": ms, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                ent[key] = {"kernel_ms": ms, "work_rate": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "drrs_per_s": B / (ms * 1e-3)}
             out["poses"][str(B)] = ent
             log(f"[bench] config ct, {B} pose(s): forward {ent['forward']['kernel_ms']:.3f} ms (fp32 bricks "
@@ -1130,6 +1140,7 @@ def few_poses_config(rt, poses=(1, 2, 8), det=256, D=512):
                                                                  storage="q16p"), 60, 40)
                     e[key] = {"kernel_ms": ms, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "drrs_per_s": B / (ms * 1e-3)}
+                    assert e[key]["frac"] < 1.0  # (every voxel of these volumes is read: a fraction)
                 ent[str(B)] = e
             fb = ops.brick_fallbacks(V, "q16p")
             if fb is not None:
@@ -1159,6 +1170,163 @@ def summary_of(res):
     if "registration" in res:
         out["registration"] = res["registration"]
     return out
+
+
+LINE_LIMIT = 6144  # bytes of the final stdout line (the driver parses the tail of stdout; the
+#                    26.6 KB line of round 5 came back `parsed: null`)
+
+
+def _sig(x, n=5):
+    """Floats of the printed line: n significant digits (the full record keeps every digit)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x == 0.0 or not math.isfinite(x):
+        return x if math.isfinite(x) else None
+    return float(f"{x:.{n}g}")
+
+
+def _sig_tree(o):
+    if isinstance(o, dict):
+        return {k: _sig_tree(v) for k, v in o.items() if v is not None or k in ("vs_baseline", "traffic")}
+    if isinstance(o, (list, tuple)):
+        return [_sig_tree(v) for v in o]
+    return _sig(o)
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if d is not None and k in d and d[k] is not None}
+
+
+def _cap(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 3] + "..."
+
+
+def compact_line(full, limit=LINE_LIMIT):
+    """The ONE line rank 0 prints on stdout, from the full record (`bench_full.json`, also on
+    stderr): the driver's contract keys, `roofline`, `cpu_baseline`, `reference_cpu`, the headline
+    parity numbers and a few numbers per config -- at most `limit` bytes whatever the run (sections
+    are dropped, least important first, until it fits; tests/test_bench_line.py).  Names: `frac` is
+    the contract's A / P (algorithmic bytes over kernel time over the HBM peak) and appears only
+    where it cannot exceed 1; the same quotient for kernels that skip work the count includes
+    (all-zero bricks of a CT, bytes served by LDS) is called `work_rate`."""
+    rf = full["roofline"]
+    kern0 = (rf.get("kernels") or [{}])[0]
+    ib = kern0.get("issue_bound") or {}
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                 "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in full}
+    cfg = dict(_pick(full["config"], "baseline_config", "volume", "detector", "batch_per_gpu", "global_batch",
+                     "parallelism", "brick_storage_fallbacks", "bricks"))
+    cfg["workload"] = _cap(full["config"]["workload"], 200)
+    if "brick_storage" in full["config"]:
+        cfg["brick_storage"] = full["config"]["brick_storage"].split(":")[0]
+    if "step" in full:
+        cfg["step"] = _cap(full["step"], 60)
+    line["config"] = {"workload": cfg.pop("workload"), **cfg}
+    r = _pick(rf, "kernel", "bound", "achieved", "peak", "unit", "frac")
+    r["traffic"] = rf.get("traffic")
+    r.update(_pick(rf, "kernel_ms", "algorithmic_bytes_per_launch", "units_per_launch", "launches_timed"))
+    r["algorithmic_bytes_per_unit"] = _cap(rf.get("algorithmic_bytes_per_unit"), 100)
+    if rf.get("traffic") and rf.get("kernel_ms"):
+        r["hbm_traffic_frac"] = rf["traffic"] / (rf["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    r.update(_pick(rf, "limiter"))
+    if ib:
+        # what binds the kernel is not the `bound` the contract prices it against
+        r["issue_bound"] = _pick(ib, "issue_frac", "useful_frac")
+    r["step_minus_kernel_ms"] = full["ms_per_step"] - rf["kernel_ms"] * rf.get("launches_per_step", 1.0)
+    for key in ("forward", "forward_f32", "forward_sweep"):
+        f = rf.get(key)
+        if f:
+            e = _pick(f, "kernel_ms", "frac", "poses_per_launch", "traffic")
+            if f.get("issue_bound"):
+                e["issue_bound"] = _pick(f["issue_bound"], "issue_frac", "useful_frac")
+            if f.get("parity"):
+                e.update(_pick(f["parity"], "fwd_rel_err", "fwd_rel_err_vs_fp64"))
+            r[key] = e
+    if rf.get("forward"):
+        r["forward"]["target_frac"] = 0.70
+    r["other_kernels_ms_per_step"] = {
+        k["kernel"].replace("ddrr_", ""): k["kernel_ms"] * k["launches_per_step"]
+        for k in (rf.get("kernels") or [])[1:6]}
+    line["roofline"] = r
+    if "cpu_baseline" in full:
+        cb = dict(full["cpu_baseline"])
+        cb["sample"] = _cap(cb.get("sample"), 160)
+        line["cpu_baseline"] = cb
+    if "reference_cpu" in full:
+        line["reference_cpu"] = _pick(full["reference_cpu"], "value", "unit", "cores", "kind", "source")
+    pkeys = ("fwd_rel_err", "fwd_rel_err_vs_fp64", "ref_fp32_fwd_rel_err_vs_fp64", "pose_grad_rel_err_vs_fp64",
+             "ref_fp32_pose_grad_rel_err_vs_fp64", "fwd_rel_err_all_pixels", "ref_off_pixels", "poses")
+    if full.get("parity"):
+        par = _pick(full["parity"], *pkeys)
+        par["tolerance"] = "fwd 1e-4 (vs fp32 ref where it is within 1e-4 of fp64, vs fp64 everywhere); " \
+                           "pose grad vs fp64 <= 2x the reference's own fp32 error + 1e-3"
+        if full["parity"].get("phantom"):
+            par["phantom"] = _pick(full["parity"]["phantom"], "fwd_rel_err", "fwd_rel_err_vs_fp64",
+                                   "pose_grad_rel_err_vs_fp64", "ref_fp32_pose_grad_rel_err_vs_fp64",
+                                   "brick_storage_fallbacks")
+        line["parity"] = par
+    if "sweep" in full:
+        line["sweep"] = _pick(full["sweep"], "value", "unit", "n_gpus", "scaling", "ms_per_step", "steps",
+                              "poses", "poses_per_launch")
+    if "ranks" in full:
+        line["ranks"] = full["ranks"]
+    for k in ("rccl_ranks", "devices_visible", "registration"):
+        if k in full:
+            line[k] = full[k]
+    configs = {}
+    for name, c in (full.get("configs") or {}).items():
+        if name in ("ct", "sparse"):
+            e = {"poses": {}}
+            for B, ent in c.get("poses", {}).items():
+                e["poses"][B] = {k: _sig(v["kernel_ms"], 4) if isinstance(v, dict) and "kernel_ms" in v else
+                                 (_sig(v["ms"], 4) if isinstance(v, dict) and "ms" in v else v)
+                                 for k, v in ent.items()
+                                 if isinstance(v, dict) and ("kernel_ms" in v or "ms" in v)}
+            e["unit"] = "ms per launch"
+            e.update(_pick(c, "brick_storage_fallbacks", "bricks", "p_subsample", "reference_published_ms"))
+            if c.get("parity"):
+                e["parity"] = {k: (_pick(v, "fwd_rel_err", "fwd_rel_err_vs_fp64") if isinstance(v, dict) else v)
+                               for k, v in c["parity"].items() if k not in ("tolerance", "oracle", "pose")}
+        elif name == "few_poses":
+            e = {"unit": "ms per launch [forward, forward + record]"}
+            for kind in ("noise", "phantom"):
+                if kind in c:
+                    e[kind] = {B: [_sig(v["forward"]["kernel_ms"], 4), _sig(v["forward_record"]["kernel_ms"], 4)]
+                               for B, v in c[kind].items() if isinstance(v, dict)}
+        else:
+            dk = c.get("dominant_kernel") or {}
+            e = _pick(c, "value", "unit", "ms_per_step")
+            e["kernel_ms"] = dk.get("kernel_ms")
+            e["frac"] = dk.get("frac")
+            if c.get("forward"):
+                e["forward_frac"] = c["forward"].get("frac")
+            e.update(_pick(c.get("parity") or {}, "fwd_rel_err", "fwd_rel_err_vs_fp64", "pose_grad_rel_err_vs_fp64",
+                           "ref_fp32_pose_grad_rel_err_vs_fp64", "volume_grad_rel_err", "ncc_abs_err"))
+            e.update(_pick(c, "brick_storage_fallbacks"))
+            if "b4" in c:
+                e["b4"] = _pick(c["b4"], "value", "ms_per_step")
+            if "registration" in c:
+                e["registration"] = _pick(c["registration"], "hip_graph", "ncc_after", "iterations",
+                                          "rot_error_rad", "xyz_error_mm")
+        configs[name] = e
+    if configs:
+        line["configs"] = configs
+    line["full_record"] = "bench_full.json (beside bench.py) and stderr"
+    exact = {k: line[k] for k in ("value", "ms_per_step") if k in line}  # (the driver's consistency check)
+    line = _sig_tree(line)
+    line.update(exact)
+    # by construction, not by luck: drop the least important sections until the line fits
+    for drop in (("configs", "few_poses"), ("configs", "ct"), ("configs", "sparse"), ("roofline", "other_kernels_ms_per_step"),
+                 ("configs",), ("reference_cpu",), ("ranks",), ("sweep",)):
+        if len(json.dumps(line)) <= limit:
+            break
+        tgt = line
+        for k in drop[:-1]:
+            tgt = tgt.get(k, {})
+        if tgt.pop(drop[-1], None) is not None:
+            line.setdefault("dropped_for_size", []).append(".".join(drop))
+    assert len(json.dumps(line)) <= limit, "bench line over its size limit"
+    return line
 
 
 def main():
@@ -1192,6 +1360,17 @@ def main():
                          "DDRR_BENCH_HOOK routes diffdrr_amd.ops to, see tests/test_dist_gloo.py)")
     args = ap.parse_args()
 
+    if args.device == "cuda":
+        # pre-flight, before anything is spawned: more ranks than devices would die one by one in
+        # torch.cuda.set_device under a torchrun traceback -- one JSON line and rc 2 instead
+        visible = torch.cuda.device_count()
+        want = max(args.gpus, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+        if want > visible or visible == 0:
+            if int(os.environ.get("RANK", "0")) == 0:
+                print(json.dumps({"error": f"--gpus {args.gpus}: {want} rank(s) on this node need {want} "
+                                           f"GPU(s), torch.cuda.device_count() = {visible}",
+                                  "n_gpus_requested": args.gpus, "n_gpus_visible": visible}), flush=True)
+            sys.exit(2)
     if args.gpus > 1 and "RANK" not in os.environ:
         # no launcher: start one rank per GPU ourselves (RCCL needs one process per device)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
@@ -1247,7 +1426,18 @@ def main():
                               "(the sweep's launch size), same volume and detector as the headline")
                 result["roofline"]["forward_sweep"] = fs
     if rt.rank == 0:
-        print(json.dumps(result), flush=True)
+        result["rccl_ranks"] = rt.rccl_ranks  # (ranks counted by an all_reduce of ones on the devices)
+        result["devices_visible"] = torch.cuda.device_count() if rt.on_gpu else 0
+        # the full record: a file beside bench.py and stderr, BEFORE the line the driver parses
+        full = json.dumps(result)
+        try:
+            with open(os.path.join(ROOT, "bench_full.json"), "w") as f:
+                f.write(full + "\n")
+        except OSError as exc:
+            log(f"[bench] bench_full.json not written: {exc}")
+        log("[bench] full record: " + full)
+        sys.stderr.flush()
+        print(json.dumps(compact_line(result)), flush=True)
 
     if rt.world > 1:
         rt.dist.barrier()

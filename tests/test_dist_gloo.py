@@ -202,7 +202,11 @@ def test_bench_harness_spawns_its_ranks(config, extra, world):
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout  # rank 0 only
+    assert res.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 8192  # (what the driver parses)
     out = json.loads(lines[0])
+    assert out["rccl_ranks"] == world  # (counted by an all_reduce of ones, not read from the environment)
+    full = [ln for ln in res.stderr.splitlines() if ln.startswith("[bench] full record: ")]
+    assert len(full) == 1 and json.loads(full[0].split(": ", 1)[1])["roofline"]["kernels"]
     assert out["n_gpus"] == world and out["steps"] == 2 and out["warmup"] == 1
     assert out["value"] > 0 and out["unit"] == "DRRs/s" and out["higher_is_better"] is True
     if config == "headline":
