@@ -180,11 +180,15 @@ __host__ __device__ inline NccWs ncc_ws(void *ws, int B) {
 // XCD's whole L2 back, per wave that executes it -- tens of microseconds with the record just
 // written (measured: the first form of these kernels, with __threadfence(), ran 2x the launches it
 // fuses).  What has to be ordered are atomics only: every accumulator update is a device-scope
-// atomic, performed at the coherence point; the wave that issued them waits for their completion
-// (a workgroup-scope release = s_waitcnt) before the workgroup takes its ticket, and the last
-// workgroup reads the accumulators with atomics again.
+// atomic, performed at the coherence point; the wave that issued them waits until they have been
+// performed before the workgroup takes its ticket, and the last workgroup reads the accumulators
+// with atomics again.  The wait is spelled out: the accumulator updates are no-return atomics, counted
+// by vmcnt, and a workgroup-scope release fence lowers to `s_waitcnt lgkmcnt(0)` alone on gfx950
+// (checked in the ISA) -- without `vmcnt(0)` the ticket, an atomic to another address and
+// possibly another channel, could be performed before the sums it announces.
 __device__ __forceinline__ bool last_workgroup_of_pose(int *ticket, int *shared_flag) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's atomics have completed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's atomics have been performed
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (and its LDS traffic, for the barrier)
     __syncthreads();
     if (threadIdx.x == 0) *shared_flag = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
     __syncthreads();

@@ -285,6 +285,10 @@ class DRR(nn.Module):
               and fixed.device == rot.device and not fixed.requires_grad and B > 0)
         if not ok:
             img = self(rot, xyz, parameterization="euler_angles", convention=convention, degrees=degrees)
+            if img.dim() == 3 and det.n_subsample is None:
+                # DRR(reshape=False) hands (B, C, N) back: the criterion wants the detector's grid,
+                # as the fused path reads it
+                img = img.view(B, -1, det.height, det.width)
             return NormalizedCrossCorrelation2d(eps=eps)(fixed.expand(B, -1, -1, -1), img)
         _check_convention(convention)
         if degrees:

@@ -48,8 +48,10 @@ class PoseAdam(torch.optim.Optimizer):
     takes four (a step-counter and an update launch per group), ~19 us of a 0.19 ms iteration at
     512^3 -> 256^2.  Same update rule (no weight decay, no amsgrad), same state layout
     (``state[p] = {"step", "exp_avg", "exp_avg_sq"}``, the counters on the device: safe to capture
-    in a HIP graph), same param groups (learning rates may be changed between steps through
-    ``param_groups``).  Parameters: float32 ``(B, 3)`` on the GPU."""
+    in a HIP graph), same param groups (learning rates may be changed between EAGER steps through
+    ``param_groups``; they are host numbers handed to the kernel as arguments, so a captured step
+    keeps the values it was captured with -- ``GraphedIteration`` raises rather than replay a stale
+    learning rate).  Parameters: float32 ``(B, 3)`` on the GPU."""
 
     def __init__(self, rotation, translation, lr_rotation, lr_translation, betas=(0.9, 0.999), eps=1e-8,
                  maximize=False):
@@ -108,7 +110,12 @@ class GraphedIteration:
     The optimizer must not synchronise in ``step()`` (``torch.optim.SGD``; Adam with
     ``capturable=True``).  Everything the iteration touches keeps its address: the parameters
     of ``reg`` and the optimizer state are updated in place, ``target`` is read in place.
-    ``maximize`` / learning rates are whatever the optimizer was built with.
+    ``maximize`` / learning rates are whatever the optimizer was built with -- and FROZEN at
+    capture: hyper-parameters that are Python numbers (``PoseAdam``'s and torch's ``lr``, ``betas``,
+    ``eps``) are baked into the captured kernel arguments, so an ``lr_scheduler`` or a manual
+    ``param_groups`` edit between replays would be ignored silently.  ``__call__`` therefore raises
+    if a group's host-side hyper-parameters differ from the captured ones (build a new
+    ``GraphedIteration`` after changing them; a tensor ``lr`` is read by the kernels and may change).
 
     Construction has no side effects on the optimisation: the ``warmup`` eager iterations and
     the capture itself (which runs the iteration once more) are undone -- parameters and
@@ -212,7 +219,20 @@ class GraphedIteration:
                         old = saved_state[p].get(name)
                         val.copy_(old) if old is not None else val.zero_()
 
+        self._captured_hyper = self._host_hyper()
+
+    def _host_hyper(self):
+        """The param groups' hyper-parameters that live on the host (baked into the graph)."""
+        return [tuple(sorted((k, v) for k, v in g.items()
+                             if k != "params" and isinstance(v, (bool, int, float, tuple, type(None)))))
+                for g in self.optimizer.param_groups]
+
     def __call__(self) -> torch.Tensor:
+        if self._host_hyper() != self._captured_hyper:
+            raise RuntimeError(
+                "GraphedIteration: the optimizer's hyper-parameters changed after capture "
+                f"({self._captured_hyper} -> {self._host_hyper()}); they are baked into the graph -- "
+                "build a new GraphedIteration (or use tensor-valued learning rates)")
         self.graph.replay()
         self.iterations_done += 1
         return self.loss

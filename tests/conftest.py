@@ -797,3 +797,21 @@ def check_fused_ncc_step(device):
         with torch.no_grad():
             v = drr.ncc(base, rot0, xyz0)
         assert v.shape == (B,) and np.abs(v.cpu().numpy() - v_base).max() < 2e-6
+        # the composed route with gradients: more poses than the fused step takes per call, and a
+        # DRR(reshape=False), whose renders are (B, 1, N) (the fallback must hand the
+        # criterion the detector's grid) -- same values, same gradients as the fused route
+        flat = DRR(synthetic_subject((40, 48, 36), kind="phantom", seed=3), sdd=500.0, height=H, width=W,
+                   delx=2.5, stop_gradients_through_grid_sample=stop, reshape=False).to(device)
+        had = DRR.FUSED_NCC_MAX_POSES
+        outs = []
+        for d, cap in ((drr, had), (drr, 2), (flat, had), (flat, 2)):
+            d.FUSED_NCC_MAX_POSES = cap
+            r, x = rot0.clone().requires_grad_(), xyz0.clone().requires_grad_()
+            val = d.ncc(base, r, x, convention="ZXY")
+            assert type(val.grad_fn).__name__.startswith("_EulerSiddonNccFn") == (cap == had)
+            (val * w).sum().backward()
+            outs.append((val.detach().cpu().numpy(), r.grad.cpu().numpy(), x.grad.cpu().numpy()))
+            d.FUSED_NCC_MAX_POSES = had
+        for v_, gr_, gx_ in outs[1:]:
+            assert np.abs(v_ - outs[0][0]).max() < 2e-6
+            assert rel_err(gr_, outs[0][1]) < 2e-4 and rel_err(gx_, outs[0][2]) < 2e-4

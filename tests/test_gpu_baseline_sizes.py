@@ -15,6 +15,7 @@ Tolerances: forward image-normalised error <= 1e-4 vs the
 oracle and no further from the fp64 oracle than twice the fp32 oracle is; gradients no
 further from fp64 than 2 x the fp32 oracle + 1e-3."""
 import copy
+import math
 
 import numpy as np
 import pytest
@@ -472,6 +473,13 @@ def test_graphed_iteration_with_pose_adam_follows_torch_adam(gpu):
     assert torch.allclose(reg_g._rotation.detach(), reg_e._rotation.detach(), atol=5e-3)
     assert torch.allclose(reg_g._translation.detach(), reg_e._translation.detach(), atol=5e-1)
     assert graphed[-1] > graphed[0]
+    # the learning rates are host numbers baked into the captured launch: a scheduler's edit between
+    # replays is refused loudly, not ignored; putting the value back replays again
+    opt_g.param_groups[0]["lr"] = 5e-3
+    with pytest.raises(RuntimeError, match="hyper-parameters changed after capture"):
+        step()
+    opt_g.param_groups[0]["lr"] = 1e-2
+    assert math.isfinite(step().item())
 
 
 def test_hu_to_density_on_the_gpu(gpu):
