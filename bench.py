@@ -54,6 +54,7 @@ Diagnostics go to stderr.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import math
 import os
@@ -605,6 +606,12 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
         step()
     fence(pending)
     pending.clear()
+    # (the collector stays out of the timed region, as in `timeit`: a generation-2 pass of a process
+    # that has imported torch takes ~50 ms -- 40 steps' worth -- and WHERE it falls depends on the
+    # allocation count of everything before it: the driver's 20-step run of round 6's first build
+    # read 3.38 ms per step where 400 steps read 1.50, profiles/r06/gc_pause_in_the_timed_region.txt)
+    gc.collect()
+    gc.disable()
     timer.enabled, timer.only = True, (dominant if cfg != "4" else None)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -612,6 +619,7 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
     fence(pending)
     dt = time.perf_counter() - t0
     timer.enabled, timer.only = False, None
+    gc.enable()
     assert torch.isfinite(last).all()
     # the step's other kernels: a few steps of their own, every launch but the dominant one timed
     census_steps = 0

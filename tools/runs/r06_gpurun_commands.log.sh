@@ -1,0 +1,11 @@
+#!/bin/bash
+# DISPOSABLE LOG, not source: the command lists of every gpurun call of round 6, in order (tools/runs/README.md)
+
+# ---------------------------------------------------------------- 2026-10-01T03:33:56Z  r06 first: new gpu tests + bench line parses
+mkdir -p gpurun_out/r06a; python -m pytest tests -m gpu -x -q -k "guarded_16bit or fused_ncc or pose_adam or PoseAdam or graph" 2>&1 | tail -15 > gpurun_out/r06a/tests_new.txt; python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06a/bench_stdout.txt 2> gpurun_out/r06a/bench_stderr.txt; echo rc=$? >> gpurun_out/r06a/tests_new.txt; cp bench_full.json gpurun_out/r06a/; wc -c gpurun_out/r06a/bench_stdout.txt; cat gpurun_out/r06a/tests_new.txt; python bench.py --gpus 4 --steps 2 > gpurun_out/r06a/preflight.txt 2>&1; echo rc=$?; cat gpurun_out/r06a/preflight.txt | tail -3
+
+# ---------------------------------------------------------------- 2026-10-01T03:35:27Z  r06: is the 3.29 ms headline kernel reproducible?
+mkdir -p gpurun_out/r06b; for i in 1 2 3; do python bench.py --steps 20 --warmup 5 --no-configs --no-cpu-baseline 2>&1 >/dev/null | grep "config headline:" ; done; python bench.py --steps 400 --warmup 10 --no-configs --no-cpu-baseline 2>&1 >/dev/null | grep "config headline:"; git -C . log -1 --format=%h 2>/dev/null
+
+# ---------------------------------------------------------------- 2026-10-01T03:36:08Z  r06 diag: event creation cost; bench per-step
+python tools/_diag_events.py; python bench.py --steps 20 --warmup 5 --no-configs --no-cpu-baseline 2>&1 >/dev/null | grep "config headline:"; python bench.py --steps 20 --warmup 30 --no-configs --no-cpu-baseline 2>&1 >/dev/null | grep "config headline:"; python bench.py --steps 100 --warmup 5 --no-configs --no-cpu-baseline 2>&1 >/dev/null | grep "config headline:"; python bench.py --steps 20 --warmup 5 --no-configs --no-cpu-baseline --unfused 2>&1 >/dev/null | grep "config headline:"
