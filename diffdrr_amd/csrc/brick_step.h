@@ -403,10 +403,16 @@ DDRR_HD Q16Range q16_range(float vmin, float vmax) {
 // range is at most kQ16RangeOverLevel times its LEVEL -- the smallest mean |V| of any of its
 // 4 x 4 x 4 blocks (brick_range_kernel; over the non-zero voxels when the minimum is 0, which
 // q = 0 stores exactly): every voxel's error is then <= 12 / 131070 = 9.2e-5 of the mean of the
-// dimmest block a ray can cross, even if all rounding errors along a ray had one sign -- under the
-// 1e-4 the forward is held to PER PIXEL, with room for the fp32 arithmetic (3e-6).  (Rounds 4 and
-// early 5 had 8 = 6.1e-5, chosen without that arithmetic: it sent 644 instead of 369 of the 512^3
-// phantom's 2048 bricks to the fp32 path.)  Any
+// dimmest block of its brick, even if all rounding errors along a ray had one sign: a pixel is
+// within 9.2e-5 of the line integral of the brick LEVELS along its ray (+ 3e-6 of fp32 arithmetic).
+// That is a bound relative to the levels, NOT to the pixel's own value: a ray that
+// crosses mostly air (stored exactly, but counted in no level) and a sliver of skin inside
+// tissue-level bricks carries the tissue's step against a small integral.  Measured on noisy
+// CT-like volumes, fp64, quantisation alone (tests/test_brick_storage_guard.py): image-normalised
+// <= 2.2e-6 (the gate: 1e-4); relative to the pixel's own value <= 1.6e-4 at pixels above 1e-3 of
+// the image's maximum, where the reference's own fp32 arithmetic is 1.5e-4 ... 2.5e-4 off.
+// (Rounds 4 and early 5 had 8 = 6.1e-5: it sent 644 instead of 369 of the 512^3 phantom's 2048
+// bricks to the fp32 path.)  Any
 // other brick -- and any brick holding inf / NaN or a range outside what the 2^64 pre-scaling
 // of the walk carries -- is rendered from the volume's own fp32 values (bricks_fwd.hip MIXED).
 constexpr float kQ16RangeOverLevel = 12.0f;
