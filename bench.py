@@ -1103,6 +1103,93 @@ def ct_config(rt, poses=(1, 8, 32), det=200):
     return out
 
 
+def sparse_config(rt, poses=(1, 8), det=200, p=0.1):
+    """`configs.sparse`: the reference's own speed lever on its own example geometry -- the CT-like
+    512 x 512 x 133 volume of `configs.ct` -> 200 x 200 with `p_subsample = 0.1` (reference
+    drr.py:36-39, 142-147; published: 5.15 ms per forward call on an RTX 2080 Ti,
+    notebooks/tutorials/introduction.ipynb:611) at 1 and 8 poses: the MODULE call, forward (no
+    grad) and forward + backward to the Euler pose, wall time per call between HIP events --
+    on the volume-stationary kernels (the subsample's grid is rendered by the fused entries and
+    gathered: `DRR._render_sparse`), next to the same module on the per-ray kernels (where every
+    subsample went until round 5) and to the dense 200 x 200 render; parity of the subsample
+    against the oracle on exactly the listed rays."""
+    import numpy as np
+
+    import oracle
+    from diffdrr_amd import DRR
+    from diffdrr_amd.data import ct_like_hu_volume, make_subject, transform_hu_to_density
+
+    device = rt.device
+    density = transform_hu_to_density(ct_like_hu_volume((512, 512, 133), seed=0))
+    subject = make_subject(density, spacing=(0.703, 0.703, 2.5), orientation="AP")
+    torch.manual_seed(0)
+    sub = DRR(subject, sdd=1020.0, height=det, delx=2.0, renderer="siddon", p_subsample=p).to(device)
+    dense = DRR(subject, sdd=1020.0, height=det, delx=2.0, renderer="siddon").to(device)
+    out = {"workload": f"512x512x133 CT-like volume -> {det}x{det}, Siddon, p_subsample = {p} "
+                       f"({sub.detector.n_subsample} rays per pose), module calls",
+           "p_subsample": p, "unit": "ms per module call (HIP events around 50 calls)",
+           "reference_published_ms": 5.15,
+           "reference_published": "one pose, forward, RTX 2080 Ti (notebooks/tutorials/introduction.ipynb:611); "
+                                  "dense 200 x 200: 25.2 ms (README.md:85-87)",
+           "poses": {}}
+
+    def timed(fn, warm=20, n=50):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    def call(drr, rot0, xyz0, grad):
+        if not grad:
+            def fn():
+                with torch.no_grad():
+                    drr(rot0, xyz0, parameterization="euler_angles", convention="ZXY")
+            return fn
+        rot, xyz = rot0.clone().requires_grad_(), xyz0.clone().requires_grad_()
+
+        def fn():
+            rot.grad = xyz.grad = None
+            drr(rot, xyz, parameterization="euler_angles", convention="ZXY").sum().backward()
+        return fn
+
+    for B in poses:
+        rot0, xyz0 = perturbed_poses(B, seed=2, device=device)
+        ent = {}
+        for key, drr, fused in (("bricks", sub, True), ("per_ray", sub, False), ("dense", dense, True)):
+            drr.fuse_ray_generation = fused
+            for grad in (False, True):
+                ent[f"{key}_{'forward_backward' if grad else 'forward'}"] = {"ms": timed(call(drr, rot0, xyz0, grad))}
+            drr.fuse_ray_generation = True
+        out["poses"][str(B)] = ent
+        log(f"[bench] config sparse, {B} pose(s), p_subsample {p}: forward {ent['bricks_forward']['ms']:.3f} ms "
+            f"(per-ray kernels {ent['per_ray_forward']['ms']:.3f}, dense {ent['dense_forward']['ms']:.3f}), "
+            f"forward + backward {ent['bricks_forward_backward']['ms']:.3f} ms "
+            f"(per-ray {ent['per_ray_forward_backward']['ms']:.3f}, dense {ent['dense_forward_backward']['ms']:.3f})")
+    # parity: the subsample of pose 0 against the oracle on exactly those rays
+    rot0, xyz0 = perturbed_poses(1, seed=2, device=device)
+    sub.reshape = False
+    with torch.no_grad():
+        mine = sub(rot0, xyz0, parameterization="euler_angles", convention="ZXY").reshape(-1).cpu().numpy()
+        from diffdrr_amd.pose import convert
+        src, tgt = sub.detector(convert(rot0, xyz0, parameterization="euler_angles", convention="ZXY"), None)
+        L = (tgt - src).norm(dim=-1)
+        s, t = sub.affine_inverse(src), sub.affine_inverse(tgt)
+    a32 = (sub.density.cpu().numpy(), s.cpu().numpy(), t.cpu().numpy(), L.cpu().numpy())
+    r32 = oracle.siddon(*a32)["out"].reshape(-1)
+    r64 = oracle.siddon(*(a.astype(np.float64) for a in a32))["out"].reshape(-1)
+    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - b).max() / np.abs(b).max())  # noqa: E731
+    out["parity"] = {"rays": int(mine.size), "fwd_rel_err": rel(mine, r32), "fwd_rel_err_vs_fp64": rel(mine, r64),
+                     "ref_fp32_fwd_rel_err_vs_fp64": rel(r32, r64),
+                     "tolerance": "fwd_rel_err <= 1e-4 (image-normalised)"}
+    return out
+
+
 def few_poses_config(rt, poses=(1, 2, 8), det=256, D=512):
     """`configs.few_poses`: kernel-only timings of ddrr_siddon_forward_bricks at the headline size with
     1 / 2 / 8 poses per launch -- what a registration step or a small sweep launches -- on the bench's
@@ -1283,7 +1370,15 @@ def compact_line(full, limit=LINE_LIMIT):
             line[k] = full[k]
     configs = {}
     for name, c in (full.get("configs") or {}).items():
-        if name in ("ct", "sparse"):
+        if name == "sparse":
+            e = {"unit": "ms per module call [forward, forward + backward]", "poses": {}}
+            for B, ent in c.get("poses", {}).items():
+                e["poses"][B] = {k: [_sig(ent[f"{k}_forward"]["ms"], 4), _sig(ent[f"{k}_forward_backward"]["ms"], 4)]
+                                 for k in ("bricks", "per_ray", "dense") if f"{k}_forward" in ent}
+            e.update(_pick(c, "p_subsample", "reference_published_ms"))
+            if c.get("parity"):
+                e["parity"] = _pick(c["parity"], "fwd_rel_err", "fwd_rel_err_vs_fp64")
+        elif name == "ct":
             e = {"poses": {}}
             for B, ent in c.get("poses", {}).items():
                 e["poses"][B] = {k: _sig(v["kernel_ms"], 4) if isinstance(v, dict) and "kernel_ms" in v else
@@ -1294,7 +1389,7 @@ def compact_line(full, limit=LINE_LIMIT):
             e.update(_pick(c, "brick_storage_fallbacks", "bricks", "p_subsample", "reference_published_ms"))
             if c.get("parity"):
                 e["parity"] = {k: (_pick(v, "fwd_rel_err", "fwd_rel_err_vs_fp64") if isinstance(v, dict) else v)
-                               for k, v in c["parity"].items() if k not in ("tolerance", "oracle", "pose")}
+                               for k, v in c["parity"].items() if k not in ("tolerance", "oracle", "pose", "rays")}
         elif name == "few_poses":
             e = {"unit": "ms per launch [forward, forward + record]"}
             for kind in ("noise", "phantom"):
@@ -1418,6 +1513,9 @@ def main():
             t0 = time.perf_counter()
             configs["few_poses"] = few_poses_config(rt)
             configs["few_poses"]["wall_s"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            configs["sparse"] = sparse_config(rt)
+            configs["sparse"]["wall_s"] = time.perf_counter() - t0
         if rt.rank == 0:
             c5 = configs["5"]
             result["sweep"] = {"metric": c5["metric"], "value": c5["value"], "unit": c5["unit"],

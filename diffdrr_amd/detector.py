@@ -93,8 +93,8 @@ class Detector(torch.nn.Module):
         """3x3 pinhole intrinsic matrix."""
         return make_intrinsic_matrix(self).to(self.source)
 
-    def _initialize_carm(self):
-        """Unit-spaced pixel centres on the plane z = 1, centred on the optical axis."""
+    def _unit_grid(self):
+        """(1, H W, 3) unit-spaced pixel centres on the plane z = 1, row-major (detector.py:97-131)."""
         h_off = 1.0 if self.height % 2 else 0.5
         w_off = 1.0 if self.width % 2 else 0.5
         rows = -(torch.arange(-self.height // 2, self.height // 2) + h_off)
@@ -102,7 +102,38 @@ class Detector(torch.nn.Module):
         if not self.reverse_x_axis:
             cols = -cols
         yy, xx = torch.meshgrid(rows, cols, indexing="ij")
-        target = torch.stack([xx, yy, torch.ones_like(xx)], dim=-1).reshape(1, -1, 3)
+        return torch.stack([xx, yy, torch.ones_like(xx)], dim=-1).reshape(1, -1, 3).to(torch.float32)
+
+    def full_target(self):
+        """The WHOLE detector grid's unit points, whatever ``n_subsample`` kept of it in ``target``
+        (the volume-stationary kernels render grids: a subsample is rendered as its grid and
+        gathered, ``DRR._render_fused_Mw``).  Not a registered buffer -- ``state_dict`` stays the
+        reference's -- but cached per device."""
+        if self.n_subsample is None:
+            return self.target
+        dev = self.target.device
+        cached = getattr(self, "_full_target", None)
+        if cached is None or cached.device != dev:
+            cached = self._unit_grid().to(dev)
+            self._full_target = cached
+        return cached
+
+    def subsample_index(self):
+        """The pixel indices ``target`` holds (``subsamples[-1]``, detector.py:134-137) as an int64
+        tensor on the detector's device, in the order the renderer's output has; None without
+        ``n_subsample``."""
+        if self.n_subsample is None:
+            return None
+        dev = self.target.device
+        cached = getattr(self, "_subsample_index", None)
+        if cached is None or cached.device != dev or cached.numel() != len(self.subsamples[-1]):
+            cached = torch.tensor(self.subsamples[-1], dtype=torch.int64, device=dev)
+            self._subsample_index = cached
+        return cached
+
+    def _initialize_carm(self):
+        """Unit-spaced pixel centres on the plane z = 1, centred on the optical axis."""
+        target = self._unit_grid()
         source = torch.zeros(1, 1, 3)
         if self.n_subsample is not None:
             sample = torch.randperm(self.height * self.width)[: int(self.n_subsample)]

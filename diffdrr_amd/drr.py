@@ -159,8 +159,14 @@ class DRR(nn.Module):
     fuse_ray_generation = True
     _rays_from_detector = False  # set around the render call of forward()
 
-    def _fused_ok(self, mask_to_channels, kwargs, cal=None):
+    def _fused_ok(self, mask_to_channels, kwargs, cal=None, dense_only=False):
+        """Whether the call can take the fused pose -> rays -> brick-kernel entries.  ``patch_size`` and
+        ``p_subsample`` -- the reference's own speed levers (drr.py:36-39, 142-147, 218-225) -- stay on
+        them (``_render_sparse``); ``dense_only``: callers that read the record of the whole grid
+        (``ncc``) do not take a subsample."""
         r = self.renderer
+        if dense_only and self.detector.n_subsample is not None:
+            return False
         if cal is not None and getattr(getattr(cal, "matrix", None), "requires_grad", False):
             return False  # gradients w.r.t. the intrinsics flow through Detector.forward only
         # (the marcher's fused entry takes its one everyday keyword, n_points)
@@ -171,30 +177,36 @@ class DRR(nn.Module):
                 and ops.on_device(self.density) and self.density.dtype == torch.float32
                 and (not mask_to_channels or getattr(self, "mask", None) is not None)
                 and kw_ok and not self.checkpoint_gradients
-                and self.patch_size is None and self.detector.n_subsample is None
+                and (self.patch_size is None or self.n_patches >= 1)
                 and min(self.detector.height, self.detector.width) >= 2)
 
     def _render_fused(self, pose, calibration, mask_to_channels=False, **kwargs):
         Mw = (pose.matrix @ self.detector._reorient)[:, :3, :]   # reorient.compose(extrinsic)
         return self._render_fused_Mw(Mw, calibration, mask_to_channels, **kwargs)
 
+    def _calibrated_points(self, calibration=None):
+        """(H W, 3) calibrated points of the WHOLE detector grid (detector.py:147-150; with
+        ``p_subsample`` the grid the subsample was drawn from).  They only change with the
+        intrinsics: cached per (calibration buffer version, grid buffer, device) -- the key holds
+        the buffer objects themselves: alive, so not confusable with new ones."""
+        det = self.detector
+        grid = det.full_target()
+        if calibration is not None:
+            return calibration(grid)[0].detach()
+        key = getattr(self, "_P_key", None)
+        if key is None or key[0] is not det._calibration or key[1] != det._calibration._version \
+                or key[2] is not grid or key[3] != grid._version:
+            self._P_cache = det.calibration(grid)[0].detach()
+            self._P_key = (det._calibration, det._calibration._version, grid, grid._version)
+        return self._P_cache
+
     def _render_fused_Mw(self, Mw, calibration, mask_to_channels=False, **kwargs):
         det = self.detector
-        if calibration is None:
-            # the calibrated detector points only change with the intrinsics: cached per
-            # (calibration buffer version, target buffer, device)
-            # (the key holds the buffer objects themselves: alive, so not confusable with new ones)
-            key = getattr(self, "_P_key", None)
-            if key is None or key[0] is not det._calibration or key[1] != det._calibration._version \
-                    or key[2] is not det.target or key[3] != det.target._version:
-                self._P_cache = det.calibration(det.target)[0].detach()
-                self._P_key = (det._calibration, det._calibration._version, det.target,
-                               det.target._version)
-            P = self._P_cache
-        else:
-            P = calibration(det.target)[0].detach()          # (N,3) detector.py:147-150
+        P = self._calibrated_points(calibration)
         Ainv = self._affine_inverse[0, :3, :] if self._affine_inverse.dim() == 3 \
             else self._affine_inverse[:3, :]
+        if self.patch_size is not None or det.n_subsample is not None:
+            return self._render_sparse(Mw, P, Ainv, self.mask if mask_to_channels else None, **kwargs)
         # the grid contract holds for THIS call only (rays generated right here): a later direct
         # `drr.renderer(...)` call with rays of its own is checked again (renderers._grid_or_none)
         self.renderer.detector_shape = (det.height, det.width)
@@ -205,6 +217,94 @@ class DRR(nn.Module):
                                               **kwargs)
         finally:
             self.renderer.trust_detector_shape = False
+
+    def _sparse_plan(self):
+        """``patch_size`` / ``p_subsample`` as the brick kernels see them: the rendered rays, in the
+        renderer's output order (the subsample's order, else row-major), cut into the reference's
+        chunks (``target.chunk(n_patches, dim=1)``, drr.py:218-225) -> per chunk (first detector
+        row, number of rows, index of the chunk's rays inside those rows or None = all of them in
+        order, the chunk's pixel indices in the whole grid or None = a contiguous run [a, b)).
+        A chunk is rendered as the smallest run of whole detector rows that holds it -- itself a
+        row-major affine grid, which is what the volume-stationary kernels take -- and gathered."""
+        det = self.detector
+        H, W = det.height, det.width
+        key = (H, W, self.patch_size, id(det), None if det.n_subsample is None else len(det.subsamples))
+        plan = getattr(self, "_sparse_plan_cache", None)
+        if plan is not None and plan[0] == key and plan[2] == det.target.device:
+            return plan[1]
+        idx = det.subsample_index()
+        n = H * W if idx is None else int(idx.numel())
+        if self.patch_size is not None:
+            k = self.n_patches
+            size = -(-n // k)  # torch.chunk: chunks of ceil(n / k) rays, the last one shorter
+            bounds = [(a, min(a + size, n)) for a in range(0, n, size)]
+        else:
+            bounds = [(0, n)]
+        host = None if idx is None else idx.cpu()
+        chunks = []
+        for a, b in bounds:
+            if host is None:
+                r0, r1 = a // W, (b - 1) // W
+            else:
+                r0, r1 = int(host[a:b].min()) // W, int(host[a:b].max()) // W
+            if r1 == r0:  # (a grid has at least two rows)
+                r0, r1 = (r0, r0 + 1) if r0 + 1 < H else (r0 - 1, r0)
+            whole = host is None and a == r0 * W and b == (r1 + 1) * W
+            local = None if whole else (
+                torch.arange(a - r0 * W, b - r0 * W, device=det.target.device) if host is None
+                else idx[a:b] - r0 * W)
+            chunks.append((r0, r1 - r0 + 1, local, None if host is None else idx[a:b], (a, b)))
+        self._sparse_plan_cache = (key, chunks, det.target.device)
+        return chunks
+
+    def _render_sparse(self, Mw, P, Ainv, mask, **kwargs):
+        """``patch_size`` and / or ``p_subsample`` on the volume-stationary kernels.
+
+        Siddon is per-ray independent: neither the chunking nor the choice of rays changes a ray's
+        value, so the whole grid is rendered by ONE fused launch and the rendered rays
+        are gathered from it -- patches cost nothing, a subsample costs what the grid costs (which
+        is 3-12x less than the same rays through the per-ray kernels, profiles/r06/sparse.txt).
+        The marcher's sample positions depend on the marching range of the rays of ONE renderer
+        call (renderers.py:220-223): the range is taken over exactly the rays of each chunk, as
+        the reference's patch loop does, and every chunk is rendered on the bricks as the run of
+        whole detector rows that holds it (``_sparse_plan``), with that range."""
+        from .renderers import _RaygenFn, get_alpha_minmax
+
+        det, r = self.detector, self.renderer
+        H, W = det.height, det.width
+        idx = det.subsample_index()
+        if isinstance(r, Siddon):
+            r.detector_shape, r.trust_detector_shape = (H, W), True
+            try:
+                dense = r.render_poses(self.density, Mw, P, Ainv, mask=mask)  # (B, C, H W)
+            finally:
+                r.trust_detector_shape = False
+            return dense if idx is None else dense.index_select(-1, idx)
+        source, target, img = _RaygenFn.apply(Mw, P, Ainv)
+        given = kwargs.get("alphamin") is not None and kwargs.get("alphamax") is not None
+        need_grad = torch.is_grad_enabled() and (source.requires_grad or target.requires_grad)
+        outs = []
+        for r0, rows, local, pix, (a, b) in self._sparse_plan():
+            kw = dict(kwargs)
+            t_rows = target[:, r0 * W:(r0 + rows) * W]
+            i_rows = img[:, r0 * W:(r0 + rows) * W]
+            if not given:
+                # the reference's range of THIS renderer call: the chunk's own rays
+                t_c = t_rows if local is None else t_rows.index_select(1, local)
+                if need_grad:
+                    lo, hi = get_alpha_minmax(source, t_c, r.dims(self.density), r.voxel_shift, r.eps)
+                    kw["alphamin"], kw["alphamax"] = lo.min(), hi.max()
+                else:
+                    kw["alphamin"], kw["alphamax"] = ops.trilinear_alpha_range(
+                        source.detach(), t_c.detach().contiguous(), self.density.shape,
+                        voxel_shift=r.voxel_shift, eps=r.eps)
+            r.detector_shape, r.trust_detector_shape = (rows, W), True
+            try:
+                out = r(self.density, source, t_rows.contiguous(), i_rows.contiguous(), mask=mask, **kw)
+            finally:
+                r.trust_detector_shape = False
+            outs.append(out if local is None else out.index_select(-1, local))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1)
 
     def _render_euler_inference(self, rot, xyz, convention, degrees):
         """The everyday call -- ``drr(rot, xyz, parameterization="euler_angles")`` with nothing to
@@ -224,12 +324,7 @@ class DRR(nn.Module):
         if degrees:
             rot = rot / 180 * math.pi
         axes = tuple(_AXIS[c] for c in convention)
-        key = getattr(self, "_P_key", None)
-        if key is None or key[0] is not det._calibration or key[1] != det._calibration._version \
-                or key[2] is not det.target or key[3] != det.target._version:
-            self._P_cache = det.calibration(det.target)[0].detach()
-            self._P_key = (det._calibration, det._calibration._version, det.target, det.target._version)
-        P = self._P_cache
+        P = self._calibrated_points()
         Ainv = self._affine_inverse[0, :3, :] if self._affine_inverse.dim() == 3 \
             else self._affine_inverse[:3, :]
         cfg = r._cfg(False, det=(det.height, det.width))
@@ -244,6 +339,9 @@ class DRR(nn.Module):
                                       voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
                                       storage=_brick_storage(self.density, cfg), out=out, launch_ws=launch_ws,
                                       cleared=True)
+            idx = det.subsample_index()  # (p_subsample: the grid is rendered, the subsample gathered)
+            if idx is not None:
+                out = out.index_select(-1, idx)
         return out.unsqueeze(1)
 
     FUSED_NCC_MAX_POSES = 32
@@ -276,7 +374,7 @@ class DRR(nn.Module):
         # not measured beyond: profiles/r05/fused_step.txt)
         ok = (torch.is_grad_enabled() and (rot.requires_grad or xyz.requires_grad)
               and B <= self.FUSED_NCC_MAX_POSES
-              and self._fused_ok(False, {}, None) and isinstance(r, Siddon)
+              and self._fused_ok(False, {}, None, dense_only=True) and isinstance(r, Siddon)
               and r.grid_path == "bricks" and not r.packed_record and not self.density.requires_grad
               and all(torch.is_tensor(a) and a.dim() == 2 and a.shape == (B, 3)
                       and a.dtype == torch.float32 and ops.on_device(a) for a in (rot, xyz))
@@ -295,11 +393,7 @@ class DRR(nn.Module):
             rot = rot / 180 * math.pi
         axes = tuple(_AXIS[c] for c in convention)
         # (as _render_fused_Mw: the calibrated detector points, cached per intrinsics)
-        key = getattr(self, "_P_key", None)
-        if key is None or key[0] is not det._calibration or key[1] != det._calibration._version \
-                or key[2] is not det.target or key[3] != det.target._version:
-            self._P_cache = det.calibration(det.target)[0].detach()
-            self._P_key = (det._calibration, det._calibration._version, det.target, det.target._version)
+        self._calibrated_points()
         Ainv = self._affine_inverse[0, :3, :] if self._affine_inverse.dim() == 3 \
             else self._affine_inverse[:3, :]
         cfg = r._cfg(False, det=(det.height, det.width))
@@ -336,7 +430,16 @@ class DRR(nn.Module):
         target = self.affine_inverse(target)
 
         kwargs["mask"] = self.mask if mask_to_channels else None
-        full_grid = (self.detector.n_subsample is None and self.patch_size is None and
+        r = self.renderer
+        # Siddon is per-ray independent: where the whole grid goes to the volume-stationary kernel
+        # (nothing is materialised per segment there), the patch loop changes nothing but the
+        # number of launches -- one render (the reference's chunking exists to bound the memory of
+        # its (B, N, M) tensors, drr.py:218-225)
+        unpatched = self.patch_size is None or (
+            isinstance(r, Siddon) and r.supports_pose_entry() and r.grid_path == "bricks"
+            and ops.on_device(density) and density.dtype == torch.float32
+            and not kwargs.get("align_corners", False) and self.n_patches >= 1)
+        full_grid = (self.detector.n_subsample is None and unpatched and
                      target.shape[1] == self.detector.height * self.detector.width)
         # `detector_shape` is a CONTRACT with the renderer, not a hint: the volume-stationary
         # kernels cull rays with an affine model of the detector grid.  Rays that forward() got
@@ -350,7 +453,7 @@ class DRR(nn.Module):
             (self.detector.height, self.detector.width) if full_grid else None
         self.renderer.trust_detector_shape = True  # generated or checked right here ...
         try:
-            if self.patch_size is None:
+            if unpatched and (self.patch_size is None or full_grid):
                 return self.renderer(density, source, target, img, **kwargs)
             partials = [
                 self.renderer(density, source, t, i, **kwargs)
@@ -413,8 +516,15 @@ class DRR(nn.Module):
 
 
 def reshape_subsampled_drr(img: torch.Tensor, detector: Detector, batch_size: int):
+    """(B, 1, n) subsampled line integrals -> (B, 1, H, W) with zeros elsewhere (reference
+    drr.py:142-147).  The indices come from the detector's cached device tensor: indexing with the
+    Python list ``subsamples[-1]``, as the reference does, builds and uploads a 4000-element
+    tensor per call -- 6 ms of a 0.1 ms render (profiles/r06/sparse.txt)."""
     n_points = detector.height * detector.width
-    drr = torch.zeros(batch_size, n_points).to(img)
+    idx = detector.subsample_index()
+    if idx.device != img.device:
+        idx = idx.to(img.device)
     # (the reference's `drr[:, idx] = img` only broadcasts for batch_size == 1)
-    drr[:, detector.subsamples[-1]] = img.reshape(batch_size, -1)
+    drr = torch.zeros(batch_size, n_points, dtype=img.dtype, device=img.device)
+    drr = drr.index_copy(1, idx, img.reshape(batch_size, -1))
     return drr.view(batch_size, 1, detector.height, detector.width)

@@ -815,3 +815,66 @@ def check_fused_ncc_step(device):
         for v_, gr_, gx_ in outs[1:]:
             assert np.abs(v_ - outs[0][0]).max() < 2e-6
             assert rel_err(gr_, outs[0][1]) < 2e-4 and rel_err(gx_, outs[0][2]) < 2e-4
+
+
+SPARSE_CASES = {  # tests/golden/make_golden_sparse.py: name -> (renderer, DRR kwargs, call kwargs, poses)
+    "siddon_sub": ("siddon", dict(p_subsample=0.3), {}, 1),
+    "siddon_sub_flat": ("siddon", dict(p_subsample=0.3, reshape=False), {}, 2),
+    "siddon_patch4": ("siddon", dict(patch_size=4), {}, 2),
+    "siddon_patch4_channels": ("siddon", dict(patch_size=4), dict(mask_to_channels=True), 2),
+    "trilinear_sub_flat": ("trilinear", dict(p_subsample=0.3, reshape=False), dict(n_points=40), 2),
+    "trilinear_patch4": ("trilinear", dict(patch_size=4), dict(n_points=40), 2),
+    "trilinear_patch5": ("trilinear", dict(patch_size=5), dict(n_points=40), 2),
+    "trilinear_patch5_sub": ("trilinear", dict(patch_size=5, p_subsample=0.3), dict(n_points=40), 1),
+    "trilinear_patch4_channels": ("trilinear", dict(patch_size=4), dict(n_points=40, mask_to_channels=True), 2),
+    "trilinear_unpatched": ("trilinear", {}, dict(n_points=40), 2),
+}
+
+
+def check_sparse_lever(name, device, ops, calls=None):
+    """``p_subsample`` / ``patch_size`` of ``DRR`` (reference drr.py:36-39, 142-147, 218-225) against
+    the fixture of the UNMODIFIED reference (tests/golden/drr_sparse.npz): the same subsample drawn
+    (``torch.manual_seed`` + ``randperm``), image and pose gradients -- and, asked for by VERDICT r05
+    next 2, ON THE VOLUME-STATIONARY KERNELS: ``calls`` collects the C-ABI entries the render went
+    through; the per-ray forward kernels must not be among them."""
+    import torch
+
+    from diffdrr_amd import DRR
+    from diffdrr_amd.data import Image, Subject
+
+    g = golden("drr_sparse")
+    renderer, ctor, call, B = SPARSE_CASES[name]
+    T = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).to(device)  # noqa: E731
+    vol = T(g["volume"])
+    mask = Image(T(g["mask"]).unsqueeze(0), g["affine"])
+    subject = Subject(Image(vol.unsqueeze(0), g["affine"]), Image(vol.unsqueeze(0), g["affine"]),
+                      torch.from_numpy(g["reorient"]), mask)
+    geo = {k[4:]: g[k].item() for k in g.files if k.startswith("geo_")}
+    geo["height"], geo["width"] = int(geo["height"]), int(geo["width"])
+    torch.manual_seed(int(g["seed"]))
+    drr = DRR(subject, renderer=renderer, **geo, **ctor).to(device)
+    if "p_subsample" in ctor:
+        assert drr.detector.subsamples[-1] == g[f"{name}_subsample"].tolist()  # the reference's draw
+    rot = T(g["rot"])[:B].clone().requires_grad_()
+    xyz = T(g["xyz"])[:B].clone().requires_grad_()
+    if calls is not None:
+        calls.clear()
+    img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY", **call)
+    assert img.shape == g[f"{name}_img_f32"].shape
+    assert rel_err(img.detach().cpu().numpy(), g[f"{name}_img_f32"]) < 1e-4, name
+    assert rel_err(img.detach().cpu().numpy(), g[f"{name}_img_f64"]) < 1e-4, name
+    img.backward(T(g[f"{name}_grad_out_f32"]))
+    # (the gradient gate of DESIGN section 4: no further from fp64 than 2 x the reference's own fp32
+    # arithmetic + 1e-3 -- a noise volume, a dozen rays per chunk, ranges routed to arg-min rays)
+    for mine, key in ((rot.grad, "g_rot"), (xyz.grad, "g_xyz")):
+        own = rel_err(g[f"{name}_{key}_f32"], g[f"{name}_{key}_f64"])
+        assert rel_err(mine.cpu().numpy(), g[f"{name}_{key}_f64"]) < 2 * own + 1e-3, (name, key, own)
+    with torch.no_grad():  # the everyday call without gradients: the same image
+        again = drr(rot.detach(), xyz.detach(), parameterization="euler_angles", convention="ZXY", **call)
+    assert rel_err(again.cpu().numpy(), img.detach().cpu().numpy()) < 2e-6, name
+    if calls is not None:
+        per_ray = {"ddrr_siddon_forward", "ddrr_trilinear_forward", "ddrr_siddon_forward_channels",
+                   "ddrr_trilinear_forward_channels", "ddrr_trilinear_backward", "ddrr_siddon_backward_channels"}
+        assert not per_ray & set(calls), (name, sorted(per_ray & set(calls)))
+        assert any(c.endswith("_bricks") for c in calls), (name, calls)
+    return drr

@@ -1143,3 +1143,86 @@ def test_euler_inference_path(gpu):
 @pytest.mark.gpu
 def test_pose_adam_matches_torch_adam(gpu):
     conftest.check_pose_adam(gpu)
+
+
+@pytest.mark.parametrize("name", sorted(conftest.SPARSE_CASES))
+def test_subsample_and_patches_match_reference_on_the_bricks(gpu, monkeypatch, name):
+    """``p_subsample`` / ``patch_size`` against the fixture of the unmodified
+    reference, on the device, with the C-ABI entries the render went through recorded: brick
+    kernels, no per-ray forward kernel."""
+    calls = []
+    launch = ops._launch
+    monkeypatch.setattr(ops, "_launch", lambda n, d, *a: (calls.append(n), launch(n, d, *a))[1])
+    conftest.check_sparse_lever(name, gpu, ops, calls)
+
+
+@pytest.mark.parametrize("renderer", ["siddon", "trilinear"])
+def test_subsample_list_and_patched_render_vs_oracle(gpu, renderer):
+    """The same levers at a size where the brick grid matters (a CT-like 192 x 192 x 67 volume through
+    transform_hu_to_density, 112 x 96 detector, 3 poses) against the ORACLE on exactly the rays the
+    reference would render: a 10 % subsample list (the oracle gets the listed rays, the marcher its
+    range over them) and a patched render (the oracle chunk by chunk, the marcher's range per
+    chunk, 6 ragged chunks); images 1e-4 of the image scale vs the oracle's fp32 and fp64 (gradients:
+    the reference's fixture above)."""
+    import oracle
+    from diffdrr_amd.data import ct_like_hu_volume, make_subject, transform_hu_to_density
+
+    vol = transform_hu_to_density(ct_like_hu_volume((192, 192, 67), seed=4))
+    H, W, B, P = 112, 96, 3, 150
+    kw = dict(n_points=P) if renderer == "trilinear" else {}
+    g = torch.Generator().manual_seed(9)
+    rot = ((torch.rand(B, 3, generator=g) - 0.5) * 1.2).to(gpu)
+    xyz = (torch.tensor([0.0, 500.0, 0.0]) + (torch.rand(B, 3, generator=g) - 0.5) * 30).to(gpu)
+    v64 = vol.numpy().astype(np.float64)
+
+    def oracle_render(drr, pix, dtype):
+        """the oracle on the rays `pix` of every pose (range: over exactly those rays)"""
+        with torch.no_grad():
+            pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+            src, tgt = drr.detector(pose, None)
+            L = (tgt - src).norm(dim=-1)
+            s, t = drr.affine_inverse(src), drr.affine_inverse(tgt)
+        a = [x.cpu().numpy().astype(dtype) for x in (s, t[:, pix] if pix is not None else t,
+                                                      L[:, pix] if pix is not None else L)]
+        fn = oracle.siddon if renderer == "siddon" else oracle.trilinear
+        return fn(v64.astype(dtype), *a, **kw)["out"].reshape(B, -1)
+
+    # (a) a subsample list
+    torch.manual_seed(77)
+    sub = DRR(make_subject(vol, spacing=(1.0, 1.0, 2.0)), sdd=1000.0, height=H, width=W, delx=2.2,
+              renderer=renderer, p_subsample=0.1, reshape=False).to(gpu)
+    n = int(H * W * 0.1)
+    assert len(sub.detector.subsamples[-1]) == n
+    with torch.no_grad():
+        img = sub(rot, xyz, parameterization="euler_angles", convention="ZXY", **kw)
+    assert img.shape == (B, 1, n)
+    # (the detector's own `target` IS the subsample: the oracle renders what Detector.forward hands over)
+    r32, r64 = oracle_render(sub, None, np.float32), oracle_render(sub, None, np.float64)
+    mine = img.reshape(B, n).cpu().numpy()
+    assert rel_err(mine, r64) < 1e-4 and rel_err(mine, r32) < 1e-4, (rel_err(mine, r64), rel_err(mine, r32))
+    # reshape=True scatters the same values into zeros (drr.py:142-147)
+    sub.reshape = True
+    with torch.no_grad():
+        full = sub(rot[:1], xyz[:1], parameterization="euler_angles", convention="ZXY", **kw)
+    idx = torch.tensor(sub.detector.subsamples[-1], device=gpu)
+    assert full.shape == (1, 1, H, W) and int((full != 0).sum()) <= n
+    # (two launches: the float atomics of the partial integrals arrive in another order)
+    assert torch.allclose(full.reshape(-1)[idx], img[0, 0], rtol=2e-6, atol=0)
+    # (b) a patched render: 6 ragged chunks of ceil(10752 / 6) rays
+    pat = DRR(make_subject(vol, spacing=(1.0, 1.0, 2.0)), sdd=1000.0, height=H, width=W, delx=2.2,
+              renderer=renderer, patch_size=42).to(gpu)
+    assert pat.n_patches == 6
+    with torch.no_grad():
+        pimg = pat(rot, xyz, parameterization="euler_angles", convention="ZXY", **kw).reshape(B, H * W)
+    size = -(-H * W // 6)
+    for dtype in (np.float32, np.float64):
+        ref = np.concatenate([oracle_render(pat, np.arange(a, min(a + size, H * W)), dtype)
+                              for a in range(0, H * W, size)], axis=1)
+        assert rel_err(pimg.cpu().numpy(), ref) < 1e-4, (renderer, dtype, rel_err(pimg.cpu().numpy(), ref))
+    if renderer == "trilinear":
+        # (the chunks' ranges differ: unpatched, the image is another one)
+        whole = DRR(make_subject(vol, spacing=(1.0, 1.0, 2.0)), sdd=1000.0, height=H, width=W, delx=2.2,
+                    renderer=renderer).to(gpu)
+        with torch.no_grad():
+            wimg = whole(rot, xyz, parameterization="euler_angles", convention="ZXY", **kw).reshape(B, H * W)
+        assert rel_err(wimg.cpu().numpy(), ref) > 1e-4

@@ -1048,3 +1048,13 @@ def test_euler_inference_path_on_the_host_twin(emulated_ops):
 
 def test_pose_adam_matches_torch_adam_on_the_host_twin(emulated_ops):
     conftest.check_pose_adam("cpu")
+
+
+@pytest.mark.parametrize("name", sorted(conftest.SPARSE_CASES))
+def test_subsample_and_patches_match_reference_on_the_bricks(emulated_ops, monkeypatch, name):
+    """The reference's own speed levers through the host build of the brick
+    entries: fixture of the unmodified reference, and no per-ray forward kernel in the call list."""
+    calls = []
+    launch = emulated_ops._launch
+    monkeypatch.setattr(emulated_ops, "_launch", lambda n, d, *a: (calls.append(n), launch(n, d, *a))[1])
+    conftest.check_sparse_lever(name, "cpu", emulated_ops, calls)

@@ -9,3 +9,6 @@ mkdir -p gpurun_out/r06b; for i in 1 2 3; do python bench.py --steps 20 --warmup
 
 # ---------------------------------------------------------------- 2026-10-01T03:36:08Z  r06 diag: event creation cost; bench per-step
 python tools/_diag_events.py; python bench.py --steps 20 --warmup 5 --no-configs --no-cpu-baseline 2>&1 >/dev/null | grep "config headline:"; python bench.py --steps 20 --warmup 30 --no-configs --no-cpu-baseline 2>&1 >/dev/null | grep "config headline:"; python bench.py --steps 100 --warmup 5 --no-configs --no-cpu-baseline 2>&1 >/dev/null | grep "config headline:"; python bench.py --steps 20 --warmup 5 --no-configs --no-cpu-baseline --unfused 2>&1 >/dev/null | grep "config headline:"
+
+# ---------------------------------------------------------------- 2026-10-01T03:43:58Z  r06: sparse levers parity on GPU + bench
+mkdir -p gpurun_out/r06c; python -m pytest tests -m gpu -x -q -k "subsample or guarded_16bit or patches" 2>&1 | tail -15 > gpurun_out/r06c/tests.txt; cat gpurun_out/r06c/tests.txt; python tools/sparse_levers_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06c/sparse.txt
