@@ -43,6 +43,7 @@ struct BrickArgs {
     int *ws_header;               // ... the workspace's header words
     int ranges_valid;             // ... already computed for this volume
     const unsigned char *packed;  // 16-bit bricks: their LDS images, brick after brick (or null)
+    const unsigned *fingerprint;  // 16-bit bricks: bit patterns of kFingerprintWords voxels of the volume the workspace was built from
     int vec;                      // bricks_fwd.hip brick_range_kernel: 16-byte loads serve the volume
     const int *order;             // bricks_fwd.hip: k-th brick handed out (NULL: k itself)
     int *order_ws;                // ... this launch's workspace for it: order_cap weights, order_cap ints

@@ -533,6 +533,22 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
 #endif
         ;
     const int n_wg = (int)gridDim.x;
+    // The cached 16-bit workspace against the live volume (brick_core.h kFingerprintWords): every
+    // workgroup compares the build pass's fingerprint for itself -- 16 KB out of L2, one barrier,
+    // once per launch -- and a launch that finds the volume changed renders EVERY brick from the
+    // volume's own fp32 values (the fallback path) instead of the stale bricks: an edit that
+    // bypassed the caller's version counter costs speed, not correctness.
+    bool stale = false;
+    if constexpr (C::MIXED) {
+        if (p.fingerprint != nullptr && p.ranges_valid) {
+            const long n_vox = (long)p.D.x * p.D.y * p.D.z;
+            int bad = 0;
+            for (int i = tid; i < kFingerprintWords; i += C::THREADS)
+                bad |= __float_as_uint(p.vol[fingerprint_index(i, n_vox)]) != p.fingerprint[i];
+            stale = __syncthreads_or(bad) != 0;
+            if (stale && blockIdx.x == 0 && tid == 0) atomicAdd(p.ws_header + 2, 1);
+        }
+    }
     PackedPrefetch<C> pf;
     pf.clear();
     // (workgroup-uniform) la_item / la_brick / la_lo / la_hi: the next item as published by the
@@ -587,7 +603,7 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
             sub = 0;
             n_sub = 1;
             if (C::MIXED) {
-                f32_brick = known ? la_f32 : (p.fallback && p.fallback[brick_id] != 0);
+                f32_brick = stale || (known ? la_f32 : (p.fallback && p.fallback[brick_id] != 0));
                 const int z0 = (brick_id % nbz) * C::BZ;
                 n_sub = f32_brick && p.D.z - z0 > C::HZ ? 2 : 1;
             }
@@ -612,7 +628,7 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
             if (claim) req_item = atomicAdd(p.work, 1);
             if (nx_item >= 0 && nx_item < n_bricks) {
                 req_brick = p.order ? p.order[nx_item] : nx_item;
-                req_fb = C::MIXED && p.fallback ? p.fallback[req_brick] : 0;
+                req_fb = stale ? 1 : (C::MIXED && p.fallback ? p.fallback[req_brick] : 0);
                 req_lo = p.ranges[2 * req_brick];
                 req_hi = p.ranges[2 * req_brick + 1];
             }
@@ -1303,7 +1319,15 @@ __global__ __launch_bounds__(256) void brick_fallback_count_kernel(const int *__
     if (threadIdx.x == 0) {
         header[0] = total;
         header[1] = n_bricks;
+        header[2] = 0;  // launches that found the volume changed under the workspace (fingerprint)
     }
+}
+
+// The build pass's fingerprint of the volume (brick_core.h kFingerprintWords).
+__global__ __launch_bounds__(1024) void brick_fingerprint_kernel(const float *__restrict__ vol, long n_vox,
+                                                                 unsigned *__restrict__ fp) {
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < kFingerprintWords) fp[i] = __float_as_uint(vol[fingerprint_index(i, n_vox)]);
 }
 
 // ------------------------------------------------------------------ heaviest bricks first
@@ -1417,6 +1441,8 @@ int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t
                                const_cast<int *>(p.fallback), p.vec);
             hipLaunchKernelGGL(brick_fallback_count_kernel, dim3(1), dim3(256), 0, st, p.fallback,
                                n_bricks, p.ws_header);
+            hipLaunchKernelGGL(brick_fingerprint_kernel, dim3(kFingerprintWords / 1024), dim3(1024), 0, st,
+                               p.vol, (long)p.D.x * p.D.y * p.D.z, const_cast<unsigned *>(p.fingerprint));
             if (p.packed) {
                 static bool pack_attr[kMaxDev] = {false};
                 {
@@ -1540,15 +1566,18 @@ bool order_bricks(BrickArgs &q, int BX, int BY, int BZ, int nby, int nbz, int n_
 // variant: DDRR_BRICKS_F32 (0) or DDRR_BRICKS_Q16 (1); tools builds know more (g_brick_variant)
 // bytes of the caller's brick workspace: the (min, max) pairs, 2 floats per 32^3 brick (any brick
 // grid fits), then, for the packed storage, the LDS images of the 32 x 32 x 64 bricks
-// layout: [header: 64 words, word 0 = bricks on the fp32 path, word 1 = bricks]
+// layout: [header: 64 words, word 0 = bricks on the fp32 path, word 1 = bricks, word 2 = launches
+//          that found the volume changed under the workspace]
 //         [(min, max) per brick: room for every 32^3 brick] [fallback flag per brick: int]
+//         [fingerprint of the volume the workspace was built from: kFingerprintWords words]
 //         [packed storage: the 16-bit bricks' LDS images]
 constexpr long kWsHeaderBytes = 256;
 static long n32_bricks(int dx, int dy, int dz) {
     return (long)((dx + 31) / 32) * ((dy + 31) / 32) * ((dz + 31) / 32);
 }
+constexpr long kFingerprintBytes = kFingerprintWords * (long)sizeof(unsigned);
 static long ranges_bytes(int dx, int dy, int dz) {
-    return kWsHeaderBytes + (n32_bricks(dx, dy, dz) * 3 * (long)sizeof(float) + 255) / 256 * 256;
+    return kWsHeaderBytes + (n32_bricks(dx, dy, dz) * 3 * (long)sizeof(float) + 255) / 256 * 256 + kFingerprintBytes;
 }
 
 long brick_workspace_bytes(int dx, int dy, int dz, int brick_storage) {
@@ -1615,6 +1644,10 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
     p.packed = packed && brick_ranges
                    ? reinterpret_cast<const unsigned char *>(brick_ranges) + ranges_bytes(dx, dy, dz)
                    : nullptr;
+    p.fingerprint = brick_ranges ? reinterpret_cast<const unsigned *>(
+                                       reinterpret_cast<const unsigned char *>(brick_ranges) +
+                                       ranges_bytes(dx, dy, dz) - kFingerprintBytes)
+                                 : nullptr;
     p.order = nullptr;
     p.clear = clear;
     p.clear_n = clear_n;

@@ -109,6 +109,12 @@ class DRR(nn.Module):
                 img = reshape_subsampled_drr(img, self.detector, batch_size)
         return img
 
+    def volume_changed(self):
+        """``self.density`` was edited through ``.data`` (PyTorch does not track that): rebuild the
+        renderer's cached bricks on the next render.  See ``Siddon.volume_changed`` -- without the
+        call such an edit is still rendered from the live values, at the fp32 bricks' speed."""
+        ops.invalidate_brick_workspace(self.density)
+
     # --------------------------------------------------------------- forward
     def forward(self, *args, parameterization: str = None, convention: str = None,
                 calibration: RigidTransform = None, mask_to_channels: bool = False,

@@ -213,11 +213,12 @@ _range_cache = {}  # (id(volume), storage) -> _Workspace
 
 class _Workspace:
     """Cache entry of :func:`brick_workspace`: the buffer and what it was built from."""
-    __slots__ = ("ref", "buf", "built_version", "churn", "event", "stream")
+    __slots__ = ("ref", "buf", "built_version", "built_ptr", "churn", "event", "stream")
 
     def __init__(self, ref, buf):
         self.ref, self.buf = ref, buf
         self.built_version = None  # volume._version the buffer holds the bricks of (None: nothing)
+        self.built_ptr = None      # ... and the address of the storage they were read from
         self.churn = 0             # rebuilds because the volume had changed
         self.event = self.stream = None  # end of the building launch, and the stream it ran on
 
@@ -237,7 +238,15 @@ def brick_workspace(volume, storage="q16"):
     launch after the volume changed (one pass over the volume); the launch that filled it
     reports so with :func:`brick_workspace_commit`, and only then do later calls get
     ``valid`` = 1 -- a call that returns early (empty batch) or fails leaves it unbuilt.
-    (In-place edits that bypass the version counter, ``volume.data[...] = x``, are not seen.)
+    "Changed" is what PyTorch itself tracks: the tensor's version counter (any in-place op,
+    ``no_grad`` or not) and the address of its storage (``volume.data = other``).  In-place edits
+    that bypass the version counter -- ``volume.data[...] = x``, ``volume.data.copy_(x)`` -- are
+    caught ON THE DEVICE: the workspace carries a fingerprint of the volume it was built from (4096
+    voxels spread over it, csrc/brick_core.h) and a launch that finds it changed renders every
+    brick from the volume's own fp32 values -- slower, never stale
+    (:func:`brick_workspace_stale` reports it; :func:`invalidate_brick_workspace` /
+    ``Siddon.volume_changed`` rebuild).  Only an edit of a few voxels that misses all 4096 samples
+    needs the explicit call.
     -> (tensor, valid)"""
     key = (id(volume), storage)
     ent = _workspace_entry(volume, storage)
@@ -248,7 +257,8 @@ def brick_workspace(volume, storage="q16"):
         ent = _Workspace(weakref.ref(volume, lambda _, k=key: _range_cache.pop(k, None)),
                          torch.empty(n, dtype=torch.float32, device=volume.device))
         _range_cache[key] = ent
-    valid = int(ent.built_version is not None and ent.built_version == volume._version)
+    valid = int(ent.built_version is not None and ent.built_version == volume._version
+                and ent.built_ptr == volume.data_ptr())
     if valid and ent.event is not None and not torch.cuda.is_current_stream_capturing():
         # built on another stream: this stream's launches must not overtake the build
         if ent.event.query():
@@ -262,7 +272,7 @@ def brick_workspace_commit(volume, storage):
     """The launch that was handed ``valid`` = 0 has been enqueued: the workspace now holds (in
     stream order) the bricks of the volume's current version."""
     ent = _workspace_entry(volume, storage)
-    if ent is None or ent.built_version == volume._version:
+    if ent is None or (ent.built_version == volume._version and ent.built_ptr == volume.data_ptr()):
         return
     if volume.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
         # a captured launch has not run: the workspace stays unbuilt for eager launches (which
@@ -271,11 +281,33 @@ def brick_workspace_commit(volume, storage):
     if ent.built_version is not None:
         ent.churn += 1  # workspace_churn() lets the renderer stop paying for rebuilds
     ent.built_version = volume._version
+    ent.built_ptr = volume.data_ptr()
     ent.event = ent.stream = None
     if volume.device.type == "cuda":
         ent.stream = torch.cuda.current_stream(volume.device)
         ent.event = torch.cuda.Event()
         ent.event.record(ent.stream)
+
+
+def invalidate_brick_workspace(volume):
+    """The volume was edited in a way PyTorch does not track (``volume.data[...] = x``): the next
+    render rebuilds its cached 16-bit bricks (every storage).  Without this call such an edit is
+    still rendered correctly -- the launch notices (:func:`brick_workspace`) and takes the fp32
+    path for every brick -- but at the fp32 bricks' speed until the workspace is rebuilt."""
+    for storage in ("q16", "q16p"):
+        ent = _workspace_entry(volume, storage)
+        if ent is not None:
+            ent.built_version = ent.built_ptr = None
+
+
+def brick_workspace_stale(volume, storage):
+    """How many launches found the volume changed under this built workspace (its fingerprint did
+    not match: they rendered from the fp32 values); 0 for a workspace in step with its volume, None
+    if none is built.  Reads one word from the device (a host sync)."""
+    ent = _workspace_entry(volume, storage)
+    if ent is None or ent.built_version is None:
+        return None
+    return int(ent.buf[2:3].view(torch.int32).item())
 
 
 def workspace_churn(volume, storage):

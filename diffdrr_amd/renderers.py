@@ -635,6 +635,16 @@ class Siddon(torch.nn.Module):
     def dims(self, volume):
         return torch.tensor(volume.shape).to(volume)
 
+    @staticmethod
+    def volume_changed(volume):
+        """Tell the renderer that ``volume`` was edited in a way PyTorch does not track
+        (``volume.data[...] = x``): its cached 16-bit bricks are rebuilt by the next render.
+        Tracked edits (any in-place op on the tensor itself, ``volume.data = other``) need no call;
+        an untracked edit without this call is still rendered from the live values -- the launch
+        checks a fingerprint of the volume and falls back to fp32 bricks (``ops.brick_workspace``)
+        -- only slower, until this is called."""
+        ops.invalidate_brick_workspace(volume)
+
     def _cfg(self, align_corners, det="unchecked", reducefn=None):
         if self.mode == "bilinear":
             lookup = "mid_trilinear"

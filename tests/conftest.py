@@ -878,3 +878,78 @@ def check_sparse_lever(name, device, ops, calls=None):
         assert not per_ray & set(calls), (name, sorted(per_ray & set(calls)))
         assert any(c.endswith("_bricks") for c in calls), (name, calls)
     return drr
+
+
+def check_untracked_volume_edits(device, ops):
+    """the default storage renders from a cache of 16-bit bricks
+    keyed on what PyTorch tracks (the tensor's version counter, its storage's address).  Edits
+    that bypass the counter (``volume.data.mul_(2)``) used to render the OLD bricks, silently.
+    Now: the workspace carries a fingerprint of the volume it was built from and the launch
+    compares it with the live volume -- a changed volume is rendered from its own fp32 values
+    (correct, slower) until ``volume_changed()`` has the bricks rebuilt; ``volume.data = other``
+    (a new storage) is seen by the host-side key.  The one thing left to the explicit call: an
+    edit of a few voxels that misses all 4096 samples (documented here, not hidden)."""
+    import torch
+
+    from diffdrr_amd import DRR, Siddon
+    from diffdrr_amd.data import make_subject
+
+    vol = 0.2 + torch.rand(64, 64, 128, generator=torch.Generator().manual_seed(2))
+    vol[:, :, :16] = 0.0  # (some air)
+    drr = DRR(make_subject(vol, spacing=(1.0, 1.0, 1.0)), sdd=1000.0, height=40, delx=2.0).to(device)
+    V = drr.density
+    rot = torch.tensor([[0.2, -0.1, 0.3], [-0.4, 0.25, 0.1]], device=device)
+    xyz = torch.tensor([[3.0, 500.0, -2.0], [-4.0, 520.0, 5.0]], device=device)
+    from test_gpu_parity import voxel_rays
+    s, t, L = voxel_rays(drr, rot, xyz)
+    render = lambda: ops.siddon_forward_bricks(V, s, t, L, (40, 40), storage="q16p")[0].clone()  # noqa: E731
+    img0 = render()
+    assert ops.brick_workspace(V, "q16p")[1] == 1 and ops.brick_workspace_stale(V, "q16p") == 0
+    n_f32, n = ops.brick_fallbacks(V, "q16p")
+    assert n_f32 < n  # (quantised bricks take part)
+    # 1. an untracked in-place edit of the whole volume
+    version = V._version
+    V.data.mul_(2.0)
+    assert V._version == version and ops.brick_workspace(V, "q16p")[1] == 1  # the host sees nothing ...
+    img1 = render()
+    assert rel_err(img1.cpu().numpy(), 2.0 * img0.cpu().numpy()) < 2e-5      # ... the launch does
+    assert ops.brick_workspace_stale(V, "q16p") == 1
+    render()
+    assert ops.brick_workspace_stale(V, "q16p") == 2                          # (slow path until told)
+    Siddon.volume_changed(V)
+    assert ops.brick_workspace(V, "q16p")[1] == 0
+    img2 = render()
+    assert rel_err(img2.cpu().numpy(), 2.0 * img0.cpu().numpy()) < 2e-5
+    assert ops.brick_workspace_stale(V, "q16p") == 0 and ops.brick_fallbacks(V, "q16p") == (n_f32, n)
+    # through the module too
+    with torch.no_grad():
+        m0 = drr(rot, xyz, parameterization="euler_angles", convention="ZXY").clone()
+        drr.density.data.mul_(0.5)
+        m1 = drr(rot, xyz, parameterization="euler_angles", convention="ZXY").clone()
+        drr.volume_changed()
+        m2 = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    assert rel_err(m1.cpu().numpy(), 0.5 * m0.cpu().numpy()) < 2e-5
+    assert rel_err(m2.cpu().numpy(), 0.5 * m0.cpu().numpy()) < 2e-5
+    # 2. a new storage under the same tensor object: the host-side key
+    img_before = render()
+    V.data = (V.data * 3.0).clone()
+    assert ops.brick_workspace(V, "q16p")[1] == 0
+    assert rel_err(render().cpu().numpy(), 3.0 * img_before.cpu().numpy()) < 2e-5
+    # 3. the documented limit: a few voxels between the samples (4096 samples, 524 288 voxels: one in
+    # 128) -- an edit the fingerprint cannot see is rendered from the old bricks until volume_changed()
+    img_before = render()
+    flat = V.data.view(-1)
+    n_vox = flat.numel()  # (csrc/brick_core.h fingerprint_index)
+    sampled = {min(((i * n_vox) >> 12) + (((i * 2654435761 + 0x9e3779b9) & 0xffffffff) >> 7) % max(1, n_vox >> 12),
+                   n_vox - 1) for i in range(4096)}
+    center = (32 * 64 + 32) * 128 + 64
+    k = next(j for j in range(center, center + 200) if j not in sampled)
+    flat[k] += 5.0
+    unseen = render()
+    assert ops.brick_workspace_stale(V, "q16p") == 0  # (not noticed: `unseen` shows the old bricks)
+    if str(device) != "cpu":  # (the emulation stages from the live volume: it keeps no packed copy)
+        assert (unseen - img_before).abs().max() < 1e-3
+    Siddon.volume_changed(V)
+    seen = render()
+    assert (seen - img_before).abs().max() > 1e-3  # the brighter voxel shows after the explicit call
+    assert ops.brick_workspace_stale(V, "q16p") == 0

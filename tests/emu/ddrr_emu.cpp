@@ -361,6 +361,7 @@ long ddrr_brick_workspace_bytes(int dx, int dy, int dz, int brick_storage) {
     if (brick_storage == DDRR_BRICKS_F32 || dx < 1 || dy < 1 || dz < 1) return 0;
     const long n32 = (long)((dx + 31) / 32) * ((dy + 31) / 32) * ((dz + 31) / 32);
     long n = 256 + (n32 * 12 + 255) / 256 * 256;  // header, (min, max) and fallback flag per brick
+    n += kFingerprintWords * 4;                   // the volume's fingerprint (brick_core.h)
     if (brick_storage == DDRR_BRICKS_Q16_PACKED)
         n += (long)((dx + 31) / 32) * ((dy + 31) / 32) * ((dz + 63) / 64) * 133184;
     return n;
@@ -389,6 +390,22 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
     int *brick_fallback = brick_ws ? reinterpret_cast<int *>(brick_ranges + 2 * n32) : nullptr;
     int n_fallback = 0;
     const bool q16 = brick_storage == DDRR_BRICKS_Q16 || brick_storage == DDRR_BRICKS_Q16_PACKED;
+    // the fingerprint of the volume the workspace was built from (brick_core.h): a workspace handed
+    // over as valid whose volume has changed renders every brick from its fp32 values
+    unsigned *fingerprint = brick_ws ? reinterpret_cast<unsigned *>(
+        reinterpret_cast<unsigned char *>(brick_ws) + 256 + (n32 * 12 + 255) / 256 * 256) : nullptr;
+    bool stale = false;
+    if (q16 && fingerprint) {
+        const long n_vox = (long)dx * dy * dz;
+        for (int i = 0; i < kFingerprintWords; ++i) {
+            unsigned bits;
+            memcpy(&bits, volume + fingerprint_index(i, n_vox), 4);
+            if (!ranges_valid) fingerprint[i] = bits;
+            else stale = stale || fingerprint[i] != bits;
+        }
+        if (!ranges_valid) ws_header[2] = 0;
+        else if (stale) ws_header[2] += 1;
+    }
     // 16-bit bricks (bricks_fwd.hip CfgQ16x2): rows and planes padded by one element
     const int qsy = 32 * 2 + 2, qsx = 32 * qsy + 2;
     std::vector<unsigned short> qbrick((size_t)qsx * 32 / 2);
@@ -457,7 +474,7 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
             if (ranges_valid) {
                 vmin = brick_ranges[2 * id];
                 vmax = brick_ranges[2 * id + 1];
-                fallback = brick_fallback[id] != 0;
+                fallback = stale || brick_fallback[id] != 0;
             } else {
                 brick_ranges[2 * id] = vmin;
                 brick_ranges[2 * id + 1] = vmax;

@@ -162,3 +162,8 @@ def test_quantisation_error_per_pixel_on_noisy_ct_like_volumes(seed, lung_sigma,
           f"bricks on the fp32 path; quantisation error: image-normalised {err.max() / exact.max():.2e}, "
           f"at most {float((err / (bound + 1e-30)).max()):.2f} of the guaranteed bound; relative to the pixel's own "
           f"value, " + "; ".join(figures))
+
+
+def test_untracked_volume_edits_are_rendered_from_the_live_values(emulated_ops):
+    """(host emulation; the device twin: tests/test_gpu_brick_storage.py)"""
+    conftest.check_untracked_volume_edits("cpu", emulated_ops)

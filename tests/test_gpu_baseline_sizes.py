@@ -558,3 +558,56 @@ def test_channel_renders_sum_to_the_plain_render_at_the_published_size(gpu):
                     mask_to_channels=True, **kw)
         assert c.shape == (2, C, H, H)
         assert rel_err(c.sum(1, keepdim=True).cpu().numpy(), a.cpu().numpy()) < 3e-5, renderer
+
+
+@pytest.mark.parametrize("kind", ["noise", "phantom"])
+@pytest.mark.parametrize("D,det,delx,B", [(128, 128, 2.4, 1), (128, 128, 2.4, 32), (256, 256, 1.2, 1), (256, 256, 1.2, 32)])
+def test_drr_ncc_vs_fp64_oracle_chain(gpu, D, det, delx, B, kind):
+    """``DRR.ncc`` -- the registration objective of reference
+    registration.py:32-42 + metrics.py:21-44 as three fused launches around the brick kernel
+    (ddrr_pose_raygen_forward, ddrr_siddon_ncc_forward, ddrr_siddon_ncc_backward_pose) -- held to
+    the fp64 ORACLE chain, not to the HIP composition it replaces: per pose the value against NCC
+    (float64) of the fp64 oracle's image, and d/d(rot, xyz) against the oracle's analytic fp64 ray
+    gradients under d NCC / d image (float64), chained through float64 ray generation to the pose
+    parameters; yardstick = the same chain in the reference's fp32 arithmetic.  Fused AND composed
+    (``FUSED_NCC_MAX_POSES = 0``: DRR.forward + the NCC module through autograd), 1 and 32 poses
+    per call (32: every value, the gradients of 4 poses -- 32 on a host with >= 64 cores)."""
+    import os
+
+    from bench import OracleChain, _ncc_grad64
+
+    drr, rot, xyz = scene(D, det, delx, B + 1, gpu, seed=5, kind=kind)
+    with torch.no_grad():
+        fixed = drr(rot[:1], xyz[:1], parameterization="euler_angles", convention="ZXY")  # the AP view
+    rot, xyz = rot[1:].contiguous(), xyz[1:].contiguous()                                 # B perturbed poses
+    results = {}
+    for route, cap in (("fused", 32), ("composed", 0)):
+        drr.FUSED_NCC_MAX_POSES = cap
+        r, x = rot.clone().requires_grad_(), xyz.clone().requires_grad_()
+        vals = drr.ncc(fixed, r, x, convention="ZXY")
+        assert type(vals.grad_fn).__name__.startswith("_EulerSiddonNccFn") == (route == "fused")
+        vals.sum().backward()
+        results[route] = (vals.detach().cpu().numpy(), r.grad.cpu().numpy(), x.grad.cpu().numpy())
+    drr.FUSED_NCC_MAX_POSES = 32
+    chain = OracleChain(drr)
+    fx = fixed.reshape(-1).cpu().numpy()
+    picks = range(B) if (os.cpu_count() or 1) >= 64 else range(0, B, max(1, B // 4))
+    worst = {}
+    for b in picks:
+        rays32 = tuple(a.cpu().numpy() for a in voxel_rays(drr, rot[b:b + 1], xyz[b:b + 1]))
+        _, _, img64 = chain(rot[b], xyz[b], rays32, np.zeros(fx.size), np.float64)
+        z = lambda a: (a - a.mean()) / np.sqrt(a.var() + 1e-5)  # noqa: E731
+        ncc64 = float((z(fx.astype(np.float64)) * z(img64.astype(np.float64))).mean())
+        W = _ncc_grad64(fx, img64)
+        gr64, gx64, _ = chain(rot[b], xyz[b], rays32, W, np.float64)
+        gr32, gx32, _ = chain(rot[b], xyz[b], rays32, W, np.float32)
+        truth = np.concatenate([gr64, gx64 * 100.0])  # (mm -> a scale comparable with radians)
+        own = rel_err(np.concatenate([gr32, gx32 * 100.0]), truth)
+        for route, (v, g_r, g_x) in results.items():
+            assert abs(v[b] - ncc64) < 1e-5, (route, b, v[b], ncc64)
+            err = rel_err(np.concatenate([g_r[b], g_x[b] * 100.0]), truth)
+            worst[route] = max(worst.get(route, 0.0), err)
+            assert err < 2 * own + GRAD_TOL, (route, b, err, own)
+        worst["reference fp32"] = max(worst.get("reference fp32", 0.0), own)
+    print(f"[DRR.ncc vs the fp64 oracle chain, {kind} {D}^3 -> {det}^2, {B} pose(s), {len(list(picks))} checked] "
+          + ", ".join(f"{k}: {v:.2e}" for k, v in worst.items()))

@@ -426,3 +426,9 @@ def test_guarded_16bit_bricks_per_pixel_on_noisy_ct_like_volumes(gpu, seed, lung
     assert 0 < n_f32 < n  # (both paths took part)
     print(f"[guard fuzz seed {seed}, lung x{lung_sigma}, tissue x{tissue_sigma}] worst per-pixel relative "
           f"|q16p - f32| = {worst:.2e}; {n_f32} of {n} bricks on the fp32 path")
+
+
+def test_untracked_volume_edits_are_rendered_from_the_live_values(gpu):
+    """`volume.data.mul_(2)` between renders: the launch notices (fingerprint), renders from fp32,
+    and `volume_changed()` gets the 16-bit bricks back."""
+    conftest.check_untracked_volume_edits(gpu, ops)
