@@ -593,6 +593,15 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
                     f"poses sharded over the ranks, all_gather of the per-pose similarities")
         dominant = "ddrr_siddon_forward_bricks"
 
+    # The collector stays out of the timed region, as in `timeit`: a generation-2 pass of a process
+    # that has imported torch takes ~50 ms -- 40 steps' worth -- and WHERE it falls depends on the
+    # allocation count of everything before it (the driver's 20-step run of round 6's first build
+    # read 3.38 ms per step where 400 steps read 1.50: profiles/r06/gc_pause_in_the_timed_region.txt).
+    # Collected HERE, in front of the priming steps: the pause idles the board, and an idle board
+    # needs ~0.1 s under load to clock up again (collected directly in front of the timed region, the
+    # same 20-step run read kernels of 1.56 instead of 1.41 ms).
+    gc.collect()
+    gc.disable()
     if on_gpu:
         # set-up, not measurement: the first launches on a fresh box allocate (caching allocator,
         # the 16-bit bricks of the volume) and run at boot clocks; the driver's own --warmup may be
@@ -606,12 +615,6 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
         step()
     fence(pending)
     pending.clear()
-    # (the collector stays out of the timed region, as in `timeit`: a generation-2 pass of a process
-    # that has imported torch takes ~50 ms -- 40 steps' worth -- and WHERE it falls depends on the
-    # allocation count of everything before it: the driver's 20-step run of round 6's first build
-    # read 3.38 ms per step where 400 steps read 1.50, profiles/r06/gc_pause_in_the_timed_region.txt)
-    gc.collect()
-    gc.disable()
     timer.enabled, timer.only = True, (dominant if cfg != "4" else None)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -619,7 +622,8 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
     fence(pending)
     dt = time.perf_counter() - t0
     timer.enabled, timer.only = False, None
-    gc.enable()
+    # (the collector stays off for the legs that follow -- forward-only launches between HIP events,
+    # the other configs: every run_config collects once, up front)
     assert torch.isfinite(last).all()
     # the step's other kernels: a few steps of their own, every launch but the dominant one timed
     census_steps = 0

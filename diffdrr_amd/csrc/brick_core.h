@@ -28,24 +28,25 @@ namespace ddrr {
 constexpr int BRICK = 32;  // brick edge in voxels
 
 // Fingerprint of the volume a cached 16-bit brick workspace was built from: the bit patterns of
-// kFingerprintWords voxels spread evenly over the flat volume.  The build pass stores them in the
+// kFingerprintWords voxels spread over the flat volume.  The build pass stores them in the
 // workspace; every launch that is handed the workspace as valid compares them with the live volume
-// (siddon_fwd_brick_kernel) and, on a mismatch, renders every brick from the volume's own fp32
-// values -- the caller's validity test cannot see edits that bypass its version counter
-// (PyTorch: `volume.data[...] = x`).  Catches any edit that touches a sampled voxel (a replaced
-// or rescaled volume: always); an edit of a few voxels between the samples is not seen.
-// Sample i lies in the i-th of 4096 equal cells of the flat volume, at a hashed offset inside its
+// (siddon_fwd_brick_kernel: one voxel per thread, one round trip, ~2 us per launch) and, on a
+// mismatch, renders every brick from the volume's own fp32 values -- the caller's validity test
+// cannot see edits that bypass its version counter (PyTorch: `volume.data[...] = x`).  Catches any
+// edit that touches a sampled voxel (a replaced or rescaled volume: always); an edit of a few
+// voxels between the samples is not seen.
+// Sample i lies in the i-th of 1024 equal cells of the flat volume, at a hashed offset inside its
 // cell: an even stride alone is a multiple of the row length for every power-of-two volume (512^3:
 // every sample in slice z = 0 -- air, in a CT) and would see nothing of an edit of the body.
-constexpr int kFingerprintWords = 4096;
+constexpr int kFingerprintWords = 1024;
 DDRR_HD long fingerprint_index(int i, long n_vox) {
-    const unsigned long long base = ((unsigned long long)i * (unsigned long long)n_vox) >> 12;
-    const unsigned cell = (unsigned)(n_vox >> 12) > 0u ? (unsigned)(n_vox >> 12) : 1u;  // (volumes below 2^44 voxels)
-    const unsigned h = ((unsigned)i * 2654435761u + 0x9e3779b9u) >> 7;
-    const long idx = (long)(base + h % cell);
+    const unsigned long long cell = n_vox >> 10 > 0 ? (unsigned long long)(n_vox >> 10) : 1ull;
+    // offsets below the largest power of two in the cell: a mask, not a division
+    const unsigned long long mask = (1ull << (63 - __builtin_clzll(cell))) - 1ull;
+    const unsigned long long h = ((unsigned)i * 2654435761u + 0x9e3779b9u) >> 4;
+    const long idx = (long)((unsigned long long)i * cell + (h & mask));
     return idx < n_vox ? idx : n_vox - 1;
 }
-static_assert(kFingerprintWords == 1 << 12, "fingerprint_index");
 
 struct BrickGrid {
     int nx, ny, nz;

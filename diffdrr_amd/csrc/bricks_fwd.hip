@@ -534,8 +534,8 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
         ;
     const int n_wg = (int)gridDim.x;
     // The cached 16-bit workspace against the live volume (brick_core.h kFingerprintWords): every
-    // workgroup compares the build pass's fingerprint for itself -- 16 KB out of L2, one barrier,
-    // once per launch -- and a launch that finds the volume changed renders EVERY brick from the
+    // workgroup compares the build pass's fingerprint for itself -- one voxel per thread, one
+    // barrier, once per launch -- and a launch that finds the volume changed renders EVERY brick from the
     // volume's own fp32 values (the fallback path) instead of the stale bricks: an edit that
     // bypassed the caller's version counter costs speed, not correctness.
     bool stale = false;
@@ -1441,7 +1441,7 @@ int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t
                                const_cast<int *>(p.fallback), p.vec);
             hipLaunchKernelGGL(brick_fallback_count_kernel, dim3(1), dim3(256), 0, st, p.fallback,
                                n_bricks, p.ws_header);
-            hipLaunchKernelGGL(brick_fingerprint_kernel, dim3(kFingerprintWords / 1024), dim3(1024), 0, st,
+            hipLaunchKernelGGL(brick_fingerprint_kernel, dim3((kFingerprintWords + 1023) / 1024), dim3(1024), 0, st,
                                p.vol, (long)p.D.x * p.D.y * p.D.z, const_cast<unsigned *>(p.fingerprint));
             if (p.packed) {
                 static bool pack_attr[kMaxDev] = {false};

@@ -241,11 +241,11 @@ def brick_workspace(volume, storage="q16"):
     "Changed" is what PyTorch itself tracks: the tensor's version counter (any in-place op,
     ``no_grad`` or not) and the address of its storage (``volume.data = other``).  In-place edits
     that bypass the version counter -- ``volume.data[...] = x``, ``volume.data.copy_(x)`` -- are
-    caught ON THE DEVICE: the workspace carries a fingerprint of the volume it was built from (4096
+    caught ON THE DEVICE: the workspace carries a fingerprint of the volume it was built from (1024
     voxels spread over it, csrc/brick_core.h) and a launch that finds it changed renders every
     brick from the volume's own fp32 values -- slower, never stale
     (:func:`brick_workspace_stale` reports it; :func:`invalidate_brick_workspace` /
-    ``Siddon.volume_changed`` rebuild).  Only an edit of a few voxels that misses all 4096 samples
+    ``Siddon.volume_changed`` rebuild).  Only an edit of a few voxels that misses all 1024 samples
     needs the explicit call.
     -> (tensor, valid)"""
     key = (id(volume), storage)

@@ -888,7 +888,7 @@ def check_untracked_volume_edits(device, ops):
     compares it with the live volume -- a changed volume is rendered from its own fp32 values
     (correct, slower) until ``volume_changed()`` has the bricks rebuilt; ``volume.data = other``
     (a new storage) is seen by the host-side key.  The one thing left to the explicit call: an
-    edit of a few voxels that misses all 4096 samples (documented here, not hidden)."""
+    edit of a few voxels that misses all 1024 samples (documented here, not hidden)."""
     import torch
 
     from diffdrr_amd import DRR, Siddon
@@ -935,13 +935,15 @@ def check_untracked_volume_edits(device, ops):
     V.data = (V.data * 3.0).clone()
     assert ops.brick_workspace(V, "q16p")[1] == 0
     assert rel_err(render().cpu().numpy(), 3.0 * img_before.cpu().numpy()) < 2e-5
-    # 3. the documented limit: a few voxels between the samples (4096 samples, 524 288 voxels: one in
-    # 128) -- an edit the fingerprint cannot see is rendered from the old bricks until volume_changed()
+    # 3. the documented limit: a few voxels between the samples (1024 samples, 524 288 voxels: one in
+    # 512) -- an edit the fingerprint cannot see is rendered from the old bricks until volume_changed()
     img_before = render()
     flat = V.data.view(-1)
     n_vox = flat.numel()  # (csrc/brick_core.h fingerprint_index)
-    sampled = {min(((i * n_vox) >> 12) + (((i * 2654435761 + 0x9e3779b9) & 0xffffffff) >> 7) % max(1, n_vox >> 12),
-                   n_vox - 1) for i in range(4096)}
+    cell = max(1, n_vox >> 10)
+    mask = (1 << (cell.bit_length() - 1)) - 1
+    sampled = {min(i * cell + ((((i * 2654435761 + 0x9e3779b9) & 0xffffffff) >> 4) & mask), n_vox - 1)
+               for i in range(1024)}
     center = (32 * 64 + 32) * 128 + 64
     k = next(j for j in range(center, center + 200) if j not in sampled)
     flat[k] += 5.0

@@ -591,23 +591,32 @@ def test_drr_ncc_vs_fp64_oracle_chain(gpu, D, det, delx, B, kind):
     drr.FUSED_NCC_MAX_POSES = 32
     chain = OracleChain(drr)
     fx = fixed.reshape(-1).cpu().numpy()
-    picks = range(B) if (os.cpu_count() or 1) >= 64 else range(0, B, max(1, B // 4))
-    worst = {}
+    picks = list(range(B) if (os.cpu_count() or 1) >= 64 else range(0, B, max(1, B // 4)))
+    truths, refs = [], []
     for b in picks:
         rays32 = tuple(a.cpu().numpy() for a in voxel_rays(drr, rot[b:b + 1], xyz[b:b + 1]))
         _, _, img64 = chain(rot[b], xyz[b], rays32, np.zeros(fx.size), np.float64)
         z = lambda a: (a - a.mean()) / np.sqrt(a.var() + 1e-5)  # noqa: E731
         ncc64 = float((z(fx.astype(np.float64)) * z(img64.astype(np.float64))).mean())
+        for route, (v, _, _) in results.items():
+            assert abs(v[b] - ncc64) < 1e-5, (route, b, v[b], ncc64)
         W = _ncc_grad64(fx, img64)
         gr64, gx64, _ = chain(rot[b], xyz[b], rays32, W, np.float64)
         gr32, gx32, _ = chain(rot[b], xyz[b], rays32, W, np.float32)
-        truth = np.concatenate([gr64, gx64 * 100.0])  # (mm -> a scale comparable with radians)
-        own = rel_err(np.concatenate([gr32, gx32 * 100.0]), truth)
-        for route, (v, g_r, g_x) in results.items():
-            assert abs(v[b] - ncc64) < 1e-5, (route, b, v[b], ncc64)
-            err = rel_err(np.concatenate([g_r[b], g_x[b] * 100.0]), truth)
-            worst[route] = max(worst.get(route, 0.0), err)
-            assert err < 2 * own + GRAD_TOL, (route, b, err, own)
-        worst["reference fp32"] = max(worst.get("reference fp32", 0.0), own)
-    print(f"[DRR.ncc vs the fp64 oracle chain, {kind} {D}^3 -> {det}^2, {B} pose(s), {len(list(picks))} checked] "
+        truths.append(np.concatenate([gr64, gx64 * 100.0]))  # (mm -> a scale comparable with radians)
+        refs.append(np.concatenate([gr32, gx32 * 100.0]))
+    # errors in units of the batch's largest gradient component: a pose whose own gradient happens to
+    # be small (NCC near a ridge) carries the same ABSOLUTE fp32 error as its neighbours -- per-pose
+    # normalisation reads that as 1.5e-3 for every kernel here, the per-ray walk included
+    # (profiles/r06/ncc_grad_probe.txt)
+    truths, refs = np.stack(truths), np.stack(refs)
+    scale = np.abs(truths).max()
+    own = np.abs(refs - truths).max() / scale
+    worst = {"reference fp32": own}
+    for route, (_, g_r, g_x) in results.items():
+        mine = np.concatenate([g_r[picks], g_x[picks] * 100.0], axis=1)
+        err = np.abs(mine - truths).max(axis=1) / scale
+        worst[route] = float(err.max())
+        assert err.max() < 2 * own + GRAD_TOL, (route, int(err.argmax()), float(err.max()), own)
+    print(f"[DRR.ncc vs the fp64 oracle chain, {kind} {D}^3 -> {det}^2, {B} pose(s), {len(picks)} checked] "
           + ", ".join(f"{k}: {v:.2e}" for k, v in worst.items()))

@@ -12,3 +12,12 @@ python tools/_diag_events.py; python bench.py --steps 20 --warmup 5 --no-configs
 
 # ---------------------------------------------------------------- 2026-10-01T03:43:58Z  r06: sparse levers parity on GPU + bench
 mkdir -p gpurun_out/r06c; python -m pytest tests -m gpu -x -q -k "subsample or guarded_16bit or patches" 2>&1 | tail -15 > gpurun_out/r06c/tests.txt; cat gpurun_out/r06c/tests.txt; python tools/sparse_levers_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06c/sparse.txt
+
+# ---------------------------------------------------------------- 2026-10-01T03:51:26Z  r06: full gpu suite + bench driver command
+mkdir -p gpurun_out/r06d; python -m pytest tests -m gpu -x -q -s 2>&1 | grep -v "^$" | tail -60 > gpurun_out/r06d/gpu_suite.txt; tail -5 gpurun_out/r06d/gpu_suite.txt; python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06d/bench_stdout.txt 2> gpurun_out/r06d/bench_stderr.txt; echo bench rc=$?; cp bench_full.json gpurun_out/r06d/; grep -v "full record" gpurun_out/r06d/bench_stderr.txt | grep "config headline\|sparse\|few poses"
+
+# ---------------------------------------------------------------- 2026-10-01T03:54:10Z  r06: ncc grad probe 128 phantom
+python tools/ncc_grad_probe.py 128 128 2.4 phantom 31 0 8 16 2>&1 | grep -v amdgpu.ids
+
+# ---------------------------------------------------------------- 2026-10-01T03:54:48Z  r06: ncc oracle chain + untracked edits + sparse tests
+python -m pytest tests -m gpu -x -q -s -k "ncc_vs_fp64 or untracked or subsample or PoseAdam or pose_adam" 2>&1 | grep -v "^$" | tail -30
