@@ -480,7 +480,9 @@ __global__ __launch_bounds__(C::THREADS) void brick_pack_kernel(BrickArgs p, int
 #define DDRR_TRACE(k, how) {}
 #endif
 
-template <bool AUX, class C>
+// PRE (launches of a few poses on the 16-bit storages): the workgroup's first claim is made in front
+// of the loop, see the fingerprint comparison below.
+template <bool AUX, class C, bool PRE = false>
 __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict__ aux) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -533,22 +535,6 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
 #endif
         ;
     const int n_wg = (int)gridDim.x;
-    // The cached 16-bit workspace against the live volume (brick_core.h kFingerprintWords): every
-    // workgroup compares the build pass's fingerprint for itself -- one voxel per thread, one
-    // barrier, once per launch -- and a launch that finds the volume changed renders EVERY brick from the
-    // volume's own fp32 values (the fallback path) instead of the stale bricks: an edit that
-    // bypassed the caller's version counter costs speed, not correctness.
-    bool stale = false;
-    if constexpr (C::MIXED) {
-        if (p.fingerprint != nullptr && p.ranges_valid) {
-            const long n_vox = (long)p.D.x * p.D.y * p.D.z;
-            int bad = 0;
-            for (int i = tid; i < kFingerprintWords; i += C::THREADS)
-                bad |= __float_as_uint(p.vol[fingerprint_index(i, n_vox)]) != p.fingerprint[i];
-            stale = __syncthreads_or(bad) != 0;
-            if (stale && blockIdx.x == 0 && tid == 0) atomicAdd(p.ws_header + 2, 1);
-        }
-    }
     PackedPrefetch<C> pf;
     pf.clear();
     // (workgroup-uniform) la_item / la_brick / la_lo / la_hi: the next item as published by the
@@ -556,6 +542,54 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
     int la_item = -1, la_brick = 0, la_after = -1;
     float la_lo = 0.f, la_hi = 0.f;
     bool la_f32 = false;  // the next item's brick is on the fp32 path
+    // The cached 16-bit workspace against the live volume (brick_core.h kFingerprintWords): every
+    // workgroup compares the build pass's fingerprint for itself -- one voxel per thread, one
+    // barrier, once per launch -- and a launch that finds the volume changed renders EVERY brick from
+    // the volume's own fp32 values (the fallback path) instead of the stale bricks: an edit that
+    // bypassed the caller's version counter costs speed, not correctness.  Waited for on its own in
+    // front of the loop the comparison costs a launch ~3 us: 0.2 % of a 32-pose launch, 2.7 % of a
+    // one-pose launch (110 us).  PRE, the instantiation for launches of at most 8 poses, hides the
+    // round trip behind the workgroup's FIRST claim, made here by thread 0 with the lookups behind
+    // it (order, fallback flag, range: three dependent round trips) and handed to the loop as an item
+    // already known, like the look-ahead's: one pose 0.113 -> 0.110 ms.  (As the only form it cost the
+    // 32-pose launches 1 % -- 1.446 against 1.432 ms with the record, same box, the loop's register
+    // allocation -- hence two instantiations: profiles/r06/fingerprint_placement_ab.txt.)
+    bool stale = false;
+    if constexpr (C::MIXED) {
+        if (p.fingerprint != nullptr && p.ranges_valid) {
+            static_assert(kFingerprintWords <= C::THREADS, "one sample per thread");
+            int bad = 0;
+            if (tid < kFingerprintWords)
+                bad = __float_as_uint(p.vol[fingerprint_index(tid, (long)p.D.x * p.D.y * p.D.z)]) != p.fingerprint[tid];
+            if constexpr (PRE) {
+                if (tid == 0) {
+                    const int it = atomicAdd(p.work, 1);
+                    int b = 0, fb = 0;
+                    float lo = 0.f, hi = 0.f;
+                    if (it < n_bricks) {
+                        b = p.order ? p.order[it] : it;
+                        fb = p.fallback ? p.fallback[b] : 0;
+                        lo = p.ranges[2 * b];
+                        hi = p.ranges[2 * b + 1];
+                    }
+                    ahead[0] = it;
+                    ahead[1] = b | (fb ? kLaStage : 0);
+                    ahead[2] = __float_as_int(lo);
+                    ahead[3] = __float_as_int(hi);
+                }
+            }
+            stale = __syncthreads_or(bad) != 0;
+            if constexpr (PRE) {
+                la_item = uni(ahead[0]);
+                const int b = uni(ahead[1]);
+                la_brick = b & ~kLaStage;
+                la_f32 = stale || (b & kLaStage) != 0;
+                la_lo = __int_as_float(uni(ahead[2]));
+                la_hi = __int_as_float(uni(ahead[3]));
+            }
+            if (stale && blockIdx.x == 0 && tid == 0) atomicAdd(p.ws_header + 2, 1);
+        }
+    }
     // what `pf` holds for the unit (brick, or half of a brick on the fp32 path) after the one in
     // hand: 0 nothing, 1 the packed image of a quantised brick (or nothing to load: air), 2 a half's
     // fp32 values
@@ -1410,7 +1444,7 @@ __global__ __launch_bounds__(256) void brick_clear_kernel(float *__restrict__ bu
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) buf[(n4 << 2) + threadIdx.x] = 0.f;
 }
 
-template <bool AUX, class C>
+template <bool AUX, class C, bool PRE = false>
 int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t st) {
     static_assert(C::LDS <= C::LDS_BUDGET, "LDS budget");
     constexpr int kMaxDev = 64;
@@ -1424,7 +1458,7 @@ int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t
         std::lock_guard<std::mutex> lock(mu);
         if (!attr_set[dev]) {
             if ((e = hipFuncSetAttribute(
-                     reinterpret_cast<const void *>(&siddon_fwd_brick_kernel<AUX, C>),
+                     reinterpret_cast<const void *>(&siddon_fwd_brick_kernel<AUX, C, PRE>),
                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS)) != hipSuccess)
                 return fail_hip(e, "hipFuncSetAttribute");
             attr_set[dev] = true;
@@ -1483,7 +1517,7 @@ int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t
             return fail_hip(e, "hipMemsetAsync");
     }
     const dim3 grid(n_bricks < slots ? n_bricks : slots), block(C::THREADS);
-    hipLaunchKernelGGL((siddon_fwd_brick_kernel<AUX, C>), grid, block, C::LDS, st, q, out, aux);
+    hipLaunchKernelGGL((siddon_fwd_brick_kernel<AUX, C, PRE>), grid, block, C::LDS, st, q, out, aux);
     return 0;
 }
 
@@ -1689,7 +1723,14 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
     }
     switch (variant) {
         case DDRR_BRICKS_F32: rc = DDRR_LAUNCH(CfgF32); break;
-        case DDRR_BRICKS_Q16: rc = DDRR_LAUNCH(CfgQ16Z64); break;
+        case DDRR_BRICKS_Q16:
+            // (a few poses: the instantiation whose first claim hides the fingerprint's round trip)
+            if (B <= 8)
+                rc = aux ? launch_cfg<true, CfgQ16Z64, true>(p, n_cu, out, aux, st)
+                         : launch_cfg<false, CfgQ16Z64, true>(p, n_cu, out, aux, st);
+            else
+                rc = DDRR_LAUNCH(CfgQ16Z64);
+            break;
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)
         case 2: rc = DDRR_LAUNCH(CfgQ16x1); break;
         case 10: rc = DDRR_LAUNCH(CfgQ16x2); break;

@@ -21,3 +21,15 @@ python tools/ncc_grad_probe.py 128 128 2.4 phantom 31 0 8 16 2>&1 | grep -v amdg
 
 # ---------------------------------------------------------------- 2026-10-01T03:54:48Z  r06: ncc oracle chain + untracked edits + sparse tests
 python -m pytest tests -m gpu -x -q -s -k "ncc_vs_fp64 or untracked or subsample or PoseAdam or pose_adam" 2>&1 | grep -v "^$" | tail -30
+
+# ---------------------------------------------------------------- 2026-10-01T03:57:18Z  r06: bench driver command after gc/clock fix + fingerprint cost
+mkdir -p gpurun_out/r06e; for i in 1 2; do python bench.py --gpus 1 --steps 20 --warmup 5 --no-configs --no-cpu-baseline 2>&1 >/dev/null | grep "config headline:"; done; python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06e/bench_stdout.txt 2> gpurun_out/r06e/bench_stderr.txt; echo bench rc=$?; cp bench_full.json gpurun_out/r06e/; grep -v "full record" gpurun_out/r06e/bench_stderr.txt | grep "config headline\|sparse\|few poses\|config ct\|config 4"; python -m pytest tests -m gpu -x -q -k "ncc_vs_fp64 or untracked or subsample" 2>&1 | tail -3
+
+# ---------------------------------------------------------------- 2026-10-01T04:01:55Z  r06: fingerprint hidden behind the first claim: brick tests + bench
+python -m pytest tests -m gpu -x -q -k "brick or look_ahead or untracked or headline or storage" 2>&1 | tail -3; python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>&1 >/dev/null | grep -v "full record" | grep "config headline\|few poses\|config ct\|config 4:"
+
+# ---------------------------------------------------------------- 2026-10-01T04:04:19Z  r06: A/B fingerprint placement
+for r in 1 2; do for v in A_preclaim B_before_loop; do cp tools/_build/ab/lib$v.so diffdrr_amd/csrc/libdiffdrr_hip.so; echo == $v; python bench.py --gpus 1 --steps 200 --warmup 5 --no-cpu-baseline --no-configs 2>&1 >/dev/null | grep -v "full record" | grep "config headline" | sed "s/| backward.*//"; done; done
+
+# ---------------------------------------------------------------- 2026-10-01T04:05:36Z  r06: PRE instantiation: brick tests + bench legs
+python -m pytest tests -m gpu -x -q -k "brick or look_ahead or untracked or headline or storage or registration or graph" 2>&1 | tail -3; python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>&1 >/dev/null | grep -v "full record" | grep "config headline\|few poses\|config ct\|config 4:"
