@@ -476,6 +476,7 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
         gathered = torch.empty(world * B, device=device) if world > 1 else None
         pending = []  # the in-flight all_gather of the last step
         keep = {}
+        one = torch.ones((), device=device)  # d (sum of the per-pose values) / d itself, ready-made
 
         def step():
             rot.grad = None
@@ -483,11 +484,16 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
             if args.unfused:
                 img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
                 loss = ncc(base.expand(B, -1, -1, -1), img)  # (B,) one similarity per pose
+                loss.sum().backward()
             else:
                 # the same objective through DRR.ncc: pose -> rays, image-from-record + NCC and NCC
-                # backward -> pose parameters as three fused launches around the brick kernel
-                loss = drr.ncc(base, rot, xyz, convention="ZXY", eps=ncc.eps)
-            loss.sum().backward()
+                # backward -> pose parameters as three fused launches around the brick kernel; the
+                # batch's sum comes out of the forward epilogue and its gradient goes back in as one
+                # ready-made value: no reduction, no fill
+                total = drr.ncc(base, rot, xyz, convention="ZXY", eps=ncc.eps, reduction="sum")
+                total.backward(gradient=one)
+                # (the per-pose values: what the epilogue wrote on its way to the sum)
+                loss = drr.ncc_per_pose
             if world > 1:
                 # the 4 B/pose of losses travel on RCCL's own stream while the next step renders:
                 # nothing on the compute stream waits for them before fence()

@@ -160,19 +160,25 @@ __global__ __launch_bounds__(kBlock) void pose_euler_bwd_kernel(
 // The workspace (moments, dL/dMw accumulators, tickets) is caller-owned, zero when it is first
 // handed over, and left zero by every call: no fills.  Reference: diffdrr/pose.py:140-190,
 // detector.py:144-154, drr.py:201-205, metrics.py:21-44 and their autograd.
-constexpr int kStepRaysPerBlock = 1024;  // rays of one pose per workgroup of the two epilogues
+constexpr int kStepRaysPerBlock = 1024;  // rays of one pose per workgroup of the backward epilogue
+constexpr int kNccFwdQuads = 4;          // 16-byte runs of four rays per thread of the forward epilogue ...
+constexpr int kNccFwdRaysPerBlock = 4 * kNccFwdQuads * kBlock;  // ... 4096 rays of one pose per workgroup
 
 struct NccWs {
     double *mom;   // [B][5]  sum x1, x2, x1^2, x2^2, x1 x2
+    double *total; // sum of the pairs' NCC (ncc_sum)
     float *gacc;   // [B][12] dLoss/dMw
     int *tick1, *tick2;  // [B] each
+    int *tick_all;       // pairs that have added their NCC to `total`
 };
 __host__ __device__ inline NccWs ncc_ws(void *ws, int B) {
     NccWs w;
     w.mom = reinterpret_cast<double *>(ws);
-    w.gacc = reinterpret_cast<float *>(w.mom + 5 * (long)B);
+    w.total = w.mom + 5 * (long)B;
+    w.gacc = reinterpret_cast<float *>(w.total + 1);
     w.tick1 = reinterpret_cast<int *>(w.gacc + 12 * (long)B);
     w.tick2 = w.tick1 + B;
+    w.tick_all = w.tick2 + B;
     return w;
 }
 
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void pose_raygen_fwd_kernel(
 __global__ __launch_bounds__(kBlock) void siddon_ncc_fwd_kernel(
     const float *__restrict__ aux, const float *__restrict__ img, const float *__restrict__ x1,
     long x1_stride, int B, int N, float eps, void *ws_raw, float *__restrict__ ncc_out,
-    float *__restrict__ stats, float *__restrict__ out) {
+    float *__restrict__ stats, float *__restrict__ out, float *__restrict__ ncc_sum) {
     __shared__ double red[5][kWavesPerBlock];
     __shared__ int last;
     const NccWs ws = ncc_ws(ws_raw, B);
@@ -265,23 +271,37 @@ __global__ __launch_bounds__(kBlock) void siddon_ncc_fwd_kernel(
     };
     const float *p1 = x1 + b * x1_stride, *pl = img + (long)b * N;
     const long r0 = (long)b * N;
-    const int n0 = blockIdx.x * kStepRaysPerBlock, n_end = min(N, n0 + kStepRaysPerBlock);
-    // four consecutive rays per thread: plane I of rays 4 k .. 4 k + 3 is one aligned 16-byte run of
-    // the blocked record (record_layout.h), like the rays' lengths and the fixed image's pixels
+    const int n0 = blockIdx.x * kNccFwdRaysPerBlock, n_end = min(N, n0 + kNccFwdRaysPerBlock);
+    // four consecutive rays per load: plane I of rays 4 k .. 4 k + 3 is one aligned 16-byte run of
+    // the blocked record (record_layout.h), like the rays' lengths and the fixed image's pixels.
+    // A thread takes kNccFwdQuads such quads, ALL requested before the first is summed (twelve
+    // 16-byte loads in flight per thread, two workgroups per CU and pose at 256^2: the kernel
+    // streams 12 B per ray and round 5's one quad per thread -- then the reduction tail, then a
+    // ticket, in four times as many workgroups -- left it at 1 TB/s: 24 us for 25 MB).
     const bool vec = (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(pl) |
                                        reinterpret_cast<uintptr_t>(aux)) & 15) == 0 &&
                      (!out || (reinterpret_cast<uintptr_t>(out) & 15) == 0);
     if (vec) {
-        for (int n = n0 + 4 * threadIdx.x; n < n_end; n += 4 * kBlock) {
-            const float4 I4 = *reinterpret_cast<const float4 *>(aux + rec_index(r0 + n, 0));
-            const float4 L4 = *reinterpret_cast<const float4 *>(pl + n);
-            const float4 a4 = *reinterpret_cast<const float4 *>(p1 + n);
-            const float4 x4 = make_float4(L4.x * I4.x, L4.y * I4.y, L4.z * I4.z, L4.w * I4.w);
-            if (out) *reinterpret_cast<float4 *>(out + r0 + n) = x4;
-            take(a4.x, x4.x);
-            take(a4.y, x4.y);
-            take(a4.z, x4.z);
-            take(a4.w, x4.w);
+        float4 I4[kNccFwdQuads], L4[kNccFwdQuads], a4[kNccFwdQuads];
+        bool in[kNccFwdQuads];
+#pragma unroll
+        for (int k = 0; k < kNccFwdQuads; ++k) {
+            const int n_k = n0 + 4 * ((int)threadIdx.x + k * kBlock);
+            in[k] = n_k < n_end;
+            const int n = in[k] ? n_k : n0;  // (a quad beyond the image re-reads the first with weight 0)
+            I4[k] = *reinterpret_cast<const float4 *>(aux + rec_index(r0 + n, 0));
+            L4[k] = *reinterpret_cast<const float4 *>(pl + n);
+            a4[k] = *reinterpret_cast<const float4 *>(p1 + n);
+        }
+#pragma unroll
+        for (int k = 0; k < kNccFwdQuads; ++k) {
+            if (!in[k]) continue;
+            const float4 x4 = make_float4(L4[k].x * I4[k].x, L4[k].y * I4[k].y, L4[k].z * I4[k].z, L4[k].w * I4[k].w);
+            if (out) *reinterpret_cast<float4 *>(out + r0 + n0 + 4 * ((int)threadIdx.x + k * kBlock)) = x4;
+            take(a4[k].x, x4.x);
+            take(a4[k].y, x4.y);
+            take(a4[k].z, x4.z);
+            take(a4[k].w, x4.w);
         }
     } else {
         for (int n = n0 + threadIdx.x; n < n_end; n += kBlock) {
@@ -328,6 +348,18 @@ __global__ __launch_bounds__(kBlock) void siddon_ncc_fwd_kernel(
     stats[b * 5 + 2] = (float)mu2;
     stats[b * 5 + 3] = s2;
     stats[b * 5 + 4] = ncc;
+    if (ncc_sum) {
+        // the batch's objective: every pair adds its value, the last pair to do so hands the sum over
+        // (same ordering rule as last_workgroup_of_pose: the addition has been performed before the
+        // ticket is taken) and leaves the two words zero for the next call
+        atomicAdd(ws.total, (double)ncc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(ws.tick_all, 1) == B - 1) {
+            *ncc_sum = (float)atomicAdd(ws.total, 0.0);  // (a coherent read)
+            *ws.total = 0.0;
+            *ws.tick_all = 0;
+        }
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void siddon_ncc_bwd_pose_kernel(
@@ -355,7 +387,10 @@ __global__ __launch_bounds__(kBlock) void siddon_ncc_bwd_pose_kernel(
     // re-reads the last one with weight 0
     constexpr int kPer = kStepRaysPerBlock / kBlock;
     const int n_end = min(N, (int)(blockIdx.x + 1) * kStepRaysPerBlock);
-    float rec[kPer][SIDDON_AUX], Ls[kPer], x1s[kPer], ts[kPer][3], Ps[kPer][3];
+    // (a ray's voxel-space target and length are NOT read back -- 16 of the 52 bytes per ray this kernel
+    // streamed: they are regenerated from the pose's matrix and the detector point, which is read
+    // anyway, by the very function that wrote them, raygen_core.h raygen_ray: the same bits)
+    float rec[kPer][SIDDON_AUX], x1s[kPer], Ps[kPer][3];
     bool in[kPer];
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
@@ -364,22 +399,21 @@ __global__ __launch_bounds__(kBlock) void siddon_ncc_bwd_pose_kernel(
         const int n = in[k] ? n0 : n_end - 1;
         const long r = (long)b * N + n;
         rec_blocked_load(aux, r, rec[k]);
-        Ls[k] = img[r];
         x1s[k] = x1[b * x1_stride + n];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            ts[k][a] = target_v[r * 3 + a];
-            Ps[k][a] = P[n * 3 + a];
-        }
+        for (int a = 0; a < 3; ++a) Ps[k][a] = P[n * 3 + a];
     }
+    (void)img;
+    (void)target_v;
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
-        const float L = Ls[k];
+        const RayGenOut ray = raygen_ray(M, Ainv, Ps[k]);
+        const float L = ray.L;
         // d ncc / d x2[n] (= ncc_bwd_kernel on x2 = L I)
         const float z1 = (x1s[k] - mu1) / s1, z2 = (L * rec[k][0] - mu2) / s2;
         const float g = in[k] ? gn * (z1 - z2 * ncc) / s2 : 0.f;
         float gs[3], gt[3];
-        siddon_backward_ray<REDUCE_SUM>(rec[k], s, ts[k], eps, g * L, gs, gt);
+        siddon_backward_ray<REDUCE_SUM>(rec[k], s, ray.tv, eps, g * L, gs, gt);
         raygen_ray_adjoint(M, Ainv, Ps[k], gt, gs, with_img_path ? g * rec[k][0] : 0.f, L, acc);
     }
 #pragma unroll
@@ -654,7 +688,8 @@ int ddrr_ncc_backward(const float *x1, long x1_stride, const float *x2, const fl
 }
 
 long ddrr_siddon_ncc_workspace_bytes(int B) {
-    return B < 1 ? 0 : (long)B * (5 * sizeof(double) + 12 * sizeof(float) + 2 * sizeof(int));
+    return B < 1 ? 0 : (long)B * (5 * sizeof(double) + 12 * sizeof(float) + 2 * sizeof(int)) +
+                           (long)(sizeof(double) + 2 * sizeof(int));
 }
 
 static int check_axes(int a0, int a1, int a2) {
@@ -687,15 +722,15 @@ int ddrr_pose_raygen_forward(const float *rot, const float *xyz, int a0, int a1,
 
 int ddrr_siddon_ncc_forward(const float *aux, const float *img, const float *x1, long x1_stride, int B,
                             int N, float eps, void *ws, float *ncc, float *stats, float *out,
-                            void *stream) {
+                            float *ncc_sum, void *stream) {
     if (!aux || !img || !x1 || !ws || !ncc || !stats) return fail(-1, "null pointer");
     if (x1_stride != 0 && x1_stride != N) return fail(-1, "x1_stride must be N, or 0 for a shared image");
     if (B < 0 || N < 1) return fail(-1, "bad batch / image size");
     if (B == 0) return 0;
     if (B > 65535) return fail(-1, "at most 65535 pairs per call");
-    const dim3 grid((N + kStepRaysPerBlock - 1) / kStepRaysPerBlock, B), block(kBlock);
+    const dim3 grid((N + kNccFwdRaysPerBlock - 1) / kNccFwdRaysPerBlock, B), block(kBlock);
     hipLaunchKernelGGL(siddon_ncc_fwd_kernel, grid, block, 0, (hipStream_t)stream, aux, img, x1,
-                       x1_stride, B, N, eps, ws, ncc, stats, out);
+                       x1_stride, B, N, eps, ws, ncc, stats, out, ncc_sum);
     return finish("ddrr_siddon_ncc_forward");
 }
 

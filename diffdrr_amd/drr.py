@@ -353,7 +353,8 @@ class DRR(nn.Module):
     FUSED_NCC_MAX_POSES = 32
 
     def ncc(self, fixed: torch.Tensor, rot: torch.Tensor, xyz: torch.Tensor, *,
-            convention: str = "ZXY", degrees: bool = False, eps: float = 1e-5) -> torch.Tensor:
+            convention: str = "ZXY", degrees: bool = False, eps: float = 1e-5,
+            reduction: str = "none") -> torch.Tensor:
         """Per-pose normalised cross-correlation of ``fixed`` ((1 | B), 1, H, W) with the DRRs at the
         Euler poses (rot, xyz) (B, 3): ``NormalizedCrossCorrelation2d(eps=eps)(fixed.expand(B, ...),
         self(rot, xyz, parameterization="euler_angles", convention=convention))`` -- the objective of
@@ -365,8 +366,14 @@ class DRR(nn.Module):
         parameters: ``renderers._EulerSiddonNccFn``): 13 % of a one-pose registration iteration
         (0.246 -> 0.213 ms; up to ``FUSED_NCC_MAX_POSES`` poses per call).
         Anything else (no gradient wanted: the forward-only kernel is the faster one; other
-        renderers, subsampling, patches, a volume that requires a gradient) composes the same
-        result from ``forward`` and the NCC module."""
+        renderers, subsampling, a volume that requires a gradient) composes the same
+        result from ``forward`` and the NCC module.
+
+        ``reduction="sum"``: the batch's objective ``sum_b ncc_b`` as a 0-dim tensor -- what a batched
+        registration step maximises.  On the fused route the sum comes out of the epilogue's own
+        launch and its gradient goes back in as one value: ``loss.backward(gradient=one)`` with a
+        ready-made ``one`` is a step without a reduction or a fill launch.  The per-pose values of
+        the call (detached, (B,)) are left in ``self.ncc_per_pose``."""
         from .metrics import NormalizedCrossCorrelation2d
         from .pose import _AXIS, _check_convention
         from .renderers import _EulerSiddonNccFn
@@ -387,13 +394,19 @@ class DRR(nn.Module):
               and torch.is_tensor(fixed) and fixed.dim() == 4 and fixed.shape[0] in (1, B)
               and fixed.shape[1:] == (1, det.height, det.width) and fixed.dtype == torch.float32
               and fixed.device == rot.device and not fixed.requires_grad and B > 0)
+        if reduction not in ("none", "sum"):
+            raise ValueError(f"reduction must be 'none' or 'sum', not {reduction}")
         if not ok:
             img = self(rot, xyz, parameterization="euler_angles", convention=convention, degrees=degrees)
             if img.dim() == 3 and det.n_subsample is None:
                 # DRR(reshape=False) hands (B, C, N) back: the criterion wants the detector's grid,
                 # as the fused path reads it
                 img = img.view(B, -1, det.height, det.width)
-            return NormalizedCrossCorrelation2d(eps=eps)(fixed.expand(B, -1, -1, -1), img)
+            vals = NormalizedCrossCorrelation2d(eps=eps)(fixed.expand(B, -1, -1, -1), img)
+            if reduction == "sum":
+                self.ncc_per_pose = vals.detach()
+                return vals.sum()
+            return vals
         _check_convention(convention)
         if degrees:
             rot = rot / 180 * math.pi
@@ -404,8 +417,12 @@ class DRR(nn.Module):
             else self._affine_inverse[:3, :]
         cfg = r._cfg(False, det=(det.height, det.width))
         x1 = fixed.reshape(fixed.shape[0], det.height * det.width)
-        return _EulerSiddonNccFn.apply(rot, xyz, self.density, det._reorient[:3, :].contiguous(),
-                                       self._P_cache, Ainv, x1, axes, cfg, float(eps))
+        res = _EulerSiddonNccFn.apply(rot, xyz, self.density, det._reorient[:3, :].contiguous(),
+                                      self._P_cache, Ainv, x1, axes, cfg, float(eps), reduction == "sum")
+        if reduction == "sum":
+            total, self.ncc_per_pose = res
+            return total
+        return res
 
     @torch.no_grad()
     def marching_range(self, *args, parameterization: str = None, convention: str = None,

@@ -467,7 +467,9 @@ def ncc_backward(x1, x2, stats, g_out, want_x1, want_x2):
     shared = x1.shape[0] == 1 and B != 1
     x1, x2 = x1.contiguous(), x2.contiguous()
     # (the gradient of `.sum()` / `.mean()` arrives as an expanded scalar: read in place, stride 0)
-    g_stride = 0 if (g_out.dim() == 1 and B > 1 and g_out.stride(0) == 0) else 1
+    # (one value for the whole batch: the gradient of a summed objective -- a 0-dim tensor, or what
+    # autograd expands it to)
+    g_stride = 0 if (g_out.dim() == 0 or (g_out.dim() == 1 and B > 1 and g_out.stride(0) == 0)) else 1
     if g_stride:
         g_out = g_out.contiguous()
     g_x2 = torch.empty_like(x2) if want_x2 else None
@@ -586,10 +588,11 @@ def pose_raygen_forward(rot, xyz, axes, reorient34, Ainv, P, *, clear=None, clea
     return Mw, source, target, img
 
 
-def siddon_ncc_forward(aux, img, x1, eps, *, want_image=False):
+def siddon_ncc_forward(aux, img, x1, eps, *, want_image=False, want_sum=False):
     """Per-pose NCC of the fixed image(s) ``x1`` ((B | 1), N) with the DRRs whose blocked record
     is ``aux`` (``img`` (B,N): the rays' lengths): the image is formed from the record on the fly.
-    -> (ncc (B), stats (B,5), image (B,N) | None)"""
+    -> (ncc (B), stats (B,5), image (B,N) | None[, sum of the B values (0-dim), with ``want_sum``:
+    put together by the same launch])"""
     B, N = img.shape
     shared = x1.shape[0] == 1 and B != 1
     x1, img = x1.contiguous(), img.contiguous()
@@ -597,11 +600,13 @@ def siddon_ncc_forward(aux, img, x1, eps, *, want_image=False):
     ncc = torch.empty(B, dtype=torch.float32, device=dev)
     stats = torch.empty(B, 5, dtype=torch.float32, device=dev)
     out = torch.empty(B, N, dtype=torch.float32, device=dev) if want_image else None
+    total = (torch.empty((), dtype=torch.float32, device=dev) if B else
+             torch.zeros((), dtype=torch.float32, device=dev)) if want_sum else None
     if B:
         _launch("ddrr_siddon_ncc_forward", dev, aux.data_ptr(), img.data_ptr(), x1.data_ptr(),
                 0 if shared else N, B, N, float(eps), siddon_ncc_workspace(B, dev).data_ptr(),
-                ncc.data_ptr(), stats.data_ptr(), _ptr(out))
-    return ncc, stats, out
+                ncc.data_ptr(), stats.data_ptr(), _ptr(out), _ptr(total))
+    return (ncc, stats, out, total) if want_sum else (ncc, stats, out)
 
 
 def pose_adam_step(rot, xyz, g_rot, g_xyz, m_rot, v_rot, m_xyz, v_xyz, step_rot, step_xyz, *, lr_rot, lr_xyz,
@@ -629,7 +634,9 @@ def siddon_ncc_backward_pose(aux, img, x1, stats, g_out, source, target, Mw, Ain
     pose_euler_backward in one launch."""
     B, N = img.shape
     shared = x1.shape[0] == 1 and B != 1
-    g_stride = 0 if (g_out.dim() == 1 and B > 1 and g_out.stride(0) == 0) else 1
+    # (one value for the whole batch: the gradient of a summed objective -- a 0-dim tensor, or what
+    # autograd expands it to)
+    g_stride = 0 if (g_out.dim() == 0 or (g_out.dim() == 1 and B > 1 and g_out.stride(0) == 0)) else 1
     if g_stride:
         g_out = g_out.contiguous()
     x1, img, source, target = (t.contiguous() for t in (x1, img, source, target))

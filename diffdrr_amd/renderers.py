@@ -467,7 +467,7 @@ class _EulerSiddonNccFn(torch.autograd.Function):
     (reference registration.py:32-42, metrics.py:21-44); only the order of the sums differs."""
 
     @staticmethod
-    def forward(ctx, rot, xyz, volume, reorient34, P, Ainv, fixed, axes, cfg, ncc_eps):
+    def forward(ctx, rot, xyz, volume, reorient34, P, Ainv, fixed, axes, cfg, ncc_eps, reduce_sum=False):
         # (the record and the brick counter of the render are cleared by the launch in front of it)
         B, N = rot.shape[0], P.shape[0]
         aux = ops.brick_record_buffer(B, N, rot.device)
@@ -480,18 +480,25 @@ class _EulerSiddonNccFn(torch.autograd.Function):
             volume, source, target, img, cfg["det"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
             want_aux=True, storage=_brick_storage(volume, cfg), want_image=False, aux=aux,
             launch_ws=launch_ws, cleared=some)
-        ncc, stats, _ = ops.siddon_ncc_forward(aux, img, fixed, ncc_eps)
+        ncc, stats, _, total = ops.siddon_ncc_forward(aux, img, fixed, ncc_eps, want_sum=True) if reduce_sum \
+            else (*ops.siddon_ncc_forward(aux, img, fixed, ncc_eps), None)
         ctx.axes, ctx.cfg = axes, cfg
         ctx.save_for_backward(rot, xyz, reorient34, P, Ainv, fixed, Mw, source, target, img, aux, stats)
+        # (reduce_sum: the batch's objective sum_b ncc_b, put together by the epilogue's own launch; its
+        # gradient arrives as ONE value, which the backward epilogue reads with stride 0; the per-pose
+        # values ride along, not differentiable)
+        if reduce_sum:
+            ctx.mark_non_differentiable(ncc)
+            return total, ncc
         return ncc
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g_values=None):
         rot, xyz, reorient34, P, Ainv, fixed, Mw, source, target, img, aux, stats = ctx.saved_tensors
         g_rot, g_xyz = ops.siddon_ncc_backward_pose(
             aux, img, fixed, stats, g, source, target, Mw, Ainv, P, rot, xyz, ctx.axes, reorient34,
             eps=ctx.cfg["eps"], with_img_path=not ctx.cfg["stop_gradients"])
-        return g_rot, g_xyz, None, None, None, None, None, None, None, None
+        return g_rot, g_xyz, None, None, None, None, None, None, None, None, None
 
 
 def _cat_channels(blocks):

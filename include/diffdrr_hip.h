@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 30
+#define DDRR_ABI_VERSION 31
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -473,9 +473,16 @@ int ddrr_pose_euler_backward(const float *rot, const float *xyz, int a0, int a1,
  *   ddrr_siddon_ncc_forward       = the image from the record (out = img * plane I; `out` may be
  *                                   NULL) + ddrr_ncc_forward, many workgroups per pair (moments
  *                                   by double atomics; the pair's last workgroup finishes `stats`);
+ *                                   ABI 31: `ncc_sum` (one float, or NULL) receives sum_b ncc[b], put
+ *                                   together by the pairs' last workgroups -- the objective of a
+ *                                   batched registration step without a reduction launch behind it;
  *   ddrr_siddon_ncc_backward_pose = ddrr_ncc_backward + ddrr_siddon_backward_pose +
  *                                   ddrr_pose_euler_backward: g_rot, g_xyz (B, 3) of
  *                                   sum_b g_out[b] ncc[b], nothing per ray or per pixel is written.
+ *                                   `target_v` and `img` are what ddrr_pose_raygen_forward wrote for
+ *                                   (Mw, Ainv, P): the kernel regenerates a ray's target and length
+ *                                   from those -- the same bits, 16 of 52 bytes per ray not read --
+ *                                   and the two pointers are only checked for NULL;
  * aux: the BLOCKED float record of ddrr_siddon_forward_bricks (which may be called with
  * out = NULL when only the record is wanted).  x1: the fixed image(s), (B, N) with
  * x1_stride = N or one image with x1_stride = 0.  ws: ddrr_siddon_ncc_workspace_bytes(B) bytes,
@@ -489,7 +496,7 @@ int ddrr_pose_raygen_forward(const float *rot, const float *xyz, int a0, int a1,
                              long clear_floats, void *clear_launch_ws, void *stream);
 int ddrr_siddon_ncc_forward(const float *aux, const float *img, const float *x1, long x1_stride, int B,
                             int N, float eps, void *ws, float *ncc, float *stats, float *out,
-                            void *stream);
+                            float *ncc_sum, void *stream);
 int ddrr_siddon_ncc_backward_pose(const float *aux, const float *img, const float *x1, long x1_stride,
                                   const float *stats, const float *g_out, int g_stride,
                                   const float *source_v, const float *target_v, const float *Mw,

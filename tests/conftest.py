@@ -793,8 +793,21 @@ def check_fused_ncc_step(device):
         if device != "cpu":  # (the host emulation does not touch the workspace)
             torch.cuda.synchronize()
             assert float(ops.siddon_ncc_workspace(B, device).abs().max()) == 0.0
+        # reduction="sum": the batch's objective out of the epilogue's own launch (ABI 31 ncc_sum), its
+        # gradient back in as one ready-made value -- the values and gradients of `.sum().backward()`
+        ref_r, ref_x = rot0.clone().requires_grad_(), xyz0.clone().requires_grad_()
+        ref_v = drr.ncc(base, ref_r, ref_x, convention="ZXY")
+        (ref_v.sum() * 1.7).backward()
+        r, x = rot0.clone().requires_grad_(), xyz0.clone().requires_grad_()
+        tot = drr.ncc(base, r, x, convention="ZXY", reduction="sum")
+        assert tot.dim() == 0 and type(tot.grad_fn).__name__.startswith("_EulerSiddonNccFn")
+        assert abs(float(tot.detach()) - float(ref_v.detach().sum())) < 2e-6
+        tot.backward(gradient=torch.tensor(1.7, device=device))
+        assert rel_err(r.grad.cpu().numpy(), ref_r.grad.cpu().numpy()) < 2e-5
+        assert rel_err(x.grad.cpu().numpy(), ref_x.grad.cpu().numpy()) < 2e-5
         # nothing to differentiate: the composition (forward-only kernel), same values
         with torch.no_grad():
+            assert abs(float(drr.ncc(base, rot0, xyz0, reduction="sum")) - float(ref_v.detach().sum())) < 2e-6
             v = drr.ncc(base, rot0, xyz0)
         assert v.shape == (B,) and np.abs(v.cpu().numpy() - v_base).max() < 2e-6
         # the composed route with gradients: more poses than the fused step takes per call, and a

@@ -1455,7 +1455,7 @@ int ddrr_pose_adam_step(float *rot, float *xyz, const float *g_rot, const float 
     return 0;
 }
 
-long ddrr_siddon_ncc_workspace_bytes(int B) { return B < 1 ? 0 : (long)B * (5 * 8 + 12 * 4 + 2 * 4); }
+long ddrr_siddon_ncc_workspace_bytes(int B) { return B < 1 ? 0 : (long)B * (5 * 8 + 12 * 4 + 2 * 4) + 16; }
 
 int ddrr_pose_raygen_forward(const float *rot, const float *xyz, int a0, int a1, int a2,
                              const float *reorient34, const float *Ainv, const float *P, int B, int N,
@@ -1470,11 +1470,18 @@ int ddrr_pose_raygen_forward(const float *rot, const float *xyz, int a0, int a1,
 }
 
 int ddrr_siddon_ncc_forward(const float *aux, const float *img, const float *x1, long x1_stride, int B,
-                            int N, float eps, void *, float *ncc, float *stats, float *out, void *st) {
+                            int N, float eps, void *, float *ncc, float *stats, float *out, float *ncc_sum,
+                            void *st) {
     std::vector<float> x2((size_t)B * N);
     for (long r = 0; r < (long)B * N; ++r) x2[r] = img[r] * aux[rec_index(r, 0)];
     if (out) memcpy(out, x2.data(), sizeof(float) * x2.size());
-    return ddrr_ncc_forward(x1, x1_stride, x2.data(), B, N, eps, ncc, stats, st);
+    if (int rc = ddrr_ncc_forward(x1, x1_stride, x2.data(), B, N, eps, ncc, stats, st)) return rc;
+    if (ncc_sum) {
+        double total = 0.;
+        for (int b = 0; b < B; ++b) total += (double)ncc[b];
+        *ncc_sum = (float)total;
+    }
+    return 0;
 }
 
 int ddrr_siddon_ncc_backward_pose(const float *aux, const float *img, const float *x1, long x1_stride,

@@ -152,21 +152,21 @@ def test_argument_checks_return_errors_without_touching_a_device():
     assert c.ddrr_pose_euler_forward(P, P, 0, 0, 1, P, 1, P, None) != 0  # repeated axis
     # the fused registration step (ABI 29): the same checks as the entries it fuses
     L = ctypes.c_long
-    assert c.ddrr_siddon_ncc_workspace_bytes(3) == 3 * 96 and c.ddrr_siddon_ncc_workspace_bytes(0) == 0
+    assert c.ddrr_siddon_ncc_workspace_bytes(3) == 3 * 96 + 16 and c.ddrr_siddon_ncc_workspace_bytes(0) == 0
     assert c.ddrr_pose_raygen_forward(P, P, 2, 2, 1, P, P, P, 1, 4, P, P, P, P, None, L(0), None, None) != 0
     assert b"Euler" in c.ddrr_last_error()
     assert c.ddrr_pose_raygen_forward(P, P, 2, 0, 1, P, P, P, 1, 4, P, P, P, P, None, L(8), None, None) != 0
     assert b"clear_floats" in c.ddrr_last_error()
     assert c.ddrr_pose_raygen_forward(P, P, 2, 0, 1, P, P, P, 0, 4, P, P, P, P, P, L(8), None, None) != 0
     assert b"empty batch" in c.ddrr_last_error()
-    assert c.ddrr_siddon_ncc_forward(P, P, P, L(3), 1, 4, f(1e-5), P, P, P, None, None) != 0
+    assert c.ddrr_siddon_ncc_forward(P, P, P, L(3), 1, 4, f(1e-5), P, P, P, None, None, None) != 0
     assert b"x1_stride" in c.ddrr_last_error()
-    assert c.ddrr_siddon_ncc_forward(P, P, P, L(0), 1, 4, f(1e-5), None, P, P, None, None) != 0
+    assert c.ddrr_siddon_ncc_forward(P, P, P, L(0), 1, 4, f(1e-5), None, P, P, None, None, None) != 0
     assert b"null" in c.ddrr_last_error()
     assert c.ddrr_siddon_ncc_backward_pose(P, P, P, L(0), P, P, 2, P, P, P, P, P, P, P, 2, 0, 1, P, 1, 4,
                                            f(1e-8), 1, P, P, P, None) != 0
     assert b"g_stride" in c.ddrr_last_error()
-    assert c.ddrr_siddon_ncc_forward(P, P, P, L(0), 0, 4, f(1e-5), P, P, P, None, None) == 0  # empty batch
+    assert c.ddrr_siddon_ncc_forward(P, P, P, L(0), 0, 4, f(1e-5), P, P, P, None, None, None) == 0  # empty batch
     # the fused pose Adam step (ABI 30)
     assert c.ddrr_pose_adam_step(P, P, P, P, P, P, P, P, P, None, 1, f(0.1), f(5.0), f(0.9), f(0.999), f(1e-8), 1,
                                  None) != 0

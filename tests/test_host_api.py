@@ -325,9 +325,17 @@ def test_fused_entry_is_skipped_when_a_general_feature_is_asked_for(emulated_ops
     assert not drr2._fused_ok(False, {"n_points": 50, "align_corners": True})
     drr2.renderer.mode = "nearest"
     assert not drr2._fused_ok(False, {})
+    # patch_size / p_subsample stay on the fused entries since round 6 (DRR._render_sparse) -- except
+    # for callers that read the record of the whole grid (DRR.ncc) with a subsample
     drr3 = DRR(synthetic_subject(24, kind="phantom", seed=0), sdd=300.0, height=12, delx=2.0,
                patch_size=6)
-    assert not drr3._fused_ok(False, {})
+    assert drr3._fused_ok(False, {}) and drr3._fused_ok(False, {}, None, dense_only=True)
+    drr4 = DRR(synthetic_subject(24, kind="phantom", seed=0), sdd=300.0, height=12, delx=2.0,
+               p_subsample=0.5)
+    assert drr4._fused_ok(False, {}) and not drr4._fused_ok(False, {}, None, dense_only=True)
+    drr5 = DRR(synthetic_subject(24, kind="phantom", seed=0), sdd=300.0, height=12, delx=2.0,
+               patch_size=13)  # (more than the detector holds: the reference's chunk(0) raises)
+    assert not drr5._fused_ok(False, {})
 
 
 @pytest.mark.parametrize("stop", [False, True])
