@@ -160,9 +160,12 @@ __global__ __launch_bounds__(kBlock) void pose_euler_bwd_kernel(
 // The workspace (moments, dL/dMw accumulators, tickets) is caller-owned, zero when it is first
 // handed over, and left zero by every call: no fills.  Reference: diffdrr/pose.py:140-190,
 // detector.py:144-154, drr.py:201-205, metrics.py:21-44 and their autograd.
-constexpr int kStepRaysPerBlock = 1024;  // rays of one pose per workgroup of the backward epilogue
-constexpr int kNccFwdQuads = 4;          // 16-byte runs of four rays per thread of the forward epilogue ...
-constexpr int kNccFwdRaysPerBlock = 4 * kNccFwdQuads * kBlock;  // ... 4096 rays of one pose per workgroup
+// Rays of one pose per workgroup of the two epilogues, by launch size (template parameters): a launch
+// of many poses is bound by its bytes and wants them in flight -- forward 4096 rays per workgroup
+// (four 16-byte triples per thread: 27 -> 16 us at 32 poses), backward 2048 (eight rays per thread:
+// 33.5 -> 28 us) --, a launch of one pose is bound by its latency and wants workgroups (1024 rays
+// each, as in round 5: with the large ones a registration iteration went 0.175 -> 0.180 ms).
+constexpr int kStepWorkgroupsWanted = 512;  // two per CU before the large workgroups pay
 
 struct NccWs {
     double *mom;   // [B][5]  sum x1, x2, x1^2, x2^2, x1 x2
@@ -252,6 +255,7 @@ __global__ __launch_bounds__(kBlock) void pose_raygen_fwd_kernel(
     img[r] = o.L;
 }
 
+template <int kNccFwdQuads>
 __global__ __launch_bounds__(kBlock) void siddon_ncc_fwd_kernel(
     const float *__restrict__ aux, const float *__restrict__ img, const float *__restrict__ x1,
     long x1_stride, int B, int N, float eps, void *ws_raw, float *__restrict__ ncc_out,
@@ -271,6 +275,7 @@ __global__ __launch_bounds__(kBlock) void siddon_ncc_fwd_kernel(
     };
     const float *p1 = x1 + b * x1_stride, *pl = img + (long)b * N;
     const long r0 = (long)b * N;
+    constexpr int kNccFwdRaysPerBlock = 4 * kNccFwdQuads * kBlock;
     const int n0 = blockIdx.x * kNccFwdRaysPerBlock, n_end = min(N, n0 + kNccFwdRaysPerBlock);
     // four consecutive rays per load: plane I of rays 4 k .. 4 k + 3 is one aligned 16-byte run of
     // the blocked record (record_layout.h), like the rays' lengths and the fixed image's pixels.
@@ -362,6 +367,7 @@ __global__ __launch_bounds__(kBlock) void siddon_ncc_fwd_kernel(
     }
 }
 
+template <int kStepRaysPerBlock>
 __global__ __launch_bounds__(kBlock) void siddon_ncc_bwd_pose_kernel(
     const float *__restrict__ aux, const float *__restrict__ img, const float *__restrict__ x1,
     long x1_stride, const float *__restrict__ stats, const float *__restrict__ g_out, int g_stride,
@@ -728,9 +734,13 @@ int ddrr_siddon_ncc_forward(const float *aux, const float *img, const float *x1,
     if (B < 0 || N < 1) return fail(-1, "bad batch / image size");
     if (B == 0) return 0;
     if (B > 65535) return fail(-1, "at most 65535 pairs per call");
-    const dim3 grid((N + kNccFwdRaysPerBlock - 1) / kNccFwdRaysPerBlock, B), block(kBlock);
-    hipLaunchKernelGGL(siddon_ncc_fwd_kernel, grid, block, 0, (hipStream_t)stream, aux, img, x1,
-                       x1_stride, B, N, eps, ws, ncc, stats, out, ncc_sum);
+    const dim3 block(kBlock);
+    if ((long)B * ((N + 4095) / 4096) >= kStepWorkgroupsWanted)
+        hipLaunchKernelGGL(siddon_ncc_fwd_kernel<4>, dim3((N + 4095) / 4096, B), block, 0, (hipStream_t)stream,
+                           aux, img, x1, x1_stride, B, N, eps, ws, ncc, stats, out, ncc_sum);
+    else
+        hipLaunchKernelGGL(siddon_ncc_fwd_kernel<1>, dim3((N + 1023) / 1024, B), block, 0, (hipStream_t)stream,
+                           aux, img, x1, x1_stride, B, N, eps, ws, ncc, stats, out, ncc_sum);
     return finish("ddrr_siddon_ncc_forward");
 }
 
@@ -750,10 +760,17 @@ int ddrr_siddon_ncc_backward_pose(const float *aux, const float *img, const floa
     if (B < 0 || N < 1) return fail(-1, "bad batch / image size");
     if (B == 0) return 0;
     if (B > 65535) return fail(-1, "at most 65535 poses per call");
-    const dim3 grid((N + kStepRaysPerBlock - 1) / kStepRaysPerBlock, B), block(kBlock);
-    hipLaunchKernelGGL(siddon_ncc_bwd_pose_kernel, grid, block, 0, (hipStream_t)stream, aux, img, x1,
-                       x1_stride, stats, g_out, g_stride, source_v, target_v, Mw, Ainv, P, rot, xyz,
-                       a0, a1, a2, reorient34, B, N, eps, with_img_path, ws, g_rot, g_xyz);
+    const dim3 block(kBlock);
+    if ((long)B * ((N + 2047) / 2048) >= kStepWorkgroupsWanted)
+        hipLaunchKernelGGL(siddon_ncc_bwd_pose_kernel<2048>, dim3((N + 2047) / 2048, B), block, 0,
+                           (hipStream_t)stream, aux, img, x1, x1_stride, stats, g_out, g_stride, source_v,
+                           target_v, Mw, Ainv, P, rot, xyz, a0, a1, a2, reorient34, B, N, eps, with_img_path,
+                           ws, g_rot, g_xyz);
+    else
+        hipLaunchKernelGGL(siddon_ncc_bwd_pose_kernel<1024>, dim3((N + 1023) / 1024, B), block, 0,
+                           (hipStream_t)stream, aux, img, x1, x1_stride, stats, g_out, g_stride, source_v,
+                           target_v, Mw, Ainv, P, rot, xyz, a0, a1, a2, reorient34, B, N, eps, with_img_path,
+                           ws, g_rot, g_xyz);
     return finish("ddrr_siddon_ncc_backward_pose");
 }
 

@@ -33,3 +33,38 @@ for r in 1 2; do for v in A_preclaim B_before_loop; do cp tools/_build/ab/lib$v.
 
 # ---------------------------------------------------------------- 2026-10-01T04:05:36Z  r06: PRE instantiation: brick tests + bench legs
 python -m pytest tests -m gpu -x -q -k "brick or look_ahead or untracked or headline or storage or registration or graph" 2>&1 | tail -3; python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>&1 >/dev/null | grep -v "full record" | grep "config headline\|few poses\|config ct\|config 4:"
+
+# ---------------------------------------------------------------- 2026-10-01T04:12:58Z  r06: epilogues v2: tests + bench + kernel trace
+mkdir -p gpurun_out/r06f; python -m pytest tests -m gpu -x -q -k "ncc or registration or graph or trajectory or adam" 2>&1 | tail -3; python bench.py --gpus 1 --steps 100 --warmup 5 --no-cpu-baseline --no-configs 2>&1 >/dev/null | grep -v "full record" | grep "config headline:"; python - <<PY
+import json
+d=json.load(open("bench_full.json"))
+for k in d["roofline"]["kernels"]: print(k["kernel"], round(k["kernel_ms"],4), k["launches_per_step"])
+print("step-kernel", d["ms_per_step"]-d["roofline"]["kernel_ms"])
+PY
+python bench.py --gpus 1 --config 2 --steps 200 --warmup 5 --no-cpu-baseline 2>&1 >/dev/null | grep -v "full record" | grep "config 2:"; python - <<PY
+import json
+d=json.load(open("bench_full.json"))
+for k in d["roofline"]["kernels"]: print(k["kernel"], round(k["kernel_ms"],4), k["launches_per_step"])
+print("step-kernel", d["ms_per_step"]-d["roofline"]["kernel_ms"])
+PY
+python bench.py --gpus 1 --config 4 --no-cpu-baseline 2>&1 >/dev/null | grep -v "full record" | grep "config 4:"
+
+# ---------------------------------------------------------------- 2026-10-01T04:14:54Z  r06: bwd epilogue 2048 rays per workgroup
+python bench.py --gpus 1 --steps 100 --warmup 5 --no-cpu-baseline --no-configs 2>&1 >/dev/null | grep -v "full record" | grep "config headline:" | cut -c1-120; python - <<PY
+import json
+d=json.load(open("bench_full.json"))
+for k in d["roofline"]["kernels"]: print(k["kernel"], round(k["kernel_ms"],4), k["launches_per_step"])
+print("step-kernel", d["ms_per_step"]-d["roofline"]["kernel_ms"])
+PY
+python -m pytest tests -m gpu -x -q -k "fused_ncc" 2>&1 | tail -2
+
+# ---------------------------------------------------------------- 2026-10-01T04:15:18Z  r06: config 4 / 2 with the 2048-ray backward epilogue
+for c in 4 4 2; do python bench.py --gpus 1 --config $c --no-cpu-baseline 2>&1 >/dev/null | grep -v "full record" | grep "config $c:" | cut -c1-150; done
+
+# ---------------------------------------------------------------- 2026-10-01T04:16:38Z  r06: epilogues by launch size: tests + configs
+python -m pytest tests -m gpu -x -q -k "ncc or registration or graph or trajectory or adam" 2>&1 | tail -2; for c in 4 4 2; do python bench.py --gpus 1 --config $c --no-cpu-baseline 2>&1 >/dev/null | grep -v "full record" | grep "config $c:" | cut -c1-150; done; python bench.py --gpus 1 --steps 100 --warmup 5 --no-cpu-baseline --no-configs 2>&1 >/dev/null | grep -v "full record" | grep "config headline:" | cut -c1-120; python - <<PY
+import json
+d=json.load(open("bench_full.json"))
+for k in d["roofline"]["kernels"]: print(k["kernel"], round(k["kernel_ms"],4), k["launches_per_step"])
+print("step-kernel", d["ms_per_step"]-d["roofline"]["kernel_ms"])
+PY
