@@ -343,7 +343,7 @@ class DRR(nn.Module):
             # (the density tensor itself: its packed bricks are cached per tensor object and version)
             ops.siddon_forward_bricks(self.density, source, target, img, cfg["det"],
                                       voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
-                                      storage=_brick_storage(self.density, cfg), out=out, launch_ws=launch_ws,
+                                      storage=_brick_storage(self.density, cfg, B), out=out, launch_ws=launch_ws,
                                       cleared=True)
             idx = det.subsample_index()  # (p_subsample: the grid is rendered, the subsample gathered)
             if idx is not None:

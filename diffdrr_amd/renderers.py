@@ -109,13 +109,35 @@ def _record_vmax(volume, want_aux, cfg):
 _cu_count = {}
 
 
-def _brick_storage(volume, cfg):
+# Which storage renders a volume with FEW double bricks (32 x 32 x 64) per CU faster, by poses per
+# launch: measured, not one constant (tools/storage_table.py, profiles/r06/storage_table.txt; the two
+# storages are within ~10 % of each other everywhere in this regime, forward and with the record).
+#   (double bricks per CU below, poses per launch from, to): "q16p" inside, "f32" outside
+#   < 1.5  (256^3: 1.00)             q16p at <= 5 poses: half as many work items, and a few poses pay per
+#                                    item; from 8 poses on the 512 fp32 bricks balance better (-15 ... -24 %)
+#   < 2.5  (384 x 384 x 256: 2.25)   q16p throughout (-3 ... -10 %)
+#   < 4    (512 x 512 x 133: 3.00,   q16p at 8 ... 12 poses (-5 ... -10 % with the record, a tie without);
+#           the example CT's shape)  f32 below (a one-pose launch: 0.066 against 0.077 ms) and beyond
+#                                    (32 poses: 0.298 against 0.335 ms)
+#   >= 4                             q16p (512^3: 8 per CU)
+_FEW_BRICKS_POLICY = ((1.5, 1, 5), (2.5, 1, 1 << 30), (4.0, 8, 12))
+
+
+def _few_bricks_take_q16(per_cu: float, poses) -> bool:
+    """The table above: a volume with ``per_cu`` < 4 double bricks per CU, ``poses`` per launch."""
+    if poses is None:
+        return False
+    lo, hi = next((a, b) for r, a, b in _FEW_BRICKS_POLICY if per_cu < r)
+    return lo <= int(poses) <= hi
+
+
+def _brick_storage(volume, cfg, poses=None):
     """How the brick kernel stages the volume (Siddon.brick_storage).  fp32 bricks whatever the
     setting for a volume that is being optimised (it changes every step: its 16-bit ranges would
     be recomputed per launch, one more pass over the volume, and its gradient is taken w.r.t. the
-    exact values) and for a volume with fewer than 4 double bricks per CU: too few to balance
-    over the persistent workgroups (256^3 = 256 bricks of 32 x 32 x 64, one per CU: 0.83 ms
-    against 0.74 ms with 512 fp32 bricks handed out dynamically)."""
+    exact values); for a volume with fewer than 4 double bricks per CU -- too few to balance over
+    the persistent workgroups whatever the batch -- the measured table above decides by the poses
+    of the launch (``poses`` = None: unknown, fp32 bricks as until round 5)."""
     storage = cfg.get("storage", "f32")
     if storage not in ("q16", "q16p") or volume.requires_grad:
         return "f32"
@@ -133,7 +155,8 @@ def _brick_storage(volume, cfg):
         if dev not in _cu_count:
             _cu_count[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
         dx, dy, dz = volume.shape
-        if (-(-dx // 32)) * (-(-dy // 32)) * (-(-dz // 64)) < 4 * _cu_count[dev]:
+        per_cu = (-(-dx // 32)) * (-(-dy // 32)) * (-(-dz // 64)) / _cu_count[dev]
+        if per_cu < 4 and not _few_bricks_take_q16(per_cu, poses):
             return "f32"
     if ops.workspace_churn(volume, storage) >= 3:
         # edited in place between renders again and again (a reconstruction loop on a plain
@@ -161,7 +184,7 @@ class _SiddonFn(torch.autograd.Function):
             out, aux = ops.siddon_forward_bricks(
                 volume, source, target, img, cfg["det"], voxel_shift=cfg["voxel_shift"],
                 eps=cfg["eps"], want_aux=want_aux, record_vmax=_record_vmax(volume, want_aux, cfg),
-                storage=_brick_storage(volume, cfg))
+                storage=_brick_storage(volume, cfg, source.shape[0]))
         else:
             out, aux, _ = ops.siddon_forward(
                 volume, source, target, img, voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
@@ -431,7 +454,7 @@ class _SiddonPoseFn(torch.autograd.Function):
             out, aux = ops.siddon_forward_bricks(
                 volume, source, target, img, cfg["det"], voxel_shift=cfg["voxel_shift"],
                 eps=cfg["eps"], want_aux=want_aux, record_vmax=_record_vmax(volume, want_aux, cfg),
-                storage=_brick_storage(volume, cfg))
+                storage=_brick_storage(volume, cfg, source.shape[0]))
         else:
             out, aux, _ = ops.siddon_forward(
                 volume, source, target, img, voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
@@ -478,7 +501,7 @@ class _EulerSiddonNccFn(torch.autograd.Function):
                                                           clear_launch_ws=launch_ws if some else None)
         ops.siddon_forward_bricks(
             volume, source, target, img, cfg["det"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
-            want_aux=True, storage=_brick_storage(volume, cfg), want_image=False, aux=aux,
+            want_aux=True, storage=_brick_storage(volume, cfg, B), want_image=False, aux=aux,
             launch_ws=launch_ws, cleared=some)
         ncc, stats, _, total = ops.siddon_ncc_forward(aux, img, fixed, ncc_eps, want_sum=True) if reduce_sum \
             else (*ops.siddon_ncc_forward(aux, img, fixed, ncc_eps), None)

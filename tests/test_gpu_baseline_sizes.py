@@ -189,9 +189,13 @@ def test_ct_like_volume_vs_oracle(gpu):
             assert err < 2 * err_ref + GRAD_TOL, (storage, key, err, err_ref)
     n_f32, n = ops.brick_fallbacks(V, "q16p")
     assert n == 768 and 100 < n_f32 < 400, (n_f32, n)
-    # ... and through the module: this shape (3 double bricks per CU) renders from fp32 bricks
+    # ... and through the module: this shape (3 double bricks per CU) renders from fp32 bricks except at
+    # 8 ... 12 poses per launch (the measured table of renderers._brick_storage)
     from diffdrr_amd.renderers import _brick_storage
-    assert _brick_storage(V, {"storage": drr.renderer.brick_storage}) == "f32"
+    cfg = {"storage": drr.renderer.brick_storage}
+    assert _brick_storage(V, cfg) == "f32" and _brick_storage(V, cfg, 1) == "f32" and _brick_storage(V, cfg, 32) == "f32"
+    if torch.cuda.get_device_properties(gpu).multi_processor_count == 256:
+        assert _brick_storage(V, cfg, 8) == "q16p"
     with torch.no_grad():
         img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY").reshape(B, N).cpu().numpy()
     assert all(np.abs(img[b] - r64[b]).max() <= FWD_TOL * np.abs(r32[b]).max() for b in range(B))

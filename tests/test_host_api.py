@@ -981,6 +981,12 @@ def test_brick_workspace_follows_the_volume(emulated_ops):
     assert _brick_storage(torch.rand(64, 64, 126), cfg) == "q16p"
     assert _brick_storage(torch.rand(64, 64, 133), cfg) == "q16p"
     assert _brick_storage(torch.rand(64, 64, 128, requires_grad=True), cfg) == "f32"
+    # volumes with few double bricks per CU: the measured table (profiles/r06/storage_table.txt)
+    from diffdrr_amd.renderers import _few_bricks_take_q16 as take
+    assert [take(1.0, b) for b in (1, 5, 6, 8, 32)] == [True, True, False, False, False]        # 256^3
+    assert all(take(2.25, b) for b in (1, 8, 32, 512))                                          # 384 x 384 x 256
+    assert [take(3.0, b) for b in (1, 7, 8, 12, 13, 32)] == [False, False, True, True, False, False]  # the example CT's shape
+    assert not take(3.0, None) and not take(1.0, None)
 
 
 def test_trilinear_channels_on_bricks_on_the_host(emulated_ops):

@@ -68,3 +68,12 @@ d=json.load(open("bench_full.json"))
 for k in d["roofline"]["kernels"]: print(k["kernel"], round(k["kernel_ms"],4), k["launches_per_step"])
 print("step-kernel", d["ms_per_step"]-d["roofline"]["kernel_ms"])
 PY
+
+# ---------------------------------------------------------------- 2026-10-01T04:24:36Z  r06: storage table for thin volumes
+python tools/storage_table.py 2>&1 | grep -v amdgpu.ids
+
+# ---------------------------------------------------------------- 2026-10-01T04:25:23Z  r06: storage table, the band around 8 poses
+python tools/storage_table.py 5 6 7 8 9 10 12 14 2>&1 | grep -v amdgpu.ids
+
+# ---------------------------------------------------------------- 2026-10-01T04:26:43Z  r06: fp32 bricks general vs configurable kernel by pose count
+python tools/f32_kernel_table.py 2>&1 | grep -v amdgpu.ids
