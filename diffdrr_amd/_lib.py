@@ -90,6 +90,8 @@ _SIGNATURES = {
     "ddrr_pose_adam_step": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _P],
     "ddrr_ncc_forward": [_P, _L, _P, _I, _I, _F, _P, _P, _P],
     "ddrr_ncc_backward": [_P, _L, _P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "ddrr_ncc_patch_forward": [_P, _L, _P, _I, _I, _I, _I, _F, _P, _P, _P],
+    "ddrr_ncc_patch_backward": [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "ddrr_sobel_forward": [_P, _I, _I, _I, _P, _P],
     "ddrr_sobel_backward": [_P, _I, _I, _I, _P, _P],
     "ddrr_raygen_forward": [_P, _P, _P, _I, _I, _P, _P, _P, _P],

@@ -5,6 +5,7 @@
 #include "raygen_core.h"
 #include "record_pack.h"
 #include "record_layout.h"
+#include "ncc_patch_core.h"
 #include "sobel_core.h"
 
 using namespace ddrr;
@@ -549,6 +550,86 @@ __global__ __launch_bounds__(kBlock) void ncc_bwd_kernel(
     if (g_x1) g_x1[(long)b * N + n] = g * (z2 - z1 * ncc) / s1;
 }
 
+
+// ------------------------------------------------- patch-wise NCC (multiscale NCC)
+// NormalizedCrossCorrelation2d(patch_size = p), reference metrics.py:16-44 (ncc_patch_core.h has the
+// formulas).  Forward: a workgroup takes 16 x 16 windows of one pair, stages the (16 + p - 1)^2
+// pixels they cover of both images in LDS, every thread z-scores its own window in two passes and
+// -- for the backward -- writes the window's four coefficients; the pair's score is the mean of
+// the windows' values (block sums, one atomic per workgroup; the entry zeroes the B floats).
+constexpr int kPatchTile = 16;
+
+__global__ __launch_bounds__(kPatchTile *kPatchTile) void ncc_patch_fwd_kernel(
+    const float *__restrict__ x1, long x1_stride, const float *__restrict__ x2, int H, int W, int p,
+    float eps, float *__restrict__ ncc_out, float4 *__restrict__ coef) {
+    extern __shared__ float patch_lds[];
+    const int T = kPatchTile + p - 1;
+    float *ta = patch_lds, *tb = patch_lds + T * T;
+    __shared__ float red[kPatchTile * kPatchTile / 64];
+    const int b = blockIdx.z, hw = H - p + 1, ww = W - p + 1;
+    const int y0 = blockIdx.y * kPatchTile, x0 = blockIdx.x * kPatchTile;
+    const float *a = x1 + b * x1_stride, *m = x2 + (long)b * H * W;
+    for (int i = threadIdx.x; i < T * T; i += kPatchTile * kPatchTile) {
+        const int y = y0 + i / T, x = x0 + i % T;
+        const bool in = y < H && x < W;
+        ta[i] = in ? a[(long)y * W + x] : 0.f;
+        tb[i] = in ? m[(long)y * W + x] : 0.f;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / kPatchTile, lx = threadIdx.x % kPatchTile;
+    const int wy = y0 + ly, wx = x0 + lx;
+    float v = 0.f;
+    if (wy < hw && wx < ww) {
+        float c[4];
+        const float *pa = ta + ly * T + lx, *pb = tb + ly * T + lx;
+        v = ncc_patch_window([&](int y, int x) { return pa[y * T + x]; },
+                             [&](int y, int x) { return pb[y * T + x]; }, p, eps, c);
+        if (coef) coef[((long)b * hw + wy) * ww + wx] = make_float4(c[0], c[1], c[2], c[3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < kPatchTile * kPatchTile / 64; ++w) t += red[w];
+        unsafeAtomicAdd(ncc_out + b, t / ((float)hw * (float)ww));
+    }
+}
+
+// Backward: a workgroup takes 16 x 16 pixels of one pair and stages the coefficients of the
+// (16 + p - 1)^2 windows that hold any of them (zeros outside the window grid); a thread adds up
+// its pixel's p^2 windows.
+__global__ __launch_bounds__(kPatchTile *kPatchTile) void ncc_patch_bwd_kernel(
+    const float *__restrict__ x1, long x1_stride, const float *__restrict__ x2,
+    const float4 *__restrict__ coef, const float *__restrict__ g_out, int g_stride, int H, int W, int p,
+    float *__restrict__ g_x2) {
+    extern __shared__ float4 coef_lds[];
+    const int T = kPatchTile + p - 1;
+    const int b = blockIdx.z, hw = H - p + 1, ww = W - p + 1;
+    const int y0 = blockIdx.y * kPatchTile, x0 = blockIdx.x * kPatchTile;
+    for (int i = threadIdx.x; i < T * T; i += kPatchTile * kPatchTile) {
+        const int wy = y0 - (p - 1) + i / T, wx = x0 - (p - 1) + i % T;
+        const bool in = wy >= 0 && wx >= 0 && wy < hw && wx < ww;
+        coef_lds[i] = in ? coef[((long)b * hw + wy) * ww + wx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / kPatchTile, lx = threadIdx.x % kPatchTile;
+    const int y = y0 + ly, x = x0 + lx;
+    if (y >= H || x >= W) return;
+    // (tile coordinates: window (wy, wx) sits at (wy - y0 + p - 1, wx - x0 + p - 1))
+    const float4 *c0 = coef_lds + (p - 1 - y0) * T + (p - 1 - x0);
+    const float a = x1[b * x1_stride + (long)y * W + x], m = x2[((long)b * H + y) * W + x];
+    const float s = ncc_patch_pixel_grad(
+        [&](int wy, int wx, int k) {
+            const float4 c = c0[wy * T + wx];
+            return k == 0 ? c.x : (k == 1 ? c.y : (k == 2 ? c.z : c.w));
+        },
+        y, x, p, a, m);
+    const float g = g_out[b * g_stride] / ((float)hw * (float)ww * (float)(p * p));
+    g_x2[((long)b * H + y) * W + x] = g * s;
+}
+
 // ------------------------------------------------- Sobel pair (gradient NCC)
 // out (B, 2, H, W) = {Gx, Gy} * img (B, H, W), zero padding (sobel_core.h); one pixel per thread
 __global__ __launch_bounds__(kBlock) void sobel_fwd_kernel(const float *__restrict__ img, int H,
@@ -772,6 +853,43 @@ int ddrr_siddon_ncc_backward_pose(const float *aux, const float *img, const floa
                            target_v, Mw, Ainv, P, rot, xyz, a0, a1, a2, reorient34, B, N, eps, with_img_path,
                            ws, g_rot, g_xyz);
     return finish("ddrr_siddon_ncc_backward_pose");
+}
+
+int ddrr_ncc_patch_forward(const float *x1, long x1_stride, const float *x2, int B, int H, int W, int p,
+                           float eps, float *out, float *coef, void *stream) {
+    if (!x1 || !x2 || !out) return fail(-1, "null pointer");
+    if (B < 0 || H < 1 || W < 1) return fail(-1, "bad batch / image size");
+    if (p < 1 || p > H || p > W || p > 64) return fail(-1, "patch_size must be 1 ... min(H, W, 64)");
+    if (x1_stride != 0 && x1_stride != (long)H * W) return fail(-1, "x1_stride must be H W, or 0 for a shared image");
+    if (B == 0) return 0;
+    if (B > 65535) return fail(-1, "at most 65535 pairs per call");
+    const int hw = H - p + 1, ww = W - p + 1, T = kPatchTile + p - 1;
+    if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)B, (hipStream_t)stream) != hipSuccess)
+        return fail(-1, "hipMemsetAsync");
+    const dim3 grid((ww + kPatchTile - 1) / kPatchTile, (hw + kPatchTile - 1) / kPatchTile, B);
+    hipLaunchKernelGGL(ncc_patch_fwd_kernel, grid, dim3(kPatchTile * kPatchTile), 2 * T * T * sizeof(float),
+                       (hipStream_t)stream, x1, x1_stride, x2, H, W, p, eps, out,
+                       reinterpret_cast<float4 *>(coef));
+    return finish("ddrr_ncc_patch_forward");
+}
+
+int ddrr_ncc_patch_backward(const float *x1, long x1_stride, const float *x2, const float *coef,
+                            const float *g_out, int g_stride, int B, int H, int W, int p, float *g_x2,
+                            void *stream) {
+    if (!x1 || !x2 || !coef || !g_out || !g_x2) return fail(-1, "null pointer");
+    if (B < 0 || H < 1 || W < 1) return fail(-1, "bad batch / image size");
+    if (p < 1 || p > H || p > W || p > 64) return fail(-1, "patch_size must be 1 ... min(H, W, 64)");
+    if (x1_stride != 0 && x1_stride != (long)H * W) return fail(-1, "x1_stride must be H W, or 0 for a shared image");
+    if (g_stride != 0 && g_stride != 1) return fail(-1, "g_stride must be 1, or 0 for one value shared by the batch");
+    if (B == 0) return 0;
+    if (B > 65535) return fail(-1, "at most 65535 pairs per call");
+    if ((reinterpret_cast<uintptr_t>(coef) & 15) != 0) return fail(-1, "coef must be 16-byte aligned");
+    const int T = kPatchTile + p - 1;
+    const dim3 grid((W + kPatchTile - 1) / kPatchTile, (H + kPatchTile - 1) / kPatchTile, B);
+    hipLaunchKernelGGL(ncc_patch_bwd_kernel, grid, dim3(kPatchTile * kPatchTile), T * T * sizeof(float4),
+                       (hipStream_t)stream, x1, x1_stride, x2, reinterpret_cast<const float4 *>(coef), g_out,
+                       g_stride, H, W, p, g_x2);
+    return finish("ddrr_ncc_patch_backward");
 }
 
 int ddrr_pose_adam_step(float *rot, float *xyz, const float *g_rot, const float *g_xyz, float *m_rot,

@@ -36,6 +36,35 @@ class _NCCFn(torch.autograd.Function):
         return g1, g2, None
 
 
+class _PatchNCCFn(torch.autograd.Function):
+    """Patch-wise NCC (``patch_size = p``) of single-channel image pairs without the reference's
+    (B, windows, p, p) tensors: ddrr_ncc_patch_forward / ddrr_ncc_patch_backward.
+    x1 (B or 1, H, W), x2 (B, H, W) -> (B,).  The gradient w.r.t. the moving image x2 is one launch;
+    one w.r.t. x1 (the fixed image is data: rare) is the same two launches with the roles swapped --
+    the similarity is symmetric."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, p, eps):
+        out, coef = ops.ncc_patch_forward(x1, x2, p, eps, want_coef=ctx.needs_input_grad[1])
+        ctx.p, ctx.eps = p, eps
+        ctx.save_for_backward(x1, x2, coef)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, x2, coef = ctx.saved_tensors
+        g1 = g2 = None
+        if ctx.needs_input_grad[1]:
+            g2 = ops.ncc_patch_backward(x1, x2, coef, g, ctx.p)
+        if ctx.needs_input_grad[0]:
+            a = x1.expand_as(x2).contiguous()
+            _, coef1 = ops.ncc_patch_forward(x2, a, ctx.p, ctx.eps)
+            g1 = ops.ncc_patch_backward(x2, a, coef1, g, ctx.p)
+            if x1.shape[0] == 1 and x2.shape[0] != 1:
+                g1 = g1.sum(0, keepdim=True)
+        return g1, g2, None, None
+
+
 def to_patches(x, patch_size):
     """Every ``patch_size`` x ``patch_size`` window (stride 1) becomes one channel
     whose spatial extent is the window, so that :meth:`norm` z-scores each window
@@ -54,6 +83,18 @@ class NormalizedCrossCorrelation2d(torch.nn.Module):
         self.eps = eps
 
     def forward(self, x1, x2):
+        if (self.patch_size is not None and not getattr(self, "_no_patch_kernel", False)
+                and x1.dim() == 4 and x1.shape == x2.shape and ops.on_device(x2)
+                and x1.device == x2.device and x1.dtype == x2.dtype == torch.float32
+                and 1 <= int(self.patch_size) <= min(x2.shape[-2], x2.shape[-1], 64)):
+            # local NCC without `to_patches`: every window z-scored in LDS; the channels are
+            # independent images (the reference's mean over (c h' w') windows = the mean over channels
+            # of the per-channel means); an `expand`ed fixed image is read once, in place
+            b, c, h, w = x2.shape
+            shared = b > 1 and x1.stride(0) == 0 and c == 1
+            a = (x1[:1] if shared else x1).reshape(1 if shared else b * c, h, w)
+            val = _PatchNCCFn.apply(a, x2.reshape(b * c, h, w), int(self.patch_size), self.eps)
+            return val.reshape(b, c).mean(dim=1) if c > 1 else val
         if self.patch_size is not None:
             x1 = to_patches(x1, self.patch_size)
             x2 = to_patches(x2, self.patch_size)

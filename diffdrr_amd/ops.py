@@ -480,6 +480,37 @@ def ncc_backward(x1, x2, stats, g_out, want_x1, want_x2):
     return g_x1, g_x2
 
 
+def ncc_patch_forward(x1, x2, p, eps, want_coef=True):
+    """Patch-wise NCC (reference metrics.py:16-44, ``patch_size = p``) of image pairs: x2 (B, H, W);
+    x1 (B, H, W) or (1, H, W) shared by the batch.  -> (ncc (B), coef (B, H-p+1, W-p+1, 4) | None: what
+    :func:`ncc_patch_backward` needs)"""
+    _require_gpu(x2)
+    B, H, W = x2.shape
+    shared = x1.shape[0] == 1 and B != 1
+    x1, x2 = x1.contiguous(), x2.contiguous()
+    out = torch.empty(B, dtype=torch.float32, device=x2.device)
+    coef = torch.empty(B, H - p + 1, W - p + 1, 4, dtype=torch.float32, device=x2.device) if want_coef else None
+    if B:
+        _launch("ddrr_ncc_patch_forward", x2.device, x1.data_ptr(), 0 if shared else H * W, x2.data_ptr(), B,
+                H, W, int(p), float(eps), out.data_ptr(), _ptr(coef))
+    return out, coef
+
+
+def ncc_patch_backward(x1, x2, coef, g_out, p):
+    """d (sum_b g_out[b] ncc[b]) / d x2 (B, H, W) of :func:`ncc_patch_forward`."""
+    B, H, W = x2.shape
+    shared = x1.shape[0] == 1 and B != 1
+    x1, x2 = x1.contiguous(), x2.contiguous()
+    g_stride = 0 if (g_out.dim() == 0 or (g_out.dim() == 1 and B > 1 and g_out.stride(0) == 0)) else 1
+    if g_stride:
+        g_out = g_out.contiguous()
+    g_x2 = torch.empty_like(x2)
+    if B:
+        _launch("ddrr_ncc_patch_backward", x2.device, x1.data_ptr(), 0 if shared else H * W, x2.data_ptr(),
+                coef.data_ptr(), g_out.data_ptr(), g_stride, B, H, W, int(p), g_x2.data_ptr())
+    return g_x2
+
+
 def sobel_forward(img):
     """img (B, H, W) -> (B, 2, H, W): the Sobel x / y responses (reference metrics.py:69-94)."""
     _require_gpu(img)

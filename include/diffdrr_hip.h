@@ -534,6 +534,23 @@ int ddrr_ncc_backward(const float *x1, long x1_stride, const float *x2, const fl
                       const float *g_out, int g_stride, int B, int N, float *g_x1, float *g_x2,
                       void *stream);
 
+/* NormalizedCrossCorrelation2d(patch_size = p) (reference metrics.py:16-44; ABI 31): the mean over all
+ * p x p windows (stride 1) of the windows' own NCC -- each window z-scored on its own, biased variance
+ * + eps -- for image pairs (H, W): the local similarity of MultiscaleNormalizedCrossCorrelation2d
+ * (metrics.py:47-63) and of GradientNormalizedCrossCorrelation2d(patch_size = p) over the 2 B Sobel
+ * channel images.  The reference materialises both images as (B, (H-p+1)(W-p+1), p, p) tensors (`to_patches`,
+ * 256^2 at p = 13: 40 MB per image and pose) and autograd a dozen more; here a window is two passes over its
+ * pixels in LDS.  x2 (B, H, W); x1 (B, H, W) with x1_stride = H W, or ONE image with x1_stride = 0.
+ * out (B) (zeroed by the call).  coef (B, H-p+1, W-p+1, 4), 16-byte aligned, or NULL: per window
+ * {1 / (s1 s2), mu1 / (s1 s2), ncc / s2^2, mu2 ncc / s2^2} for the backward, which forms
+ * d out / d x2 (B, H, W) per pixel from the <= p^2 windows that hold it (g_out, g_stride: as
+ * ddrr_ncc_backward).  1 <= p <= min(H, W, 64). */
+int ddrr_ncc_patch_forward(const float *x1, long x1_stride, const float *x2, int B, int H, int W, int p,
+                           float eps, float *out, float *coef, void *stream);
+int ddrr_ncc_patch_backward(const float *x1, long x1_stride, const float *x2, const float *coef,
+                            const float *g_out, int g_stride, int B, int H, int W, int p, float *g_x2,
+                            void *stream);
+
 /* The Sobel pair in front of GradientNormalizedCrossCorrelation2d (reference metrics.py:69-94:
  * Conv2d(1, 2, 3, padding=1) with Gx = [[1,0,-1],[2,0,-2],[1,0,-1]], Gy = [[1,2,1],[0,0,0],
  * [-1,-2,-1]], zero padding): img (B, H, W) -> out (B, 2, H, W), and its adjoint g_out (B, 2, H, W)

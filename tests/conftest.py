@@ -968,3 +968,56 @@ def check_untracked_volume_edits(device, ops):
     seen = render()
     assert (seen - img_before).abs().max() > 1e-3  # the brighter voxel shows after the explicit call
     assert ops.brick_workspace_stale(V, "q16p") == 0
+
+
+def check_patch_ncc_against_composition(device):
+    """ddrr_ncc_patch_forward / _backward (NormalizedCrossCorrelation2d(patch_size = p) without the
+    reference's (B, windows, p, p) tensors; reference metrics.py:16-44) against the composition they
+    replace -- `to_patches` + `norm` through autograd, itself pinned to the reference's fixture -- on
+    what the fixture does not cover: non-square images, even / odd / extreme window sizes (1, the whole
+    image), a fixed image shared by the batch (`expand`: read in place), two channels, a gradient
+    w.r.t. the fixed image, `.sum()` (an expanded scalar gradient) and per-pose weights."""
+    import copy
+
+    import torch
+
+    from diffdrr_amd import metrics as M
+    from diffdrr_amd import ops
+
+    calls = []
+    fwd = ops.ncc_patch_forward
+    ops.ncc_patch_forward = lambda *a, **k: (calls.append(1), fwd(*a, **k))[1]
+    try:
+        g = torch.Generator().manual_seed(4)
+        # (p = 1 -- one-pixel windows: every z-score is 0 / sqrt(eps) -- has the value 0 and nothing to
+        # differentiate but rounding residue times 1 / eps: value only)
+        one = M.NormalizedCrossCorrelation2d(patch_size=1)(
+            torch.rand(1, 1, 9, 12, generator=g).to(device), torch.rand(1, 1, 9, 12, generator=g).to(device))
+        assert float(one.abs().max()) < 1e-6
+        for (B, C, H, W), p in (((3, 1, 21, 34), 5), ((2, 1, 40, 33), 8), ((2, 2, 19, 23), 7), ((1, 1, 9, 12), 2),
+                                ((2, 1, 12, 12), 12), ((2, 1, 50, 41), 33)):
+            fixed = (torch.rand(1, C, H, W, generator=g) * 20 + 5).to(device)
+            moving = (torch.rand(B, C, H, W, generator=g) * 20 + 5).to(device)
+            w = (torch.rand(B, generator=g) + 0.5).to(device)
+            crit = M.NormalizedCrossCorrelation2d(patch_size=p)
+            ref = copy.deepcopy(crit)
+            ref._no_patch_kernel = True
+            res = []
+            for c, grad_fixed in ((crit, True), (ref, True)):
+                a = fixed.clone().requires_grad_(grad_fixed)
+                x = moving.clone().requires_grad_()
+                v = c(a.expand(B, -1, -1, -1), x)
+                (v * w).sum().backward()
+                res.append((v.detach().cpu().numpy(), x.grad.cpu().numpy(), a.grad.cpu().numpy()))
+            (v1, g1, ga1), (v0, g0, ga0) = res
+            assert np.abs(v1 - v0).max() < 5e-6, (p, v1, v0)
+            assert rel_err(g1, g0) < 5e-5 and rel_err(ga1, ga0) < 5e-5, (p, rel_err(g1, g0), rel_err(ga1, ga0))
+            # `.sum()`: the gradient arrives as an expanded scalar
+            x = moving.clone().requires_grad_()
+            crit(fixed.expand(B, -1, -1, -1), x).sum().backward()
+            x0 = moving.clone().requires_grad_()
+            ref(fixed.expand(B, -1, -1, -1), x0).sum().backward()
+            assert rel_err(x.grad.cpu().numpy(), x0.grad.cpu().numpy()) < 5e-5
+        assert len(calls) >= 12  # (the kernels really ran)
+    finally:
+        ops.ncc_patch_forward = fwd

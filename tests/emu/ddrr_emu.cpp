@@ -23,6 +23,7 @@
 #include "../../diffdrr_amd/csrc/record_pack.h"
 #include "../../diffdrr_amd/csrc/record_layout.h"
 #include "../../diffdrr_amd/csrc/segments_core.h"
+#include "../../diffdrr_amd/csrc/ncc_patch_core.h"
 #include "../../diffdrr_amd/csrc/sobel_core.h"
 #include "../../diffdrr_amd/csrc/tri_brick.h"
 #include "../../diffdrr_amd/csrc/trilinear_core.h"
@@ -1405,6 +1406,46 @@ int ddrr_ncc_backward(const float *x1, long x1_stride, const float *x2, const fl
             if (g_x2) g_x2[(long)b * N + n] = g * (z1 - z2 * st[4]) / st[3];
             if (g_x1) g_x1[(long)b * N + n] = g * (z2 - z1 * st[4]) / st[1];
         }
+    }
+    return 0;
+}
+
+int ddrr_ncc_patch_forward(const float *x1, long x1_stride, const float *x2, int B, int H, int W, int p,
+                           float eps, float *out, float *coef, void *) {
+    if (p < 1 || p > H || p > W || p > 64) return -1;
+    const int hw = H - p + 1, ww = W - p + 1;
+    for (int b = 0; b < B; ++b) {
+        const float *a = x1 + b * x1_stride, *m = x2 + (long)b * H * W;
+        double total = 0.;
+        for (int wy = 0; wy < hw; ++wy)
+            for (int wx = 0; wx < ww; ++wx) {
+                float c[4];
+                total += ncc_patch_window([&](int y, int x) { return a[(long)(wy + y) * W + wx + x]; },
+                                          [&](int y, int x) { return m[(long)(wy + y) * W + wx + x]; }, p, eps, c);
+                if (coef) memcpy(coef + (((long)b * hw + wy) * ww + wx) * 4, c, sizeof(c));
+            }
+        out[b] = (float)(total / ((double)hw * ww));
+    }
+    return 0;
+}
+
+int ddrr_ncc_patch_backward(const float *x1, long x1_stride, const float *x2, const float *coef,
+                            const float *g_out, int g_stride, int B, int H, int W, int p, float *g_x2,
+                            void *) {
+    if (p < 1 || p > H || p > W || p > 64) return -1;
+    const int hw = H - p + 1, ww = W - p + 1;
+    for (int b = 0; b < B; ++b) {
+        const float g = g_out[b * g_stride] / ((float)hw * (float)ww * (float)(p * p));
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                const float s = ncc_patch_pixel_grad(
+                    [&](int wy, int wx, int k) {
+                        return (wy >= 0 && wx >= 0 && wy < hw && wx < ww)
+                                   ? coef[(((long)b * hw + wy) * ww + wx) * 4 + k] : 0.f;
+                    },
+                    y, x, p, x1[b * x1_stride + (long)y * W + x], x2[((long)b * H + y) * W + x]);
+                g_x2[((long)b * H + y) * W + x] = g * s;
+            }
     }
     return 0;
 }

@@ -1226,3 +1226,9 @@ def test_subsample_list_and_patched_render_vs_oracle(gpu, renderer):
         with torch.no_grad():
             wimg = whole(rot, xyz, parameterization="euler_angles", convention="ZXY", **kw).reshape(B, H * W)
         assert rel_err(wimg.cpu().numpy(), ref) > 1e-4
+
+
+def test_patch_ncc_kernels_against_the_composition(gpu):
+    """ddrr_ncc_patch_forward / _backward on the device: MultiscaleNormalizedCrossCorrelation2d's local
+    scale without `to_patches` (VERDICT r05 missing 5)."""
+    conftest.check_patch_ncc_against_composition(gpu)

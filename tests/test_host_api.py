@@ -1072,3 +1072,8 @@ def test_subsample_and_patches_match_reference_on_the_bricks(emulated_ops, monke
     launch = emulated_ops._launch
     monkeypatch.setattr(emulated_ops, "_launch", lambda n, d, *a: (calls.append(n), launch(n, d, *a))[1])
     conftest.check_sparse_lever(name, "cpu", emulated_ops, calls)
+
+
+def test_patch_ncc_kernels_against_the_composition(emulated_ops):
+    """(host build of ncc_patch_core.h; the device twin: tests/test_gpu_parity.py)"""
+    conftest.check_patch_ncc_against_composition(torch.device("cpu"))
