@@ -34,6 +34,8 @@ _SIGNATURES = {
                             _I, _I, _P, _P, _P, _P],
     "ddrr_siddon_forward_bricks": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _F, _I,
                                    _P, _I, _P, _P],
+    "ddrr_siddon_forward_bricks_masked": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _F, _I,
+                                          _P, _I, _P, _P, _P],
     "ddrr_siddon_backward_rays": [_P, _I, _P, _P, _I, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P],
     "ddrr_siddon_backward_volume": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _F, _F, _I, _I,
                                     _I, _I, _I, _P, _P],

@@ -43,6 +43,7 @@ struct BrickArgs {
     int *ws_header;               // ... the workspace's header words
     int ranges_valid;             // ... already computed for this volume
     const unsigned char *packed;  // 16-bit bricks: their LDS images, brick after brick (or null)
+    const unsigned *pix_mask;     // the forward kernels: bit n of word n / 32 = detector pixel n is rendered (NULL: every pixel)
     const unsigned *fingerprint;  // 16-bit bricks: bit patterns of kFingerprintWords voxels of the volume the workspace was built from
     int vec;                      // bricks_fwd.hip brick_range_kernel: 16-byte loads serve the volume
     const int *order;             // bricks_fwd.hip: k-th brick handed out (NULL: k itself)
@@ -222,7 +223,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
                   int det_w, float voxel_shift, float eps, float *out, float *aux,
                   float *g_volume, hipStream_t st, void *launch_ws, const char *who, int n_points = 0,
                   const float *amin = nullptr, const float *amax = nullptr, float rec_q = 0.f,
-                  const unsigned char *labels = nullptr, int n_channels = 0);
+                  const unsigned char *labels = nullptr, int n_channels = 0,
+                  const unsigned *pix_mask = nullptr);
 
 // The configurable Siddon forward / forward + record kernel (bricks_fwd.hip).  variant:
 // DDRR_BRICKS_F32 / DDRR_BRICKS_Q16 (fp32 bricks at fewer than 8 poses, and volumes of fewer than four
@@ -238,7 +240,8 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
                       int dx, int dy, int dz, const float *source, const float *target,
                       const float *img, int B, int det_h, int det_w, float voxel_shift, float eps,
                       float *out, float *aux, float rec_q, hipStream_t st, void *launch_ws,
-                      const char *who, float *clear = nullptr, long clear_n = 0);
+                      const char *who, float *clear = nullptr, long clear_n = 0,
+                      const unsigned *pix_mask = nullptr);
 
 // experiment switches (tools builds: mutable; product: constants)
 #if defined(DDRR_EXPERIMENTS) || defined(DDRR_BRICK_PROFILE)

@@ -762,7 +762,10 @@ __global__ __launch_bounds__(kBrickThreads) void siddon_brick_kernel(
                                          1.0f / (float)uni(r.count));
                 int pix = 0;
                 float n_est = 0.f;
-                const bool hit = valid && brick_candidate(r, local, p.det_w, pix, n_est);
+                bool hit = valid && brick_candidate(r, local, p.det_w, pix, n_est);
+                // a subsample of the detector (reference drr.py:36-39: p_subsample): pixels whose bit is
+                // not set are no candidates
+                if (p.pix_mask != nullptr) hit = hit && ((p.pix_mask[pix >> 5] >> (pix & 31)) & 1u) != 0u;
                 // With the float backward record (5 atomics per hit instead of 1; the packed
                 // record's 3 are cheap enough to go per lane) the length class
                 // of a hit is that of the longest hit among its 8 neighbours in candidate
@@ -1089,9 +1092,11 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
                   int det_w, float voxel_shift, float eps, float *out, float *aux,
                   float *g_volume, hipStream_t st, void *launch_ws, const char *who, int n_points,
                   const float *amin, const float *amax, float rec_q,
-                  const unsigned char *labels, int n_channels) {
+                  const unsigned char *labels, int n_channels, const unsigned *pix_mask) {
     const int N = det_h * det_w;
     BrickArgs p;
+    p.pix_mask = pix_mask;
+    p.fingerprint = nullptr;
     p.vol = volume;
     p.D = Dims{dx, dy, dz};
     p.source = source;
@@ -1284,11 +1289,12 @@ int ddrr_brick_profile_read(unsigned long long *host16) {
 }
 #endif
 
-int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
-                               const float *target, const float *img, int B, int det_h,
-                               int det_w, float voxel_shift, float eps, float *out, float *aux,
-                               float record_vmax, int brick_storage, float *brick_ranges,
-                               int ranges_valid, void *launch_ws, void *stream) {
+static int siddon_forward_bricks_impl(const float *volume, int dx, int dy, int dz, const float *source,
+                                      const float *target, const float *img, int B, int det_h,
+                                      int det_w, float voxel_shift, float eps, float *out, float *aux,
+                                      float record_vmax, int brick_storage, float *brick_ranges,
+                                      int ranges_valid, void *launch_ws, const unsigned *pixel_mask,
+                                      void *stream) {
     const int N = det_h * det_w;
     if (int rc = check_common(volume, dx, dy, dz, source, 1, target, B, N)) return rc;
     if (!out && !aux) return fail(-1, "null out pointer");  // (the record alone: ddrr_siddon_ncc_forward forms the image)
@@ -1325,13 +1331,36 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                                    source, target, img, B, det_h, det_w, voxel_shift, eps, out, aux,
                                    rec_q, st, launch_ws, "ddrr_siddon_forward_bricks",
                                    packed || cleared ? nullptr : (aux ? aux : out),
-                                   cleared ? -1 : (packed ? 0 : (long)fill)))
+                                   cleared ? -1 : (packed ? 0 : (long)fill), pixel_mask))
         return rc;
     if (!aux) return 0;
     if (out)
         hipLaunchKernelGGL(siddon_out_from_record_kernel, dim3((unsigned)((R + kBlock - 1) / kBlock)),
                            dim3(kBlock), 0, st, aux + (packed ? 4 * R : 0), packed ? 0 : 1, img, R, out);
     return finish("ddrr_siddon_forward_bricks");
+}
+
+int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
+                               const float *target, const float *img, int B, int det_h,
+                               int det_w, float voxel_shift, float eps, float *out, float *aux,
+                               float record_vmax, int brick_storage, float *brick_ranges,
+                               int ranges_valid, void *launch_ws, void *stream) {
+    return siddon_forward_bricks_impl(volume, dx, dy, dz, source, target, img, B, det_h, det_w, voxel_shift,
+                                      eps, out, aux, record_vmax, brick_storage, brick_ranges, ranges_valid,
+                                      launch_ws, nullptr, stream);
+}
+
+int ddrr_siddon_forward_bricks_masked(const float *volume, int dx, int dy, int dz, const float *source,
+                                      const float *target, const float *img, int B, int det_h,
+                                      int det_w, float voxel_shift, float eps, float *out, float *aux,
+                                      float record_vmax, int brick_storage, float *brick_ranges,
+                                      int ranges_valid, void *launch_ws, const unsigned *pixel_mask,
+                                      void *stream) {
+    if (pixel_mask && (reinterpret_cast<uintptr_t>(pixel_mask) & 3) != 0)
+        return fail(-1, "pixel_mask must be 4-byte aligned");
+    return siddon_forward_bricks_impl(volume, dx, dy, dz, source, target, img, B, det_h, det_w, voxel_shift,
+                                      eps, out, aux, record_vmax, brick_storage, brick_ranges, ranges_valid,
+                                      launch_ws, pixel_mask, stream);
 }
 
 long ddrr_brick_workspace_bytes(int dx, int dy, int dz, int brick_storage) {

@@ -788,7 +788,11 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
                     const bool valid = local < uni(r.count);
                     int pix = 0;
                     float n_est = 0.f;
-                    const bool hit = valid && brick_candidate(r, local, p.det_w, pix, n_est);
+                    bool hit = valid && brick_candidate(r, local, p.det_w, pix, n_est);
+                    // a subsample of the detector (reference drr.py:36-39, p_subsample): pixels whose
+                    // bit is not set are no candidates -- the walks, the ray loads and the atomics of
+                    // nine tenths of the rays at p_subsample = 0.1 (a uniform branch per unit otherwise)
+                    if (p.pix_mask != nullptr) hit = hit && ((p.pix_mask[pix >> 5] >> (pix & 31)) & 1u) != 0u;
                     // float record: classes per run of 8 adjacent pixels (see bricks.hip)
                     float n_grp = hit ? n_est : 0.f;
                     if (GROUPED) {
@@ -1627,7 +1631,7 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
                       const float *volume, int dx, int dy, int dz, const float *source, const float *target,
                       const float *img, int B, int det_h, int det_w, float voxel_shift, float eps,
                       float *out, float *aux, float rec_q, hipStream_t st, void *launch_ws,
-                      const char *who, float *clear, long clear_n) {
+                      const char *who, float *clear, long clear_n, const unsigned *pix_mask) {
     const int N = det_h * det_w;
     // (brick_range_kernel: 16-byte loads where the volume's rows are aligned, else dwords)
     const bool vec_ok = (dz & 3) == 0 && (reinterpret_cast<uintptr_t>(volume) & 15) == 0;
@@ -1652,7 +1656,7 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
             return fail(-1, "hipMemsetAsync");
         return launch_bricks(aux ? BRICK_FWD_AUX : BRICK_FWD, volume, dx, dy, dz, source, target, img,
                              nullptr, B, det_h, det_w, voxel_shift, eps, out, aux, nullptr, st,
-                             launch_ws, who, 0, nullptr, nullptr, rec_q);
+                             launch_ws, who, 0, nullptr, nullptr, rec_q, nullptr, 0, pix_mask);
     }
     BrickArgs p = {};
     p.vol = volume;
@@ -1666,6 +1670,7 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
     p.shift = voxel_shift;
     p.eps = eps;
     p.vec = vec_ok ? 1 : 0;
+    p.pix_mask = pix_mask;
     if ((long)B * N * 12 >= (1L << 32))
         return fail(-1, "B * N too large for one brick launch (12 B N must stay below 2^32): "
                         "split the pose batch");

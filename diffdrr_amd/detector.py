@@ -131,6 +131,19 @@ class Detector(torch.nn.Module):
             self._subsample_index = cached
         return cached
 
+    def subsample_mask(self):
+        """One bit per pixel of the whole grid, set for the subsample's pixels (``ops.pixel_mask_of``):
+        what the brick kernels take to render the subsample alone; cached per device."""
+        idx = self.subsample_index()
+        if idx is None:
+            return None
+        cached = getattr(self, "_subsample_mask", None)
+        if cached is None or cached[0] is not idx:
+            from . import ops
+            cached = (idx, ops.pixel_mask_of(idx, self.height * self.width))
+            self._subsample_mask = cached
+        return cached[1]
+
     def _initialize_carm(self):
         """Unit-spaced pixel centres on the plane z = 1, centred on the optical axis."""
         target = self._unit_grid()

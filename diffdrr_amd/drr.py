@@ -129,22 +129,20 @@ class DRR(nn.Module):
                                                           or self.density.requires_grad))):
                 img = self._render_euler_inference(args[0], args[1], convention, degrees)
                 if img is not None:
-                    return self.reshape_transform(img, batch_size=len(args[0]))
+                    return self._reshape_fused(img, len(args[0]))
             # pose parameters -> world matrix in one kernel (pose.py euler_world_pose)
             Mw = euler_world_pose(args[0], args[1], convention, self.detector._reorient,
                                   degrees=degrees)
-            return self.reshape_transform(
-                self._render_fused_Mw(Mw, calibration, mask_to_channels, **kwargs),
-                batch_size=len(Mw))
+            return self._reshape_fused(self._render_fused_Mw(Mw, calibration, mask_to_channels, **kwargs),
+                                       len(Mw))
         if parameterization is None:
             pose = args[0]
         else:
             pose = convert(*args, parameterization=parameterization, convention=convention,
                            degrees=degrees)
         if fused:
-            return self.reshape_transform(
-                self._render_fused(pose, calibration, mask_to_channels, **kwargs),
-                batch_size=len(pose))
+            return self._reshape_fused(self._render_fused(pose, calibration, mask_to_channels, **kwargs),
+                                       len(pose))
         source, target = self.detector(pose, calibration)
         # (rays straight out of the Detector: a row-major affine grid by construction)
         self._rays_from_detector = True
@@ -157,6 +155,18 @@ class DRR(nn.Module):
         finally:
             self._rays_from_detector = False
         return self.reshape_transform(img, batch_size=len(pose))
+
+    def _reshape_fused(self, img, batch_size):
+        """``reshape_transform`` of a fused render.  A subsample rendered through the brick kernels'
+        pixel mask arrives as ``_ScatteredGrid``: the whole grid with zeros at the pixels that were
+        not drawn -- which IS what ``reshape_subsampled_drr`` builds (reference drr.py:142-147) --
+        so ``reshape=True`` is a view and ``reshape=False`` one gather."""
+        if isinstance(img, _ScatteredGrid):
+            det = self.detector
+            if self.reshape:
+                return img.dense.view(batch_size, -1, det.height, det.width)
+            return img.dense.index_select(-1, det.subsample_index())
+        return self.reshape_transform(img, batch_size=batch_size)
 
     # The DRR case end to end on the GPU: pose -> rays -> line integrals without the
     # (B, N, 3) ray tensors (and their gradients) passing through PyTorch ops.  Same maths
@@ -280,11 +290,17 @@ class DRR(nn.Module):
         H, W = det.height, det.width
         idx = det.subsample_index()
         if isinstance(r, Siddon):
+            # a subsample, plain render: the brick kernels drop the pixels that were not drawn right
+            # after the candidate test (ddrr_siddon_forward_bricks_masked) -- a tenth of the walks at
+            # p_subsample = 0.1, and the image they leave is the scattered one
+            pm = det.subsample_mask() if (idx is not None and mask is None and r.grid_path == "bricks") else None
             r.detector_shape, r.trust_detector_shape = (H, W), True
             try:
-                dense = r.render_poses(self.density, Mw, P, Ainv, mask=mask)  # (B, C, H W)
+                dense = r.render_poses(self.density, Mw, P, Ainv, mask=mask, pixel_mask=pm)  # (B, C, H W)
             finally:
                 r.trust_detector_shape = False
+            if pm is not None:
+                return _ScatteredGrid(dense)
             return dense if idx is None else dense.index_select(-1, idx)
         source, target, img = _RaygenFn.apply(Mw, P, Ainv)
         given = kwargs.get("alphamin") is not None and kwargs.get("alphamax") is not None
@@ -344,10 +360,9 @@ class DRR(nn.Module):
             ops.siddon_forward_bricks(self.density, source, target, img, cfg["det"],
                                       voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
                                       storage=_brick_storage(self.density, cfg, B), out=out, launch_ws=launch_ws,
-                                      cleared=True)
-            idx = det.subsample_index()  # (p_subsample: the grid is rendered, the subsample gathered)
-            if idx is not None:
-                out = out.index_select(-1, idx)
+                                      cleared=True, pixel_mask=det.subsample_mask())
+        if det.n_subsample is not None:  # (p_subsample: the scattered grid, see _reshape_fused)
+            return _ScatteredGrid(out.unsqueeze(1))
         return out.unsqueeze(1)
 
     FUSED_NCC_MAX_POSES = 32
@@ -536,6 +551,15 @@ class DRR(nn.Module):
         x = self.detector.sdd * torch.einsum(
             "ij,bnj->bni", torch.linalg.inv(self.detector.intrinsic), uv1)
         return self.detector.reorient.compose(pose)(x)
+
+
+class _ScatteredGrid:
+    """A subsample as the masked brick kernels leave it: ``dense`` (B, 1, H W), zeros at the pixels
+    that were not drawn (``DRR._reshape_fused``)."""
+    __slots__ = ("dense",)
+
+    def __init__(self, dense):
+        self.dense = dense
 
 
 def reshape_subsampled_drr(img: torch.Tensor, detector: Detector, batch_size: int):

@@ -349,7 +349,7 @@ def brick_record_buffer(B, N, device):
 
 def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, eps=1e-8,
                           want_aux=False, record_vmax=0.0, storage="f32", want_image=True,
-                          aux=None, out=None, launch_ws=None, cleared=False):
+                          aux=None, out=None, launch_ws=None, cleared=False, pixel_mask=None):
     """Detector-grid Siddon (sum) through the volume-stationary brick kernel: every 32^3
     brick is staged in LDS once and all rays of all poses are traced through it.
     Requires the targets to be the affine detector grid DRR builds.
@@ -364,7 +364,9 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
     launch workspace (:func:`launch_workspace`) the caller brings along; ``cleared``: what the
     launch's atomics add to (the record if one is wanted, else the image) and the workspace's
     counter are zero already (:func:`pose_raygen_forward` did it in its launch) -- the call then
-    clears nothing."""
+    clears nothing.  ``pixel_mask``: an int32 tensor of ceil(N / 32) words, one bit per pixel of the
+    grid (:func:`pixel_mask_of`): only the pixels whose bit is set are rendered, image and record
+    hold zeros at the others (``p_subsample``: reference drr.py:36-39, 142-147)."""
     B, N = _check_rays(volume, source, target, img)
     H, W = int(det[0]), int(det[1])
     if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
@@ -395,15 +397,30 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
         return out, aux
     if launch_ws is None:
         launch_ws = launch_workspace(volume.shape, volume.device)
+    if pixel_mask is not None and (pixel_mask.dtype != torch.int32 or pixel_mask.numel() != (N + 31) // 32
+                                   or not pixel_mask.is_contiguous() or pixel_mask.device != volume.device):
+        raise ValueError("pixel_mask: a contiguous int32 tensor of ceil(N / 32) words on the volume's device")
     _launch(
-        "ddrr_siddon_forward_bricks", volume.device, volume.data_ptr(), *volume.shape,
+        "ddrr_siddon_forward_bricks" if pixel_mask is None else "ddrr_siddon_forward_bricks_masked",
+        volume.device, volume.data_ptr(), *volume.shape,
         source.data_ptr(), target.data_ptr(), _ptr(img), B, H, W, float(voxel_shift), float(eps),
         _ptr(out), _ptr(aux), float(record_vmax) if packed else 0.0,
         _BRICK_STORAGE[storage], _ptr(ranges), int(valid) | (_lib.BRICKS_CLEARED if cleared else 0),
-        launch_ws.data_ptr())
+        launch_ws.data_ptr(), *(() if pixel_mask is None else (pixel_mask.data_ptr(),)))
     if storage != "f32" and not valid:
         brick_workspace_commit(volume, storage)
     return out, aux
+
+
+def pixel_mask_of(index, n_pixels):
+    """One bit per pixel of a detector grid of ``n_pixels`` pixels, set for the pixels listed in
+    ``index`` (int64 tensor): the ``pixel_mask`` of :func:`siddon_forward_bricks`, int32 words on
+    ``index``'s device."""
+    words = torch.zeros((n_pixels + 31) // 32 * 32, dtype=torch.bool, device=index.device)
+    words[index] = True
+    weights = (1 << torch.arange(32, dtype=torch.int64, device=index.device))
+    packed = (words.view(-1, 32).to(torch.int64) * weights).sum(dim=1)
+    return (packed - ((packed >> 31) << 32)).to(torch.int32).contiguous()  # (two's complement words)
 
 
 def siddon_backward_rays(aux, grad_out, source, target, img, *, eps=1e-8, reducefn="sum",

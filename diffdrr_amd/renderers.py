@@ -454,7 +454,7 @@ class _SiddonPoseFn(torch.autograd.Function):
             out, aux = ops.siddon_forward_bricks(
                 volume, source, target, img, cfg["det"], voxel_shift=cfg["voxel_shift"],
                 eps=cfg["eps"], want_aux=want_aux, record_vmax=_record_vmax(volume, want_aux, cfg),
-                storage=_brick_storage(volume, cfg, source.shape[0]))
+                storage=_brick_storage(volume, cfg, source.shape[0]), pixel_mask=cfg.get("pixel_mask"))
         else:
             out, aux, _ = ops.siddon_forward(
                 volume, source, target, img, voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
@@ -697,12 +697,15 @@ class Siddon(torch.nn.Module):
         """Whether ``render_poses`` (the fused DRR entry) computes what ``forward`` would."""
         return self.mode == "nearest" and self.reducefn == "sum"
 
-    def render_poses(self, volume, Mw, P, Ainv, mask=None):
+    def render_poses(self, volume, Mw, P, Ainv, mask=None, pixel_mask=None):
         """The DRR case without materialising the ray tensors in PyTorch: ``Mw`` (B,3,4)
         world pose per DRR (extrinsic o reorient), ``P`` (N,3) calibrated detector points,
         ``Ainv`` (3,4) world -> voxel.  Equals ``forward(volume, *rays(Mw, P, Ainv), mask=mask)``;
-        -> (B, 1, N), or (B, C, N) with a mask."""
+        -> (B, 1, N), or (B, C, N) with a mask.  ``pixel_mask`` (``Detector.subsample_mask``, plain
+        render on the bricks only): the pixels rendered, zeros at the others."""
         cfg = self._cfg(False)
+        if pixel_mask is not None and mask is None and cfg["path"] == "bricks":
+            cfg["pixel_mask"] = pixel_mask
         if mask is not None:
             source, target, img = _RaygenFn.apply(Mw, P, Ainv)
             return _cat_channels(_chunk(_SiddonChannelsFn.apply(volume, source, target, img, labels, C, cfg), k0)

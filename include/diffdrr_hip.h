@@ -152,6 +152,20 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                                int det_w, float voxel_shift, float eps, float *out, float *aux,
                                float record_vmax, int brick_storage, float *brick_ranges,
                                int ranges_valid, void *launch_ws, void *stream);
+/* The same render of a SUBSAMPLE of the detector grid (ABI 31; reference drr.py:36-39, 142-147 and
+ * detector.py:134-137: `p_subsample` keeps a random subset of the pixels and `reshape_subsampled_drr`
+ * scatters the rendered values into zeros): pixel_mask holds one bit per pixel of the det_h x det_w
+ * grid -- bit n % 32 of word n / 32 set = pixel n is rendered -- shared by the B poses, ceil(det_h det_w
+ * / 32) words, 4-byte aligned; NULL = every pixel (= ddrr_siddon_forward_bricks).  source / target /
+ * img are still the whole grid's (the kernels cull candidates with the grid's affine model, then
+ * drop the pixels whose bit is clear before any ray is loaded or walked); out (B, N) / aux hold zeros
+ * at the other pixels: `out` IS the scattered image the reference builds. */
+int ddrr_siddon_forward_bricks_masked(const float *volume, int dx, int dy, int dz, const float *source,
+                                      const float *target, const float *img, int B, int det_h,
+                                      int det_w, float voxel_shift, float eps, float *out, float *aux,
+                                      float record_vmax, int brick_storage, float *brick_ranges,
+                                      int ranges_valid, void *launch_ws, const unsigned *pixel_mask,
+                                      void *stream);
 
 /* Volume gradient for the DRR case of ddrr_siddon_forward_bricks (reduce sum), also
  * volume-stationary: each 32^3 brick of g_volume is accumulated in LDS (ds_add_f32) from

@@ -889,7 +889,15 @@ def check_sparse_lever(name, device, ops, calls=None):
         per_ray = {"ddrr_siddon_forward", "ddrr_trilinear_forward", "ddrr_siddon_forward_channels",
                    "ddrr_trilinear_forward_channels", "ddrr_trilinear_backward", "ddrr_siddon_backward_channels"}
         assert not per_ray & set(calls), (name, sorted(per_ray & set(calls)))
-        assert any(c.endswith("_bricks") for c in calls), (name, calls)
+        assert any("_bricks" in c for c in calls), (name, calls)
+        if renderer == "siddon" and "p_subsample" in ctor:
+            # the subsample goes through the kernels' pixel mask: the rays that were not drawn are
+            # dropped after the candidate test, and what is left is the scattered image itself
+            assert "ddrr_siddon_forward_bricks_masked" in calls, calls
+            if ctor.get("reshape", True):
+                drawn = torch.zeros(geo["height"] * geo["width"], dtype=torch.bool, device=device)
+                drawn[torch.tensor(drr.detector.subsamples[-1], device=device)] = True
+                assert float(img.detach().reshape(B, -1)[:, ~drawn].abs().max()) == 0.0
     return drr
 
 

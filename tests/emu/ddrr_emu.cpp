@@ -375,11 +375,36 @@ long ddrr_brick_launch_workspace_bytes(int dx, int dy, int dz) {
     return 256 + (n32 * 8 + 255) / 256 * 256;
 }
 
+static int emu_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
+                                     const float *target, const float *img, int B, int det_h,
+                                     int det_w, float voxel_shift, float eps, float *out, float *aux,
+                                     float record_vmax, int brick_storage, float *brick_ws,
+                                     int ranges_valid, const unsigned *pixel_mask);
+
 int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
                                const float *target, const float *img, int B, int det_h,
                                int det_w, float voxel_shift, float eps, float *out, float *aux,
                                float record_vmax, int brick_storage, float *brick_ws,
                                int ranges_valid, void * /*launch_ws*/, void *) {
+    return emu_siddon_forward_bricks(volume, dx, dy, dz, source, target, img, B, det_h, det_w, voxel_shift, eps,
+                                     out, aux, record_vmax, brick_storage, brick_ws, ranges_valid, nullptr);
+}
+
+int ddrr_siddon_forward_bricks_masked(const float *volume, int dx, int dy, int dz, const float *source,
+                                      const float *target, const float *img, int B, int det_h,
+                                      int det_w, float voxel_shift, float eps, float *out, float *aux,
+                                      float record_vmax, int brick_storage, float *brick_ws,
+                                      int ranges_valid, void * /*launch_ws*/, const unsigned *pixel_mask,
+                                      void *) {
+    return emu_siddon_forward_bricks(volume, dx, dy, dz, source, target, img, B, det_h, det_w, voxel_shift, eps,
+                                     out, aux, record_vmax, brick_storage, brick_ws, ranges_valid, pixel_mask);
+}
+
+static int emu_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, const float *source,
+                                     const float *target, const float *img, int B, int det_h,
+                                     int det_w, float voxel_shift, float eps, float *out, float *aux,
+                                     float record_vmax, int brick_storage, float *brick_ws,
+                                     int ranges_valid, const unsigned *pixel_mask) {
     ranges_valid &= 1;  // (DDRR_BRICKS_CLEARED: the emulation clears its outputs anyway)
     const Dims D{dx, dy, dz};
     // workspace layout of the product (bricks_fwd.hip): header, (min, max) per brick, fallback
@@ -545,6 +570,8 @@ int ddrr_siddon_forward_bricks(const float *volume, int dx, int dy, int dz, cons
                 if (pix != (row.i0 + local / row.w) * det_w + row.j0 + local % row.w) abort();
                 if (!maybe) continue;
                 cand[pix] = 1;
+                // (a subsample: the pixel's bit decides after the conservative test, as in the kernel)
+                if (pixel_mask && !((pixel_mask[pix >> 5] >> (pix & 31)) & 1u)) continue;
                 auto &qk = queues[n_est < 14.f ? 0 : (n_est < 34.f ? 1 : 2)];
                 qk.emplace_back(b, pix);
                 if (qk.size() >= 64) {  // a full wave of hits of one length class: walk them

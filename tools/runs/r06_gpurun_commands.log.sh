@@ -77,3 +77,9 @@ python tools/storage_table.py 5 6 7 8 9 10 12 14 2>&1 | grep -v amdgpu.ids
 
 # ---------------------------------------------------------------- 2026-10-01T04:26:43Z  r06: fp32 bricks general vs configurable kernel by pose count
 python tools/f32_kernel_table.py 2>&1 | grep -v amdgpu.ids
+
+# ---------------------------------------------------------------- 2026-10-01T04:32:54Z  r06: patch NCC kernels: tests + bench vs composition
+python -m pytest tests -m gpu -x -q -k "patch_ncc or metrics" 2>&1 | tail -3; python tools/patch_ncc_bench.py 2>&1 | grep -v amdgpu.ids
+
+# ---------------------------------------------------------------- 2026-10-01T04:38:07Z  r06: patch NCC kernels: tests + bench vs composition (retry)
+python -m pytest tests -m gpu -x -q -k "patch_ncc or metrics" 2>&1 | tail -3; python tools/patch_ncc_bench.py 2>&1 | grep -v amdgpu.ids
