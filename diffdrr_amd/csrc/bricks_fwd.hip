@@ -482,7 +482,9 @@ __global__ __launch_bounds__(C::THREADS) void brick_pack_kernel(BrickArgs p, int
 
 // PRE (launches of a few poses on the 16-bit storages): the workgroup's first claim is made in front
 // of the loop, see the fingerprint comparison below.
-template <bool AUX, class C, bool PRE = false>
+// SUB: the launch renders a subsample of the detector (p.pix_mask; an instantiation of its own: as a
+// uniform branch per unit the test cost the one-pose launches 1 - 2 us of 111).
+template <bool AUX, class C, bool PRE = false, bool SUB = false>
 __global__ __launch_bounds__(C::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict__ aux) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -791,8 +793,8 @@ siddon_fwd_brick_kernel(BrickArgs p, float *__restrict__ out, float *__restrict_
                     bool hit = valid && brick_candidate(r, local, p.det_w, pix, n_est);
                     // a subsample of the detector (reference drr.py:36-39, p_subsample): pixels whose
                     // bit is not set are no candidates -- the walks, the ray loads and the atomics of
-                    // nine tenths of the rays at p_subsample = 0.1 (a uniform branch per unit otherwise)
-                    if (p.pix_mask != nullptr) hit = hit && ((p.pix_mask[pix >> 5] >> (pix & 31)) & 1u) != 0u;
+                    // nine tenths of the rays at p_subsample = 0.1
+                    if constexpr (SUB) hit = hit && ((p.pix_mask[pix >> 5] >> (pix & 31)) & 1u) != 0u;
                     // float record: classes per run of 8 adjacent pixels (see bricks.hip)
                     float n_grp = hit ? n_est : 0.f;
                     if (GROUPED) {
@@ -1448,7 +1450,7 @@ __global__ __launch_bounds__(256) void brick_clear_kernel(float *__restrict__ bu
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) buf[(n4 << 2) + threadIdx.x] = 0.f;
 }
 
-template <bool AUX, class C, bool PRE = false>
+template <bool AUX, class C, bool PRE = false, bool SUB = false>
 int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t st) {
     static_assert(C::LDS <= C::LDS_BUDGET, "LDS budget");
     constexpr int kMaxDev = 64;
@@ -1462,7 +1464,7 @@ int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t
         std::lock_guard<std::mutex> lock(mu);
         if (!attr_set[dev]) {
             if ((e = hipFuncSetAttribute(
-                     reinterpret_cast<const void *>(&siddon_fwd_brick_kernel<AUX, C, PRE>),
+                     reinterpret_cast<const void *>(&siddon_fwd_brick_kernel<AUX, C, PRE, SUB>),
                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS)) != hipSuccess)
                 return fail_hip(e, "hipFuncSetAttribute");
             attr_set[dev] = true;
@@ -1521,7 +1523,7 @@ int launch_cfg(const BrickArgs &p, int n_cu, float *out, float *aux, hipStream_t
             return fail_hip(e, "hipMemsetAsync");
     }
     const dim3 grid(n_bricks < slots ? n_bricks : slots), block(C::THREADS);
-    hipLaunchKernelGGL((siddon_fwd_brick_kernel<AUX, C, PRE>), grid, block, C::LDS, st, q, out, aux);
+    hipLaunchKernelGGL((siddon_fwd_brick_kernel<AUX, C, PRE, SUB>), grid, block, C::LDS, st, q, out, aux);
     return 0;
 }
 
@@ -1719,8 +1721,12 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
     if (g_brick_dbg & 512) p.order_ws = nullptr;  // (bricks in id order)
 #endif
     int rc = 0;
-#define DDRR_LAUNCH(C) (aux ? launch_cfg<true, C>(p, n_cu, out, aux, st) \
-                            : launch_cfg<false, C>(p, n_cu, out, aux, st))
+#define DDRR_LAUNCH_P(C, PRE_)                                                               \
+    (p.pix_mask ? (aux ? launch_cfg<true, C, PRE_, true>(p, n_cu, out, aux, st)             \
+                       : launch_cfg<false, C, PRE_, true>(p, n_cu, out, aux, st))           \
+                : (aux ? launch_cfg<true, C, PRE_, false>(p, n_cu, out, aux, st)            \
+                       : launch_cfg<false, C, PRE_, false>(p, n_cu, out, aux, st)))
+#define DDRR_LAUNCH(C) DDRR_LAUNCH_P(C, false)
     // (length-class thresholds: flat within 1.5 % around these, profiles/r03)
     if (variant == DDRR_BRICKS_Q16 || variant == 5) {
         p.t1 = g_brick_t1 * (22.f / 18.f);
@@ -1731,8 +1737,7 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
         case DDRR_BRICKS_Q16:
             // (a few poses: the instantiation whose first claim hides the fingerprint's round trip)
             if (B <= 8)
-                rc = aux ? launch_cfg<true, CfgQ16Z64, true>(p, n_cu, out, aux, st)
-                         : launch_cfg<false, CfgQ16Z64, true>(p, n_cu, out, aux, st);
+                rc = DDRR_LAUNCH_P(CfgQ16Z64, true);
             else
                 rc = DDRR_LAUNCH(CfgQ16Z64);
             break;
@@ -1760,6 +1765,7 @@ int launch_fwd_bricks(int variant, int packed, float *brick_ranges, int ranges_v
         default: return fail(-1, "unknown brick variant");
     }
 #undef DDRR_LAUNCH
+#undef DDRR_LAUNCH_P
     if (rc) return rc;
     return finish(who);
 }

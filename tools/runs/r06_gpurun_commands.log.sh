@@ -83,3 +83,6 @@ python -m pytest tests -m gpu -x -q -k "patch_ncc or metrics" 2>&1 | tail -3; py
 
 # ---------------------------------------------------------------- 2026-10-01T04:38:07Z  r06: patch NCC kernels: tests + bench vs composition (retry)
 python -m pytest tests -m gpu -x -q -k "patch_ncc or metrics" 2>&1 | tail -3; python tools/patch_ncc_bench.py 2>&1 | grep -v amdgpu.ids
+
+# ---------------------------------------------------------------- 2026-10-01T04:45:39Z  r06: A/B mask branch at few poses
+bash tools/_build/ab/ab.sh 2>&1 | grep "==\|few poses\|config ct" | cut -c1-200
