@@ -1055,8 +1055,10 @@ def ct_config(rt, poses=(1, 8, 32), det=200):
     out["module_default_storage"] = {
         "storage": _brick_storage(V, {"storage": drr.renderer.brick_storage}),
         "why": "Siddon.brick_storage = \"q16p\" applies to volumes with >= 4 double bricks per CU; this shape has "
-               "768 (3 per CU), so the module renders it from 32^3 fp32 bricks (`forward_f32` / "
-               "`forward_record_f32` below are what a DRR of this volume runs)"}
+               "768 (3 per CU): the module decides by the poses of the launch from a measured table "
+               "(renderers._FEW_BRICKS_POLICY, profiles/r06/storage_table.txt) -- 16-bit bricks at 8 ... 12 "
+               "poses, fp32 bricks (`forward_f32` / `forward_record_f32`) otherwise",
+        "by_poses": {str(B): _brick_storage(V, {"storage": drr.renderer.brick_storage}, B) for B in poses}}
 
     def timed(fn, n_prime, n_timed):
         for _ in range(n_prime):

@@ -105,6 +105,18 @@ for case in range(a.cases):
             e_q = max(e_q, (oq - ref).abs().max().item() / scale, (op - ref).abs().max().item() / scale)
             giq = ops.siddon_backward_rays(auxq, go, s, t, L)[2]
             e_q = max(e_q, ((giq - gig).abs().max() / (gig.abs().max() + 1e-30)).item())
+        # a subsample through the kernels' pixel mask (every storage, with and without the record):
+        # the drawn pixels as in the unmasked render, exact zeros at the others
+        keep = torch.rand(H * W, generator=g) < (0.1 if case % 2 else 0.5)
+        idx = keep.nonzero().flatten().to(dev)
+        if idx.numel():
+            pm = ops.pixel_mask_of(idx, H * W)
+            for st in ("f32", "q16p"):
+                for aux_ in (False, True):
+                    om, _ = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=aux_, storage=st, pixel_mask=pm)
+                    od, _ = ops.siddon_forward_bricks(V, s, t, L, (H, W), want_aux=aux_, storage=st)
+                    assert float(om[:, ~keep.to(dev)].abs().max()) == 0.0 if (~keep).any() else True
+                    e_q = max(e_q, (om[:, idx] - od[:, idx]).abs().max().item() / scale)
     # mask_to_channels on the bricks against the per-ray channel kernels
     e_c = e_cb = e_cg = e_cv = e_ctv = 0.0
     if min(H, W) >= 2:

@@ -86,3 +86,6 @@ python -m pytest tests -m gpu -x -q -k "patch_ncc or metrics" 2>&1 | tail -3; py
 
 # ---------------------------------------------------------------- 2026-10-01T04:45:39Z  r06: A/B mask branch at few poses
 bash tools/_build/ab/ab.sh 2>&1 | grep "==\|few poses\|config ct" | cut -c1-200
+
+# ---------------------------------------------------------------- 2026-10-01T04:47:50Z  r06: SUB instantiation: tests + bench legs
+python -m pytest tests -m gpu -x -q -k "subsample or patches or brick or headline" 2>&1 | tail -2; python bench.py --gpus 1 --steps 100 --warmup 5 --no-cpu-baseline 2>&1 >/dev/null | grep -v "full record" | grep "config headline\|sparse\|few poses\|config ct\|config 4:" | cut -c1-200
