@@ -511,12 +511,17 @@ class _EulerSiddonNccFn(torch.autograd.Function):
         # gradient arrives as ONE value, which the backward epilogue reads with stride 0; the per-pose
         # values ride along, not differentiable)
         if reduce_sum:
+            # (the per-pose values take no gradient -- and autograd is not to fill one with zeros
+            # for them: one launch per step)
             ctx.mark_non_differentiable(ncc)
+            ctx.set_materialize_grads(False)
             return total, ncc
         return ncc
 
     @staticmethod
     def backward(ctx, g, _g_values=None):
+        if g is None:  # (reduce_sum with nothing flowing back)
+            return (None,) * 11
         rot, xyz, reorient34, P, Ainv, fixed, Mw, source, target, img, aux, stats = ctx.saved_tensors
         g_rot, g_xyz = ops.siddon_ncc_backward_pose(
             aux, img, fixed, stats, g, source, target, Mw, Ainv, P, rot, xyz, ctx.axes, reorient34,

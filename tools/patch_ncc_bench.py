@@ -35,25 +35,31 @@ def unfused(crit):
 
 
 g = torch.Generator().manual_seed(0)
+CASES = (("NCC(patch 13)", lambda: M.NormalizedCrossCorrelation2d(patch_size=13)),
+         ("Multiscale([13, None], [0.5, 0.5])", lambda: M.MultiscaleNormalizedCrossCorrelation2d([13, None], [0.5, 0.5])),
+         ("GradientNCC(patch 9, sigma 1)", lambda: M.GradientNormalizedCrossCorrelation2d(patch_size=9, sigma=1.0)),
+         ("GradientNCC(sigma 1)", lambda: M.GradientNormalizedCrossCorrelation2d(sigma=1.0)))
 for B in (1, 8, 32):
     fixed = (torch.rand(1, 1, 256, 256, generator=g) * 50).to(dev)
     moving = (torch.rand(B, 1, 256, 256, generator=g) * 50).to(dev)
-    for name, crit in (("NCC(patch 13)", M.NormalizedCrossCorrelation2d(patch_size=13)),
-                       ("Multiscale([13, None], [0.5, 0.5])", M.MultiscaleNormalizedCrossCorrelation2d([13, None], [0.5, 0.5])),
-                       ("GradientNCC(patch 9, sigma 1)", M.GradientNormalizedCrossCorrelation2d(patch_size=9, sigma=1.0)),
-                       ("GradientNCC(sigma 1)", M.GradientNormalizedCrossCorrelation2d(sigma=1.0))):
-        res = []
-        for c in (crit, unfused(crit)):
+    rows = {}
+    # (every fused criterion first, then the compositions: those leave gigabytes in the caching allocator)
+    for which in ("fused", "composition"):
+        for name, make in CASES:
+            c = make() if which == "fused" else unfused(make())
             x = moving.clone().requires_grad_()
 
             def fn():
                 x.grad = None
                 c(fixed.expand(B, -1, -1, -1), x).sum().backward()
             try:
-                res.append(timed(fn))
-                vals = c(fixed.expand(B, -1, -1, -1), x).detach()
+                ms = timed(fn)
+                vals = c(fixed.expand(B, -1, -1, -1), x).detach()[:2].tolist()
             except torch.OutOfMemoryError:
-                res.append(float("nan"))
-            res.append(vals[:2].tolist())
-        print(f"B = {B:2d}  {name:38s} fused {res[0]:8.3f} ms   composition {res[2]:8.3f} ms   "
-              f"values {res[1]} / {res[3]}", flush=True)
+                ms, vals = float("nan"), None
+            rows.setdefault(name, {})[which] = (ms, vals)
+            del x
+        torch.cuda.empty_cache()
+    for name, r in rows.items():
+        print(f"B = {B:2d}  {name:38s} fused {r['fused'][0]:8.3f} ms   composition {r['composition'][0]:8.3f} ms   "
+              f"values {r['fused'][1]} / {r['composition'][1]}", flush=True)

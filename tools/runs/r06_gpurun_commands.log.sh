@@ -89,3 +89,12 @@ bash tools/_build/ab/ab.sh 2>&1 | grep "==\|few poses\|config ct" | cut -c1-200
 
 # ---------------------------------------------------------------- 2026-10-01T04:47:50Z  r06: SUB instantiation: tests + bench legs
 python -m pytest tests -m gpu -x -q -k "subsample or patches or brick or headline" 2>&1 | tail -2; python bench.py --gpus 1 --steps 100 --warmup 5 --no-cpu-baseline 2>&1 >/dev/null | grep -v "full record" | grep "config headline\|sparse\|few poses\|config ct\|config 4:" | cut -c1-200
+
+# ---------------------------------------------------------------- 2026-10-01T04:51:46Z  r06: full GPU suite with printouts
+mkdir -p gpurun_out/r06g; python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^$" > gpurun_out/r06g/gpu_suite_full.txt; tail -3 gpurun_out/r06g/gpu_suite_full.txt; grep -c "^\[" gpurun_out/r06g/gpu_suite_full.txt; python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r06g/smoke.txt 2>&1; tail -3 gpurun_out/r06g/smoke.txt
+
+# ---------------------------------------------------------------- 2026-10-01T04:55:02Z  r06: evidence: rocprof + PMC of the bench, driver command, configs, tools
+mkdir -p gpurun_out/r06h; tools/prof_bench.sh gpurun_out/r06prof > gpurun_out/r06h/rocprof_bench.txt 2>&1; python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06h/bench_line_driver_command.json 2> gpurun_out/r06h/bench_stderr_driver_command.txt; cp bench_full.json gpurun_out/r06h/bench_full_driver_command.json; python bench.py > gpurun_out/r06h/bench_line_default.json 2> gpurun_out/r06h/bench_stderr_default.txt; cp bench_full.json gpurun_out/r06h/bench_full.json; for c in 2 3 4 5; do python bench.py --config $c > gpurun_out/r06h/bench_line_config_$c.json 2>/dev/null; cp bench_full.json gpurun_out/r06h/bench_config_$c.json; done; python tools/sparse_levers_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06h/sparse.txt; python tools/patch_ncc_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06h/patch_ncc.txt; python tools/fuzz_bricks.py --cases 64 2>&1 | grep -v amdgpu.ids > gpurun_out/r06h/fuzz_bricks.txt; tail -2 gpurun_out/r06h/fuzz_bricks.txt | cut -c1-300; head -20 gpurun_out/r06h/rocprof_bench.txt | cut -c1-200; wc -c gpurun_out/r06h/bench_line_*.json
+
+# ---------------------------------------------------------------- 2026-10-01T04:59:13Z  r06: multiscale 32-pose slowness probe
+python tools/_ms_probe.py 2>&1 | grep -v amdgpu.ids | cut -c1-200
