@@ -1423,6 +1423,8 @@ def compact_line(full, limit=LINE_LIMIT):
             if "registration" in c:
                 e["registration"] = _pick(c["registration"], "hip_graph", "ncc_after", "iterations",
                                           "rot_error_rad", "xyz_error_mm")
+        if isinstance(c, dict) and "error" in c:
+            e = {"error": _cap(c["error"], 120)}
         configs[name] = e
     if configs:
         line["configs"] = configs
@@ -1508,41 +1510,59 @@ def main():
         # with their parity; N > 1: the sweep only (config 5 -- 4096 poses over the N ranks, the
         # informative strong-scaling curve; the headline above is N independent 32-pose steps).
         configs = {}
-        for cfg in (("2", "3", "4", "5") if rt.world == 1 and plain_headline else ("5",)):
+
+        def guarded(name, fn):
+            """One GPU: a side run that fails must not cost the driver its headline line (the failure is
+            recorded in its place and on stderr).  Several ranks: exceptions propagate -- a rank that
+            skipped a collective would hang the others."""
             t0 = time.perf_counter()
-            res = run_config(cfg, args, rt, short=True)
+            if rt.world > 1:
+                out = fn()
+            else:
+                try:
+                    out = fn()
+                except Exception as exc:  # noqa: BLE001
+                    import traceback
+
+                    log(f"[bench] configs.{name} FAILED: {type(exc).__name__}: {exc}\n{traceback.format_exc()}")
+                    out = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            if isinstance(out, dict):
+                out["wall_s"] = time.perf_counter() - t0
+            return out
+
+        for cfg in (("2", "3", "4", "5") if rt.world == 1 and plain_headline else ("5",)):
+            res = guarded(cfg, lambda: summary_of(run_config(cfg, args, rt, short=True)) if rt.rank == 0 or rt.world == 1
+                          else run_config(cfg, args, rt, short=True))
             if rt.rank == 0:
-                configs[cfg] = summary_of(res)
-                configs[cfg]["wall_s"] = time.perf_counter() - t0
+                configs[cfg] = res
         if rt.world == 1 and plain_headline:
             # SURVEY 8(d): config 3 also at B = 4 (timing only; the parity block above is B = 1's)
-            res = run_config("3", args, rt, short=True, batch=4, parity=False)
-            configs["3"]["b4"] = {k: res[k] for k in ("value", "unit", "ms_per_step", "steps")}
-            configs["3"]["b4"]["kernels"] = res["roofline"]["kernels"]
-            t0 = time.perf_counter()
-            configs["ct"] = ct_config(rt)
-            configs["ct"]["wall_s"] = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            configs["few_poses"] = few_poses_config(rt)
-            configs["few_poses"]["wall_s"] = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            configs["sparse"] = sparse_config(rt)
-            configs["sparse"]["wall_s"] = time.perf_counter() - t0
-        if rt.rank == 0:
+            def b4():
+                res = run_config("3", args, rt, short=True, batch=4, parity=False)
+                out = {k: res[k] for k in ("value", "unit", "ms_per_step", "steps")}
+                out["kernels"] = res["roofline"]["kernels"]
+                return out
+            if "error" not in configs["3"]:
+                configs["3"]["b4"] = guarded("3.b4", b4)
+            configs["ct"] = guarded("ct", lambda: ct_config(rt))
+            configs["few_poses"] = guarded("few_poses", lambda: few_poses_config(rt))
+            configs["sparse"] = guarded("sparse", lambda: sparse_config(rt))
+        if rt.rank == 0 and "error" not in configs["5"]:
             c5 = configs["5"]
             result["sweep"] = {"metric": c5["metric"], "value": c5["value"], "unit": c5["unit"],
                                "n_gpus": rt.world, "scaling": "strong", "ms_per_step": c5["ms_per_step"],
                                "steps": c5["steps"], "poses": args.sweep_poses or 4096, "poses_per_launch": 512,
                                "what": "bench.py --config 5, short: the candidate sweep of BASELINE "
                                        "configs[4], pose-sharded over the ranks"}
-            if rt.world == 1 and plain_headline:
-                result["configs"] = configs
+            if rt.world == 1 and plain_headline and c5.get("forward"):
                 # the north star's figure at the batch size it is met at: 512 poses per launch
                 fs = dict(c5["forward"])
                 fs["parity"] = c5["parity"]
                 fs["what"] = ("the forward-only kernel on 512 of config 5's candidate poses per launch "
                               "(the sweep's launch size), same volume and detector as the headline")
                 result["roofline"]["forward_sweep"] = fs
+        if rt.rank == 0 and rt.world == 1 and plain_headline:
+            result["configs"] = configs
     if rt.rank == 0:
         result["rccl_ranks"] = rt.rccl_ranks  # (ranks counted by an all_reduce of ones on the devices)
         result["devices_visible"] = torch.cuda.device_count() if rt.on_gpu else 0
