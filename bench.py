@@ -556,8 +556,14 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
         try:
             if not on_gpu:
                 raise RuntimeError("no HIP graphs on the cpu harness")
-            graphed = GraphedIteration(reg, ncc, opt, gt)
-            extra["registration"] = {"hip_graph": True}
+            crit = ncc
+            if args.criterion != "ncc":
+                from diffdrr_amd.metrics import (GradientNormalizedCrossCorrelation2d,
+                                                 MultiscaleNormalizedCrossCorrelation2d)
+                crit = (MultiscaleNormalizedCrossCorrelation2d([13, None], [0.5, 0.5]) if args.criterion == "multiscale"
+                        else GradientNormalizedCrossCorrelation2d(patch_size=9, sigma=1.0))
+            graphed = GraphedIteration(reg, crit, opt, gt)
+            extra["registration"] = {"hip_graph": True, "criterion": args.criterion}
         except Exception as exc:  # noqa: BLE001
             log(f"[bench] config 4: eager loop ({type(exc).__name__}: {exc})")
             graphed = None
@@ -1470,6 +1476,11 @@ def main():
                     help="DRR.FUSED_NCC_MAX_POSES for this run (measurement: where the fused step stops paying)")
     ap.add_argument("--torch-adam", action="store_true",
                     help="config 4: torch.optim.Adam(fused, capturable) instead of diffdrr_amd.PoseAdam")
+    ap.add_argument("--criterion", default="ncc", choices=["ncc", "multiscale", "gradient"],
+                    help="config 4: the similarity of the registration loop -- NormalizedCrossCorrelation2d (the fused "
+                         "step), MultiscaleNormalizedCrossCorrelation2d([13, None], [0.5, 0.5]) (metrics.ipynb:94) or "
+                         "GradientNormalizedCrossCorrelation2d(patch_size=9, sigma=1): composed from the renderer and "
+                         "the metric kernels inside the same HIP graph")
     ap.add_argument("--packed-record", action="store_true",
                     help="Siddon.packed_record = True (the opt-in fixed-point backward record)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],

@@ -98,3 +98,7 @@ mkdir -p gpurun_out/r06h; tools/prof_bench.sh gpurun_out/r06prof > gpurun_out/r0
 
 # ---------------------------------------------------------------- 2026-10-01T04:59:13Z  r06: multiscale 32-pose slowness probe
 python tools/_ms_probe.py 2>&1 | grep -v amdgpu.ids | cut -c1-200
+
+# ---------------------------------------------------------------- 2026-10-01T05:05:29Z  r06: registration loop with multiscale / gradient NCC in the graph
+for c in ncc multiscale gradient; do echo == $c; python bench.py --config 4 --criterion $c --no-cpu-baseline 2>&1 >/dev/null | grep -v "full record" | grep "config 4" | cut -c1-120; python -c "
+import json; d=json.load(open(\"bench_full.json\")); print(d[\"value\"], d[\"registration\"])"; done
