@@ -244,8 +244,10 @@ class DRR(nn.Module):
         row-major affine grid, which is what the volume-stationary kernels take -- and gathered."""
         det = self.detector
         H, W = det.height, det.width
-        key = (H, W, self.patch_size, id(det), None if det.n_subsample is None else len(det.subsamples))
-        plan = getattr(self, "_sparse_plan_cache", None)
+        # (cached ON the detector: a new detector -- set_intrinsics_ -- starts without a plan, whatever
+        # address it is given)
+        key = (H, W, self.patch_size, None if det.n_subsample is None else len(det.subsamples))
+        plan = getattr(det, "_sparse_plan_cache", None)
         if plan is not None and plan[0] == key and plan[2] == det.target.device:
             return plan[1]
         idx = det.subsample_index()
@@ -270,7 +272,7 @@ class DRR(nn.Module):
                 torch.arange(a - r0 * W, b - r0 * W, device=det.target.device) if host is None
                 else idx[a:b] - r0 * W)
             chunks.append((r0, r1 - r0 + 1, local, None if host is None else idx[a:b], (a, b)))
-        self._sparse_plan_cache = (key, chunks, det.target.device)
+        det._sparse_plan_cache = (key, chunks, det.target.device)
         return chunks
 
     def _render_sparse(self, Mw, P, Ainv, mask, **kwargs):
