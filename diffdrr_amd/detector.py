@@ -111,10 +111,9 @@ class Detector(torch.nn.Module):
         reference's -- but cached per device."""
         if self.n_subsample is None:
             return self.target
-        dev = self.target.device
         cached = getattr(self, "_full_target", None)
-        if cached is None or cached.device != dev:
-            cached = self._unit_grid().to(dev)
+        if cached is None or cached.device != self.target.device or cached.dtype != self.target.dtype:
+            cached = self._unit_grid().to(self.target)  # (device and dtype of the module)
             self._full_target = cached
         return cached
 
