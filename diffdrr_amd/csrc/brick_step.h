@@ -512,6 +512,14 @@ DDRR_HD float pack_voxel_label_below(float v, unsigned lab, unsigned n_channels)
 // (the selects only compare alphas; the lengths are their differences), so that a flush is the
 // address and the atomic alone.  16 + 3 vector instructions per step; the flush -- a divergent
 // block whenever ANY lane of the wave changes label -- adds 4.
+// A flush functor that can hand a run over UNDER AN EXEC MASK inside the step -- no branch around a
+// divergent block whenever any lane of the wave changes label -- says so with a member
+// `masked(lab, cur, run) -> run'` (device only; bricks.hip BrickColumnFlush).
+template <class F, class = void>
+struct has_masked_flush { static constexpr bool value = false; };
+template <class F>
+struct has_masked_flush<F, decltype(void(F::kMaskedFlush))> { static constexpr bool value = F::kMaskedFlush; };
+
 template <class Fetch, class Flush>
 DDRR_HD void step_walk_channels(const Fetch &fetch, const StepGeom &G, const StepEntry &E,
                                 const Flush &flush, float scale = 1.f) {
@@ -545,7 +553,10 @@ DDRR_HD void step_walk_channels(const Fetch &fetch, const StepGeom &G, const Ste
         an1 = fmaf(t1, st1, an1);                                                         \
         an2 = fmaf(t2, st2, an2);                                                         \
         const unsigned w = float_bits(Vc), lab = w & 0xffu;                               \
-        if (lab != cur) {                                                                 \
+        if constexpr (has_masked_flush<Flush>::value) {                                   \
+            run = flush.masked(lab, cur, run);                                            \
+            cur = lab;                                                                    \
+        } else if (lab != cur) {                                                          \
             flush(cur, run);                                                              \
             run = 0.f;                                                                    \
             cur = lab;                                                                    \

@@ -175,6 +175,31 @@ struct BrickColumnFlush {
                             SCALED ? L * run : run);
         }
     }
+#if !defined(DDRR_CHANNELS_BRANCHY_FLUSH)
+    // The flush of a label change inside the step, branch-free ("lanes whose label
+    // changed flush under an exec mask in the step's own iteration"): compare, narrow the exec mask to
+    // the lanes that changed, one multiply-add for the address, the fire-and-forget atomic, restore
+    // -- five instructions every step instead of a divergent block with its own branch whenever ANY
+    // lane of the wave changes label (most steps, on a real label map).  -> the run to go on with
+    // (0 where it was handed over).  Unscaled, unchecked flushes only (the Siddon channel render).
+    static constexpr bool kMaskedFlush = !SCALED && !CHECKED;
+    __device__ __forceinline__ float masked(unsigned lab, unsigned cur, float run) const {
+        unsigned long long saved;
+        unsigned off;
+        float next;
+        asm volatile(
+            "v_cmp_ne_u32_e32 vcc, %[lab], %[cur]\n\t"
+            "s_and_saveexec_b64 %[sv], vcc\n\t"
+            "v_mad_u32_u24 %[off], %[cur], %[n4], %[colb]\n\t"
+            "global_atomic_add_f32 %[off], %[run], %[base]\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            "v_cndmask_b32_e64 %[next], %[run], 0, vcc"
+            : [sv] "=&s"(saved), [off] "=&v"(off), [next] "=&v"(next)
+            : [lab] "v"(lab), [cur] "v"(cur), [n4] "v"(N4), [colb] "v"(colb), [run] "v"(run), [base] "s"(out)
+            : "vcc", "memory");
+        return next;
+    }
+#endif
 };
 
 // The incoming gradient of the ray's own output column, by label (BRICK_CHANNELS_AUX): a gather

@@ -102,3 +102,6 @@ python tools/_ms_probe.py 2>&1 | grep -v amdgpu.ids | cut -c1-200
 # ---------------------------------------------------------------- 2026-10-01T05:05:29Z  r06: registration loop with multiscale / gradient NCC in the graph
 for c in ncc multiscale gradient; do echo == $c; python bench.py --config 4 --criterion $c --no-cpu-baseline 2>&1 >/dev/null | grep -v "full record" | grep "config 4" | cut -c1-120; python -c "
 import json; d=json.load(open(\"bench_full.json\")); print(d[\"value\"], d[\"registration\"])"; done
+
+# ---------------------------------------------------------------- 2026-10-01T05:09:21Z  r06: channel render vs plain on the final tree
+python tools/channels_fwd_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-220
