@@ -175,13 +175,16 @@ struct BrickColumnFlush {
                             SCALED ? L * run : run);
         }
     }
-#if !defined(DDRR_CHANNELS_BRANCHY_FLUSH)
-    // The flush of a label change inside the step, branch-free ("lanes whose label
-    // changed flush under an exec mask in the step's own iteration"): compare, narrow the exec mask to
-    // the lanes that changed, one multiply-add for the address, the fire-and-forget atomic, restore
-    // -- five instructions every step instead of a divergent block with its own branch whenever ANY
-    // lane of the wave changes label (most steps, on a real label map).  -> the run to go on with
-    // (0 where it was handed over).  Unscaled, unchecked flushes only (the Siddon channel render).
+#if defined(DDRR_CHANNELS_MASKED_FLUSH)
+    // EXPERIMENT, measured and not adopted (tools builds with -DDDRR_CHANNELS_MASKED_FLUSH;
+    // profiles/r06/channel_masked_flush_experiment.txt).  The flush of a label change inside the step,
+    // branch-free ("lanes whose label changed flush under an exec mask in the step's
+    // own iteration"): compare, narrow the exec mask to the lanes that changed, one multiply-add for
+    // the address, the fire-and-forget atomic, restore -- six instructions EVERY step instead of a
+    // divergent block behind a branch whenever any lane of the wave changes label.  1.5 % slower on
+    // the reference's label map (0.281 against 0.276 ms at 8 poses), 1.6 % on synthetic blocks: the
+    // branch is not what the flush costs.  -> the run to go on with (0 where it was handed over).
+    // Unscaled, unchecked flushes only (the Siddon channel render).
     static constexpr bool kMaskedFlush = !SCALED && !CHECKED;
     __device__ __forceinline__ float masked(unsigned lab, unsigned cur, float run) const {
         unsigned long long saved;

@@ -105,3 +105,6 @@ import json; d=json.load(open(\"bench_full.json\")); print(d[\"value\"], d[\"reg
 
 # ---------------------------------------------------------------- 2026-10-01T05:09:21Z  r06: channel render vs plain on the final tree
 python tools/channels_fwd_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-220
+
+# ---------------------------------------------------------------- 2026-10-01T05:13:11Z  r06: masked channel flush: tests + channels bench
+python -m pytest tests -m gpu -x -q -k "channel or mask" 2>&1 | tail -2; python tools/channels_fwd_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-90; python tools/fuzz_bricks.py --cases 24 2>&1 | tail -1 | cut -c1-300
