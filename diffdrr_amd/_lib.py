@@ -43,6 +43,9 @@ _SIGNATURES = {
                                      _I, _I, _I, _P, _P],
     "ddrr_siddon_forward_channels_bricks": [_P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _F,
                                             _P, _P, _P],
+    "ddrr_channel_words": [_P, _P, _L, _I, _P, _P, _I, _P],
+    "ddrr_siddon_forward_channels_bricks_words": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _F,
+                                                  _P, _P, _P],
     "ddrr_siddon_backward_channels_bricks": [_P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _F,
                                              _P, _P, _P],
     "ddrr_siddon_backward_channels_volume_bricks": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _F,
@@ -113,6 +116,7 @@ _SIGNATURES = {
                                        _P, _I, _I, _I, _P, _P],
     "ddrr_trilinear_samples_general_backward": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _D,
                                                 _D, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
+    "ddrr_channel_words_state_bytes": [],
     "ddrr_brick_workspace_bytes": [_I, _I, _I, _I],
     "ddrr_brick_launch_workspace_bytes": [_I, _I, _I],
     "ddrr_trilinear_forward_channels_bricks": [_P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _F,
@@ -120,7 +124,7 @@ _SIGNATURES = {
 }
 # (entries that return a size, not a status)
 _RESTYPES = {"ddrr_brick_workspace_bytes": c_long, "ddrr_brick_launch_workspace_bytes": c_long,
-             "ddrr_siddon_ncc_workspace_bytes": c_long}
+             "ddrr_siddon_ncc_workspace_bytes": c_long, "ddrr_channel_words_state_bytes": c_long}
 EXPORTS = ["ddrr_abi_version", "ddrr_last_error", *_SIGNATURES]
 
 

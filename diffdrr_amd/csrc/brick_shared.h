@@ -120,6 +120,7 @@ constexpr int BRICK_TRI_CHANNELS = 7; // trilinear marcher, out (B, C, N): sampl
 constexpr int BRICK_CHANNELS_AUX = 8; // backward of BRICK_CHANNELS w.r.t. the rays: the record of the volume weighted by grad_out[b, label, n]
 constexpr int BRICK_TRI_CHANNELS_AUX = 9;  // backward of BRICK_TRI_CHANNELS w.r.t. the rays: the marcher's record weighted by grad_out[b, label, n]
 constexpr int BRICK_CHANNELS_VOLGRAD = 10;  // backward of BRICK_CHANNELS w.r.t. the volume: the LDS accumulator's words carry the voxel's label in their low byte
+constexpr int BRICK_CHANNELS_WORDS = 12;  // BRICK_CHANNELS from a volume of ready-packed words (value | label): staged like a plain brick
 constexpr int BRICK_TRI_CHANNELS_VOLGRAD = 11;  // the same for the marcher (owner bricks; labels outside the owned box from the label map)
 
 

@@ -405,7 +405,7 @@ __device__ __forceinline__ void brick_item(const BrickArgs &p, const float *bric
     DDRR_PROF(PROF_LOADS);
     const StepEntry E = step_enter(SG, s, t, p.shift, p.eps, LdsAbsFetch::base_of(brick));
     DDRR_PROF(PROF_SETUP);
-    if (MODE == BRICK_CHANNELS) {
+    if (MODE == BRICK_CHANNELS || MODE == BRICK_CHANNELS_WORDS) {
         const unsigned N = (unsigned)(p.det_h * p.det_w), C = (unsigned)p.n_channels;
         unsigned n4 = N * 4u;
         asm volatile("" : "+v"(n4));  // (in a vector register before the loop, not moved there per flush)
@@ -1189,7 +1189,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     {
         std::lock_guard<std::mutex> lock(mu);
         if (!attr_set[dev]) {
-            const void *fns[12] = {
+            const void *fns[13] = {
+                reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_CHANNELS_WORDS>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_CHANNELS_VOLGRAD>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_CHANNELS_VOLGRAD>),
                 reinterpret_cast<const void *>(&siddon_brick_kernel<BRICK_TRI_CHANNELS_AUX>),
@@ -1231,7 +1232,7 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
     // the Siddon modes hand their bricks out heaviest first like the forward kernels (the marcher's
     // bricks are cells + halo with their own boxes: id order)
     if (mode == BRICK_FWD || mode == BRICK_FWD_AUX || mode == BRICK_VOLGRAD || mode == BRICK_CHANNELS ||
-        mode == BRICK_CHANNELS_AUX || mode == BRICK_CHANNELS_VOLGRAD)
+        mode == BRICK_CHANNELS_WORDS || mode == BRICK_CHANNELS_AUX || mode == BRICK_CHANNELS_VOLGRAD)
         order_bricks(p, BRICK, BRICK, BRICK, bg.ny, bg.nz, n_bricks, n_cu_dev, st);
     // (the marcher's volume gradient: owner bricks = the plain grid; a brick's walks are long
     // whatever the pose count)
@@ -1251,6 +1252,8 @@ int launch_bricks(int mode, const float *volume, int dx, int dy, int dz, const f
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_FWD_AUX>, grid, block, lds, st, p, out, aux);
     else if (mode == BRICK_CHANNELS)
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_CHANNELS>, grid, block, lds, st, p, out, aux);
+    else if (mode == BRICK_CHANNELS_WORDS)
+        hipLaunchKernelGGL(siddon_brick_kernel<BRICK_CHANNELS_WORDS>, grid, block, lds, st, p, out, aux);
     else if (mode == BRICK_CHANNELS_AUX)
         hipLaunchKernelGGL(siddon_brick_kernel<BRICK_CHANNELS_AUX>, grid, block, lds, st, p, out, aux);
     else if (mode == BRICK_TRI_CHANNELS)
@@ -1420,6 +1423,86 @@ int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char
     return launch_bricks(BRICK_CHANNELS, volume, dx, dy, dz, source, target, img, nullptr, B, det_h,
                          det_w, voxel_shift, eps, out, nullptr, nullptr, st, launch_ws,
                          "ddrr_siddon_forward_channels_bricks", 0, nullptr, nullptr, 0.f, labels, C);
+}
+
+// The channel render's staged words -- value rounded to a 16-bit mantissa | label, labels without a
+// channel as the value 0 under label 0 (brick_step.h pack_voxel_label_below) -- for a whole volume at
+// once: what ddrr_siddon_forward_channels_bricks_words stages with straight 16-byte copies.
+// Launched in front of EVERY render from the words, and self-healing: every workgroup first compares
+// the fingerprint the last repack left (brick_core.h kFingerprintWords voxels: the volume's bits and
+// the label bytes) with the live volume and label map; unchanged -> the launch ends (a few
+// microseconds); changed -- an edit the caller's bookkeeping cannot see (PyTorch:
+// `volume.data[...] = x`) --, or `force` -> the words are packed again, and the last workgroup to
+// finish (a ticket) leaves the new fingerprint.  state: [0] ticket, [1] repacks so far (both int),
+// then 2 x kFingerprintWords words.
+constexpr int kChannelWordsStateWords = 2 + 2 * kFingerprintWords;
+
+__global__ __launch_bounds__(kBlock) void channel_words_kernel(const float *__restrict__ vol,
+                                                               const unsigned char *__restrict__ labels, long n,
+                                                               unsigned n_channels, float *__restrict__ words,
+                                                               int *__restrict__ state, int force) {
+    __shared__ int last;
+    unsigned *fp = reinterpret_cast<unsigned *>(state + 2);
+    int bad = force;
+    for (int i = threadIdx.x; i < kFingerprintWords; i += kBlock) {
+        const long at = fingerprint_index(i, n);
+        bad |= (__float_as_uint(vol[at]) != fp[i]) | ((unsigned)labels[at] != fp[kFingerprintWords + i]);
+    }
+    const bool stale = __syncthreads_or(bad) != 0;
+    if (stale) {
+        const long stride = (long)gridDim.x * kBlock;
+        for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+            words[i] = pack_voxel_label_below(vol[i], labels[i], n_channels);
+    }
+    // (the fingerprint is only rewritten once every workgroup has compared with the old one)
+    if (threadIdx.x == 0) last = atomicAdd(state, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    if (stale) {
+        for (int i = threadIdx.x; i < kFingerprintWords; i += kBlock) {
+            const long at = fingerprint_index(i, n);
+            fp[i] = __float_as_uint(vol[at]);
+            fp[kFingerprintWords + i] = (unsigned)labels[at];
+        }
+    }
+    if (threadIdx.x == 0) {
+        state[0] = 0;
+        if (stale) state[1] += 1;
+    }
+}
+
+long ddrr_channel_words_state_bytes(void) { return (long)kChannelWordsStateWords * 4; }
+
+int ddrr_channel_words(const float *volume, const unsigned char *labels, long n_voxels, int C, float *words,
+                       void *state, int force, void *stream) {
+    if (!volume || !labels || !words || !state || C < 1 || n_voxels < 0)
+        return fail(-1, "null pointer or C < 1");
+    if (n_voxels == 0) return 0;
+    const long blocks = (n_voxels + 4L * kBlock - 1) / (4L * kBlock);
+    hipLaunchKernelGGL(channel_words_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(kBlock), 0,
+                       (hipStream_t)stream, volume, labels, n_voxels, (unsigned)C, words,
+                       reinterpret_cast<int *>(state), force ? 1 : 0);
+    return finish("ddrr_channel_words");
+}
+
+int ddrr_siddon_forward_channels_bricks_words(const float *words, int dx, int dy, int dz, const float *source,
+                                              const float *target, const float *img, int B, int det_h,
+                                              int det_w, int C, float voxel_shift, float eps, float *out,
+                                              void *launch_ws, void *stream) {
+    const int N = det_h * det_w;
+    if (int rc = check_common(words, dx, dy, dz, source, 1, target, B, N)) return rc;
+    if (!out || C < 1) return fail(-1, "null out or C < 1");
+    if (det_h < 2 || det_w < 2) return fail(-1, "the brick path needs a detector of at least 2x2");
+    if ((long)B * C * N >= (1L << 30) || N >= (1 << 22))
+        return fail(-1, "B * C * N must stay below 2^30 (and N below 2^22) for one channel launch "
+                        "on the bricks: split the pose batch or use ddrr_siddon_forward_channels");
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C * N, st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+    return launch_bricks(BRICK_CHANNELS_WORDS, words, dx, dy, dz, source, target, img, nullptr, B, det_h,
+                         det_w, voxel_shift, eps, out, nullptr, nullptr, st, launch_ws,
+                         "ddrr_siddon_forward_channels_bricks_words", 0, nullptr, nullptr, 0.f, nullptr, C);
 }
 
 int ddrr_siddon_backward_channels_bricks(const float *volume, const unsigned char *labels, int dx,

@@ -758,10 +758,70 @@ def siddon_forward_channels(volume, labels_u8, n_channels, source, target, img, 
     return out
 
 
+_words_cache = {}  # (id(volume), id(labels), C) -> _ChannelWords
+
+
+class _ChannelWords:
+    """Cache entry of :func:`channel_words`."""
+    __slots__ = ("vol", "lab", "tracked", "words", "state", "seen")
+
+    def __init__(self, vol, lab):
+        self.vol, self.lab = vol, lab   # weak references
+        self.tracked = None             # what PyTorch tracks of the pair when the words were last packed
+        self.words = self.state = None
+        self.seen = 0                   # renders of this pair in this tracked state
+
+
+def channel_words(volume, labels_u8, n_channels, build=True):
+    """The channel render's staged words (value with a 16-bit mantissa | label) for the whole volume,
+    one float per voxel, for a (volume, label map) pair that is rendered again and again:
+    :func:`siddon_forward_channels_bricks` then stages a brick with straight 16-byte copies -- no label
+    loads, no packing (one pose 0.088 -> 0.071 ms, 8 poses 0.279 -> 0.254 on the reference's example
+    shape and label map).  Cached per (volume tensor, label tensor, channels) while both live;
+    +100 % of the volume's bytes.  EVERY call launches ``ddrr_channel_words``: it compares a
+    fingerprint of volume and labels on the device (1024 voxels each) and returns after a few
+    microseconds if nothing changed; a change PyTorch tracks (version counters, storage addresses)
+    forces the repack, one it does not (``volume.data[...] = x``) is found by the fingerprint.
+    ``build=False``: None unless the pair has been seen before in its present state (the first render
+    of a pair does not pay for a pass it may never use)."""
+    key = (id(volume), id(labels_u8), int(n_channels))
+    tracked = (volume._version, labels_u8._version, volume.data_ptr(), labels_u8.data_ptr())
+    ent = _words_cache.get(key)
+    if ent is None or ent.vol() is not volume or ent.lab() is not labels_u8:
+        drop = lambda _, k=key: _words_cache.pop(k, None)  # noqa: E731
+        ent = _words_cache[key] = _ChannelWords(weakref.ref(volume, drop), weakref.ref(labels_u8, drop))
+    if not build:
+        if ent.words is None:
+            ent.seen = ent.seen + 1 if ent.tracked == tracked else 1
+            ent.tracked = tracked
+            if ent.seen < 2:
+                return None
+    force = ent.words is None or ent.tracked != tracked
+    if ent.words is None:
+        ent.words = torch.empty_like(volume)
+        n = int(_query("ddrr_channel_words_state_bytes"))
+        ent.state = torch.zeros((n + 3) // 4, dtype=torch.int32, device=volume.device)
+    ent.tracked = tracked
+    if volume.numel():
+        _launch("ddrr_channel_words", volume.device, volume.data_ptr(), labels_u8.data_ptr(), volume.numel(),
+                int(n_channels), ent.words.data_ptr(), ent.state.data_ptr(), int(force))
+    return ent.words
+
+
+def channel_words_repacks(volume, labels_u8, n_channels):
+    """How often the words of this pair were packed (1 after the first build; +1 for every change found
+    by the tracked state or by the device-side fingerprint), or None.  Reads a word from the device."""
+    ent = _words_cache.get((id(volume), id(labels_u8), int(n_channels)))
+    if ent is None or ent.state is None or ent.vol() is not volume:
+        return None
+    return int(ent.state[1].item())
+
+
 def siddon_forward_channels_bricks(volume, labels_u8, n_channels, source, target, img, det, *,
-                                   voxel_shift=0.5, eps=1e-8):
+                                   voxel_shift=0.5, eps=1e-8, words=None):
     """:func:`siddon_forward_channels` for a detector grid on the volume-stationary brick
-    kernel (the label rides in the low byte of the staged voxel word).  -> (B, C, N)"""
+    kernel (the label rides in the low byte of the staged voxel word).  ``words``: the volume's
+    ready-packed words (:func:`channel_words`) -- staged as they are.  -> (B, C, N)"""
     B, N = _check_rays(volume, source, target, img)
     H, W = int(det[0]), int(det[1])
     if H * W != N or source.shape[1] != 1 or min(H, W) < 2:
@@ -774,6 +834,13 @@ def siddon_forward_channels_bricks(volume, labels_u8, n_channels, source, target
     labels_u8, volume = labels_u8.contiguous(), volume.contiguous()
     source, target = source.contiguous(), target.contiguous()
     img = None if img is None else img.contiguous()
+    if words is not None:
+        if words.shape != volume.shape or words.dtype != torch.float32 or not words.is_contiguous():
+            raise ValueError("words: channel_words(volume, labels, n_channels)")
+        _launch("ddrr_siddon_forward_channels_bricks_words", volume.device, words.data_ptr(), *volume.shape,
+                source.data_ptr(), target.data_ptr(), _ptr(img), B, H, W, int(n_channels), float(voxel_shift),
+                float(eps), out.data_ptr(), launch_workspace(volume.shape, volume.device).data_ptr())
+        return out
     _launch("ddrr_siddon_forward_channels_bricks", volume.device, volume.data_ptr(),
             labels_u8.data_ptr(), *volume.shape, source.data_ptr(), target.data_ptr(), _ptr(img),
             B, H, W, int(n_channels), float(voxel_shift), float(eps), out.data_ptr(),

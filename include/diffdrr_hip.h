@@ -226,6 +226,24 @@ int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char
                                         const float *img, int B, int det_h, int det_w, int C,
                                         float voxel_shift, float eps, float *out, void *launch_ws,
                                         void *stream);
+/* The same render from a volume of READY-PACKED words (ABI 31): ddrr_channel_words writes, for every
+ * voxel, the word the channel kernel stages -- the value rounded to a 16-bit mantissa in the upper 24
+ * bits, the label in the low byte, labels >= C as the value 0 under label 0 -- into `words` (n_voxels
+ * floats); ddrr_siddon_forward_channels_bricks_words then stages a brick with straight 16-byte copies
+ * (no label loads, no packing): for a (volume, label map) pair that is rendered many times.
+ * Call ddrr_channel_words in front of EVERY such render: it compares a fingerprint of volume and
+ * labels (1024 voxels each, kept in `state`) and ends after a few microseconds if nothing changed;
+ * if something did -- or with force != 0: the first call, or a change the caller knows of -- it packs
+ * the words again.  state: ddrr_channel_words_state_bytes() bytes, 4-byte aligned, caller-owned, ZERO
+ * when first handed over (int32 word 1 counts the repacks).  Same result as
+ * ddrr_siddon_forward_channels_bricks. */
+long ddrr_channel_words_state_bytes(void);
+int ddrr_channel_words(const float *volume, const unsigned char *labels, long n_voxels, int C, float *words,
+                       void *state, int force, void *stream);
+int ddrr_siddon_forward_channels_bricks_words(const float *words, int dx, int dy, int dz, const float *source,
+                                              const float *target, const float *img, int B, int det_h,
+                                              int det_w, int C, float voxel_shift, float eps, float *out,
+                                              void *launch_ws, void *stream);
 
 /* Backward of the channel render w.r.t. the RAYS for the DRR case, on the volume-stationary
  * bricks (replaces ScatterAddBackward . SortBackward of renderers.py:77-89 for source / target /

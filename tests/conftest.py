@@ -1029,3 +1029,53 @@ def check_patch_ncc_against_composition(device):
         assert len(calls) >= 12  # (the kernels really ran)
     finally:
         ops.ncc_patch_forward = fwd
+
+
+def check_channel_words(device, ops):
+    """mask_to_channels from the volume's ready-packed words (ops.channel_words, ddrr_channel_words +
+    ddrr_siddon_forward_channels_bricks_words; reference renderers.py:77-89): the first render of a
+    (volume, label map) pair stages from both, the second packs the words, later ones stage them as
+    they are -- same images --, a tracked edit forces a repack, an UNTRACKED one (`density.data.mul_`)
+    is found by the call's own fingerprint comparison on the device and repacked too: never old
+    words."""
+    import torch
+
+    from diffdrr_amd import DRR
+    from diffdrr_amd.data import synthetic_subject
+    from diffdrr_amd.renderers import _labels_u8
+
+    drr = DRR(synthetic_subject((40, 70, 36), kind="noise", seed=5, n_labels=9), sdd=600.0, height=24, width=31,
+              delx=3.0).to(device)
+    rot = torch.tensor([[0.3, 0.2, -0.1], [1.5, 0.1, 0.0]], device=device)
+    xyz = torch.tensor([[5.0, 420.0, -3.0], [0.0, 400.0, 0.0]], device=device)
+    calls = []
+    launch = ops._launch
+    ops._launch = lambda n, d, *a: (calls.append(n), launch(n, d, *a))[1]
+    try:
+        def render():
+            calls.clear()
+            with torch.no_grad():
+                return drr(rot, xyz, parameterization="euler_angles", convention="ZXY", mask_to_channels=True).clone()
+        labels, C, _ = _labels_u8(drr.mask)[0]
+        first = render()
+        assert "ddrr_siddon_forward_channels_bricks" in calls and "ddrr_channel_words" not in calls
+        second = render()
+        assert "ddrr_channel_words" in calls and "ddrr_siddon_forward_channels_bricks_words" in calls
+        assert ops.channel_words_repacks(drr.density, labels, C) == 1
+        third = render()
+        assert ops.channel_words_repacks(drr.density, labels, C) == 1           # (compared, not packed again)
+        scale = float(first.abs().max())
+        assert float((second - first).abs().max()) <= 2e-6 * scale and float((third - first).abs().max()) <= 2e-6 * scale
+        with torch.no_grad():
+            drr.density[3, 4, 5] += 0.5                                          # tracked: the version counter
+        fourth = render()
+        assert ops.channel_words_repacks(drr.density, labels, C) == 2
+        drr.renderer.channel_words = False
+        assert float((fourth - render()).abs().max()) <= 2e-6 * scale            # = staged from volume + labels
+        drr.renderer.channel_words = True
+        drr.density.data.mul_(2.0)                                               # untracked
+        fifth = render()
+        assert ops.channel_words_repacks(drr.density, labels, C) == 3            # found on the device
+        assert rel_err(fifth.cpu().numpy(), 2.0 * fourth.cpu().numpy()) < 2e-5
+    finally:
+        ops._launch = launch

@@ -865,11 +865,35 @@ int ddrr_siddon_forward_channels(const float *volume, const unsigned char *label
 // Host emulation of the channel render on the bricks: per brick, the packed value | label words
 // are staged exactly as the kernel stages them, and every ray of every pose is clipped and
 // walked with the kernel's own step_walk_channels.
-int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char *labels, int dx,
-                                        int dy, int dz, const float *source, const float *target,
-                                        const float *img, int B, int det_h, int det_w, int C,
-                                        float voxel_shift, float eps, float *out, void *,
-                                        void *) {
+long ddrr_channel_words_state_bytes(void) { return (long)(2 + 2 * kFingerprintWords) * 4; }
+
+int ddrr_channel_words(const float *volume, const unsigned char *labels, long n_voxels, int C, float *words,
+                       void *state_raw, int force, void *) {
+    int *state = static_cast<int *>(state_raw);
+    unsigned *fp = reinterpret_cast<unsigned *>(state + 2);
+    bool stale = force != 0;
+    for (int i = 0; i < kFingerprintWords && n_voxels > 0; ++i) {
+        const long at = fingerprint_index(i, n_voxels);
+        unsigned bits;
+        memcpy(&bits, volume + at, 4);
+        stale = stale || bits != fp[i] || (unsigned)labels[at] != fp[kFingerprintWords + i];
+    }
+    if (!stale) return 0;
+    for (long i = 0; i < n_voxels; ++i) words[i] = pack_voxel_label_below(volume[i], labels[i], (unsigned)C);
+    for (int i = 0; i < kFingerprintWords && n_voxels > 0; ++i) {
+        const long at = fingerprint_index(i, n_voxels);
+        memcpy(&fp[i], volume + at, 4);
+        fp[kFingerprintWords + i] = (unsigned)labels[at];
+    }
+    state[1] += 1;
+    return 0;
+}
+
+// (labels == NULL: `volume` holds the ready-packed words of ddrr_channel_words)
+static int emu_channels_bricks(const float *volume, const unsigned char *labels, int dx,
+                               int dy, int dz, const float *source, const float *target,
+                               const float *img, int B, int det_h, int det_w, int C,
+                               float voxel_shift, float eps, float *out) {
     const Dims D{dx, dy, dz};
     const int N = det_h * det_w;
     memset(out, 0, sizeof(float) * (size_t)B * C * N);
@@ -885,7 +909,7 @@ int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char
                 for (int z = box.lo[2]; z < box.hi[2]; ++z) {
                     const long at = ((long)x * dy + y) * dz + z;
                     brick[(x - box.lo[0]) * lay.sx + (y - box.lo[1]) * lay.sy + (z - box.lo[2])] =
-                        pack_voxel_label_below(volume[at], labels[at], (unsigned)C);
+                        labels ? pack_voxel_label_below(volume[at], labels[at], (unsigned)C) : volume[at];
                 }
         for (int b = 0; b < B; ++b)
             for (int pix = 0; pix < N; ++pix) {
@@ -905,6 +929,24 @@ int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char
             }
     }
     return 0;
+}
+
+int ddrr_siddon_forward_channels_bricks(const float *volume, const unsigned char *labels, int dx,
+                                        int dy, int dz, const float *source, const float *target,
+                                        const float *img, int B, int det_h, int det_w, int C,
+                                        float voxel_shift, float eps, float *out, void *,
+                                        void *) {
+    if (!labels) return -1;
+    return emu_channels_bricks(volume, labels, dx, dy, dz, source, target, img, B, det_h, det_w, C, voxel_shift,
+                               eps, out);
+}
+
+int ddrr_siddon_forward_channels_bricks_words(const float *words, int dx, int dy, int dz, const float *source,
+                                              const float *target, const float *img, int B, int det_h,
+                                              int det_w, int C, float voxel_shift, float eps, float *out,
+                                              void *, void *) {
+    return emu_channels_bricks(words, nullptr, dx, dy, dz, source, target, img, B, det_h, det_w, C, voxel_shift,
+                               eps, out);
 }
 
 // Host emulation of the channel render's ray backward on the bricks: the blocked record of the

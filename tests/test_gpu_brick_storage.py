@@ -432,3 +432,8 @@ def test_untracked_volume_edits_are_rendered_from_the_live_values(gpu):
     """`volume.data.mul_(2)` between renders: the launch notices (fingerprint), renders from fp32,
     and `volume_changed()` gets the 16-bit bricks back."""
     conftest.check_untracked_volume_edits(gpu, ops)
+
+
+def test_channel_render_from_ready_packed_words(gpu):
+    """mask_to_channels staged from the pair's cached words: same images, self-healing on edits."""
+    conftest.check_channel_words(gpu, ops)

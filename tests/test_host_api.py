@@ -1077,3 +1077,7 @@ def test_subsample_and_patches_match_reference_on_the_bricks(emulated_ops, monke
 def test_patch_ncc_kernels_against_the_composition(emulated_ops):
     """(host build of ncc_patch_core.h; the device twin: tests/test_gpu_parity.py)"""
     conftest.check_patch_ncc_against_composition(torch.device("cpu"))
+
+
+def test_channel_render_from_ready_packed_words_on_the_host(emulated_ops):
+    conftest.check_channel_words("cpu", emulated_ops)

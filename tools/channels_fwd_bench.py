@@ -63,6 +63,18 @@ for which in ("synthetic",) if "--cube" in sys.argv else ("synthetic", "real"):
                         row["channels"], _ = timeit(
                             lambda: ops.siddon_forward_channels_bricks(V, labels, C, s_, t_, L, (H, H)))
                     c_new = ops.siddon_forward_channels_bricks(V, labels, C, s_, t_, L, (H, H))
+                    # ... and from the volume's ready-packed words (ops.channel_words, cached per pair)
+                    words = ops.channel_words(V, labels, C)
+                    for _ in range(2):
+                        row["channels, words"], _ = timeit(
+                            lambda: ops.siddon_forward_channels_bricks(V, labels, C, s_, t_, L, (H, H), words=words))
+                    # ... as the module calls it: the fingerprint comparison in front of every render
+                    for _ in range(2):
+                        row["channels, words + check"], _ = timeit(
+                            lambda: ops.siddon_forward_channels_bricks(V, labels, C, s_, t_, L, (H, H),
+                                                                       words=ops.channel_words(V, labels, C)))
+                    c_words = ops.siddon_forward_channels_bricks(V, labels, C, s_, t_, L, (H, H), words=words)
+                    assert float((c_words - c_new).abs().max()) <= 2e-6 * float(c_new.abs().max())
                 for st in ("f32", "q16p"):
                     if (var == -1 or dbg != 0) and st != ("f32" if var == -1 else "q16p"):
                         continue  # (the general kernel: fp32 bricks; the look-ahead: packed bricks)

@@ -108,3 +108,6 @@ python tools/channels_fwd_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-220
 
 # ---------------------------------------------------------------- 2026-10-01T05:13:11Z  r06: masked channel flush: tests + channels bench
 python -m pytest tests -m gpu -x -q -k "channel or mask" 2>&1 | tail -2; python tools/channels_fwd_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-90; python tools/fuzz_bricks.py --cases 24 2>&1 | tail -1 | cut -c1-300
+
+# ---------------------------------------------------------------- 2026-10-01T05:17:57Z  r06: channel words experiment
+python tools/channels_fwd_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-110
