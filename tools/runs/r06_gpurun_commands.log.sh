@@ -111,3 +111,6 @@ python -m pytest tests -m gpu -x -q -k "channel or mask" 2>&1 | tail -2; python 
 
 # ---------------------------------------------------------------- 2026-10-01T05:17:57Z  r06: channel words experiment
 python tools/channels_fwd_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-110
+
+# ---------------------------------------------------------------- 2026-10-01T05:22:19Z  r06: channel words with the check: tests + bench
+python -m pytest tests -m gpu -x -q -k "channel or ready_packed or mask" 2>&1 | tail -2; python tools/channels_fwd_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-140
