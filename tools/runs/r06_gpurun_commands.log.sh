@@ -114,3 +114,6 @@ python tools/channels_fwd_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-110
 
 # ---------------------------------------------------------------- 2026-10-01T05:22:19Z  r06: channel words with the check: tests + bench
 python -m pytest tests -m gpu -x -q -k "channel or ready_packed or mask" 2>&1 | tail -2; python tools/channels_fwd_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-140
+
+# ---------------------------------------------------------------- 2026-10-01T05:27:20Z  r06: channel words with the check: tests + bench (retry)
+python -m pytest tests -m gpu -x -q -k "channel or ready_packed or mask" 2>&1 | tail -2; python tools/channels_fwd_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-170
