@@ -776,8 +776,8 @@ def channel_words(volume, labels_u8, n_channels, build=True):
     """The channel render's staged words (value with a 16-bit mantissa | label) for the whole volume,
     one float per voxel, for a (volume, label map) pair that is rendered again and again:
     :func:`siddon_forward_channels_bricks` then stages a brick with straight 16-byte copies -- no label
-    loads, no packing (one pose 0.088 -> 0.071 ms, 8 poses 0.279 -> 0.254 on the reference's example
-    shape and label map).  Cached per (volume tensor, label tensor, channels) while both live;
+    loads, no packing (one pose 0.089 -> 0.079 ms, 8 poses 0.280 -> 0.262 on the reference's example
+    shape and label map, the comparison launches included).  Cached per (volume tensor, label tensor, channels) while both live;
     +100 % of the volume's bytes.  EVERY call launches ``ddrr_channel_words``: it compares a
     fingerprint of volume and labels on the device (1024 voxels each) and returns after a few
     microseconds if nothing changed; a change PyTorch tracks (version counters, storage addresses)

@@ -675,7 +675,7 @@ class Siddon(torch.nn.Module):
         self.channels_on_bricks = True
         # ... from the volume's ready-packed words once a (volume, label map) pair is rendered a second
         # time (ops.channel_words: +100 % of the volume's bytes per pair, self-healing on the device;
-        # one pose 0.088 -> 0.071 ms, 8 poses 0.279 -> 0.254 = 1.44x the plain render on the reference's
+        # one pose 0.089 -> 0.079 ms, 8 poses 0.280 -> 0.262 = 1.50x the plain render on the reference's
         # example shape and label map).  False: staged from volume and label map every time.
         self.channel_words = True
 

@@ -117,3 +117,6 @@ python -m pytest tests -m gpu -x -q -k "channel or ready_packed or mask" 2>&1 | 
 
 # ---------------------------------------------------------------- 2026-10-01T05:27:20Z  r06: channel words with the check: tests + bench (retry)
 python -m pytest tests -m gpu -x -q -k "channel or ready_packed or mask" 2>&1 | tail -2; python tools/channels_fwd_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-170
+
+# ---------------------------------------------------------------- 2026-10-01T05:30:12Z  r06: channel words, two-launch check
+python -m pytest tests -m gpu -x -q -k "ready_packed" 2>&1 | tail -2; python tools/channels_fwd_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-130
