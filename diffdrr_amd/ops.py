@@ -763,13 +763,14 @@ _words_cache = {}  # (id(volume), id(labels), C) -> _ChannelWords
 
 class _ChannelWords:
     """Cache entry of :func:`channel_words`."""
-    __slots__ = ("vol", "lab", "tracked", "words", "state", "seen")
+    __slots__ = ("vol", "lab", "tracked", "words", "state", "seen", "churn")
 
     def __init__(self, vol, lab):
         self.vol, self.lab = vol, lab   # weak references
         self.tracked = None             # what PyTorch tracks of the pair when the words were last packed
         self.words = self.state = None
         self.seen = 0                   # renders of this pair in this tracked state
+        self.churn = 0                  # repacks in a row because the pair had changed between two renders
 
 
 def channel_words(volume, labels_u8, n_channels, build=True):
@@ -797,6 +798,14 @@ def channel_words(volume, labels_u8, n_channels, build=True):
             if ent.seen < 2:
                 return None
     force = ent.words is None or ent.tracked != tracked
+    if not build:
+        # a pair that changes between renders again and again (a volume edited in place every
+        # iteration) gains nothing from words that are packed anew for every render: given up for it
+        ent.churn = ent.churn + 1 if (force and ent.words is not None) else 0
+        if ent.churn >= 3:
+            ent.words = ent.state = None
+            ent.tracked, ent.seen, ent.churn = tracked, -(1 << 30), 0
+            return None
     if ent.words is None:
         ent.words = torch.empty_like(volume)
         n = int(_query("ddrr_channel_words_state_bytes"))
