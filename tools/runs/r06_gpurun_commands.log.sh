@@ -123,3 +123,9 @@ python -m pytest tests -m gpu -x -q -k "ready_packed" 2>&1 | tail -2; python too
 
 # ---------------------------------------------------------------- 2026-10-01T05:33:41Z  r06: FINAL evidence: suite, smoke, rocprof + PMC, bench lines, configs, tools
 mkdir -p gpurun_out/r06z; python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^$" > gpurun_out/r06z/gpu_suite_full.txt; tail -1 gpurun_out/r06z/gpu_suite_full.txt; python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r06z/smoke.txt 2>&1; tail -1 gpurun_out/r06z/smoke.txt; tools/prof_bench.sh gpurun_out/r06zprof > gpurun_out/r06z/rocprof_bench.txt 2>&1; python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06z/bench_line_driver_command.json 2> gpurun_out/r06z/bench_stderr_driver_command.txt; echo rc=$?; python bench.py > gpurun_out/r06z/bench_line_default.json 2> gpurun_out/r06z/bench_stderr_default.txt; cp bench_full.json gpurun_out/r06z/bench_full.json; for c in 2 3 4 5; do python bench.py --config $c > gpurun_out/r06z/bench_line_config_$c.json 2>/dev/null; cp bench_full.json gpurun_out/r06z/bench_config_$c.json; done; python tools/sparse_levers_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06z/sparse.txt; python tools/patch_ncc_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06z/patch_ncc.txt; python tools/fuzz_bricks.py --cases 64 2>&1 | grep -v amdgpu.ids > gpurun_out/r06z/fuzz_bricks.txt; tail -1 gpurun_out/r06z/fuzz_bricks.txt | cut -c1-300; wc -c gpurun_out/r06z/bench_line_*.json; head -9 gpurun_out/r06z/rocprof_bench.txt | cut -c1-150
+
+# ---------------------------------------------------------------- 2026-10-01T05:43:14Z  r06: last check of the final commit: suite + smoke + driver bench
+python -m pytest tests -m gpu -x -q 2>&1 | tail -2; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1; python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | python -c "
+import sys, json
+l = sys.stdin.read().strip().splitlines()
+print(len(l), len(l[-1])); d = json.loads(l[-1]); print(d[\"value\"], d[\"ms_per_step\"], d[\"roofline\"][\"frac\"], d[\"cpu_baseline\"][\"value\"], list(d[\"configs\"]))"
