@@ -129,3 +129,18 @@ python -m pytest tests -m gpu -x -q 2>&1 | tail -2; python -c "import __graft_en
 import sys, json
 l = sys.stdin.read().strip().splitlines()
 print(len(l), len(l[-1])); d = json.loads(l[-1]); print(d[\"value\"], d[\"ms_per_step\"], d[\"roofline\"][\"frac\"], d[\"cpu_baseline\"][\"value\"], list(d[\"configs\"]))"
+
+# ---------------------------------------------------------------- 2026-10-01T05:47:45Z  r06: robustness: fuzz 160 cases seed 7, GPU suite twice more
+mkdir -p gpurun_out/r06y; python tools/fuzz_bricks.py --cases 160 --seed 7 2>&1 | grep -v amdgpu.ids > gpurun_out/r06y/fuzz_bricks_seed7.txt; tail -1 gpurun_out/r06y/fuzz_bricks_seed7.txt | cut -c1-320; python tools/fuzz_bricks.py --cases 60 --seed 3 --smooth 2>&1 | grep -v amdgpu.ids > gpurun_out/r06y/fuzz_bricks_smooth.txt; tail -1 gpurun_out/r06y/fuzz_bricks_smooth.txt | cut -c1-320; for i in 1 2; do python -m pytest tests -m gpu -q -x 2>&1 | tail -1; done
+
+# ---------------------------------------------------------------- 2026-10-01T05:54:59Z  r06: robustness: fuzz 160 cases seed 7, smooth 60, GPU suite twice more (retry)
+mkdir -p gpurun_out/r06y; python tools/fuzz_bricks.py --cases 160 --seed 7 2>&1 | grep -v amdgpu.ids > gpurun_out/r06y/fuzz_bricks_seed7.txt; tail -1 gpurun_out/r06y/fuzz_bricks_seed7.txt | cut -c1-320; python tools/fuzz_bricks.py --cases 60 --seed 3 --smooth 2>&1 | grep -v amdgpu.ids > gpurun_out/r06y/fuzz_bricks_smooth.txt; tail -1 gpurun_out/r06y/fuzz_bricks_smooth.txt | cut -c1-320; for i in 1 2; do python -m pytest tests -m gpu -q -x 2>&1 | tail -1; done
+
+# ---------------------------------------------------------------- 2026-10-01T06:02:41Z  r06: r05's fuzz script (same random stream) on the current library
+python tools/_fuzz_r05.py --cases 64 --seed 0 2>&1 | grep -v amdgpu.ids > gpurun_out/r06y/fuzz_r05_script.txt; tail -1 gpurun_out/r06y/fuzz_r05_script.txt | cut -c1-200
+
+# ---------------------------------------------------------------- 2026-10-01T06:04:13Z  r06: r05's fuzz script on the current library (retry with dir)
+mkdir -p gpurun_out/r06y; python tools/_fuzz_r05.py --cases 64 --seed 0 2>&1 | grep -v amdgpu.ids > gpurun_out/r06y/fuzz_r05_script.txt; tail -1 gpurun_out/r06y/fuzz_r05_script.txt | cut -c1-200
+
+# ---------------------------------------------------------------- 2026-10-01T06:05:02Z  r06: A/B fuzz: round 5's tree against the current one, same script, same seed
+mkdir -p gpurun_out/r06y; (cd r05tree && python tools/fuzz_bricks.py --cases 64 --seed 0 2>&1 | grep -v amdgpu.ids > ../gpurun_out/r06y/fuzz_r05_tree.txt); python tools/_fuzz_r05.py --cases 64 --seed 0 2>&1 | grep -v amdgpu.ids > gpurun_out/r06y/fuzz_r05_script.txt; tail -1 gpurun_out/r06y/fuzz_r05_tree.txt | cut -c1-160; tail -1 gpurun_out/r06y/fuzz_r05_script.txt | cut -c1-160
