@@ -1266,6 +1266,26 @@ def few_poses_config(rt, poses=(1, 2, 8), det=256, D=512):
     return out
 
 
+def guarded_run(world, name, fn):
+    """One GPU: a side run that fails must not cost the driver its headline line (the failure is
+    recorded in its place and on stderr).  Several ranks: exceptions propagate -- a rank that
+    skipped a collective would hang the others."""
+    t0 = time.perf_counter()
+    if world > 1:
+        out = fn()
+    else:
+        try:
+            out = fn()
+        except Exception as exc:  # noqa: BLE001
+            import traceback
+
+            log(f"[bench] configs.{name} FAILED: {type(exc).__name__}: {exc}\n{traceback.format_exc()}")
+            out = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    if isinstance(out, dict):
+        out["wall_s"] = time.perf_counter() - t0
+    return out
+
+
 def summary_of(res):
     """What the default line keeps of a short config run."""
     rf = res["roofline"]
@@ -1523,23 +1543,7 @@ def main():
         configs = {}
 
         def guarded(name, fn):
-            """One GPU: a side run that fails must not cost the driver its headline line (the failure is
-            recorded in its place and on stderr).  Several ranks: exceptions propagate -- a rank that
-            skipped a collective would hang the others."""
-            t0 = time.perf_counter()
-            if rt.world > 1:
-                out = fn()
-            else:
-                try:
-                    out = fn()
-                except Exception as exc:  # noqa: BLE001
-                    import traceback
-
-                    log(f"[bench] configs.{name} FAILED: {type(exc).__name__}: {exc}\n{traceback.format_exc()}")
-                    out = {"error": f"{type(exc).__name__}: {exc}"[:300]}
-            if isinstance(out, dict):
-                out["wall_s"] = time.perf_counter() - t0
-            return out
+            return guarded_run(rt.world, name, fn)
 
         for cfg in (("2", "3", "4", "5") if rt.world == 1 and plain_headline else ("5",)):
             res = guarded(cfg, lambda: summary_of(run_config(cfg, args, rt, short=True)) if rt.rank == 0 or rt.world == 1

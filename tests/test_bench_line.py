@@ -99,3 +99,22 @@ def test_more_ranks_than_devices_is_one_json_error_line_and_rc_2():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert "error" in out and out["n_gpus_requested"] == 64 and out["n_gpus_visible"] == torch.cuda.device_count()
+
+
+def test_a_failing_side_run_is_recorded_not_fatal():
+    """`configs.*` of the default line are side runs: on one GPU a failure is recorded in its place (and
+    the line keeps its size and its contract keys); with several ranks the exception propagates."""
+    def boom():
+        raise RuntimeError("no such kernel " + "x" * 1000)
+
+    out = bench.guarded_run(1, "ct", boom)
+    assert out["error"].startswith("RuntimeError: no such kernel") and len(out["error"]) <= 300 and out["wall_s"] >= 0
+    assert bench.guarded_run(1, "ok", lambda: {"value": 1.0})["value"] == 1.0
+    with pytest.raises(RuntimeError):
+        bench.guarded_run(2, "ct", boom)
+    with open(FULL_RECORDS[-1]) as f:
+        full = json.load(f)
+    full["configs"]["ct"] = out
+    full["configs"]["3"] = bench.guarded_run(1, "3", boom)
+    back = _check(bench.compact_line(full))
+    assert back["configs"]["ct"]["error"].startswith("RuntimeError") and "error" in back["configs"]["3"]
