@@ -144,3 +144,7 @@ mkdir -p gpurun_out/r06y; python tools/_fuzz_r05.py --cases 64 --seed 0 2>&1 | g
 
 # ---------------------------------------------------------------- 2026-10-01T06:05:02Z  r06: A/B fuzz: round 5's tree against the current one, same script, same seed
 mkdir -p gpurun_out/r06y; (cd r05tree && python tools/fuzz_bricks.py --cases 64 --seed 0 2>&1 | grep -v amdgpu.ids > ../gpurun_out/r06y/fuzz_r05_tree.txt); python tools/_fuzz_r05.py --cases 64 --seed 0 2>&1 | grep -v amdgpu.ids > gpurun_out/r06y/fuzz_r05_script.txt; tail -1 gpurun_out/r06y/fuzz_r05_tree.txt | cut -c1-160; tail -1 gpurun_out/r06y/fuzz_r05_script.txt | cut -c1-160
+
+# ---------------------------------------------------------------- 2026-10-01T06:07:25Z  r06: bench of the final bench.py
+mkdir -p gpurun_out/r06x; python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06x/bench_line_driver_command.json 2> gpurun_out/r06x/stderr.txt; echo rc=$?; cp bench_full.json gpurun_out/r06x/; python -c "
+import json; l=open(\"gpurun_out/r06x/bench_line_driver_command.json\").read().strip().splitlines(); print(len(l), len(l[-1])); d=json.loads(l[-1]); print(d[\"value\"], d[\"ms_per_step\"], d[\"roofline\"][\"frac\"], d[\"roofline\"][\"step_minus_kernel_ms\"], [k for k,v in d[\"configs\"].items() if \"error\" in v])"
