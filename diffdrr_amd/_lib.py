@@ -15,7 +15,7 @@ from ctypes import c_double, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffdrr_hip.so")
-ABI_VERSION = 31
+ABI_VERSION = 32
 BRICKS_CLEARED = 2  # include/diffdrr_hip.h DDRR_BRICKS_CLEARED (a bit of ranges_valid)
 
 REDUCE_SUM, REDUCE_MAX = 0, 1
@@ -99,6 +99,8 @@ _SIGNATURES = {
     "ddrr_ncc_patch_backward": [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "ddrr_sobel_forward": [_P, _I, _I, _I, _P, _P],
     "ddrr_sobel_backward": [_P, _I, _I, _I, _P, _P],
+    "ddrr_blur_sobel_forward": [_P, _L, _I, _I, _I, _P, _I, _P, _P],
+    "ddrr_blur_sobel_backward": [_P, _I, _I, _I, _P, _I, _P, _P],
     "ddrr_raygen_forward": [_P, _P, _P, _I, _I, _P, _P, _P, _P],
     "ddrr_siddon_backward_pose": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P, _P],
     "ddrr_siddon_forward_f64": [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _D, _D, _I, _P, _P, _P],

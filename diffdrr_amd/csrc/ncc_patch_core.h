@@ -18,11 +18,15 @@
 
 namespace ddrr {
 
-template <class FA, class FB>
-DDRR_HD float ncc_patch_window(const FA &fa, const FB &fb, int p, float eps, float coef[4]) {
+// P > 0: the window size as a compile-time constant (the rows unrolled: LDS offsets become immediates
+// and the loop arithmetic goes -- the common sizes are instantiated, pose_ncc.hip), else `p`.
+template <int P = 0, class FA, class FB>
+DDRR_HD float ncc_patch_window(const FA &fa, const FB &fb, int p_rt, float eps, float coef[4]) {
+    const int p = P > 0 ? P : p_rt;
     float sa = 0.f, sb = 0.f;
     for (int y = 0; y < p; ++y)
-        for (int x = 0; x < p; ++x) {
+#pragma unroll
+        for (int x = 0; x < (P > 0 ? P : p); ++x) {
             sa += fa(y, x);
             sb += fb(y, x);
         }
@@ -30,7 +34,8 @@ DDRR_HD float ncc_patch_window(const FA &fa, const FB &fb, int p, float eps, flo
     const float mua = sa * inv_n, mub = sb * inv_n;
     float va = 0.f, vb = 0.f, cab = 0.f;
     for (int y = 0; y < p; ++y)
-        for (int x = 0; x < p; ++x) {
+#pragma unroll
+        for (int x = 0; x < (P > 0 ? P : p); ++x) {
             const float da = fa(y, x) - mua, db = fb(y, x) - mub;
             va = fmaf(da, da, va);
             vb = fmaf(db, db, vb);
@@ -49,11 +54,14 @@ DDRR_HD float ncc_patch_window(const FA &fa, const FB &fb, int p, float eps, flo
 
 // `fc(wy, wx, k)`: coefficient k of the window whose top-left pixel is (wy, wx), 0 outside the
 // window grid; the windows holding pixel (y, x) are wy in [y - p + 1, y], wx in [x - p + 1, x].
-template <class FC>
-DDRR_HD float ncc_patch_pixel_grad(const FC &fc, int y, int x, int p, float a, float b) {
+template <int P = 0, class FC>
+DDRR_HD float ncc_patch_pixel_grad(const FC &fc, int y, int x, int p_rt, float a, float b) {
+    const int p = P > 0 ? P : p_rt;
     float S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f;
     for (int wy = y - p + 1; wy <= y; ++wy)
-        for (int wx = x - p + 1; wx <= x; ++wx) {
+#pragma unroll
+        for (int k = 0; k < (P > 0 ? P : p); ++k) {
+            const int wx = x - p + 1 + k;
             S1 += fc(wy, wx, 0);
             S2 += fc(wy, wx, 1);
             S3 += fc(wy, wx, 2);

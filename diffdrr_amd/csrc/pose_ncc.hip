@@ -7,6 +7,7 @@
 #include "record_layout.h"
 #include "ncc_patch_core.h"
 #include "sobel_core.h"
+#include "blur_core.h"
 
 using namespace ddrr;
 using namespace ddrr_rt;
@@ -558,33 +559,48 @@ __global__ __launch_bounds__(kBlock) void ncc_bwd_kernel(
 // -- for the backward -- writes the window's four coefficients; the pair's score is the mean of
 // the windows' values (block sums, one atomic per workgroup; the entry zeroes the B floats).
 constexpr int kPatchTile = 16;
+// LDS row strides: a ds_read_b32 lane group is two rows of 16 windows on 32 banks, a ds_read_b128 one (the
+// backward's coefficients) rows of 16-byte slots on 64: strides of 16 mod 32 floats / a multiple of 16 float4
+// keep the rows of a group on different banks (T = 28 at p = 13 has them collide: every read 2 cycles for 1).
+__host__ __device__ inline int patch_stride_fwd(int T) { return ((T + 15) / 32) * 32 + 16; }
+__host__ __device__ inline int patch_stride_bwd(int T) { return (T + 15) & ~15; }
+// (workgroups per pair: every tile its own up to 2048 workgroups a launch, beyond that a workgroup walks
+// several tiles -- its one atomic on the pair's float is what the launch waits for at 32 pairs x 256 tiles)
+constexpr int kPatchWorkgroupsWanted = 2048, kPatchWorkgroupsPerPairMin = 32;
 
+template <int P>
 __global__ __launch_bounds__(kPatchTile *kPatchTile) void ncc_patch_fwd_kernel(
-    const float *__restrict__ x1, long x1_stride, const float *__restrict__ x2, int H, int W, int p,
+    const float *__restrict__ x1, long x1_stride, const float *__restrict__ x2, int H, int W, int p_rt,
     float eps, float *__restrict__ ncc_out, float4 *__restrict__ coef) {
+    const int p = P > 0 ? P : p_rt;
     extern __shared__ float patch_lds[];
-    const int T = kPatchTile + p - 1;
-    float *ta = patch_lds, *tb = patch_lds + T * T;
+    const int T = kPatchTile + p - 1, S = patch_stride_fwd(T);
+    float *ta = patch_lds, *tb = patch_lds + T * S;
     __shared__ float red[kPatchTile * kPatchTile / 64];
     const int b = blockIdx.z, hw = H - p + 1, ww = W - p + 1;
-    const int y0 = blockIdx.y * kPatchTile, x0 = blockIdx.x * kPatchTile;
+    const int ntx = (ww + kPatchTile - 1) / kPatchTile, nty = (hw + kPatchTile - 1) / kPatchTile;
     const float *a = x1 + b * x1_stride, *m = x2 + (long)b * H * W;
-    for (int i = threadIdx.x; i < T * T; i += kPatchTile * kPatchTile) {
-        const int y = y0 + i / T, x = x0 + i % T;
-        const bool in = y < H && x < W;
-        ta[i] = in ? a[(long)y * W + x] : 0.f;
-        tb[i] = in ? m[(long)y * W + x] : 0.f;
-    }
-    __syncthreads();
     const int ly = threadIdx.x / kPatchTile, lx = threadIdx.x % kPatchTile;
-    const int wy = y0 + ly, wx = x0 + lx;
     float v = 0.f;
-    if (wy < hw && wx < ww) {
-        float c[4];
-        const float *pa = ta + ly * T + lx, *pb = tb + ly * T + lx;
-        v = ncc_patch_window([&](int y, int x) { return pa[y * T + x]; },
-                             [&](int y, int x) { return pb[y * T + x]; }, p, eps, c);
-        if (coef) coef[((long)b * hw + wy) * ww + wx] = make_float4(c[0], c[1], c[2], c[3]);
+    for (int tile = blockIdx.x; tile < ntx * nty; tile += gridDim.x) {
+        const int y0 = (tile / ntx) * kPatchTile, x0 = (tile % ntx) * kPatchTile;
+        for (int i = threadIdx.x; i < T * T; i += kPatchTile * kPatchTile) {
+            const int r = i / T, c = i - r * T;
+            const int y = y0 + r, x = x0 + c;
+            const bool in = y < H && x < W;
+            ta[r * S + c] = in ? a[(long)y * W + x] : 0.f;
+            tb[r * S + c] = in ? m[(long)y * W + x] : 0.f;
+        }
+        __syncthreads();
+        const int wy = y0 + ly, wx = x0 + lx;
+        if (wy < hw && wx < ww) {
+            float c[4];
+            const float *pa = ta + ly * S + lx, *pb = tb + ly * S + lx;
+            v += ncc_patch_window<P>([&](int y, int x) { return pa[y * S + x]; },
+                                     [&](int y, int x) { return pb[y * S + x]; }, p, eps, c);
+            if (coef) coef[((long)b * hw + wy) * ww + wx] = make_float4(c[0], c[1], c[2], c[3]);
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -600,29 +616,32 @@ __global__ __launch_bounds__(kPatchTile *kPatchTile) void ncc_patch_fwd_kernel(
 // Backward: a workgroup takes 16 x 16 pixels of one pair and stages the coefficients of the
 // (16 + p - 1)^2 windows that hold any of them (zeros outside the window grid); a thread adds up
 // its pixel's p^2 windows.
+template <int P>
 __global__ __launch_bounds__(kPatchTile *kPatchTile) void ncc_patch_bwd_kernel(
     const float *__restrict__ x1, long x1_stride, const float *__restrict__ x2,
-    const float4 *__restrict__ coef, const float *__restrict__ g_out, int g_stride, int H, int W, int p,
+    const float4 *__restrict__ coef, const float *__restrict__ g_out, int g_stride, int H, int W, int p_rt,
     float *__restrict__ g_x2) {
+    const int p = P > 0 ? P : p_rt;
     extern __shared__ float4 coef_lds[];
-    const int T = kPatchTile + p - 1;
+    const int T = kPatchTile + p - 1, S = patch_stride_bwd(T);
     const int b = blockIdx.z, hw = H - p + 1, ww = W - p + 1;
     const int y0 = blockIdx.y * kPatchTile, x0 = blockIdx.x * kPatchTile;
     for (int i = threadIdx.x; i < T * T; i += kPatchTile * kPatchTile) {
-        const int wy = y0 - (p - 1) + i / T, wx = x0 - (p - 1) + i % T;
+        const int r = i / T, c = i - r * T;
+        const int wy = y0 - (p - 1) + r, wx = x0 - (p - 1) + c;
         const bool in = wy >= 0 && wx >= 0 && wy < hw && wx < ww;
-        coef_lds[i] = in ? coef[((long)b * hw + wy) * ww + wx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        coef_lds[r * S + c] = in ? coef[((long)b * hw + wy) * ww + wx] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     const int ly = threadIdx.x / kPatchTile, lx = threadIdx.x % kPatchTile;
     const int y = y0 + ly, x = x0 + lx;
     if (y >= H || x >= W) return;
     // (tile coordinates: window (wy, wx) sits at (wy - y0 + p - 1, wx - x0 + p - 1))
-    const float4 *c0 = coef_lds + (p - 1 - y0) * T + (p - 1 - x0);
+    const float4 *c0 = coef_lds + (p - 1 - y0) * S + (p - 1 - x0);
     const float a = x1[b * x1_stride + (long)y * W + x], m = x2[((long)b * H + y) * W + x];
-    const float s = ncc_patch_pixel_grad(
+    const float s = ncc_patch_pixel_grad<P>(
         [&](int wy, int wx, int k) {
-            const float4 c = c0[wy * T + wx];
+            const float4 c = c0[wy * S + wx];
             return k == 0 ? c.x : (k == 1 ? c.y : (k == 2 ? c.z : c.w));
         },
         y, x, p, a, m);
@@ -650,6 +669,119 @@ __global__ __launch_bounds__(kBlock) void sobel_bwd_kernel(const float *__restri
     const int i = n / W, j = n - i * W;
     const float *gx = g + ((long)b * 2) * H * W;
     g_img[(long)b * H * W + n] = sobel_pixel_adjoint(gx, gx + (long)H * W, H, W, i, j);
+}
+
+// ------------------------------------------- Gaussian blur + Sobel pair (gradient NCC, sigma > 0)
+// The reference's Sobel module blurs first (metrics.py:88-92, torchvision's gaussian_blur: blur_core.h) -- through
+// torch that is a reflect pad, a k x k depthwise convolution and its backward, 0.43 of the 0.63 ms of a 32-image
+// gradient-NCC call (profiles/r06/gradient_ncc.txt).  Here one launch each way: a 32 x 32 tile of the output, the
+// blur as two separable passes through LDS over the tile + its Sobel halo, then the 3 x 3 pair (sobel_core.h).
+// The blurred image is zero outside the image for the Sobel's zero padding, like the reference's.
+constexpr int kBlurTile = 32, kBlurBlock = 256;
+
+// K > 0: the number of taps as a compile-time constant (7 = the reference's default sigma = 1: the tile sizes
+// and with them every index division become constants, the tap loops unroll), else `k`.
+template <int K>
+__global__ __launch_bounds__(kBlurBlock) void blur_sobel_fwd_kernel(
+    const float *__restrict__ img, long img_stride, int H, int W, const float *__restrict__ taps_g, int k_rt,
+    float *__restrict__ out) {
+    extern __shared__ float lds[];
+    const int k = K > 0 ? K : k_rt;
+    const int r = k >> 1, BH = kBlurTile + 2, IN = BH + 2 * r;
+    float *taps = lds, *in = taps + 32, *tmp = in + IN * IN, *bl = tmp + IN * BH;
+    const int b = blockIdx.z, y0 = blockIdx.y * kBlurTile, x0 = blockIdx.x * kBlurTile;
+    const float *src = img + (long)b * img_stride;
+    if (threadIdx.x < 32) taps[threadIdx.x] = (int)threadIdx.x < k ? taps_g[threadIdx.x] : 0.f;
+    for (int i = threadIdx.x; i < IN * IN; i += kBlurBlock) {
+        const int yy = i / IN, xx = i - yy * IN;
+        in[i] = src[(long)blur_reflect(y0 - 1 - r + yy, H) * W + blur_reflect(x0 - 1 - r + xx, W)];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < IN * BH; i += kBlurBlock) {  // along x
+        const int yy = i / BH, c = i - yy * BH;
+        float s = 0.f;
+        for (int t = 0; t < k; ++t) s = fmaf(taps[t], in[yy * IN + c + t], s);
+        tmp[i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < BH * BH; i += kBlurBlock) {  // along y
+        const int rr = i / BH, c = i - rr * BH;
+        const int y = y0 - 1 + rr, x = x0 - 1 + c;
+        float s = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W)
+            for (int t = 0; t < k; ++t) s = fmaf(taps[t], tmp[(rr + t) * BH + c], s);
+        bl[i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kBlurTile * kBlurTile; i += kBlurBlock) {
+        const int ly = i / kBlurTile, lx = i - ly * kBlurTile;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y >= H || x >= W) continue;
+        float gx, gy;
+        const float *c = bl + (ly + 1) * BH + lx + 1;  // (the tile carries its own halo: no bounds)
+        sobel_of([&](int di, int dj) { return c[di * BH + dj]; }, gx, gy);
+        out[((long)b * 2 * H + y) * W + x] = gx;
+        out[(((long)b * 2 + 1) * H + y) * W + x] = gy;
+    }
+}
+
+// The adjoint: the Sobel pair's over the tile + r, then the blur's two passes with the reflect padding folded
+// back into the weights (blur_adjoint_weight).
+template <int K>
+__global__ __launch_bounds__(kBlurBlock) void blur_sobel_bwd_kernel(
+    const float *__restrict__ g, int H, int W, const float *__restrict__ taps_g, int k_rt,
+    float *__restrict__ g_img) {
+    extern __shared__ float lds[];
+    const int k = K > 0 ? K : k_rt;
+    const int r = k >> 1, GB = kBlurTile + 2 * r, GG = GB + 2;
+    float *taps = lds, *gx = taps + 32, *gy = gx + GG * GG, *gb = gy + GG * GG, *tmp = gb + GB * GB;
+    const int b = blockIdx.z, y0 = blockIdx.y * kBlurTile, x0 = blockIdx.x * kBlurTile;
+    const float *sx = g + (long)b * 2 * H * W, *sy = sx + (long)H * W;
+    if (threadIdx.x < 32) taps[threadIdx.x] = (int)threadIdx.x < k ? taps_g[threadIdx.x] : 0.f;
+    for (int i = threadIdx.x; i < GG * GG; i += kBlurBlock) {
+        const int yy = i / GG, xx = i - yy * GG;
+        const int y = y0 - r - 1 + yy, x = x0 - r - 1 + xx;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;
+        gx[i] = in ? sx[(long)y * W + x] : 0.f;
+        gy[i] = in ? sy[(long)y * W + x] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < GB * GB; i += kBlurBlock) {
+        const int yy = i / GB, xx = i - yy * GB;
+        const int y = y0 - r + yy, x = x0 - r + xx;
+        const float *cx = gx + (yy + 1) * GG + xx + 1, *cy = gy + (yy + 1) * GG + xx + 1;
+        gb[i] = (y >= 0 && y < H && x >= 0 && x < W)
+                    ? sobel_adjoint_of([&](int di, int dj) { return cx[di * GG + dj]; },
+                                       [&](int di, int dj) { return cy[di * GG + dj]; })
+                    : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kBlurTile * GB; i += kBlurBlock) {  // along y
+        const int li = i / GB, c = i - li * GB;
+        const int y = y0 + li;
+        float s = 0.f;
+        if (y < H) {
+            if (blur_adjoint_plain(y, H, r))
+                for (int d = -r; d <= r; ++d) s = fmaf(taps[r - d], gb[(li + r + d) * GB + c], s);
+            else
+                for (int d = -r; d <= r; ++d)
+                    s = fmaf(blur_adjoint_weight(taps, k, y, y + d, H), gb[(li + r + d) * GB + c], s);
+        }
+        tmp[i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kBlurTile * kBlurTile; i += kBlurBlock) {  // along x
+        const int li = i / kBlurTile, lj = i - li * kBlurTile;
+        const int y = y0 + li, x = x0 + lj;
+        if (y >= H || x >= W) continue;
+        float s = 0.f;
+        if (blur_adjoint_plain(x, W, r))
+            for (int d = -r; d <= r; ++d) s = fmaf(taps[r - d], tmp[li * GB + lj + r + d], s);
+        else
+            for (int d = -r; d <= r; ++d)
+                s = fmaf(blur_adjoint_weight(taps, k, x, x + d, W), tmp[li * GB + lj + r + d], s);
+        g_img[((long)b * H + y) * W + x] = s;
+    }
 }
 
 // One Adam step of the two pose parameter groups of a registration (reference
@@ -715,6 +847,49 @@ int ddrr_sobel_backward(const float *g_out, int B, int H, int W, float *g_img, v
     hipLaunchKernelGGL(sobel_bwd_kernel, dim3((H * W + kBlock - 1) / kBlock, B), dim3(kBlock), 0,
                        (hipStream_t)stream, g_out, H, W, g_img);
     return finish("ddrr_sobel_backward");
+}
+
+static int blur_args_ok(int B, int H, int W, int k) {
+    if (B < 0 || H < 1 || W < 1) return fail(-1, "bad batch / image size");
+    if (k < 1 || k > kBlurMaxTaps || !(k & 1)) return fail(-1, "the blur takes an odd number of taps, 1 ... 31");
+    if ((k >> 1) >= H || (k >> 1) >= W) return fail(-1, "reflect padding needs k // 2 < min(H, W)");
+    if (B > 65535) return fail(-1, "at most 65535 images per call");
+    return 0;
+}
+
+int ddrr_blur_sobel_forward(const float *img, long img_stride, int B, int H, int W, const float *taps, int k,
+                            float *out, void *stream) {
+    if (!img || !taps || !out) return fail(-1, "null pointer");
+    if (int rc = blur_args_ok(B, H, W, k)) return rc;
+    if (img_stride != 0 && img_stride != (long)H * W) return fail(-1, "img_stride must be H W, or 0 for one image");
+    if (B == 0) return 0;
+    const int BH = kBlurTile + 2, IN = BH + 2 * (k >> 1);
+    const dim3 grid((W + kBlurTile - 1) / kBlurTile, (H + kBlurTile - 1) / kBlurTile, B);
+    const size_t lds = sizeof(float) * (32 + IN * IN + IN * BH + BH * BH);
+    if (k == 7)
+        hipLaunchKernelGGL(blur_sobel_fwd_kernel<7>, grid, dim3(kBlurBlock), lds, (hipStream_t)stream, img,
+                           img_stride, H, W, taps, k, out);
+    else
+        hipLaunchKernelGGL(blur_sobel_fwd_kernel<0>, grid, dim3(kBlurBlock), lds, (hipStream_t)stream, img,
+                           img_stride, H, W, taps, k, out);
+    return finish("ddrr_blur_sobel_forward");
+}
+
+int ddrr_blur_sobel_backward(const float *g_out, int B, int H, int W, const float *taps, int k, float *g_img,
+                             void *stream) {
+    if (!g_out || !taps || !g_img) return fail(-1, "null pointer");
+    if (int rc = blur_args_ok(B, H, W, k)) return rc;
+    if (B == 0) return 0;
+    const int GB = kBlurTile + 2 * (k >> 1), GG = GB + 2;
+    const dim3 grid((W + kBlurTile - 1) / kBlurTile, (H + kBlurTile - 1) / kBlurTile, B);
+    const size_t lds = sizeof(float) * (32 + 2 * GG * GG + GB * GB + kBlurTile * GB);
+    if (k == 7)
+        hipLaunchKernelGGL(blur_sobel_bwd_kernel<7>, grid, dim3(kBlurBlock), lds, (hipStream_t)stream, g_out, H, W,
+                           taps, k, g_img);
+    else
+        hipLaunchKernelGGL(blur_sobel_bwd_kernel<0>, grid, dim3(kBlurBlock), lds, (hipStream_t)stream, g_out, H, W,
+                           taps, k, g_img);
+    return finish("ddrr_blur_sobel_backward");
 }
 
 int ddrr_raygen_forward(const float *Mw, const float *Ainv, const float *P, int B, int N,
@@ -866,10 +1041,24 @@ int ddrr_ncc_patch_forward(const float *x1, long x1_stride, const float *x2, int
     const int hw = H - p + 1, ww = W - p + 1, T = kPatchTile + p - 1;
     if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)B, (hipStream_t)stream) != hipSuccess)
         return fail(-1, "hipMemsetAsync");
-    const dim3 grid((ww + kPatchTile - 1) / kPatchTile, (hw + kPatchTile - 1) / kPatchTile, B);
-    hipLaunchKernelGGL(ncc_patch_fwd_kernel, grid, dim3(kPatchTile * kPatchTile), 2 * T * T * sizeof(float),
-                       (hipStream_t)stream, x1, x1_stride, x2, H, W, p, eps, out,
-                       reinterpret_cast<float4 *>(coef));
+    const int tiles = ((ww + kPatchTile - 1) / kPatchTile) * ((hw + kPatchTile - 1) / kPatchTile);
+    const int per_pair = std::min(tiles, std::max(kPatchWorkgroupsPerPairMin, kPatchWorkgroupsWanted / B));
+    const dim3 grid(per_pair, 1, B);
+    // (the window sizes the reference's notebooks use, as compile-time constants: 13 -- metrics.ipynb:94 --,
+    // 9 -- 05_metrics.ipynb:291 --, and their neighbours; any other size takes the run-time loop)
+#define DDRR_PATCH_FWD(P_)                                                                                     \
+    hipLaunchKernelGGL(ncc_patch_fwd_kernel<P_>, grid, dim3(kPatchTile * kPatchTile),                   \
+                       2 * T * patch_stride_fwd(T) * sizeof(float),                                            \
+                       (hipStream_t)stream, x1, x1_stride, x2, H, W, p, eps, out, reinterpret_cast<float4 *>(coef))
+    switch (p) {
+        case 5: DDRR_PATCH_FWD(5); break;
+        case 7: DDRR_PATCH_FWD(7); break;
+        case 9: DDRR_PATCH_FWD(9); break;
+        case 11: DDRR_PATCH_FWD(11); break;
+        case 13: DDRR_PATCH_FWD(13); break;
+        default: DDRR_PATCH_FWD(0); break;
+    }
+#undef DDRR_PATCH_FWD
     return finish("ddrr_ncc_patch_forward");
 }
 
@@ -886,9 +1075,27 @@ int ddrr_ncc_patch_backward(const float *x1, long x1_stride, const float *x2, co
     if ((reinterpret_cast<uintptr_t>(coef) & 15) != 0) return fail(-1, "coef must be 16-byte aligned");
     const int T = kPatchTile + p - 1;
     const dim3 grid((W + kPatchTile - 1) / kPatchTile, (H + kPatchTile - 1) / kPatchTile, B);
-    hipLaunchKernelGGL(ncc_patch_bwd_kernel, grid, dim3(kPatchTile * kPatchTile), T * T * sizeof(float4),
-                       (hipStream_t)stream, x1, x1_stride, x2, reinterpret_cast<const float4 *>(coef), g_out,
-                       g_stride, H, W, p, g_x2);
+#define DDRR_PATCH_BWD(P_)                                                                                  \
+    hipLaunchKernelGGL(ncc_patch_bwd_kernel<P_>, grid, dim3(kPatchTile * kPatchTile),          \
+                       T * patch_stride_bwd(T) * sizeof(float4),                                            \
+                       (hipStream_t)stream, x1, x1_stride, x2, reinterpret_cast<const float4 *>(coef), g_out,  \
+                       g_stride, H, W, p, g_x2)
+    // (windows past 48: more than the 64 KB of LDS a launch may ask for unannounced)
+    const size_t lds_bytes = (size_t)T * patch_stride_bwd(T) * sizeof(float4);
+    if (lds_bytes > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ncc_patch_bwd_kernel<0>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute");
+    }
+    switch (p) {
+        case 5: DDRR_PATCH_BWD(5); break;
+        case 7: DDRR_PATCH_BWD(7); break;
+        case 9: DDRR_PATCH_BWD(9); break;
+        case 11: DDRR_PATCH_BWD(11); break;
+        case 13: DDRR_PATCH_BWD(13); break;
+        default: DDRR_PATCH_BWD(0); break;
+    }
+#undef DDRR_PATCH_BWD
     return finish("ddrr_ncc_patch_backward");
 }
 

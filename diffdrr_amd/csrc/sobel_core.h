@@ -13,27 +13,33 @@ DDRR_HD float sobel_at(const float *img, int H, int W, int i, int j) {
     return (i >= 0 && i < H && j >= 0 && j < W) ? img[i * W + j] : 0.f;
 }
 
-// gx, gy at (i, j): out[c, i, j] = sum_{u, v} G_c[u, v] img[i + u - 1, j + v - 1]
-DDRR_HD void sobel_pixel(const float *img, int H, int W, int i, int j, float &gx, float &gy) {
-    const float a = sobel_at(img, H, W, i - 1, j - 1), b = sobel_at(img, H, W, i - 1, j);
-    const float c = sobel_at(img, H, W, i - 1, j + 1), d = sobel_at(img, H, W, i, j - 1);
-    const float f = sobel_at(img, H, W, i, j + 1), g = sobel_at(img, H, W, i + 1, j - 1);
-    const float h = sobel_at(img, H, W, i + 1, j), k = sobel_at(img, H, W, i + 1, j + 1);
-    gx = (a - c) + 2.f * (d - f) + (g - k);
+// gx, gy from the 3 x 3 neighbourhood f(di, dj), di, dj in {-1, 0, 1}:
+// out[c] = sum_{u, v} G_c[u, v] f(u - 1, v - 1)
+template <class F>
+DDRR_HD void sobel_of(const F &f, float &gx, float &gy) {
+    const float a = f(-1, -1), b = f(-1, 0), c = f(-1, 1), d = f(0, -1);
+    const float e = f(0, 1), g = f(1, -1), h = f(1, 0), k = f(1, 1);
+    gx = (a - c) + 2.f * (d - e) + (g - k);
     gy = (a + 2.f * b + c) - (g + 2.f * h + k);
 }
 
-// adjoint: d loss / d img[i, j] = sum_c sum_{u, v} G_c[u, v] g[c, i - u + 1, j - v + 1]
-DDRR_HD float sobel_pixel_adjoint(const float *gx, const float *gy, int H, int W, int i, int j) {
-    // gx contributions: G_x[u, v] at output pixel (i - u + 1, j - v + 1)
-    const float x = (sobel_at(gx, H, W, i + 1, j + 1) - sobel_at(gx, H, W, i + 1, j - 1)) +
-                    2.f * (sobel_at(gx, H, W, i, j + 1) - sobel_at(gx, H, W, i, j - 1)) +
-                    (sobel_at(gx, H, W, i - 1, j + 1) - sobel_at(gx, H, W, i - 1, j - 1));
-    const float y = (sobel_at(gy, H, W, i + 1, j + 1) + 2.f * sobel_at(gy, H, W, i + 1, j) +
-                     sobel_at(gy, H, W, i + 1, j - 1)) -
-                    (sobel_at(gy, H, W, i - 1, j + 1) + 2.f * sobel_at(gy, H, W, i - 1, j) +
-                     sobel_at(gy, H, W, i - 1, j - 1));
+// adjoint: d loss / d img[i, j] = sum_c sum_{u, v} G_c[u, v] g[c, i - u + 1, j - v + 1], from the two
+// channels' neighbourhoods fx(di, dj), fy(di, dj)
+template <class FX, class FY>
+DDRR_HD float sobel_adjoint_of(const FX &fx, const FY &fy) {
+    const float x = (fx(1, 1) - fx(1, -1)) + 2.f * (fx(0, 1) - fx(0, -1)) + (fx(-1, 1) - fx(-1, -1));
+    const float y = (fy(1, 1) + 2.f * fy(1, 0) + fy(1, -1)) - (fy(-1, 1) + 2.f * fy(-1, 0) + fy(-1, -1));
     return x + y;
+}
+
+// the same on an H x W image in memory, zero outside
+DDRR_HD void sobel_pixel(const float *img, int H, int W, int i, int j, float &gx, float &gy) {
+    sobel_of([&](int di, int dj) { return sobel_at(img, H, W, i + di, j + dj); }, gx, gy);
+}
+
+DDRR_HD float sobel_pixel_adjoint(const float *gx, const float *gy, int H, int W, int i, int j) {
+    return sobel_adjoint_of([&](int di, int dj) { return sobel_at(gx, H, W, i + di, j + dj); },
+                            [&](int di, int dj) { return sobel_at(gy, H, W, i + di, j + dj); });
 }
 
 }  // namespace ddrr

@@ -130,16 +130,35 @@ class _SobelFn(torch.autograd.Function):
         return ops.sobel_backward(g).unsqueeze(1)
 
 
+class _BlurSobelFn(torch.autograd.Function):
+    """(B, 1, H, W) -> (B, 2, H, W): Gaussian blur (reflect padding) + Sobel pair, one launch each way:
+    ddrr_blur_sobel_forward / ddrr_blur_sobel_backward (reference metrics.py:88-93)."""
+
+    @staticmethod
+    def forward(ctx, x, taps):
+        ctx.taps = taps
+        return ops.blur_sobel_forward(x[:, 0], taps)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.blur_sobel_backward(g, ctx.taps).unsqueeze(1), None
+
+
+def gaussian_taps(kernel_size, sigma, dtype=torch.float32, device=None):
+    """The 1-D taps of torchvision's gaussian_blur (see :func:`gaussian_blur`)."""
+    half = (kernel_size - 1) * 0.5
+    x = torch.linspace(-half, half, steps=kernel_size, dtype=dtype, device=device)
+    k1 = torch.exp(-0.5 * (x / sigma).pow(2))
+    return k1 / k1.sum()
+
+
 def gaussian_blur(img, kernel_size, sigma):
     """torchvision.transforms.functional.gaussian_blur as the reference's ``Sobel`` calls it
     (metrics.py:66, 88-92; torchvision is a third-party dependency that is neither vendored by
     the reference nor installed here: restated from its published algorithm): taps exp(-x^2 / 2 sigma^2) on
     linspace(-(k-1)/2, (k-1)/2, k), normalised, separable, REFLECT padding by k // 2.  A few tensor
     ops on (B, 1, H, W) images; differentiable by autograd."""
-    half = (kernel_size - 1) * 0.5
-    x = torch.linspace(-half, half, steps=kernel_size, dtype=img.dtype, device=img.device)
-    k1 = torch.exp(-0.5 * (x / sigma).pow(2))
-    k1 = k1 / k1.sum()
+    k1 = gaussian_taps(kernel_size, sigma, img.dtype, img.device)
     c = img.shape[-3]
     kernel = torch.mm(k1[:, None], k1[None, :]).expand(c, 1, kernel_size, kernel_size)
     pad = [kernel_size // 2] * 4
@@ -152,11 +171,19 @@ class Sobel(torch.nn.Module):
     def __init__(self, sigma: float):
         super().__init__()
         self.sigma = sigma
+        self._taps = {}  # device -> the blur's taps there (computed on the host as torchvision does)
 
     def forward(self, img):
         x = img
         if self.sigma > 0:
-            x = gaussian_blur(img, int(6 * self.sigma + 1) | 1, self.sigma)
+            k = int(6 * self.sigma + 1) | 1
+            if (img.dim() == 4 and img.shape[1] == 1 and ops.on_device(img) and img.dtype == torch.float32
+                    and k <= 31 and k // 2 < min(img.shape[-2:]) and not getattr(self, "_no_blur_kernel", False)):
+                key = (img.device, float(self.sigma))
+                if key not in self._taps:
+                    self._taps = {key: gaussian_taps(k, self.sigma).to(img.device)}
+                return _BlurSobelFn.apply(img, self._taps[key])
+            x = gaussian_blur(img, k, self.sigma)
         if (x.shape[1] == 1 and ops.on_device(x) and x.dtype == torch.float32):
             return _SobelFn.apply(x)
         Gx = torch.tensor([[1, 0, -1], [2, 0, -2], [1, 0, -1]], dtype=x.dtype, device=x.device)

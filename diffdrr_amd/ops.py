@@ -549,6 +549,33 @@ def sobel_backward(g_out):
     return g_img
 
 
+def blur_sobel_forward(img, taps):
+    """img (B, H, W) -- or one image expanded over the batch -- -> (B, 2, H, W): the Sobel responses of the
+    Gaussian-blurred image (reference metrics.py:66, 88-93) in one launch; taps: (k) on the device."""
+    _require_gpu(img)
+    B, H, W = img.shape
+    shared = B > 1 and img.stride(0) == 0
+    if shared:
+        img = img[:1]
+    img = img.contiguous()
+    out = torch.empty(B, 2, H, W, dtype=torch.float32, device=img.device)
+    if B:
+        _launch("ddrr_blur_sobel_forward", img.device, img.data_ptr(), 0 if shared else H * W, B, H, W,
+                taps.data_ptr(), int(taps.numel()), out.data_ptr())
+    return out
+
+
+def blur_sobel_backward(g_out, taps):
+    """Adjoint of :func:`blur_sobel_forward`: g_out (B, 2, H, W) -> (B, H, W)."""
+    B, _, H, W = g_out.shape
+    g_out = g_out.contiguous()
+    g_img = torch.empty(B, H, W, dtype=torch.float32, device=g_out.device)
+    if B:
+        _launch("ddrr_blur_sobel_backward", g_out.device, g_out.data_ptr(), B, H, W, taps.data_ptr(),
+                int(taps.numel()), g_img.data_ptr())
+    return g_img
+
+
 def raygen_forward(Mw, Ainv, P):
     """Fused ray generation (detector.py:151-153 + drr.py:201-205).  Mw (B,3,4) world pose
     per DRR, Ainv (3,4) world -> voxel, P (N,3) calibrated detector points.

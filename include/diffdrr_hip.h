@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 31
+#define DDRR_ABI_VERSION 32
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -589,6 +589,18 @@ int ddrr_ncc_patch_backward(const float *x1, long x1_stride, const float *x2, co
  * -> g_img (B, H, W).  The similarity itself is ddrr_ncc_forward over the 2 B channel images. */
 int ddrr_sobel_forward(const float *img, int B, int H, int W, float *out, void *stream);
 int ddrr_sobel_backward(const float *g_out, int B, int H, int W, float *g_img, void *stream);
+
+/* The same with the reference's Gaussian blur in front (metrics.py:66, 88-92: Sobel(sigma > 0) calls
+ * torchvision's gaussian_blur(img, k = int(6 sigma + 1) | 1, sigma) -- REFLECT padding by k // 2, then the outer
+ * product of k normalised taps; the default of GradientNormalizedCrossCorrelation2d is sigma = 1, k = 7) in one
+ * launch each way: img (B, H, W) with img_stride = H W, or ONE image with img_stride = 0 -> out (B, 2, H, W),
+ * and the adjoint g_out (B, 2, H, W) -> g_img (B, H, W).  taps: k floats ON THE DEVICE (the host computes them
+ * as torchvision does: exp(-x^2 / 2 sigma^2) on linspace(-(k-1)/2, (k-1)/2, k), normalised), k odd, <= 31,
+ * k // 2 < min(H, W).  The blurred image is zero outside the image for the Sobel's zero padding. */
+int ddrr_blur_sobel_forward(const float *img, long img_stride, int B, int H, int W, const float *taps, int k,
+                            float *out, void *stream);
+int ddrr_blur_sobel_backward(const float *g_out, int B, int H, int W, const float *taps, int k, float *g_img,
+                             void *stream);
 
 /* ---- double precision ---------------------------------------------------------------------
  * The reference computes in the dtype its module holds: `DRR(...).to(torch.float64)` renders and

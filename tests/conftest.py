@@ -1003,7 +1003,7 @@ def check_patch_ncc_against_composition(device):
             torch.rand(1, 1, 9, 12, generator=g).to(device), torch.rand(1, 1, 9, 12, generator=g).to(device))
         assert float(one.abs().max()) < 1e-6
         for (B, C, H, W), p in (((3, 1, 21, 34), 5), ((2, 1, 40, 33), 8), ((2, 2, 19, 23), 7), ((1, 1, 9, 12), 2),
-                                ((2, 1, 12, 12), 12), ((2, 1, 50, 41), 33)):
+                                ((2, 1, 12, 12), 12), ((2, 1, 50, 41), 33), ((1, 1, 70, 66), 64)):
             fixed = (torch.rand(1, C, H, W, generator=g) * 20 + 5).to(device)
             moving = (torch.rand(B, C, H, W, generator=g) * 20 + 5).to(device)
             w = (torch.rand(B, generator=g) + 0.5).to(device)
@@ -1026,9 +1026,70 @@ def check_patch_ncc_against_composition(device):
             x0 = moving.clone().requires_grad_()
             ref(fixed.expand(B, -1, -1, -1), x0).sum().backward()
             assert rel_err(x.grad.cpu().numpy(), x0.grad.cpu().numpy()) < 5e-5
-        assert len(calls) >= 12  # (the kernels really ran)
+        assert len(calls) >= 14  # (the kernels really ran)
     finally:
         ops.ncc_patch_forward = fwd
+
+
+def check_blur_sobel_against_composition(device):
+    """ddrr_blur_sobel_forward / _backward (Sobel(sigma > 0): torchvision's gaussian_blur + the 3 x 3 pair in
+    one launch each way; reference metrics.py:66, 88-93) against the composition they replace -- reflect pad,
+    k x k depthwise conv2d, Sobel kernel, through autograd; itself pinned to the reference's fixture
+    (`gncc_sigma1`) -- on what the fixture does not cover: image sizes that are not multiples of the kernels'
+    32 x 32 tile, images barely larger than the padding (k // 2 = min(H, W) - 1: every pixel is folded),
+    3 ... 31 taps, a fixed image shared by the batch (`expand`: read in place).  33 taps take the composition."""
+    import copy
+
+    import torch
+
+    from diffdrr_amd import metrics as M
+    from diffdrr_amd import ops
+
+    calls = []
+    fwd = ops.blur_sobel_forward
+    ops.blur_sobel_forward = lambda *a, **k: (calls.append(1), fwd(*a, **k))[1]
+    try:
+        g = torch.Generator().manual_seed(5)
+        for (B, H, W), sigma in (((2, 45, 70), 1.0), ((3, 32, 64), 0.4), ((1, 4, 5), 1.0), ((2, 16, 33), 5.0),
+                                 ((2, 100, 37), 2.3), ((2, 70, 70), 5.3)):
+            img = (torch.rand(B, 1, H, W, generator=g) * 30).to(device)
+            w = torch.randn(B, 2, H, W, generator=g).to(device)
+            sob = M.Sobel(sigma)
+            ref = copy.deepcopy(sob)
+            ref._no_blur_kernel = True
+            n = len(calls)
+            res = []
+            for m in (sob, ref):
+                x = img.clone().requires_grad_()
+                out = m(x)
+                (out * w).sum().backward()
+                res.append((out.detach().cpu().numpy(), x.grad.cpu().numpy()))
+            assert (len(calls) > n) == ((int(6 * sigma + 1) | 1) <= 31), sigma
+            assert rel_err(res[0][0], res[1][0]) < 2e-6, (sigma, rel_err(res[0][0], res[1][0]))
+            assert rel_err(res[0][1], res[1][1]) < 2e-6, (sigma, rel_err(res[0][1], res[1][1]))
+            # one image for the whole batch
+            one = img[:1].clone().requires_grad_()
+            out = sob(one.expand(3, -1, -1, -1))
+            (out * w[:1]).sum().backward()
+            assert rel_err(out[2].detach().cpu().numpy(), res[1][0][0]) < 2e-6
+            assert rel_err(one.grad.cpu().numpy()[0], 3 * res[1][1][0]) < 1e-5
+        # the criterion end to end
+        a = (torch.rand(2, 1, 40, 52, generator=g) * 30).to(device)
+        b = (torch.rand(2, 1, 40, 52, generator=g) * 30).to(device)
+        for patch in (None, 9):
+            crit = M.GradientNormalizedCrossCorrelation2d(patch_size=patch, sigma=1.0)
+            ref = copy.deepcopy(crit)
+            ref.sobel._no_blur_kernel = True
+            res = []
+            for c in (crit, ref):
+                x = b.clone().requires_grad_()
+                v = c(a, x)
+                v.sum().backward()
+                res.append((v.detach().cpu().numpy(), x.grad.cpu().numpy()))
+            assert np.abs(res[0][0] - res[1][0]).max() < 2e-6
+            assert rel_err(res[0][1], res[1][1]) < 2e-5, rel_err(res[0][1], res[1][1])
+    finally:
+        ops.blur_sobel_forward = fwd
 
 
 def check_channel_words(device, ops):

@@ -25,6 +25,7 @@
 #include "../../diffdrr_amd/csrc/segments_core.h"
 #include "../../diffdrr_amd/csrc/ncc_patch_core.h"
 #include "../../diffdrr_amd/csrc/sobel_core.h"
+#include "../../diffdrr_amd/csrc/blur_core.h"
 #include "../../diffdrr_amd/csrc/tri_brick.h"
 #include "../../diffdrr_amd/csrc/trilinear_core.h"
 #include "../../diffdrr_amd/csrc/f64_core.h"
@@ -1439,6 +1440,61 @@ int ddrr_sobel_backward(const float *g, int B, int H, int W, float *g_img, void 
             for (int j = 0; j < W; ++j)
                 g_img[(long)b * H * W + i * W + j] = sobel_pixel_adjoint(
                     g + ((long)b * 2) * H * W, g + ((long)b * 2 + 1) * H * W, H, W, i, j);
+    return 0;
+}
+
+// blur_core.h's passes over whole images (the device does them per tile through LDS, pose_ncc.hip)
+int ddrr_blur_sobel_forward(const float *img, long img_stride, int B, int H, int W, const float *taps, int k,
+                            float *out, void *) {
+    if (k < 1 || k > kBlurMaxTaps || !(k & 1) || (k >> 1) >= H || (k >> 1) >= W) return -1;
+    const int r = k >> 1;
+    std::vector<float> tmp((size_t)H * W), bl((size_t)H * W);
+    for (int b = 0; b < B; ++b) {
+        const float *src = img + b * img_stride;
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < W; ++j) {
+                float s = 0.f;
+                for (int t = 0; t < k; ++t) s = fmaf(taps[t], src[(long)i * W + blur_reflect(j + t - r, W)], s);
+                tmp[(size_t)i * W + j] = s;
+            }
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < W; ++j) {
+                float s = 0.f;
+                for (int t = 0; t < k; ++t) s = fmaf(taps[t], tmp[(size_t)blur_reflect(i + t - r, H) * W + j], s);
+                bl[(size_t)i * W + j] = s;
+            }
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < W; ++j)
+                sobel_pixel(bl.data(), H, W, i, j, out[((long)b * 2) * H * W + i * W + j],
+                            out[((long)b * 2 + 1) * H * W + i * W + j]);
+    }
+    return 0;
+}
+
+int ddrr_blur_sobel_backward(const float *g, int B, int H, int W, const float *taps, int k, float *g_img, void *) {
+    if (k < 1 || k > kBlurMaxTaps || !(k & 1) || (k >> 1) >= H || (k >> 1) >= W) return -1;
+    const int r = k >> 1;
+    std::vector<float> gb((size_t)H * W), tmp((size_t)H * W);
+    for (int b = 0; b < B; ++b) {
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < W; ++j)
+                gb[(size_t)i * W + j] = sobel_pixel_adjoint(g + ((long)b * 2) * H * W, g + ((long)b * 2 + 1) * H * W,
+                                                            H, W, i, j);
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < W; ++j) {
+                float s = 0.f;
+                for (int o = i - r < 0 ? 0 : i - r; o <= i + r && o < H; ++o)
+                    s = fmaf(blur_adjoint_weight(taps, k, i, o, H), gb[(size_t)o * W + j], s);
+                tmp[(size_t)i * W + j] = s;
+            }
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < W; ++j) {
+                float s = 0.f;
+                for (int o = j - r < 0 ? 0 : j - r; o <= j + r && o < W; ++o)
+                    s = fmaf(blur_adjoint_weight(taps, k, j, o, W), tmp[(size_t)i * W + o], s);
+                g_img[(long)b * H * W + i * W + j] = s;
+            }
+    }
     return 0;
 }
 

@@ -1079,5 +1079,10 @@ def test_patch_ncc_kernels_against_the_composition(emulated_ops):
     conftest.check_patch_ncc_against_composition(torch.device("cpu"))
 
 
+def test_blur_sobel_kernels_against_the_composition(emulated_ops):
+    """(host build of blur_core.h; the device twin: tests/test_gpu_parity.py)"""
+    conftest.check_blur_sobel_against_composition(torch.device("cpu"))
+
+
 def test_channel_render_from_ready_packed_words_on_the_host(emulated_ops):
     conftest.check_channel_words("cpu", emulated_ops)

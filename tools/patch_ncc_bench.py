@@ -1,6 +1,7 @@
 """Patch-wise / multiscale / gradient NCC (reference metrics.py:16-107) with the fused window kernels against the
 `to_patches` composition they replace (development tool, GPU): 256 x 256 images, forward + backward w.r.t. the moving
 image, ms per call."""
+import gc
 import os
 import sys
 
@@ -10,6 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffdrr_amd import metrics as M  # noqa: E402
 
 dev = torch.device("cuda:0")
+gc.collect()
+gc.disable()  # (a generation-2 pass inside a 20-call timed region reads as +2 ms per call)
 
 
 def timed(fn, warm=10, n=20):
@@ -31,6 +34,8 @@ def unfused(crit):
     c = copy.deepcopy(crit)
     for m in [c] + list(getattr(c, "nccs", [])):
         m._no_patch_kernel = True
+    if hasattr(c, "sobel"):
+        c.sobel._no_blur_kernel = True
     return c
 
 
