@@ -560,8 +560,13 @@ def run_config(cfg, args, rt, short=False, batch=None, parity=True):
             if args.criterion != "ncc":
                 from diffdrr_amd.metrics import (GradientNormalizedCrossCorrelation2d,
                                                  MultiscaleNormalizedCrossCorrelation2d)
-                crit = (MultiscaleNormalizedCrossCorrelation2d([13, None], [0.5, 0.5]) if args.criterion == "multiscale"
-                        else GradientNormalizedCrossCorrelation2d(patch_size=9, sigma=1.0))
+                # ("gradient": the class's own defaults, metrics.py:99 -- whole-image NCC of the blurred Sobel
+                #  pair; with patch_size=9 the phantom's smooth projections leave most windows flat and the
+                #  notebook's learning rates walk away from the optimum: a timing run only)
+                crit = {"multiscale": lambda: MultiscaleNormalizedCrossCorrelation2d([13, None], [0.5, 0.5]),
+                        "gradient": lambda: GradientNormalizedCrossCorrelation2d(),
+                        "gradient_patch9": lambda: GradientNormalizedCrossCorrelation2d(patch_size=9, sigma=1.0),
+                        }[args.criterion]()
             graphed = GraphedIteration(reg, crit, opt, gt)
             extra["registration"] = {"hip_graph": True, "criterion": args.criterion}
         except Exception as exc:  # noqa: BLE001
@@ -1496,11 +1501,12 @@ def main():
                     help="DRR.FUSED_NCC_MAX_POSES for this run (measurement: where the fused step stops paying)")
     ap.add_argument("--torch-adam", action="store_true",
                     help="config 4: torch.optim.Adam(fused, capturable) instead of diffdrr_amd.PoseAdam")
-    ap.add_argument("--criterion", default="ncc", choices=["ncc", "multiscale", "gradient"],
+    ap.add_argument("--criterion", default="ncc", choices=["ncc", "multiscale", "gradient", "gradient_patch9"],
                     help="config 4: the similarity of the registration loop -- NormalizedCrossCorrelation2d (the fused "
-                         "step), MultiscaleNormalizedCrossCorrelation2d([13, None], [0.5, 0.5]) (metrics.ipynb:94) or "
-                         "GradientNormalizedCrossCorrelation2d(patch_size=9, sigma=1): composed from the renderer and "
-                         "the metric kernels inside the same HIP graph")
+                         "step), MultiscaleNormalizedCrossCorrelation2d([13, None], [0.5, 0.5]) (metrics.ipynb:94), "
+                         "GradientNormalizedCrossCorrelation2d() or GradientNormalizedCrossCorrelation2d(patch_size=9, "
+                         "sigma=1) (a timing run: it does not converge on the phantom): composed from the renderer "
+                         "and the metric kernels inside the same HIP graph")
     ap.add_argument("--packed-record", action="store_true",
                     help="Siddon.packed_record = True (the opt-in fixed-point backward record)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
