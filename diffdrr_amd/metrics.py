@@ -222,4 +222,15 @@ class MultiscaleNormalizedCrossCorrelation2d(torch.nn.Module):
         self.patch_weights = patch_weights
 
     def forward(self, x1, x2):
-        return sum(w * ncc(x1, x2) for w, ncc in zip(self.patch_weights, self.nccs))
+        # sum_i w_i ncc_i (reference metrics.py:58-63: the weighted scores stacked and summed) with one
+        # launch per scale: the first scaled, the others added with their weight as `alpha`
+        total = None
+        for w, ncc in zip(self.patch_weights, self.nccs):
+            v = ncc(x1, x2)
+            if total is None:
+                total = v * w
+            elif isinstance(w, (int, float)):
+                total = torch.add(total, v, alpha=w)
+            else:  # (a tensor weight)
+                total = total + v * w
+        return total
