@@ -148,3 +148,6 @@ mkdir -p gpurun_out/r06y; (cd r05tree && python tools/fuzz_bricks.py --cases 64 
 # ---------------------------------------------------------------- 2026-10-01T06:07:25Z  r06: bench of the final bench.py
 mkdir -p gpurun_out/r06x; python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06x/bench_line_driver_command.json 2> gpurun_out/r06x/stderr.txt; echo rc=$?; cp bench_full.json gpurun_out/r06x/; python -c "
 import json; l=open(\"gpurun_out/r06x/bench_line_driver_command.json\").read().strip().splitlines(); print(len(l), len(l[-1])); d=json.loads(l[-1]); print(d[\"value\"], d[\"ms_per_step\"], d[\"roofline\"][\"frac\"], d[\"roofline\"][\"step_minus_kernel_ms\"], [k for k,v in d[\"configs\"].items() if \"error\" in v])"
+
+# ---------------------------------------------------------------- 2026-10-01T07:01:49Z  r06: evidence refresh on the final tree (ABI 32)
+mkdir -p gpurun_out/r06y; python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^$" > gpurun_out/r06y/gpu_suite_full.txt; tail -1 gpurun_out/r06y/gpu_suite_full.txt; python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r06y/smoke.txt 2>&1; tail -1 gpurun_out/r06y/smoke.txt; tools/prof_bench.sh gpurun_out/r06yprof > gpurun_out/r06y/rocprof_bench.txt 2>&1; python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06y/bench_line_driver_command.json 2> gpurun_out/r06y/bench_stderr_driver_command.txt; echo rc=$?; cp bench_full.json gpurun_out/r06y/bench_full_driver_command.json; python bench.py > gpurun_out/r06y/bench_line_default.json 2> gpurun_out/r06y/bench_stderr_default.txt; cp bench_full.json gpurun_out/r06y/bench_full.json; for c in 2 3 4 5; do python bench.py --config $c > gpurun_out/r06y/bench_line_config_$c.json 2>/dev/null; cp bench_full.json gpurun_out/r06y/bench_config_$c.json; done; for c in ncc multiscale gradient gradient_patch9; do python bench.py --config 4 --criterion $c 2>/dev/null | tail -1 > gpurun_out/r06y/c4_$c.json; done; python tools/patch_ncc_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06y/patch_ncc.txt; wc -c gpurun_out/r06y/bench_line_*.json; head -9 gpurun_out/r06y/rocprof_bench.txt | cut -c1-150; cp gpurun_out/r06yprof/traffic.json gpurun_out/r06y/ 2>/dev/null; find gpurun_out/r06yprof -name "*kernel_stats.csv" -exec cp {} gpurun_out/r06y/rocprof_bench_kernel_stats.csv \;; cp gpurun_out/r06yprof/bench_line_under_trace.json gpurun_out/r06y/
