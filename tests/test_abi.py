@@ -66,6 +66,53 @@ def test_library_builds_loads_and_exports_every_symbol():
     assert every == set(_declared()), every ^ set(_declared())
 
 
+def test_every_entry_rejects_null_pointers_and_negative_sizes_before_any_launch():
+    """The boundary's error behaviour (include/diffdrr_hip.h: "0 on success, a negative code and
+    ddrr_last_error() otherwise"): every status-returning entry point checks its arguments BEFORE it
+    touches a device -- so it can be shown without one.  All pointers NULL: -1 and a message that names
+    the pointers; pointers to host memory with every size -1: -1 and a message that names the size (or
+    the enum) that is wrong.  No entry gets as far as a launch (which, here, would report the missing
+    device instead).  The reference raises Python exceptions for bad arguments (drr.py:99-101,
+    renderers.py:183); through the binding these codes surface as RuntimeError (_lib.DdrrLibrary.call)."""
+    import ctypes
+
+    import __graft_entry__ as entry
+
+    entry.build_hip()
+    lib = _lib.DdrrLibrary(_lib.LIB_PATH)
+    buf = (ctypes.c_char * 4096)()
+    addr = ctypes.addressof(buf)
+    status_entries = [n for n in _lib._SIGNATURES if n not in _lib._RESTYPES]
+    assert len(status_entries) >= 54
+    for name in status_entries:
+        argtypes = _lib._SIGNATURES[name]
+        for pointers, ints, expect in ((None, 0, "null"), (addr, -1, None)):
+            args = [pointers if t is _lib._P else (ints if t in (_lib._I, _lib._L) else 0.0) for t in argtypes]
+            args[-1] = None  # the stream
+            rc = getattr(lib.cdll, name)(*args)
+            msg = lib.cdll.ddrr_last_error().decode(errors="replace")
+            assert rc < 0 and msg, (name, rc, msg)
+            assert "hip" not in msg.lower() and "device" not in msg.lower(), (name, msg)  # (never launched)
+            if expect:
+                assert expect in msg, (name, msg)
+        # ... and through the binding: an exception that carries the entry's name and its message
+        with pytest.raises(RuntimeError, match=name):
+            lib.call(name, *[None if t is _lib._P else (0 if t in (_lib._I, _lib._L) else 0.0) for t in argtypes])
+    # argument rules of the image-space similarity entries, one by one
+    for name, args, what in (
+            ("ddrr_blur_sobel_forward", (addr, 64, 1, 8, 8, addr, 4, addr, None), "odd number of taps"),
+            ("ddrr_blur_sobel_forward", (addr, 64, 1, 8, 8, addr, 33, addr, None), "odd number of taps"),
+            ("ddrr_blur_sobel_forward", (addr, 16, 1, 4, 4, addr, 9, addr, None), "reflect padding"),
+            ("ddrr_blur_sobel_forward", (addr, 3, 1, 8, 8, addr, 7, addr, None), "img_stride"),
+            ("ddrr_blur_sobel_backward", (addr, 1, 8, 3, addr, 7, addr, None), "reflect padding"),
+            ("ddrr_ncc_patch_forward", (addr, 64, addr, 1, 8, 8, 9, 1e-5, addr, None, None), "patch_size"),
+            ("ddrr_ncc_patch_forward", (addr, 5, addr, 1, 8, 8, 3, 1e-5, addr, None, None), "x1_stride"),
+            ("ddrr_ncc_patch_backward", (addr, 64, addr, addr, addr, 2, 1, 8, 8, 3, addr, None), "g_stride"),
+            ("ddrr_sobel_forward", (addr, 70000, 8, 8, addr, None), "65535")):
+        with pytest.raises(RuntimeError, match=what):
+            lib.call(name, *args)
+
+
 def test_library_contains_gfx950_code_object():
     import __graft_entry__ as entry
 
