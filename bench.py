@@ -1496,7 +1496,8 @@ def main():
                     help="Siddon.brick_storage (default: the module's default, q16p)")
     ap.add_argument("--unfused", action="store_true",
                     help="headline / config 2: the step as DRR.forward + the NCC module through autograd "
-                         "(nine small launches around the brick kernel) instead of DRR.ncc (three)")
+                         "(six small launches around the brick kernel; nine before the render became one autograd node) "
+                         "instead of DRR.ncc (three)")
     ap.add_argument("--fused-max-poses", type=int, default=None,
                     help="DRR.FUSED_NCC_MAX_POSES for this run (measurement: where the fused step stops paying)")
     ap.add_argument("--torch-adam", action="store_true",

@@ -15,7 +15,7 @@ from ctypes import c_double, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffdrr_hip.so")
-ABI_VERSION = 32
+ABI_VERSION = 33
 BRICKS_CLEARED = 2  # include/diffdrr_hip.h DDRR_BRICKS_CLEARED (a bit of ranges_valid)
 
 REDUCE_SUM, REDUCE_MAX = 0, 1
@@ -92,6 +92,8 @@ _SIGNATURES = {
     "ddrr_siddon_ncc_forward": [_P, _P, _P, _L, _I, _I, _F, _P, _P, _P, _P, _P, _P],
     "ddrr_siddon_ncc_backward_pose": [_P, _P, _P, _L, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I,
                                       _P, _I, _I, _F, _I, _P, _P, _P, _P],
+    "ddrr_siddon_backward_pose_euler": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _F, _I, _P,
+                                        _P, _P, _P],
     "ddrr_pose_adam_step": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _P],
     "ddrr_ncc_forward": [_P, _L, _P, _I, _I, _F, _P, _P, _P],
     "ddrr_ncc_backward": [_P, _L, _P, _P, _P, _I, _I, _I, _P, _P, _P],

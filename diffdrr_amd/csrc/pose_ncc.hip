@@ -369,7 +369,10 @@ __global__ __launch_bounds__(kBlock) void siddon_ncc_fwd_kernel(
     }
 }
 
-template <int kStepRaysPerBlock>
+// EXPLICIT: the per-pixel gradient of ANY image-space objective arrives ready-made in `x1` ((B, N),
+// x1_stride = N; stats and g_out unused) instead of being formed from the NCC statistics:
+// ddrr_siddon_backward_pose_euler, the differentiable `drr(rot, xyz, parameterization="euler_angles")`.
+template <int kStepRaysPerBlock, bool EXPLICIT = false>
 __global__ __launch_bounds__(kBlock) void siddon_ncc_bwd_pose_kernel(
     const float *__restrict__ aux, const float *__restrict__ img, const float *__restrict__ x1,
     long x1_stride, const float *__restrict__ stats, const float *__restrict__ g_out, int g_stride,
@@ -384,9 +387,12 @@ __global__ __launch_bounds__(kBlock) void siddon_ncc_bwd_pose_kernel(
     const int b = blockIdx.y;
     const float *M = Mw + (long)b * 12;
     const float s[3] = {source_v[b * 3], source_v[b * 3 + 1], source_v[b * 3 + 2]};
-    const float mu1 = stats[b * 5], s1 = stats[b * 5 + 1], mu2 = stats[b * 5 + 2];
-    const float s2 = stats[b * 5 + 3], ncc = stats[b * 5 + 4];
-    const float gn = g_out[b * g_stride] / (float)N;
+    float mu1 = 0.f, s1 = 1.f, mu2 = 0.f, s2 = 1.f, ncc = 0.f, gn = 0.f;
+    if constexpr (!EXPLICIT) {
+        mu1 = stats[b * 5], s1 = stats[b * 5 + 1], mu2 = stats[b * 5 + 2];
+        s2 = stats[b * 5 + 3], ncc = stats[b * 5 + 4];
+        gn = g_out[b * g_stride] / (float)N;
+    }
     float acc[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.f;
@@ -418,8 +424,13 @@ __global__ __launch_bounds__(kBlock) void siddon_ncc_bwd_pose_kernel(
         const RayGenOut ray = raygen_ray(M, Ainv, Ps[k]);
         const float L = ray.L;
         // d ncc / d x2[n] (= ncc_bwd_kernel on x2 = L I)
-        const float z1 = (x1s[k] - mu1) / s1, z2 = (L * rec[k][0] - mu2) / s2;
-        const float g = in[k] ? gn * (z1 - z2 * ncc) / s2 : 0.f;
+        float g;
+        if constexpr (EXPLICIT) {
+            g = in[k] ? x1s[k] : 0.f;
+        } else {
+            const float z1 = (x1s[k] - mu1) / s1, z2 = (L * rec[k][0] - mu2) / s2;
+            g = in[k] ? gn * (z1 - z2 * ncc) / s2 : 0.f;
+        }
         float gs[3], gt[3];
         siddon_backward_ray<REDUCE_SUM>(rec[k], s, ray.tv, eps, g * L, gs, gt);
         raygen_ray_adjoint(M, Ainv, Ps[k], gt, gs, with_img_path ? g * rec[k][0] : 0.f, L, acc);
@@ -1028,6 +1039,31 @@ int ddrr_siddon_ncc_backward_pose(const float *aux, const float *img, const floa
                            target_v, Mw, Ainv, P, rot, xyz, a0, a1, a2, reorient34, B, N, eps, with_img_path,
                            ws, g_rot, g_xyz);
     return finish("ddrr_siddon_ncc_backward_pose");
+}
+
+int ddrr_siddon_backward_pose_euler(const float *aux, const float *grad_out, const float *source_v,
+                                    const float *Mw, const float *Ainv, const float *P, const float *rot,
+                                    const float *xyz, int a0, int a1, int a2, const float *reorient34, int B,
+                                    int N, float eps, int with_img_path, void *ws, float *g_rot, float *g_xyz,
+                                    void *stream) {
+    if (!aux || !grad_out || !source_v || !Mw || !Ainv || !P || !rot || !xyz || !reorient34 || !ws || !g_rot ||
+        !g_xyz)
+        return fail(-1, "null pointer");
+    if (int rc = check_axes(a0, a1, a2)) return rc;
+    if (B < 0 || N < 1) return fail(-1, "bad batch / image size");
+    if (B == 0) return 0;
+    if (B > 65535) return fail(-1, "at most 65535 poses per call");
+    const dim3 block(kBlock);
+    const float *none = nullptr;
+    if ((long)B * ((N + 2047) / 2048) >= kStepWorkgroupsWanted)
+        hipLaunchKernelGGL((siddon_ncc_bwd_pose_kernel<2048, true>), dim3((N + 2047) / 2048, B), block, 0,
+                           (hipStream_t)stream, aux, none, grad_out, (long)N, none, none, 0, source_v, none, Mw,
+                           Ainv, P, rot, xyz, a0, a1, a2, reorient34, B, N, eps, with_img_path, ws, g_rot, g_xyz);
+    else
+        hipLaunchKernelGGL((siddon_ncc_bwd_pose_kernel<1024, true>), dim3((N + 1023) / 1024, B), block, 0,
+                           (hipStream_t)stream, aux, none, grad_out, (long)N, none, none, 0, source_v, none, Mw,
+                           Ainv, P, rot, xyz, a0, a1, a2, reorient34, B, N, eps, with_img_path, ws, g_rot, g_xyz);
+    return finish("ddrr_siddon_backward_pose_euler");
 }
 
 int ddrr_ncc_patch_forward(const float *x1, long x1_stride, const float *x2, int B, int H, int W, int p,

@@ -130,6 +130,10 @@ class DRR(nn.Module):
                 img = self._render_euler_inference(args[0], args[1], convention, degrees)
                 if img is not None:
                     return self._reshape_fused(img, len(args[0]))
+            if not mask_to_channels and calibration is None and not kwargs:
+                img = self._render_euler_differentiable(args[0], args[1], convention, degrees)
+                if img is not None:
+                    return self._reshape_fused(img, len(args[0]))
             # pose parameters -> world matrix in one kernel (pose.py euler_world_pose)
             Mw = euler_world_pose(args[0], args[1], convention, self.detector._reorient,
                                   degrees=degrees)
@@ -365,6 +369,36 @@ class DRR(nn.Module):
                                       cleared=True, pixel_mask=det.subsample_mask())
         if det.n_subsample is not None:  # (p_subsample: the scattered grid, see _reshape_fused)
             return _ScatteredGrid(out.unsqueeze(1))
+        return out.unsqueeze(1)
+
+    def _render_euler_differentiable(self, rot, xyz, convention, degrees):
+        """``drr(rot, xyz, parameterization="euler_angles")`` with pose parameters that take a gradient
+        and a similarity computed outside (any criterion of ``metrics``, a user's loss): the render's
+        forward in three launches and its backward in one (``renderers._EulerSiddonImageFn``) where the
+        composition of ``euler_world_pose`` and ``render_poses`` takes five and three.  None where that
+        does not apply -- a dense Siddon render on the bricks of a volume that takes no gradient, at most
+        ``FUSED_NCC_MAX_POSES`` poses (beyond, the launches are bound by their bytes, not their count)."""
+        from .pose import _AXIS, _check_convention
+        from .renderers import _EulerSiddonImageFn
+
+        r, det = self.renderer, self.detector
+        B = rot.shape[0]
+        if not (torch.is_grad_enabled() and (rot.requires_grad or xyz.requires_grad)
+                and not self.density.requires_grad and isinstance(r, Siddon) and r.grid_path == "bricks"
+                and not r.packed_record and 0 < B <= self.FUSED_NCC_MAX_POSES and rot.shape == xyz.shape
+                and rot.device == self.density.device == xyz.device
+                and self.patch_size is None and det.n_subsample is None and self.fuse_ray_generation):
+            return None
+        _check_convention(convention)
+        if degrees:
+            rot = rot / 180 * math.pi
+        axes = tuple(_AXIS[c] for c in convention)
+        P = self._calibrated_points()
+        Ainv = self._affine_inverse[0, :3, :] if self._affine_inverse.dim() == 3 \
+            else self._affine_inverse[:3, :]
+        cfg = r._cfg(False, det=(det.height, det.width))
+        out = _EulerSiddonImageFn.apply(rot, xyz, self.density, det._reorient[:3, :].contiguous(), P, Ainv,
+                                        axes, cfg)
         return out.unsqueeze(1)
 
     FUSED_NCC_MAX_POSES = 32

@@ -384,9 +384,9 @@ def siddon_forward_bricks(volume, source, target, img, det, *, voxel_shift=0.5, 
         out = torch.empty(B, N, dtype=torch.float32, device=volume.device)
     ranges, valid = brick_workspace(volume, storage) if storage != "f32" else (None, 0)
     packed = bool(want_aux and record_vmax and record_vmax > 0.0)
-    if cleared and (launch_ws is None or packed or (want_aux and (aux is None or want_image))):
-        raise ValueError("cleared=True: the float record (no image with it) or the image, and the launch "
-                         "workspace, as the caller cleared them")
+    if cleared and (launch_ws is None or packed or (want_aux and aux is None)):
+        raise ValueError("cleared=True: the float record (an image with it is formed from the record afterwards) "
+                         "or the image, and the launch workspace, as the caller cleared them")
     if want_aux and aux is None:
         shape = (_lib.PACKED_AUX_PLANES, B, N) if packed else \
             (record_blocks(B, N), _lib.REC_BLOCK_FLOATS)
@@ -726,6 +726,24 @@ def siddon_ncc_backward_pose(aux, img, x1, stats, g_out, source, target, Mw, Ain
                 xyz.data_ptr(), *axes, reorient34.data_ptr(), B, N, float(eps),
                 int(bool(with_img_path)), siddon_ncc_workspace(B, dev).data_ptr(), g_rot.data_ptr(),
                 g_xyz.data_ptr())
+    return g_rot, g_xyz
+
+
+def siddon_backward_pose_euler(aux, grad_out, source, Mw, Ainv, P, rot, xyz, axes, reorient34, *, eps=1e-8,
+                               with_img_path=True):
+    """(g_rot (B,3), g_xyz (B,3)) of any objective of the image with per-pixel gradient ``grad_out`` (B, N):
+    siddon_backward_pose and pose_euler_backward in one launch (the rays as pose_raygen_forward made them)."""
+    B, N = grad_out.shape
+    grad_out, source = grad_out.contiguous(), source.contiguous()
+    Mw, Ainv, P, rot, xyz, reorient34 = (t.contiguous() for t in (Mw, Ainv, P, rot, xyz, reorient34))
+    dev = grad_out.device
+    g_rot = torch.empty(B, 3, dtype=torch.float32, device=dev)
+    g_xyz = torch.empty(B, 3, dtype=torch.float32, device=dev)
+    if B:
+        _launch("ddrr_siddon_backward_pose_euler", dev, aux.data_ptr(), grad_out.data_ptr(), source.data_ptr(),
+                Mw.data_ptr(), Ainv.data_ptr(), P.data_ptr(), rot.data_ptr(), xyz.data_ptr(), *axes,
+                reorient34.data_ptr(), B, N, float(eps), int(bool(with_img_path)),
+                siddon_ncc_workspace(B, dev).data_ptr(), g_rot.data_ptr(), g_xyz.data_ptr())
     return g_rot, g_xyz
 
 

@@ -529,6 +529,38 @@ class _EulerSiddonNccFn(torch.autograd.Function):
         return g_rot, g_xyz, None, None, None, None, None, None, None, None, None
 
 
+class _EulerSiddonImageFn(torch.autograd.Function):
+    """``drr(rot, xyz, parameterization="euler_angles")`` for pose parameters that take a gradient, when the
+    similarity is computed OUTSIDE the render (reference registration.py:32-42 with any criterion of
+    metrics.py, or a user's own loss): forward ddrr_pose_raygen_forward (pose -> matrix -> rays, and the
+    clears of the render behind it) + the brick kernel with its record + the image from the record -- three
+    launches for five; backward ddrr_siddon_backward_pose_euler -- one for three (a fill, the record's ray
+    gradients reduced to dL/dMw, matrix -> pose parameters).  Same arithmetic per element as
+    ``_PoseEulerFn`` + ``_SiddonPoseFn``; (rot, xyz) -> image (B, N)."""
+
+    @staticmethod
+    def forward(ctx, rot, xyz, volume, reorient34, P, Ainv, axes, cfg):
+        B, N = rot.shape[0], P.shape[0]
+        aux = ops.brick_record_buffer(B, N, rot.device)
+        launch_ws = ops.launch_workspace(volume.shape, volume.device)
+        Mw, source, target, img = ops.pose_raygen_forward(rot, xyz, axes, reorient34, Ainv, P,
+                                                          clear=aux, clear_launch_ws=launch_ws)
+        out, _ = ops.siddon_forward_bricks(
+            volume, source, target, img, cfg["det"], voxel_shift=cfg["voxel_shift"], eps=cfg["eps"],
+            want_aux=True, storage=_brick_storage(volume, cfg, B), aux=aux, launch_ws=launch_ws, cleared=True)
+        ctx.axes, ctx.cfg = axes, cfg
+        ctx.save_for_backward(rot, xyz, reorient34, P, Ainv, Mw, source, aux)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rot, xyz, reorient34, P, Ainv, Mw, source, aux = ctx.saved_tensors
+        g_rot, g_xyz = ops.siddon_backward_pose_euler(
+            aux, g, source, Mw, Ainv, P, rot, xyz, ctx.axes, reorient34, eps=ctx.cfg["eps"],
+            with_img_path=not ctx.cfg["stop_gradients"])
+        return g_rot, g_xyz, None, None, None, None, None, None
+
+
 def _cat_channels(blocks):
     """Channel blocks of the label chunks side by side (one chunk -- up to 256 labels -- is the
     result itself: no copy of the (B, C, N) tensor)."""

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define DDRR_ABI_VERSION 32
+#define DDRR_ABI_VERSION 33
 
 #define DDRR_REDUCE_SUM 0 /* reducefn="sum"  renderers.py:176-177 */
 #define DDRR_REDUCE_MAX 1 /* reducefn="max"  renderers.py:178-179 */
@@ -536,6 +536,19 @@ int ddrr_siddon_ncc_backward_pose(const float *aux, const float *img, const floa
                                   int a0, int a1, int a2, const float *reorient34, int B, int N,
                                   float eps, int with_img_path, void *ws, float *g_rot, float *g_xyz,
                                   void *stream);
+
+/* ddrr_siddon_backward_pose + ddrr_pose_euler_backward in one launch (ABI 33): (g_rot, g_xyz) (B, 3) of ANY
+ * objective of the image, given its per-pixel gradient grad_out (B, N) -- what autograd hands the render of
+ * `drr(rot, xyz, parameterization="euler_angles")` (reference drr.py:155-188, registration.py:32-33) when
+ * the similarity is computed outside it (MultiscaleNormalizedCrossCorrelation2d, GradientNormalized-
+ * CrossCorrelation2d, a user's own loss).  The same kernel as ddrr_siddon_ncc_backward_pose with the
+ * gradient read instead of formed from NCC statistics; aux, source_v, Mw and ws as there (rays from
+ * ddrr_pose_raygen_forward for (rot, xyz, reorient34, Ainv, P); ws: ddrr_siddon_ncc_workspace_bytes(B)). */
+int ddrr_siddon_backward_pose_euler(const float *aux, const float *grad_out, const float *source_v,
+                                    const float *Mw, const float *Ainv, const float *P, const float *rot,
+                                    const float *xyz, int a0, int a1, int a2, const float *reorient34, int B,
+                                    int N, float eps, int with_img_path, void *ws, float *g_rot, float *g_xyz,
+                                    void *stream);
 
 /* One Adam step of a registration's two pose parameter groups in ONE launch (ABI 30): rot, xyz
  * (B, 3) updated in place from their gradients, with torch.optim.Adam's update rule (no weight

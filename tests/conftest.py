@@ -668,7 +668,7 @@ def check_filter_intersections_outside_volume(device):
 def check_euler_inference_path(device):
     """``drr(rot, xyz, parameterization="euler_angles")`` with nothing to differentiate takes two
     launches (DRR._render_euler_inference: pose -> matrix -> rays + the clears, the brick kernel);
-    with a gradient wanted it takes the differentiable path (pose, rays, clear, render): the same
+    with a gradient wanted it takes a differentiable path (check_euler_differentiable_path): the same
     kernels' arithmetic, so the images agree to the atomics' order of summation -- in radians and
     degrees, for every brick storage, and through ``convert`` + ``drr(pose)`` (reference
     drr.py:155-188)."""
@@ -699,6 +699,66 @@ def check_euler_inference_path(device):
         assert float((fast_deg - fast).abs().max()) <= 2e-5 * scale
         assert float((via_pose - fast).abs().max()) <= 2e-5 * scale
     assert len(calls) == 6  # (both no-grad calls of every storage)
+
+
+def check_euler_differentiable_path(device, ops=None, calls=None):
+    """``drr(rot, xyz, parameterization="euler_angles")`` with pose parameters that take a gradient and the
+    similarity computed outside the render (reference registration.py:32-42 with any criterion): the
+    render's forward in three launches, its backward in ONE (DRR._render_euler_differentiable,
+    renderers._EulerSiddonImageFn: ddrr_pose_raygen_forward with the clears, the brick kernel with its
+    record, the image from the record | ddrr_siddon_backward_pose_euler) against the composition it
+    replaces (euler_world_pose + render_poses: five and three launches; switched back on by
+    FUSED_NCC_MAX_POSES = 0) -- images and the gradients of a random per-pixel weighting and of a criterion,
+    in radians and degrees, two conventions, with and without stop_gradients_through_grid_sample, every
+    brick storage.  The composition is itself pinned to the reference's fixtures (test_drr_module_golden,
+    the registration trajectory)."""
+    import torch
+
+    from diffdrr_amd import DRR
+    from diffdrr_amd.data import synthetic_subject
+    from diffdrr_amd.metrics import MultiscaleNormalizedCrossCorrelation2d
+
+    g = torch.Generator().manual_seed(21)
+    for stop, storage, conv, deg, B in ((False, "f32", "ZXY", False, 3), (True, "q16p", "ZYX", True, 1),
+                                        (False, "q16", "ZXY", False, 2)):
+        drr = DRR(synthetic_subject(40, kind="phantom", seed=3), sdd=600.0, height=30, width=26, delx=3.0,
+                  stop_gradients_through_grid_sample=stop).to(device)
+        drr.renderer.brick_storage = storage
+        rot0 = ((torch.rand(B, 3, generator=g) - 0.5) * 0.8)
+        rot0 = (rot0 * 180 / torch.pi if deg else rot0).to(device)
+        xyz0 = (torch.tensor([0.0, 400.0, 0.0]) + (torch.rand(B, 3, generator=g) - 0.5) * 20).to(device)
+        w = torch.randn(B, 1, 30, 26, generator=g).to(device)
+        with torch.no_grad():
+            fixed = drr(rot0[:1] * 0, xyz0[:1], parameterization="euler_angles", convention=conv)
+        crit = MultiscaleNormalizedCrossCorrelation2d([None, 7], [0.5, 0.5])
+        res = []
+        for cap in (DRR.FUSED_NCC_MAX_POSES, 0):
+            drr.FUSED_NCC_MAX_POSES = cap
+            n = len(calls) if calls is not None else 0
+            rot, xyz = rot0.clone().requires_grad_(), xyz0.clone().requires_grad_()
+            img = drr(rot, xyz, parameterization="euler_angles", convention=conv, degrees=deg)
+            loss = (img * w).sum() + 100.0 * crit(fixed.expand(B, -1, -1, -1), img).sum()
+            loss.backward()
+            res.append((img.detach(), rot.grad.clone(), xyz.grad.clone()))
+            if calls is not None:
+                took = [c for c in calls[n:] if c == "ddrr_siddon_backward_pose_euler"]
+                assert len(took) == (1 if cap else 0), (cap, calls[n:])
+        (i1, r1, x1), (i0, r0, x0) = res
+        scale = float(i0.abs().max())
+        assert i1.shape == i0.shape == (B, 1, 30, 26) and scale > 0
+        assert float((i1 - i0).abs().max()) <= 2e-6 * scale, storage
+        for a, b in ((r1, r0), (x1, x0)):
+            assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7, (storage, a, b)
+    # what the route leaves alone: a volume that takes a gradient, more poses than the cap
+    drr = DRR(synthetic_subject(24, kind="phantom", seed=3), sdd=600.0, height=16, delx=4.0).to(device)
+    rot = torch.zeros(2, 3, device=device, requires_grad=True)
+    xyz = torch.tensor([[0.0, 400.0, 0.0]] * 2, device=device)
+    assert drr._render_euler_differentiable(rot, xyz, "ZXY", False) is not None
+    drr.density.requires_grad_(True)
+    assert drr._render_euler_differentiable(rot, xyz, "ZXY", False) is None
+    drr.density.requires_grad_(False)
+    with torch.no_grad():
+        assert drr._render_euler_differentiable(rot, xyz, "ZXY", False) is None
 
 
 def check_pose_adam(device):

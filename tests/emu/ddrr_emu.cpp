@@ -1668,6 +1668,25 @@ int ddrr_siddon_ncc_backward_pose(const float *aux, const float *img, const floa
     return ddrr_pose_euler_backward(rot, xyz, a0, a1, a2, reorient34, gMw.data(), B, g_rot, g_xyz, st);
 }
 
+int ddrr_siddon_backward_pose_euler(const float *aux, const float *grad_out, const float *source_v,
+                                    const float *Mw, const float *Ainv, const float *P, const float *rot,
+                                    const float *xyz, int a0, int a1, int a2, const float *reorient34, int B,
+                                    int N, float eps, int with_img_path, void *, float *g_rot, float *g_xyz,
+                                    void *st) {
+    // (the rays' targets and lengths as the device regenerates them: raygen_core.h raygen_ray)
+    std::vector<float> target((size_t)B * N * 3), img((size_t)B * N), gMw((size_t)B * 12);
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n) {
+            const RayGenOut ray = raygen_ray(Mw + (long)b * 12, Ainv, P + (long)n * 3);
+            for (int a = 0; a < 3; ++a) target[((long)b * N + n) * 3 + a] = ray.tv[a];
+            img[(long)b * N + n] = ray.L;
+        }
+    if (int rc = ddrr_siddon_backward_pose(aux, DDRR_AUX_BLOCKED, grad_out, source_v, target.data(), img.data(), Mw,
+                                           Ainv, P, B, N, eps, with_img_path, gMw.data(), st))
+        return rc;
+    return ddrr_pose_euler_backward(rot, xyz, a0, a1, a2, reorient34, gMw.data(), B, g_rot, g_xyz, st);
+}
+
 // ---- double precision (csrc/f64_rays.hip): the same per-ray cores, host loops
 static void ray64(const double *source, int src_n, const double *target, long r, int N, double s[3],
                   double t[3]) {

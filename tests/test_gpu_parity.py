@@ -1238,3 +1238,13 @@ def test_blur_sobel_kernels_against_the_composition(gpu):
     """ddrr_blur_sobel_forward / _backward on the device: the Gaussian blur + Sobel pair in front of
     GradientNormalizedCrossCorrelation2d (reference metrics.py:88-93) without the k x k convolution."""
     conftest.check_blur_sobel_against_composition(gpu)
+
+
+def test_euler_differentiable_path(gpu, monkeypatch):
+    """ddrr_siddon_backward_pose_euler and the three-launch forward behind `drr(rot, xyz,
+    parameterization="euler_angles")` with a gradient wanted, against the composition they replace."""
+    from diffdrr_amd import ops
+
+    calls, launch = [], ops._launch
+    monkeypatch.setattr(ops, "_launch", lambda n, d, *a: (calls.append(n), launch(n, d, *a))[1])
+    conftest.check_euler_differentiable_path(gpu, ops, calls)

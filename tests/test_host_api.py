@@ -1060,6 +1060,13 @@ def test_euler_inference_path_on_the_host_twin(emulated_ops):
     conftest.check_euler_inference_path("cpu")
 
 
+def test_euler_differentiable_path_on_the_host_twin(emulated_ops, monkeypatch):
+    """(the Python / autograd wiring and the C-ABI entries taken; the device twin: tests/test_gpu_parity.py)"""
+    calls, launch = [], emulated_ops._launch
+    monkeypatch.setattr(emulated_ops, "_launch", lambda n, d, *a: (calls.append(n), launch(n, d, *a))[1])
+    conftest.check_euler_differentiable_path("cpu", emulated_ops, calls)
+
+
 def test_pose_adam_matches_torch_adam_on_the_host_twin(emulated_ops):
     conftest.check_pose_adam("cpu")
 
