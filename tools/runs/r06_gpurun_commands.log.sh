@@ -151,3 +151,6 @@ import json; l=open(\"gpurun_out/r06x/bench_line_driver_command.json\").read().s
 
 # ---------------------------------------------------------------- 2026-10-01T07:01:49Z  r06: evidence refresh on the final tree (ABI 32)
 mkdir -p gpurun_out/r06y; python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^$" > gpurun_out/r06y/gpu_suite_full.txt; tail -1 gpurun_out/r06y/gpu_suite_full.txt; python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r06y/smoke.txt 2>&1; tail -1 gpurun_out/r06y/smoke.txt; tools/prof_bench.sh gpurun_out/r06yprof > gpurun_out/r06y/rocprof_bench.txt 2>&1; python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06y/bench_line_driver_command.json 2> gpurun_out/r06y/bench_stderr_driver_command.txt; echo rc=$?; cp bench_full.json gpurun_out/r06y/bench_full_driver_command.json; python bench.py > gpurun_out/r06y/bench_line_default.json 2> gpurun_out/r06y/bench_stderr_default.txt; cp bench_full.json gpurun_out/r06y/bench_full.json; for c in 2 3 4 5; do python bench.py --config $c > gpurun_out/r06y/bench_line_config_$c.json 2>/dev/null; cp bench_full.json gpurun_out/r06y/bench_config_$c.json; done; for c in ncc multiscale gradient gradient_patch9; do python bench.py --config 4 --criterion $c 2>/dev/null | tail -1 > gpurun_out/r06y/c4_$c.json; done; python tools/patch_ncc_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06y/patch_ncc.txt; wc -c gpurun_out/r06y/bench_line_*.json; head -9 gpurun_out/r06y/rocprof_bench.txt | cut -c1-150; cp gpurun_out/r06yprof/traffic.json gpurun_out/r06y/ 2>/dev/null; find gpurun_out/r06yprof -name "*kernel_stats.csv" -exec cp {} gpurun_out/r06y/rocprof_bench_kernel_stats.csv \;; cp gpurun_out/r06yprof/bench_line_under_trace.json gpurun_out/r06y/
+
+# ---------------------------------------------------------------- 2026-10-01T07:19:16Z  r06: full suite + bench after the one-node render (ABI 33)
+mkdir -p gpurun_out/r06w; python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^$" > gpurun_out/r06w/gpu_suite_full.txt; tail -1 gpurun_out/r06w/gpu_suite_full.txt; python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r06w/smoke.txt 2>&1; tail -1 gpurun_out/r06w/smoke.txt; python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06w/bench_line_driver_command.json 2> gpurun_out/r06w/bench_stderr_driver_command.txt; echo rc=$?; cp bench_full.json gpurun_out/r06w/bench_full_driver_command.json; for c in ncc multiscale gradient gradient_patch9; do python bench.py --config 4 --criterion $c 2>/dev/null | tail -1 > gpurun_out/r06w/c4_$c.json; done; python bench.py --unfused --no-configs --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r06w/bench_unfused.json
